@@ -1,0 +1,368 @@
+"""CPU oracle for the SNAG fusion + negative-sampled scoring hot path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it.  The product path (``snag_amd``) never imports anything from
+``oracle/`` and has no CPU fallback.
+
+It is a plain-PyTorch fp32 restatement (no reference imports, no reference
+source) of the reference's algorithms, written from SURVEY.md Appendix C.  Every
+function cites the reference file:line it follows (paths relative to
+``/root/reference/SNAG_MMEA``).  Because everything is ordinary differentiable
+torch code, ``torch.autograd`` of these functions is the backward oracle too.
+
+Parity status
+-------------
+* PINNED against the reference itself (imported in the build container, vectors
+  committed under ``tests/golden/`` by ``tests/golden/gen_golden.py``):
+  fusion forward/backward (a1-a4), projections (a5), noise injection (a6),
+  in-tree TransE-L2^2 margin scorer ``MSNEA.kge`` term 1 (a7), similarity
+  eval / CSLS / Hits@k / mutual-NN (a8).
+* PARITY UNPINNED (the MKGC source is absent from the reference tree, SURVEY.md
+  par. 0.1): the K>1 "one positive vs K negative tails" pairing of the margin
+  loss, and the ``Mformer_hd_mean`` / ``Mformer_hd_graph`` read-out names.  They
+  follow BASELINE.json's north_star text; their fixtures are self-generated.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+# --------------------------------------------------------------------------
+# small building blocks
+# --------------------------------------------------------------------------
+
+
+def nrm(v: Tensor) -> Tensor:
+    """``F.normalize(v)`` : v / max(||v||_2, 1e-12) over dim 1 (last dim for 2-D).
+
+    reference: model/SNAG_tools.py:44,48 ; model/MSNEA.py:151-152
+    """
+    n = v.pow(2).sum(dim=-1, keepdim=True).sqrt().clamp_min(1e-12)
+    return v / n
+
+
+def layer_norm(v: Tensor, g: Tensor, b: Tensor, eps: float = 1e-12) -> Tensor:
+    """nn.LayerNorm over the last dim, biased variance, eps inside the sqrt.
+
+    reference: model/SNAG_tools.py:215,221,259,265
+    """
+    mu = v.mean(dim=-1, keepdim=True)
+    var = (v - mu).pow(2).mean(dim=-1, keepdim=True)
+    return (v - mu) / torch.sqrt(var + eps) * g + b
+
+
+def gelu_erf(x: Tensor) -> Tensor:
+    """ACT2FN["gelu"] == exact erf GELU.  reference: model/SNAG_tools.py:248"""
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    """nn.Linear: x @ w.T + b with w[out, in].  reference: model/SNAG_tools.py:92-96,134-150"""
+    y = x @ w.t()
+    if b is not None:
+        y = y + b
+    return y
+
+
+def projection_head(x: Tensor, w1: Tensor, w2: Tensor,
+                    keep_mask: Optional[Tensor] = None, p: float = 0.0) -> Tensor:
+    """ProjectionHead: Linear(no bias) -> ReLU -> dropout -> Linear(no bias).
+
+    reference: model/layers.py:135-148 (wired in model/MCLEA_tools.py:96-100).
+    ``keep_mask`` (0/1, same shape as the hidden activation) makes dropout
+    explicit: h * keep / (1 - p).
+    """
+    h = torch.relu(x @ w1.t())
+    if keep_mask is not None:
+        h = h * keep_mask.to(h.dtype) / (1.0 - p)
+    return h @ w2.t()
+
+
+# --------------------------------------------------------------------------
+# a1-a4, a9: Mformer fusion
+# --------------------------------------------------------------------------
+
+
+def _apply_keep(x: Tensor, keep: Optional[Tensor], p: float) -> Tensor:
+    if keep is None:
+        return x
+    return x * keep.to(x.dtype) / (1.0 - p)
+
+
+def fusion_forward(embs: Sequence[Optional[Tensor]],
+                   params: Dict[str, Tensor],
+                   num_heads: int,
+                   num_layers: int = 1,
+                   use_intermediate: bool = False,
+                   drop_masks: Optional[List[Dict[str, Tensor]]] = None,
+                   drop_p: float = 0.1,
+                   ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """MformerFusion.forward.
+
+    reference: model/SNAG_tools.py:32-51 (fusion), 178-209 (self-attention),
+    218-222 (self-output), 244-266 (FFN), 279-298 (layer).
+
+    ``params`` uses the reference's state_dict keys (``weight_raw``,
+    ``fusion_layer.{l}.attention.self.query.weight`` ...).  ``drop_masks`` is
+    ``None`` for eval mode, else one dict per layer with 0/1 keep masks
+    ``probs`` [N,H,M,M], ``attn_out`` [N,M,D] and (FFN only) ``ffn_out`` [N,M,D]
+    (inverted dropout, p = 0.1, reference lines 169,201,216,220,260,264).
+    Returns (joint_emb, joint_emb_fz, hidden_states, weight_norm).
+    """
+    embs = [e for e in embs if e is not None]                       # :33
+    M = len(embs)
+    x = torch.stack(embs, dim=1)                                    # :36  [N,M,D]
+    N, _, D = x.shape
+    H = num_heads
+    d = D // H
+    probs = None
+    for l in range(num_layers):
+        pre = f"fusion_layer.{l}."
+        dm = drop_masks[l] if drop_masks is not None else {}
+        q = linear(x, params[pre + "attention.self.query.weight"], params[pre + "attention.self.query.bias"])
+        k = linear(x, params[pre + "attention.self.key.weight"], params[pre + "attention.self.key.bias"])
+        v = linear(x, params[pre + "attention.self.value.weight"], params[pre + "attention.self.value.bias"])
+        q = q.view(N, M, H, d).permute(0, 2, 1, 3)                   # :171-176
+        k = k.view(N, M, H, d).permute(0, 2, 1, 3)
+        v = v.view(N, M, H, d).permute(0, 2, 1, 3)
+        s = (q @ k.transpose(-1, -2)) / math.sqrt(d)                 # :192-193
+        probs = torch.softmax(s, dim=-1)                             # :196
+        probs = _apply_keep(probs, dm.get("probs"), drop_p)          # :201
+        ctx = (probs @ v).permute(0, 2, 1, 3).reshape(N, M, D)       # :202-206
+        o = linear(ctx, params[pre + "attention.output.dense.weight"], params[pre + "attention.output.dense.bias"])
+        o = _apply_keep(o, dm.get("attn_out"), drop_p)               # :220
+        y = layer_norm(o + x, params[pre + "attention.output.LayerNorm.weight"],
+                       params[pre + "attention.output.LayerNorm.bias"])   # :221
+        if use_intermediate:                                         # :284-298
+            z = gelu_erf(linear(y, params[pre + "intermediate.dense.weight"], params[pre + "intermediate.dense.bias"]))
+            z = linear(z, params[pre + "output.dense.weight"], params[pre + "output.dense.bias"])
+            z = _apply_keep(z, dm.get("ffn_out"), drop_p)            # :264
+            y = layer_norm(z + y, params[pre + "output.LayerNorm.weight"], params[pre + "output.LayerNorm.bias"])
+        x = y
+    hidden = x
+    att = probs.sum(dim=-3)                                          # :41  sum over heads  [N,M,M]
+    comb = att.sum(dim=-2) / math.sqrt(M * H)                        # :42  sum over queries [N,M]
+    w = torch.softmax(comb, dim=-1)                                  # :43
+    joint = torch.cat([w[:, m:m + 1] * nrm(embs[m]) for m in range(M)], dim=1)       # :44-45
+    w_fz = torch.softmax(params["weight_raw"], dim=0)                # :46  over all 6 entries
+    joint_fz = torch.cat([w_fz[m] * nrm(embs[m]) for m in range(M)], dim=1)          # :48-49
+    return joint, joint_fz, hidden, w
+
+
+JOINT_WAYS = ("Mformer_hd_mean", "Mformer_hd_graph", "Mformer_weight", "learnable_weight")
+
+
+def readout(joint_way: str, joint: Tensor, joint_fz: Tensor, hidden: Tensor, graph_index: int) -> Tensor:
+    """MKGC ``joint_way`` read-outs (README.md:51, names only; PARITY UNPINNED for hd_*).
+
+    hd_mean = hidden.mean(1)   (cf. comment at model/MEAformer_tools.py:66-68)
+    hd_graph = hidden[:, g]    (g = position of the structural token)
+    Mformer_weight = joint ; learnable_weight = joint_fz (model/SNAG_tools.py:44-49)
+    """
+    if joint_way == "Mformer_hd_mean":
+        return hidden.mean(dim=1)
+    if joint_way == "Mformer_hd_graph":
+        return hidden[:, graph_index, :]
+    if joint_way == "Mformer_weight":
+        return joint
+    if joint_way == "learnable_weight":
+        return joint_fz
+    raise ValueError(f"unknown joint_way {joint_way!r}")
+
+
+# --------------------------------------------------------------------------
+# a6: Gaussian noise-mask injection
+# --------------------------------------------------------------------------
+
+
+def col_mean_std(x: Tensor, exclude_rows: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """Per-column mean and *unbiased* std over rows; optionally skip rows.
+
+    reference: model/SNAG.py:77-84 (img stats skip ``ent_wo_img``), 94-95.
+    """
+    if exclude_rows is not None and exclude_rows.numel() > 0:
+        keep = torch.ones(x.shape[0], dtype=torch.bool)
+        keep[exclude_rows.long()] = False
+        x = x[keep]
+    return x.mean(dim=0), x.std(dim=0)
+
+
+def add_noise_rows(x: Tensor, mean: Tensor, std: Tensor, row_mask: Tensor, z: Tensor, mask_ratio: float) -> Tensor:
+    """X[mask] = (1-eps) X[mask] + eps (mean + std * z), z compact [n_masked, F].
+
+    reference: model/SNAG.py:66-75 (mask = rand(N) < noise_ratio ; z = randn_like(X[mask])).
+    Returns a new tensor (the reference mutates a clone, :89-91).
+    """
+    out = x.clone()
+    sel = out[row_mask]
+    noise = mean + std * z
+    out[row_mask] = (1.0 - mask_ratio) * sel + mask_ratio * noise
+    return out
+
+
+def entity_noise_blend(e: Tensor, noise: Tensor, row_mask: Tensor, mask_ratio: float) -> Tensor:
+    """e[mask] = (1 - eps/2) e[mask] + (eps/2) noise[mask]   (noise is a constant).
+
+    reference: model/SNAG_tools.py:127-128 ; noise/mask built at model/SNAG.py:94-98.
+    """
+    m = row_mask.to(e.dtype).unsqueeze(1)
+    a = mask_ratio * 0.5
+    return e * (1.0 - a * m) + (a * m) * noise
+
+
+# --------------------------------------------------------------------------
+# a7: negative-sampled margin score
+# --------------------------------------------------------------------------
+
+
+def transe_l2sq(e: Tensor, r: Tensor, h_idx: Tensor, r_idx: Tensor, t_idx: Tensor) -> Tensor:
+    """s(h,r,t) = || nrm(E[h]) + nrm(R[r]) - nrm(E[t]) ||_2^2.
+
+    reference: model/MSNEA.py:110-121,151-152 (lower = more plausible).
+    """
+    dis = nrm(e[h_idx.long()]) + nrm(r[r_idx.long()]) - nrm(e[t_idx.long()])
+    return dis.pow(2).sum(dim=-1)
+
+
+def kge_intree(e: Tensor, r: Tensor, p_h, p_r, p_t, n_h, n_r, n_t, margin: float):
+    """In-tree loss, term 1: sum(relu(margin + pos - neg)) with equal-length pos/neg lists.
+
+    reference: model/MSNEA.py:120-122 (neg_triple_num == 1 in-tree).
+    """
+    pos = transe_l2sq(e, r, p_h, p_r, p_t)
+    neg = transe_l2sq(e, r, n_h, n_r, n_t)
+    return torch.relu(margin + pos - neg).sum(), pos, neg
+
+
+def score_margin(e: Tensor, r: Tensor, h: Tensor, rel: Tensor, t: Tensor, neg_t: Tensor, margin: float):
+    """MKGC shape: one positive (h,r,t) against K negative tails neg_t[b, :].
+
+    loss = sum_b sum_k relu(margin + s(h,r,t) - s(h,r,neg_t[b,k]))  -- the K>1
+    pairing is PARITY UNPINNED (north_star text); the score itself follows
+    model/MSNEA.py:110-122.  Returns (loss, pos[B], neg[B,K]).
+    """
+    B, K = neg_t.shape
+    q = nrm(e[h.long()]) + nrm(r[rel.long()])                      # [B,D]
+    pos = (q - nrm(e[t.long()])).pow(2).sum(-1)                    # [B]
+    tn = nrm(e[neg_t.long().reshape(-1)]).view(B, K, -1)
+    neg = (q.unsqueeze(1) - tn).pow(2).sum(-1)                     # [B,K]
+    loss = torch.relu(margin + pos.unsqueeze(1) - neg).sum()
+    return loss, pos, neg
+
+
+def rank_full_table(e: Tensor, r: Tensor, h: Tensor, rel: Tensor, t: Tensor,
+                    filter_mask: Optional[Tensor] = None) -> Tensor:
+    """Link-prediction rank of the true tail against all N entities (count-less-than).
+
+    PARITY UNPINNED (MKGC eval absent from the tree).  rank[b] = #{n : s(h,r,n) < s(h,r,t_b),
+    n not filtered}.  ``filter_mask`` [B,N] bool marks known true tails to skip.
+    """
+    q = nrm(e[h.long()]) + nrm(r[rel.long()])
+    en = nrm(e)
+    s = (q.unsqueeze(1) - en.unsqueeze(0)).pow(2).sum(-1)          # [B,N]
+    st = s.gather(1, t.long().view(-1, 1))
+    less = s < st
+    if filter_mask is not None:
+        less = less & ~filter_mask
+    return less.sum(dim=1)
+
+
+# --------------------------------------------------------------------------
+# a8: similarity evaluation
+# --------------------------------------------------------------------------
+
+
+def pairwise_distances(x: Tensor, y: Optional[Tensor] = None) -> Tensor:
+    """clamp(|x|^2 + |y|^2 - 2 x y^T, 0).  reference: src/utils.py:202-218"""
+    xn = x.pow(2).sum(1).view(-1, 1)
+    if y is None:
+        y = x
+        yn = xn.view(1, -1)
+    else:
+        yn = y.pow(2).sum(1).view(1, -1)
+    return torch.clamp(xn + yn - 2.0 * (x @ y.t()), min=0.0)
+
+
+def csls_sim(sim: Tensor, k: int) -> Tensor:
+    """C[i,j] = 2 S[i,j] - mean(topk_j S[i,:]) - mean(topk_i S[:,j]).  reference: src/utils.py:417-435"""
+    r1 = torch.topk(sim, k, dim=1)[0].mean(1)
+    r2 = torch.topk(sim.t(), k, dim=1)[0].mean(1)
+    c = 2 * sim.t() - r1
+    return c.t() - r2
+
+
+def rank_metrics(emb_left: Tensor, emb_right: Tensor, csls_k: int = 0, top_k=(1, 10, 50)) -> dict:
+    """Runner._test from the already-gathered, already-normalised rows.
+
+    reference: main.py:376-436.  rank = #{j : Dist'[i,j] < Dist'[i,i]} which equals the
+    index of i in the ascending sort when the row is tie-free.
+    """
+    dist = pairwise_distances(emb_left, emb_right)
+    if csls_k and csls_k > 0:
+        dist = 1 - csls_sim(1 - dist, csls_k)
+    diag = dist.diagonal()
+    rank_l2r = (dist < diag.view(-1, 1)).sum(dim=1)
+    rank_r2l = (dist < diag.view(1, -1)).sum(dim=0)
+    out = {"rank_l2r": rank_l2r, "rank_r2l": rank_r2l, "dist": dist}
+    for name, rk in (("l2r", rank_l2r), ("r2l", rank_r2l)):
+        n = rk.numel()
+        rkf = rk.to(torch.float64)
+        out[f"hits_{name}"] = [round(float((rk < k).sum().item()) / n, 4) for k in top_k]
+        out[f"mr_{name}"] = float((rkf + 1).mean())
+        out[f"mrr_{name}"] = float((1.0 / (rkf + 1)).mean())
+    return out
+
+
+def mutual_nearest(final_emb: Tensor, left: Tensor, right: Tensor, chunk: int = 1000):
+    """Iter_new_links' distance part: row argmin / column argmin / mutual pairs.
+
+    reference: model/SNAG.py:195-204 (1000-row chunks, first-branch filter).
+    """
+    ds = [pairwise_distances(final_emb[left[i:i + chunk]], final_emb[right]) for i in range(0, len(left), chunk)]
+    dist = torch.cat(ds, dim=0)
+    pl = torch.argmin(dist, dim=1)
+    pr = torch.argmin(dist.t(), dim=1)
+    pairs = [(int(left[i]), int(right[p])) for i, p in enumerate(pl.tolist()) if int(pr[p]) == i]
+    return pl, pr, pairs
+
+
+# --------------------------------------------------------------------------
+# whole MKGC step (fusion + score), used by the CPU baseline and end-to-end tests
+# --------------------------------------------------------------------------
+
+
+def mkgc_forward(feats: Sequence[Tensor], proj: Sequence[Dict[str, Tensor]], ent_table: Tensor,
+                 fusion_params: Dict[str, Tensor], rel_table: Tensor,
+                 h: Tensor, rel: Tensor, t: Tensor, neg_t: Tensor, *,
+                 num_heads: int, margin: float, joint_way: str = "Mformer_hd_graph",
+                 use_intermediate: bool = False, num_layers: int = 1,
+                 ent_noise: Optional[Tensor] = None, ent_noise_mask: Optional[Tensor] = None,
+                 mask_ratio: float = 0.0):
+    """One MKGC hot-path step: projections -> tokens -> Mformer -> read-out -> margin score.
+
+    Token order is [modality_0, ..., modality_{P-1}, structural]; the structural token is the
+    (optionally noise-blended) entity-table row (model/SNAG_tools.py:122-152 with the GAT removed,
+    which is how SURVEY par. 8 a5 scopes the MKGC structural token).  ``proj[i]`` holds either
+    {"weight","bias"} (num_proj=1) or {"l1","l2"} (+ optional "weight","bias" applied first).
+    """
+    toks = []
+    for f, p in zip(feats, proj):
+        if "weight" in p:
+            f = linear(f, p["weight"], p.get("bias"))
+        if "l1" in p:
+            f = projection_head(f, p["l1"], p["l2"])
+        toks.append(f)
+    e = ent_table
+    if ent_noise is not None:
+        e = entity_noise_blend(e, ent_noise, ent_noise_mask, mask_ratio)
+    toks.append(e)
+    joint, joint_fz, hidden, w = fusion_forward(toks, fusion_params, num_heads, num_layers, use_intermediate)
+    ent = readout(joint_way, joint, joint_fz, hidden, graph_index=len(toks) - 1)
+    loss, pos, neg = score_margin(ent, rel_table, h, rel, t, neg_t, margin)
+    return loss, pos, neg, ent

@@ -1,0 +1,415 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference, which never travels to
+the GPU box).  It executes the reference's own Python (CPU, fp32) on seeded
+synthetic inputs and stores inputs + outputs as .npz.  Nothing from the
+reference's source text is written anywhere: the fixtures are data only.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+Vectors (SURVEY.md par. 8c):
+  g1_fusion_*.npz    MformerFusion.forward eval / train(dropout masks) + autograd grads
+  g2_noise.npz       SNAG.add_noise_to_embeddings / get_mean_std / update_noise
+  g3_score.npz       MSNEA.kge relation loss (term 1) + grads
+  g4_eval_*.npz      pairwise_distances / csls_sim / Runner._test metrics + l2r ranks
+  g5_il.npz          SNAG.Iter_new_links mutual nearest neighbours
+  g6_proj.npz        nn.Linear projections + ProjectionHead fwd/grads
+  g7_encoder.npz     MultiModalEncoder.forward (projections + entity noise blend + fusion), GAT stubbed to identity
+"""
+import csv
+import io
+import logging
+import os
+import re
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/SNAG_MMEA"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+
+if not os.path.isdir(REF):
+    sys.exit("reference tree not present; golden vectors can only be generated in the build container")
+
+# --- SURVEY.md Appendix A import recipe ------------------------------------
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+for name, attrs in [("easydict", {"EasyDict": dict}),
+                    ("unidecode", {"unidecode": lambda s: s}),
+                    ("torch.utils.tensorboard", {"SummaryWriter": object})]:
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+sys.path.insert(0, REF)
+from model.SNAG_tools import MformerFusion, MultiModalEncoder  # noqa: E402
+from model.SNAG import SNAG  # noqa: E402
+from model.MSNEA import MSNEA  # noqa: E402
+from model.layers import ProjectionHead  # noqa: E402
+from src.utils import pairwise_distances, csls_sim, Loss_log  # noqa: E402
+import main as ref_main  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+torch.set_num_threads(1)   # deterministic reduction order for the stored vectors
+
+
+def npify(d):
+    out = {}
+    for k, v in d.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    return out
+
+
+def save(name, d):
+    path = os.path.join(OUT, name)
+    np.savez(path, **npify(d))
+    print(f"{name:32s} {os.path.getsize(path) / 1024:8.1f} KB")
+
+
+def fusion_args(D, H, I, ffn, L=1):
+    return types.SimpleNamespace(hidden_size=D, num_attention_heads=H, num_hidden_layers=L,
+                                 use_intermediate=ffn, intermediate_size=I)
+
+
+class DropoutRecorder:
+    """Replace F.dropout by an explicit-mask inverted dropout and record the masks in call order."""
+
+    def __init__(self, gen):
+        self.gen = gen
+        self.masks = []
+        self._orig = F.dropout
+
+    def __enter__(self):
+        def fake(x, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return x
+            keep = (torch.rand(x.shape, generator=self.gen) >= p)
+            self.masks.append(keep.to(torch.uint8))
+            return x * keep.to(x.dtype) / (1.0 - p)
+        F.dropout = fake
+        torch.nn.functional.dropout = fake
+        return self
+
+    def __exit__(self, *a):
+        F.dropout = self._orig
+        torch.nn.functional.dropout = self._orig
+
+
+def randomize_(module, gen, scale=1.0):
+    """Non-trivial parameters everywhere (LayerNorm affine, biases, weight_raw included)."""
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if "LayerNorm.weight" in n:
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+            elif n.endswith("weight_raw"):
+                p.copy_(torch.randn(p.shape, generator=gen))
+            elif p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=gen) * (scale / np.sqrt(p.shape[-1])))
+            else:
+                p.copy_(0.1 * torch.randn(p.shape, generator=gen))
+
+
+# --------------------------------------------------------------------------
+def gen_g1():
+    cases = [
+        # name,              N,  M, D,   H, I,   ffn, L, pattern of None slots (6), modes that store parameter grads
+        ("m3_d128_h2",       64, 3, 128, 2, 400, 0, 1, [1, 1, 1, 0, 0, 0], ("eval", "train")),
+        ("m3_d128_h2_skip",  50, 3, 128, 2, 400, 0, 1, [1, 0, 1, 1, 0, 0], ()),
+        ("m4_d128_h2_ffn",   48, 4, 128, 2, 400, 1, 1, [1, 1, 1, 1, 0, 0], ("train",)),
+        ("m6_d128_h2_ffn",   40, 6, 128, 2, 400, 1, 1, [1, 1, 1, 1, 1, 1], ()),
+        ("m4_d300_h1_ffn",   40, 4, 300, 1, 400, 1, 1, [1, 1, 1, 1, 0, 0], ("eval",)),
+        ("m3_d64_h4_l2",     33, 3, 64,  4, 96,  1, 2, [1, 1, 1, 0, 0, 0], ("eval", "train")),
+    ]
+    for ci, (name, N, M, D, H, I, ffn, L, pat, pgrad_modes) in enumerate(cases):
+        g = torch.Generator().manual_seed(1000 + ci)
+        fus = MformerFusion(fusion_args(D, H, I, ffn, L), modal_num=M)
+        randomize_(fus, g)
+        scales = [1.0, 0.3, 2.0, 0.05, 1.5, 0.7]
+        embs = [(torch.randn(N, D, generator=g) * scales[i]).requires_grad_(True) if pat[i] else None for i in range(6)]
+        if name == "m3_d128_h2":           # one all-zero row exercises the normalize eps branch
+            with torch.no_grad():
+                embs[1][7].zero_()
+        # fixed linear functional of the four outputs -> scalar for the gradient check
+        cw = [torch.randn(N, M * D, generator=g), torch.randn(N, M * D, generator=g),
+              torch.randn(N, M, D, generator=g), torch.randn(N, M, generator=g)]
+        d = {"N": N, "M": M, "D": D, "H": H, "I": I, "ffn": ffn, "L": L, "pattern": np.array(pat)}
+        for i, e in enumerate(embs):
+            if e is not None:
+                d[f"emb{i}"] = e
+        for k, v in fus.state_dict().items():
+            d["p." + k] = v
+        for i, c in enumerate(cw):
+            d[f"cw{i}"] = c
+        for mode in ("eval", "train"):
+            fus.train(mode == "train")
+            fus.zero_grad()
+            for e in embs:
+                if e is not None:
+                    e.grad = None
+            with DropoutRecorder(torch.Generator().manual_seed(77 + ci)) as rec:
+                outs = fus(embs)
+            scalar = sum((o * c).sum() for o, c in zip(outs, cw))
+            scalar.backward()
+            for nm, o in zip(("joint", "joint_fz", "hidden", "weight_norm"), outs):
+                d[f"{mode}.{nm}"] = o
+            d[f"{mode}.scalar"] = scalar
+            for i, e in enumerate(embs):
+                if e is not None:
+                    d[f"{mode}.g.emb{i}"] = e.grad
+            for k, p in fus.named_parameters():
+                if mode in pgrad_modes or k == "weight_raw":
+                    d[f"{mode}.g.p.{k}"] = p.grad if p.grad is not None else torch.zeros_like(p)
+            if mode == "train":
+                # call order inside a layer: probs dropout, attention-output dropout, [FFN output dropout]
+                per_layer = 3 if ffn else 2
+                assert len(rec.masks) == per_layer * L, len(rec.masks)
+                for l in range(L):
+                    d[f"mask.{l}.probs"] = rec.masks[l * per_layer + 0]
+                    d[f"mask.{l}.attn_out"] = rec.masks[l * per_layer + 1]
+                    if ffn:
+                        d[f"mask.{l}.ffn_out"] = rec.masks[l * per_layer + 2]
+        save(f"g1_fusion_{name}.npz", d)
+
+
+# --------------------------------------------------------------------------
+def gen_g2():
+    N, F_img, F_rel, F_att, D = 211, 48, 40, 24, 32
+    g = torch.Generator().manual_seed(2024)
+    img = F.normalize(torch.rand(N, F_img, generator=g))
+    rel = torch.randn(N, F_rel, generator=g) * 2 + 0.5
+    att = (torch.rand(N, F_att, generator=g) < 0.3).float()
+    ent_wo_img = torch.tensor(sorted(set(torch.randint(0, N, (17,), generator=g).tolist())))
+    ent_w = torch.randn(N, D, generator=g) / np.sqrt(N)
+    args = types.SimpleNamespace(noise_ratio=0.2, mask_ratio=0.7)
+    fake = types.SimpleNamespace(args=args, img_features=img, rel_features=rel, att_features=att,
+                                 ent_wo_img=ent_wo_img,
+                                 multimodal_encoder=types.SimpleNamespace(
+                                     entity_emb=types.SimpleNamespace(weight=torch.nn.Parameter(ent_w.clone()))))
+    fake.add_noise_to_embeddings = types.MethodType(SNAG.add_noise_to_embeddings, fake)
+    SNAG.get_mean_std(fake)
+    d = {"img": img, "rel": rel, "att": att, "ent_wo_img": ent_wo_img, "ent_w": ent_w,
+         "noise_ratio": args.noise_ratio, "mask_ratio": args.mask_ratio,
+         "img_mean": fake.img_mean, "img_std": fake.img_std, "rel_mean": fake.rel_mean, "rel_std": fake.rel_std,
+         "att_mean": fake.att_mean, "att_std": fake.att_std}
+    seed = 4242
+    torch.manual_seed(seed)
+    SNAG.update_noise(fake)
+    d.update({"seed": seed, "rel_noisy": fake.rel_noisy_features, "att_noisy": fake.att_noisy_features,
+              "img_noisy": fake.img_noisy_features, "ent_mean": fake.ent_mean, "ent_std": fake.ent_std,
+              "entity_noise": fake.entity_noise, "entity_noise_mask": fake.entity_noise_mask})
+    # replay of the reference's global-RNG call order (SNAG.py:68-70 x3, then :96, :98) -> explicit (mask, z)
+    torch.manual_seed(seed)
+    for nm, X in (("rel", rel), ("att", att), ("img", img)):
+        mask = torch.rand(N) < args.noise_ratio
+        z = torch.randn_like(X[mask])
+        d[f"{nm}_mask"] = mask
+        d[f"{nm}_z"] = z
+    d["ent_z"] = torch.randn_like(ent_w)
+    d["ent_u"] = torch.rand(N)
+    assert torch.equal(d["ent_u"] < args.noise_ratio * 0.5, fake.entity_noise_mask)
+    save("g2_noise.npz", d)
+
+
+# --------------------------------------------------------------------------
+def gen_g3():
+    N, R, D, B = 157, 11, 128, 96
+    g = torch.Generator().manual_seed(33)
+    ent = torch.nn.Embedding(N, D)
+    relm = torch.nn.Embedding(R, D)
+    with torch.no_grad():
+        ent.weight.copy_(torch.randn(N, D, generator=g) * 0.7)
+        relm.weight.copy_(torch.randn(R, D, generator=g) * 0.2)
+        ent.weight[5].zero_()     # exercises normalize eps
+    zeros = lambda e: torch.zeros(e.shape[0], D)
+    fake = types.SimpleNamespace(args=types.SimpleNamespace(margin=1.5), ent_embed=ent, rel_embed=relm,
+                                 name_features=None, char_features=None)
+    fake.r_rep = types.MethodType(MSNEA.r_rep, fake)
+    fake.i_w = lambda e: zeros(e)                                   # term 2 becomes the constant n*margin
+    fake._emb_generate = lambda e, a, b: (zeros(e), zeros(e), zeros(e), None, None)
+    fake.fusion = lambda lst: lst[0]
+    p_h = torch.randint(0, N, (B,), generator=g)
+    p_r = torch.randint(0, R, (B,), generator=g)
+    p_t = torch.randint(0, N, (B,), generator=g)
+    p_h[0] = 5
+    # in-tree sampler semantics: head-or-tail corruption, one negative per positive
+    corrupt_head = torch.rand(B, generator=g) < 0.5
+    n_h = torch.where(corrupt_head, torch.randint(0, N, (B,), generator=g), p_h)
+    n_t = torch.where(corrupt_head, p_t, torch.randint(0, N, (B,), generator=g))
+    n_r = p_r.clone()
+    e1 = torch.arange(4)
+    loss, *_ = MSNEA.kge(fake, p_h, p_r, p_t, n_h, n_r, n_t, e1, e1)
+    loss.backward()
+    term1 = loss.detach() - B * fake.args.margin                    # i_w == 0 -> pos1 = neg1 = 1 -> relu(margin)
+    with torch.no_grad():
+        pos = torch.sum(torch.square(fake.r_rep(p_h) + F.normalize(relm(p_r), 2, -1) - fake.r_rep(p_t)), dim=1)
+        neg = torch.sum(torch.square(fake.r_rep(n_h) + F.normalize(relm(n_r), 2, -1) - fake.r_rep(n_t)), dim=1)
+    save("g3_score.npz", {"ent": ent.weight, "rel": relm.weight, "p_h": p_h, "p_r": p_r, "p_t": p_t,
+                          "n_h": n_h, "n_r": n_r, "n_t": n_t, "margin": fake.args.margin,
+                          "loss_term1": term1, "loss_kge_total": loss, "pos": pos, "neg": neg,
+                          "g.ent": ent.weight.grad, "g.rel": relm.weight.grad})
+
+
+# --------------------------------------------------------------------------
+class _ListHandler(logging.Handler):
+    def __init__(self):
+        super().__init__()
+        self.lines = []
+
+    def emit(self, record):
+        self.lines.append(record.getMessage())
+
+
+def run_ref_test(final_emb, left, right, csls, csls_k):
+    lg = logging.getLogger("golden")
+    lg.setLevel(logging.INFO)
+    lg.propagate = False
+    h = _ListHandler()
+    lg.handlers = [h]
+    tmp = tempfile.mkdtemp()
+    args = types.SimpleNamespace(model_name="SNAG", distance=2, csls=csls, csls_k=csls_k, data_path=tmp,
+                                 data_choice="GOLD")
+    model = types.SimpleNamespace(joint_emb_generat=lambda: (final_emb, None), state_dict=lambda: {})
+    fake = types.SimpleNamespace(args=args, model=model, logger=lg, epoch=0, loss_item=0.0,
+                                 early_stop_count=3, early_stop_init=3, loss_log=Loss_log())
+    ref_main.Runner._test(fake, left, right, last_epoch=True, save_name="g")
+    ranks = []
+    with open(os.path.join(tmp, "SNAG", "g_pred", "GOLD_pred.txt")) as f:
+        rd = csv.reader(f)
+        next(rd)
+        for row in rd:
+            ranks.append(int(row[1]))
+    out = {"rank_l2r": np.array(ranks)}
+    for line in h.lines:
+        m = re.search(r"\| (l2r|r2l): acc of top \[1, 10, 50\] = \[([^\]]*)\], mr = ([\d.]+), mrr = ([\d.]+)", line)
+        if m:
+            out[f"hits_{m.group(1)}"] = np.array([float(x) for x in m.group(2).split()], dtype=np.float64)
+            out[f"mr_{m.group(1)}_3dp"] = float(m.group(3))
+            out[f"mrr_{m.group(1)}_3dp"] = float(m.group(4))
+    assert "hits_l2r" in out and "hits_r2l" in out, h.lines
+    return out
+
+
+def gen_g4_g5():
+    for ci, (name, n, dim, csls_k, sigma) in enumerate((("d64", 300, 64, 3, 2.4), ("d1200", 120, 1200, 3, 11.0),
+                                                        ("d64_nocsls", 200, 64, 0, 2.2))):
+        g = torch.Generator().manual_seed(400 + ci)
+        total = 2 * n + 40
+        left_rows = torch.randn(n, dim, generator=g)
+        right_rows = left_rows + sigma * torch.randn(n, dim, generator=g)      # planted signal: hits@1 in (0,1)
+        extra = torch.randn(40, dim, generator=g)
+        emb = torch.cat([left_rows, right_rows, extra], 0) * 3.0              # un-normalised on purpose
+        perm = torch.randperm(total, generator=g)
+        emb = emb[perm]
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(total)
+        left = inv[:n].clone()
+        right = inv[n:2 * n].clone()
+        final = F.normalize(emb)
+        dist = pairwise_distances(final[left], final[right])
+        d = {"emb": emb, "left": left, "right": right, "csls_k": csls_k, "dist": dist}
+        if csls_k:
+            d["csls"] = csls_sim(1 - dist, csls_k)
+        d.update(run_ref_test(emb, left, right, bool(csls_k), csls_k))
+        save(f"g4_eval_{name}.npz", d)
+
+    # G5: Iter_new_links (mutual nearest neighbours) with >1 chunk of 1000 rows
+    g = torch.Generator().manual_seed(55)
+    nl, nr, dim = 1300, 1100, 48
+    base = torch.randn(max(nl, nr), dim, generator=g)
+    final = F.normalize(torch.cat([base[:nl] + 0.6 * torch.randn(nl, dim, generator=g),
+                                   base[:nr] + 0.6 * torch.randn(nr, dim, generator=g)], 0))
+    left = list(range(nl))
+    right = list(range(nl, nl + nr))
+    fake = types.SimpleNamespace(args=types.SimpleNamespace(semi_learn_step=5))
+    links = SNAG.Iter_new_links(fake, 4, left, final, right, new_links=[])   # (4+1) % 25 == 5 -> first branch
+    save("g5_il.npz", {"final": final, "left": np.array(left), "right": np.array(right),
+                       "links": np.array(links, dtype=np.int64)})
+
+
+# --------------------------------------------------------------------------
+def gen_g6():
+    g = torch.Generator().manual_seed(66)
+    N, Fin, D = 70, 200, 128
+    x = torch.randn(N, Fin, generator=g)
+    lin = torch.nn.Linear(Fin, D)
+    randomize_(lin, g)
+    cw = torch.randn(N, D, generator=g)
+    y = lin(x)
+    (y * cw).sum().backward()
+    d = {"x": x, "lin.weight": lin.weight, "lin.bias": lin.bias, "cw": cw, "lin.y": y,
+         "lin.g.weight": lin.weight.grad, "lin.g.bias": lin.bias.grad}
+    ph = ProjectionHead(Fin, 96, D, dropout=0.25)
+    randomize_(ph, g)
+    xr = x.clone().requires_grad_(True)
+    for mode in ("eval", "train"):
+        ph.train(mode == "train")
+        ph.zero_grad()
+        xr.grad = None
+        with DropoutRecorder(torch.Generator().manual_seed(9)) as rec:
+            y2 = ph(xr)
+        (y2 * cw).sum().backward()
+        d[f"ph.{mode}.y"] = y2
+        d[f"ph.{mode}.g.l1"] = ph.l1.weight.grad
+        d[f"ph.{mode}.g.l2"] = ph.l2.weight.grad
+        d[f"ph.{mode}.g.x"] = xr.grad
+        if mode == "train":
+            d["ph.mask"] = rec.masks[0]
+    d.update({"ph.l1": ph.l1.weight, "ph.l2": ph.l2.weight, "ph.p": 0.25})
+    save("g6_proj.npz", d)
+
+
+# --------------------------------------------------------------------------
+def gen_g7():
+    """MultiModalEncoder.forward with the structural encoder stubbed to identity (GAT is out of scope)."""
+    g = torch.Generator().manual_seed(707)
+    N, D, F_img, F_att = 61, 128, 96, 80
+    args = types.SimpleNamespace(
+        attr_dim=D, img_dim=D, name_dim=D, char_dim=D, dropout=0.0, hidden_units=f"{D},{D},{D}", heads="2,2",
+        structure_encoder="gcn", attn_dropout=0.0, instance_normalization=False, inner_view_num=4, with_weight=1,
+        w_gcn=True, w_img=True, w_rel=True, w_attr=True, w_name=False, w_char=False, mask_ratio=0.7,
+        hidden_size=D, num_attention_heads=2, num_hidden_layers=1, use_intermediate=0, intermediate_size=400)
+    enc = MultiModalEncoder(args, ent_num=N, img_feature_dim=F_img, char_feature_dim=100, attr_input_dim=F_att)
+    randomize_(enc, g)
+    with torch.no_grad():
+        enc.entity_emb.weight.copy_(torch.randn(N, D, generator=g) / np.sqrt(N))
+    class _Identity(torch.nn.Module):
+        def forward(self, x, adj):
+            return x
+    enc.cross_graph_model = _Identity()
+    enc.eval()
+    img = F.normalize(torch.rand(N, F_img, generator=g))
+    rel = torch.randn(N, 1000, generator=g) * (torch.rand(N, 1000, generator=g) < 0.05)
+    att = (torch.rand(N, F_att, generator=g) < 0.2).float()
+    noise = torch.randn(N, D, generator=g) * 0.1
+    nmask = torch.rand(N, generator=g) < 0.3
+    idx = torch.arange(N)
+    d = {"img": img, "rel": rel, "att": att, "entity_noise": noise, "entity_noise_mask": nmask, "mask_ratio": 0.7}
+    for k, v in enc.state_dict().items():
+        if k.startswith(("entity_emb", "rel_fc", "att_fc", "img_fc", "fusion")):
+            d["p." + k] = v
+    names = ("gph", "img", "rel", "att", "name", "char", "joint", "joint_fz", "hidden", "weight_norm")
+    for tag, kw in (("clean", {}), ("noisy", {"entity_noise": noise, "entity_noise_mask": nmask})):
+        enc.zero_grad()
+        outs = enc(idx, None, img, rel, att, None, None, **kw)
+        for nm, o in zip(names, outs):
+            if o is not None:
+                d[f"{tag}.{nm}"] = o
+        # gradient of sum(hidden[:, graph slot]) w.r.t. the entity table (checks the (1 - eps/2) scaling)
+        outs[8][:, 3, :].sum().backward()
+        d[f"{tag}.g.entity_emb"] = enc.entity_emb.weight.grad.clone()
+    save("g7_encoder.npz", d)
+
+
+if __name__ == "__main__":
+    gen_g1()
+    gen_g2()
+    gen_g3()
+    gen_g4_g5()
+    gen_g6()
+    gen_g7()

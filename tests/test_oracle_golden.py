@@ -1,0 +1,154 @@
+"""CPU: pin oracle/ref_cpu.py against the golden vectors produced by the imported reference.
+
+The reference has no tests of its own (SURVEY.md par. 4); these fixtures are the pins (par. 8c).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import ATOL, T, assert_close, fusion_cases, fusion_inputs, fusion_masks, load
+from oracle import ref_cpu as O
+
+torch.set_num_threads(4)
+OUTS = ("joint", "joint_fz", "hidden", "weight_norm")
+
+
+@pytest.mark.parametrize("case", fusion_cases())
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_fusion_forward_backward(case, mode):
+    z = load(case)
+    embs, params, cfg = fusion_inputs(z, requires_grad=True)
+    masks = fusion_masks(z, cfg["L"]) if mode == "train" else None
+    outs = O.fusion_forward(embs, params, cfg["H"], cfg["L"], cfg["ffn"], drop_masks=masks)
+    for nm, o in zip(OUTS, outs):
+        assert_close(o, z[f"{mode}.{nm}"], atol=2e-6, rtol=2e-6, what=f"{case}/{mode}/{nm}")
+    scalar = sum((o * T(z[f"cw{i}"])).sum() for i, o in enumerate(outs))
+    scalar.backward()
+    for i, e in enumerate(embs):
+        if e is not None:
+            assert_close(e.grad, z[f"{mode}.g.emb{i}"], atol=2e-5, rtol=1e-4, what=f"{case}/{mode}/g.emb{i}")
+    for k, p in params.items():
+        key = f"{mode}.g.p.{k}"
+        if key in z:
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            assert_close(g, z[key], atol=5e-5, rtol=1e-4, what=key)
+
+
+def test_readouts():
+    z = load("g1_fusion_m3_d128_h2.npz")
+    hid, j, jf = T(z["eval.hidden"]), T(z["eval.joint"]), T(z["eval.joint_fz"])
+    assert torch.equal(O.readout("Mformer_hd_graph", j, jf, hid, 2), hid[:, 2])
+    assert_close(O.readout("Mformer_hd_mean", j, jf, hid, 2), hid.mean(1), atol=0)
+    assert O.readout("Mformer_weight", j, jf, hid, 2) is j
+    assert O.readout("learnable_weight", j, jf, hid, 2) is jf
+    with pytest.raises(ValueError):
+        O.readout("nope", j, jf, hid, 0)
+
+
+def test_noise():
+    z = load("g2_noise.npz")
+    eps = float(z["mask_ratio"])
+    m, s = O.col_mean_std(T(z["img"]), T(z["ent_wo_img"]))
+    assert_close(m, z["img_mean"], atol=1e-7)
+    assert_close(s, z["img_std"], atol=1e-7)
+    for nm in ("rel", "att"):
+        m, s = O.col_mean_std(T(z[nm]))
+        assert_close(m, z[f"{nm}_mean"], atol=1e-6)
+        assert_close(s, z[f"{nm}_std"], atol=1e-6)
+    for nm in ("rel", "att", "img"):
+        out = O.add_noise_rows(T(z[nm]), T(z[f"{nm}_mean"]), T(z[f"{nm}_std"]), T(z[f"{nm}_mask"]), T(z[f"{nm}_z"]), eps)
+        assert torch.equal(out, T(z[f"{nm}_noisy"])), nm     # bit-exact replay of the reference RNG stream
+    m, s = O.col_mean_std(T(z["ent_w"]))
+    assert_close(m, z["ent_mean"], atol=1e-7)
+    assert_close(s, z["ent_std"], atol=1e-7)
+    assert torch.equal(T(z["ent_mean"]) + T(z["ent_std"]) * T(z["ent_z"]), T(z["entity_noise"]))
+    assert np.array_equal(z["ent_u"] < float(z["noise_ratio"]) * 0.5, z["entity_noise_mask"])
+
+
+def test_score_intree():
+    z = load("g3_score.npz")
+    e = T(z["ent"]).requires_grad_(True)
+    r = T(z["rel"]).requires_grad_(True)
+    idx = [T(z[k]) for k in ("p_h", "p_r", "p_t", "n_h", "n_r", "n_t")]
+    loss, pos, neg = O.kge_intree(e, r, *idx, float(z["margin"]))
+    assert_close(pos, z["pos"], atol=1e-6)
+    assert_close(neg, z["neg"], atol=1e-6)
+    assert_close(loss, z["loss_term1"], atol=1e-4)
+    loss.backward()
+    assert_close(e.grad, z["g.ent"], atol=1e-5)
+    assert_close(r.grad, z["g.rel"], atol=1e-5)
+    # K=1 negative-tail form reduces to the in-tree pairing when only tails are corrupted
+    tails_only = torch.from_numpy(z["n_h"] == z["p_h"])
+    sel = tails_only.nonzero().flatten()
+    l2, p2, n2 = O.score_margin(e.detach(), r.detach(), idx[0][sel], idx[1][sel], idx[2][sel], idx[5][sel].view(-1, 1),
+                                float(z["margin"]))
+    assert_close(p2, z["pos"][sel.numpy()], atol=1e-6)
+    assert_close(n2.flatten(), z["neg"][sel.numpy()], atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["d64", "d1200", "d64_nocsls"])
+def test_eval(name):
+    z = load(f"g4_eval_{name}.npz")
+    final = O.nrm(T(z["emb"]))
+    left, right = T(z["left"]), T(z["right"])
+    k = int(z["csls_k"])
+    assert_close(O.pairwise_distances(final[left], final[right]), z["dist"], atol=1e-6)
+    if k:
+        assert_close(O.csls_sim(1 - T(z["dist"]), k), z["csls"], atol=1e-6)
+    res = O.rank_metrics(final[left], final[right], csls_k=k)
+    assert np.array_equal(res["rank_l2r"].numpy(), z["rank_l2r"])           # ranking indices: bit-exact
+    for d in ("l2r", "r2l"):
+        assert np.allclose(res[f"hits_{d}"], z[f"hits_{d}"], atol=1e-7), (res[f"hits_{d}"], z[f"hits_{d}"])
+        assert round(res[f"mr_{d}"], 3) == pytest.approx(float(z[f"mr_{d}_3dp"]), abs=1.1e-3)
+        assert round(res[f"mrr_{d}"], 3) == pytest.approx(float(z[f"mrr_{d}_3dp"]), abs=1.1e-3)
+    assert 0.05 < res["hits_l2r"][0] < 0.999        # the fixture is informative
+
+
+def test_mutual_nearest():
+    z = load("g5_il.npz")
+    _, _, pairs = O.mutual_nearest(T(z["final"]), z["left"].tolist(), z["right"].tolist())
+    assert np.array_equal(np.array(pairs, dtype=np.int64), z["links"])
+    assert len(pairs) > 50
+
+
+def test_projections():
+    z = load("g6_proj.npz")
+    x = T(z["x"]).requires_grad_(True)
+    w, b = T(z["lin.weight"]).requires_grad_(True), T(z["lin.bias"]).requires_grad_(True)
+    y = O.linear(x, w, b)
+    assert_close(y, z["lin.y"], atol=2e-6)
+    (y * T(z["cw"])).sum().backward()
+    assert_close(w.grad, z["lin.g.weight"], atol=1e-5)
+    assert_close(b.grad, z["lin.g.bias"], atol=1e-5)
+    for mode in ("eval", "train"):
+        x = T(z["x"]).requires_grad_(True)
+        w1, w2 = T(z["ph.l1"]).requires_grad_(True), T(z["ph.l2"]).requires_grad_(True)
+        mask = T(z["ph.mask"]) if mode == "train" else None
+        y = O.projection_head(x, w1, w2, mask, float(z["ph.p"]))
+        assert_close(y, z[f"ph.{mode}.y"], atol=2e-6)
+        (y * T(z["cw"])).sum().backward()
+        assert_close(w1.grad, z[f"ph.{mode}.g.l1"], atol=1e-5)
+        assert_close(w2.grad, z[f"ph.{mode}.g.l2"], atol=1e-5)
+        assert_close(x.grad, z[f"ph.{mode}.g.x"], atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["clean", "noisy"])
+def test_encoder(tag):
+    """MultiModalEncoder.forward (SNAG_tools.py:122-156): projections + entity noise blend + fusion."""
+    z = load("g7_encoder.npz")
+    P = {k[2:]: T(v) for k, v in z.items() if k.startswith("p.")}
+    ent = P["entity_emb.weight"].clone().requires_grad_(True)
+    e = ent
+    if tag == "noisy":
+        e = O.entity_noise_blend(ent, T(z["entity_noise"]), T(z["entity_noise_mask"]), float(z["mask_ratio"]))
+    img = O.linear(T(z["img"]), P["img_fc.weight"], P["img_fc.bias"])
+    rel = O.linear(T(z["rel"]), P["rel_fc.weight"], P["rel_fc.bias"])
+    att = O.linear(T(z["att"]), P["att_fc.weight"], P["att_fc.bias"])
+    for nm, v in (("img", img), ("rel", rel), ("att", att), ("gph", e)):
+        assert_close(v, z[f"{tag}.{nm}"], atol=2e-6, what=nm)
+    fp = {k[len("fusion."):]: v for k, v in P.items() if k.startswith("fusion.")}
+    outs = O.fusion_forward([img, att, rel, e, None, None], fp, num_heads=2)
+    for nm, o in zip(OUTS, outs):
+        assert_close(o, z[f"{tag}.{nm}"], atol=3e-6, what=nm)
+    outs[2][:, 3, :].sum().backward()
+    assert_close(ent.grad, z[f"{tag}.g.entity_emb"], atol=1e-5)
