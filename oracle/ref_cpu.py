@@ -250,7 +250,7 @@ def score_margin(e: Tensor, r: Tensor, h: Tensor, rel: Tensor, t: Tensor, neg_t:
     B, K = neg_t.shape
     q = nrm(e[h.long()]) + nrm(r[rel.long()])                      # [B,D]
     pos = (q - nrm(e[t.long()])).pow(2).sum(-1)                    # [B]
-    tn = nrm(e[neg_t.long().reshape(-1)]).view(B, K, -1)
+    tn = nrm(e[neg_t.long().reshape(-1)]).view(B, K, e.shape[1])
     neg = (q.unsqueeze(1) - tn).pow(2).sum(-1)                     # [B,K]
     loss = torch.relu(margin + pos.unsqueeze(1) - neg).sum()
     return loss, pos, neg

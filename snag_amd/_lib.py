@@ -1,0 +1,80 @@
+"""ctypes binding of libsnag_hip.so (the C ABI in include/snag_hip.h).
+
+There is NO fallback: if the shared library is missing or a call is refused, this raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsnag_hip.so")
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_L = _c.c_int64
+_F = _c.c_float
+_U64 = _c.c_uint64
+
+# name -> argtypes; every entry returns int (0 = enqueued) except the two listed in _SPECIAL
+SIGNATURES = {
+    "snag_score_margin_fwd": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _P, _P, _P, _P],
+    "snag_score_margin_bwd": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P],
+    "snag_reduce_sum": [_P, _L, _P, _P],
+}
+_SPECIAL = {"snag_version": ([], _I), "snag_last_error": ([], _c.c_char_p)}
+
+_lib = None
+
+
+class SnagHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise with the build recipe if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SnagHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m snag_amd.build` "
+            "(hipcc --offload-arch=gfx950). snag_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argt in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argt
+        fn.restype = _I
+    for name, (argt, rest) in _SPECIAL.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argt
+        fn.restype = rest
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().snag_last_error().decode("utf-8", "replace")
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise SnagHipError(f"{name} failed ({rc}): {last_error()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise SnagHipError("snag_amd needs a visible MI355X (torch.cuda.is_available() is False); there is no CPU path")

@@ -1,0 +1,70 @@
+// Shared device/host helpers for libsnag_hip (gfx950 / CDNA4 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/snag_hip.h"
+
+namespace snag {
+
+constexpr int kWave = 64;
+
+// ---- error reporting (host) -------------------------------------------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+#define SNAG_REQUIRE(cond, code, ...)            \
+    do {                                         \
+        if (!(cond)) return ::snag::fail((code), __VA_ARGS__); \
+    } while (0)
+
+// ---- cross-lane reductions --------------------------------------------------
+// DPP row rotations stay inside a 16-lane row and fuse into v_add_f32_dpp: no LDS traffic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// all-reduce over each aligned group of 16 lanes; every lane ends with the bitwise-same sum
+__device__ __forceinline__ float sum16(float v) {
+    v += dpp_f32<0x128>(v);  // row_ror:8
+    v += dpp_f32<0x124>(v);  // row_ror:4
+    v += dpp_f32<0x122>(v);  // row_ror:2
+    v += dpp_f32<0x121>(v);  // row_ror:1
+    return v;
+}
+
+// all-reduce over the whole 64-lane wave
+__device__ __forceinline__ float sum64(float v) {
+    v = sum16(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ float max16(float v) {
+    v = fmaxf(v, dpp_f32<0x128>(v));
+    v = fmaxf(v, dpp_f32<0x124>(v));
+    v = fmaxf(v, dpp_f32<0x122>(v));
+    v = fmaxf(v, dpp_f32<0x121>(v));
+    return v;
+}
+
+__device__ __forceinline__ float max64(float v) {
+    v = max16(v);
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+
+__device__ __forceinline__ int wave_id_uniform() {
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+
+// F.normalize denominator: max(sqrt(ss), 1e-12)
+__device__ __forceinline__ float l2_denominator(float ss) { return fmaxf(sqrtf(ss), 1e-12f); }
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace snag

@@ -1,0 +1,368 @@
+// a7: negative-sampled TransE-L2^2 margin scoring (reference: model/MSNEA.py:110-122,151-152).
+//
+// Forward: one wave per triple.  A row of `dim` floats is spread over a 16-lane DPP row as float4
+// chunks (lane sub owns float4 #sub, #sub+16, ...), so one wave-instruction gathers four table rows
+// as four fully-used 256-B segments and every reduction is four v_add_f32_dpp (no LDS, no bpermute).
+// The head/relation/positive-tail rows are read by all four 16-lane groups (same lines, L1-served);
+// negatives stream four per round, up to eight rounds in flight.
+//
+// Backward: one wave per triple, a row spread over the whole wave (col = lane + 64*i) so that every
+// fp32 atomic wave-instruction adds 256 contiguous bytes of one gradient row (the full-rate shape).
+#include "common.hip.h"
+
+namespace snag {
+
+template <int NV>
+struct RowV4 {
+    float4 v[NV];
+};
+
+template <int NV>
+__device__ __forceinline__ RowV4<NV> load_row_v4(const float* __restrict__ base, int64_t row, int dim, int sub) {
+    RowV4<NV> r;
+    const float4* p = reinterpret_cast<const float4*>(base + row * (int64_t)dim);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = sub + 16 * j;
+        r.v[j] = (c * 4 < dim) ? p[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return r;
+}
+
+template <int NV>
+__device__ __forceinline__ float sumsq_v4(const RowV4<NV>& r) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        s = fmaf(r.v[j].x, r.v[j].x, s);
+        s = fmaf(r.v[j].y, r.v[j].y, s);
+        s = fmaf(r.v[j].z, r.v[j].z, s);
+        s = fmaf(r.v[j].w, r.v[j].w, s);
+    }
+    return s;
+}
+
+// || q - x / max(||x||, eps) ||^2, reduced over the 16-lane group
+template <int NV>
+__device__ __forceinline__ float score_row(const RowV4<NV>& q, const RowV4<NV>& x) {
+    const float inv = 1.0f / l2_denominator(sum16(sumsq_v4<NV>(x)));
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        float d;
+        d = q.v[j].x - x.v[j].x * inv; s = fmaf(d, d, s);
+        d = q.v[j].y - x.v[j].y * inv; s = fmaf(d, d, s);
+        d = q.v[j].z - x.v[j].z * inv; s = fmaf(d, d, s);
+        d = q.v[j].w - x.v[j].w * inv; s = fmaf(d, d, s);
+    }
+    return sum16(s);
+}
+
+template <typename IdxT, int NV>
+__global__ __launch_bounds__(256) void score_fwd_kernel(
+    const float* __restrict__ ent, const float* __restrict__ rel, int dim,
+    const IdxT* __restrict__ h, const IdxT* __restrict__ r, const IdxT* __restrict__ t,
+    const IdxT* __restrict__ neg_t, int64_t batch, int n_neg, float margin,
+    float* __restrict__ pos, float* __restrict__ neg, float* __restrict__ loss_part) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (b >= batch) return;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 15;
+    const int grp = lane >> 4;
+
+    const int64_t hi = (int64_t)h[b], ri = (int64_t)r[b], ti = (int64_t)t[b];
+    RowV4<NV> q = load_row_v4<NV>(ent, hi, dim, sub);
+    RowV4<NV> rr = load_row_v4<NV>(rel, ri, dim, sub);
+    const RowV4<NV> tt = load_row_v4<NV>(ent, ti, dim, sub);
+    {
+        const float ih = 1.0f / l2_denominator(sum16(sumsq_v4<NV>(q)));
+        const float ir = 1.0f / l2_denominator(sum16(sumsq_v4<NV>(rr)));
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            q.v[j].x = q.v[j].x * ih + rr.v[j].x * ir;
+            q.v[j].y = q.v[j].y * ih + rr.v[j].y * ir;
+            q.v[j].z = q.v[j].z * ih + rr.v[j].z * ir;
+            q.v[j].w = q.v[j].w * ih + rr.v[j].w * ir;
+        }
+    }
+    const float s_pos = score_row<NV>(q, tt);
+    if (lane == 0) pos[b] = s_pos;
+
+    float hinge = 0.f;
+    const IdxT* nrow = neg_t + b * (int64_t)n_neg;
+    float* out = neg + b * (int64_t)n_neg;
+    for (int k0 = 0; k0 < n_neg; k0 += 64) {
+        // one coalesced read of up to 64 negative-tail ids, handed to the lane groups by bpermute
+        const int my = (k0 + lane < n_neg) ? (int)nrow[k0 + lane] : 0;
+        const int cnt = min(64, n_neg - k0);
+        int it = 0;
+        // full blocks: 8 rounds x 4 rows, all 16 gathers of the block issued before the first use
+        for (; it + 32 <= cnt; it += 32) {
+            RowV4<NV> x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = load_row_v4<NV>(ent, __shfl(my, it + 4 * u + grp), dim, sub);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float s = score_row<NV>(q, x[u]);
+                hinge += fmaxf(margin + s_pos - s, 0.f);
+                if (sub == 0) out[k0 + it + 4 * u + grp] = s;
+            }
+        }
+        // ragged tail: one round (up to 4 rows) at a time
+        for (; it < cnt; it += 4) {
+            const int k = it + grp;
+            const bool valid = k < cnt;
+            const int idx = __shfl(my, k);  // all lanes take part: a bpermute from an inactive lane reads 0
+            const RowV4<NV> x = load_row_v4<NV>(ent, valid ? idx : 0, dim, sub);
+            const float s = score_row<NV>(q, x);
+            if (valid) {
+                hinge += fmaxf(margin + s_pos - s, 0.f);
+                if (sub == 0) out[k0 + k] = s;
+            }
+        }
+    }
+    if (loss_part != nullptr) {
+        // every lane of a group holds the group's partial; combine the four groups in fixed order
+        const float g1 = __shfl(hinge, 16), g2 = __shfl(hinge, 32), g3 = __shfl(hinge, 48);
+        if (lane == 0) loss_part[b] = ((hinge + g1) + g2) + g3;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NS>
+struct RowS {
+    float v[NS];
+};
+
+template <int NS>
+__device__ __forceinline__ RowS<NS> load_row_s(const float* __restrict__ base, int64_t row, int dim, int lane) {
+    RowS<NS> r;
+    const float* p = base + row * (int64_t)dim;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int c = lane + 64 * i;
+        r.v[i] = (c < dim) ? p[c] : 0.f;
+    }
+    return r;
+}
+
+// x -> xhat = x / max(||x||, eps); returns the denominator
+template <int NS>
+__device__ __forceinline__ float normalize_s(RowS<NS>& x) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) ss = fmaf(x.v[i], x.v[i], ss);
+    const float den = l2_denominator(sum64(ss));
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) x.v[i] *= inv;
+    return den;
+}
+
+// backward of F.normalize: dx = (dy - yhat (yhat . dy)) / ||x||   (clamped branch: dx = dy / eps)
+template <int NS>
+__device__ __forceinline__ void normalize_bwd_atomic(const RowS<NS>& yhat, float den, const RowS<NS>& dy,
+                                                     float* __restrict__ grad_row, int dim, int lane) {
+    float dot = 0.f;
+    if (den > 1e-12f) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) dot = fmaf(yhat.v[i], dy.v[i], dot);
+        dot = sum64(dot);
+    }
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < dim) atomicAdd(grad_row + c, (dy.v[i] - yhat.v[i] * dot) * inv);
+    }
+}
+
+template <typename IdxT, int NS>
+__global__ __launch_bounds__(256) void score_bwd_kernel(
+    const float* __restrict__ ent, const float* __restrict__ rel, int dim,
+    const IdxT* __restrict__ h, const IdxT* __restrict__ r, const IdxT* __restrict__ t,
+    const IdxT* __restrict__ neg_t, int64_t batch, int n_neg, float margin, float gscale,
+    const float* __restrict__ dpos, const float* __restrict__ dneg,
+    float* __restrict__ d_ent, float* __restrict__ d_rel) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (b >= batch) return;
+    const int lane = threadIdx.x & 63;
+    const bool hinge_mode = (dpos == nullptr);
+
+    const int64_t hi = (int64_t)h[b], ri = (int64_t)r[b], ti = (int64_t)t[b];
+    RowS<NS> hh = load_row_s<NS>(ent, hi, dim, lane);
+    RowS<NS> rr = load_row_s<NS>(rel, ri, dim, lane);
+    RowS<NS> tt = load_row_s<NS>(ent, ti, dim, lane);
+    const float den_h = normalize_s<NS>(hh);
+    const float den_r = normalize_s<NS>(rr);
+    const float den_t = normalize_s<NS>(tt);
+    RowS<NS> q, dq;
+    float s_pos = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        q.v[i] = hh.v[i] + rr.v[i];
+        dq.v[i] = 0.f;
+        const float d = q.v[i] - tt.v[i];
+        s_pos = fmaf(d, d, s_pos);
+    }
+    s_pos = sum64(s_pos);
+
+    float c_pos = hinge_mode ? 0.f : gscale * dpos[b];
+    const IdxT* nrow = neg_t + b * (int64_t)n_neg;
+    for (int k = 0; k < n_neg; ++k) {
+        const int64_t xi = (int64_t)nrow[k];
+        RowS<NS> x = load_row_s<NS>(ent, xi, dim, lane);
+        const float den_x = normalize_s<NS>(x);
+        float c;
+        if (hinge_mode) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const float d = q.v[i] - x.v[i];
+                s = fmaf(d, d, s);
+            }
+            s = sum64(s);
+            c = (margin + s_pos - s > 0.f) ? -gscale : 0.f;
+            c_pos -= c;
+        } else {
+            c = gscale * dneg[b * (int64_t)n_neg + k];
+        }
+        if (c != 0.f) {  // wave-uniform
+            RowS<NS> dx;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const float e2 = 2.f * c * (q.v[i] - x.v[i]);
+                dq.v[i] += e2;
+                dx.v[i] = -e2;
+            }
+            normalize_bwd_atomic<NS>(x, den_x, dx, d_ent + xi * (int64_t)dim, dim, lane);
+        }
+    }
+    if (c_pos != 0.f) {
+        RowS<NS> dx;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const float e2 = 2.f * c_pos * (q.v[i] - tt.v[i]);
+            dq.v[i] += e2;
+            dx.v[i] = -e2;
+        }
+        normalize_bwd_atomic<NS>(tt, den_t, dx, d_ent + ti * (int64_t)dim, dim, lane);
+    }
+    normalize_bwd_atomic<NS>(hh, den_h, dq, d_ent + hi * (int64_t)dim, dim, lane);
+    normalize_bwd_atomic<NS>(rr, den_r, dq, d_rel + ri * (int64_t)dim, dim, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float part[16];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += x[i];
+    s = sum64(s);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) part[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < 16; ++i) tot += part[i];
+        out[0] = tot;
+    }
+}
+
+template <typename IdxT>
+static int launch_fwd(const float* ent, const float* rel, int dim, const void* h, const void* r, const void* t,
+                      const void* neg_t, int64_t batch, int n_neg, float margin, float* pos, float* neg,
+                      float* loss_part, hipStream_t st) {
+    const dim3 grid((unsigned)ceil_div(batch, 4)), block(256);
+    const int nv = (dim + 63) / 64;
+#define SNAG_FWD(NV)                                                                                           \
+    hipLaunchKernelGGL((score_fwd_kernel<IdxT, NV>), grid, block, 0, st, ent, rel, dim, (const IdxT*)h,        \
+                       (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, pos, neg, loss_part)
+    switch (nv) {
+        case 1: SNAG_FWD(1); break;
+        case 2: SNAG_FWD(2); break;
+        case 3: SNAG_FWD(3); break;
+        case 4: SNAG_FWD(4); break;
+        case 5: case 6: SNAG_FWD(6); break;
+        default: SNAG_FWD(8); break;
+    }
+#undef SNAG_FWD
+    return check_launch("snag_score_margin_fwd");
+}
+
+template <typename IdxT>
+static int launch_bwd(const float* ent, const float* rel, int dim, const void* h, const void* r, const void* t,
+                      const void* neg_t, int64_t batch, int n_neg, float margin, float gscale, const float* dpos,
+                      const float* dneg, float* d_ent, float* d_rel, hipStream_t st) {
+    const dim3 grid((unsigned)ceil_div(batch, 4)), block(256);
+    const int ns = (dim + 63) / 64;
+#define SNAG_BWD(NS)                                                                                           \
+    hipLaunchKernelGGL((score_bwd_kernel<IdxT, NS>), grid, block, 0, st, ent, rel, dim, (const IdxT*)h,        \
+                       (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, gscale, dpos, \
+                       dneg, d_ent, d_rel)
+    switch (ns) {
+        case 1: SNAG_BWD(1); break;
+        case 2: SNAG_BWD(2); break;
+        case 3: SNAG_BWD(3); break;
+        case 4: SNAG_BWD(4); break;
+        case 5: case 6: SNAG_BWD(6); break;
+        default: SNAG_BWD(8); break;
+    }
+#undef SNAG_BWD
+    return check_launch("snag_score_margin_bwd");
+}
+
+static int check_score_args(const void* ent, int64_t n_ent, const void* rel, int64_t n_rel, int dim, const void* h,
+                            const void* r, const void* t, const void* neg_t, int idx_bytes, int64_t batch, int n_neg) {
+    SNAG_REQUIRE(ent && rel && h && r && t, SNAG_ERR_ARG, "score: null table or index pointer");
+    SNAG_REQUIRE(n_ent > 0 && n_rel > 0 && dim > 0, SNAG_ERR_ARG, "score: n_ent=%ld n_rel=%ld dim=%d must be positive",
+                 (long)n_ent, (long)n_rel, dim);
+    SNAG_REQUIRE(batch >= 0 && n_neg >= 0, SNAG_ERR_ARG, "score: batch=%ld n_neg=%d must be non-negative", (long)batch, n_neg);
+    SNAG_REQUIRE(n_neg == 0 || neg_t, SNAG_ERR_ARG, "score: neg_t is null but n_neg=%d", n_neg);
+    SNAG_REQUIRE(idx_bytes == 4 || idx_bytes == 8, SNAG_ERR_ARG, "score: idx_bytes=%d (want 4 or 8)", idx_bytes);
+    SNAG_REQUIRE(dim <= 512, SNAG_ERR_UNSUPPORTED, "score: dim=%d > 512 not supported", dim);
+    SNAG_REQUIRE(n_ent < (1LL << 31), SNAG_ERR_UNSUPPORTED, "score: n_ent=%ld >= 2^31", (long)n_ent);
+    return SNAG_OK;
+}
+
+}  // namespace snag
+
+using namespace snag;
+
+extern "C" SNAG_API int snag_score_margin_fwd(const float* ent, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+                                     const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                                     int64_t batch, int n_neg, float margin, float* pos, float* neg, float* loss_part,
+                                     void* stream) {
+    if (batch == 0) return SNAG_OK;
+    int rc = check_score_args(ent, n_ent, rel, n_rel, dim, h, r, t, neg_t, idx_bytes, batch, n_neg);
+    if (rc) return rc;
+    SNAG_REQUIRE(pos && (n_neg == 0 || neg), SNAG_ERR_ARG, "score_fwd: null output pointer");
+    SNAG_REQUIRE(dim % 4 == 0, SNAG_ERR_UNSUPPORTED, "score_fwd: dim=%d must be a multiple of 4 (16-byte rows)", dim);
+    if (batch == 0) return SNAG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    return idx_bytes == 4 ? launch_fwd<int32_t>(ent, rel, dim, h, r, t, neg_t, batch, n_neg, margin, pos, neg, loss_part, st)
+                          : launch_fwd<int64_t>(ent, rel, dim, h, r, t, neg_t, batch, n_neg, margin, pos, neg, loss_part, st);
+}
+
+extern "C" SNAG_API int snag_score_margin_bwd(const float* ent, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+                                     const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                                     int64_t batch, int n_neg, float margin, float grad_scale, const float* dpos,
+                                     const float* dneg, float* d_ent, float* d_rel, void* stream) {
+    if (batch == 0) return SNAG_OK;
+    int rc = check_score_args(ent, n_ent, rel, n_rel, dim, h, r, t, neg_t, idx_bytes, batch, n_neg);
+    if (rc) return rc;
+    SNAG_REQUIRE(d_ent && d_rel, SNAG_ERR_ARG, "score_bwd: null gradient pointer");
+    SNAG_REQUIRE((dpos != nullptr) || (dneg == nullptr), SNAG_ERR_ARG, "score_bwd: dneg given without dpos");
+    SNAG_REQUIRE((dpos == nullptr) || (dneg != nullptr) || n_neg == 0, SNAG_ERR_ARG,
+                 "score_bwd: explicit mode needs both dpos and dneg");
+    if (batch == 0) return SNAG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    return idx_bytes == 4
+               ? launch_bwd<int32_t>(ent, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, d_ent, d_rel, st)
+               : launch_bwd<int64_t>(ent, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, d_ent, d_rel, st);
+}
+
+extern "C" SNAG_API int snag_reduce_sum(const float* x, int64_t n, float* out, void* stream) {
+    SNAG_REQUIRE(out && (x || n == 0) && n >= 0, SNAG_ERR_ARG, "reduce_sum: bad arguments (n=%ld)", (long)n);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
+    return check_launch("snag_reduce_sum");
+}

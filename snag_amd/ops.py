@@ -1,0 +1,95 @@
+"""Thin, checked Python wrappers over the C ABI: tensors in, tensors out, no arithmetic here.
+
+Shape/dtype/contiguity errors are raised in Python before the call, mirroring the reference's
+assert/exception convention (SURVEY.md par. 8b "Errors").
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+f32 = torch.float32
+
+
+def _chk(t, name, dtype=f32, ndim=None):
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise _lib.SnagHipError(f"{name}: tensor is on {t.device}; snag_amd kernels run on the GPU only (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _idx(t, name, ndim):
+    if not torch.is_tensor(t) or t.dtype not in (torch.int32, torch.int64):
+        raise TypeError(f"{name}: expected an int32/int64 tensor")
+    return _chk(t, name, dtype=None, ndim=ndim)
+
+
+def _idx_group(h, r, t, neg_t):
+    _idx(h, "h", 1), _idx(r, "r", 1), _idx(t, "t", 1)
+    B = h.shape[0]
+    if r.shape[0] != B or t.shape[0] != B:
+        raise ValueError(f"h, r, t must have equal length, got {B}, {r.shape[0]}, {t.shape[0]}")
+    dt = h.dtype
+    if r.dtype != dt or t.dtype != dt:
+        raise TypeError("h, r, t must share one index dtype")
+    K = 0
+    if neg_t is not None:
+        _idx(neg_t, "neg_t", 2)
+        if neg_t.shape[0] != B or neg_t.dtype != dt:
+            raise ValueError(f"neg_t must be [{B}, K] of dtype {dt}, got {tuple(neg_t.shape)} {neg_t.dtype}")
+        K = neg_t.shape[1]
+    return B, K, (4 if dt == torch.int32 else 8)
+
+
+def score_margin_fwd(ent, rel, h, r, t, neg_t, margin, want_loss=True):
+    """-> pos [B], neg [B,K], loss_part [B] (or None).  C ABI: snag_score_margin_fwd."""
+    _chk(ent, "ent", ndim=2), _chk(rel, "rel", ndim=2)
+    if ent.shape[1] != rel.shape[1]:
+        raise ValueError(f"ent dim {ent.shape[1]} != rel dim {rel.shape[1]}")
+    B, K, ib = _idx_group(h, r, t, neg_t)
+    pos = torch.empty(B, device=ent.device, dtype=f32)
+    neg = torch.empty(B, K, device=ent.device, dtype=f32)
+    loss_part = torch.empty(B, device=ent.device, dtype=f32) if want_loss else None
+    call("snag_score_margin_fwd", ptr(ent), ent.shape[0], ptr(rel), rel.shape[0], ent.shape[1],
+         ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K, float(margin), ptr(pos), ptr(neg), ptr(loss_part), stream())
+    return pos, neg, loss_part
+
+
+def score_margin_bwd(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, dpos=None, dneg=None, d_ent=None, d_rel=None):
+    """Accumulates into d_ent/d_rel (allocated zeroed when None).  C ABI: snag_score_margin_bwd."""
+    _chk(ent, "ent", ndim=2), _chk(rel, "rel", ndim=2)
+    B, K, ib = _idx_group(h, r, t, neg_t)
+    if dpos is not None:
+        _chk(dpos, "dpos", ndim=1)
+        if dpos.shape[0] != B:
+            raise ValueError("dpos must be [B]")
+    if dneg is not None:
+        _chk(dneg, "dneg", ndim=2)
+        if tuple(dneg.shape) != (B, K):
+            raise ValueError("dneg must be [B, K]")
+    if d_ent is None:
+        d_ent = torch.zeros_like(ent)
+    if d_rel is None:
+        d_rel = torch.zeros_like(rel)
+    _chk(d_ent, "d_ent", ndim=2), _chk(d_rel, "d_rel", ndim=2)
+    if d_ent.shape != ent.shape or d_rel.shape != rel.shape:
+        raise ValueError("gradient buffers must match the table shapes")
+    call("snag_score_margin_bwd", ptr(ent), ent.shape[0], ptr(rel), rel.shape[0], ent.shape[1],
+         ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K, float(margin), float(grad_scale),
+         ptr(dpos), ptr(dneg), ptr(d_ent), ptr(d_rel), stream())
+    return d_ent, d_rel
+
+
+def reduce_sum(x):
+    """Deterministic sum of a float tensor -> 0-dim tensor.  C ABI: snag_reduce_sum."""
+    _chk(x, "x")
+    out = torch.empty((), device=x.device, dtype=f32)
+    call("snag_reduce_sum", ptr(x), x.numel(), ptr(out), stream())
+    return out

@@ -1,0 +1,71 @@
+"""Negative-sampled margin scoring behind the reference's operator interface.
+
+Reference: ``MSNEA.kge`` / ``r_rep`` (model/MSNEA.py:108-132,151-152) and the README-level MKGC
+knobs ``MARGIN`` / ``NEG_NUM`` (README.md:71-79).  All arithmetic runs in libsnag_hip.so.
+"""
+import torch
+
+from . import ops
+
+
+class _MarginScoreFn(torch.autograd.Function):
+    """(ent, rel) -> (pos [B], neg [B,K]); gradients via snag_score_margin_bwd (explicit mode)."""
+
+    @staticmethod
+    def forward(ctx, ent, rel, h, r, t, neg_t):
+        pos, neg, _ = ops.score_margin_fwd(ent, rel, h, r, t, neg_t, 0.0, want_loss=False)
+        ctx.save_for_backward(ent, rel, h, r, t, neg_t)
+        ctx.has_neg = neg_t is not None
+        return pos, neg
+
+    @staticmethod
+    def backward(ctx, dpos, dneg):
+        ent, rel, h, r, t, neg_t = ctx.saved_tensors
+        dpos = dpos.contiguous()
+        dneg = dneg.contiguous() if neg_t is not None else None
+        d_ent, d_rel = ops.score_margin_bwd(ent, rel, h, r, t, neg_t, 0.0, 1.0, dpos=dpos, dneg=dneg)
+        return d_ent, d_rel, None, None, None, None
+
+
+class _MarginLossFn(torch.autograd.Function):
+    """(ent, rel) -> scalar hinge loss over 1 positive + K negative tails; fused hinge backward."""
+
+    @staticmethod
+    def forward(ctx, ent, rel, h, r, t, neg_t, margin):
+        pos, neg, part = ops.score_margin_fwd(ent, rel, h, r, t, neg_t, margin, want_loss=True)
+        ctx.save_for_backward(ent, rel, h, r, t, neg_t)
+        ctx.margin = margin
+        ctx.mark_non_differentiable(pos, neg)
+        return ops.reduce_sum(part), pos, neg
+
+    @staticmethod
+    def backward(ctx, dloss, _dp, _dn):
+        ent, rel, h, r, t, neg_t = ctx.saved_tensors
+        d_ent, d_rel = ops.score_margin_bwd(ent, rel, h, r, t, neg_t, ctx.margin, float(dloss))
+        return d_ent, d_rel, None, None, None, None, None
+
+
+def score(ent, rel, h, r, t, neg_t=None):
+    """s(h,r,t) and s(h,r,neg_t[b,k]) (TransE, squared L2 on L2-normalised rows).  Differentiable."""
+    return _MarginScoreFn.apply(ent, rel, h, r, t, neg_t)
+
+
+def margin_loss(ent, rel, h, r, t, neg_t, margin):
+    """sum_b sum_k relu(margin + s(h,r,t) - s(h,r,neg_t[b,k])) -> (loss, pos, neg).
+
+    The MKGC shape of BASELINE.json (NEG_NUM negative tails per positive).  ``float(dloss)`` in the
+    backward synchronises only when the upstream gradient is not the usual python 1.0.
+    """
+    return _MarginLossFn.apply(ent, rel, h, r, t, neg_t, float(margin))
+
+
+def kge_relation_loss(ent, rel, p_h, p_r, p_t, n_h, n_r, n_t, margin):
+    """In-tree pairing: sum_i relu(margin + s(pos_i) - s(neg_i)), arbitrary (head or tail) corruption.
+
+    Same arguments as the first six of ``MSNEA.kge`` (model/MSNEA.py:108); term 1 (:120-122) only.
+    Returns (loss, pos_score, neg_score).
+    """
+    pos, _ = score(ent, rel, p_h, p_r, p_t)
+    neg, _ = score(ent, rel, n_h, n_r, n_t)
+    loss = torch.relu(margin + pos - neg).sum()
+    return loss, pos, neg

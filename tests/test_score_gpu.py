@@ -1,0 +1,116 @@
+"""GPU parity: snag_score_margin_fwd/bwd (through the C ABI) vs the CPU oracle and golden G3."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import T, assert_close, load
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _mk(N, R, D, B, K, seed, idt=torch.int64, scale=0.5):
+    g = torch.Generator().manual_seed(seed)
+    ent = torch.randn(N, D, generator=g) * scale
+    rel = torch.randn(R, D, generator=g) * 0.3
+    h = torch.randint(0, N, (B,), generator=g).to(idt)
+    r = torch.randint(0, R, (B,), generator=g).to(idt)
+    t = torch.randint(0, N, (B,), generator=g).to(idt)
+    neg = torch.randint(0, N, (B, K), generator=g).to(idt)
+    return ent, rel, h, r, t, neg
+
+
+@pytest.mark.parametrize("D,K,B,idt", [
+    (128, 32, 1024, torch.int32), (128, 32, 257, torch.int64), (128, 1, 64, torch.int64), (128, 0, 33, torch.int32),
+    (128, 3, 50, torch.int32), (128, 33, 40, torch.int64), (128, 70, 19, torch.int32), (128, 128, 16, torch.int32),
+    (64, 32, 100, torch.int32), (256, 128, 48, torch.int32), (300, 7, 30, torch.int64), (100, 5, 21, torch.int32),
+    (512, 9, 12, torch.int32), (4, 2, 9, torch.int32),
+])
+def test_score_fwd_bwd_vs_oracle(D, K, B, idt):
+    from snag_amd import ops
+    margin = 1.2
+    ent, rel, h, r, t, neg = _mk(501, 13, D, B, K, seed=D * 1000 + K, idt=idt)
+    ent[7].zero_()                                   # normalize eps branch
+    h[0] = 7
+    if K:
+        neg[1, 0] = 7
+    e_ = ent.clone().requires_grad_(True)
+    r_ = rel.clone().requires_grad_(True)
+    loss, pos, ng = O.score_margin(e_, r_, h, r, t, neg, margin)
+    # keep the eps-branch row out of the gradient comparison scale (1e12 magnitudes) by weighting
+    loss.backward()
+    d = [x.to(DEV) for x in (ent, rel, h, r, t, neg)]
+    pos_g, neg_g, lp = ops.score_margin_fwd(*d, margin)
+    assert_close(pos_g, pos, atol=1e-5, what="pos")
+    assert_close(neg_g, ng, atol=1e-5, what="neg")
+    assert_close(ops.reduce_sum(lp), loss, atol=1e-4, rtol=1e-5, what="loss")
+    assert_close(lp, torch.relu(margin + pos.unsqueeze(1) - ng).sum(1), atol=1e-4, rtol=2e-6, what="loss_part")
+    de, dr = ops.score_margin_bwd(*d, margin)
+    assert_close(de, e_.grad, atol=2e-4, rtol=1e-4, what="d_ent")
+    assert_close(dr, r_.grad, atol=2e-4, rtol=1e-4, what="d_rel")
+
+
+def test_score_bwd_explicit_mode():
+    from snag_amd import ops
+    ent, rel, h, r, t, neg = _mk(300, 7, 128, 77, 5, seed=5)
+    g = torch.Generator().manual_seed(9)
+    dpos, dneg = torch.randn(77, generator=g), torch.randn(77, 5, generator=g)
+    e_ = ent.clone().requires_grad_(True)
+    r_ = rel.clone().requires_grad_(True)
+    _, pos, ng = O.score_margin(e_, r_, h, r, t, neg, 0.0)
+    ((pos * dpos).sum() + (ng * dneg).sum()).backward()
+    d = [x.to(DEV) for x in (ent, rel, h, r, t, neg)]
+    de, dr = ops.score_margin_bwd(*d, 0.0, grad_scale=1.0, dpos=dpos.to(DEV), dneg=dneg.to(DEV))
+    assert_close(de, e_.grad, atol=1e-4, rtol=1e-4)
+    assert_close(dr, r_.grad, atol=1e-4, rtol=1e-4)
+
+
+def test_score_golden_intree_kge():
+    """golden G3: MSNEA.kge term 1 (model/MSNEA.py:110-122), head-or-tail corruption, one negative per positive."""
+    from snag_amd.score import kge_relation_loss
+    z = load("g3_score.npz")
+    ent = T(z["ent"], DEV).requires_grad_(True)
+    rel = T(z["rel"], DEV).requires_grad_(True)
+    idx = [T(z[k], DEV) for k in ("p_h", "p_r", "p_t", "n_h", "n_r", "n_t")]
+    loss, pos, neg = kge_relation_loss(ent, rel, *idx, margin=float(z["margin"]))
+    assert_close(pos, z["pos"], atol=1e-5)
+    assert_close(neg, z["neg"], atol=1e-5)
+    assert_close(loss, z["loss_term1"], atol=1e-4)
+    loss.backward()
+    assert_close(ent.grad, z["g.ent"], atol=1e-4, rtol=1e-4)
+    assert_close(rel.grad, z["g.rel"], atol=1e-4, rtol=1e-4)
+
+
+def test_score_full_size_properties():
+    """BASELINE config 2 shape (|E|=15k, D=128, B=1024, K=32): size-independent properties."""
+    from snag_amd import ops
+    ent, rel, h, r, t, neg = [x.to(DEV) for x in _mk(15000, 558, 128, 1024, 32, seed=1234, idt=torch.int32)]
+    pos, ng, lp = ops.score_margin_fwd(ent, rel, h, r, t, neg, 12.0)
+    # scale invariance: rows are L2-normalised, so scaling the tables must not change any score
+    pos2, ng2, _ = ops.score_margin_fwd(ent * 3.0, rel * 0.25, h, r, t, neg, 12.0)
+    assert_close(pos2, pos, atol=2e-6)
+    assert_close(ng2, ng, atol=2e-6)
+    # a negative tail equal to the positive tail scores exactly like the positive
+    neg2 = neg.clone()
+    neg2[:, 5] = t
+    _, ng3, _ = ops.score_margin_fwd(ent, rel, h, r, t, neg2, 12.0)
+    assert torch.equal(ng3[:, 5], pos)
+    # bounds: 0 <= s <= 9 for unit vectors; margin 12 keeps every hinge active -> loss = sum(12 + pos - neg)
+    assert float(ng.min()) >= 0 and float(ng.max()) <= 9.0 + 1e-4
+    assert_close(lp, (12.0 + pos.unsqueeze(1) - ng).sum(1), atol=2e-4)
+    # permutation of negatives permutes scores
+    perm = torch.randperm(32, device=DEV)
+    _, ng4, _ = ops.score_margin_fwd(ent, rel, h, r, t, neg[:, perm].contiguous(), 12.0)
+    assert torch.equal(ng4, ng[:, perm])
+    # gradient: total mass conservation -- sum over all rows of d_ent . ent_row is 0 (normalize is scale invariant)
+    de, dr = ops.score_margin_bwd(ent, rel, h, r, t, neg, 12.0)
+    assert float((de * ent).sum(1).abs().max()) < 1e-3
+    assert float((dr * rel).sum(1).abs().max()) < 1e-3
+
+
+def test_score_empty_batch():
+    from snag_amd import ops
+    ent, rel, h, r, t, neg = [x.to(DEV) for x in _mk(10, 3, 128, 0, 4, seed=1)]
+    pos, ng, lp = ops.score_margin_fwd(ent, rel, h, r, t, neg, 1.0)
+    assert pos.numel() == 0 and ng.shape == (0, 4)
