@@ -74,6 +74,43 @@ SNAG_API int snag_score_margin_bwd(const float* ent, int64_t n_ent, const float*
 /* Deterministic (fixed-order) sum of n floats into out[0]; used for the scalar loss. */
 SNAG_API int snag_reduce_sum(const float* x, int64_t n, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Dense fp32 contraction on the exact-f32 matrix cores (v_mfma_f32_32x32x2_f32).
+ * Replaces the aten addmm/mm calls of the path: per-modality projections nn.Linear(F_m, D)
+ * (model/SNAG_tools.py:92-96,134-150), ProjectionHead (model/layers.py:135-148), the Mformer
+ * linears (model/SNAG_tools.py:183-186,219,251,263) and their autograd.
+ *
+ *   C[m,n] (=|+=) add1[m,n] + add2[m,n] + keep(m,n) * act( alpha * sum_k A(m,k) B(n,k) + bias[n] )
+ *
+ * a_kcontig: 1 -> A(m,k) = A[m*lda + k] ; 0 -> A(m,k) = A[k*lda + m]        (same for B with n)
+ * act: 0 none, 1 relu, 2 gelu(erf), 3 multiply by gelu'(aux[m,n]), 4 multiply by (aux[m,n] > 0)
+ * (3/4 are the backward of 2/1 with aux = the saved pre-activation / activation).
+ * pre_act (optional, ld = ldc) receives alpha*acc + bias.
+ * keep_mask (optional) is a dense uint8 [M,N] inverted-dropout mask, keep_scale = 1/(1-p).
+ * workspace (optional, workspace_floats long) enables deterministic split-K for small-output /
+ * long-K shapes; snag_gemm_workspace_floats(M,N,K) is the size that never limits the split.
+ */
+typedef struct snag_gemm_desc {
+    int32_t M, N, K;
+    int32_t a_kcontig, b_kcontig;
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    float* C; int64_t ldc;
+    const float* bias;
+    float alpha;
+    int32_t act;
+    float* pre_act;
+    const uint8_t* keep_mask; float keep_scale;
+    const float* add1; int64_t ld1;
+    const float* add2; int64_t ld2;
+    int32_t accumulate;
+    float* workspace; int64_t workspace_floats;
+    const float* aux; int64_t ldaux;
+} snag_gemm_desc;
+
+SNAG_API int snag_gemm_f32(const snag_gemm_desc* desc, void* stream);
+SNAG_API int64_t snag_gemm_workspace_floats(int M, int N, int K);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,13 +17,29 @@ _L = _c.c_int64
 _F = _c.c_float
 _U64 = _c.c_uint64
 
+
+
+class GemmDesc(_c.Structure):
+    """struct snag_gemm_desc (include/snag_hip.h)."""
+    _fields_ = [("M", _c.c_int32), ("N", _c.c_int32), ("K", _c.c_int32),
+                ("a_kcontig", _c.c_int32), ("b_kcontig", _c.c_int32),
+                ("A", _P), ("lda", _L), ("B", _P), ("ldb", _L), ("C", _P), ("ldc", _L),
+                ("bias", _P), ("alpha", _F), ("act", _c.c_int32), ("pre_act", _P),
+                ("keep_mask", _P), ("keep_scale", _F),
+                ("add1", _P), ("ld1", _L), ("add2", _P), ("ld2", _L),
+                ("accumulate", _c.c_int32), ("workspace", _P), ("workspace_floats", _L),
+                ("aux", _P), ("ldaux", _L)]
+
+
 # name -> argtypes; every entry returns int (0 = enqueued) except the two listed in _SPECIAL
 SIGNATURES = {
     "snag_score_margin_fwd": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _P, _P, _P, _P],
     "snag_score_margin_bwd": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P],
     "snag_reduce_sum": [_P, _L, _P, _P],
+    "snag_gemm_f32": [_c.POINTER(GemmDesc), _P],
 }
-_SPECIAL = {"snag_version": ([], _I), "snag_last_error": ([], _c.c_char_p)}
+_SPECIAL = {"snag_version": ([], _I), "snag_last_error": ([], _c.c_char_p),
+            "snag_gemm_workspace_floats": ([_I, _I, _I], _L)}
 
 _lib = None
 

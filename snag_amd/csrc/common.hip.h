@@ -67,4 +67,9 @@ __device__ __forceinline__ float l2_denominator(float ss) { return fmaxf(sqrtf(s
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// gemm.hip
+int gemm_check(const snag_gemm_desc* d);
+int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st);
+int64_t gemm_workspace_floats(int M, int N, int K);
+
 }  // namespace snag

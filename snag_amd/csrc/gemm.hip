@@ -1,0 +1,165 @@
+// snag_gemm_f32: the dense contraction behind the projections (a5), the Mformer linears (a2-a4),
+// their backward passes, and (with the distance epilogue in eval.hip) the similarity GEMM (a8).
+#include <algorithm>
+
+#include "gemm.hip.h"
+
+namespace snag {
+
+struct Epilogue {
+    float* C;
+    int64_t ldc;
+    const float* bias;      // [N]
+    float alpha;
+    int act;                // 0 none, 1 relu, 2 gelu(erf), 3 v *= gelu'(aux), 4 v *= (aux > 0)
+    const float* aux;       // [M,N] ld = ldaux, for act 3/4 (backward through an activation)
+    int64_t ldaux;
+    float* pre;             // optional copy of alpha*acc + bias (before activation), same ld as C
+    const uint8_t* mask;    // optional keep mask [M, N] dense (ld = N)
+    float mscale;
+    const float* add1;
+    int64_t ld1;
+    const float* add2;
+    int64_t ld2;
+    int accumulate;         // C += result instead of C = result
+    int M, N;
+
+    __device__ __forceinline__ void operator()(int m, int n, float v) const {
+        if (m >= M || n >= N) return;
+        v *= alpha;
+        if (bias) v += bias[n];
+        if (pre) pre[(int64_t)m * ldc + n] = v;
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        else if (act == 3) {
+            const float u = aux[(int64_t)m * ldaux + n];
+            // d/du [0.5 u (1 + erf(u/sqrt2))] = 0.5 (1 + erf(u/sqrt2)) + u exp(-u^2/2) / sqrt(2 pi)
+            v *= 0.5f * (1.0f + erff(u * 0.70710678118654752440f)) + u * expf(-0.5f * u * u) * 0.39894228040143267794f;
+        } else if (act == 4) {
+            v = aux[(int64_t)m * ldaux + n] > 0.f ? v : 0.f;
+        }
+        if (mask) v = mask[(int64_t)m * N + n] ? v * mscale : 0.f;
+        if (add1) v += add1[(int64_t)m * ld1 + n];
+        if (add2) v += add2[(int64_t)m * ld2 + n];
+        float* c = C + (int64_t)m * ldc + n;
+        *c = accumulate ? *c + v : v;
+    }
+};
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperands p, Epilogue epi, float* __restrict__ slab) {
+    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC>;
+    __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    Core core;
+    core.run(p, smem, m0, n0, kbeg, kend);
+    if (slab == nullptr) {
+        core.for_each(smem, m0, n0, epi);
+    } else {
+        float* s = slab + (int64_t)blockIdx.z * p.M * p.N;
+        const int M = p.M, N = p.N;
+        core.for_each(smem, m0, n0, [=](int m, int n, float v) {
+            if (m < M && n < N) s[(int64_t)m * N + n] = v;
+        });
+    }
+}
+
+// sums the split-K slabs in slab order (deterministic) and applies the epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, Epilogue epi) {
+    const int64_t total = (int64_t)epi.M * epi.N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += slab[(int64_t)z * total + i];
+        epi((int)(i / epi.N), (int)(i % epi.N), v);
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_cfg(const GemmOperands& p, const Epilogue& e, float* slab, int splits, bool a_kc, bool b_kc, hipStream_t st) {
+    dim3 grid(ceil_div(p.N, BN), ceil_div(p.M, BM), splits), block(256);
+#define SNAG_GEMM(AK, BK_)                                                                               \
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, AK, BK_>), grid, block, 0, st, p, e, slab)
+    if (a_kc && b_kc) SNAG_GEMM(true, true);
+    else if (a_kc && !b_kc) SNAG_GEMM(true, false);
+    else if (!a_kc && b_kc) SNAG_GEMM(false, true);
+    else SNAG_GEMM(false, false);
+#undef SNAG_GEMM
+}
+
+int64_t gemm_workspace_floats(int M, int N, int K) {
+    // worst case the heuristic below can ask for
+    const int64_t tiles = (int64_t)ceil_div(M, 64) * ceil_div(N, 128);
+    if (tiles >= 128 || K <= 4 * kBK) return 0;
+    int splits = (int)std::min<int64_t>(512 / tiles, (int64_t)ceil_div(K, 2 * kBK));
+    return splits > 1 ? (int64_t)splits * M * N : 0;
+}
+
+int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
+    GemmOperands p;
+    p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb; p.M = d->M; p.N = d->N; p.K = d->K;
+    p.a_vec = (d->lda % 4 == 0) && (((uintptr_t)d->A & 15) == 0);
+    p.b_vec = (d->ldb % 4 == 0) && (((uintptr_t)d->B & 15) == 0);
+    Epilogue e;
+    e.C = d->C; e.ldc = d->ldc; e.bias = d->bias; e.alpha = d->alpha; e.act = d->act; e.pre = d->pre_act;
+    e.mask = d->keep_mask; e.mscale = d->keep_scale; e.add1 = d->add1; e.ld1 = d->ld1; e.add2 = d->add2; e.ld2 = d->ld2;
+    e.accumulate = d->accumulate; e.M = d->M; e.N = d->N; e.aux = d->aux; e.ldaux = d->ldaux;
+
+    // tile choice: 128x128 when that already fills the chip, else 64x128 for twice the blocks
+    const int64_t big_tiles = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128);
+    const bool big = big_tiles >= 512;
+    const int64_t tiles = big ? big_tiles : (int64_t)ceil_div(p.M, 64) * ceil_div(p.N, 128);
+    // split K when the output alone cannot fill 256 CUs (the dW = dY^T X shapes: tiny output, long K)
+    int splits = 1;
+    if (d->workspace != nullptr && tiles < 128 && p.K > 4 * kBK) {
+        splits = (int)std::min<int64_t>(512 / tiles, (int64_t)ceil_div(p.K, 2 * kBK));
+        const int64_t cap = d->workspace_floats / ((int64_t)p.M * p.N);
+        if (splits > cap) splits = (int)cap;
+        if (splits < 1) splits = 1;
+    }
+    const int kps = ceil_div(ceil_div(p.K, splits), kBK) * kBK;
+    splits = ceil_div(p.K, kps);
+    p.k_per_split = kps;
+    float* slab = splits > 1 ? d->workspace : nullptr;
+    if (big) launch_cfg<128, 128, 64, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
+    else launch_cfg<64, 128, 32, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
+    int rc = check_launch("snag_gemm_f32");
+    if (rc) return rc;
+    if (splits > 1) {
+        const int64_t total = (int64_t)p.M * p.N;
+        const int blocks = (int)std::min<int64_t>(2048, (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, splits, e);
+        rc = check_launch("snag_gemm_f32(split-K reduce)");
+    }
+    return rc;
+}
+
+int gemm_check(const snag_gemm_desc* d) {
+    SNAG_REQUIRE(d != nullptr, SNAG_ERR_ARG, "gemm: null descriptor");
+    SNAG_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, SNAG_ERR_ARG, "gemm: negative size M=%d N=%d K=%d", d->M, d->N, d->K);
+    if (d->M == 0 || d->N == 0) return SNAG_OK;
+    SNAG_REQUIRE(d->C != nullptr, SNAG_ERR_ARG, "gemm: null C");
+    SNAG_REQUIRE(d->K == 0 || (d->A && d->B), SNAG_ERR_ARG, "gemm: null A or B");
+    SNAG_REQUIRE(d->ldc >= d->N, SNAG_ERR_ARG, "gemm: ldc=%ld < N=%d", (long)d->ldc, d->N);
+    SNAG_REQUIRE(d->lda >= (d->a_kcontig ? d->K : d->M), SNAG_ERR_ARG, "gemm: lda=%ld too small", (long)d->lda);
+    SNAG_REQUIRE(d->ldb >= (d->b_kcontig ? d->K : d->N), SNAG_ERR_ARG, "gemm: ldb=%ld too small", (long)d->ldb);
+    SNAG_REQUIRE(d->act >= 0 && d->act <= 4, SNAG_ERR_ARG, "gemm: act=%d unknown", d->act);
+    SNAG_REQUIRE(d->act < 3 || (d->aux && d->ldaux >= d->N), SNAG_ERR_ARG, "gemm: act=%d needs aux [M,N]", d->act);
+    SNAG_REQUIRE(!d->add1 || d->ld1 >= d->N, SNAG_ERR_ARG, "gemm: ld1 too small");
+    SNAG_REQUIRE(!d->add2 || d->ld2 >= d->N, SNAG_ERR_ARG, "gemm: ld2 too small");
+    return SNAG_OK;
+}
+
+}  // namespace snag
+
+using namespace snag;
+
+extern "C" SNAG_API int snag_gemm_f32(const snag_gemm_desc* d, void* stream) {
+    int rc = gemm_check(d);
+    if (rc) return rc;
+    if (d->M == 0 || d->N == 0) return SNAG_OK;
+    return gemm_dispatch(d, (hipStream_t)stream);
+}
+
+extern "C" SNAG_API int64_t snag_gemm_workspace_floats(int M, int N, int K) { return gemm_workspace_floats(M, N, K); }

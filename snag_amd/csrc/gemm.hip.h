@@ -1,0 +1,203 @@
+// Exact-fp32 MFMA GEMM core (v_mfma_f32_32x32x2_f32: bitwise a k-ordered fmaf chain, 157 TFLOP/s peak).
+//
+//   C[m,n] = epilogue( sum_k A(m,k) * B(n,k) )
+//
+// Each operand is either "K-contiguous" (element (r,k) at ptr[r*ld + k]: activations [rows,K],
+// nn.Linear weights W[out,in]) or "row-contiguous" (element (r,k) at ptr[k*ld + r]: the transposed
+// uses in the backward GEMMs).  Both land in LDS k-major (tile[k][row]) so that an MFMA operand
+// fetch is one conflict-free ds_read_b32 per lane; K-contiguous operands are transposed on the
+// way in (row stride = tile + 2 makes the four ds_write_b32 of a float4 conflict-free).
+// 256 threads = 4 waves in a 2x2 grid, double-buffered LDS, global loads for tile t+1 in flight
+// while tile t feeds the matrix pipe.
+#pragma once
+#include "common.hip.h"
+
+namespace snag {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kBK = 16;
+
+struct GemmOperands {
+    const float* A;
+    const float* B;
+    int64_t lda, ldb;
+    int M, N, K;
+    int a_vec, b_vec;    // 16-byte loads legal for this operand (base and ld aligned)
+    int k_per_split;     // K range handled by one blockIdx.z (multiple of kBK); == K rounded up when no split
+};
+
+// --- global -> register staging ---------------------------------------------------------------
+// One "slot" is a float4: along k for K-contiguous operands, along the row index otherwise.
+template <int BR, bool KC>
+struct Stager {
+    static constexpr int SLOTS = BR * kBK / 4 / 256;   // float4 per thread per tile
+    static_assert(BR * kBK % 1024 == 0, "tile must split evenly over 256 threads");
+    float4 r[SLOTS];
+
+    __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int vec_ok, int row0, int nrows, int k0,
+                                         int kend, int tid) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int slot = tid + 256 * s;
+            int row, k;
+            if (KC) {
+                row = row0 + slot / (kBK / 4);
+                k = k0 + (slot % (kBK / 4)) * 4;
+            } else {
+                row = row0 + (slot % (BR / 4)) * 4;
+                k = k0 + slot / (BR / 4);
+            }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KC) {
+                if (row < nrows) {
+                    const float* g = P + (int64_t)row * ld + k;
+                    if (vec_ok && k + 3 < kend) {
+                        v = *reinterpret_cast<const float4*>(g);
+                    } else {
+                        if (k + 0 < kend) v.x = g[0];
+                        if (k + 1 < kend) v.y = g[1];
+                        if (k + 2 < kend) v.z = g[2];
+                        if (k + 3 < kend) v.w = g[3];
+                    }
+                }
+            } else {
+                if (k < kend) {
+                    const float* g = P + (int64_t)k * ld + row;
+                    if (vec_ok && row + 3 < nrows) {
+                        v = *reinterpret_cast<const float4*>(g);
+                    } else {
+                        if (row + 0 < nrows) v.x = g[0];
+                        if (row + 1 < nrows) v.y = g[1];
+                        if (row + 2 < nrows) v.z = g[2];
+                        if (row + 3 < nrows) v.w = g[3];
+                    }
+                }
+            }
+            r[s] = v;
+        }
+    }
+
+    // tile is k-major: tile[k * LD + row]
+    template <int LD>
+    __device__ __forceinline__ void store(float* __restrict__ tile, int tid) const {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int slot = tid + 256 * s;
+            if (KC) {
+                const int row = slot / (kBK / 4);
+                const int k = (slot % (kBK / 4)) * 4;
+                tile[(k + 0) * LD + row] = r[s].x;
+                tile[(k + 1) * LD + row] = r[s].y;
+                tile[(k + 2) * LD + row] = r[s].z;
+                tile[(k + 3) * LD + row] = r[s].w;
+            } else {
+                const int row = (slot % (BR / 4)) * 4;
+                const int k = slot / (BR / 4);
+                *reinterpret_cast<float4*>(tile + k * LD + row) = r[s];
+            }
+        }
+    }
+};
+
+template <int BR, bool KC>
+struct TileLd {
+    static constexpr int value = KC ? BR + 2 : BR + 4;
+};
+
+// Main loop.  acc[mi][ni] is the 32x32 tile (mi, ni) of this wave's WM x WN patch:
+//   row = wm0 + 32*mi + (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5),  col = wn0 + 32*ni + (lane & 31).
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+struct GemmCore {
+    static constexpr int TM = WM / 32, TN = WN / 32;
+    static constexpr int LDA = TileLd<BM, A_KC>::value, LDB = TileLd<BN, B_KC>::value;
+    static constexpr int TILE_FLOATS = 2 * kBK * (LDA + LDB);
+    static constexpr int STAGE_FLOATS = 4 * 32 * WN;   // epilogue staging, 32 rows x WN per wave
+    static constexpr int SMEM_FLOATS = TILE_FLOATS > STAGE_FLOATS ? TILE_FLOATS : STAGE_FLOATS;
+    static_assert((BM / WM) * (BN / WN) == 4, "four waves per block");
+
+    f32x16 acc[TM][TN];
+
+    __device__ __forceinline__ void run(const GemmOperands& p, float* __restrict__ smem, int m0, int n0, int kbeg, int kend) {
+        const int tid = threadIdx.x;
+        const int lane = tid & 63;
+        const int wave = wave_id_uniform();
+        const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
+        float* As[2] = {smem, smem + kBK * LDA};
+        float* Bs[2] = {smem + 2 * kBK * LDA, smem + 2 * kBK * LDA + kBK * LDB};
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        Stager<BM, A_KC> sa;
+        Stager<BN, B_KC> sb;
+        const int nk = (kend - kbeg + kBK - 1) / kBK;
+        if (nk <= 0) return;
+        sa.load(p.A, p.lda, p.a_vec, m0, p.M, kbeg, kend, tid);
+        sb.load(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, kend, tid);
+        sa.template store<LDA>(As[0], tid);
+        sb.template store<LDB>(Bs[0], tid);
+        __syncthreads();
+        const int li = lane & 31, lh = lane >> 5;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) {
+                sa.load(p.A, p.lda, p.a_vec, m0, p.M, kbeg + (kt + 1) * kBK, kend, tid);
+                sb.load(p.B, p.ldb, p.b_vec, n0, p.N, kbeg + (kt + 1) * kBK, kend, tid);
+            }
+            const float* a = As[cur] + lh * LDA + wm0 + li;
+            const float* b = Bs[cur] + lh * LDB + wn0 + li;
+#pragma unroll
+            for (int s = 0; s < kBK / 2; ++s) {
+                float av[TM], bv[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[i] = a[2 * s * LDA + 32 * i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[j] = b[2 * s * LDB + 32 * j];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < nk) {
+                sa.template store<LDA>(As[cur ^ 1], tid);
+                sb.template store<LDB>(Bs[cur ^ 1], tid);
+            }
+            __syncthreads();
+        }
+    }
+
+    // Visit every element of the block tile: f(row, col, value).  The accumulators take a trip through
+    // LDS (the tile buffers are free by now) so that a wave hands f() whole 256-byte row segments:
+    // lane = column, which makes the epilogue's loads and the C store fully coalesced and keeps the
+    // accumulator indices static (a runtime-indexed f32x16 would be demoted to scratch).
+    template <class F>
+    __device__ __forceinline__ void for_each(float* __restrict__ smem, int m0, int n0, F&& f) const {
+        static_assert(WN == 64, "one lane per column of the wave patch");
+        static_assert(4 * 32 * WN <= SMEM_FLOATS, "staging fits in the tile buffers");
+        const int lane = threadIdx.x & 63;
+        const int wave = wave_id_uniform();
+        const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
+        float* stage = smem + wave * (32 * WN);
+        const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    stage[((e & 3) + 8 * (e >> 2) + 4 * lh) * WN + 32 * j + li] = acc[i][j][e];
+            __syncthreads();
+            const int row0 = m0 + wm0 + 32 * i;
+            const int col = n0 + wn0 + lane;
+            for (int r = 0; r < 32; ++r) f(row0 + r, col, stage[r * WN + lane]);
+        }
+    }
+};
+
+}  // namespace snag

@@ -93,3 +93,64 @@ def reduce_sum(x):
     out = torch.empty((), device=x.device, dtype=f32)
     call("snag_reduce_sum", ptr(x), x.numel(), ptr(out), stream())
     return out
+
+
+ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "gelu_grad": 3, "relu_grad": 4}
+
+
+def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, alpha=1.0, act=None, want_pre_act=False,
+         keep_mask=None, keep_p=0.0, add1=None, add2=None, out=None, accumulate=False, splitk=True, aux=None):
+    """C = add1 + add2 + keep * act(alpha * A.B + bias)   (C ABI: snag_gemm_f32; exact-f32 MFMA).
+
+    a: [M,K] if a_kcontig else [K,M];  b: [N,K] if b_kcontig else [K,N]  (2-D, last dim contiguous,
+    row stride free).  Returns C [M,N] (and the pre-activation when want_pre_act).
+    """
+    for t, nm in ((a, "a"), (b, "b")):
+        if not (torch.is_tensor(t) and t.is_cuda and t.dtype == f32 and t.dim() == 2 and t.stride(1) == 1):
+            raise ValueError(f"gemm: {nm} must be a 2-D fp32 CUDA tensor with unit inner stride")
+    M, K = (a.shape if a_kcontig else (a.shape[1], a.shape[0]))
+    N, Kb = (b.shape if b_kcontig else (b.shape[1], b.shape[0]))
+    if K != Kb:
+        raise ValueError(f"gemm: inner sizes differ ({K} vs {Kb})")
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=f32)
+    if tuple(out.shape) != (M, N) or out.stride(1) != 1:
+        raise ValueError("gemm: out has the wrong shape")
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.a_kcontig, d.b_kcontig = int(a_kcontig), int(b_kcontig)
+    d.A, d.lda = ptr(a), a.stride(0)
+    d.B, d.ldb = ptr(b), b.stride(0)
+    d.C, d.ldc = ptr(out), out.stride(0)
+    d.bias = ptr(_chk(bias, "bias", ndim=1)) if bias is not None else None
+    d.alpha = float(alpha)
+    d.act = ACT[act]
+    pre = None
+    if want_pre_act:
+        pre = torch.empty_strided((M, N), (out.stride(0), 1), device=a.device, dtype=f32)
+        d.pre_act = ptr(pre)
+    if keep_mask is not None:
+        _chk(keep_mask, "keep_mask", dtype=torch.uint8, ndim=2)
+        if tuple(keep_mask.shape) != (M, N):
+            raise ValueError("gemm: keep_mask must be [M,N]")
+        d.keep_mask, d.keep_scale = ptr(keep_mask), 1.0 / (1.0 - keep_p)
+    for nm, t in (("add1", add1), ("add2", add2)):
+        if t is not None:
+            if tuple(t.shape) != (M, N) or t.stride(1) != 1 or t.dtype != f32:
+                raise ValueError(f"gemm: {nm} must be [M,N] fp32")
+            setattr(d, nm, ptr(t))
+            setattr(d, "ld" + nm[-1], t.stride(0))
+    d.accumulate = int(accumulate)
+    if aux is not None:
+        if tuple(aux.shape) != (M, N) or aux.stride(1) != 1 or aux.dtype != f32:
+            raise ValueError("gemm: aux must be [M,N] fp32")
+        d.aux, d.ldaux = ptr(aux), aux.stride(0)
+    ws = None
+    if splitk:
+        nws = _lib.load().snag_gemm_workspace_floats(M, N, K)
+        if nws:
+            ws = torch.empty(nws, device=a.device, dtype=f32)
+            d.workspace, d.workspace_floats = ptr(ws), nws
+    import ctypes
+    call("snag_gemm_f32", ctypes.byref(d), stream())
+    return (out, pre) if want_pre_act else out
