@@ -111,6 +111,77 @@ typedef struct snag_gemm_desc {
 SNAG_API int snag_gemm_f32(const snag_gemm_desc* desc, void* stream);
 SNAG_API int64_t snag_gemm_workspace_floats(int M, int N, int K);
 
+/* ------------------------------------------------------------------------------------------
+ * a1-a4, a9  Mformer modality fusion.
+ * Replaces MformerFusion.forward (model/SNAG_tools.py:32-51) and the BertLayer stack under it
+ * (BertSelfAttention :178-209, BertSelfOutput :218-222, BertIntermediate/BertOutput :244-266,
+ * BertLayer :279-298), plus their autograd.  Tokens arrive stacked: x0[n, m, :] is what
+ * torch.stack(embs, dim=1) (:36) would hold after the None entries are dropped.
+ *
+ * Per layer the HOST-side array `layers[l]` carries device pointers to the parameters in the
+ * reference's state_dict layout (query/key/value stacked row-wise into wqkv [3D,D], bqkv [3D]) and
+ * the optional inverted-dropout keep masks of that layer (NULL = eval mode / no dropout):
+ * keep_probs [N,H,M,M] (:201), keep_attn_out [N*M,D] (:220), keep_ffn_out [N*M,D] (:264).
+ *
+ * Outputs: hidden [N,M,D]; joint, joint_fz [N, M*D]; weight_norm [N,M]  (any of the last three may
+ * be NULL to skip them).  `save` receives the activations the backward needs; `work` is scratch.
+ * Sizes: snag_fusion_save_floats / snag_fusion_work_floats.  M <= 6, D <= 512, D % H == 0.
+ */
+typedef struct snag_fusion_layer {
+    const float *wqkv, *bqkv;
+    const float *wo, *bo;
+    const float *ln1_g, *ln1_b;
+    const float *w1, *b1;          /* intermediate.dense [I,D],[I]   (use_intermediate only) */
+    const float *w2, *b2;          /* output.dense [D,I],[D] */
+    const float *ln2_g, *ln2_b;    /* output.LayerNorm */
+    const uint8_t *keep_probs, *keep_attn_out, *keep_ffn_out;
+} snag_fusion_layer;
+
+typedef struct snag_fusion_layer_grad {
+    float *wqkv, *bqkv, *wo, *bo, *ln1_g, *ln1_b, *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;
+} snag_fusion_layer_grad;
+
+typedef struct snag_fusion_desc {
+    int32_t N, M, D, H, I, L, use_intermediate;
+    float drop_p;
+    const snag_fusion_layer* layers;      /* host array [L] */
+    const float* weight_raw;              /* [6] */
+    const float* x0;                      /* [N,M,D] */
+    float *joint, *joint_fz, *hidden, *weight_norm;
+    float* save; int64_t save_floats;
+    float* work; int64_t work_floats;
+} snag_fusion_desc;
+
+SNAG_API int64_t snag_fusion_save_floats(int N, int M, int D, int H, int I, int L, int use_intermediate);
+SNAG_API int64_t snag_fusion_work_floats(int N, int M, int D, int H, int I, int L, int use_intermediate);
+SNAG_API int snag_fusion_fwd(const snag_fusion_desc* desc, void* stream);
+
+/* Backward.  `f` is the forward's descriptor (same save buffer, still holding the forward's
+ * activations; f.hidden etc. are not read).  Upstream gradients d_* may each be NULL (= zero).
+ * d_x0 [N,M,D] is overwritten; parameter gradients are overwritten (accumulate = 0) or added to.
+ * Deterministic: every cross-row reduction uses fixed-order partial sums, no atomics.
+ */
+typedef struct snag_fusion_bwd_desc {
+    snag_fusion_desc f;
+    const float *d_joint, *d_joint_fz, *d_hidden, *d_weight_norm;
+    float* d_x0;
+    const snag_fusion_layer_grad* grads;  /* host array [L] */
+    float* d_weight_raw;                  /* [6] */
+    int32_t accumulate;
+} snag_fusion_bwd_desc;
+
+SNAG_API int snag_fusion_bwd(const snag_fusion_bwd_desc* desc, void* stream);
+
+/* torch.stack(embs, dim=1) for up to 6 [N,D] tensors (emb[m] = src[m]) with the entity-noise blend of
+ * model/SNAG_tools.py:127-128 folded into slot g_slot when noise != NULL:
+ *   out[n,g,:] = (1 - a) e + a noise[n,:] for rows with noise_mask[n] != 0, a = mask_ratio / 2. */
+SNAG_API int snag_pack_tokens(const float* const* src_host, int M, int64_t N, int D, int g_slot,
+                              const float* noise, const uint8_t* noise_mask, float half_mask_ratio,
+                              float* out, void* stream);
+
+/* README joint_way "Mformer_hd_mean": out[n,:] = mean_m hidden[n,m,:]  (a9; parity unpinned). */
+SNAG_API int snag_token_mean(const float* hidden, int64_t N, int M, int D, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,15 +31,46 @@ class GemmDesc(_c.Structure):
                 ("aux", _P), ("ldaux", _L)]
 
 
+class FusionLayer(_c.Structure):
+    """struct snag_fusion_layer."""
+    _fields_ = [(n, _P) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b",
+                                  "keep_probs", "keep_attn_out", "keep_ffn_out")]
+
+
+class FusionLayerGrad(_c.Structure):
+    """struct snag_fusion_layer_grad."""
+    _fields_ = [(n, _P) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b")]
+
+
+class FusionDesc(_c.Structure):
+    """struct snag_fusion_desc."""
+    _fields_ = [("N", _c.c_int32), ("M", _c.c_int32), ("D", _c.c_int32), ("H", _c.c_int32), ("I", _c.c_int32),
+                ("L", _c.c_int32), ("use_intermediate", _c.c_int32), ("drop_p", _F),
+                ("layers", _c.POINTER(FusionLayer)), ("weight_raw", _P), ("x0", _P),
+                ("joint", _P), ("joint_fz", _P), ("hidden", _P), ("weight_norm", _P),
+                ("save", _P), ("save_floats", _L), ("work", _P), ("work_floats", _L)]
+
+
+class FusionBwdDesc(_c.Structure):
+    """struct snag_fusion_bwd_desc."""
+    _fields_ = [("f", FusionDesc), ("d_joint", _P), ("d_joint_fz", _P), ("d_hidden", _P), ("d_weight_norm", _P),
+                ("d_x0", _P), ("grads", _c.POINTER(FusionLayerGrad)), ("d_weight_raw", _P), ("accumulate", _c.c_int32)]
+
+
 # name -> argtypes; every entry returns int (0 = enqueued) except the two listed in _SPECIAL
 SIGNATURES = {
     "snag_score_margin_fwd": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _P, _P, _P, _P],
     "snag_score_margin_bwd": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P],
     "snag_reduce_sum": [_P, _L, _P, _P],
     "snag_gemm_f32": [_c.POINTER(GemmDesc), _P],
+    "snag_fusion_fwd": [_c.POINTER(FusionDesc), _P],
+    "snag_fusion_bwd": [_c.POINTER(FusionBwdDesc), _P],
+    "snag_pack_tokens": [_c.POINTER(_P), _I, _L, _I, _I, _P, _P, _F, _P, _P],
+    "snag_token_mean": [_P, _L, _I, _I, _P, _P],
 }
 _SPECIAL = {"snag_version": ([], _I), "snag_last_error": ([], _c.c_char_p),
-            "snag_gemm_workspace_floats": ([_I, _I, _I], _L)}
+            "snag_gemm_workspace_floats": ([_I, _I, _I], _L),
+            "snag_fusion_save_floats": ([_I] * 7, _L), "snag_fusion_work_floats": ([_I] * 7, _L)}
 
 _lib = None
 

@@ -1,0 +1,377 @@
+// snag_fusion_fwd / snag_fusion_bwd: host-side orchestration of the Mformer layer stack on one stream.
+// reference: MformerFusion.forward model/SNAG_tools.py:32-51, BertLayer :279-298.
+#include <algorithm>
+
+#include "fusion_kernels.hip.h"
+
+namespace snag {
+
+// ---- activation layout inside `save` (identical in forward and backward) ----------------------
+struct LayerSave {
+    float *qkv, *probs, *ctx, *t1, *st1, *y1, *u, *g, *t2, *st2, *y2;
+};
+
+struct SaveLayout {
+    int64_t per_layer;
+    int64_t NM, D, I, PP;
+    bool ffn;
+    SaveLayout(int N, int M, int D_, int H, int I_, bool ffn_) : NM((int64_t)N * M), D(D_), I(I_), PP((int64_t)N * H * M * M), ffn(ffn_) {
+        per_layer = NM * 3 * D + PP + NM * D /*ctx*/ + NM * D /*t1*/ + NM * 2 + NM * D /*y1*/;
+        if (ffn) per_layer += 2 * NM * I + NM * D /*t2*/ + NM * 2 + NM * D /*y2*/;
+        per_layer = (per_layer + 3) / 4 * 4;
+    }
+    LayerSave at(float* base, int l) const {
+        LayerSave s{};
+        float* p = base + per_layer * l;
+        s.qkv = p; p += NM * 3 * D;
+        s.ctx = p; p += NM * D;
+        s.t1 = p; p += NM * D;
+        s.y1 = p; p += NM * D;
+        if (ffn) {
+            s.u = p; p += NM * I;
+            s.g = p; p += NM * I;
+            s.t2 = p; p += NM * D;
+            s.y2 = p; p += NM * D;
+            s.st2 = p; p += NM * 2;
+        }
+        s.st1 = p; p += NM * 2;
+        s.probs = p;
+        return s;
+    }
+};
+
+static int pick_nu(int D) { return D <= 128 ? 2 : (D <= 320 ? 5 : 8); }
+
+// dispatch a kernel template<int M, int NU> over runtime (M, D)
+#define SNAG_MNU_CASE(KERNEL, MM, NU, grid, st, ...) \
+    hipLaunchKernelGGL((KERNEL<MM, NU>), grid, dim3(256), 0, st, __VA_ARGS__)
+#define SNAG_MNU_M(KERNEL, NU, M, grid, st, ...)                          \
+    switch (M) {                                                          \
+        case 1: SNAG_MNU_CASE(KERNEL, 1, NU, grid, st, __VA_ARGS__); break; \
+        case 2: SNAG_MNU_CASE(KERNEL, 2, NU, grid, st, __VA_ARGS__); break; \
+        case 3: SNAG_MNU_CASE(KERNEL, 3, NU, grid, st, __VA_ARGS__); break; \
+        case 4: SNAG_MNU_CASE(KERNEL, 4, NU, grid, st, __VA_ARGS__); break; \
+        case 5: SNAG_MNU_CASE(KERNEL, 5, NU, grid, st, __VA_ARGS__); break; \
+        default: SNAG_MNU_CASE(KERNEL, 6, NU, grid, st, __VA_ARGS__); break; \
+    }
+#define SNAG_MNU(KERNEL, M, D, grid, st, ...)                                  \
+    switch (pick_nu(D)) {                                                      \
+        case 2: SNAG_MNU_M(KERNEL, 2, M, grid, st, __VA_ARGS__); break;        \
+        case 5: SNAG_MNU_M(KERNEL, 5, M, grid, st, __VA_ARGS__); break;        \
+        default: SNAG_MNU_M(KERNEL, 8, M, grid, st, __VA_ARGS__); break;       \
+    }
+#define SNAG_NU(KERNEL, D, grid, st, ...)                                                          \
+    switch (pick_nu(D)) {                                                                          \
+        case 2: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(256), 0, st, __VA_ARGS__); break;       \
+        case 5: hipLaunchKernelGGL((KERNEL<5>), grid, dim3(256), 0, st, __VA_ARGS__); break;       \
+        default: hipLaunchKernelGGL((KERNEL<8>), grid, dim3(256), 0, st, __VA_ARGS__); break;      \
+    }
+
+static snag_gemm_desc gemm_desc(int M, int N, int K, const float* A, int64_t lda, bool akc, const float* B, int64_t ldb,
+                                bool bkc, float* C, int64_t ldc) {
+    snag_gemm_desc d{};
+    d.M = M; d.N = N; d.K = K;
+    d.A = A; d.lda = lda; d.a_kcontig = akc;
+    d.B = B; d.ldb = ldb; d.b_kcontig = bkc;
+    d.C = C; d.ldc = ldc;
+    d.alpha = 1.0f;
+    return d;
+}
+
+static constexpr int kRedBlocks = 256;   // fixed partial-sum fan-in for LayerNorm / bias / weight_raw gradients
+
+static int check_fusion(const snag_fusion_desc* f) {
+    SNAG_REQUIRE(f != nullptr, SNAG_ERR_ARG, "fusion: null descriptor");
+    SNAG_REQUIRE(f->N >= 0 && f->M >= 1 && f->D >= 1 && f->H >= 1 && f->L >= 1, SNAG_ERR_ARG,
+                 "fusion: bad sizes N=%d M=%d D=%d H=%d L=%d", f->N, f->M, f->D, f->H, f->L);
+    SNAG_REQUIRE(f->M <= 6, SNAG_ERR_UNSUPPORTED, "fusion: M=%d modalities > 6", f->M);
+    SNAG_REQUIRE(f->D <= 512, SNAG_ERR_UNSUPPORTED, "fusion: hidden_size=%d > 512", f->D);
+    // same condition as the reference's assert at model/SNAG_tools.py:161
+    SNAG_REQUIRE(f->D % f->H == 0, SNAG_ERR_ARG, "fusion: hidden_size %d not divisible by num_attention_heads %d", f->D, f->H);
+    SNAG_REQUIRE(!f->use_intermediate || f->I >= 1, SNAG_ERR_ARG, "fusion: use_intermediate needs intermediate_size >= 1");
+    SNAG_REQUIRE(f->drop_p >= 0.f && f->drop_p < 1.f, SNAG_ERR_ARG, "fusion: drop_p=%g outside [0,1)", f->drop_p);
+    if (f->N == 0) return SNAG_OK;
+    SNAG_REQUIRE(f->layers && f->weight_raw && f->x0 && f->save, SNAG_ERR_ARG, "fusion: null layers / weight_raw / x0 / save");
+    const int64_t need = snag_fusion_save_floats(f->N, f->M, f->D, f->H, f->I, f->L, f->use_intermediate);
+    SNAG_REQUIRE(f->save_floats >= need, SNAG_ERR_ARG, "fusion: save buffer holds %ld floats, need %ld", (long)f->save_floats, (long)need);
+    for (int l = 0; l < f->L; ++l) {
+        const snag_fusion_layer& P = f->layers[l];
+        SNAG_REQUIRE(P.wqkv && P.bqkv && P.wo && P.bo && P.ln1_g && P.ln1_b, SNAG_ERR_ARG, "fusion: layer %d has a null attention parameter", l);
+        SNAG_REQUIRE(!f->use_intermediate || (P.w1 && P.b1 && P.w2 && P.b2 && P.ln2_g && P.ln2_b), SNAG_ERR_ARG,
+                     "fusion: layer %d has a null FFN parameter", l);
+    }
+    return SNAG_OK;
+}
+
+int fusion_fwd(const snag_fusion_desc* f, hipStream_t st) {
+    const int N = f->N, M = f->M, D = f->D, H = f->H, I = f->I;
+    const bool ffn = f->use_intermediate != 0;
+    const int64_t NM = (int64_t)N * M;
+    SNAG_REQUIRE(NM < (1LL << 31), SNAG_ERR_UNSUPPORTED, "fusion: N*M=%ld rows >= 2^31", (long)NM);
+    SNAG_REQUIRE(f->hidden != nullptr, SNAG_ERR_ARG, "fusion_fwd: null hidden output");
+    const SaveLayout lay(N, M, D, H, I, ffn);
+    const float kscale = 1.0f / (1.0f - f->drop_p);
+    const dim3 egrid((unsigned)ceil_div(N, 4)), rgrid((unsigned)ceil_div(NM, 4));
+    const float* xin = f->x0;
+    int rc;
+    for (int l = 0; l < f->L; ++l) {
+        const snag_fusion_layer& P = f->layers[l];
+        const LayerSave S = lay.at(f->save, l);
+        const bool last = (l == f->L - 1);
+        // Q,K,V = X W^T + b                                   (:183-186)
+        snag_gemm_desc g = gemm_desc((int)NM, 3 * D, D, xin, D, true, P.wqkv, D, true, S.qkv, 3 * D);
+        g.bias = P.bqkv;
+        if ((rc = gemm_dispatch(&g, st))) return rc;
+        // softmax(QK^T/sqrt(d)), dropout, P~V                   (:192-206)
+        SNAG_MNU(attn_fwd_kernel, M, D, egrid, st, (const float*)S.qkv, N, D, H, 1.0f / sqrtf((float)(D / H)), P.keep_probs, kscale, S.probs, S.ctx);
+        if ((rc = check_launch("fusion attention"))) return rc;
+        // dense + dropout + residual                            (:219-221)
+        g = gemm_desc((int)NM, D, D, S.ctx, D, true, P.wo, D, true, S.t1, D);
+        g.bias = P.bo; g.keep_mask = P.keep_attn_out; g.keep_scale = kscale; g.add1 = xin; g.ld1 = D;
+        if ((rc = gemm_dispatch(&g, st))) return rc;
+        float* y1 = (!ffn && last) ? f->hidden : S.y1;
+        SNAG_NU(ln_fwd_kernel, D, rgrid, st, (const float*)S.t1, NM, D, P.ln1_g, P.ln1_b, 1e-12f, y1, S.st1);
+        if ((rc = check_launch("fusion LayerNorm"))) return rc;
+        float* yout = y1;
+        if (ffn) {                                              // :295-298
+            g = gemm_desc((int)NM, I, D, y1, D, true, P.w1, D, true, S.g, I);
+            g.bias = P.b1; g.act = 2; g.pre_act = S.u;
+            if ((rc = gemm_dispatch(&g, st))) return rc;
+            g = gemm_desc((int)NM, D, I, S.g, I, true, P.w2, I, true, S.t2, D);
+            g.bias = P.b2; g.keep_mask = P.keep_ffn_out; g.keep_scale = kscale; g.add1 = y1; g.ld1 = D;
+            if ((rc = gemm_dispatch(&g, st))) return rc;
+            yout = last ? f->hidden : S.y2;
+            SNAG_NU(ln_fwd_kernel, D, rgrid, st, (const float*)S.t2, NM, D, P.ln2_g, P.ln2_b, 1e-12f, yout, S.st2);
+            if ((rc = check_launch("fusion LayerNorm 2"))) return rc;
+        }
+        xin = yout;
+    }
+    if (f->joint || f->joint_fz || f->weight_norm) {
+        const LayerSave S = lay.at(f->save, f->L - 1);
+        SNAG_MNU(fuse_out_fwd_kernel, M, D, egrid, st, (const float*)S.probs, f->x0, f->weight_raw, N, D, H, f->joint, f->joint_fz, f->weight_norm);
+        if ((rc = check_launch("fusion epilogue"))) return rc;
+    }
+    return SNAG_OK;
+}
+
+// ---- backward work-buffer carving --------------------------------------------------------------
+struct Work {
+    float *dA, *dB, *dC, *dqkv, *dU, *dpx, *dx0e, *part, *gemm_ws;
+    int64_t gemm_ws_floats;
+};
+
+static int64_t bwd_gemm_ws(int N, int M, int D, int I, bool ffn) {
+    const int NM = N * M;
+    int64_t w = std::max(gemm_workspace_floats(3 * D, D, NM), gemm_workspace_floats(D, D, NM));
+    if (ffn) w = std::max({w, gemm_workspace_floats(D, I, NM), gemm_workspace_floats(I, D, NM)});
+    return w;
+}
+
+static int64_t work_floats(int N, int M, int D, int H, int I, bool ffn) {
+    const int64_t NM = (int64_t)N * M;
+    int64_t w = 3 * NM * D + NM * 3 * D + (ffn ? NM * I : 0) + (int64_t)N * H * M * M + NM * D;
+    w += (int64_t)kRedBlocks * 2 * std::max(3 * D, I) + 64;
+    w += bwd_gemm_ws(N, M, D, I, ffn);
+    return (w + 3) / 4 * 4 + 64;
+}
+
+static Work carve(float* base, int N, int M, int D, int H, int I, bool ffn) {
+    const int64_t NM = (int64_t)N * M;
+    Work w{};
+    float* p = base;
+    w.dA = p; p += NM * D;
+    w.dB = p; p += NM * D;
+    w.dC = p; p += NM * D;
+    w.dqkv = p; p += NM * 3 * D;
+    if (ffn) { w.dU = p; p += NM * I; }
+    w.dx0e = p; p += NM * D;
+    w.dpx = p; p += (int64_t)N * H * M * M;
+    p += (4 - ((p - base) & 3)) & 3;
+    w.part = p; p += (int64_t)kRedBlocks * 2 * std::max(3 * D, I) + 64;
+    p += (4 - ((p - base) & 3)) & 3;
+    w.gemm_ws = p;
+    w.gemm_ws_floats = bwd_gemm_ws(N, M, D, I, ffn);
+    return w;
+}
+
+// bias gradient: out[c] (=|+=) sum_r x[r, c]
+static int colsum(const float* x, int64_t R, int C, float* part, float* out, int accumulate, hipStream_t st) {
+    const int by = (int)std::min<int64_t>(kRedBlocks, (R + 3) / 4);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(ceil_div(C, 64), by), dim3(256), 0, st, x, R, C, (int64_t)C, part);
+    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float*)part, by, (int64_t)C, C, out, accumulate);
+    return check_launch("fusion bias gradient");
+}
+
+static int ln_bwd(const float* dy, const float* t, const float* stats, const float* g, int64_t R, int D, const uint8_t* keep,
+                  float kscale, float* dt, float* dtm, float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t st) {
+    const int blocks = (int)std::min<int64_t>(kRedBlocks, (R + 3) / 4);
+    SNAG_NU(ln_bwd_kernel, D, dim3(blocks), st, dy, t, stats, g, R, D, keep, kscale, dt, dtm, part);
+    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, st, (const float*)part, blocks, (int64_t)2 * D, D, dgamma, accumulate);
+    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, st, (const float*)part + D, blocks, (int64_t)2 * D, D, dbeta, accumulate);
+    return check_launch("fusion LayerNorm backward");
+}
+
+int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
+    const snag_fusion_desc* f = &b->f;
+    const int N = f->N, M = f->M, D = f->D, H = f->H, I = f->I, L = f->L;
+    const bool ffn = f->use_intermediate != 0;
+    const int64_t NM = (int64_t)N * M;
+    const int acc = b->accumulate;
+    const SaveLayout lay(N, M, D, H, I, ffn);
+    const Work W = carve(f->work, N, M, D, H, I, ffn);
+    const float kscale = 1.0f / (1.0f - f->drop_p);
+    const dim3 egrid((unsigned)ceil_div(N, 4));
+    int rc;
+
+    // 1. epilogue backward: joint / joint_fz / weight_norm -> d_x0 (normalise routes), dP~ (weights route), d weight_raw
+    const bool has_epi = b->d_joint || b->d_joint_fz || b->d_weight_norm;
+    const float* dpx = nullptr;
+    const float* dx0e = nullptr;
+    if (has_epi) {
+        const LayerSave S = lay.at(f->save, L - 1);
+        const int blocks = (int)std::min<int64_t>(kRedBlocks, (N + 3) / 4);
+        SNAG_MNU(fuse_out_bwd_kernel, M, D, dim3(blocks), st, (const float*)S.probs, f->x0, f->weight_raw, N, D, H, b->d_joint,
+                 b->d_joint_fz, b->d_weight_norm, W.dx0e, W.dpx, W.part);
+        if ((rc = check_launch("fusion epilogue backward"))) return rc;
+        if (b->d_weight_raw) {
+            hipLaunchKernelGGL(weight_raw_bwd_kernel, dim3(1), dim3(64), 0, st, (const float*)W.part, blocks, f->weight_raw, b->d_weight_raw, acc);
+            if ((rc = check_launch("fusion weight_raw backward"))) return rc;
+        }
+        dpx = W.dpx;
+        dx0e = W.dx0e;
+    } else if (b->d_weight_raw && !acc) {
+        if (hipMemsetAsync(b->d_weight_raw, 0, 6 * sizeof(float), st) != hipSuccess) return fail(SNAG_ERR_LAUNCH, "fusion_bwd: memset failed");
+    }
+
+    // 2. layers, last to first.  dout = gradient w.r.t. the layer's output.
+    const float* dout = b->d_hidden;
+    if (dout == nullptr) {
+        if (hipMemsetAsync(W.dC, 0, NM * D * sizeof(float), st) != hipSuccess) return fail(SNAG_ERR_LAUNCH, "fusion_bwd: memset failed");
+        dout = W.dC;
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        const snag_fusion_layer& P = f->layers[l];
+        const snag_fusion_layer_grad& G = b->grads[l];
+        const LayerSave S = lay.at(f->save, l);
+        const float* xin = (l == 0) ? f->x0 : (ffn ? lay.at(f->save, l - 1).y2 : lay.at(f->save, l - 1).y1);
+        snag_gemm_desc g;
+        if (ffn) {
+            // LN2 backward -> dA = dT2 (residual route to y1), dB = dT2 * keep (route into output.dense)
+            float* dtm = P.keep_ffn_out ? W.dB : nullptr;
+            if ((rc = ln_bwd(dout, S.t2, S.st2, P.ln2_g, NM, D, P.keep_ffn_out, kscale, W.dA, dtm, W.part, G.ln2_g, G.ln2_b, acc, st))) return rc;
+            const float* dz = dtm ? dtm : W.dA;
+            // dW2 = dz^T G ; db2 = colsum(dz)
+            g = gemm_desc(D, I, (int)NM, dz, D, false, S.g, I, false, G.w2, I);
+            g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
+            if ((rc = gemm_dispatch(&g, st))) return rc;
+            if ((rc = colsum(dz, NM, D, W.part, G.b2, acc, st))) return rc;
+            // dU = (dz W2) * gelu'(u)
+            g = gemm_desc((int)NM, I, D, dz, D, true, P.w2, I, false, W.dU, I);
+            g.act = 3; g.aux = S.u; g.ldaux = I;
+            if ((rc = gemm_dispatch(&g, st))) return rc;
+            // dW1 = dU^T y1 ; db1
+            g = gemm_desc(I, D, (int)NM, W.dU, I, false, S.y1, D, false, G.w1, D);
+            g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
+            if ((rc = gemm_dispatch(&g, st))) return rc;
+            if ((rc = colsum(W.dU, NM, I, W.part, G.b1, acc, st))) return rc;
+            // dy1 = dU W1 + dT2   -> dC
+            g = gemm_desc((int)NM, D, I, W.dU, I, true, P.w1, D, false, W.dC, D);
+            g.add1 = W.dA; g.ld1 = D;
+            if ((rc = gemm_dispatch(&g, st))) return rc;
+            dout = W.dC;
+        }
+        // LN1 backward -> dA = dT1 (residual route to the layer input), dB = dT1 * keep
+        float* dtm = P.keep_attn_out ? W.dB : nullptr;
+        if ((rc = ln_bwd(dout, S.t1, S.st1, P.ln1_g, NM, D, P.keep_attn_out, kscale, W.dA, dtm, W.part, G.ln1_g, G.ln1_b, acc, st))) return rc;
+        const float* dz = dtm ? dtm : W.dA;
+        // dWo = dz^T ctx ; dbo
+        g = gemm_desc(D, D, (int)NM, dz, D, false, S.ctx, D, false, G.wo, D);
+        g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
+        if ((rc = gemm_dispatch(&g, st))) return rc;
+        if ((rc = colsum(dz, NM, D, W.part, G.bo, acc, st))) return rc;
+        // dctx = dz Wo   -> dC  (dout is dead from here on)
+        g = gemm_desc((int)NM, D, D, dz, D, true, P.wo, D, false, W.dC, D);
+        if ((rc = gemm_dispatch(&g, st))) return rc;
+        // attention backward -> dqkv
+        SNAG_MNU(attn_bwd_kernel, M, D, egrid, st, (const float*)S.qkv, (const float*)W.dC, N, D, H, 1.0f / sqrtf((float)(D / H)), P.keep_probs,
+                 kscale, (l == L - 1) ? dpx : (const float*)nullptr, W.dqkv);
+        if ((rc = check_launch("fusion attention backward"))) return rc;
+        // dWqkv = dqkv^T xin ; dbqkv
+        g = gemm_desc(3 * D, D, (int)NM, W.dqkv, 3 * D, false, xin, D, false, G.wqkv, D);
+        g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
+        if ((rc = gemm_dispatch(&g, st))) return rc;
+        if ((rc = colsum(W.dqkv, NM, 3 * D, W.part, G.bqkv, acc, st))) return rc;
+        // d(layer input) = dqkv Wqkv + dT1 (+ epilogue route at layer 0)
+        float* dxin = (l == 0) ? b->d_x0 : W.dC;
+        g = gemm_desc((int)NM, D, 3 * D, W.dqkv, 3 * D, true, P.wqkv, D, false, dxin, D);
+        g.add1 = W.dA; g.ld1 = D;
+        if (l == 0 && dx0e) { g.add2 = dx0e; g.ld2 = D; }
+        if ((rc = gemm_dispatch(&g, st))) return rc;
+        dout = W.dC;
+    }
+    return SNAG_OK;
+}
+
+}  // namespace snag
+
+using namespace snag;
+
+extern "C" SNAG_API int64_t snag_fusion_save_floats(int N, int M, int D, int H, int I, int L, int use_intermediate) {
+    if (N < 0 || M < 1 || D < 1 || H < 1 || L < 1) return 0;
+    return SaveLayout(N, M, D, H, I, use_intermediate != 0).per_layer * L;
+}
+
+extern "C" SNAG_API int64_t snag_fusion_work_floats(int N, int M, int D, int H, int I, int L, int use_intermediate) {
+    if (N < 0 || M < 1 || D < 1 || H < 1 || L < 1) return 0;
+    return work_floats(N, M, D, H, I, use_intermediate != 0);
+}
+
+extern "C" SNAG_API int snag_fusion_fwd(const snag_fusion_desc* f, void* stream) {
+    int rc = check_fusion(f);
+    if (rc) return rc;
+    if (f->N == 0) return SNAG_OK;
+    return fusion_fwd(f, (hipStream_t)stream);
+}
+
+extern "C" SNAG_API int snag_fusion_bwd(const snag_fusion_bwd_desc* b, void* stream) {
+    SNAG_REQUIRE(b != nullptr, SNAG_ERR_ARG, "fusion_bwd: null descriptor");
+    int rc = check_fusion(&b->f);
+    if (rc) return rc;
+    if (b->f.N == 0) return SNAG_OK;
+    SNAG_REQUIRE(b->d_x0 && b->grads && b->f.work, SNAG_ERR_ARG, "fusion_bwd: null d_x0 / grads / work");
+    const int64_t need = snag_fusion_work_floats(b->f.N, b->f.M, b->f.D, b->f.H, b->f.I, b->f.L, b->f.use_intermediate);
+    SNAG_REQUIRE(b->f.work_floats >= need, SNAG_ERR_ARG, "fusion_bwd: work buffer holds %ld floats, need %ld", (long)b->f.work_floats, (long)need);
+    for (int l = 0; l < b->f.L; ++l) {
+        const snag_fusion_layer_grad& G = b->grads[l];
+        SNAG_REQUIRE(G.wqkv && G.bqkv && G.wo && G.bo && G.ln1_g && G.ln1_b, SNAG_ERR_ARG, "fusion_bwd: layer %d has a null attention gradient", l);
+        SNAG_REQUIRE(!b->f.use_intermediate || (G.w1 && G.b1 && G.w2 && G.b2 && G.ln2_g && G.ln2_b), SNAG_ERR_ARG,
+                     "fusion_bwd: layer %d has a null FFN gradient", l);
+    }
+    return fusion_bwd(b, (hipStream_t)stream);
+}
+
+extern "C" SNAG_API int snag_pack_tokens(const float* const* src_host, int M, int64_t N, int D, int g_slot, const float* noise,
+                                         const uint8_t* noise_mask, float half_mask_ratio, float* out, void* stream) {
+    SNAG_REQUIRE(src_host && out && M >= 1 && M <= 6 && N >= 0 && D >= 1, SNAG_ERR_ARG, "pack_tokens: bad arguments (M=%d)", M);
+    SNAG_REQUIRE((noise == nullptr) == (noise_mask == nullptr), SNAG_ERR_ARG, "pack_tokens: noise and noise_mask go together");
+    if (N == 0) return SNAG_OK;
+    TokenPtrs tp{};
+    for (int m = 0; m < M; ++m) {
+        SNAG_REQUIRE(src_host[m] != nullptr, SNAG_ERR_ARG, "pack_tokens: token %d is null", m);
+        tp.p[m] = src_host[m];
+    }
+    const int64_t total = N * M * (int64_t)D;
+    const int blocks = (int)std::min<int64_t>(4096, (total + 255) / 256);
+    hipLaunchKernelGGL(pack_tokens_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tp, M, N, D, g_slot, noise, noise_mask,
+                       half_mask_ratio, out);
+    return check_launch("snag_pack_tokens");
+}
+
+extern "C" SNAG_API int snag_token_mean(const float* hidden, int64_t N, int M, int D, float* out, void* stream) {
+    SNAG_REQUIRE(hidden && out && N >= 0 && M >= 1 && D >= 1, SNAG_ERR_ARG, "token_mean: bad arguments");
+    if (N == 0) return SNAG_OK;
+    const int64_t total = N * (int64_t)D;
+    const int blocks = (int)std::min<int64_t>(4096, (total + 255) / 256);
+    hipLaunchKernelGGL(token_mean_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, hidden, N, M, D, out);
+    return check_launch("snag_token_mean");
+}

@@ -1,0 +1,552 @@
+// Row-wise device kernels of the Mformer fusion (a1-a4, a9): everything between the GEMMs.
+// One wave per entity (attention, read-outs) or per token row (LayerNorm); a row of D floats is
+// spread over the wave as col = lane + 64*u, u < NU, so every load/store is a 256-byte segment.
+#pragma once
+#include "common.hip.h"
+
+namespace snag {
+
+template <int NU>
+struct Cols {
+    float v[NU];
+};
+
+template <int NU>
+__device__ __forceinline__ Cols<NU> ld_cols(const float* __restrict__ p, int D, int lane) {
+    Cols<NU> r;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int c = lane + 64 * u;
+        r.v[u] = c < D ? p[c] : 0.f;
+    }
+    return r;
+}
+
+template <int NU>
+__device__ __forceinline__ void st_cols(float* __restrict__ p, const Cols<NU>& r, int D, int lane) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int c = lane + 64 * u;
+        if (c < D) p[c] = r.v[u];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Self-attention over the M modality tokens of one entity.
+// reference: BertSelfAttention.forward, model/SNAG_tools.py:178-209
+//   S = Q K^T / sqrt(d) ; P = softmax(S) ; P~ = dropout(P) ; ctx = P~ V    (per head)
+template <int M, int NU>
+__device__ __forceinline__ void head_scores(const Cols<NU> (&q)[M], const Cols<NU> (&k)[M], int lo, int hi, int lane,
+                                            float inv_sqrt_d, float (&p)[M][M]) {
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            float part = 0.f;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int c = lane + 64 * u;
+                part += (c >= lo && c < hi) ? q[i].v[u] * k[j].v[u] : 0.f;
+            }
+            p[i][j] = sum64(part) * inv_sqrt_d;
+        }
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        float mx = p[i][0];
+#pragma unroll
+        for (int j = 1; j < M; ++j) mx = fmaxf(mx, p[i][j]);
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            p[i][j] = expf(p[i][j] - mx);
+            den += p[i][j];
+        }
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int j = 0; j < M; ++j) p[i][j] *= inv;
+    }
+}
+
+template <int M, int NU>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int N, int D, int H, float inv_sqrt_d,
+                                                       const uint8_t* __restrict__ keep, float kscale,
+                                                       float* __restrict__ probs, float* __restrict__ ctx) {
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (n >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int d = D / H;
+    Cols<NU> q[M], k[M], v[M], o[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const float* row = qkv + (n * M + i) * (int64_t)(3 * D);
+        q[i] = ld_cols<NU>(row, D, lane);
+        k[i] = ld_cols<NU>(row + D, D, lane);
+        v[i] = ld_cols<NU>(row + 2 * D, D, lane);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) o[i].v[u] = 0.f;
+    }
+    for (int h = 0; h < H; ++h) {
+        const int lo = h * d, hi = lo + d;
+        float p[M][M];
+        head_scores<M, NU>(q, k, lo, hi, lane, inv_sqrt_d, p);
+        const int64_t pbase = (n * H + h) * (int64_t)(M * M);
+        if (keep != nullptr) {
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int j = 0; j < M; ++j) p[i][j] = keep[pbase + i * M + j] ? p[i][j] * kscale : 0.f;
+        }
+        // lanes 0..M*M-1 store one probability each (select chain keeps p[][] in registers)
+        {
+            float mine = 0.f;
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int j = 0; j < M; ++j) mine = (lane == i * M + j) ? p[i][j] : mine;
+            if (lane < M * M) probs[pbase + lane] = mine;
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int c = lane + 64 * u;
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < M; ++j) acc += p[i][j] * v[j].v[u];
+                o[i].v[u] += (c >= lo && c < hi) ? acc : 0.f;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) st_cols<NU>(ctx + (n * M + i) * (int64_t)D, o[i], D, lane);
+}
+
+// backward of the above; P is recomputed from Q,K (a dropped probability still shapes the softmax
+// Jacobian, so P~ alone is not enough).  dprobs_extra is the gradient that reaches P~ through the
+// attention-derived modality weights (model/SNAG_tools.py:41-43), last layer only.
+template <int M, int NU>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx, int N,
+                                                       int D, int H, float inv_sqrt_d, const uint8_t* __restrict__ keep,
+                                                       float kscale, const float* __restrict__ dprobs_extra,
+                                                       float* __restrict__ dqkv) {
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (n >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int d = D / H;
+    Cols<NU> q[M], k[M], v[M], go[M], dq[M], dk[M], dv[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const float* row = qkv + (n * M + i) * (int64_t)(3 * D);
+        q[i] = ld_cols<NU>(row, D, lane);
+        k[i] = ld_cols<NU>(row + D, D, lane);
+        v[i] = ld_cols<NU>(row + 2 * D, D, lane);
+        go[i] = ld_cols<NU>(dctx + (n * M + i) * (int64_t)D, D, lane);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) dq[i].v[u] = dk[i].v[u] = dv[i].v[u] = 0.f;
+    }
+    for (int h = 0; h < H; ++h) {
+        const int lo = h * d, hi = lo + d;
+        float p[M][M], ds[M][M];
+        head_scores<M, NU>(q, k, lo, hi, lane, inv_sqrt_d, p);
+        const int64_t pbase = (n * H + h) * (int64_t)(M * M);
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            float dp[M];
+            float rowdot = 0.f;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                float part = 0.f;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int c = lane + 64 * u;
+                    part += (c >= lo && c < hi) ? go[i].v[u] * v[j].v[u] : 0.f;
+                }
+                float g = sum64(part);                                   // d loss / d P~[i][j] through ctx
+                if (dprobs_extra != nullptr) g += dprobs_extra[pbase + i * M + j];
+                const float km = (keep == nullptr) ? 1.f : (keep[pbase + i * M + j] ? kscale : 0.f);
+                // dV_j += P~[i][j] * dctx_i
+                const float pt = p[i][j] * km;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int c = lane + 64 * u;
+                    dv[j].v[u] += (c >= lo && c < hi) ? pt * go[i].v[u] : 0.f;
+                }
+                dp[j] = g * km;                                          // d loss / d P[i][j]
+                rowdot += dp[j] * p[i][j];
+            }
+#pragma unroll
+            for (int j = 0; j < M; ++j) ds[i][j] = p[i][j] * (dp[j] - rowdot) * inv_sqrt_d;
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int c = lane + 64 * u;
+                const bool in = (c >= lo && c < hi);
+                float aq = 0.f, ak = 0.f;
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    aq += ds[i][j] * k[j].v[u];      // dQ_i = sum_j dS_ij K_j
+                    ak += ds[j][i] * q[j].v[u];      // dK_i = sum_j dS_ji Q_j
+                }
+                dq[i].v[u] += in ? aq : 0.f;
+                dk[i].v[u] += in ? ak : 0.f;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        float* row = dqkv + (n * M + i) * (int64_t)(3 * D);
+        st_cols<NU>(row, dq[i], D, lane);
+        st_cols<NU>(row + D, dk[i], D, lane);
+        st_cols<NU>(row + 2 * D, dv[i], D, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim, eps inside the sqrt, biased variance (nn.LayerNorm(eps=1e-12)).
+// reference: model/SNAG_tools.py:215,221 and :259,265.   stats[row] = (mean, rstd)
+template <int NU>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ t, int64_t R, int D, const float* __restrict__ g,
+                                                     const float* __restrict__ b, float eps, float* __restrict__ y,
+                                                     float* __restrict__ stats) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (row >= R) return;
+    const int lane = threadIdx.x & 63;
+    const Cols<NU> x = ld_cols<NU>(t + row * D, D, lane);
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) s += x.v[u];
+    const float mean = sum64(s) / (float)D;
+    float vs = 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const float dlt = (lane + 64 * u < D) ? x.v[u] - mean : 0.f;
+        vs = fmaf(dlt, dlt, vs);
+    }
+    const float rstd = 1.0f / sqrtf(sum64(vs) / (float)D + eps);
+    const Cols<NU> gg = ld_cols<NU>(g, D, lane), bb = ld_cols<NU>(b, D, lane);
+    Cols<NU> o;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) o.v[u] = (x.v[u] - mean) * rstd * gg.v[u] + bb.v[u];
+    st_cols<NU>(y + row * D, o, D, lane);
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+// dT = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)), dxhat = dY gamma.
+// Optional second output dTm = dT * keep * kscale (gradient w.r.t. the pre-dropout dense output).
+// Per-block partial sums of dgamma/dbeta go to part[block][2][D]; a second kernel adds them in order.
+template <int NU>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ t,
+                                                     const float* __restrict__ stats, const float* __restrict__ g, int64_t R,
+                                                     int D, const uint8_t* __restrict__ keep, float kscale,
+                                                     float* __restrict__ dt, float* __restrict__ dtm, float* __restrict__ part) {
+    __shared__ float red[4][2][64 * NU];
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id_uniform();
+    const Cols<NU> gg = ld_cols<NU>(g, D, lane);
+    Cols<NU> ag, ab;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) ag.v[u] = ab.v[u] = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < R; row += (int64_t)gridDim.x * 4) {
+        const Cols<NU> x = ld_cols<NU>(t + row * D, D, lane);
+        const Cols<NU> gy = ld_cols<NU>(dy + row * D, D, lane);
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        Cols<NU> xh, dxh;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const bool in = lane + 64 * u < D;
+            xh.v[u] = in ? (x.v[u] - mean) * rstd : 0.f;
+            dxh.v[u] = gy.v[u] * gg.v[u];
+            s1 += dxh.v[u];
+            s2 = fmaf(dxh.v[u], xh.v[u], s2);
+            ag.v[u] = fmaf(gy.v[u], xh.v[u], ag.v[u]);
+            ab.v[u] += gy.v[u];
+        }
+        s1 = sum64(s1) / (float)D;
+        s2 = sum64(s2) / (float)D;
+        Cols<NU> o;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) o.v[u] = rstd * (dxh.v[u] - s1 - xh.v[u] * s2);
+        st_cols<NU>(dt + row * D, o, D, lane);
+        if (dtm != nullptr) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int c = lane + 64 * u;
+                if (c < D) dtm[row * D + c] = keep[row * D + c] ? o.v[u] * kscale : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        red[wave][0][lane + 64 * u] = ag.v[u];
+        red[wave][1][lane + 64 * u] = ab.v[u];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * 64 * NU; i += 256) {
+        const int which = i / (64 * NU), c = i % (64 * NU);
+        if (c < D) part[((int64_t)blockIdx.x * 2 + which) * D + c] = ((red[0][which][c] + red[1][which][c]) + red[2][which][c]) + red[3][which][c];
+    }
+}
+
+// out[c] (=|+=) sum over blocks of part[block][c], fixed order
+__global__ __launch_bounds__(256) void slab_colsum_kernel(const float* __restrict__ part, int nblocks, int64_t stride, int ncol,
+                                                          float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncol) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * stride + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// column sums of a [R, C] matrix (bias gradients): part[blockIdx.y][c]
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, int64_t R, int C, int64_t ld,
+                                                          float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = wave_id_uniform();
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < C)
+        for (int64_t r = (int64_t)blockIdx.y * 4 + wave; r < R; r += (int64_t)gridDim.y * 4) s += x[r * ld + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < C) part[(int64_t)blockIdx.y * C + c] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fusion epilogue.  reference: MformerFusion.forward, model/SNAG_tools.py:41-49
+//   c_j = sum_h sum_i P~[h,i,j] / sqrt(M H) ; w = softmax(c) ; joint_m = w_m nrm(x_m) ;
+//   joint_fz_m = softmax(weight_raw[0:6])_m nrm(x_m)        (x_m = the ORIGINAL token m)
+template <int M, int NU>
+__global__ __launch_bounds__(256) void fuse_out_fwd_kernel(const float* __restrict__ probs, const float* __restrict__ x0,
+                                                           const float* __restrict__ weight_raw, int N, int D, int H,
+                                                           float* __restrict__ joint, float* __restrict__ joint_fz,
+                                                           float* __restrict__ wnorm) {
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (n >= N) return;
+    const int lane = threadIdx.x & 63;
+    float w[M];
+    {
+        const float inv = 1.0f / sqrtf((float)(M * H));
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            float s = 0.f;
+            for (int h = 0; h < H; ++h)
+#pragma unroll
+                for (int i = 0; i < M; ++i) s += probs[((n * H + h) * M + i) * (int64_t)M + j];
+            w[j] = s * inv;
+            mx = fmaxf(mx, w[j]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            w[j] = expf(w[j] - mx);
+            den += w[j];
+        }
+#pragma unroll
+        for (int j = 0; j < M; ++j) w[j] /= den;
+    }
+    float wf[6];
+    {
+        float mx = -INFINITY, den = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) mx = fmaxf(mx, weight_raw[j]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            wf[j] = expf(weight_raw[j] - mx);
+            den += wf[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) wf[j] /= den;
+    }
+    if (wnorm != nullptr && lane < M) {
+        float mine = 0.f;
+#pragma unroll
+        for (int j = 0; j < M; ++j) mine = (lane == j) ? w[j] : mine;
+        wnorm[n * M + lane] = mine;
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const Cols<NU> x = ld_cols<NU>(x0 + (n * M + m) * (int64_t)D, D, lane);
+        float ss = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) ss = fmaf(x.v[u], x.v[u], ss);
+        const float inv = 1.0f / l2_denominator(sum64(ss));
+        Cols<NU> a, b;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const float xh = x.v[u] * inv;
+            a.v[u] = w[m] * xh;
+            b.v[u] = wf[m] * xh;
+        }
+        if (joint != nullptr) st_cols<NU>(joint + (n * M + m) * (int64_t)D, a, D, lane);
+        if (joint_fz != nullptr) st_cols<NU>(joint_fz + (n * M + m) * (int64_t)D, b, D, lane);
+    }
+}
+
+// backward: (d_joint, d_joint_fz, d_wnorm) -> d_x0 [N,M,D], dprobs_extra [N,H,M,M], partial d(softmax(weight_raw))
+// part[block][6] holds sum_n d_joint_fz_m . nrm(x_m) for the block's entities (zero for m >= M).
+template <int M, int NU>
+__global__ __launch_bounds__(256) void fuse_out_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ x0,
+                                                           const float* __restrict__ weight_raw, int N, int D, int H,
+                                                           const float* __restrict__ d_joint, const float* __restrict__ d_joint_fz,
+                                                           const float* __restrict__ d_wnorm, float* __restrict__ d_x0,
+                                                           float* __restrict__ dprobs_extra, float* __restrict__ part) {
+    __shared__ float red[4][6];
+    const int lane = threadIdx.x & 63, wave = wave_id_uniform();
+    float wf[6];
+    {
+        float mx = -INFINITY, den = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) mx = fmaxf(mx, weight_raw[j]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            wf[j] = expf(weight_raw[j] - mx);
+            den += wf[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) wf[j] /= den;
+    }
+    float dwf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
+        float w[M], dw[M];
+        {
+            const float inv = 1.0f / sqrtf((float)(M * H));
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                float s = 0.f;
+                for (int h = 0; h < H; ++h)
+#pragma unroll
+                    for (int i = 0; i < M; ++i) s += probs[((n * H + h) * M + i) * (int64_t)M + j];
+                w[j] = s * inv;
+                mx = fmaxf(mx, w[j]);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                w[j] = expf(w[j] - mx);
+                den += w[j];
+            }
+#pragma unroll
+            for (int j = 0; j < M; ++j) w[j] /= den;
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int64_t off = (n * M + m) * (int64_t)D;
+            Cols<NU> x = ld_cols<NU>(x0 + off, D, lane);
+            float ss = 0.f;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) ss = fmaf(x.v[u], x.v[u], ss);
+            const float den = l2_denominator(sum64(ss));
+            const float inv = 1.0f / den;
+            Cols<NU> gj, gf, dxh;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) gj.v[u] = gf.v[u] = 0.f;
+            if (d_joint != nullptr) gj = ld_cols<NU>(d_joint + off, D, lane);
+            if (d_joint_fz != nullptr) gf = ld_cols<NU>(d_joint_fz + off, D, lane);
+            float a = 0.f, b = 0.f, dot = 0.f;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                x.v[u] *= inv;                                   // xhat
+                a = fmaf(gj.v[u], x.v[u], a);                    // d w_m
+                b = fmaf(gf.v[u], x.v[u], b);                    // d wfz_m
+                dxh.v[u] = w[m] * gj.v[u] + wf[m] * gf.v[u];     // d xhat
+                dot = fmaf(dxh.v[u], x.v[u], dot);
+            }
+            a = sum64(a);
+            b = sum64(b);
+            dot = (den > 1e-12f) ? sum64(dot) : 0.f;
+            dw[m] = a + (d_wnorm != nullptr ? d_wnorm[n * M + m] : 0.f);
+            dwf[m] += b;
+            Cols<NU> o;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) o.v[u] = (dxh.v[u] - x.v[u] * dot) * inv;
+            st_cols<NU>(d_x0 + off, o, D, lane);
+        }
+        // softmax backward to c, then c_j -> every P~[h,i,j]
+        float sdot = 0.f;
+#pragma unroll
+        for (int j = 0; j < M; ++j) sdot += w[j] * dw[j];
+        const float inv = 1.0f / sqrtf((float)(M * H));
+        for (int e = lane; e < H * M * M; e += 64) {   // element e = (h, i, j), j = e % M
+            const int j = e % M;
+            float val = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < M; ++jj) val = (j == jj) ? w[jj] * (dw[jj] - sdot) * inv : val;
+            dprobs_extra[n * (int64_t)(H * M * M) + e] = val;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) red[wave][j] = dwf[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) part[(int64_t)blockIdx.x * 6 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// d weight_raw = softmax backward over the 6 raw weights (reference softmaxes all 6, SNAG_tools.py:46)
+__global__ void weight_raw_bwd_kernel(const float* __restrict__ part, int nblocks, const float* __restrict__ weight_raw,
+                                      float* __restrict__ d_weight_raw, int accumulate) {
+    if (threadIdx.x != 0) return;
+    float wf[6], g[6];
+    float mx = -INFINITY, den = 0.f;
+    for (int j = 0; j < 6; ++j) mx = fmaxf(mx, weight_raw[j]);
+    for (int j = 0; j < 6; ++j) {
+        wf[j] = expf(weight_raw[j] - mx);
+        den += wf[j];
+    }
+    float sdot = 0.f;
+    for (int j = 0; j < 6; ++j) {
+        wf[j] /= den;
+        float s = 0.f;
+        for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * 6 + j];
+        g[j] = s;
+        sdot += wf[j] * s;
+    }
+    for (int j = 0; j < 6; ++j) {
+        const float v = wf[j] * (g[j] - sdot);
+        d_weight_raw[j] = accumulate ? d_weight_raw[j] + v : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Token packing: out[n, m, :] = emb_m[n, :]  (torch.stack(embs, dim=1), model/SNAG_tools.py:36), with the
+// entity-noise blend folded into the structural slot g (model/SNAG_tools.py:127-128):
+//   e = (1 - a) e + a noise   for rows with mask, a = mask_ratio / 2.
+struct TokenPtrs {
+    const float* p[6];
+};
+
+__global__ __launch_bounds__(256) void pack_tokens_kernel(TokenPtrs src, int M, int64_t N, int D, int g_slot,
+                                                          const float* __restrict__ noise, const uint8_t* __restrict__ nmask,
+                                                          float a, float* __restrict__ out) {
+    const int64_t total = N * M * (int64_t)D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % D);
+        const int64_t nm = i / D;
+        const int m = (int)(nm % M);
+        const int64_t n = nm / M;
+        float v = src.p[m][n * D + c];
+        if (m == g_slot && nmask != nullptr && nmask[n]) v = (1.0f - a) * v + a * noise[n * D + c];
+        out[i] = v;
+    }
+}
+
+// hd_mean read-out and its backward (README joint_way "Mformer_hd_mean": hidden.mean(dim=1))
+__global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict__ hidden, int64_t N, int M, int D,
+                                                         float* __restrict__ out) {
+    const int64_t total = N * (int64_t)D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / D;
+        const int c = (int)(i % D);
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s += hidden[(n * M + m) * D + c];
+        out[i] = s / (float)M;
+    }
+}
+
+}  // namespace snag

@@ -1,0 +1,108 @@
+"""GPU parity: MformerFusion on HIP (through the C ABI) vs golden G1 (reference MformerFusion.forward + autograd)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import T, assert_close, fusion_cases, fusion_inputs, fusion_masks, load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+OUTS = ("joint", "joint_fz", "hidden", "weight_norm")
+
+
+def build_module(z, cfg, params):
+    from snag_amd.fusion import MformerFusion
+    args = types.SimpleNamespace(hidden_size=cfg["D"], num_attention_heads=cfg["H"], num_hidden_layers=cfg["L"],
+                                 use_intermediate=int(cfg["ffn"]), intermediate_size=cfg["I"])
+    mod = MformerFusion(args, modal_num=cfg["M"])
+    missing, unexpected = mod.load_state_dict({k: v.cpu() for k, v in params.items()}, strict=True), None
+    return mod.to(DEV)
+
+
+@pytest.mark.parametrize("case", fusion_cases())
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_fusion_golden(case, mode):
+    z = load(case)
+    embs, params, cfg = fusion_inputs(z)
+    mod = build_module(z, cfg, params)
+    mod.train(mode == "train")
+    embs_d = [e.to(DEV).requires_grad_(True) if e is not None else None for e in embs]
+    masks = fusion_masks(z, cfg["L"], DEV) if mode == "train" else None
+    outs = mod(embs_d, drop_masks=masks)
+    for nm, o in zip(OUTS, outs):
+        assert_close(o, z[f"{mode}.{nm}"], atol=2e-5, rtol=1e-5, what=f"{case}/{mode}/{nm}")
+    scalar = sum((o * T(z[f"cw{i}"], DEV)).sum() for i, o in enumerate(outs))
+    scalar.backward()
+    for i, e in enumerate(embs_d):
+        if e is not None:
+            assert_close(e.grad, z[f"{mode}.g.emb{i}"], atol=1e-4, rtol=1e-4, what=f"{case}/{mode}/g.emb{i}")
+    sd = dict(mod.named_parameters())
+    checked = 0
+    for k, p in sd.items():
+        key = f"{mode}.g.p.{k}"
+        if key in z:
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            ref = z[key]
+            tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+            assert_close(g, ref, atol=tol, rtol=1e-4, what=key)
+            checked += 1
+    assert checked >= 1
+
+
+def test_state_dict_keys_match_reference():
+    """SURVEY.md par. 8b: checkpoint key names (probed from the reference) are preserved."""
+    z = load("g1_fusion_m4_d128_h2_ffn.npz")
+    _, params, cfg = fusion_inputs(z)
+    from snag_amd.fusion import MformerFusion
+    args = types.SimpleNamespace(hidden_size=128, num_attention_heads=2, num_hidden_layers=1, use_intermediate=1, intermediate_size=400)
+    assert set(MformerFusion(args, 4).state_dict().keys()) == set(params.keys())
+    z = load("g1_fusion_m3_d128_h2.npz")
+    _, params, cfg = fusion_inputs(z)
+    args.use_intermediate = 0
+    mod = MformerFusion(args, 3)
+    assert set(mod.state_dict().keys()) == set(params.keys())
+    assert sum(p.numel() for p in mod.parameters()) == 117894          # SURVEY.md par. 8b
+
+
+def test_fusion_full_size_properties():
+    """Config-2 shape (N=15000, M=3, D=128, H=2): size-independent properties of the operator."""
+    from snag_amd.fusion import MformerFusion
+    torch.manual_seed(0)
+    args = types.SimpleNamespace(hidden_size=128, num_attention_heads=2, num_hidden_layers=1, use_intermediate=0, intermediate_size=400)
+    mod = MformerFusion(args, 3).to(DEV).eval()
+    N = 15000
+    embs = [torch.randn(N, 128, device=DEV) * s for s in (1.0, 0.1, 3.0)]
+    joint, joint_fz, hidden, w = mod(embs)
+    assert_close(w.sum(1), torch.ones(N), atol=1e-5)                                   # softmax rows
+    # each modality block of joint has norm w_m ; of joint_fz has norm softmax(weight_raw)_m = 1/6 at init
+    nj = joint.view(N, 3, 128).norm(dim=2)
+    assert_close(nj, w, atol=1e-5)
+    assert_close(joint_fz.view(N, 3, 128).norm(dim=2), torch.full((N, 3), 1.0 / 6), atol=1e-5)
+    # LayerNorm output with default affine: zero mean, unit (biased) variance per token
+    assert float(hidden.mean(-1).abs().max()) < 1e-4
+    assert_close(hidden.var(-1, unbiased=False), torch.ones(N, 3), atol=1e-3)
+    # entity independence: a permutation of the entities permutes every output
+    perm = torch.randperm(N, device=DEV)
+    outs2 = mod([e[perm] for e in embs])
+    for a, b in zip((joint, joint_fz, hidden, w), outs2):
+        assert torch.equal(a[perm], b)
+    # read-outs
+    mod.joint_way = "Mformer_hd_graph"
+    assert torch.equal(mod.readout(joint, joint_fz, hidden, graph_index=2), hidden[:, 2])
+    mod.joint_way = "Mformer_hd_mean"
+    assert_close(mod.readout(joint, joint_fz, hidden), hidden.mean(1), atol=1e-6)
+
+
+def test_fusion_rejects_bad_input():
+    from snag_amd.fusion import MformerFusion
+    args = types.SimpleNamespace(hidden_size=128, num_attention_heads=3, num_hidden_layers=1, use_intermediate=0, intermediate_size=400)
+    with pytest.raises(AssertionError):
+        MformerFusion(args, 3)
+    args.num_attention_heads = 2
+    mod = MformerFusion(args, 3).to(DEV)
+    with pytest.raises(ValueError):
+        mod([None, None])
+    with pytest.raises(ValueError):
+        mod([torch.zeros(4, 64, device=DEV)])
