@@ -50,10 +50,12 @@ SNAG_API const char* snag_last_error(void);
  *   neg[b,k]     = s(h[b], r[b], neg_t[b,k])
  *   loss_part[b] = sum_k relu(margin + pos[b] - neg[b,k])          (optional, may be NULL)
  *
- * ent [n_ent, dim], rel [n_rel, dim]; h, r, t [batch]; neg_t [batch, n_neg]; dim <= 512.
+ * ent [n_ent, dim] with row stride ent_ld floats (>= dim; lets the scorer read the read-out slot
+ * hidden[:, g, :] of the fusion output in place), rel [n_rel, dim] dense; h, r, t [batch];
+ * neg_t [batch, n_neg]; dim <= 512, dim % 4 == 0 and ent_ld % 4 == 0 for the forward.
  * Indices are trusted to be in range (as torch's embedding gather on device is).
  */
-SNAG_API int snag_score_margin_fwd(const float* ent, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+SNAG_API int snag_score_margin_fwd(const float* ent, int64_t ent_ld, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
                           const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
                           int64_t batch, int n_neg, float margin,
                           float* pos, float* neg, float* loss_part, void* stream);
@@ -63,13 +65,14 @@ SNAG_API int snag_score_margin_fwd(const float* ent, int64_t n_ent, const float*
  *   - hinge mode (dpos == dneg == NULL): d loss / d neg[b,k] = -grad_scale * [margin + pos - neg > 0],
  *     d loss / d pos[b] = -sum_k of those; the scores are recomputed in-kernel;
  *   - explicit mode: dpos [batch], dneg [batch, n_neg] given (grad_scale multiplies them).
- * d_ent [n_ent, dim] and d_rel [n_rel, dim] are ACCUMULATED into with fp32 atomics (caller zeroes them).
+ * d_ent [n_ent, dim] (row stride d_ent_ld) and d_rel [n_rel, dim] are ACCUMULATED into with fp32
+ * atomics (caller zeroes them).
  */
-SNAG_API int snag_score_margin_bwd(const float* ent, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+SNAG_API int snag_score_margin_bwd(const float* ent, int64_t ent_ld, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
                           const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
                           int64_t batch, int n_neg, float margin, float grad_scale,
                           const float* dpos, const float* dneg,
-                          float* d_ent, float* d_rel, void* stream);
+                          float* d_ent, int64_t d_ent_ld, float* d_rel, void* stream);
 
 /* Deterministic (fixed-order) sum of n floats into out[0]; used for the scalar loss. */
 SNAG_API int snag_reduce_sum(const float* x, int64_t n, float* out, void* stream);
@@ -181,6 +184,58 @@ SNAG_API int snag_pack_tokens(const float* const* src_host, int M, int64_t N, in
 
 /* README joint_way "Mformer_hd_mean": out[n,:] = mean_m hidden[n,m,:]  (a9; parity unpinned). */
 SNAG_API int snag_token_mean(const float* hidden, int64_t N, int M, int D, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a6  Gaussian noise-mask injection (GMNM) and its statistics.
+ * snag_colstats: per-column mean and UNBIASED std over the rows with exclude[n] == 0
+ *   (replaces SNAG.get_mean_std model/SNAG.py:77-84 and the entity stats :94-95; n_valid = number
+ *   of such rows, exclude may be NULL).  work: snag_colstats_work_floats(C) floats.  std may be NULL.
+ * snag_noise_apply: replaces SNAG.add_noise_to_embeddings model/SNAG.py:66-75 for one feature table:
+ *   out[n,:] = (1 - mask_ratio) x[n,:] + mask_ratio (mean + std * z[n,:]) where row_mask[n] != 0, else x[n,:].
+ *   Parity mode: z is the reference's compact randn_like(X[mask]) [n_sel, F] and sel_index[n] the
+ *   row of z that belongs to entity n.  Perf mode (z == sel_index == NULL): z = Philox(seed).
+ * snag_dropout_keep_mask: Bernoulli keep mask (u >= p) from Philox(seed): the row mask of :68 with
+ *   p = 1 - noise_ratio inverted by the caller, and the nn.Dropout(0.1) masks of the Bert blocks.
+ *   tick (optional device counter, see snag_tick) is mixed into the seed so that a replayed
+ *   hipGraph draws a fresh mask every step.
+ * snag_gaussian_fill: out[n,c] = mean[c] + std[c] * z, z ~ Philox(seed)  (entity_noise, :96).
+ */
+SNAG_API int64_t snag_colstats_work_floats(int C);
+SNAG_API int snag_colstats(const float* x, int64_t R, int C, const uint8_t* exclude, int64_t n_valid,
+                           float* mean, float* std_, float* work, void* stream);
+SNAG_API int snag_noise_apply(const float* x, int64_t N, int F, const float* mean, const float* std_,
+                              const uint8_t* row_mask, const int32_t* sel_index, const float* z,
+                              uint64_t seed, float mask_ratio, float* out, void* stream);
+SNAG_API int snag_dropout_keep_mask(uint64_t seed, const uint64_t* tick, int64_t n, float p, uint8_t* out, void* stream);
+SNAG_API int snag_gaussian_fill(uint64_t seed, int64_t N, int F, const float* mean, const float* std_,
+                                float* out, void* stream);
+
+/* Pieces of the projection / read-out backward that are not GEMMs.
+ * snag_colsum: out[c] (=|+=) sum_r x[r*ld + c]  (nn.Linear bias gradient), fixed-order partial sums;
+ *   work: 256*C floats.
+ * snag_token_mean_bwd: d_hidden[n,m,:] = d_out[n,:] / M  (backward of snag_token_mean).
+ * snag_entity_token_bwd: gradient of the entity table through the noise blend of
+ *   model/SNAG_tools.py:127-128: d_table[n,:] (=|+=) (noise_mask[n] ? 1 - a : 1) * d_tok[n*ld + :];
+ *   snag_entity_token_fwd is the forward blend written straight into a token slot (row stride out_ld). */
+SNAG_API int snag_colsum(const float* x, int64_t R, int C, int64_t ld, float* out, int accumulate,
+                         float* work, void* stream);
+SNAG_API int snag_token_mean_bwd(const float* d_out, int64_t N, int M, int D, float* d_hidden, void* stream);
+SNAG_API int snag_entity_token_fwd(const float* table, int64_t N, int D, const float* noise, const uint8_t* noise_mask,
+                                   float half_mask_ratio, float* out, int64_t out_ld, void* stream);
+SNAG_API int snag_entity_token_bwd(const float* d_tok, int64_t ld, int64_t N, int D, const uint8_t* noise_mask,
+                                   float half_mask_ratio, float* d_table, int accumulate, void* stream);
+
+/* torch.optim.AdamW update over one flat buffer (the reference's optimiser, src/utils.py:25-80,
+ * is out of the hot path; this only closes the benchmark's training step without leaving HIP).
+ * grad is multiplied by grad_scale first (1/world_size after a summed all-reduce). */
+SNAG_API int snag_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                             const uint64_t* tick, float grad_scale, void* stream);
+
+/* Device-resident step counter: tick[0] += 1.  When `tick` is given to snag_adamw_step the bias
+ * correction uses t = tick[0] + 1 instead of the host `step`, which lets a captured hipGraph of a
+ * whole training step be replayed without re-recording. */
+SNAG_API int snag_tick(uint64_t* tick, void* stream);
 
 #ifdef __cplusplus
 }

@@ -59,18 +59,29 @@ class FusionBwdDesc(_c.Structure):
 
 # name -> argtypes; every entry returns int (0 = enqueued) except the two listed in _SPECIAL
 SIGNATURES = {
-    "snag_score_margin_fwd": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _P, _P, _P, _P],
-    "snag_score_margin_bwd": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P],
+    "snag_score_margin_fwd": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _P, _P, _P, _P],
+    "snag_score_margin_bwd": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _L, _P, _P],
     "snag_reduce_sum": [_P, _L, _P, _P],
     "snag_gemm_f32": [_c.POINTER(GemmDesc), _P],
     "snag_fusion_fwd": [_c.POINTER(FusionDesc), _P],
     "snag_fusion_bwd": [_c.POINTER(FusionBwdDesc), _P],
     "snag_pack_tokens": [_c.POINTER(_P), _I, _L, _I, _I, _P, _P, _F, _P, _P],
     "snag_token_mean": [_P, _L, _I, _I, _P, _P],
+    "snag_colstats": [_P, _L, _I, _P, _L, _P, _P, _P, _P],
+    "snag_noise_apply": [_P, _L, _I, _P, _P, _P, _P, _P, _U64, _F, _P, _P],
+    "snag_dropout_keep_mask": [_U64, _P, _L, _F, _P, _P],
+    "snag_gaussian_fill": [_U64, _L, _I, _P, _P, _P, _P],
+    "snag_colsum": [_P, _L, _I, _L, _P, _I, _P, _P],
+    "snag_token_mean_bwd": [_P, _L, _I, _I, _P, _P],
+    "snag_entity_token_bwd": [_P, _L, _L, _I, _P, _F, _P, _I, _P],
+    "snag_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _P, _F, _P],
+    "snag_tick": [_P, _P],
+    "snag_entity_token_fwd": [_P, _L, _I, _P, _P, _F, _P, _L, _P],
 }
 _SPECIAL = {"snag_version": ([], _I), "snag_last_error": ([], _c.c_char_p),
             "snag_gemm_workspace_floats": ([_I, _I, _I], _L),
-            "snag_fusion_save_floats": ([_I] * 7, _L), "snag_fusion_work_floats": ([_I] * 7, _L)}
+            "snag_fusion_save_floats": ([_I] * 7, _L), "snag_fusion_work_floats": ([_I] * 7, _L),
+            "snag_colstats_work_floats": ([_I], _L)}
 
 _lib = None
 

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // out[c] (=|+=) sum over blocks of part[block][c], fixed order
-__global__ __launch_bounds__(256) void slab_colsum_kernel(const float* __restrict__ part, int nblocks, int64_t stride, int ncol,
+static __global__ __launch_bounds__(256) void slab_colsum_kernel(const float* __restrict__ part, int nblocks, int64_t stride, int ncol,
                                                           float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= ncol) return;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void slab_colsum_kernel(const float* __restric
 }
 
 // column sums of a [R, C] matrix (bias gradients): part[blockIdx.y][c]
-__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, int64_t R, int C, int64_t ld,
+static __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, int64_t R, int C, int64_t ld,
                                                           float* __restrict__ part) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = wave_id_uniform();
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void fuse_out_bwd_kernel(const float* __restri
 }
 
 // d weight_raw = softmax backward over the 6 raw weights (reference softmaxes all 6, SNAG_tools.py:46)
-__global__ void weight_raw_bwd_kernel(const float* __restrict__ part, int nblocks, const float* __restrict__ weight_raw,
+static __global__ void weight_raw_bwd_kernel(const float* __restrict__ part, int nblocks, const float* __restrict__ weight_raw,
                                       float* __restrict__ d_weight_raw, int accumulate) {
     if (threadIdx.x != 0) return;
     float wf[6], g[6];
@@ -521,7 +521,7 @@ struct TokenPtrs {
     const float* p[6];
 };
 
-__global__ __launch_bounds__(256) void pack_tokens_kernel(TokenPtrs src, int M, int64_t N, int D, int g_slot,
+static __global__ __launch_bounds__(256) void pack_tokens_kernel(TokenPtrs src, int M, int64_t N, int D, int g_slot,
                                                           const float* __restrict__ noise, const uint8_t* __restrict__ nmask,
                                                           float a, float* __restrict__ out) {
     const int64_t total = N * M * (int64_t)D;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void pack_tokens_kernel(TokenPtrs src, int M, 
 }
 
 // hd_mean read-out and its backward (README joint_way "Mformer_hd_mean": hidden.mean(dim=1))
-__global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict__ hidden, int64_t N, int M, int D,
+static __global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict__ hidden, int64_t N, int M, int D,
                                                          float* __restrict__ out) {
     const int64_t total = N * (int64_t)D;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {

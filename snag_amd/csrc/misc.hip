@@ -1,0 +1,297 @@
+// a6 noise-mask injection (model/SNAG.py:66-98, model/SNAG_tools.py:127-128), column statistics,
+// Philox keep-masks for the Bert dropouts, bias-gradient column sums, the hd_mean read-out backward
+// and the fused AdamW update that closes a training step.
+#include <algorithm>
+
+#include "fusion_kernels.hip.h"
+
+namespace snag {
+
+// ---- Philox4x32-10 (counter-based: element i of stream `seed` is a pure function of (seed, i)) ----
+struct Philox4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t ctr) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x5a17c0deu, c3 = 0x9e3779b9u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0,1)
+
+// four standard normals from one Philox draw (Box-Muller)
+__device__ __forceinline__ float4 normal4(uint64_t seed, uint64_t ctr) {
+    const Philox4 r = philox4x32_10(seed, ctr);
+    const float r0 = sqrtf(-2.0f * logf(u01(r.x))), r1 = sqrtf(-2.0f * logf(u01(r.z)));
+    float s0, c0, s1, c1;
+    sincosf(6.28318530717958647692f * u01(r.y), &s0, &c0);
+    sincosf(6.28318530717958647692f * u01(r.w), &s1, &c1);
+    return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
+}
+
+// keep[i] = (u >= p): the inverted-dropout keep mask of nn.Dropout(p)
+__global__ __launch_bounds__(256) void bernoulli_keep_kernel(uint64_t seed, const uint64_t* __restrict__ tick, int64_t n, float p,
+                                                             uint8_t* __restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one Philox draw = 4 elements
+    if (q * 4 >= n) return;
+    if (tick != nullptr) seed += tick[0] * 0x9E3779B97F4A7C15ull;    // a fresh stream per training step inside a replayed graph
+    const Philox4 r = philox4x32_10(seed, (uint64_t)q);
+    const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (q * 4 + e < n) out[q * 4 + e] = u01(rr[e]) >= p ? 1 : 0;
+}
+
+// out[n, c] = mean[c] + std[c] * z    (model/SNAG.py:96)
+__global__ __launch_bounds__(256) void gaussian_fill_kernel(uint64_t seed, int64_t N, int F, const float* __restrict__ mean,
+                                                            const float* __restrict__ std_, float* __restrict__ out) {
+    const int64_t total = N * (int64_t)F;
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q * 4 >= total) return;
+    const float4 z = normal4(seed, (uint64_t)q);
+    const float zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t i = q * 4 + e;
+        if (i < total) {
+            const int c = (int)(i % F);
+            out[i] = mean[c] + std_[c] * zz[e];
+        }
+    }
+}
+
+// Row-level Gaussian noise injection (model/SNAG.py:66-75):
+//   masked row: out = (1 - eps) x + eps (mean + std * z) ; other rows: out = x.
+// z comes from the caller (compact [n_sel, F], row sel_index[n]) or from Philox(seed, n*F + c).
+__global__ __launch_bounds__(256) void noise_apply_kernel(const float* __restrict__ x, int64_t N, int F,
+                                                          const float* __restrict__ mean, const float* __restrict__ std_,
+                                                          const uint8_t* __restrict__ row_mask, const int32_t* __restrict__ sel_index,
+                                                          const float* __restrict__ z, uint64_t seed, float eps,
+                                                          float* __restrict__ out) {
+    const int64_t total = N * (int64_t)F;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / F;
+        const int c = (int)(i % F);
+        float v = x[i];
+        if (row_mask[n]) {
+            float zv;
+            if (z != nullptr) {
+                zv = z[(int64_t)sel_index[n] * F + c];
+            } else {
+                const float4 g = normal4(seed, (uint64_t)(i >> 2));
+                const int e = (int)(i & 3);
+                zv = e == 0 ? g.x : (e == 1 ? g.y : (e == 2 ? g.z : g.w));
+            }
+            v = (1.0f - eps) * v + eps * (mean[c] + std_[c] * zv);
+        }
+        out[i] = v;
+    }
+}
+
+// column statistics, two passes over fixed-order partial sums; rows with exclude[n] != 0 are skipped
+__global__ __launch_bounds__(256) void colstat_part_kernel(const float* __restrict__ x, int64_t R, int C,
+                                                           const uint8_t* __restrict__ exclude, const float* __restrict__ mean,
+                                                           float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = wave_id_uniform();
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < C) {
+        const float mu = mean ? mean[c] : 0.f;
+        for (int64_t r = (int64_t)blockIdx.y * 4 + wave; r < R; r += (int64_t)gridDim.y * 4) {
+            if (exclude && exclude[r]) continue;
+            const float v = x[r * C + c];
+            s += mean ? (v - mu) * (v - mu) : v;
+        }
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < C) part[(int64_t)blockIdx.y * C + c] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+// mode 0: out = sum / n ; mode 1: out = sqrt(sum / (n - 1))
+__global__ __launch_bounds__(256) void colstat_finish_kernel(const float* __restrict__ part, int nblocks, int C, float n, int mode,
+                                                             float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * C + c];
+    out[c] = mode == 0 ? s / n : sqrtf(s / (n - 1.0f));
+}
+
+// d hidden[n, m, :] = d_out[n, :] / M
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float* __restrict__ d_out, int64_t N, int M, int D,
+                                                             float* __restrict__ d_hidden) {
+    const int64_t total = N * M * (int64_t)D;
+    const float inv = 1.0f / (float)M;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % D);
+        const int64_t n = i / ((int64_t)M * D);
+        d_hidden[i] = d_out[n * D + c] * inv;
+    }
+}
+
+// entity-table gradient through the noise blend: d_table[n,:] (=|+=) scale_n * d_tok[n,:], scale_n = 1 - a for masked rows
+__global__ __launch_bounds__(256) void scaled_rows_kernel(const float* __restrict__ d_tok, int64_t ld, int64_t N, int D,
+                                                          const uint8_t* __restrict__ nmask, float a, float* __restrict__ d_table,
+                                                          int accumulate) {
+    const int64_t total = N * (int64_t)D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / D;
+        const int c = (int)(i % D);
+        float v = d_tok[n * ld + c];
+        if (nmask != nullptr && nmask[n]) v *= (1.0f - a);
+        d_table[i] = accumulate ? d_table[i] + v : v;
+    }
+}
+
+// torch.optim.AdamW semantics (decoupled weight decay), one launch over a flat parameter buffer
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2, float gscale,
+                                                    const uint64_t* __restrict__ tick) {
+    if (tick != nullptr) {          // step number lives on the device (graph replay): t = tick + 1
+        const float t = (float)(tick[0] + 1);
+        bc1 = 1.0f - powf(b1, t);
+        bc2 = 1.0f - powf(b2, t);
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+__global__ void tick_kernel(uint64_t* tick) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) tick[0] += 1;
+}
+
+// structural token: out[n*ld + :] = blend(table[n,:])   (model/SNAG_tools.py:127-128)
+__global__ __launch_bounds__(256) void entity_token_fwd_kernel(const float* __restrict__ table, int64_t N, int D,
+                                                               const float* __restrict__ noise, const uint8_t* __restrict__ nmask,
+                                                               float a, float* __restrict__ out, int64_t ld) {
+    const int64_t total = N * (int64_t)D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / D;
+        const int c = (int)(i % D);
+        float v = table[i];
+        if (nmask != nullptr && nmask[n]) v = (1.0f - a) * v + a * noise[i];
+        out[n * ld + c] = v;
+    }
+}
+
+static int grid_for(int64_t n) { return (int)std::min<int64_t>(4096, (n + 255) / 256); }
+
+}  // namespace snag
+
+using namespace snag;
+
+extern "C" SNAG_API int snag_dropout_keep_mask(uint64_t seed, const uint64_t* tick, int64_t n, float p, uint8_t* out, void* stream) {
+    SNAG_REQUIRE(n >= 0 && (out || n == 0) && p >= 0.f && p < 1.f, SNAG_ERR_ARG, "dropout_keep_mask: bad arguments (n=%ld p=%g)", (long)n, p);
+    if (n == 0) return SNAG_OK;
+    hipLaunchKernelGGL(bernoulli_keep_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, seed, tick, n, p, out);
+    return check_launch("snag_dropout_keep_mask");
+}
+
+extern "C" SNAG_API int snag_gaussian_fill(uint64_t seed, int64_t N, int F, const float* mean, const float* std_, float* out, void* stream) {
+    SNAG_REQUIRE(N >= 0 && F >= 1 && mean && std_ && (out || N == 0), SNAG_ERR_ARG, "gaussian_fill: bad arguments");
+    if (N == 0) return SNAG_OK;
+    const int64_t total = N * (int64_t)F;
+    hipLaunchKernelGGL(gaussian_fill_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, seed, N, F, mean, std_, out);
+    return check_launch("snag_gaussian_fill");
+}
+
+extern "C" SNAG_API int snag_noise_apply(const float* x, int64_t N, int F, const float* mean, const float* std_, const uint8_t* row_mask,
+                                         const int32_t* sel_index, const float* z, uint64_t seed, float mask_ratio, float* out,
+                                         void* stream) {
+    SNAG_REQUIRE(N >= 0 && F >= 1, SNAG_ERR_ARG, "noise_apply: bad sizes");
+    if (N == 0) return SNAG_OK;
+    SNAG_REQUIRE(x && mean && std_ && row_mask && out, SNAG_ERR_ARG, "noise_apply: null pointer");
+    SNAG_REQUIRE((z == nullptr) == (sel_index == nullptr), SNAG_ERR_ARG, "noise_apply: z and sel_index go together");
+    hipLaunchKernelGGL(noise_apply_kernel, dim3(grid_for(N * (int64_t)F)), dim3(256), 0, (hipStream_t)stream, x, N, F, mean, std_, row_mask,
+                       sel_index, z, seed, mask_ratio, out);
+    return check_launch("snag_noise_apply");
+}
+
+extern "C" SNAG_API int64_t snag_colstats_work_floats(int C) { return (int64_t)256 * C; }
+
+extern "C" SNAG_API int snag_colstats(const float* x, int64_t R, int C, const uint8_t* exclude, int64_t n_valid, float* mean, float* std_,
+                                      float* work, void* stream) {
+    SNAG_REQUIRE(x && mean && work && R >= 1 && C >= 1, SNAG_ERR_ARG, "colstats: bad arguments");
+    SNAG_REQUIRE(n_valid >= 1 && n_valid <= R, SNAG_ERR_ARG, "colstats: n_valid=%ld outside [1, %ld]", (long)n_valid, (long)R);
+    hipStream_t st = (hipStream_t)stream;
+    const int by = (int)std::min<int64_t>(256, (R + 3) / 4);
+    const dim3 grid(ceil_div(C, 64), by), fgrid(ceil_div(C, 256));
+    hipLaunchKernelGGL(colstat_part_kernel, grid, dim3(256), 0, st, x, R, C, exclude, (const float*)nullptr, work);
+    hipLaunchKernelGGL(colstat_finish_kernel, fgrid, dim3(256), 0, st, (const float*)work, by, C, (float)n_valid, 0, mean);
+    if (std_ != nullptr) {
+        hipLaunchKernelGGL(colstat_part_kernel, grid, dim3(256), 0, st, x, R, C, exclude, (const float*)mean, work);
+        hipLaunchKernelGGL(colstat_finish_kernel, fgrid, dim3(256), 0, st, (const float*)work, by, C, (float)n_valid, 1, std_);
+    }
+    return check_launch("snag_colstats");
+}
+
+extern "C" SNAG_API int snag_colsum(const float* x, int64_t R, int C, int64_t ld, float* out, int accumulate, float* work, void* stream) {
+    SNAG_REQUIRE(x && out && work && R >= 0 && C >= 1 && ld >= C, SNAG_ERR_ARG, "colsum: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int by = (int)std::max<int64_t>(1, std::min<int64_t>(256, (R + 3) / 4));
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(ceil_div(C, 64), by), dim3(256), 0, st, x, R, C, ld, work);
+    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float*)work, by, (int64_t)C, C, out, accumulate);
+    return check_launch("snag_colsum");
+}
+
+extern "C" SNAG_API int snag_token_mean_bwd(const float* d_out, int64_t N, int M, int D, float* d_hidden, void* stream) {
+    SNAG_REQUIRE(d_out && d_hidden && N >= 0 && M >= 1 && D >= 1, SNAG_ERR_ARG, "token_mean_bwd: bad arguments");
+    if (N == 0) return SNAG_OK;
+    hipLaunchKernelGGL(token_mean_bwd_kernel, dim3(grid_for(N * M * (int64_t)D)), dim3(256), 0, (hipStream_t)stream, d_out, N, M, D, d_hidden);
+    return check_launch("snag_token_mean_bwd");
+}
+
+extern "C" SNAG_API int snag_entity_token_bwd(const float* d_tok, int64_t ld, int64_t N, int D, const uint8_t* noise_mask,
+                                              float half_mask_ratio, float* d_table, int accumulate, void* stream) {
+    SNAG_REQUIRE(d_tok && d_table && N >= 0 && D >= 1 && ld >= D, SNAG_ERR_ARG, "entity_token_bwd: bad arguments");
+    if (N == 0) return SNAG_OK;
+    hipLaunchKernelGGL(scaled_rows_kernel, dim3(grid_for(N * (int64_t)D)), dim3(256), 0, (hipStream_t)stream, d_tok, ld, N, D, noise_mask,
+                       half_mask_ratio, d_table, accumulate);
+    return check_launch("snag_entity_token_bwd");
+}
+
+extern "C" SNAG_API int snag_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                                        float beta2, float eps, float weight_decay, int64_t step, const uint64_t* tick, float grad_scale, void* stream) {
+    SNAG_REQUIRE(n >= 0 && (step >= 1 || tick != nullptr), SNAG_ERR_ARG, "adamw_step: n=%ld step=%ld", (long)n, (long)step);
+    if (n == 0) return SNAG_OK;
+    SNAG_REQUIRE(param && grad && exp_avg && exp_avg_sq, SNAG_ERR_ARG, "adamw_step: null pointer");
+    const float bc1 = 1.0f - powf(beta1, (float)std::max<int64_t>(step, 1)), bc2 = 1.0f - powf(beta2, (float)std::max<int64_t>(step, 1));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+                       eps, weight_decay, bc1, bc2, grad_scale, tick);
+    return check_launch("snag_adamw_step");
+}
+
+extern "C" SNAG_API int snag_tick(uint64_t* tick, void* stream) {
+    SNAG_REQUIRE(tick != nullptr, SNAG_ERR_ARG, "tick: null counter");
+    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tick);
+    return check_launch("snag_tick");
+}
+
+extern "C" SNAG_API int snag_entity_token_fwd(const float* table, int64_t N, int D, const float* noise, const uint8_t* noise_mask,
+                                              float half_mask_ratio, float* out, int64_t out_ld, void* stream) {
+    SNAG_REQUIRE(table && out && N >= 0 && D >= 1 && out_ld >= D, SNAG_ERR_ARG, "entity_token_fwd: bad arguments");
+    SNAG_REQUIRE((noise == nullptr) == (noise_mask == nullptr), SNAG_ERR_ARG, "entity_token_fwd: noise and noise_mask go together");
+    if (N == 0) return SNAG_OK;
+    hipLaunchKernelGGL(entity_token_fwd_kernel, dim3(grid_for(N * (int64_t)D)), dim3(256), 0, (hipStream_t)stream, table, N, D, noise,
+                       noise_mask, half_mask_ratio, out, out_ld);
+    return check_launch("snag_entity_token_fwd");
+}

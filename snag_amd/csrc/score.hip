@@ -18,9 +18,9 @@ struct RowV4 {
 };
 
 template <int NV>
-__device__ __forceinline__ RowV4<NV> load_row_v4(const float* __restrict__ base, int64_t row, int dim, int sub) {
+__device__ __forceinline__ RowV4<NV> load_row_v4(const float* __restrict__ base, int64_t row, int64_t ld, int dim, int sub) {
     RowV4<NV> r;
-    const float4* p = reinterpret_cast<const float4*>(base + row * (int64_t)dim);
+    const float4* p = reinterpret_cast<const float4*>(base + row * ld);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = sub + 16 * j;
@@ -60,7 +60,7 @@ __device__ __forceinline__ float score_row(const RowV4<NV>& q, const RowV4<NV>& 
 
 template <typename IdxT, int NV>
 __global__ __launch_bounds__(256) void score_fwd_kernel(
-    const float* __restrict__ ent, const float* __restrict__ rel, int dim,
+    const float* __restrict__ ent, int64_t eld, const float* __restrict__ rel, int dim,
     const IdxT* __restrict__ h, const IdxT* __restrict__ r, const IdxT* __restrict__ t,
     const IdxT* __restrict__ neg_t, int64_t batch, int n_neg, float margin,
     float* __restrict__ pos, float* __restrict__ neg, float* __restrict__ loss_part) {
@@ -71,9 +71,9 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(
     const int grp = lane >> 4;
 
     const int64_t hi = (int64_t)h[b], ri = (int64_t)r[b], ti = (int64_t)t[b];
-    RowV4<NV> q = load_row_v4<NV>(ent, hi, dim, sub);
-    RowV4<NV> rr = load_row_v4<NV>(rel, ri, dim, sub);
-    const RowV4<NV> tt = load_row_v4<NV>(ent, ti, dim, sub);
+    RowV4<NV> q = load_row_v4<NV>(ent, hi, eld, dim, sub);
+    RowV4<NV> rr = load_row_v4<NV>(rel, ri, dim, dim, sub);
+    const RowV4<NV> tt = load_row_v4<NV>(ent, ti, eld, dim, sub);
     {
         const float ih = 1.0f / l2_denominator(sum16(sumsq_v4<NV>(q)));
         const float ir = 1.0f / l2_denominator(sum16(sumsq_v4<NV>(rr)));
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(
         for (; it + 32 <= cnt; it += 32) {
             RowV4<NV> x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = load_row_v4<NV>(ent, __shfl(my, it + 4 * u + grp), dim, sub);
+            for (int u = 0; u < 8; ++u) x[u] = load_row_v4<NV>(ent, __shfl(my, it + 4 * u + grp), eld, dim, sub);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float s = score_row<NV>(q, x[u]);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(
             const int k = it + grp;
             const bool valid = k < cnt;
             const int idx = __shfl(my, k);  // all lanes take part: a bpermute from an inactive lane reads 0
-            const RowV4<NV> x = load_row_v4<NV>(ent, valid ? idx : 0, dim, sub);
+            const RowV4<NV> x = load_row_v4<NV>(ent, valid ? idx : 0, eld, dim, sub);
             const float s = score_row<NV>(q, x);
             if (valid) {
                 hinge += fmaxf(margin + s_pos - s, 0.f);
@@ -135,9 +135,9 @@ struct RowS {
 };
 
 template <int NS>
-__device__ __forceinline__ RowS<NS> load_row_s(const float* __restrict__ base, int64_t row, int dim, int lane) {
+__device__ __forceinline__ RowS<NS> load_row_s(const float* __restrict__ base, int64_t row, int64_t ld, int dim, int lane) {
     RowS<NS> r;
-    const float* p = base + row * (int64_t)dim;
+    const float* p = base + row * ld;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int c = lane + 64 * i;
@@ -179,20 +179,20 @@ __device__ __forceinline__ void normalize_bwd_atomic(const RowS<NS>& yhat, float
 
 template <typename IdxT, int NS>
 __global__ __launch_bounds__(256) void score_bwd_kernel(
-    const float* __restrict__ ent, const float* __restrict__ rel, int dim,
+    const float* __restrict__ ent, int64_t eld, const float* __restrict__ rel, int dim,
     const IdxT* __restrict__ h, const IdxT* __restrict__ r, const IdxT* __restrict__ t,
     const IdxT* __restrict__ neg_t, int64_t batch, int n_neg, float margin, float gscale,
     const float* __restrict__ dpos, const float* __restrict__ dneg,
-    float* __restrict__ d_ent, float* __restrict__ d_rel) {
+    float* __restrict__ d_ent, int64_t dld, float* __restrict__ d_rel) {
     const int64_t b = (int64_t)blockIdx.x * 4 + wave_id_uniform();
     if (b >= batch) return;
     const int lane = threadIdx.x & 63;
     const bool hinge_mode = (dpos == nullptr);
 
     const int64_t hi = (int64_t)h[b], ri = (int64_t)r[b], ti = (int64_t)t[b];
-    RowS<NS> hh = load_row_s<NS>(ent, hi, dim, lane);
-    RowS<NS> rr = load_row_s<NS>(rel, ri, dim, lane);
-    RowS<NS> tt = load_row_s<NS>(ent, ti, dim, lane);
+    RowS<NS> hh = load_row_s<NS>(ent, hi, eld, dim, lane);
+    RowS<NS> rr = load_row_s<NS>(rel, ri, dim, dim, lane);
+    RowS<NS> tt = load_row_s<NS>(ent, ti, eld, dim, lane);
     const float den_h = normalize_s<NS>(hh);
     const float den_r = normalize_s<NS>(rr);
     const float den_t = normalize_s<NS>(tt);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(
     const IdxT* nrow = neg_t + b * (int64_t)n_neg;
     for (int k = 0; k < n_neg; ++k) {
         const int64_t xi = (int64_t)nrow[k];
-        RowS<NS> x = load_row_s<NS>(ent, xi, dim, lane);
+        RowS<NS> x = load_row_s<NS>(ent, xi, eld, dim, lane);
         const float den_x = normalize_s<NS>(x);
         float c;
         if (hinge_mode) {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(
                 dq.v[i] += e2;
                 dx.v[i] = -e2;
             }
-            normalize_bwd_atomic<NS>(x, den_x, dx, d_ent + xi * (int64_t)dim, dim, lane);
+            normalize_bwd_atomic<NS>(x, den_x, dx, d_ent + xi * dld, dim, lane);
         }
     }
     if (c_pos != 0.f) {
@@ -246,9 +246,9 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(
             dq.v[i] += e2;
             dx.v[i] = -e2;
         }
-        normalize_bwd_atomic<NS>(tt, den_t, dx, d_ent + ti * (int64_t)dim, dim, lane);
+        normalize_bwd_atomic<NS>(tt, den_t, dx, d_ent + ti * dld, dim, lane);
     }
-    normalize_bwd_atomic<NS>(hh, den_h, dq, d_ent + hi * (int64_t)dim, dim, lane);
+    normalize_bwd_atomic<NS>(hh, den_h, dq, d_ent + hi * dld, dim, lane);
     normalize_bwd_atomic<NS>(rr, den_r, dq, d_rel + ri * (int64_t)dim, dim, lane);
 }
 
@@ -269,13 +269,13 @@ __global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restric
 }
 
 template <typename IdxT>
-static int launch_fwd(const float* ent, const float* rel, int dim, const void* h, const void* r, const void* t,
+static int launch_fwd(const float* ent, int64_t eld, const float* rel, int dim, const void* h, const void* r, const void* t,
                       const void* neg_t, int64_t batch, int n_neg, float margin, float* pos, float* neg,
                       float* loss_part, hipStream_t st) {
     const dim3 grid((unsigned)ceil_div(batch, 4)), block(256);
     const int nv = (dim + 63) / 64;
 #define SNAG_FWD(NV)                                                                                           \
-    hipLaunchKernelGGL((score_fwd_kernel<IdxT, NV>), grid, block, 0, st, ent, rel, dim, (const IdxT*)h,        \
+    hipLaunchKernelGGL((score_fwd_kernel<IdxT, NV>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h,        \
                        (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, pos, neg, loss_part)
     switch (nv) {
         case 1: SNAG_FWD(1); break;
@@ -290,15 +290,15 @@ static int launch_fwd(const float* ent, const float* rel, int dim, const void* h
 }
 
 template <typename IdxT>
-static int launch_bwd(const float* ent, const float* rel, int dim, const void* h, const void* r, const void* t,
+static int launch_bwd(const float* ent, int64_t eld, const float* rel, int dim, const void* h, const void* r, const void* t,
                       const void* neg_t, int64_t batch, int n_neg, float margin, float gscale, const float* dpos,
-                      const float* dneg, float* d_ent, float* d_rel, hipStream_t st) {
+                      const float* dneg, float* d_ent, int64_t dld, float* d_rel, hipStream_t st) {
     const dim3 grid((unsigned)ceil_div(batch, 4)), block(256);
     const int ns = (dim + 63) / 64;
 #define SNAG_BWD(NS)                                                                                           \
-    hipLaunchKernelGGL((score_bwd_kernel<IdxT, NS>), grid, block, 0, st, ent, rel, dim, (const IdxT*)h,        \
+    hipLaunchKernelGGL((score_bwd_kernel<IdxT, NS>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h,        \
                        (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, gscale, dpos, \
-                       dneg, d_ent, d_rel)
+                       dneg, d_ent, dld, d_rel)
     switch (ns) {
         case 1: SNAG_BWD(1); break;
         case 2: SNAG_BWD(2); break;
@@ -328,7 +328,7 @@ static int check_score_args(const void* ent, int64_t n_ent, const void* rel, int
 
 using namespace snag;
 
-extern "C" SNAG_API int snag_score_margin_fwd(const float* ent, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+extern "C" SNAG_API int snag_score_margin_fwd(const float* ent, int64_t ent_ld, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
                                      const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
                                      int64_t batch, int n_neg, float margin, float* pos, float* neg, float* loss_part,
                                      void* stream) {
@@ -336,29 +336,31 @@ extern "C" SNAG_API int snag_score_margin_fwd(const float* ent, int64_t n_ent, c
     int rc = check_score_args(ent, n_ent, rel, n_rel, dim, h, r, t, neg_t, idx_bytes, batch, n_neg);
     if (rc) return rc;
     SNAG_REQUIRE(pos && (n_neg == 0 || neg), SNAG_ERR_ARG, "score_fwd: null output pointer");
-    SNAG_REQUIRE(dim % 4 == 0, SNAG_ERR_UNSUPPORTED, "score_fwd: dim=%d must be a multiple of 4 (16-byte rows)", dim);
+    SNAG_REQUIRE(dim % 4 == 0 && ent_ld % 4 == 0, SNAG_ERR_UNSUPPORTED, "score_fwd: dim=%d and ent_ld=%ld must be multiples of 4 (16-byte rows)", dim, (long)ent_ld);
+    SNAG_REQUIRE(ent_ld >= dim, SNAG_ERR_ARG, "score_fwd: ent_ld=%ld < dim=%d", (long)ent_ld, dim);
     if (batch == 0) return SNAG_OK;
     hipStream_t st = (hipStream_t)stream;
-    return idx_bytes == 4 ? launch_fwd<int32_t>(ent, rel, dim, h, r, t, neg_t, batch, n_neg, margin, pos, neg, loss_part, st)
-                          : launch_fwd<int64_t>(ent, rel, dim, h, r, t, neg_t, batch, n_neg, margin, pos, neg, loss_part, st);
+    return idx_bytes == 4 ? launch_fwd<int32_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, pos, neg, loss_part, st)
+                          : launch_fwd<int64_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, pos, neg, loss_part, st);
 }
 
-extern "C" SNAG_API int snag_score_margin_bwd(const float* ent, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+extern "C" SNAG_API int snag_score_margin_bwd(const float* ent, int64_t ent_ld, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
                                      const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
                                      int64_t batch, int n_neg, float margin, float grad_scale, const float* dpos,
-                                     const float* dneg, float* d_ent, float* d_rel, void* stream) {
+                                     const float* dneg, float* d_ent, int64_t d_ent_ld, float* d_rel, void* stream) {
     if (batch == 0) return SNAG_OK;
     int rc = check_score_args(ent, n_ent, rel, n_rel, dim, h, r, t, neg_t, idx_bytes, batch, n_neg);
     if (rc) return rc;
     SNAG_REQUIRE(d_ent && d_rel, SNAG_ERR_ARG, "score_bwd: null gradient pointer");
+    SNAG_REQUIRE(ent_ld >= dim && d_ent_ld >= dim, SNAG_ERR_ARG, "score_bwd: row stride smaller than dim=%d", dim);
     SNAG_REQUIRE((dpos != nullptr) || (dneg == nullptr), SNAG_ERR_ARG, "score_bwd: dneg given without dpos");
     SNAG_REQUIRE((dpos == nullptr) || (dneg != nullptr) || n_neg == 0, SNAG_ERR_ARG,
                  "score_bwd: explicit mode needs both dpos and dneg");
     if (batch == 0) return SNAG_OK;
     hipStream_t st = (hipStream_t)stream;
     return idx_bytes == 4
-               ? launch_bwd<int32_t>(ent, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, d_ent, d_rel, st)
-               : launch_bwd<int64_t>(ent, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, d_ent, d_rel, st);
+               ? launch_bwd<int32_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, d_ent, d_ent_ld, d_rel, st)
+               : launch_bwd<int64_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, d_ent, d_ent_ld, d_rel, st);
 }
 
 extern "C" SNAG_API int snag_reduce_sum(const float* x, int64_t n, float* out, void* stream) {

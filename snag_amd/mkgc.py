@@ -1,0 +1,373 @@
+"""MKGC hot path (BASELINE.json north_star): per-modality projections -> modality tokens ->
+Mformer fusion -> ``joint_way`` read-out -> margin score of 1 positive + NEG_NUM negative tails,
+forward and backward, as one stream of HIP launches over preallocated buffers.
+
+The reference's MKGC driver is not in the tree (SURVEY.md par. 0.1); this engine follows the README
+knobs (README.md:43-80: ``num_proj``, ``use_intermediate``, ``joint_way``, noise/mask ratio,
+``EMB_DIM``, ``NUM_BATCH``, ``MARGIN``, ``NEG_NUM``) and re-uses, operator by operator, what IS in the
+tree: ``MultiModalEncoder.forward`` (model/SNAG_tools.py:122-156) with the GAT removed,
+``MformerFusion`` (:23-51), the noise injection (model/SNAG.py:66-98) and the TransE-L2^2 margin
+scorer (model/MSNEA.py:110-122).
+
+Every learnable tensor is a view into ONE flat fp32 buffer (and its gradient into one flat gradient
+buffer), so the data-parallel exchange is a single RCCL all-reduce and the optimiser a single launch.
+"""
+import ctypes
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+f32 = torch.float32
+
+
+@dataclass
+class MKGCConfig:
+    n_ent: int = 15000
+    n_rel: int = 558
+    dim: int = 128                      # EMB_DIM
+    feat_dims: List[int] = field(default_factory=lambda: [4096, 768])   # visual, text raw feature widths
+    num_proj: int = 2                   # README "num_proj: 1 / 2"
+    joint_way: str = "Mformer_hd_graph"
+    num_heads: int = 2
+    num_layers: int = 1
+    use_intermediate: int = 0
+    intermediate_size: int = 400
+    margin: float = 12.0                # MARGIN
+    neg_num: int = 32                   # NEG_NUM
+    add_noise: int = 1                  # NOISE
+    noise_ratio: float = 0.2
+    mask_ratio: float = 0.7
+    dropout: float = 0.1                # nn.Dropout(0.1) inside the Bert blocks (SNAG_tools.py:169,216)
+    lr: float = 1e-4                    # LR
+    weight_decay: float = 1e-4
+    seed: int = 1234
+
+    @property
+    def n_tokens(self):
+        return len(self.feat_dims) + 1
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class MKGCHotPath:
+    """Owns parameters, activations and the launch sequence of one training / scoring step."""
+
+    def __init__(self, cfg: MKGCConfig, feats: List[torch.Tensor], device="cuda"):
+        _lib.require_gpu()
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        self.lib = _lib.load()
+        N, R, D, M = cfg.n_ent, cfg.n_rel, cfg.dim, cfg.n_tokens
+        if cfg.joint_way not in ("Mformer_hd_graph", "Mformer_hd_mean"):
+            raise ValueError("the scoring step reads an [N, dim] read-out: joint_way must be Mformer_hd_graph or Mformer_hd_mean")
+        if len(feats) != len(cfg.feat_dims):
+            raise ValueError("one feature table per entry of feat_dims")
+        self.feats = []
+        for f, fd in zip(feats, cfg.feat_dims):
+            if tuple(f.shape) != (N, fd) or f.dtype != f32:
+                raise ValueError(f"feature table must be fp32 [{N}, {fd}], got {tuple(f.shape)}")
+            self.feats.append(f.to(self.dev).contiguous())
+        self.g_slot = M - 1                                   # structural token last
+        I, L, ffn = cfg.intermediate_size, cfg.num_layers, bool(cfg.use_intermediate)
+
+        # ---- flat parameter layout ---------------------------------------------------------------
+        self.slices = {}
+        off = 0
+
+        def add(name, *shape):
+            nonlocal off
+            n = int(math.prod(shape))
+            self.slices[name] = (off, tuple(shape))
+            off = _align(off + n)
+
+        add("ent", N, D)
+        add("rel", R, D)
+        for i, fd in enumerate(cfg.feat_dims):
+            if cfg.num_proj == 1:
+                add(f"proj{i}.weight", D, fd)
+                add(f"proj{i}.bias", D)
+            else:
+                add(f"proj{i}.l1", D, fd)
+                add(f"proj{i}.l2", D, D)
+        add("weight_raw", 6)
+        for l in range(L):
+            add(f"layer{l}.wqkv", 3 * D, D); add(f"layer{l}.bqkv", 3 * D)
+            add(f"layer{l}.wo", D, D); add(f"layer{l}.bo", D)
+            add(f"layer{l}.ln1_g", D); add(f"layer{l}.ln1_b", D)
+            if ffn:
+                add(f"layer{l}.w1", I, D); add(f"layer{l}.b1", I)
+                add(f"layer{l}.w2", D, I); add(f"layer{l}.b2", D)
+                add(f"layer{l}.ln2_g", D); add(f"layer{l}.ln2_b", D)
+        self.n_params = off
+        self.flat = torch.zeros(off, device=self.dev, dtype=f32)
+        self.gflat = torch.zeros(off, device=self.dev, dtype=f32)
+        self.exp_avg = torch.zeros(off, device=self.dev, dtype=f32)
+        self.exp_avg_sq = torch.zeros(off, device=self.dev, dtype=f32)
+        self.p = {k: self.flat[o:o + math.prod(s)].view(s) for k, (o, s) in self.slices.items()}
+        self.g = {k: self.gflat[o:o + math.prod(s)].view(s) for k, (o, s) in self.slices.items()}
+        self._init_params()
+
+        # ---- activations / scratch ---------------------------------------------------------------
+        dev = self.dev
+        self.x0 = torch.empty(N, M, D, device=dev)
+        self.hidden = torch.empty(N, M, D, device=dev)
+        self.d_hidden = torch.empty(N, M, D, device=dev)
+        self.d_x0 = torch.empty(N, M, D, device=dev)
+        self.mid = [torch.empty(N, D, device=dev) for _ in cfg.feat_dims] if cfg.num_proj == 2 else []
+        self.d_mid = torch.empty(N, D, device=dev) if cfg.num_proj == 2 else None
+        self.repr_mean = torch.empty(N, D, device=dev) if cfg.joint_way == "Mformer_hd_mean" else None
+        self.d_repr = torch.empty(N, D, device=dev) if cfg.joint_way == "Mformer_hd_mean" else None
+        lib = self.lib
+        self.save = torch.empty(lib.snag_fusion_save_floats(N, M, D, cfg.num_heads, I, L, int(ffn)), device=dev)
+        ws = lib.snag_fusion_work_floats(N, M, D, cfg.num_heads, I, L, int(ffn))
+        for fd in cfg.feat_dims:
+            ws = max(ws, lib.snag_gemm_workspace_floats(D, fd, N) + 64, 256 * max(D, fd))
+        ws = max(ws, lib.snag_gemm_workspace_floats(D, D, N) + 64)
+        self.work = torch.empty(ws, device=dev)
+        H = cfg.num_heads
+        self.keep_probs = [torch.ones(N, H, M, M, device=dev, dtype=torch.uint8) for _ in range(L)]
+        self.keep_attn = [torch.ones(N * M, D, device=dev, dtype=torch.uint8) for _ in range(L)]
+        self.keep_ffn = [torch.ones(N * M, D, device=dev, dtype=torch.uint8) for _ in range(L)] if ffn else None
+        self.tick = torch.zeros(1, device=dev, dtype=torch.int64)      # device-side step counter
+        # noise state (model/SNAG.py:86-98)
+        self.noisy = [f.clone() for f in self.feats]
+        self.feat_stats = None
+        self.ent_noise = torch.zeros(N, D, device=dev)
+        self.ent_noise_mask = torch.zeros(N, device=dev, dtype=torch.uint8)
+        self.row_mask = torch.zeros(N, device=dev, dtype=torch.uint8)
+        self.noise_active = False
+        self.noise_epoch = 0
+        self.training = True
+        self._loss_part = None
+        self.loss = torch.zeros((), device=dev)
+        self._build_descs()
+
+    # ------------------------------------------------------------------------------------------
+    def _init_params(self):
+        """Reference initialisers: entity table N(0, 1/sqrt(N)) (SNAG_tools.py:85), nn.Linear defaults, LN 1/0, weight_raw 1."""
+        cfg = self.cfg
+        g = torch.Generator().manual_seed(cfg.seed)
+        N, D = cfg.n_ent, cfg.dim
+
+        def lin(shape_out_in):
+            bound = 1.0 / math.sqrt(shape_out_in[1])            # kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), +)
+            return (torch.rand(shape_out_in, generator=g) * 2 - 1) * bound
+
+        def bias(n, fan_in):
+            return (torch.rand(n, generator=g) * 2 - 1) / math.sqrt(fan_in)
+
+        self.p["ent"].copy_(torch.randn(N, D, generator=g) / math.sqrt(N))
+        self.p["rel"].copy_(torch.randn(cfg.n_rel, D, generator=g) * math.sqrt(2.0 / (cfg.n_rel + D)))   # xavier normal
+        for i, fd in enumerate(cfg.feat_dims):
+            if cfg.num_proj == 1:
+                self.p[f"proj{i}.weight"].copy_(lin((D, fd)))
+                self.p[f"proj{i}.bias"].copy_(bias(D, fd))
+            else:
+                self.p[f"proj{i}.l1"].copy_(lin((D, fd)))
+                self.p[f"proj{i}.l2"].copy_(lin((D, D)))
+        self.p["weight_raw"].fill_(1.0)
+        I = cfg.intermediate_size
+        for l in range(cfg.num_layers):
+            self.p[f"layer{l}.wqkv"].copy_(torch.cat([lin((D, D)) for _ in range(3)], 0))
+            self.p[f"layer{l}.bqkv"].copy_(torch.cat([bias(D, D) for _ in range(3)], 0))
+            self.p[f"layer{l}.wo"].copy_(lin((D, D)))
+            self.p[f"layer{l}.bo"].copy_(bias(D, D))
+            self.p[f"layer{l}.ln1_g"].fill_(1.0)
+            self.p[f"layer{l}.ln1_b"].zero_()
+            if cfg.use_intermediate:
+                self.p[f"layer{l}.w1"].copy_(lin((I, D))); self.p[f"layer{l}.b1"].copy_(bias(I, D))
+                self.p[f"layer{l}.w2"].copy_(lin((D, I))); self.p[f"layer{l}.b2"].copy_(bias(D, I))
+                self.p[f"layer{l}.ln2_g"].fill_(1.0); self.p[f"layer{l}.ln2_b"].zero_()
+
+    def _build_descs(self):
+        cfg = self.cfg
+        L, ffn = cfg.num_layers, bool(cfg.use_intermediate)
+        self._layers = (_lib.FusionLayer * L)()
+        self._grads = (_lib.FusionLayerGrad * L)()
+        names = ["wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b"] + (["w1", "b1", "w2", "b2", "ln2_g", "ln2_b"] if ffn else [])
+        for l in range(L):
+            for nm in names:
+                setattr(self._layers[l], nm, ptr(self.p[f"layer{l}.{nm}"]))
+                setattr(self._grads[l], nm, ptr(self.g[f"layer{l}.{nm}"]))
+        d = _lib.FusionDesc()
+        d.N, d.M, d.D, d.H, d.I, d.L = cfg.n_ent, cfg.n_tokens, cfg.dim, cfg.num_heads, cfg.intermediate_size, L
+        d.use_intermediate = int(ffn)
+        d.drop_p = cfg.dropout
+        d.layers = ctypes.cast(self._layers, ctypes.POINTER(_lib.FusionLayer))
+        d.weight_raw = ptr(self.p["weight_raw"])
+        d.x0 = ptr(self.x0)
+        d.hidden = ptr(self.hidden)          # joint / joint_fz / weight_norm are not needed by the hd_* read-outs
+        d.save, d.save_floats = ptr(self.save), self.save.numel()
+        d.work, d.work_floats = ptr(self.work), self.work.numel()
+        self._fdesc = d
+        b = _lib.FusionBwdDesc()
+        b.d_hidden = ptr(self.d_hidden)
+        b.d_x0 = ptr(self.d_x0)
+        b.grads = ctypes.cast(self._grads, ctypes.POINTER(_lib.FusionLayerGrad))
+        b.d_weight_raw = ptr(self.g["weight_raw"])
+        b.accumulate = 0
+        self._bdesc = b
+        self._set_dropout(self.training)
+
+    def _set_dropout(self, on):
+        for l in range(self.cfg.num_layers):
+            self._layers[l].keep_probs = ptr(self.keep_probs[l]) if on else None
+            self._layers[l].keep_attn_out = ptr(self.keep_attn[l]) if on else None
+            self._layers[l].keep_ffn_out = ptr(self.keep_ffn[l]) if (on and self.keep_ffn) else None
+        self._bdesc.f = self._fdesc
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        self._set_dropout(self.training and self.cfg.dropout > 0)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # ------------------------------------------------------------------------------------------
+    def _gemm(self, M, N, K, A, lda, akc, B, ldb, bkc, C, ldc, *, bias=None, act=0, pre=None, add1=None, ld1=0,
+              aux=None, ldaux=0, splitk=False):
+        d = _lib.GemmDesc()
+        d.M, d.N, d.K = M, N, K
+        d.a_kcontig, d.b_kcontig = int(akc), int(bkc)
+        d.A, d.lda, d.B, d.ldb, d.C, d.ldc = A, lda, B, ldb, C, ldc
+        d.bias, d.alpha, d.act, d.pre_act = bias, 1.0, act, pre
+        d.add1, d.ld1 = add1, ld1
+        d.aux, d.ldaux = aux, ldaux
+        if splitk:
+            d.workspace, d.workspace_floats = ptr(self.work), self.work.numel()
+        call("snag_gemm_f32", ctypes.byref(d), self._st)
+
+    def update_noise(self, seed: Optional[int] = None):
+        """Once per epoch (README "noise-level: epoch", main.py:253-254 -> SNAG.update_noise model/SNAG.py:86-98)."""
+        cfg = self.cfg
+        st = stream()
+        from . import ops
+        if self.feat_stats is None:            # clean-table statistics are constants (get_mean_std, :77-84)
+            self.feat_stats = [ops.colstats(f) for f in self.feats]
+        self.noise_epoch += 1
+        base = (cfg.seed if seed is None else seed) * 1000003 + self.noise_epoch * 7919
+        N, D = cfg.n_ent, cfg.dim
+        for i, f in enumerate(self.feats):
+            # row mask = rand(N) < noise_ratio  ==  NOT keep with keep = (u >= noise_ratio)
+            call("snag_dropout_keep_mask", base + 11 * i + 1, None, N, float(cfg.noise_ratio), ptr(self.row_mask), st)
+            self.row_mask.bitwise_xor_(1)
+            mean, std = self.feat_stats[i]
+            call("snag_noise_apply", ptr(f), N, f.shape[1], ptr(mean), ptr(std), ptr(self.row_mask), None, None,
+                 base + 11 * i + 2, float(cfg.mask_ratio), ptr(self.noisy[i]), st)
+        mean, std = ops.colstats(self.p["ent"])
+        call("snag_gaussian_fill", base + 101, N, D, ptr(mean), ptr(std), ptr(self.ent_noise), st)
+        call("snag_dropout_keep_mask", base + 102, None, N, float(cfg.noise_ratio) * 0.5, ptr(self.ent_noise_mask), st)
+        self.ent_noise_mask.bitwise_xor_(1)
+        self.noise_active = True
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, h, r, t, neg_t, want_scores=False):
+        """Projections -> tokens -> fusion -> read-out -> scores/loss.  Returns the device scalar loss."""
+        cfg = self.cfg
+        N, D, M = cfg.n_ent, cfg.dim, cfg.n_tokens
+        st = self._st = stream()
+        noisy = self.training and cfg.add_noise and self.noise_active
+        MD = M * D
+        x0p = self.x0.data_ptr()
+        for i, fd in enumerate(cfg.feat_dims):
+            feat = self.noisy[i] if noisy else self.feats[i]
+            slot = x0p + 4 * i * D
+            if cfg.num_proj == 1:
+                self._gemm(N, D, fd, ptr(feat), fd, 1, ptr(self.p[f"proj{i}.weight"]), fd, 1, slot, MD, bias=ptr(self.p[f"proj{i}.bias"]))
+            else:   # ProjectionHead: Linear(no bias) -> ReLU -> Linear(no bias)   (model/layers.py:135-148)
+                self._gemm(N, D, fd, ptr(feat), fd, 1, ptr(self.p[f"proj{i}.l1"]), fd, 1, ptr(self.mid[i]), D, act=1)
+                self._gemm(N, D, D, ptr(self.mid[i]), D, 1, ptr(self.p[f"proj{i}.l2"]), D, 1, slot, MD)
+        call("snag_entity_token_fwd", ptr(self.p["ent"]), N, D, ptr(self.ent_noise) if noisy else None,
+             ptr(self.ent_noise_mask) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD, st)
+        if self.training and cfg.dropout > 0:
+            for l in range(cfg.num_layers):
+                call("snag_dropout_keep_mask", cfg.seed + 17 * l + 1, ptr(self.tick), self.keep_probs[l].numel(), cfg.dropout, ptr(self.keep_probs[l]), st)
+                call("snag_dropout_keep_mask", cfg.seed + 17 * l + 2, ptr(self.tick), self.keep_attn[l].numel(), cfg.dropout, ptr(self.keep_attn[l]), st)
+                if self.keep_ffn:
+                    call("snag_dropout_keep_mask", cfg.seed + 17 * l + 3, ptr(self.tick), self.keep_ffn[l].numel(), cfg.dropout, ptr(self.keep_ffn[l]), st)
+        call("snag_fusion_fwd", ctypes.byref(self._fdesc), st)
+        if cfg.joint_way == "Mformer_hd_mean":
+            call("snag_token_mean", ptr(self.hidden), N, M, D, ptr(self.repr_mean), st)
+            self._repr, self._repr_ld = self.repr_mean.data_ptr(), D
+        else:
+            self._repr, self._repr_ld = self.hidden.data_ptr() + 4 * self.g_slot * D, MD
+        B, K = neg_t.shape
+        if self._loss_part is None or self._loss_part.shape[0] != B:
+            self._loss_part = torch.empty(B, device=self.dev)
+            self._pos = torch.empty(B, device=self.dev)
+            self._neg = torch.empty(B, K, device=self.dev)
+        ib = 4 if h.dtype == torch.int32 else 8
+        call("snag_score_margin_fwd", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r), ptr(t), ptr(neg_t),
+             ib, B, K, float(cfg.margin), ptr(self._pos), ptr(self._neg), ptr(self._loss_part), st)
+        call("snag_reduce_sum", ptr(self._loss_part), B, ptr(self.loss), st)
+        self._batch = (h, r, t, neg_t, ib, B, K)
+        if want_scores:
+            return self.loss, self._pos, self._neg
+        return self.loss
+
+    def backward(self, grad_scale=1.0):
+        """Gradient of grad_scale * loss w.r.t. every parameter, written (not added) into the flat gradient buffer."""
+        cfg = self.cfg
+        N, D, M = cfg.n_ent, cfg.dim, cfg.n_tokens
+        st = self._st
+        MD = M * D
+        h, r, t, neg_t, ib, B, K = self._batch
+        noisy = self.training and cfg.add_noise and self.noise_active
+        self.g["rel"].zero_()
+        if cfg.joint_way == "Mformer_hd_mean":
+            self.d_repr.zero_()
+            d_repr, d_ld = self.d_repr.data_ptr(), D
+        else:
+            self.d_hidden.zero_()
+            d_repr, d_ld = self.d_hidden.data_ptr() + 4 * self.g_slot * D, MD
+        call("snag_score_margin_bwd", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r), ptr(t), ptr(neg_t),
+             ib, B, K, float(cfg.margin), float(grad_scale), None, None, d_repr, d_ld, ptr(self.g["rel"]), st)
+        if cfg.joint_way == "Mformer_hd_mean":
+            call("snag_token_mean_bwd", ptr(self.d_repr), N, M, D, ptr(self.d_hidden), st)
+        call("snag_fusion_bwd", ctypes.byref(self._bdesc), st)
+        dx0 = self.d_x0.data_ptr()
+        wk = ptr(self.work)
+        for i, fd in enumerate(cfg.feat_dims):
+            feat = self.noisy[i] if noisy else self.feats[i]
+            dslot = dx0 + 4 * i * D
+            if cfg.num_proj == 1:
+                # dW = dTok^T feat ; db = colsum(dTok)
+                self._gemm(D, fd, N, dslot, MD, 0, ptr(feat), fd, 0, ptr(self.g[f"proj{i}.weight"]), fd, splitk=True)
+                call("snag_colsum", dslot, N, D, MD, ptr(self.g[f"proj{i}.bias"]), 0, wk, st)
+            else:
+                self._gemm(D, D, N, dslot, MD, 0, ptr(self.mid[i]), D, 0, ptr(self.g[f"proj{i}.l2"]), D, splitk=True)
+                # d mid = (dTok l2) * [mid > 0]
+                self._gemm(N, D, D, dslot, MD, 1, ptr(self.p[f"proj{i}.l2"]), D, 0, ptr(self.d_mid), D, act=4, aux=ptr(self.mid[i]), ldaux=D)
+                self._gemm(D, fd, N, ptr(self.d_mid), D, 0, ptr(feat), fd, 0, ptr(self.g[f"proj{i}.l1"]), fd, splitk=True)
+        call("snag_entity_token_bwd", dx0 + 4 * self.g_slot * D, MD, N, D, ptr(self.ent_noise_mask) if noisy else None,
+             float(cfg.mask_ratio) * 0.5, ptr(self.g["ent"]), 0, st)
+
+    def optimizer_step(self, grad_scale=1.0):
+        cfg = self.cfg
+        call("snag_adamw_step", ptr(self.flat), ptr(self.gflat), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n_params,
+             float(cfg.lr), 0.9, 0.999, 1e-8, float(cfg.weight_decay), 0, ptr(self.tick), float(grad_scale), self._st)
+        call("snag_tick", ptr(self.tick), self._st)
+
+    def train_step(self, h, r, t, neg_t, allreduce=None):
+        """forward + backward (+ gradient exchange) + AdamW.  ``allreduce(gflat)`` sums gradients across ranks."""
+        self.forward(h, r, t, neg_t)
+        self.backward()
+        if allreduce is not None:
+            allreduce(self.gflat)
+        self.optimizer_step()
+        return self.loss
+
+    # parameters as a name -> tensor dict (for tests / checkpoints)
+    def named_parameters(self):
+        return dict(self.p)
+
+    def named_gradients(self):
+        return dict(self.g)

@@ -48,23 +48,32 @@ def _idx_group(h, r, t, neg_t):
     return B, K, (4 if dt == torch.int32 else 8)
 
 
+def _rows(t, name):
+    """2-D fp32 CUDA tensor with unit inner stride (row stride free: lets a [N, M, D] slot be used in place)."""
+    if not (torch.is_tensor(t) and t.dim() == 2 and t.dtype == f32 and t.stride(1) == 1):
+        raise ValueError(f"{name}: expected a 2-D fp32 tensor with unit inner stride")
+    if not t.is_cuda:
+        raise _lib.SnagHipError(f"{name}: tensor is on {t.device}; snag_amd kernels run on the GPU only (no CPU fallback)")
+    return t
+
+
 def score_margin_fwd(ent, rel, h, r, t, neg_t, margin, want_loss=True):
     """-> pos [B], neg [B,K], loss_part [B] (or None).  C ABI: snag_score_margin_fwd."""
-    _chk(ent, "ent", ndim=2), _chk(rel, "rel", ndim=2)
+    _rows(ent, "ent"), _chk(rel, "rel", ndim=2)
     if ent.shape[1] != rel.shape[1]:
         raise ValueError(f"ent dim {ent.shape[1]} != rel dim {rel.shape[1]}")
     B, K, ib = _idx_group(h, r, t, neg_t)
     pos = torch.empty(B, device=ent.device, dtype=f32)
     neg = torch.empty(B, K, device=ent.device, dtype=f32)
     loss_part = torch.empty(B, device=ent.device, dtype=f32) if want_loss else None
-    call("snag_score_margin_fwd", ptr(ent), ent.shape[0], ptr(rel), rel.shape[0], ent.shape[1],
+    call("snag_score_margin_fwd", ptr(ent), ent.stride(0), ent.shape[0], ptr(rel), rel.shape[0], ent.shape[1],
          ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K, float(margin), ptr(pos), ptr(neg), ptr(loss_part), stream())
     return pos, neg, loss_part
 
 
 def score_margin_bwd(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, dpos=None, dneg=None, d_ent=None, d_rel=None):
     """Accumulates into d_ent/d_rel (allocated zeroed when None).  C ABI: snag_score_margin_bwd."""
-    _chk(ent, "ent", ndim=2), _chk(rel, "rel", ndim=2)
+    _rows(ent, "ent"), _chk(rel, "rel", ndim=2)
     B, K, ib = _idx_group(h, r, t, neg_t)
     if dpos is not None:
         _chk(dpos, "dpos", ndim=1)
@@ -75,15 +84,15 @@ def score_margin_bwd(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, dpos=None
         if tuple(dneg.shape) != (B, K):
             raise ValueError("dneg must be [B, K]")
     if d_ent is None:
-        d_ent = torch.zeros_like(ent)
+        d_ent = torch.zeros(ent.shape, device=ent.device, dtype=f32)
     if d_rel is None:
         d_rel = torch.zeros_like(rel)
-    _chk(d_ent, "d_ent", ndim=2), _chk(d_rel, "d_rel", ndim=2)
+    _rows(d_ent, "d_ent"), _chk(d_rel, "d_rel", ndim=2)
     if d_ent.shape != ent.shape or d_rel.shape != rel.shape:
         raise ValueError("gradient buffers must match the table shapes")
-    call("snag_score_margin_bwd", ptr(ent), ent.shape[0], ptr(rel), rel.shape[0], ent.shape[1],
+    call("snag_score_margin_bwd", ptr(ent), ent.stride(0), ent.shape[0], ptr(rel), rel.shape[0], ent.shape[1],
          ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K, float(margin), float(grad_scale),
-         ptr(dpos), ptr(dneg), ptr(d_ent), ptr(d_rel), stream())
+         ptr(dpos), ptr(dneg), ptr(d_ent), d_ent.stride(0), ptr(d_rel), stream())
     return d_ent, d_rel
 
 
@@ -154,3 +163,82 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, alpha=1.0, act=None
     import ctypes
     call("snag_gemm_f32", ctypes.byref(d), stream())
     return (out, pre) if want_pre_act else out
+
+
+# ---- a6 noise / statistics ------------------------------------------------------------------------
+def colstats(x, exclude=None, n_valid=None, want_std=True):
+    """Per-column mean and unbiased std over rows with exclude == 0.  C ABI: snag_colstats."""
+    _chk(x, "x", ndim=2)
+    R, C = x.shape
+    if exclude is not None:
+        _chk(exclude, "exclude", dtype=torch.uint8, ndim=1)
+        if n_valid is None:
+            n_valid = R - int(exclude.sum().item())
+    elif n_valid is None:
+        n_valid = R
+    mean = torch.empty(C, device=x.device, dtype=f32)
+    std = torch.empty(C, device=x.device, dtype=f32) if want_std else None
+    work = torch.empty(_lib.load().snag_colstats_work_floats(C), device=x.device, dtype=f32)
+    call("snag_colstats", ptr(x), R, C, ptr(exclude), int(n_valid), ptr(mean), ptr(std), ptr(work), stream())
+    return mean, std
+
+
+def noise_apply(x, mean, std, row_mask, mask_ratio, z=None, sel_index=None, seed=0, out=None):
+    """Row-level Gaussian noise injection.  C ABI: snag_noise_apply."""
+    _chk(x, "x", ndim=2), _chk(mean, "mean", ndim=1), _chk(std, "std", ndim=1)
+    _chk(row_mask, "row_mask", dtype=torch.uint8, ndim=1)
+    N, F = x.shape
+    if row_mask.shape[0] != N or mean.shape[0] != F or std.shape[0] != F:
+        raise ValueError("noise_apply: shape mismatch")
+    if z is not None:
+        _chk(z, "z", ndim=2)
+        _chk(sel_index, "sel_index", dtype=torch.int32, ndim=1)
+    if out is None:
+        out = torch.empty_like(x)
+    call("snag_noise_apply", ptr(x), N, F, ptr(mean), ptr(std), ptr(row_mask), ptr(sel_index), ptr(z),
+         int(seed), float(mask_ratio), ptr(out), stream())
+    return out
+
+
+def dropout_keep_mask(shape, p, seed, device="cuda", tick=None, out=None):
+    """uint8 keep mask (u >= p) from Philox(seed [+ device tick]).  C ABI: snag_dropout_keep_mask."""
+    if out is None:
+        out = torch.empty(shape, device=device, dtype=torch.uint8)
+    call("snag_dropout_keep_mask", int(seed), ptr(tick), out.numel(), float(p), ptr(out), stream())
+    return out
+
+
+def gaussian_fill(mean, std, N, seed):
+    """[N, F] tensor mean + std * z.  C ABI: snag_gaussian_fill."""
+    _chk(mean, "mean", ndim=1), _chk(std, "std", ndim=1)
+    out = torch.empty(N, mean.shape[0], device=mean.device, dtype=f32)
+    call("snag_gaussian_fill", int(seed), N, mean.shape[0], ptr(mean), ptr(std), ptr(out), stream())
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    """out[c] = sum_r x[r, c] for a 2-D tensor with free row stride.  C ABI: snag_colsum."""
+    _rows(x, "x")
+    R, C = x.shape
+    if out is None:
+        out = torch.empty(C, device=x.device, dtype=f32)
+    work = torch.empty(256 * C, device=x.device, dtype=f32)
+    call("snag_colsum", ptr(x), R, C, x.stride(0), ptr(out), int(accumulate), ptr(work), stream())
+    return out
+
+
+def pack_tokens(embs, g_slot=-1, noise=None, noise_mask=None, mask_ratio=0.0, out=None):
+    """torch.stack(embs, dim=1) (+ entity-noise blend in slot g_slot).  C ABI: snag_pack_tokens."""
+    import ctypes
+    M = len(embs)
+    for i, e in enumerate(embs):
+        _chk(e, f"embs[{i}]", ndim=2)
+    N, D = embs[0].shape
+    if out is None:
+        out = torch.empty(N, M, D, device=embs[0].device, dtype=f32)
+    arr = (ctypes.c_void_p * M)(*[e.data_ptr() for e in embs])
+    if noise is not None:
+        _chk(noise, "noise", ndim=2), _chk(noise_mask, "noise_mask", dtype=torch.uint8, ndim=1)
+    call("snag_pack_tokens", arr, M, N, D, g_slot % M if M else 0, ptr(noise), ptr(noise_mask), float(mask_ratio) * 0.5,
+         ptr(out), stream())
+    return out

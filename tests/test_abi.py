@@ -33,7 +33,7 @@ def test_argument_refusal_needs_no_gpu():
     """NULL pointers are refused before any HIP call, with a message."""
     from snag_amd import _lib
     lib = _lib.load()
-    rc = lib.snag_score_margin_fwd(None, 10, None, 2, 128, None, None, None, None, 4, 8, 4, 1.0, None, None, None, None)
+    rc = lib.snag_score_margin_fwd(None, 128, 10, None, 2, 128, None, None, None, None, 4, 8, 4, 1.0, None, None, None, None)
     assert rc == -1
     assert "null" in _lib.last_error().lower()
 

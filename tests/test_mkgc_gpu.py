@@ -1,0 +1,108 @@
+"""GPU parity: the whole MKGC hot-path step (projections -> fusion -> read-out -> margin score, fwd + bwd)
+through the C ABI vs the CPU oracle's autograd on the same seeded inputs."""
+import pytest
+import torch
+
+from helpers import assert_close
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def oracle_params(eng):
+    """engine flat-buffer views -> the oracle's (reference state_dict-keyed) parameter dicts, on CPU with grad."""
+    cfg = eng.cfg
+    D = cfg.dim
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in eng.named_parameters().items()}
+    proj = []
+    for i in range(len(cfg.feat_dims)):
+        if cfg.num_proj == 1:
+            proj.append({"weight": p[f"proj{i}.weight"], "bias": p[f"proj{i}.bias"]})
+        else:
+            proj.append({"l1": p[f"proj{i}.l1"], "l2": p[f"proj{i}.l2"]})
+    fp = {"weight_raw": p["weight_raw"]}
+    for l in range(cfg.num_layers):
+        pre = f"fusion_layer.{l}."
+        wqkv, bqkv = p[f"layer{l}.wqkv"], p[f"layer{l}.bqkv"]
+        for j, nm in enumerate(("query", "key", "value")):
+            fp[pre + f"attention.self.{nm}.weight"] = wqkv[j * D:(j + 1) * D]
+            fp[pre + f"attention.self.{nm}.bias"] = bqkv[j * D:(j + 1) * D]
+        fp[pre + "attention.output.dense.weight"] = p[f"layer{l}.wo"]
+        fp[pre + "attention.output.dense.bias"] = p[f"layer{l}.bo"]
+        fp[pre + "attention.output.LayerNorm.weight"] = p[f"layer{l}.ln1_g"]
+        fp[pre + "attention.output.LayerNorm.bias"] = p[f"layer{l}.ln1_b"]
+        if cfg.use_intermediate:
+            fp[pre + "intermediate.dense.weight"] = p[f"layer{l}.w1"]
+            fp[pre + "intermediate.dense.bias"] = p[f"layer{l}.b1"]
+            fp[pre + "output.dense.weight"] = p[f"layer{l}.w2"]
+            fp[pre + "output.dense.bias"] = p[f"layer{l}.b2"]
+            fp[pre + "output.LayerNorm.weight"] = p[f"layer{l}.ln2_g"]
+            fp[pre + "output.LayerNorm.bias"] = p[f"layer{l}.ln2_b"]
+    return p, proj, fp
+
+
+@pytest.mark.parametrize("num_proj,joint_way,ffn,noise,idt", [
+    (2, "Mformer_hd_graph", 0, False, torch.int32),
+    (1, "Mformer_hd_mean", 0, False, torch.int64),
+    (2, "Mformer_hd_graph", 1, True, torch.int32),
+    (1, "Mformer_hd_mean", 0, True, torch.int32),
+])
+def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt):
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    N, R, D, B, K = 700, 23, 128, 96, 32
+    cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[200, 72], num_proj=num_proj, joint_way=joint_way,
+                     use_intermediate=ffn, intermediate_size=96, margin=6.0, neg_num=K, dropout=0.0, add_noise=int(noise), seed=7)
+    g = torch.Generator().manual_seed(99)
+    feats = [torch.rand(N, 200, generator=g), torch.randn(N, 72, generator=g)]
+    eng = MKGCHotPath(cfg, feats, device=DEV)
+    # make the entity table and relations O(1) so scores are not degenerate
+    eng.p["ent"].copy_(torch.randn(N, D, generator=g).to(DEV))
+    eng.p["weight_raw"].copy_(torch.randn(6, generator=g).to(DEV))
+    if noise:
+        eng.update_noise()
+    h = torch.randint(0, N, (B,), generator=g).to(idt)
+    r = torch.randint(0, R, (B,), generator=g).to(idt)
+    t = torch.randint(0, N, (B,), generator=g).to(idt)
+    neg = torch.randint(0, N, (B, K), generator=g).to(idt)
+    loss, pos, ng = eng.forward(h.to(DEV), r.to(DEV), t.to(DEV), neg.to(DEV), want_scores=True)
+    eng.backward()
+    torch.cuda.synchronize()
+
+    p, proj, fp = oracle_params(eng)
+    ofeats = [f.cpu() for f in (eng.noisy if noise else eng.feats)]
+    oloss, opos, oneg, oent = O.mkgc_forward(
+        ofeats, proj, p["ent"], fp, p["rel"], h, r, t, neg, num_heads=cfg.num_heads, margin=cfg.margin, joint_way=joint_way,
+        use_intermediate=bool(ffn), num_layers=cfg.num_layers,
+        ent_noise=eng.ent_noise.cpu() if noise else None, ent_noise_mask=eng.ent_noise_mask.cpu().bool() if noise else None,
+        mask_ratio=cfg.mask_ratio)
+    oloss.backward()
+    assert_close(pos, opos, atol=1e-4, what="pos")                      # north_star: scores within 1e-4
+    assert_close(ng, oneg, atol=1e-4, what="neg")
+    assert_close(loss, oloss, atol=1e-4, rtol=2e-6, what="loss")
+    grads = eng.named_gradients()
+    for k, ref in p.items():
+        gref = ref.grad if ref.grad is not None else torch.zeros_like(ref)
+        scale = max(1.0, float(gref.abs().max()))
+        assert_close(grads[k], gref, atol=2e-4 * scale, rtol=1e-4, what=f"grad {k}")
+
+
+def test_mkgc_train_step_reduces_loss_and_is_deterministic_in_eval():
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    N, R, D, B, K = 2000, 31, 128, 256, 32
+    cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[256, 64], margin=12.0, lr=1e-2, seed=3)
+    g = torch.Generator().manual_seed(5)
+    feats = [torch.rand(N, 256, generator=g), torch.randn(N, 64, generator=g)]
+    eng = MKGCHotPath(cfg, feats, device=DEV)
+    idx = [torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(DEV) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (N, (B, K)))]
+    eng.update_noise()
+    first = float(eng.train_step(*idx))
+    for _ in range(30):
+        last = float(eng.train_step(*idx))
+    assert last < first, (first, last)
+    eng.eval()
+    a = eng.forward(*idx, want_scores=True)
+    a = [x.clone() for x in a]
+    b = eng.forward(*idx, want_scores=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

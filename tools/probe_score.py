@@ -11,8 +11,8 @@ for B in (1024, 8192, 79872):
     pos=torch.empty(B,device=dev); ng=torch.empty(B,K,device=dev); lp=torch.empty(B,device=dev)
     de=torch.zeros_like(ent); dr=torch.zeros_like(rel)
     st=_lib.stream()
-    def fwd(): _lib.call("snag_score_margin_fwd", ent.data_ptr(),N,rel.data_ptr(),R,D,h.data_ptr(),r.data_ptr(),t.data_ptr(),neg.data_ptr(),4,B,K,12.0,pos.data_ptr(),ng.data_ptr(),lp.data_ptr(),st)
-    def bwd(): _lib.call("snag_score_margin_bwd", ent.data_ptr(),N,rel.data_ptr(),R,D,h.data_ptr(),r.data_ptr(),t.data_ptr(),neg.data_ptr(),4,B,K,12.0,1.0,None,None,de.data_ptr(),dr.data_ptr(),st)
+    def fwd(): _lib.call("snag_score_margin_fwd", ent.data_ptr(),D,N,rel.data_ptr(),R,D,h.data_ptr(),r.data_ptr(),t.data_ptr(),neg.data_ptr(),4,B,K,12.0,pos.data_ptr(),ng.data_ptr(),lp.data_ptr(),st)
+    def bwd(): _lib.call("snag_score_margin_bwd", ent.data_ptr(),D,N,rel.data_ptr(),R,D,h.data_ptr(),r.data_ptr(),t.data_ptr(),neg.data_ptr(),4,B,K,12.0,1.0,None,None,de.data_ptr(),D,dr.data_ptr(),st)
     for name,fn in (("fwd",fwd),("bwd",bwd)):
         for _ in range(20): fn()
         torch.cuda.synchronize()
