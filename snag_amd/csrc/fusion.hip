@@ -198,7 +198,7 @@ static Work carve(float* base, int N, int M, int D, int H, int I, bool ffn) {
 static int colsum(const float* x, int64_t R, int C, float* part, float* out, int accumulate, hipStream_t st) {
     const int by = (int)std::min<int64_t>(kRedBlocks, (R + 3) / 4);
     hipLaunchKernelGGL(colsum_part_kernel, dim3(ceil_div(C, 64), by), dim3(256), 0, st, x, R, C, (int64_t)C, part);
-    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float*)part, by, (int64_t)C, C, out, accumulate);
+    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, st, (const float*)part, by, (int64_t)C, C, out, accumulate);
     return check_launch("fusion bias gradient");
 }
 
@@ -206,8 +206,8 @@ static int ln_bwd(const float* dy, const float* t, const float* stats, const flo
                   float kscale, float* dt, float* dtm, float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t st) {
     const int blocks = (int)std::min<int64_t>(kRedBlocks, (R + 3) / 4);
     SNAG_NU(ln_bwd_kernel, D, dim3(blocks), st, dy, t, stats, g, R, D, keep, kscale, dt, dtm, part);
-    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, st, (const float*)part, blocks, (int64_t)2 * D, D, dgamma, accumulate);
-    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, st, (const float*)part + D, blocks, (int64_t)2 * D, D, dbeta, accumulate);
+    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(D, 64)), dim3(1024), 0, st, (const float*)part, blocks, (int64_t)2 * D, D, dgamma, accumulate);
+    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(D, 64)), dim3(1024), 0, st, (const float*)part + D, blocks, (int64_t)2 * D, D, dbeta, accumulate);
     return check_launch("fusion LayerNorm backward");
 }
 

@@ -291,14 +291,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-// out[c] (=|+=) sum over blocks of part[block][c], fixed order
-static __global__ __launch_bounds__(256) void slab_colsum_kernel(const float* __restrict__ part, int nblocks, int64_t stride, int ncol,
-                                                          float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= ncol) return;
+// out[c] (=|+=) sum over blocks of part[block][c].  16 waves each add a contiguous run of partials for
+// 64 columns, then the 16 sub-sums are combined in wave order: deterministic, and 16x shorter than one
+// serial chain per column.
+static __global__ __launch_bounds__(1024) void slab_colsum_kernel(const float* __restrict__ part, int nblocks, int64_t stride, int ncol,
+                                                                   float* __restrict__ out, int accumulate) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wave = wave_id_uniform();
+    const int c = blockIdx.x * 64 + lane;
+    const int per = (nblocks + 15) / 16;
+    const int b0 = wave * per, b1 = min(nblocks, b0 + per);
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * stride + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < ncol)
+        for (int b = b0; b < b1; ++b) s += part[(int64_t)b * stride + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < ncol) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w][lane];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // column sums of a [R, C] matrix (bias gradients): part[blockIdx.y][c]

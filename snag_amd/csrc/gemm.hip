@@ -71,7 +71,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const int64_t total = (int64_t)epi.M * epi.N;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
-        for (int z = 0; z < splits; ++z) v += slab[(int64_t)z * total + i];
+        int z = 0;
+        for (; z + 8 <= splits; z += 8) {           // eight independent loads in flight, summed in slab order
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = slab[(int64_t)(z + u) * total + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; z < splits; ++z) v += slab[(int64_t)z * total + i];
         epi((int)(i / epi.N), (int)(i % epi.N), v);
     }
 }
@@ -88,11 +96,21 @@ static void launch_cfg(const GemmOperands& p, const Epilogue& e, float* slab, in
 #undef SNAG_GEMM
 }
 
+// Split K when the output tiles alone leave the chip under-filled: with one 4-wave block per CU only one
+// 12-16 KB tile is in flight per CU and the loop runs at HBM latency, not bandwidth; ~4 co-resident
+// blocks per CU hide it.  Each split keeps at least kMinKTiles k-tiles of work.
+static constexpr int kTargetBlocks = 1024, kMinKTiles = 16;
+
+static int pick_splits(int64_t tiles, int K) {
+    if (tiles >= kTargetBlocks / 2) return 1;
+    const int64_t want = (kTargetBlocks + tiles - 1) / tiles;
+    const int64_t cap = std::max<int64_t>(1, K / (kMinKTiles * kBK));
+    return (int)std::min(want, cap);
+}
+
 int64_t gemm_workspace_floats(int M, int N, int K) {
-    // worst case the heuristic below can ask for
     const int64_t tiles = (int64_t)ceil_div(M, 64) * ceil_div(N, 128);
-    if (tiles >= 128 || K <= 4 * kBK) return 0;
-    int splits = (int)std::min<int64_t>(512 / tiles, (int64_t)ceil_div(K, 2 * kBK));
+    const int splits = pick_splits(tiles, K);
     return splits > 1 ? (int64_t)splits * M * N : 0;
 }
 
@@ -112,8 +130,8 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     const int64_t tiles = big ? big_tiles : (int64_t)ceil_div(p.M, 64) * ceil_div(p.N, 128);
     // split K when the output alone cannot fill 256 CUs (the dW = dY^T X shapes: tiny output, long K)
     int splits = 1;
-    if (d->workspace != nullptr && tiles < 128 && p.K > 4 * kBK) {
-        splits = (int)std::min<int64_t>(512 / tiles, (int64_t)ceil_div(p.K, 2 * kBK));
+    if (d->workspace != nullptr && !big) {
+        splits = pick_splits(tiles, p.K);
         const int64_t cap = d->workspace_floats / ((int64_t)p.M * p.N);
         if (splits > cap) splits = (int)cap;
         if (splits < 1) splits = 1;

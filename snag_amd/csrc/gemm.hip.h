@@ -15,6 +15,15 @@
 namespace snag {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+// LDS-qualified pointers: through a generic float* the compiler falls back to flat_load/flat_store, which
+// count on vmcnt AND lgkmcnt, so every operand fetch would also wait for the global prefetch in flight.
+#if defined(__HIP_DEVICE_COMPILE__)
+using lds_float = __attribute__((address_space(3))) float;
+using lds_float4 = __attribute__((address_space(3))) float4;
+#else   // the host pass only needs the code to parse
+using lds_float = float;
+using lds_float4 = float4;
+#endif
 
 constexpr int kBK = 16;
 
@@ -80,7 +89,7 @@ struct Stager {
 
     // tile is k-major: tile[k * LD + row]
     template <int LD>
-    __device__ __forceinline__ void store(float* __restrict__ tile, int tid) const {
+    __device__ __forceinline__ void store(lds_float* tile, int tid) const {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int slot = tid + 256 * s;
@@ -94,7 +103,7 @@ struct Stager {
             } else {
                 const int row = (slot % (BR / 4)) * 4;
                 const int k = slot / (BR / 4);
-                *reinterpret_cast<float4*>(tile + k * LD + row) = r[s];
+                *reinterpret_cast<lds_float4*>(tile + k * LD + row) = r[s];
             }
         }
     }
@@ -123,8 +132,8 @@ struct GemmCore {
         const int lane = tid & 63;
         const int wave = wave_id_uniform();
         const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
-        float* As[2] = {smem, smem + kBK * LDA};
-        float* Bs[2] = {smem + 2 * kBK * LDA, smem + 2 * kBK * LDA + kBK * LDB};
+        lds_float* const sm = (lds_float*)smem;
+        constexpr int A_BUF = kBK * LDA, B_BUF = kBK * LDB, B_BASE = 2 * kBK * LDA;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -138,8 +147,8 @@ struct GemmCore {
         if (nk <= 0) return;
         sa.load(p.A, p.lda, p.a_vec, m0, p.M, kbeg, kend, tid);
         sb.load(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, kend, tid);
-        sa.template store<LDA>(As[0], tid);
-        sb.template store<LDB>(Bs[0], tid);
+        sa.template store<LDA>(sm, tid);
+        sb.template store<LDB>(sm + B_BASE, tid);
         __syncthreads();
         const int li = lane & 31, lh = lane >> 5;
         for (int kt = 0; kt < nk; ++kt) {
@@ -148,8 +157,8 @@ struct GemmCore {
                 sa.load(p.A, p.lda, p.a_vec, m0, p.M, kbeg + (kt + 1) * kBK, kend, tid);
                 sb.load(p.B, p.ldb, p.b_vec, n0, p.N, kbeg + (kt + 1) * kBK, kend, tid);
             }
-            const float* a = As[cur] + lh * LDA + wm0 + li;
-            const float* b = Bs[cur] + lh * LDB + wn0 + li;
+            const lds_float* a = sm + cur * A_BUF + lh * LDA + wm0 + li;
+            const lds_float* b = sm + B_BASE + cur * B_BUF + lh * LDB + wn0 + li;
 #pragma unroll
             for (int s = 0; s < kBK / 2; ++s) {
                 float av[TM], bv[TN];
@@ -164,8 +173,8 @@ struct GemmCore {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
             }
             if (kt + 1 < nk) {
-                sa.template store<LDA>(As[cur ^ 1], tid);
-                sb.template store<LDB>(Bs[cur ^ 1], tid);
+                sa.template store<LDA>(sm + (cur ^ 1) * A_BUF, tid);
+                sb.template store<LDB>(sm + B_BASE + (cur ^ 1) * B_BUF, tid);
             }
             __syncthreads();
         }
@@ -182,7 +191,7 @@ struct GemmCore {
         const int lane = threadIdx.x & 63;
         const int wave = wave_id_uniform();
         const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
-        float* stage = smem + wave * (32 * WN);
+        lds_float* stage = (lds_float*)smem + wave * (32 * WN);
         const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {

@@ -249,7 +249,7 @@ extern "C" SNAG_API int snag_colsum(const float* x, int64_t R, int C, int64_t ld
     hipStream_t st = (hipStream_t)stream;
     const int by = (int)std::max<int64_t>(1, std::min<int64_t>(256, (R + 3) / 4));
     hipLaunchKernelGGL(colsum_part_kernel, dim3(ceil_div(C, 64), by), dim3(256), 0, st, x, R, C, ld, work);
-    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float*)work, by, (int64_t)C, C, out, accumulate);
+    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, st, (const float*)work, by, (int64_t)C, C, out, accumulate);
     return check_launch("snag_colsum");
 }
 

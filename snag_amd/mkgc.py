@@ -128,8 +128,8 @@ class MKGCHotPath:
         self.save = torch.empty(lib.snag_fusion_save_floats(N, M, D, cfg.num_heads, I, L, int(ffn)), device=dev)
         ws = lib.snag_fusion_work_floats(N, M, D, cfg.num_heads, I, L, int(ffn))
         for fd in cfg.feat_dims:
-            ws = max(ws, lib.snag_gemm_workspace_floats(D, fd, N) + 64, 256 * max(D, fd))
-        ws = max(ws, lib.snag_gemm_workspace_floats(D, D, N) + 64)
+            ws = max(ws, lib.snag_gemm_workspace_floats(D, fd, N) + 64, lib.snag_gemm_workspace_floats(N, D, fd) + 64, 256 * max(D, fd))
+        ws = max(ws, lib.snag_gemm_workspace_floats(D, D, N) + 64, lib.snag_gemm_workspace_floats(N, D, D) + 64)
         self.work = torch.empty(ws, device=dev)
         H = cfg.num_heads
         self.keep_probs = [torch.ones(N, H, M, M, device=dev, dtype=torch.uint8) for _ in range(L)]
@@ -145,6 +145,7 @@ class MKGCHotPath:
         self.noise_active = False
         self.noise_epoch = 0
         self.training = True
+        self.probe = None                # optional {tag: timer with .wrap(fn)}: bench.py's per-kernel HIP-event timers
         self._loss_part = None
         self.loss = torch.zeros((), device=dev)
         self._build_descs()
@@ -233,7 +234,7 @@ class MKGCHotPath:
 
     # ------------------------------------------------------------------------------------------
     def _gemm(self, M, N, K, A, lda, akc, B, ldb, bkc, C, ldc, *, bias=None, act=0, pre=None, add1=None, ld1=0,
-              aux=None, ldaux=0, splitk=False):
+              aux=None, ldaux=0, splitk=True):
         d = _lib.GemmDesc()
         d.M, d.N, d.K = M, N, K
         d.a_kcontig, d.b_kcontig = int(akc), int(bkc)
@@ -244,6 +245,10 @@ class MKGCHotPath:
         if splitk:
             d.workspace, d.workspace_floats = ptr(self.work), self.work.numel()
         call("snag_gemm_f32", ctypes.byref(d), self._st)
+
+    def _probed(self, tag, fn, *a, **k):
+        tm = self.probe.get(tag) if self.probe else None
+        return tm.wrap(fn)(*a, **k) if tm is not None else fn(*a, **k)
 
     def update_noise(self, seed: Optional[int] = None):
         """Once per epoch (README "noise-level: epoch", main.py:253-254 -> SNAG.update_noise model/SNAG.py:86-98)."""
@@ -283,7 +288,8 @@ class MKGCHotPath:
             if cfg.num_proj == 1:
                 self._gemm(N, D, fd, ptr(feat), fd, 1, ptr(self.p[f"proj{i}.weight"]), fd, 1, slot, MD, bias=ptr(self.p[f"proj{i}.bias"]))
             else:   # ProjectionHead: Linear(no bias) -> ReLU -> Linear(no bias)   (model/layers.py:135-148)
-                self._gemm(N, D, fd, ptr(feat), fd, 1, ptr(self.p[f"proj{i}.l1"]), fd, 1, ptr(self.mid[i]), D, act=1)
+                self._probed("proj_l1_fwd" if i == 0 else "", self._gemm, N, D, fd, ptr(feat), fd, 1, ptr(self.p[f"proj{i}.l1"]), fd, 1,
+                             ptr(self.mid[i]), D, act=1)
                 self._gemm(N, D, D, ptr(self.mid[i]), D, 1, ptr(self.p[f"proj{i}.l2"]), D, 1, slot, MD)
         call("snag_entity_token_fwd", ptr(self.p["ent"]), N, D, ptr(self.ent_noise) if noisy else None,
              ptr(self.ent_noise_mask) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD, st)
@@ -305,8 +311,8 @@ class MKGCHotPath:
             self._pos = torch.empty(B, device=self.dev)
             self._neg = torch.empty(B, K, device=self.dev)
         ib = 4 if h.dtype == torch.int32 else 8
-        call("snag_score_margin_fwd", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r), ptr(t), ptr(neg_t),
-             ib, B, K, float(cfg.margin), ptr(self._pos), ptr(self._neg), ptr(self._loss_part), st)
+        self._probed("score_fwd", call, "snag_score_margin_fwd", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r),
+                     ptr(t), ptr(neg_t), ib, B, K, float(cfg.margin), ptr(self._pos), ptr(self._neg), ptr(self._loss_part), st)
         call("snag_reduce_sum", ptr(self._loss_part), B, ptr(self.loss), st)
         self._batch = (h, r, t, neg_t, ib, B, K)
         if want_scores:

@@ -1,0 +1,56 @@
+"""Data parallelism for the MKGC hot path: one process per GPU, batch (triples) sharded, one
+all-reduce of the flat gradient buffer per step over RCCL/xGMI (SURVEY.md par. 8e).
+
+The reference has no working distributed path (src/distributed_utils.py is imported by nothing);
+the only behaviour to match is "G-GPU loss/gradients equal the 1-GPU run on the same global
+batch", which holds because the margin loss is a SUM over triples (model/MSNEA.py:122): summing
+per-rank gradients of per-rank partial sums needs no division.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of n_items for `rank`; the first n_items % world ranks get one extra item."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_batch(tensors, rank: int, world: int):
+    """Slice every [B, ...] tensor of a batch to this rank's triples."""
+    B = tensors[0].shape[0]
+    lo, hi = shard_range(B, rank, world)
+    return tuple(t[lo:hi].contiguous() for t in tensors)
+
+
+class GradAllReduce:
+    """Sum a flat gradient buffer across ranks.
+
+    Payload at the DB15K shape is ~10 MB (7.7 MB entity table + projections + Mformer): on 8 fully
+    connected MI355X (7 xGMI links x ~153 GB/s each) that is latency-bound, so it goes out as ONE
+    collective on the compute stream's successor rather than per-tensor buckets.  `bucket_bytes`
+    splits larger payloads (config 5: 512 MB table) so that reduce-scatter/all-gather phases of
+    consecutive buckets overlap on the links.
+    """
+
+    def __init__(self, world: int, bucket_bytes: int = 256 << 20, group=None):
+        self.world = world
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.group = group
+
+    def __call__(self, flat: torch.Tensor):
+        if self.world <= 1:
+            return flat
+        n = flat.numel()
+        if n <= self.bucket_elems:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            return flat
+        works = []
+        for lo in range(0, n, self.bucket_elems):
+            works.append(dist.all_reduce(flat[lo:lo + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        return flat
