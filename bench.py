@@ -239,7 +239,7 @@ def main():
             us, n = timers["proj_l1_fwd"].mean_us()
             flops = 2.0 * N * cfg.feat_dims[0] * D
             ach = flops / (us * 1e-6) / 1e12 if us else 0.0
-            out["roofline"] = {"kernel": "gemm_f32_kernel (visual projection l1: [15000,4096]x[4096,128], exact-f32 MFMA)",
+            out["roofline"] = {"kernel": "gemm_tile_kernel (visual projection l1: [15000,4096]x[4096,128], exact-f32 MFMA)",
                                "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_us": us, "launches_timed": n,
                                "algorithmic_flops_per_launch": flops}

@@ -237,6 +237,37 @@ SNAG_API int snag_adamw_step(float* param, const float* grad, float* exp_avg, fl
  * whole training step be replayed without re-recording. */
 SNAG_API int snag_tick(uint64_t* tick, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * a8  Entity x entity similarity evaluation (the MMEA eval path).
+ * snag_row_sqnorm:    out[i] = |x_i|^2                               (src/utils.py:210-212)
+ * snag_pairwise_dist: out[i,j] = max(xn[i] + yn[j] - 2 x_i.y_j, 0)   (pairwise_distances, src/utils.py:202-218);
+ *                     as_similarity != 0 stores 1 - that (main.py:392).  The x.y^T product is the path's one
+ *                     dense entity x entity GEMM and runs on the exact-f32 matrix cores.
+ * snag_csls_neighbourhood: r1[i] = mean of the k largest S[i,:], r2[j] = mean of the k largest S[:,j]
+ *                     (csls_sim, src/utils.py:431-432), S = mat or 1 - mat (from_dist).  k <= 16.
+ *                     work: snag_eval_work_floats(n, m) floats.
+ * snag_csls_apply:    out = (2 S - r1[:,None]) - r2[None,:]          (src/utils.py:433-434)
+ * snag_rank_diagonal: rank_l2r[i] = #{j : D'[i,j] < D'[i,i]}, rank_r2l[j] = #{i : D'[i,j] < D'[j,j]} with
+ *                     D' = dist, or (r1/r2 given) 1 - ((2 (1 - dist) - r1) - r2): the position of the true
+ *                     match in the reference's ascending torch.sort (main.py:400-402,422-424) for tie-free rows.
+ * snag_rank_summary:  out[0..ntop) = #{rank < topk[q]}, out[ntop] = sum(rank+1), out[ntop+1] = sum 1/(rank+1)
+ *                     in double (main.py:403-407,430-436); the caller divides by n and rounds Hits to 4 dp.
+ * snag_argmin_rows_cols: arg-min of every row and column (ties -> smallest index): the mutual-nearest-
+ *                     neighbour test of SNAG.Iter_new_links (model/SNAG.py:200-204).  work as above.
+ */
+SNAG_API int snag_row_sqnorm(const float* x, int64_t n, int d, int64_t ld, float* out, void* stream);
+SNAG_API int snag_pairwise_dist(const float* x, int64_t ldx, int n, const float* y, int64_t ldy, int m, int d,
+                                const float* xn, const float* yn, float* out, int64_t ld_out, int as_similarity, void* stream);
+SNAG_API int64_t snag_eval_work_floats(int n, int m);
+SNAG_API int snag_csls_neighbourhood(const float* mat, int64_t ld, int n, int m, int k, int from_dist,
+                                     float* r1, float* r2, float* work, void* stream);
+SNAG_API int snag_csls_apply(const float* sim, int64_t ld, int n, int m, const float* r1, const float* r2, float* out, void* stream);
+SNAG_API int snag_rank_diagonal(const float* dist, int64_t ld, int n, int m, const float* r1, const float* r2,
+                                int32_t* rank_l2r, int32_t* rank_r2l, void* stream);
+SNAG_API int snag_rank_summary(const int32_t* rank, int n, const int32_t* topk, int ntop, double* out, void* stream);
+SNAG_API int snag_argmin_rows_cols(const float* dist, int64_t ld, int n, int m, int32_t* row_argmin, int32_t* col_argmin,
+                                   float* work, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,12 +76,19 @@ SIGNATURES = {
     "snag_entity_token_bwd": [_P, _L, _L, _I, _P, _F, _P, _I, _P],
     "snag_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _P, _F, _P],
     "snag_tick": [_P, _P],
+    "snag_row_sqnorm": [_P, _L, _I, _L, _P, _P],
+    "snag_pairwise_dist": [_P, _L, _I, _P, _L, _I, _I, _P, _P, _P, _L, _I, _P],
+    "snag_csls_neighbourhood": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P],
+    "snag_csls_apply": [_P, _L, _I, _I, _P, _P, _P, _P],
+    "snag_rank_diagonal": [_P, _L, _I, _I, _P, _P, _P, _P, _P],
+    "snag_rank_summary": [_P, _I, _P, _I, _P, _P],
+    "snag_argmin_rows_cols": [_P, _L, _I, _I, _P, _P, _P, _P],
     "snag_entity_token_fwd": [_P, _L, _I, _P, _P, _F, _P, _L, _P],
 }
 _SPECIAL = {"snag_version": ([], _I), "snag_last_error": ([], _c.c_char_p),
             "snag_gemm_workspace_floats": ([_I, _I, _I], _L),
             "snag_fusion_save_floats": ([_I] * 7, _L), "snag_fusion_work_floats": ([_I] * 7, _L),
-            "snag_colstats_work_floats": ([_I], _L)}
+            "snag_colstats_work_floats": ([_I], _L), "snag_eval_work_floats": ([_I, _I], _L)}
 
 _lib = None
 

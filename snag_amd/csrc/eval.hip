@@ -1,0 +1,398 @@
+// a8: entity x entity similarity evaluation.
+// reference: pairwise_distances src/utils.py:202-218, csls_sim :417-435, Runner._test main.py:376-436,
+// SNAG.Iter_new_links model/SNAG.py:192-208.
+//
+//   Dist[i,j] = max(|x_i|^2 + |y_j|^2 - 2 x_i.y_j, 0)            (the one MFMA GEMM of the path)
+//   CSLS:  r1[i] = mean top-k_j S[i,:], r2[j] = mean top-k_i S[:,j], S = 1 - Dist,
+//          Dist'[i,j] = 1 - ((2 S[i,j] - r1[i]) - r2[j])            (same operation order as the reference)
+//   rank_l2r[i] = #{j : Dist'[i,j] < Dist'[i,i]} ; rank_r2l[j] = #{i : Dist'[i,j] < Dist'[j,j]}
+//
+// The distance matrix is stored once (n x m fp32; 441 MB at the DBP15K shape is nothing on 288 GB) and
+// swept twice (top-k pass, rank pass); every sweep reads whole rows with lane = column.
+#include <algorithm>
+
+#include "gemm.hip.h"
+
+namespace snag {
+
+constexpr int kMaxK = 16;     // csls_k: config.py:65 default 10, run_snag.sh:17 uses 3
+
+// ---- |x_i|^2 -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict__ x, int64_t n, int d, int64_t ld, float* __restrict__ out) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (row >= n) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float v = x[row * ld + c];
+        s = fmaf(v, v, s);
+    }
+    s = sum64(s);
+    if (lane == 0) out[row] = s;
+}
+
+// ---- distance epilogue of the similarity GEMM ------------------------------------------------------
+struct DistEpilogue {
+    float* out;
+    int64_t ld;
+    const float* xn;
+    const float* yn;
+    int M, N;
+    int as_similarity;    // store 1 - dist instead of dist
+    int vec;              // dwordx4 stores legal (out and ld 16-byte aligned)
+    __device__ __forceinline__ float one(int m, int n, float acc) const {
+        float v = fmaxf((xn[m] + yn[n]) - 2.0f * acc, 0.f);      // src/utils.py:217-218
+        return as_similarity ? 1.0f - v : v;
+    }
+    __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
+        if (m >= M || n >= N) return;
+        float* o = out + (int64_t)m * ld + n;
+        if (vec && n + 3 < N) {
+            *reinterpret_cast<float4*>(o) = make_float4(one(m, n, v.x), one(m, n + 1, v.y), one(m, n + 2, v.z), one(m, n + 3, v.w));
+        } else {
+            o[0] = one(m, n, v.x);
+            if (n + 1 < N) o[1] = one(m, n + 1, v.y);
+            if (n + 2 < N) o[2] = one(m, n + 2, v.z);
+            if (n + 3 < N) o[3] = one(m, n + 3, v.w);
+        }
+    }
+};
+
+// ---- small sorted top-k buffer in registers ----------------------------------------------------------
+struct TopK {
+    float v[kMaxK];     // descending; slots >= k stay at -inf
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < kMaxK; ++i) v[i] = -INFINITY;
+    }
+    __device__ __forceinline__ void push(float x, int k) {
+#pragma unroll
+        for (int i = 0; i < kMaxK; ++i) {       // insertion by compare-exchange down the array
+            if (i < k) {
+                const float hi = fmaxf(v[i], x), lo = fminf(v[i], x);
+                v[i] = hi;
+                x = lo;
+            }
+        }
+    }
+};
+
+// mean of the k largest entries of each row of S (or of 1 - D when from_dist): one block per row
+__global__ __launch_bounds__(256) void row_topk_mean_kernel(const float* __restrict__ mat, int64_t ld, int n, int m, int k, int from_dist,
+                                                            float* __restrict__ out) {
+    __shared__ float cand[256 * kMaxK];
+    __shared__ float wmax[4];
+    __shared__ int wpos[4];
+    const int row = blockIdx.x;
+    TopK t;
+    t.init();
+    for (int c = threadIdx.x; c < m; c += 256) {
+        float s = mat[(int64_t)row * ld + c];
+        if (from_dist) s = 1.0f - s;
+        t.push(s, k);
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxK; ++i)
+        if (i < k) cand[threadIdx.x * k + i] = t.v[i];
+    __syncthreads();
+    // k rounds of block-wide arg-max over the 256*k candidates (ties: any equal value gives the same sum)
+    const int total = 256 * k;
+    float acc = 0.f;
+    for (int round = 0; round < k; ++round) {
+        float best = -INFINITY;
+        int pos = -1;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const float c = cand[i];
+            if (c > best) { best = c; pos = i; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ob = __shfl_xor(best, off);
+            const int op = __shfl_xor(pos, off);
+            if (ob > best || (ob == best && op >= 0 && (pos < 0 || op < pos))) { best = ob; pos = op; }
+        }
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { wmax[wave] = best; wpos[wave] = pos; }
+        __syncthreads();
+        float b = wmax[0];
+        int p = wpos[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (wmax[w] > b || (wmax[w] == b && wpos[w] >= 0 && (p < 0 || wpos[w] < p))) { b = wmax[w]; p = wpos[w]; }
+        acc += b;                                   // descending order, like sum(topk(...)[0])
+        __syncthreads();
+        if (threadIdx.x == 0 && p >= 0) cand[p] = -INFINITY;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[row] = acc / (float)k;
+}
+
+// per-column partial top-k over a chunk of rows: part[chunk][i][col], i < k
+__global__ __launch_bounds__(256) void col_topk_part_kernel(const float* __restrict__ mat, int64_t ld, int n, int m, int k, int from_dist,
+                                                            int rows_per_chunk, float* __restrict__ part) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= m) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+    TopK t;
+    t.init();
+    for (int r = r0; r < r1; ++r) {
+        float s = mat[(int64_t)r * ld + col];
+        if (from_dist) s = 1.0f - s;
+        t.push(s, k);
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxK; ++i)
+        if (i < k) part[((int64_t)blockIdx.y * k + i) * m + col] = t.v[i];
+}
+
+__global__ __launch_bounds__(256) void col_topk_merge_kernel(const float* __restrict__ part, int chunks, int m, int k, float* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= m) return;
+    TopK t;
+    t.init();
+    for (int c = 0; c < chunks; ++c)
+        for (int i = 0; i < k; ++i) t.push(part[((int64_t)c * k + i) * m + col], k);
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxK; ++i)
+        if (i < k) acc += t.v[i];
+    out[col] = acc / (float)k;
+}
+
+// the value the ranks compare: Dist' (CSLS) or Dist
+__device__ __forceinline__ float eval_dist(float d, float r1, float r2, int csls) {
+    if (!csls) return d;
+    const float s = 1.0f - d;                          // main.py:392  (1 - distance)
+    return 1.0f - ((2.0f * s - r1) - r2);              // utils.py:433-434 then main.py:392
+}
+
+// out[i,j] = 2 S[i,j] - r1[i] - r2[j]   (csls_sim as a free function, src/utils.py:417-435)
+__global__ __launch_bounds__(256) void csls_apply_kernel(const float* __restrict__ sim, int64_t ld, int n, int m, const float* __restrict__ r1,
+                                                         const float* __restrict__ r2, float* __restrict__ out) {
+    const int64_t total = (int64_t)n * m;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / m), c = (int)(i % m);
+        out[i] = (2.0f * sim[(int64_t)r * ld + c] - r1[r]) - r2[c];
+    }
+}
+
+// rank_l2r[i] = #{j : D'[i,j] < D'[i,i]} : one block per row
+__global__ __launch_bounds__(256) void rank_rows_kernel(const float* __restrict__ dist, int64_t ld, int n, int m, const float* __restrict__ r1,
+                                                        const float* __restrict__ r2, int csls, int* __restrict__ rank) {
+    __shared__ int red[4];
+    const int row = blockIdx.x;
+    if (row >= m) {                                   // no diagonal element for this row
+        if (threadIdx.x == 0) rank[row] = -1;
+        return;
+    }
+    const float a = csls ? r1[row] : 0.f;
+    const float ref = eval_dist(dist[(int64_t)row * ld + row], a, csls ? r2[row] : 0.f, csls);
+    int cnt = 0;
+    for (int c = threadIdx.x; c < m; c += 256) cnt += eval_dist(dist[(int64_t)row * ld + c], a, csls ? r2[c] : 0.f, csls) < ref ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) rank[row] = red[0] + red[1] + red[2] + red[3];
+}
+
+// rank_r2l[j] = #{i : D'[i,j] < D'[j,j]} : thread per column, rows in chunks, integer atomics (exact)
+__global__ __launch_bounds__(256) void rank_cols_kernel(const float* __restrict__ dist, int64_t ld, int n, int m, const float* __restrict__ r1,
+                                                        const float* __restrict__ r2, int csls, int rows_per_chunk, int* __restrict__ rank) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= m || col >= n) return;
+    const float b = csls ? r2[col] : 0.f;
+    const float ref = eval_dist(dist[(int64_t)col * ld + col], csls ? r1[col] : 0.f, b, csls);
+    const int r0 = blockIdx.y * rows_per_chunk, r1e = min(n, r0 + rows_per_chunk);
+    int cnt = 0;
+    for (int r = r0; r < r1e; ++r) cnt += eval_dist(dist[(int64_t)r * ld + col], csls ? r1[r] : 0.f, b, csls) < ref ? 1 : 0;
+    atomicAdd(rank + col, cnt);
+}
+
+// Hits@k counts, sum(rank+1), sum(1/(rank+1)) in double, fixed order  (main.py:400-407,430-436)
+__global__ __launch_bounds__(256) void rank_summary_kernel(const int* __restrict__ rank, int n, const int* __restrict__ topk, int ntop,
+                                                           double* __restrict__ out) {
+    __shared__ double red[256];
+    for (int q = 0; q < ntop + 2; ++q) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int r = rank[i];
+            if (q < ntop) s += r < topk[q] ? 1.0 : 0.0;
+            else if (q == ntop) s += (double)(r + 1);
+            else s += 1.0 / (double)(r + 1);
+        }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[q] = red[0];
+        __syncthreads();
+    }
+}
+
+// ---- arg-min per row / per column (Iter_new_links, model/SNAG.py:200-201); ties -> smallest index ----
+__global__ __launch_bounds__(256) void argmin_rows_kernel(const float* __restrict__ dist, int64_t ld, int n, int m, int* __restrict__ out) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int row = blockIdx.x;
+    float best = INFINITY;
+    int pos = 0x7fffffff;
+    for (int c = threadIdx.x; c < m; c += 256) {
+        const float v = dist[(int64_t)row * ld + c];
+        if (v < best) { best = v; pos = c; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off);
+        const int op = __shfl_xor(pos, off);
+        if (ob < best || (ob == best && op < pos)) { best = ob; pos = op; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = pos; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (bv[w] < best || (bv[w] == best && bi[w] < pos)) { best = bv[w]; pos = bi[w]; }
+        out[row] = pos;
+    }
+}
+
+__global__ __launch_bounds__(256) void argmin_cols_part_kernel(const float* __restrict__ dist, int64_t ld, int n, int m, int rows_per_chunk,
+                                                               float* __restrict__ pv, int* __restrict__ pi) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= m) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+    float best = INFINITY;
+    int pos = 0x7fffffff;
+    for (int r = r0; r < r1; ++r) {
+        const float v = dist[(int64_t)r * ld + col];
+        if (v < best) { best = v; pos = r; }
+    }
+    pv[(int64_t)blockIdx.y * m + col] = best;
+    pi[(int64_t)blockIdx.y * m + col] = pos;
+}
+
+__global__ __launch_bounds__(256) void argmin_cols_merge_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int chunks, int m,
+                                                                int* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= m) return;
+    float best = INFINITY;
+    int pos = 0x7fffffff;
+    for (int c = 0; c < chunks; ++c) {
+        const float v = pv[(int64_t)c * m + col];
+        const int p = pi[(int64_t)c * m + col];
+        if (v < best || (v == best && p < pos)) { best = v; pos = p; }
+    }
+    out[col] = pos;
+}
+
+static constexpr int kColChunks = 64;
+
+static void launch_dist_gemm(const GemmOperands& p, const DistEpilogue& e, hipStream_t st) {
+    const int64_t big_tiles = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128);
+    if (big_tiles >= 512) {
+        hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 64, 64, true, true, DistEpilogue>), dim3(ceil_div(p.N, 128), ceil_div(p.M, 128), 1),
+                           dim3(256), 0, st, p, e, (float*)nullptr);
+    } else {
+        hipLaunchKernelGGL((gemm_tile_kernel<64, 128, 32, 64, true, true, DistEpilogue>), dim3(ceil_div(p.N, 128), ceil_div(p.M, 64), 1),
+                           dim3(256), 0, st, p, e, (float*)nullptr);
+    }
+}
+
+}  // namespace snag
+
+using namespace snag;
+
+extern "C" SNAG_API int snag_row_sqnorm(const float* x, int64_t n, int d, int64_t ld, float* out, void* stream) {
+    SNAG_REQUIRE(n >= 0 && d >= 1 && ld >= d, SNAG_ERR_ARG, "row_sqnorm: bad sizes");
+    if (n == 0) return SNAG_OK;
+    SNAG_REQUIRE(x && out, SNAG_ERR_ARG, "row_sqnorm: null pointer");
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream, x, n, d, ld, out);
+    return check_launch("snag_row_sqnorm");
+}
+
+extern "C" SNAG_API int snag_pairwise_dist(const float* x, int64_t ldx, int n, const float* y, int64_t ldy, int m, int d, const float* xn,
+                                           const float* yn, float* out, int64_t ld_out, int as_similarity, void* stream) {
+    SNAG_REQUIRE(n >= 0 && m >= 0 && d >= 1 && ldx >= d && ldy >= d && ld_out >= m, SNAG_ERR_ARG, "pairwise_dist: bad sizes n=%d m=%d d=%d", n, m, d);
+    if (n == 0 || m == 0) return SNAG_OK;
+    SNAG_REQUIRE(x && y && xn && yn && out, SNAG_ERR_ARG, "pairwise_dist: null pointer");
+    GemmOperands p;
+    p.A = x; p.B = y; p.lda = ldx; p.ldb = ldy; p.M = n; p.N = m; p.K = d;
+    p.a_vec = (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    p.b_vec = (ldy % 4 == 0) && (((uintptr_t)y & 15) == 0);
+    p.k_per_split = ceil_div(d, kBK) * kBK;
+    DistEpilogue e{out, ld_out, xn, yn, n, m, as_similarity, (int)((ld_out % 4 == 0) && (((uintptr_t)out & 15) == 0))};
+    launch_dist_gemm(p, e, (hipStream_t)stream);
+    return check_launch("snag_pairwise_dist");
+}
+
+extern "C" SNAG_API int64_t snag_eval_work_floats(int n, int m) { return (int64_t)2 * kColChunks * kMaxK * std::max(n, m) + 64; }
+
+extern "C" SNAG_API int snag_csls_neighbourhood(const float* mat, int64_t ld, int n, int m, int k, int from_dist, float* r1, float* r2, float* work,
+                                                void* stream) {
+    SNAG_REQUIRE(n >= 1 && m >= 1 && ld >= m, SNAG_ERR_ARG, "csls: bad sizes");
+    SNAG_REQUIRE(k >= 1 && k <= kMaxK, SNAG_ERR_UNSUPPORTED, "csls: k=%d outside [1, %d]", k, kMaxK);
+    SNAG_REQUIRE(k <= n && k <= m, SNAG_ERR_ARG, "csls: k=%d larger than the matrix (%d x %d)", k, n, m);   // torch.topk raises too
+    SNAG_REQUIRE(mat && r1 && r2 && work, SNAG_ERR_ARG, "csls: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(row_topk_mean_kernel, dim3(n), dim3(256), 0, st, mat, ld, n, m, k, from_dist, r1);
+    const int chunks = std::min(kColChunks, n);
+    const int rpc = ceil_div(n, chunks);
+    const int nch = ceil_div(n, rpc);
+    hipLaunchKernelGGL(col_topk_part_kernel, dim3(ceil_div(m, 256), nch), dim3(256), 0, st, mat, ld, n, m, k, from_dist, rpc, work);
+    hipLaunchKernelGGL(col_topk_merge_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, st, (const float*)work, nch, m, k, r2);
+    return check_launch("snag_csls_neighbourhood");
+}
+
+extern "C" SNAG_API int snag_csls_apply(const float* sim, int64_t ld, int n, int m, const float* r1, const float* r2, float* out, void* stream) {
+    SNAG_REQUIRE(n >= 0 && m >= 0 && ld >= m, SNAG_ERR_ARG, "csls_apply: bad sizes");
+    if (n == 0 || m == 0) return SNAG_OK;
+    SNAG_REQUIRE(sim && r1 && r2 && out, SNAG_ERR_ARG, "csls_apply: null pointer");
+    const int64_t total = (int64_t)n * m;
+    hipLaunchKernelGGL(csls_apply_kernel, dim3((unsigned)std::min<int64_t>(8192, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sim, ld,
+                       n, m, r1, r2, out);
+    return check_launch("snag_csls_apply");
+}
+
+extern "C" SNAG_API int snag_rank_diagonal(const float* dist, int64_t ld, int n, int m, const float* r1, const float* r2, int32_t* rank_l2r,
+                                           int32_t* rank_r2l, void* stream) {
+    SNAG_REQUIRE(n >= 1 && m >= 1 && ld >= m, SNAG_ERR_ARG, "rank_diagonal: bad sizes");
+    SNAG_REQUIRE(n == m, SNAG_ERR_ARG, "rank_diagonal: the test pairs form a square matrix (n=%d, m=%d)", n, m);
+    SNAG_REQUIRE(dist && (rank_l2r || rank_r2l), SNAG_ERR_ARG, "rank_diagonal: null pointer");
+    SNAG_REQUIRE((r1 == nullptr) == (r2 == nullptr), SNAG_ERR_ARG, "rank_diagonal: r1 and r2 go together");
+    hipStream_t st = (hipStream_t)stream;
+    const int csls = r1 != nullptr;
+    if (rank_l2r) hipLaunchKernelGGL(rank_rows_kernel, dim3(n), dim3(256), 0, st, dist, ld, n, m, r1, r2, csls, rank_l2r);
+    if (rank_r2l) {
+        if (hipMemsetAsync(rank_r2l, 0, sizeof(int32_t) * m, st) != hipSuccess) return fail(SNAG_ERR_LAUNCH, "rank_diagonal: memset failed");
+        const int chunks = std::min(kColChunks, n);
+        const int rpc = ceil_div(n, chunks);
+        hipLaunchKernelGGL(rank_cols_kernel, dim3(ceil_div(m, 256), ceil_div(n, rpc)), dim3(256), 0, st, dist, ld, n, m, r1, r2, csls, rpc, rank_r2l);
+    }
+    return check_launch("snag_rank_diagonal");
+}
+
+extern "C" SNAG_API int snag_rank_summary(const int32_t* rank, int n, const int32_t* topk, int ntop, double* out, void* stream) {
+    SNAG_REQUIRE(rank && topk && out && n >= 1 && ntop >= 0 && ntop <= 8, SNAG_ERR_ARG, "rank_summary: bad arguments");
+    hipLaunchKernelGGL(rank_summary_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rank, n, topk, ntop, out);
+    return check_launch("snag_rank_summary");
+}
+
+extern "C" SNAG_API int snag_argmin_rows_cols(const float* dist, int64_t ld, int n, int m, int32_t* row_argmin, int32_t* col_argmin, float* work,
+                                              void* stream) {
+    SNAG_REQUIRE(n >= 1 && m >= 1 && ld >= m && dist, SNAG_ERR_ARG, "argmin: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (row_argmin) hipLaunchKernelGGL(argmin_rows_kernel, dim3(n), dim3(256), 0, st, dist, ld, n, m, row_argmin);
+    if (col_argmin) {
+        SNAG_REQUIRE(work != nullptr, SNAG_ERR_ARG, "argmin: column arg-min needs the work buffer");
+        const int chunks = std::min(kColChunks, n);
+        const int rpc = ceil_div(n, chunks);
+        const int nch = ceil_div(n, rpc);
+        float* pv = work;
+        int* pi = reinterpret_cast<int*>(work + (int64_t)kColChunks * m);
+        hipLaunchKernelGGL(argmin_cols_part_kernel, dim3(ceil_div(m, 256), nch), dim3(256), 0, st, dist, ld, n, m, rpc, pv, pi);
+        hipLaunchKernelGGL(argmin_cols_merge_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, st, (const float*)pv, (const int*)pi, nch, m, col_argmin);
+    }
+    return check_launch("snag_argmin_rows_cols");
+}

@@ -23,9 +23,9 @@ struct Epilogue {
     int64_t ld2;
     int accumulate;         // C += result instead of C = result
     int M, N;
+    int fast;               // host-decided: the dwordx4 path of operator()(m, n, float4) is legal
 
-    __device__ __forceinline__ void operator()(int m, int n, float v) const {
-        if (m >= M || n >= N) return;
+    __device__ __forceinline__ float one(int m, int n, float v) const {
         v *= alpha;
         if (bias) v += bias[n];
         if (pre) pre[(int64_t)m * ldc + n] = v;
@@ -41,30 +41,40 @@ struct Epilogue {
         if (mask) v = mask[(int64_t)m * N + n] ? v * mscale : 0.f;
         if (add1) v += add1[(int64_t)m * ld1 + n];
         if (add2) v += add2[(int64_t)m * ld2 + n];
+        return v;
+    }
+
+    __device__ __forceinline__ void operator()(int m, int n, float v) const {
+        if (m >= M || n >= N) return;
+        v = one(m, n, v);
         float* c = C + (int64_t)m * ldc + n;
         *c = accumulate ? *c + v : v;
     }
-};
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperands p, Epilogue epi, float* __restrict__ slab) {
-    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC>;
-    __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
-    Core core;
-    core.run(p, smem, m0, n0, kbeg, kend);
-    if (slab == nullptr) {
-        core.for_each(smem, m0, n0, epi);
-    } else {
-        float* s = slab + (int64_t)blockIdx.z * p.M * p.N;
-        const int M = p.M, N = p.N;
-        core.for_each(smem, m0, n0, [=](int m, int n, float v) {
-            if (m < M && n < N) s[(int64_t)m * N + n] = v;
-        });
+    // four consecutive columns n..n+3 of row m
+    __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
+        if (m >= M || n >= N) return;
+        if (fast && n + 3 < N) {
+            // fast: only bias / relu / one residual, 16-byte aligned rows (decided on the host)
+            v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+            if (bias) {
+                const float4 b = *reinterpret_cast<const float4*>(bias + n);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (add1) {
+                const float4 a = *reinterpret_cast<const float4*>(add1 + (int64_t)m * ld1 + n);
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            }
+            *reinterpret_cast<float4*>(C + (int64_t)m * ldc + n) = v;
+            return;
+        }
+        (*this)(m, n + 0, v.x);
+        (*this)(m, n + 1, v.y);
+        (*this)(m, n + 2, v.z);
+        (*this)(m, n + 3, v.w);
     }
-}
+};
 
 // sums the split-K slabs in slab order (deterministic) and applies the epilogue
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, Epilogue epi) {
@@ -88,7 +98,7 @@ template <int BM, int BN, int WM, int WN>
 static void launch_cfg(const GemmOperands& p, const Epilogue& e, float* slab, int splits, bool a_kc, bool b_kc, hipStream_t st) {
     dim3 grid(ceil_div(p.N, BN), ceil_div(p.M, BM), splits), block(256);
 #define SNAG_GEMM(AK, BK_)                                                                               \
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, AK, BK_>), grid, block, 0, st, p, e, slab)
+    hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN, AK, BK_, Epilogue>), grid, block, 0, st, p, e, slab)
     if (a_kc && b_kc) SNAG_GEMM(true, true);
     else if (a_kc && !b_kc) SNAG_GEMM(true, false);
     else if (!a_kc && b_kc) SNAG_GEMM(false, true);
@@ -123,6 +133,9 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     e.C = d->C; e.ldc = d->ldc; e.bias = d->bias; e.alpha = d->alpha; e.act = d->act; e.pre = d->pre_act;
     e.mask = d->keep_mask; e.mscale = d->keep_scale; e.add1 = d->add1; e.ld1 = d->ld1; e.add2 = d->add2; e.ld2 = d->ld2;
     e.accumulate = d->accumulate; e.M = d->M; e.N = d->N; e.aux = d->aux; e.ldaux = d->ldaux;
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    e.fast = !d->pre_act && !d->keep_mask && !d->add2 && !d->accumulate && d->act <= 1 && (d->ldc % 4 == 0) && al16(d->C) &&
+             (!d->bias || al16(d->bias)) && (!d->add1 || (al16(d->add1) && d->ld1 % 4 == 0));
 
     // tile choice: 128x128 when that already fills the chip, else 64x128 for twice the blocks
     const int64_t big_tiles = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128);

@@ -44,6 +44,9 @@ struct Stager {
     static_assert(BR * kBK % 1024 == 0, "tile must split evenly over 256 threads");
     float4 r[SLOTS];
 
+    // FULL: the whole k-tile lies inside [kbeg, kend) -> no k predicates; rows past the edge are clamped to the
+    // last valid row (their products land in accumulator rows/cols the epilogue discards).
+    template <bool FULL>
     __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int vec_ok, int row0, int nrows, int k0,
                                          int kend, int tid) {
 #pragma unroll
@@ -59,7 +62,11 @@ struct Stager {
             }
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (KC) {
-                if (row < nrows) {
+                if (FULL) {
+                    const float* g = P + (int64_t)min(row, nrows - 1) * ld + k;
+                    if (vec_ok) v = *reinterpret_cast<const float4*>(g);
+                    else v = make_float4(g[0], g[1], g[2], g[3]);
+                } else if (row < nrows) {
                     const float* g = P + (int64_t)row * ld + k;
                     if (vec_ok && k + 3 < kend) {
                         v = *reinterpret_cast<const float4*>(g);
@@ -71,7 +78,7 @@ struct Stager {
                     }
                 }
             } else {
-                if (k < kend) {
+                if (FULL || k < kend) {
                     const float* g = P + (int64_t)k * ld + row;
                     if (vec_ok && row + 3 < nrows) {
                         v = *reinterpret_cast<const float4*>(g);
@@ -145,8 +152,13 @@ struct GemmCore {
         Stager<BN, B_KC> sb;
         const int nk = (kend - kbeg + kBK - 1) / kBK;
         if (nk <= 0) return;
-        sa.load(p.A, p.lda, p.a_vec, m0, p.M, kbeg, kend, tid);
-        sb.load(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, kend, tid);
+        if (kbeg + kBK <= kend) {
+            sa.template load<true>(p.A, p.lda, p.a_vec, m0, p.M, kbeg, kend, tid);
+            sb.template load<true>(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, kend, tid);
+        } else {
+            sa.template load<false>(p.A, p.lda, p.a_vec, m0, p.M, kbeg, kend, tid);
+            sb.template load<false>(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, kend, tid);
+        }
         sa.template store<LDA>(sm, tid);
         sb.template store<LDB>(sm + B_BASE, tid);
         __syncthreads();
@@ -154,24 +166,33 @@ struct GemmCore {
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < nk) {
-                sa.load(p.A, p.lda, p.a_vec, m0, p.M, kbeg + (kt + 1) * kBK, kend, tid);
-                sb.load(p.B, p.ldb, p.b_vec, n0, p.N, kbeg + (kt + 1) * kBK, kend, tid);
+                const int k0 = kbeg + (kt + 1) * kBK;
+                if (k0 + kBK <= kend) {             // wave-uniform: only the last tile of a ragged K takes the slow path
+                    sa.template load<true>(p.A, p.lda, p.a_vec, m0, p.M, k0, kend, tid);
+                    sb.template load<true>(p.B, p.ldb, p.b_vec, n0, p.N, k0, kend, tid);
+                } else {
+                    sa.template load<false>(p.A, p.lda, p.a_vec, m0, p.M, k0, kend, tid);
+                    sb.template load<false>(p.B, p.ldb, p.b_vec, n0, p.N, k0, kend, tid);
+                }
             }
             const lds_float* a = sm + cur * A_BUF + lh * LDA + wm0 + li;
             const lds_float* b = sm + B_BASE + cur * B_BUF + lh * LDB + wn0 + li;
+            // all operand fragments of the k-tile first (one burst of ds_reads), then the MFMA chain
+            float av[kBK / 2][TM], bv[kBK / 2][TN];
 #pragma unroll
             for (int s = 0; s < kBK / 2; ++s) {
-                float av[TM], bv[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) av[i] = a[2 * s * LDA + 32 * i];
+                for (int i = 0; i < TM; ++i) av[s][i] = a[2 * s * LDA + 32 * i];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bv[j] = b[2 * s * LDB + 32 * j];
+                for (int j = 0; j < TN; ++j) bv[s][j] = b[2 * s * LDB + 32 * j];
+            }
+#pragma unroll
+            for (int s = 0; s < kBK / 2; ++s)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-            }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[i][j], 0, 0, 0);
             if (kt + 1 < nk) {
                 sa.template store<LDA>(sm + (cur ^ 1) * A_BUF, tid);
                 sb.template store<LDB>(sm + B_BASE + (cur ^ 1) * B_BUF, tid);
@@ -180,13 +201,13 @@ struct GemmCore {
         }
     }
 
-    // Visit every element of the block tile: f(row, col, value).  The accumulators take a trip through
-    // LDS (the tile buffers are free by now) so that a wave hands f() whole 256-byte row segments:
-    // lane = column, which makes the epilogue's loads and the C store fully coalesced and keeps the
-    // accumulator indices static (a runtime-indexed f32x16 would be demoted to scratch).
+    // Visit the block tile four columns at a time: f(row, col, float4).  The accumulators take a trip through
+    // LDS (the tile buffers are free by now) so that 16 lanes cover 256 contiguous bytes of one output row:
+    // the epilogue's loads and the C store are dwordx4 and fully coalesced, and the accumulator indices stay
+    // static (a runtime-indexed f32x16 would be demoted to scratch).
     template <class F>
     __device__ __forceinline__ void for_each(float* __restrict__ smem, int m0, int n0, F&& f) const {
-        static_assert(WN == 64, "one lane per column of the wave patch");
+        static_assert(WN == 64, "sixteen float4 lanes per row of the wave patch");
         static_assert(4 * 32 * WN <= SMEM_FLOATS, "staging fits in the tile buffers");
         const int lane = threadIdx.x & 63;
         const int wave = wave_id_uniform();
@@ -202,11 +223,47 @@ struct GemmCore {
                 for (int e = 0; e < 16; ++e)
                     stage[((e & 3) + 8 * (e >> 2) + 4 * lh) * WN + 32 * j + li] = acc[i][j][e];
             __syncthreads();
-            const int row0 = m0 + wm0 + 32 * i;
-            const int col = n0 + wn0 + lane;
-            for (int r = 0; r < 32; ++r) f(row0 + r, col, stage[r * WN + lane]);
+            const int row0 = m0 + wm0 + 32 * i + (lane >> 4);
+            const int col = n0 + wn0 + (lane & 15) * 4;
+#pragma unroll 2
+            for (int r = 0; r < 32; r += 4) {
+                const float4 v = *reinterpret_cast<const lds_float4*>(stage + (r + (lane >> 4)) * WN + (lane & 15) * 4);
+                f(row0 + r, col, v);
+            }
         }
     }
 };
+
+// One block = one BM x BN output tile (x one K split): main loop, then either the epilogue functor
+// epi(row, col, float4) or, for split-K, a raw store into this split's slab.
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, class Epi>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmOperands p, Epi epi, float* __restrict__ slab) {
+    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC>;
+    __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    Core core;
+    core.run(p, smem, m0, n0, kbeg, kend);
+    if (slab == nullptr) {
+        core.for_each(smem, m0, n0, epi);
+    } else {
+        float* s = slab + (int64_t)blockIdx.z * p.M * p.N;
+        const int M = p.M, N = p.N;
+        const bool vec = (N % 4) == 0;
+        core.for_each(smem, m0, n0, [=](int m, int n, float4 v) {
+            if (m >= M || n >= N) return;
+            float* o = s + (int64_t)m * N + n;
+            if (vec) {
+                *reinterpret_cast<float4*>(o) = v;
+            } else {
+                o[0] = v.x;
+                if (n + 1 < N) o[1] = v.y;
+                if (n + 2 < N) o[2] = v.z;
+                if (n + 3 < N) o[3] = v.w;
+            }
+        });
+    }
+}
 
 }  // namespace snag

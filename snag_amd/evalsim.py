@@ -1,0 +1,107 @@
+"""Similarity evaluation on the GPU behind the reference's function names.
+
+``pairwise_distances(x, y=None)`` and ``csls_sim(sim_mat, k)`` keep the signatures of
+src/utils.py:202 and :417 (imported by name into main.py:22); ``rank_metrics`` fuses what
+``Runner._test`` (main.py:376-436) does after ``joint_emb_generat``: distance -> CSLS -> rank of the true
+match per row and per column -> Hits@k / MR / MRR, without the 2 x 10,500 ``torch.sort`` + ``.item()``
+round trips; ``mutual_nearest`` is the distance part of ``SNAG.Iter_new_links`` (model/SNAG.py:192-208).
+"""
+import torch
+
+from . import _lib, ops
+from ._lib import call, ptr, stream
+
+f32 = torch.float32
+
+
+def _sqnorm(x):
+    out = torch.empty(x.shape[0], device=x.device, dtype=f32)
+    call("snag_row_sqnorm", ptr(x), x.shape[0], x.shape[1], x.stride(0), ptr(out), stream())
+    return out
+
+
+def pairwise_distances(x, y=None, as_similarity=False):
+    """dist[i,j] = clamp(|x_i|^2 + |y_j|^2 - 2 x_i.y_j, 0)  (src/utils.py:202-218)."""
+    ops._rows(x, "x")
+    if y is None:
+        y = x
+    ops._rows(y, "y")
+    if x.shape[1] != y.shape[1]:
+        raise ValueError(f"pairwise_distances: feature sizes differ ({x.shape[1]} vs {y.shape[1]})")
+    n, m, d = x.shape[0], y.shape[0], x.shape[1]
+    out = torch.empty(n, m, device=x.device, dtype=f32)
+    xn = _sqnorm(x)
+    yn = xn if y is x else _sqnorm(y)
+    call("snag_pairwise_dist", ptr(x), x.stride(0), n, ptr(y), y.stride(0), m, d, ptr(xn), ptr(yn), ptr(out), out.stride(0),
+         int(as_similarity), stream())
+    return out
+
+
+def _neighbourhood(mat, k, from_dist):
+    n, m = mat.shape
+    r1 = torch.empty(n, device=mat.device, dtype=f32)
+    r2 = torch.empty(m, device=mat.device, dtype=f32)
+    work = torch.empty(_lib.load().snag_eval_work_floats(n, m), device=mat.device, dtype=f32)
+    call("snag_csls_neighbourhood", ptr(mat), mat.stride(0), n, m, int(k), int(from_dist), ptr(r1), ptr(r2), ptr(work), stream())
+    return r1, r2
+
+
+def csls_sim(sim_mat, k):
+    """csls[i,j] = 2 S[i,j] - mean(topk_j S[i,:]) - mean(topk_i S[:,j])  (src/utils.py:417-435)."""
+    ops._rows(sim_mat, "sim_mat")
+    n, m = sim_mat.shape
+    r1, r2 = _neighbourhood(sim_mat, k, False)
+    out = torch.empty(n, m, device=sim_mat.device, dtype=f32)
+    call("snag_csls_apply", ptr(sim_mat), sim_mat.stride(0), n, m, ptr(r1), ptr(r2), ptr(out), stream())
+    return out
+
+
+def rank_metrics(emb_left, emb_right, csls_k=0, top_k=(1, 10, 50)):
+    """Runner._test after the gather/normalise: ranks, Hits@k (rounded to 4 dp), MR, MRR in both directions.
+
+    emb_left[i] and emb_right[i] are the i-th aligned test pair (``final_emb[test_left]``, ``final_emb[test_right]``,
+    main.py:386).  csls_k = 0 disables CSLS (``--csls`` off).
+    """
+    dist = pairwise_distances(emb_left, emb_right)
+    n, m = dist.shape
+    if n != m:
+        raise ValueError("rank_metrics: left and right must hold the same number of aligned rows")
+    dev = dist.device
+    r1 = r2 = None
+    if csls_k and csls_k > 0:
+        r1, r2 = _neighbourhood(dist, csls_k, True)
+    rl = torch.empty(n, device=dev, dtype=torch.int32)
+    rr = torch.empty(m, device=dev, dtype=torch.int32)
+    call("snag_rank_diagonal", ptr(dist), dist.stride(0), n, m, ptr(r1), ptr(r2), ptr(rl), ptr(rr), stream())
+    tk = torch.tensor(list(top_k), device=dev, dtype=torch.int32)
+    out = {"rank_l2r": rl, "rank_r2l": rr, "dist": dist}
+    for name, rk in (("l2r", rl), ("r2l", rr)):
+        summ = torch.empty(len(top_k) + 2, device=dev, dtype=torch.float64)
+        call("snag_rank_summary", ptr(rk), n, ptr(tk), len(top_k), ptr(summ), stream())
+        s = summ.cpu().tolist()
+        out[f"hits_{name}"] = [round(c / n, 4) for c in s[:len(top_k)]]          # main.py:435-436
+        out[f"mr_{name}"] = s[len(top_k)] / n
+        out[f"mrr_{name}"] = s[len(top_k) + 1] / n
+    return out
+
+
+def mutual_nearest(final_emb, left, right, chunk=None):
+    """Row / column arg-min of the left x right distance matrix and the mutual pairs (model/SNAG.py:195-204).
+
+    ``left`` / ``right`` are index tensors or lists into ``final_emb``.  The reference builds the matrix in 1000-row
+    chunks only to bound memory; one launch covers it here.  Returns (preds_l, preds_r, pairs) with ``pairs`` the
+    (left_id, right_id) list of mutual nearest neighbours.
+    """
+    dev = final_emb.device
+    li = torch.as_tensor(left, device=dev, dtype=torch.int64)
+    ri = torch.as_tensor(right, device=dev, dtype=torch.int64)
+    dist = pairwise_distances(final_emb[li].contiguous(), final_emb[ri].contiguous())
+    n, m = dist.shape
+    pl = torch.empty(n, device=dev, dtype=torch.int32)
+    pr = torch.empty(m, device=dev, dtype=torch.int32)
+    work = torch.empty(_lib.load().snag_eval_work_floats(n, m), device=dev, dtype=f32)
+    call("snag_argmin_rows_cols", ptr(dist), dist.stride(0), n, m, ptr(pl), ptr(pr), ptr(work), stream())
+    plc, prc = pl.cpu().tolist(), pr.cpu().tolist()
+    lic, ric = li.cpu().tolist(), ri.cpu().tolist()
+    pairs = [(lic[i], ric[p]) for i, p in enumerate(plc) if prc[p] == i]
+    return pl, pr, pairs

@@ -1,0 +1,90 @@
+"""GPU parity: similarity eval (distance GEMM, CSLS, ranks, Hits@k, mutual NN) vs golden G4/G5 and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import T, assert_close, load
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("name", ["d64", "d1200", "d64_nocsls"])
+def test_eval_golden(name):
+    from snag_amd import evalsim as E
+    z = load(f"g4_eval_{name}.npz")
+    final = O.nrm(T(z["emb"])).to(DEV)
+    left, right = T(z["left"], DEV), T(z["right"], DEV)
+    k = int(z["csls_k"])
+    xl, xr = final[left].contiguous(), final[right].contiguous()
+    assert_close(E.pairwise_distances(xl, xr), z["dist"], atol=1e-5, what="dist")          # 1e-4 bar, fp32 GEMM order differs
+    if k:
+        assert_close(E.csls_sim(1 - T(z["dist"], DEV), k), z["csls"], atol=1e-5, what="csls")
+    res = E.rank_metrics(xl, xr, csls_k=k)
+    assert np.array_equal(res["rank_l2r"].cpu().numpy(), z["rank_l2r"])                     # ranking indices: bit-exact
+    for d in ("l2r", "r2l"):
+        assert np.allclose(res[f"hits_{d}"], z[f"hits_{d}"], atol=1e-7), (res[f"hits_{d}"], z[f"hits_{d}"])
+        assert round(res[f"mr_{d}"], 3) == pytest.approx(float(z[f"mr_{d}_3dp"]), abs=1.1e-3)
+        assert round(res[f"mrr_{d}"], 3) == pytest.approx(float(z[f"mrr_{d}_3dp"]), abs=1.1e-3)
+
+
+def test_mutual_nearest_golden():
+    from snag_amd import evalsim as E
+    z = load("g5_il.npz")
+    _, _, pairs = E.mutual_nearest(T(z["final"], DEV), z["left"].tolist(), z["right"].tolist())
+    assert np.array_equal(np.array(pairs, dtype=np.int64), z["links"])
+
+
+@pytest.mark.parametrize("n,m,d,k", [(257, 300, 96, 3), (64, 64, 20, 10), (1000, 33, 128, 16), (5, 700, 7, 1)])
+def test_pieces_vs_oracle(n, m, d, k):
+    from snag_amd import evalsim as E
+    g = torch.Generator().manual_seed(n + m)
+    x, y = O.nrm(torch.randn(n, d, generator=g)), O.nrm(torch.randn(m, d, generator=g))
+    dist = E.pairwise_distances(x.to(DEV), y.to(DEV))
+    assert_close(dist, O.pairwise_distances(x, y), atol=1e-5)
+    if k <= min(n, m):
+        sim = 1 - O.pairwise_distances(x, y)
+        assert_close(E.csls_sim(sim.to(DEV), k), O.csls_sim(sim, k), atol=2e-6)
+    assert_close(E.pairwise_distances(x.to(DEV)), O.pairwise_distances(x), atol=1e-5)
+
+
+def test_config4_shape_properties():
+    """DBP15K ja_en eval shape (10,500 x 10,500 x 1,200, csls_k = 3): size-independent properties."""
+    from snag_amd import evalsim as E
+    n, d = 10500, 1200
+    g = torch.Generator().manual_seed(4)
+    left = torch.randn(n, d, generator=g)
+    right = left + 10.0 * torch.randn(n, d, generator=g)
+    xl, xr = O.nrm(left).to(DEV), O.nrm(right).to(DEV)
+    res = E.rank_metrics(xl, xr, csls_k=3)
+    rl, rr = res["rank_l2r"].cpu(), res["rank_r2l"].cpu()
+    assert int(rl.min()) >= 0 and int(rl.max()) < n and int(rr.min()) >= 0 and int(rr.max()) < n
+    assert 0.2 < res["hits_l2r"][0] < 1.0 and res["hits_l2r"][0] <= res["hits_l2r"][1] <= res["hits_l2r"][2]
+    # transposing the problem swaps the two directions exactly (integer ranks)
+    res_t = E.rank_metrics(xr, xl, csls_k=3)
+    assert torch.equal(res_t["rank_l2r"].cpu(), rr) and torch.equal(res_t["rank_r2l"].cpu(), rl)
+    # a simultaneous permutation of the pairs permutes the ranks
+    perm = torch.randperm(n, generator=g)
+    res_p = E.rank_metrics(xl[perm.to(DEV)].contiguous(), xr[perm.to(DEV)].contiguous(), csls_k=3)
+    assert torch.equal(res_p["rank_l2r"].cpu(), rl[perm])
+    # spot-check 64 rows against the oracle's count-less-than on the same distance matrix
+    dist = res["dist"]
+    dd = 1 - O.csls_sim(1 - dist.cpu(), 3)
+    rows = torch.arange(0, n, n // 64)[:64]
+    ref = (dd[rows] < dd[rows, rows].view(-1, 1)).sum(1)
+    assert torch.equal(rl[rows].long(), ref)
+    # MR/MRR consistent with ranks
+    assert res["mr_l2r"] == pytest.approx(float((rl.double() + 1).mean()), rel=1e-12)
+    assert res["mrr_r2l"] == pytest.approx(float((1 / (rr.double() + 1)).mean()), rel=1e-12)
+
+
+def test_eval_rejects_bad_input():
+    from snag_amd import evalsim as E, _lib
+    x = torch.zeros(4, 8, device=DEV)
+    with pytest.raises(ValueError):
+        E.pairwise_distances(x, torch.zeros(4, 9, device=DEV))
+    with pytest.raises(_lib.SnagHipError):
+        E.csls_sim(x, 17)                      # k > 16 unsupported, and > matrix like torch.topk
+    with pytest.raises(ValueError):
+        E.rank_metrics(x, torch.zeros(5, 8, device=DEV))
