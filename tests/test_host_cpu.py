@@ -1,0 +1,87 @@
+"""CPU: host-side logic of the drop-in modules (no compute: that needs the GPU and fails loudly without it)."""
+import types
+
+import pytest
+import torch
+
+from helpers import fusion_inputs, load
+
+
+def _args(D=128, H=2, L=1, ffn=0, I=400):
+    return types.SimpleNamespace(hidden_size=D, num_attention_heads=H, num_hidden_layers=L, use_intermediate=ffn, intermediate_size=I)
+
+
+def test_state_dict_keys_and_shapes_match_reference():
+    """SURVEY.md par. 8b: checkpoint keys/shapes, probed from the reference and stored in the golden files."""
+    from snag_amd.fusion import MformerFusion
+    for case, ffn, M in (("g1_fusion_m4_d128_h2_ffn.npz", 1, 4), ("g1_fusion_m3_d128_h2.npz", 0, 3)):
+        _, params, cfg = fusion_inputs(load(case))
+        sd = MformerFusion(_args(ffn=ffn), M).state_dict()
+        assert set(sd) == set(params)
+        for k, v in sd.items():
+            assert tuple(v.shape) == tuple(params[k].shape), k
+    assert sum(p.numel() for p in MformerFusion(_args(), 3).parameters()) == 117894
+
+
+def test_reference_checkpoint_loads():
+    from snag_amd.fusion import MformerFusion
+    _, params, cfg = fusion_inputs(load("g1_fusion_m3_d64_h4_l2.npz"))
+    mod = MformerFusion(_args(D=64, H=4, L=2, ffn=1, I=96), 3)
+    mod.load_state_dict(params, strict=True)
+    assert torch.equal(mod.fusion_layer[1].attention.self.key.weight, params["fusion_layer.1.attention.self.key.weight"])
+    assert torch.equal(mod.weight_raw, params["weight_raw"])
+
+
+def test_default_init_matches_reference_conventions():
+    from snag_amd.fusion import MformerFusion
+    mod = MformerFusion(_args(), 3)
+    assert torch.equal(mod.weight_raw, torch.ones(6))                                    # SNAG_tools.py:28
+    ln = mod.fusion_layer[0].attention.output.LayerNorm
+    assert ln.eps == 1e-12 and torch.equal(ln.weight, torch.ones(128)) and torch.equal(ln.bias, torch.zeros(128))
+    w = mod.fusion_layer[0].attention.self.query.weight
+    assert float(w.abs().max()) <= 1 / 128 ** 0.5 + 1e-6                                 # nn.Linear kaiming-uniform bound
+
+
+def test_constructor_errors_mirror_reference():
+    from snag_amd.fusion import MformerFusion
+    with pytest.raises(AssertionError):                  # reference: assert hidden_size % heads == 0 (SNAG_tools.py:161)
+        MformerFusion(_args(H=3), 3)
+    with pytest.raises(ValueError):
+        MformerFusion(_args(), 3, joint_way="nope")
+
+
+def test_no_cpu_fallback():
+    """Without a GPU every compute entry refuses loudly instead of silently running somewhere else."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from snag_amd import _lib, evalsim
+    from snag_amd.fusion import MformerFusion
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    mod = MformerFusion(_args(), 3)
+    with pytest.raises(_lib.SnagHipError):
+        mod([torch.zeros(4, 128)] * 3)
+    with pytest.raises(_lib.SnagHipError):
+        evalsim.pairwise_distances(torch.zeros(3, 4), torch.zeros(3, 4))
+    with pytest.raises(_lib.SnagHipError):
+        MKGCHotPath(MKGCConfig(n_ent=8, n_rel=2, feat_dims=[4, 4]), [torch.zeros(8, 4), torch.zeros(8, 4)])
+
+
+def test_product_never_imports_oracle():
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "snag_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_stacked_qkv_view_is_free_when_adjacent():
+    from snag_amd.fusion import _stacked
+    flat = torch.arange(3 * 4 * 4, dtype=torch.float32).view(12, 4)
+    q, k, v = flat[0:4], flat[4:8], flat[8:12]
+    s = _stacked([q, k, v])
+    assert s.data_ptr() == flat.data_ptr() and torch.equal(s, flat)
+    s2 = _stacked([q.clone(), k.clone(), v.clone()])
+    assert torch.equal(s2, flat)

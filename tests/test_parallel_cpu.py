@@ -1,0 +1,79 @@
+"""CPU (gloo, world_size 2): the data-parallel exchange -- batch sharding + one summed all-reduce of the flat
+gradient buffer -- reproduces the single-process gradient.  The oracle stands in for the HIP kernels here
+(no GPU in this container); the N>1 GPU path differs only in the backend string ("nccl" = RCCL)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_cpu as O
+from snag_amd.parallel import GradAllReduce, shard_batch, shard_range
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 1024, 1025):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    N, R, D, B, K = 60, 5, 16, 22, 4
+    ent = torch.randn(N, D, generator=g)
+    rel = torch.randn(R, D, generator=g)
+    batch = (torch.randint(0, N, (B,), generator=g), torch.randint(0, R, (B,), generator=g),
+             torch.randint(0, N, (B,), generator=g), torch.randint(0, N, (B, K), generator=g))
+    return ent, rel, batch
+
+
+def _flat_grad(ent, rel, batch):
+    e, r = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+    loss, _, _ = O.score_margin(e, r, *batch, 2.0)
+    loss.backward()
+    return torch.cat([e.grad.flatten(), r.grad.flatten()]), float(loss)
+
+
+def _worker(rank, world, port, bucket_bytes, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        ent, rel, batch = _make()
+        local = shard_batch(batch, rank, world)
+        flat, loss = _flat_grad(ent, rel, local)
+        GradAllReduce(world, bucket_bytes=bucket_bytes)(flat)
+        lt = torch.tensor([loss], dtype=torch.float64)
+        dist.all_reduce(lt)
+        if rank == 0:
+            torch.save({"flat": flat, "loss": float(lt)}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [1 << 20, 256])          # one collective / many async buckets
+def test_two_rank_allreduce_matches_single_process(tmp_path, bucket_bytes):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), bucket_bytes, out), nprocs=2, join=True)
+    got = torch.load(out)
+    ent, rel, batch = _make()
+    ref, ref_loss = _flat_grad(ent, rel, batch)
+    # the margin loss is a SUM over triples (MSNEA.py:122): summed shard gradients == full-batch gradient, no division
+    assert torch.allclose(got["flat"], ref, atol=1e-5, rtol=1e-5)
+    assert abs(got["loss"] - ref_loss) < 1e-3 * max(1.0, abs(ref_loss))
