@@ -176,6 +176,13 @@ def main():
     feats, batches = synth(cfg, args.batch, 8, cfg.seed, device)
     eng = MKGCHotPath(cfg, feats, device=device)
     reducer = GradAllReduce(world) if world > 1 else None
+    if os.environ.get("BENCH_FORCE_ALLREDUCE") and reducer is None:          # exercise the collective on a 1-GPU box
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        _g = GradAllReduce(2)
+        reducer = lambda flat: (dist.all_reduce(flat), flat)[1]
     gscale = 1.0                                           # loss is a SUM over triples (MSNEA.py:122): sharded sum needs no division
 
     timers = {}
@@ -248,6 +255,31 @@ def main():
             ach = bytes_ / (us * 1e-6) / 1e9 if us else 0.0
             out["score_kernel"] = {"kernel": "score_fwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": ach / HBM_PEAK_GBS, "avg_us": us, "launches_timed": n, "algorithmic_bytes_per_launch": bytes_}
+            # the same kernel on a whole epoch of triples in ONE launch (78 batches): the B=1024 launch above is
+            # launch-latency-bound (18.6 MB of gathers is ~2.3 us at 8 TB/s), see SURVEY.md par. 7 "hard parts"
+            from snag_amd import ops
+            Bep = STEPS_PER_EPOCH * args.batch
+            ge = torch.Generator().manual_seed(7)
+            hh, rr, tt, nn = (torch.randint(0, hi, sz, generator=ge, dtype=torch.int32).to(device)
+                              for hi, sz in ((N, (Bep,)), (cfg.n_rel, (Bep,)), (N, (Bep,)), (N, (Bep, cfg.neg_num))))
+            table = eng.hidden[:, eng.g_slot, :]
+            for _ in range(3):
+                ops.score_margin_fwd(table, eng.p["rel"], hh, rr, tt, nn, cfg.margin)
+            evs = []
+            for _ in range(10):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                pos_b = torch.empty(Bep, device=device); neg_b = torch.empty(Bep, cfg.neg_num, device=device); lp_b = torch.empty(Bep, device=device)
+                e0.record()
+                from snag_amd._lib import call as _call, ptr as _ptr, stream as _stream
+                _call("snag_score_margin_fwd", _ptr(table), table.stride(0), N, _ptr(eng.p["rel"]), cfg.n_rel, D, _ptr(hh), _ptr(rr), _ptr(tt),
+                      _ptr(nn), 4, Bep, cfg.neg_num, float(cfg.margin), _ptr(pos_b), _ptr(neg_b), _ptr(lp_b), _stream())
+                e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            us_ep = sum(a.elapsed_time(b) for a, b in evs) * 1e3 / len(evs)
+            by_ep = Bep * ((cfg.neg_num + 3) * D * 4 + (cfg.neg_num + 3) * 4 + (cfg.neg_num + 1) * 4)
+            out["score_kernel"]["epoch_fused"] = {"triples_per_launch": Bep, "avg_us": us_ep, "achieved": by_ep / (us_ep * 1e-6) / 1e9,
+                                                  "frac": by_ep / (us_ep * 1e-6) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": by_ep}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, [f.cpu() for f in feats], args.batch, args.cpu_seconds, cfg.seed)
         print(json.dumps(out))

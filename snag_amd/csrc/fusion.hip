@@ -78,7 +78,16 @@ static snag_gemm_desc gemm_desc(int M, int N, int K, const float* A, int64_t lda
     return d;
 }
 
-static constexpr int kRedBlocks = 256;   // fixed partial-sum fan-in for LayerNorm / bias / weight_raw gradients
+// stage[0:D] -> a, stage[D:2D] -> b, stage[2D:3D] -> c  (=|+=)
+static __global__ __launch_bounds__(256) void scatter3_kernel(const float* __restrict__ stage, int D, float* __restrict__ a, float* __restrict__ b,
+                                                              float* __restrict__ c, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 3 * D) return;
+    float* dst = i < D ? a + i : (i < 2 * D ? b + (i - D) : c + (i - 2 * D));
+    *dst = accumulate ? *dst + stage[i] : stage[i];
+}
+
+static constexpr int kRedBlocks = 1024;  // fixed partial-sum fan-in for LayerNorm / bias / weight_raw gradients
 
 static int check_fusion(const snag_fusion_desc* f) {
     SNAG_REQUIRE(f != nullptr, SNAG_ERR_ARG, "fusion: null descriptor");
@@ -170,7 +179,7 @@ static int64_t bwd_gemm_ws(int N, int M, int D, int I, bool ffn) {
 static int64_t work_floats(int N, int M, int D, int H, int I, bool ffn) {
     const int64_t NM = (int64_t)N * M;
     int64_t w = 3 * NM * D + NM * 3 * D + (ffn ? NM * I : 0) + (int64_t)N * H * M * M + NM * D;
-    w += (int64_t)kRedBlocks * 2 * std::max(3 * D, I) + 64;
+    w += (int64_t)kRedBlocks * 3 * std::max(3 * D, I) + 3 * D + 64;
     w += bwd_gemm_ws(N, M, D, I, ffn);
     return (w + 3) / 4 * 4 + 64;
 }
@@ -187,7 +196,7 @@ static Work carve(float* base, int N, int M, int D, int H, int I, bool ffn) {
     w.dx0e = p; p += NM * D;
     w.dpx = p; p += (int64_t)N * H * M * M;
     p += (4 - ((p - base) & 3)) & 3;
-    w.part = p; p += (int64_t)kRedBlocks * 2 * std::max(3 * D, I) + 64;
+    w.part = p; p += (int64_t)kRedBlocks * 3 * std::max(3 * D, I) + 3 * D + 64;
     p += (4 - ((p - base) & 3)) & 3;
     w.gemm_ws = p;
     w.gemm_ws_floats = bwd_gemm_ws(N, M, D, I, ffn);
@@ -196,18 +205,22 @@ static Work carve(float* base, int N, int M, int D, int H, int I, bool ffn) {
 
 // bias gradient: out[c] (=|+=) sum_r x[r, c]
 static int colsum(const float* x, int64_t R, int C, float* part, float* out, int accumulate, hipStream_t st) {
-    const int by = (int)std::min<int64_t>(kRedBlocks, (R + 3) / 4);
+    const int by = (int)std::min<int64_t>(256, (R + 3) / 4);
     hipLaunchKernelGGL(colsum_part_kernel, dim3(ceil_div(C, 64), by), dim3(256), 0, st, x, R, C, (int64_t)C, part);
     hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, st, (const float*)part, by, (int64_t)C, C, out, accumulate);
     return check_launch("fusion bias gradient");
 }
 
+// LayerNorm backward + the bias gradient of the dense layer in front of it (colsum of what flows into that dense)
 static int ln_bwd(const float* dy, const float* t, const float* stats, const float* g, int64_t R, int D, const uint8_t* keep,
-                  float kscale, float* dt, float* dtm, float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t st) {
+                  float kscale, float* dt, float* dtm, float* part, float* dgamma, float* dbeta, float* dbias, int accumulate,
+                  hipStream_t st) {
     const int blocks = (int)std::min<int64_t>(kRedBlocks, (R + 3) / 4);
     SNAG_NU(ln_bwd_kernel, D, dim3(blocks), st, dy, t, stats, g, R, D, keep, kscale, dt, dtm, part);
-    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(D, 64)), dim3(1024), 0, st, (const float*)part, blocks, (int64_t)2 * D, D, dgamma, accumulate);
-    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(D, 64)), dim3(1024), 0, st, (const float*)part + D, blocks, (int64_t)2 * D, D, dbeta, accumulate);
+    // part is [blocks][3][D]: one launch reduces the three rows as 3*D "columns" of stride 3*D into a staging row
+    float* stage = part + (int64_t)blocks * 3 * D;
+    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(3 * D, 64)), dim3(1024), 0, st, (const float*)part, blocks, (int64_t)3 * D, 3 * D, stage, 0);
+    hipLaunchKernelGGL(scatter3_kernel, dim3(ceil_div(3 * D, 256)), dim3(256), 0, st, (const float*)stage, D, dgamma, dbeta, dbias, accumulate);
     return check_launch("fusion LayerNorm backward");
 }
 
@@ -258,13 +271,12 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
         if (ffn) {
             // LN2 backward -> dA = dT2 (residual route to y1), dB = dT2 * keep (route into output.dense)
             float* dtm = P.keep_ffn_out ? W.dB : nullptr;
-            if ((rc = ln_bwd(dout, S.t2, S.st2, P.ln2_g, NM, D, P.keep_ffn_out, kscale, W.dA, dtm, W.part, G.ln2_g, G.ln2_b, acc, st))) return rc;
+            if ((rc = ln_bwd(dout, S.t2, S.st2, P.ln2_g, NM, D, P.keep_ffn_out, kscale, W.dA, dtm, W.part, G.ln2_g, G.ln2_b, G.b2, acc, st))) return rc;
             const float* dz = dtm ? dtm : W.dA;
             // dW2 = dz^T G ; db2 = colsum(dz)
             g = gemm_desc(D, I, (int)NM, dz, D, false, S.g, I, false, G.w2, I);
             g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
             if ((rc = gemm_dispatch(&g, st))) return rc;
-            if ((rc = colsum(dz, NM, D, W.part, G.b2, acc, st))) return rc;
             // dU = (dz W2) * gelu'(u)
             g = gemm_desc((int)NM, I, D, dz, D, true, P.w2, I, false, W.dU, I);
             g.act = 3; g.aux = S.u; g.ldaux = I;
@@ -282,25 +294,25 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
         }
         // LN1 backward -> dA = dT1 (residual route to the layer input), dB = dT1 * keep
         float* dtm = P.keep_attn_out ? W.dB : nullptr;
-        if ((rc = ln_bwd(dout, S.t1, S.st1, P.ln1_g, NM, D, P.keep_attn_out, kscale, W.dA, dtm, W.part, G.ln1_g, G.ln1_b, acc, st))) return rc;
+        if ((rc = ln_bwd(dout, S.t1, S.st1, P.ln1_g, NM, D, P.keep_attn_out, kscale, W.dA, dtm, W.part, G.ln1_g, G.ln1_b, G.bo, acc, st))) return rc;
         const float* dz = dtm ? dtm : W.dA;
         // dWo = dz^T ctx ; dbo
         g = gemm_desc(D, D, (int)NM, dz, D, false, S.ctx, D, false, G.wo, D);
         g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
         if ((rc = gemm_dispatch(&g, st))) return rc;
-        if ((rc = colsum(dz, NM, D, W.part, G.bo, acc, st))) return rc;
         // dctx = dz Wo   -> dC  (dout is dead from here on)
         g = gemm_desc((int)NM, D, D, dz, D, true, P.wo, D, false, W.dC, D);
         if ((rc = gemm_dispatch(&g, st))) return rc;
         // attention backward -> dqkv
-        SNAG_MNU(attn_bwd_kernel, M, D, egrid, st, (const float*)S.qkv, (const float*)W.dC, N, D, H, 1.0f / sqrtf((float)(D / H)), P.keep_probs,
-                 kscale, (l == L - 1) ? dpx : (const float*)nullptr, W.dqkv);
+        const int ablocks = (int)std::min<int64_t>(kRedBlocks, (N + 3) / 4);
+        SNAG_MNU(attn_bwd_kernel, M, D, dim3(ablocks), st, (const float*)S.qkv, (const float*)W.dC, N, D, H, 1.0f / sqrtf((float)(D / H)), P.keep_probs,
+                 kscale, (l == L - 1) ? dpx : (const float*)nullptr, W.dqkv, W.part);
+        hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(3 * D, 64)), dim3(1024), 0, st, (const float*)W.part, ablocks, (int64_t)3 * D, 3 * D, G.bqkv, acc);
         if ((rc = check_launch("fusion attention backward"))) return rc;
         // dWqkv = dqkv^T xin ; dbqkv
         g = gemm_desc(3 * D, D, (int)NM, W.dqkv, 3 * D, false, xin, D, false, G.wqkv, D);
         g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
         if ((rc = gemm_dispatch(&g, st))) return rc;
-        if ((rc = colsum(W.dqkv, NM, 3 * D, W.part, G.bqkv, acc, st))) return rc;
         // d(layer input) = dqkv Wqkv + dT1 (+ epilogue route at layer 0)
         float* dxin = (l == 0) ? b->d_x0 : W.dC;
         g = gemm_desc((int)NM, D, 3 * D, W.dqkv, 3 * D, true, P.wqkv, D, false, dxin, D);

@@ -127,11 +127,15 @@ template <int M, int NU>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx, int N,
                                                        int D, int H, float inv_sqrt_d, const uint8_t* __restrict__ keep,
                                                        float kscale, const float* __restrict__ dprobs_extra,
-                                                       float* __restrict__ dqkv) {
-    const int64_t n = (int64_t)blockIdx.x * 4 + wave_id_uniform();
-    if (n >= N) return;
+                                                       float* __restrict__ dqkv, float* __restrict__ bias_part) {
+    __shared__ float red[4][3][64 * NU];
     const int lane = threadIdx.x & 63;
+    const int wave = wave_id_uniform();
     const int d = D / H;
+    Cols<NU> sq, sk, sv;                 // running column sums of dQ, dK, dV over this wave's entities (bias gradient)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) sq.v[u] = sk.v[u] = sv.v[u] = 0.f;
+  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
     Cols<NU> q[M], k[M], v[M], go[M], dq[M], dk[M], dv[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) {
@@ -198,6 +202,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         st_cols<NU>(row, dq[i], D, lane);
         st_cols<NU>(row + D, dk[i], D, lane);
         st_cols<NU>(row + 2 * D, dv[i], D, lane);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            sq.v[u] += dq[i].v[u];
+            sk.v[u] += dk[i].v[u];
+            sv.v[u] += dv[i].v[u];
+        }
+    }
+  }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        red[wave][0][lane + 64 * u] = sq.v[u];
+        red[wave][1][lane + 64 * u] = sk.v[u];
+        red[wave][2][lane + 64 * u] = sv.v[u];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * 64 * NU; i += 256) {
+        const int which = i / (64 * NU), c = i % (64 * NU);
+        if (c < D) bias_part[(int64_t)blockIdx.x * 3 * D + which * D + c] = ((red[0][which][c] + red[1][which][c]) + red[2][which][c]) + red[3][which][c];
     }
 }
 
@@ -236,19 +258,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ t
 
 // dT = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)), dxhat = dY gamma.
 // Optional second output dTm = dT * keep * kscale (gradient w.r.t. the pre-dropout dense output).
-// Per-block partial sums of dgamma/dbeta go to part[block][2][D]; a second kernel adds them in order.
+// Per-block partial sums of dgamma / dbeta / colsum(dTm or dT) (= the bias gradient of the dense in front of
+// this LayerNorm) go to part[block][3][D]; a second kernel adds them in order.
 template <int NU>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ t,
                                                      const float* __restrict__ stats, const float* __restrict__ g, int64_t R,
                                                      int D, const uint8_t* __restrict__ keep, float kscale,
                                                      float* __restrict__ dt, float* __restrict__ dtm, float* __restrict__ part) {
-    __shared__ float red[4][2][64 * NU];
+    __shared__ float red[4][3][64 * NU];
     const int lane = threadIdx.x & 63;
     const int wave = wave_id_uniform();
     const Cols<NU> gg = ld_cols<NU>(g, D, lane);
-    Cols<NU> ag, ab;
+    Cols<NU> ag, ab, az;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) ag.v[u] = ab.v[u] = 0.f;
+    for (int u = 0; u < NU; ++u) ag.v[u] = ab.v[u] = az.v[u] = 0.f;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < R; row += (int64_t)gridDim.x * 4) {
         const Cols<NU> x = ld_cols<NU>(t + row * D, D, lane);
         const Cols<NU> gy = ld_cols<NU>(dy + row * D, D, lane);
@@ -275,19 +298,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int c = lane + 64 * u;
-                if (c < D) dtm[row * D + c] = keep[row * D + c] ? o.v[u] * kscale : 0.f;
+                const float z = (c < D && keep[row * D + c]) ? o.v[u] * kscale : 0.f;
+                if (c < D) dtm[row * D + c] = z;
+                az.v[u] += z;
             }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) az.v[u] += o.v[u];
         }
     }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         red[wave][0][lane + 64 * u] = ag.v[u];
         red[wave][1][lane + 64 * u] = ab.v[u];
+        red[wave][2][lane + 64 * u] = az.v[u];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * 64 * NU; i += 256) {
+    for (int i = threadIdx.x; i < 3 * 64 * NU; i += 256) {
         const int which = i / (64 * NU), c = i % (64 * NU);
-        if (c < D) part[((int64_t)blockIdx.x * 2 + which) * D + c] = ((red[0][which][c] + red[1][which][c]) + red[2][which][c]) + red[3][which][c];
+        if (c < D) part[((int64_t)blockIdx.x * 3 + which) * D + c] = ((red[0][which][c] + red[1][which][c]) + red[2][which][c]) + red[3][which][c];
     }
 }
 
@@ -302,8 +331,17 @@ static __global__ __launch_bounds__(1024) void slab_colsum_kernel(const float* _
     const int per = (nblocks + 15) / 16;
     const int b0 = wave * per, b1 = min(nblocks, b0 + per);
     float s = 0.f;
-    if (c < ncol)
-        for (int b = b0; b < b1; ++b) s += part[(int64_t)b * stride + c];
+    if (c < ncol) {
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {                  // eight loads in flight, added in order
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = part[(int64_t)(b + u) * stride + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; b < b1; ++b) s += part[(int64_t)b * stride + c];
+    }
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && c < ncol) {

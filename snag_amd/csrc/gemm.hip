@@ -1,5 +1,7 @@
 // snag_gemm_f32: the dense contraction behind the projections (a5), the Mformer linears (a2-a4),
 // their backward passes, and (with the distance epilogue in eval.hip) the similarity GEMM (a8).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "gemm.hip.h"
@@ -118,9 +120,16 @@ static int pick_splits(int64_t tiles, int K) {
     return (int)std::min(want, cap);
 }
 
+static int env_int(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+static int force_tile() { static const int v = env_int("SNAG_GEMM_TILE"); return v; }        // tuning hooks: 1 = 64x128, 2 = 128x128
+static int force_splits() { static const int v = env_int("SNAG_GEMM_SPLITS"); return v; }
+
 int64_t gemm_workspace_floats(int M, int N, int K) {
     const int64_t tiles = (int64_t)ceil_div(M, 64) * ceil_div(N, 128);
-    const int splits = pick_splits(tiles, K);
+    const int splits = force_splits() > 0 ? force_splits() : pick_splits(tiles, K);
     return splits > 1 ? (int64_t)splits * M * N : 0;
 }
 
@@ -129,6 +138,8 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb; p.M = d->M; p.N = d->N; p.K = d->K;
     p.a_vec = (d->lda % 4 == 0) && (((uintptr_t)d->A & 15) == 0);
     p.b_vec = (d->ldb % 4 == 0) && (((uintptr_t)d->B & 15) == 0);
+    static const int dbg = env_int("SNAG_GEMM_DBG");
+    p.dbg = dbg;
     Epilogue e;
     e.C = d->C; e.ldc = d->ldc; e.bias = d->bias; e.alpha = d->alpha; e.act = d->act; e.pre = d->pre_act;
     e.mask = d->keep_mask; e.mscale = d->keep_scale; e.add1 = d->add1; e.ld1 = d->ld1; e.add2 = d->add2; e.ld2 = d->ld2;
@@ -139,12 +150,14 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
 
     // tile choice: 128x128 when that already fills the chip, else 64x128 for twice the blocks
     const int64_t big_tiles = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128);
-    const bool big = big_tiles >= 512;
+    bool big = big_tiles >= 512;
+    if (force_tile() == 1) big = false;
+    if (force_tile() == 2) big = true;
     const int64_t tiles = big ? big_tiles : (int64_t)ceil_div(p.M, 64) * ceil_div(p.N, 128);
     // split K when the output alone cannot fill 256 CUs (the dW = dY^T X shapes: tiny output, long K)
     int splits = 1;
-    if (d->workspace != nullptr && !big) {
-        splits = pick_splits(tiles, p.K);
+    if (d->workspace != nullptr) {
+        splits = force_splits() > 0 ? force_splits() : pick_splits(tiles, p.K);
         const int64_t cap = d->workspace_floats / ((int64_t)p.M * p.N);
         if (splits > cap) splits = (int)cap;
         if (splits < 1) splits = 1;

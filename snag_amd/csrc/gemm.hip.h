@@ -34,6 +34,7 @@ struct GemmOperands {
     int M, N, K;
     int a_vec, b_vec;    // 16-byte loads legal for this operand (base and ld aligned)
     int k_per_split;     // K range handled by one blockIdx.z (multiple of kBK); == K rounded up when no split
+    int dbg;             // tuning only: 1 = skip global loads after the first tile, 2 = also skip LDS restaging
 };
 
 // --- global -> register staging ---------------------------------------------------------------
@@ -165,7 +166,7 @@ struct GemmCore {
         const int li = lane & 31, lh = lane >> 5;
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            if (kt + 1 < nk) {
+            if (kt + 1 < nk && p.dbg == 0) {
                 const int k0 = kbeg + (kt + 1) * kBK;
                 if (k0 + kBK <= kend) {             // wave-uniform: only the last tile of a ragged K takes the slow path
                     sa.template load<true>(p.A, p.lda, p.a_vec, m0, p.M, k0, kend, tid);
@@ -193,7 +194,7 @@ struct GemmCore {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[i][j], 0, 0, 0);
-            if (kt + 1 < nk) {
+            if (kt + 1 < nk && p.dbg < 2) {
                 sa.template store<LDA>(sm + (cur ^ 1) * A_BUF, tid);
                 sb.template store<LDB>(sm + B_BASE + (cur ^ 1) * B_BUF, tid);
             }
