@@ -49,6 +49,7 @@ SNAG_API const char* snag_last_error(void);
  *   pos[b]       = s(h[b], r[b], t[b])
  *   neg[b,k]     = s(h[b], r[b], neg_t[b,k])
  *   loss_part[b] = sum_k relu(margin + pos[b] - neg[b,k])          (optional, may be NULL)
+ * neg_t == NULL with n_neg > 0 means "candidates 0..n_neg-1 for every triple" (full-table ranking).
  *
  * ent [n_ent, dim] with row stride ent_ld floats (>= dim; lets the scorer read the read-out slot
  * hidden[:, g, :] of the fusion output in place), rel [n_rel, dim] dense; h, r, t [batch];
@@ -73,6 +74,14 @@ SNAG_API int snag_score_margin_bwd(const float* ent, int64_t ent_ld, int64_t n_e
                           int64_t batch, int n_neg, float margin, float grad_scale,
                           const float* dpos, const float* dneg,
                           float* d_ent, int64_t d_ent_ld, float* d_rel, void* stream);
+
+/* MKGC link prediction (the "Hits@1/10" half of BASELINE.json's metric; PARITY UNPINNED: the MKGC eval is not in the
+ * reference tree).  Score every entity as a candidate tail by calling snag_score_margin_fwd with neg_t == NULL and
+ * n_neg == n_ent (candidate k = entity k), then
+ *   rank[b] = #{ n : scores[b,n] < scores[b, t[b]] and filter[b,n] == 0 }
+ * (filter: optional uint8 [batch, n_ent] marking the other known true tails of (h,r): the "filtered" setting). */
+SNAG_API int snag_rank_full_table(const float* scores, int64_t batch, int64_t n_ent, const void* t, int idx_bytes,
+                                  const uint8_t* filter, int32_t* rank, void* stream);
 
 /* Deterministic (fixed-order) sum of n floats into out[0]; used for the scalar loss. */
 SNAG_API int snag_reduce_sum(const float* x, int64_t n, float* out, void* stream);

@@ -62,6 +62,7 @@ SIGNATURES = {
     "snag_score_margin_fwd": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _P, _P, _P, _P],
     "snag_score_margin_bwd": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _L, _P, _P],
     "snag_reduce_sum": [_P, _L, _P, _P],
+    "snag_rank_full_table": [_P, _L, _L, _P, _I, _P, _P, _P],
     "snag_gemm_f32": [_c.POINTER(GemmDesc), _P],
     "snag_fusion_fwd": [_c.POINTER(FusionDesc), _P],
     "snag_fusion_bwd": [_c.POINTER(FusionBwdDesc), _P],

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(
     float* out = neg + b * (int64_t)n_neg;
     for (int k0 = 0; k0 < n_neg; k0 += 64) {
         // one coalesced read of up to 64 negative-tail ids, handed to the lane groups by bpermute
-        const int my = (k0 + lane < n_neg) ? (int)nrow[k0 + lane] : 0;
+        const int my = (k0 + lane < n_neg) ? (neg_t != nullptr ? (int)nrow[k0 + lane] : k0 + lane) : 0;
         const int cnt = min(64, n_neg - k0);
         int it = 0;
         // full blocks: 8 rounds x 4 rows, all 16 gathers of the block issued before the first use
@@ -252,6 +252,26 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(
     normalize_bwd_atomic<NS>(rr, den_r, dq, d_rel + ri * (int64_t)dim, dim, lane);
 }
 
+// rank[b] = #{n : score[b,n] < score[b, t_b], n not filtered}: the filtered link-prediction rank of the true tail
+template <typename IdxT>
+__global__ __launch_bounds__(256) void rank_full_kernel(const float* __restrict__ scores, int64_t n_ent, const IdxT* __restrict__ t,
+                                                        const uint8_t* __restrict__ filter, int32_t* __restrict__ rank) {
+    __shared__ int red[4];
+    const int64_t b = blockIdx.x;
+    const float* row = scores + b * n_ent;
+    const float ref = row[(int64_t)t[b]];
+    int cnt = 0;
+    for (int64_t n = threadIdx.x; n < n_ent; n += 256) {
+        const bool skip = filter != nullptr && filter[b * n_ent + n] != 0;
+        cnt += (!skip && row[n] < ref) ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) rank[b] = red[0] + red[1] + red[2] + red[3];
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
     __shared__ float part[16];
@@ -317,7 +337,6 @@ static int check_score_args(const void* ent, int64_t n_ent, const void* rel, int
     SNAG_REQUIRE(n_ent > 0 && n_rel > 0 && dim > 0, SNAG_ERR_ARG, "score: n_ent=%ld n_rel=%ld dim=%d must be positive",
                  (long)n_ent, (long)n_rel, dim);
     SNAG_REQUIRE(batch >= 0 && n_neg >= 0, SNAG_ERR_ARG, "score: batch=%ld n_neg=%d must be non-negative", (long)batch, n_neg);
-    SNAG_REQUIRE(n_neg == 0 || neg_t, SNAG_ERR_ARG, "score: neg_t is null but n_neg=%d", n_neg);
     SNAG_REQUIRE(idx_bytes == 4 || idx_bytes == 8, SNAG_ERR_ARG, "score: idx_bytes=%d (want 4 or 8)", idx_bytes);
     SNAG_REQUIRE(dim <= 512, SNAG_ERR_UNSUPPORTED, "score: dim=%d > 512 not supported", dim);
     SNAG_REQUIRE(n_ent < (1LL << 31), SNAG_ERR_UNSUPPORTED, "score: n_ent=%ld >= 2^31", (long)n_ent);
@@ -336,6 +355,7 @@ extern "C" SNAG_API int snag_score_margin_fwd(const float* ent, int64_t ent_ld, 
     int rc = check_score_args(ent, n_ent, rel, n_rel, dim, h, r, t, neg_t, idx_bytes, batch, n_neg);
     if (rc) return rc;
     SNAG_REQUIRE(pos && (n_neg == 0 || neg), SNAG_ERR_ARG, "score_fwd: null output pointer");
+    SNAG_REQUIRE(neg_t != nullptr || n_neg <= n_ent, SNAG_ERR_ARG, "score_fwd: implicit candidates need n_neg <= n_ent");
     SNAG_REQUIRE(dim % 4 == 0 && ent_ld % 4 == 0, SNAG_ERR_UNSUPPORTED, "score_fwd: dim=%d and ent_ld=%ld must be multiples of 4 (16-byte rows)", dim, (long)ent_ld);
     SNAG_REQUIRE(ent_ld >= dim, SNAG_ERR_ARG, "score_fwd: ent_ld=%ld < dim=%d", (long)ent_ld, dim);
     if (batch == 0) return SNAG_OK;
@@ -352,6 +372,7 @@ extern "C" SNAG_API int snag_score_margin_bwd(const float* ent, int64_t ent_ld, 
     int rc = check_score_args(ent, n_ent, rel, n_rel, dim, h, r, t, neg_t, idx_bytes, batch, n_neg);
     if (rc) return rc;
     SNAG_REQUIRE(d_ent && d_rel, SNAG_ERR_ARG, "score_bwd: null gradient pointer");
+    SNAG_REQUIRE(n_neg == 0 || neg_t, SNAG_ERR_ARG, "score_bwd: neg_t is null but n_neg=%d", n_neg);
     SNAG_REQUIRE(ent_ld >= dim && d_ent_ld >= dim, SNAG_ERR_ARG, "score_bwd: row stride smaller than dim=%d", dim);
     SNAG_REQUIRE((dpos != nullptr) || (dneg == nullptr), SNAG_ERR_ARG, "score_bwd: dneg given without dpos");
     SNAG_REQUIRE((dpos == nullptr) || (dneg != nullptr) || n_neg == 0, SNAG_ERR_ARG,
@@ -367,4 +388,16 @@ extern "C" SNAG_API int snag_reduce_sum(const float* x, int64_t n, float* out, v
     SNAG_REQUIRE(out && (x || n == 0) && n >= 0, SNAG_ERR_ARG, "reduce_sum: bad arguments (n=%ld)", (long)n);
     hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
     return check_launch("snag_reduce_sum");
+}
+
+extern "C" SNAG_API int snag_rank_full_table(const float* scores, int64_t batch, int64_t n_ent, const void* t, int idx_bytes,
+                                             const uint8_t* filter, int32_t* rank, void* stream) {
+    SNAG_REQUIRE(batch >= 0 && n_ent >= 1, SNAG_ERR_ARG, "rank_full_table: bad sizes");
+    if (batch == 0) return SNAG_OK;
+    SNAG_REQUIRE(scores && t && rank, SNAG_ERR_ARG, "rank_full_table: null pointer");
+    SNAG_REQUIRE(idx_bytes == 4 || idx_bytes == 8, SNAG_ERR_ARG, "rank_full_table: idx_bytes=%d", idx_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    if (idx_bytes == 4) hipLaunchKernelGGL((rank_full_kernel<int32_t>), dim3((unsigned)batch), dim3(256), 0, st, scores, n_ent, (const int32_t*)t, filter, rank);
+    else hipLaunchKernelGGL((rank_full_kernel<int64_t>), dim3((unsigned)batch), dim3(256), 0, st, scores, n_ent, (const int64_t*)t, filter, rank);
+    return check_launch("snag_rank_full_table");
 }

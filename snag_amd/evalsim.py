@@ -105,3 +105,30 @@ def mutual_nearest(final_emb, left, right, chunk=None):
     lic, ric = li.cpu().tolist(), ri.cpu().tolist()
     pairs = [(lic[i], ric[p]) for i, p in enumerate(plc) if prc[p] == i]
     return pl, pr, pairs
+
+
+def link_prediction(ent, rel, h, r, t, filter_mask=None, top_k=(1, 10)):
+    """MKGC tail prediction: rank of the true tail among ALL entities under s(h,r,x) (lower = better), optional filter.
+
+    PARITY UNPINNED (no MKGC eval code in the reference tree): the score is the in-tree TransE-L2^2 of
+    model/MSNEA.py:110-121, the rank is count-less-than as in ``rank_metrics``.  Returns ranks [B] (int32) and Hits@k/MR/MRR.
+    """
+    ops._rows(ent, "ent"), ops._chk(rel, "rel", ndim=2)
+    B, N, dev = h.shape[0], ent.shape[0], ent.device
+    pos = torch.empty(B, device=dev, dtype=f32)
+    scores = torch.empty(B, N, device=dev, dtype=f32)
+    ib = 4 if h.dtype == torch.int32 else 8
+    call("snag_score_margin_fwd", ptr(ent), ent.stride(0), N, ptr(rel), rel.shape[0], ent.shape[1], ptr(h), ptr(r), ptr(t), None, ib,
+         B, N, 0.0, ptr(pos), ptr(scores), None, stream())
+    if filter_mask is not None:
+        ops._chk(filter_mask, "filter_mask", dtype=torch.uint8, ndim=2)
+        if tuple(filter_mask.shape) != (B, N):
+            raise ValueError("filter_mask must be [B, n_ent]")
+    rank = torch.empty(B, device=dev, dtype=torch.int32)
+    call("snag_rank_full_table", ptr(scores), B, N, ptr(t), ib, ptr(filter_mask), ptr(rank), stream())
+    tk = torch.tensor(list(top_k), device=dev, dtype=torch.int32)
+    summ = torch.empty(len(top_k) + 2, device=dev, dtype=torch.float64)
+    call("snag_rank_summary", ptr(rank), B, ptr(tk), len(top_k), ptr(summ), stream())
+    s = summ.cpu().tolist()
+    return {"rank": rank, "scores": scores, "hits": [round(c / B, 4) for c in s[:len(top_k)]], "mr": s[len(top_k)] / B,
+            "mrr": s[len(top_k) + 1] / B}

@@ -371,6 +371,23 @@ class MKGCHotPath:
         self.optimizer_step()
         return self.loss
 
+    def entity_representation(self):
+        """[N, dim] fused entity read-out of the last forward (a strided view of ``hidden`` for Mformer_hd_graph)."""
+        if self.cfg.joint_way == "Mformer_hd_mean":
+            return self.repr_mean
+        return self.hidden[:, self.g_slot, :]
+
+    def link_prediction(self, h, r, t, filter_mask=None, top_k=(1, 10)):
+        """Eval-mode fusion of the whole table, then the rank of each true tail against all entities (Hits@1/10, MR, MRR)."""
+        from . import evalsim
+        was = self.training
+        self.eval()
+        dummy = t.view(-1, 1)[:, :1].contiguous()
+        self.forward(h, r, t, dummy)                     # fills hidden / read-out; the tiny score launch is discarded
+        out = evalsim.link_prediction(self.entity_representation(), self.p["rel"], h, r, t, filter_mask, top_k)
+        self.train(was)
+        return out
+
     # parameters as a name -> tensor dict (for tests / checkpoints)
     def named_parameters(self):
         return dict(self.p)

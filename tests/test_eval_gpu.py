@@ -88,3 +88,34 @@ def test_eval_rejects_bad_input():
         E.csls_sim(x, 17)                      # k > 16 unsupported, and > matrix like torch.topk
     with pytest.raises(ValueError):
         E.rank_metrics(x, torch.zeros(5, 8, device=DEV))
+
+
+@pytest.mark.parametrize("N,D,B,idt", [(500, 128, 64, torch.int64), (15000, 128, 200, torch.int32), (333, 64, 17, torch.int32)])
+def test_link_prediction_ranks_vs_oracle(N, D, B, idt):
+    """Hits@1/10 of the MKGC metric: rank of the true tail against the full entity table, filtered setting; ranks bit-exact."""
+    from snag_amd import evalsim as E
+    g = torch.Generator().manual_seed(N + B)
+    ent, rel = torch.randn(N, D, generator=g), torch.randn(9, D, generator=g) * 0.3
+    h = torch.randint(0, N, (B,), generator=g).to(idt)
+    r = torch.randint(0, 9, (B,), generator=g).to(idt)
+    # plant structure so that Hits@10 is neither 0 nor 1: t = the entity closest to h + r for half of the triples
+    q = O.nrm(ent[h.long()]) + O.nrm(rel[r.long()])
+    near = ((q.unsqueeze(1) - O.nrm(ent).unsqueeze(0)) ** 2).sum(-1).argsort(dim=1)
+    t = torch.where(torch.rand(B, generator=g) < 0.5, near[torch.arange(B), torch.randint(0, 20, (B,), generator=g)],
+                    torch.randint(0, N, (B,), generator=g)).to(idt)
+    filt = torch.rand(B, N, generator=g) < 0.01
+    filt[torch.arange(B), t.long()] = False
+    ref = O.rank_full_table(ent, rel, h, r, t, filt)
+    res = E.link_prediction(ent.to(DEV), rel.to(DEV), h.to(DEV), r.to(DEV), t.to(DEV), filt.to(torch.uint8).to(DEV))
+    got = res["rank"].cpu().long()
+    # the two implementations sum the 128 squares in different orders: allow a flip only where the scores tie to 1e-6
+    if not torch.equal(got, ref):
+        sc = res["scores"].cpu()
+        st = sc.gather(1, t.long().view(-1, 1))
+        near_ties = ((sc - st).abs() < 2e-6).sum(1) - 1
+        assert bool(((got - ref).abs() <= near_ties).all()), (got - ref).abs().max()
+    ref_u = O.rank_full_table(ent, rel, h, r, t, None)
+    res_u = E.link_prediction(ent.to(DEV), rel.to(DEV), h.to(DEV), r.to(DEV), t.to(DEV))
+    assert bool((res_u["rank"].cpu().long() >= got).all())                  # filtering can only improve a rank
+    assert int((res_u["rank"].cpu().long() - ref_u).abs().max()) <= 1
+    assert 0.0 < res["hits"][1] < 1.0 and res["hits"][0] <= res["hits"][1]

@@ -106,3 +106,34 @@ def test_mkgc_train_step_reduces_loss_and_is_deterministic_in_eval():
     b = eng.forward(*idx, want_scores=True)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_mkgc_hits_at_k_equal_oracle():
+    """BASELINE metric, second half: Hits@1/10 of the fused representation equal the CPU reference path's (ranks bit-exact
+    up to exact score ties)."""
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    N, R, D, B = 1200, 11, 128, 300
+    cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[64, 48], num_proj=2, margin=12.0, dropout=0.1, add_noise=1, seed=11, lr=5e-3)
+    g = torch.Generator().manual_seed(21)
+    feats = [torch.rand(N, 64, generator=g), torch.randn(N, 48, generator=g)]
+    eng = MKGCHotPath(cfg, feats, device=DEV)
+    h = torch.randint(0, N, (B,), generator=g, dtype=torch.int32)
+    r = torch.randint(0, R, (B,), generator=g, dtype=torch.int32)
+    t = torch.randint(0, N, (B,), generator=g, dtype=torch.int32)
+    neg = torch.randint(0, N, (B, 32), generator=g, dtype=torch.int32)
+    eng.update_noise()
+    for _ in range(25):                                 # a few real training steps so the ranking is informative
+        eng.train_step(h.to(DEV), r.to(DEV), t.to(DEV), neg.to(DEV))
+    res = eng.link_prediction(h.to(DEV), r.to(DEV), t.to(DEV))
+    p, proj, fp = oracle_params(eng)
+    with torch.no_grad():
+        _, _, _, oent = O.mkgc_forward(feats, proj, p["ent"], fp, p["rel"], h, r, t, neg, num_heads=2, margin=12.0)
+        oref = O.rank_full_table(oent, p["rel"], h, r, t)
+    got = res["rank"].cpu().long()
+    sc = res["scores"].cpu()
+    near = ((sc - sc.gather(1, t.long().view(-1, 1))).abs() < 1e-5).sum(1) - 1
+    assert bool(((got - oref).abs() <= near).all()), int((got - oref).abs().max())
+    for k, hk in zip((1, 10), res["hits"]):
+        ref_hits = round(float((oref < k).float().mean()), 4)
+        assert abs(hk - ref_hits) <= float((near > 0).float().mean()) + 1e-9, (k, hk, ref_hits)
+    assert res["hits"][1] > 0.2          # training on these triples must have made them rank well
