@@ -61,6 +61,14 @@ SNAG_API int snag_score_margin_fwd(const float* ent, int64_t ent_ld, int64_t n_e
                           int64_t batch, int n_neg, float margin,
                           float* pos, float* neg, float* loss_part, void* stream);
 
+/* Same scores from bf16 tables (raw bfloat16 bit patterns), fp32 arithmetic and outputs: the storage format of
+ * BASELINE config 5 (|E| = 1M, dim 256, 128 negatives: a 512 MB table that does not fit the Infinity Cache).
+ * dim and ent_ld (in elements) multiples of 8, dim <= 1024.  Forward only this round. */
+SNAG_API int snag_score_margin_fwd_bf16(const uint16_t* ent, int64_t ent_ld, int64_t n_ent, const uint16_t* rel, int64_t n_rel, int dim,
+                          const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                          int64_t batch, int n_neg, float margin,
+                          float* pos, float* neg, float* loss_part, void* stream);
+
 /* Backward of the above (replaces autograd of model/MSNEA.py:110-122).
  * Upstream gradient, one of:
  *   - hinge mode (dpos == dneg == NULL): d loss / d neg[b,k] = -grad_scale * [margin + pos - neg > 0],

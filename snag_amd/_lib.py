@@ -60,6 +60,7 @@ class FusionBwdDesc(_c.Structure):
 # name -> argtypes; every entry returns int (0 = enqueued) except the two listed in _SPECIAL
 SIGNATURES = {
     "snag_score_margin_fwd": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _P, _P, _P, _P],
+    "snag_score_margin_fwd_bf16": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _P, _P, _P, _P],
     "snag_score_margin_bwd": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _L, _P, _P],
     "snag_reduce_sum": [_P, _L, _P, _P],
     "snag_rank_full_table": [_P, _L, _L, _P, _I, _P, _P, _P],

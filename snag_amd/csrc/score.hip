@@ -331,6 +331,130 @@ static int launch_bwd(const float* ent, int64_t eld, const float* rel, int dim, 
     return check_launch("snag_score_margin_bwd");
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16 tables, fp32 arithmetic (BASELINE config 5: |E| = 1M, dim 256, 128 negatives).  A lane owns 16-byte chunks of
+// 8 bf16 (chunk sub, sub+16, ...), so a 16-lane row still covers 256 contiguous bytes per wave-instruction.
+template <int NC>
+struct RowB {
+    float v[8 * NC];
+};
+
+template <int NC>
+__device__ __forceinline__ RowB<NC> load_row_bf16(const uint16_t* __restrict__ base, int64_t row, int64_t ld, int dim, int sub) {
+    RowB<NC> r;
+    const uint4* p = reinterpret_cast<const uint4*>(base + row * ld);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = sub + 16 * j;
+        const uint4 q = (c * 8 < dim) ? p[c] : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r.v[8 * j + 2 * e] = __uint_as_float(w[e] << 16);             // low half = element 2e
+            r.v[8 * j + 2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); // high half = element 2e+1
+        }
+    }
+    return r;
+}
+
+template <int NC>
+__device__ __forceinline__ float sumsq_b(const RowB<NC>& r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8 * NC; ++i) s = fmaf(r.v[i], r.v[i], s);
+    return s;
+}
+
+template <int NC>
+__device__ __forceinline__ float score_row_b(const RowB<NC>& q, const RowB<NC>& x) {
+    const float inv = 1.0f / l2_denominator(sum16(sumsq_b<NC>(x)));
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8 * NC; ++i) {
+        const float d = q.v[i] - x.v[i] * inv;
+        s = fmaf(d, d, s);
+    }
+    return sum16(s);
+}
+
+template <typename IdxT, int NC>
+__global__ __launch_bounds__(256) void score_fwd_bf16_kernel(
+    const uint16_t* __restrict__ ent, int64_t eld, const uint16_t* __restrict__ rel, int dim,
+    const IdxT* __restrict__ h, const IdxT* __restrict__ r, const IdxT* __restrict__ t,
+    const IdxT* __restrict__ neg_t, int64_t batch, int n_neg, float margin,
+    float* __restrict__ pos, float* __restrict__ neg, float* __restrict__ loss_part) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (b >= batch) return;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 15;
+    const int grp = lane >> 4;
+    RowB<NC> q = load_row_bf16<NC>(ent, (int64_t)h[b], eld, dim, sub);
+    const RowB<NC> rr = load_row_bf16<NC>(rel, (int64_t)r[b], dim, dim, sub);
+    const RowB<NC> tt = load_row_bf16<NC>(ent, (int64_t)t[b], eld, dim, sub);
+    {
+        const float ih = 1.0f / l2_denominator(sum16(sumsq_b<NC>(q)));
+        const float ir = 1.0f / l2_denominator(sum16(sumsq_b<NC>(rr)));
+#pragma unroll
+        for (int i = 0; i < 8 * NC; ++i) q.v[i] = q.v[i] * ih + rr.v[i] * ir;
+    }
+    const float s_pos = score_row_b<NC>(q, tt);
+    if (lane == 0) pos[b] = s_pos;
+    float hinge = 0.f;
+    const IdxT* nrow = neg_t + b * (int64_t)n_neg;
+    float* out = neg + b * (int64_t)n_neg;
+    for (int k0 = 0; k0 < n_neg; k0 += 64) {
+        const int my = (k0 + lane < n_neg) ? (neg_t != nullptr ? (int)nrow[k0 + lane] : k0 + lane) : 0;
+        const int cnt = min(64, n_neg - k0);
+        int it = 0;
+        for (; it + 16 <= cnt; it += 16) {                       // 4 rounds x 4 rows in flight
+            RowB<NC> x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = load_row_bf16<NC>(ent, __shfl(my, it + 4 * u + grp), eld, dim, sub);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float s = score_row_b<NC>(q, x[u]);
+                hinge += fmaxf(margin + s_pos - s, 0.f);
+                if (sub == 0) out[k0 + it + 4 * u + grp] = s;
+            }
+        }
+        for (; it < cnt; it += 4) {
+            const int k = it + grp;
+            const bool valid = k < cnt;
+            const int idx = __shfl(my, k);
+            const RowB<NC> x = load_row_bf16<NC>(ent, valid ? idx : 0, eld, dim, sub);
+            const float s = score_row_b<NC>(q, x);
+            if (valid) {
+                hinge += fmaxf(margin + s_pos - s, 0.f);
+                if (sub == 0) out[k0 + k] = s;
+            }
+        }
+    }
+    if (loss_part != nullptr) {
+        const float g1 = __shfl(hinge, 16), g2 = __shfl(hinge, 32), g3 = __shfl(hinge, 48);
+        if (lane == 0) loss_part[b] = ((hinge + g1) + g2) + g3;
+    }
+}
+
+template <typename IdxT>
+static int launch_fwd_bf16(const uint16_t* ent, int64_t eld, const uint16_t* rel, int dim, const void* h, const void* r, const void* t,
+                           const void* neg_t, int64_t batch, int n_neg, float margin, float* pos, float* neg, float* loss_part,
+                           hipStream_t st) {
+    const dim3 grid((unsigned)ceil_div(batch, 4)), block(256);
+    const int nc = (dim + 127) / 128;
+#define SNAG_FWDB(NC)                                                                                              \
+    hipLaunchKernelGGL((score_fwd_bf16_kernel<IdxT, NC>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h,  \
+                       (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, pos, neg, loss_part)
+    switch (nc) {
+        case 1: SNAG_FWDB(1); break;
+        case 2: SNAG_FWDB(2); break;
+        case 3: case 4: SNAG_FWDB(4); break;
+        default: SNAG_FWDB(8); break;
+    }
+#undef SNAG_FWDB
+    return check_launch("snag_score_margin_fwd_bf16");
+}
+
 static int check_score_args(const void* ent, int64_t n_ent, const void* rel, int64_t n_rel, int dim, const void* h,
                             const void* r, const void* t, const void* neg_t, int idx_bytes, int64_t batch, int n_neg) {
     SNAG_REQUIRE(ent && rel && h && r && t, SNAG_ERR_ARG, "score: null table or index pointer");
@@ -400,4 +524,21 @@ extern "C" SNAG_API int snag_rank_full_table(const float* scores, int64_t batch,
     if (idx_bytes == 4) hipLaunchKernelGGL((rank_full_kernel<int32_t>), dim3((unsigned)batch), dim3(256), 0, st, scores, n_ent, (const int32_t*)t, filter, rank);
     else hipLaunchKernelGGL((rank_full_kernel<int64_t>), dim3((unsigned)batch), dim3(256), 0, st, scores, n_ent, (const int64_t*)t, filter, rank);
     return check_launch("snag_rank_full_table");
+}
+
+extern "C" SNAG_API int snag_score_margin_fwd_bf16(const uint16_t* ent, int64_t ent_ld, int64_t n_ent, const uint16_t* rel, int64_t n_rel,
+                                                   int dim, const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                                                   int64_t batch, int n_neg, float margin, float* pos, float* neg, float* loss_part,
+                                                   void* stream) {
+    if (batch == 0) return SNAG_OK;
+    SNAG_REQUIRE(ent && rel && h && r && t && pos && (n_neg == 0 || neg), SNAG_ERR_ARG, "score_fwd_bf16: null pointer");
+    SNAG_REQUIRE(n_ent > 0 && n_rel > 0 && batch >= 0 && n_neg >= 0, SNAG_ERR_ARG, "score_fwd_bf16: bad sizes");
+    SNAG_REQUIRE(idx_bytes == 4 || idx_bytes == 8, SNAG_ERR_ARG, "score_fwd_bf16: idx_bytes=%d", idx_bytes);
+    SNAG_REQUIRE(dim > 0 && dim % 8 == 0 && dim <= 1024 && ent_ld % 8 == 0 && ent_ld >= dim, SNAG_ERR_UNSUPPORTED,
+                 "score_fwd_bf16: dim=%d ent_ld=%ld must be multiples of 8 (16-byte chunks), dim <= 1024", dim, (long)ent_ld);
+    SNAG_REQUIRE(neg_t != nullptr || n_neg <= n_ent, SNAG_ERR_ARG, "score_fwd_bf16: implicit candidates need n_neg <= n_ent");
+    SNAG_REQUIRE(n_ent < (1LL << 31), SNAG_ERR_UNSUPPORTED, "score_fwd_bf16: n_ent >= 2^31");
+    hipStream_t st = (hipStream_t)stream;
+    return idx_bytes == 4 ? launch_fwd_bf16<int32_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, pos, neg, loss_part, st)
+                          : launch_fwd_bf16<int64_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, pos, neg, loss_part, st);
 }

@@ -71,6 +71,22 @@ def score_margin_fwd(ent, rel, h, r, t, neg_t, margin, want_loss=True):
     return pos, neg, loss_part
 
 
+def score_margin_fwd_bf16(ent, rel, h, r, t, neg_t, margin, want_loss=True):
+    """bf16 tables -> fp32 scores.  C ABI: snag_score_margin_fwd_bf16."""
+    for x, nm in ((ent, "ent"), (rel, "rel")):
+        if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1):
+            raise ValueError(f"{nm}: expected a 2-D bfloat16 CUDA tensor with unit inner stride")
+    if not rel.is_contiguous():
+        raise ValueError("rel must be contiguous")
+    B, K, ib = _idx_group(h, r, t, neg_t)
+    pos = torch.empty(B, device=ent.device, dtype=f32)
+    neg = torch.empty(B, K, device=ent.device, dtype=f32)
+    loss_part = torch.empty(B, device=ent.device, dtype=f32) if want_loss else None
+    call("snag_score_margin_fwd_bf16", ptr(ent), ent.stride(0), ent.shape[0], ptr(rel), rel.shape[0], ent.shape[1],
+         ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K, float(margin), ptr(pos), ptr(neg), ptr(loss_part), stream())
+    return pos, neg, loss_part
+
+
 def score_margin_bwd(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, dpos=None, dneg=None, d_ent=None, d_rel=None):
     """Accumulates into d_ent/d_rel (allocated zeroed when None).  C ABI: snag_score_margin_bwd."""
     _rows(ent, "ent"), _chk(rel, "rel", ndim=2)

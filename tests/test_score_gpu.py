@@ -114,3 +114,16 @@ def test_score_empty_batch():
     ent, rel, h, r, t, neg = [x.to(DEV) for x in _mk(10, 3, 128, 0, 4, seed=1)]
     pos, ng, lp = ops.score_margin_fwd(ent, rel, h, r, t, neg, 1.0)
     assert pos.numel() == 0 and ng.shape == (0, 4)
+
+
+@pytest.mark.parametrize("D,K,B", [(256, 128, 64), (128, 32, 100), (64, 5, 33), (512, 17, 9)])
+def test_score_bf16_tables(D, K, B):
+    """Config-5 storage: bf16 tables, fp32 math.  The oracle runs on the same bf16-rounded values, so parity stays 1e-5."""
+    from snag_amd import ops
+    ent, rel, h, r, t, neg = _mk(3000, 13, D, B, K, seed=D + K, idt=torch.int32)
+    eb, rb = ent.to(torch.bfloat16), rel.to(torch.bfloat16)
+    loss, pos, ng = O.score_margin(eb.float(), rb.float(), h, r, t, neg, 12.0)
+    pos_g, neg_g, lp = ops.score_margin_fwd_bf16(eb.to(DEV), rb.to(DEV), h.to(DEV), r.to(DEV), t.to(DEV), neg.to(DEV), 12.0)
+    assert_close(pos_g, pos, atol=1e-5)
+    assert_close(neg_g, ng, atol=1e-5)
+    assert_close(ops.reduce_sum(lp), loss, atol=1e-3, rtol=2e-6)

@@ -22,3 +22,21 @@ for B in (1024, 8192, 32768):
     us = e0.elapsed_time(e1) * 1e3 / n
     by = B * ((K + 3) * D * 4 + (K + 3) * 4 + (K + 1) * 4)
     print(f"N=1M D=256 K=128 fp32 B={B}: {us:.1f} us/launch, algorithmic {by / us / 1e6:.2f} TB/s = {by / us / 1e6 / 8 * 100:.1f}% of 8 TB/s, {B / us:.2f} Mtriples/s")
+
+eb = ent.to(torch.bfloat16); rb = rel.to(torch.bfloat16)
+for B in (1024, 8192, 32768):
+    h = torch.randint(0, N, (B,), generator=g, dtype=torch.int32).to(dev); r = torch.randint(0, R, (B,), generator=g, dtype=torch.int32).to(dev)
+    t = torch.randint(0, N, (B,), generator=g, dtype=torch.int32).to(dev); neg = torch.randint(0, N, (B, K), generator=g, dtype=torch.int32).to(dev)
+    pos = torch.empty(B, device=dev); ng = torch.empty(B, K, device=dev); lp = torch.empty(B, device=dev)
+    st = _lib.stream()
+    fn = lambda: _lib.call("snag_score_margin_fwd_bf16", eb.data_ptr(), D, N, rb.data_ptr(), R, D, h.data_ptr(), r.data_ptr(), t.data_ptr(), neg.data_ptr(), 4, B, K, 12.0, pos.data_ptr(), ng.data_ptr(), lp.data_ptr(), st)
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    n = 50
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / n
+    by = B * ((K + 3) * D * 2 + (K + 3) * 4 + (K + 1) * 4)
+    print(f"N=1M D=256 K=128 bf16 B={B}: {us:.1f} us/launch, algorithmic {by / us / 1e6:.2f} TB/s = {by / us / 1e6 / 8 * 100:.1f}% of 8 TB/s, {B / us:.2f} Mtriples/s")
