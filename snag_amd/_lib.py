@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnag_hip.so")
+LIB_PATH = os.environ.get("SNAG_HIP_LIB") or os.path.join(_HERE, "libsnag_hip.so")   # override: A/B builds of the same ABI
 
 _c = ctypes
 _P = _c.c_void_p

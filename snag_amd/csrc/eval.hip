@@ -291,12 +291,14 @@ static constexpr int kColChunks = 64;
 
 static void launch_dist_gemm(const GemmOperands& p, const DistEpilogue& e, hipStream_t st) {
     const int64_t big_tiles = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128);
+    const bool vec = p.a_vec && p.b_vec;
+    const dim3 gbig(ceil_div(p.N, 128), ceil_div(p.M, 128), 1), gsmall(ceil_div(p.N, 128), ceil_div(p.M, 64), 1);
     if (big_tiles >= 512) {
-        hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 64, 64, true, true, DistEpilogue>), dim3(ceil_div(p.N, 128), ceil_div(p.M, 128), 1),
-                           dim3(256), 0, st, p, e, (float*)nullptr);
+        if (vec) hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 64, 64, true, true, true, DistEpilogue>), gbig, dim3(256), 0, st, p, e, (float*)nullptr);
+        else hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 64, 64, true, true, false, DistEpilogue>), gbig, dim3(256), 0, st, p, e, (float*)nullptr);
     } else {
-        hipLaunchKernelGGL((gemm_tile_kernel<64, 128, 32, 64, true, true, DistEpilogue>), dim3(ceil_div(p.N, 128), ceil_div(p.M, 64), 1),
-                           dim3(256), 0, st, p, e, (float*)nullptr);
+        if (vec) hipLaunchKernelGGL((gemm_tile_kernel<64, 128, 32, 64, true, true, true, DistEpilogue>), gsmall, dim3(256), 0, st, p, e, (float*)nullptr);
+        else hipLaunchKernelGGL((gemm_tile_kernel<64, 128, 32, 64, true, true, false, DistEpilogue>), gsmall, dim3(256), 0, st, p, e, (float*)nullptr);
     }
 }
 

@@ -96,11 +96,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+static int env_int(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(const GemmOperands& p, const Epilogue& e, float* slab, int splits, bool a_kc, bool b_kc, hipStream_t st) {
     dim3 grid(ceil_div(p.N, BN), ceil_div(p.M, BM), splits), block(256);
-#define SNAG_GEMM(AK, BK_)                                                                               \
-    hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN, AK, BK_, Epilogue>), grid, block, 0, st, p, e, slab)
+    // VEC: every fetch is an unpredicated dwordx4 (all shapes of the hot path); otherwise the checked loader
+    // Measured on one device (tools/tune_gemm.py, A/B builds): the unpredicated loader wins 15-25 % whenever an operand is
+    // row-contiguous, but loses 5-20 % when both are K-contiguous, so those keep the checked loader.
+    static const int vec_mode = env_int("SNAG_GEMM_VEC");      // tuning: 1 = never, 2 = whenever legal
+    const bool legal = p.a_vec && p.b_vec && (a_kc || p.M % 4 == 0) && (b_kc || p.N % 4 == 0) && p.M >= 4 && p.N >= 4;
+    const bool vec = legal && vec_mode != 1 && (vec_mode == 2 || !(a_kc && b_kc));
+#define SNAG_GEMM(AK, BK_)                                                                                        \
+    do {                                                                                                          \
+        if (vec) hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN, AK, BK_, true, Epilogue>), grid, block, 0, st, p, e, slab);  \
+        else hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN, AK, BK_, false, Epilogue>), grid, block, 0, st, p, e, slab);     \
+    } while (0)
     if (a_kc && b_kc) SNAG_GEMM(true, true);
     else if (a_kc && !b_kc) SNAG_GEMM(true, false);
     else if (!a_kc && b_kc) SNAG_GEMM(false, true);
@@ -113,17 +126,14 @@ static void launch_cfg(const GemmOperands& p, const Epilogue& e, float* slab, in
 // blocks per CU hide it.  Each split keeps at least kMinKTiles k-tiles of work.
 static constexpr int kTargetBlocks = 1024, kMinKTiles = 16;
 
-static int pick_splits(int64_t tiles, int K) {
+static int pick_splits(int64_t tiles, int K, bool both_kc = false) {
     if (tiles >= kTargetBlocks / 2) return 1;
+    if (both_kc && tiles >= 192) return 1;      // measured: X W^T shapes with ~1 tile per CU gain nothing from splitting
     const int64_t want = (kTargetBlocks + tiles - 1) / tiles;
     const int64_t cap = std::max<int64_t>(1, K / (kMinKTiles * kBK));
     return (int)std::min(want, cap);
 }
 
-static int env_int(const char* name) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : 0;
-}
 static int force_tile() { static const int v = env_int("SNAG_GEMM_TILE"); return v; }        // tuning hooks: 1 = 64x128, 2 = 128x128
 static int force_splits() { static const int v = env_int("SNAG_GEMM_SPLITS"); return v; }
 
@@ -157,7 +167,7 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     // split K when the output alone cannot fill 256 CUs (the dW = dY^T X shapes: tiny output, long K)
     int splits = 1;
     if (d->workspace != nullptr) {
-        splits = force_splits() > 0 ? force_splits() : pick_splits(tiles, p.K);
+        splits = force_splits() > 0 ? force_splits() : pick_splits(tiles, p.K, d->a_kcontig && d->b_kcontig);
         const int64_t cap = d->workspace_floats / ((int64_t)p.M * p.N);
         if (splits > cap) splits = (int)cap;
         if (splits < 1) splits = 1;

@@ -4,9 +4,13 @@
 //
 // Each operand is either "K-contiguous" (element (r,k) at ptr[r*ld + k]: activations [rows,K],
 // nn.Linear weights W[out,in]) or "row-contiguous" (element (r,k) at ptr[k*ld + r]: the transposed
-// uses in the backward GEMMs).  Both land in LDS k-major (tile[k][row]) so that an MFMA operand
-// fetch is one conflict-free ds_read_b32 per lane; K-contiguous operands are transposed on the
-// way in (row stride = tile + 2 makes the four ds_write_b32 of a float4 conflict-free).
+// uses in the backward GEMMs).  A float4 fetched from global memory goes to LDS as ONE ds_write_b128:
+//   * K-contiguous: the tile keeps its row-major shape, [row][16 k] = four 16-byte chunks per row, with the chunk
+//     index XOR-swizzled by (row >> 2) & 3.  A lane fetches its MFMA operands as ds_read_b128: lane half h reads
+//     chunk 2cp + h of its row and feeds four consecutive MFMA k-steps from it, i.e. within a k-tile the sum runs
+//     over k in the order 8cp + 4h + j -- a permutation of k, applied identically to both operands (the swizzle
+//     makes every 16-lane ds_read_b128 group hit 16 distinct 16-byte slots: conflict-free);
+//   * row-contiguous: the tile is [k][row]; operands are conflict-free ds_read_b32 at the same permuted k.
 // 256 threads = 4 waves in a 2x2 grid, double-buffered LDS, global loads for tile t+1 in flight
 // while tile t feeds the matrix pipe.
 #pragma once
@@ -27,14 +31,37 @@ using lds_float4 = float4;
 
 constexpr int kBK = 16;
 
+// Build-time structure switches (A/B'ed on one device):
+//   SNAG_GEMM_SWZ  1: K-contiguous tiles stay row-major in LDS with XOR-swizzled 16-byte chunks (b128 in, b128 out)
+//                  0: K-contiguous tiles are transposed to k-major on the way in (4x ds_write_b32, b32 fragment reads)
+//   SNAG_GEMM_PIPE 1: software pipeline (fragments of tile t+1 and global loads of tile t+2 issued before the MFMAs of t)
+//                  0: load fragments, MFMA chain, stage tile t+1
+#ifndef SNAG_GEMM_SWZ
+#define SNAG_GEMM_SWZ 1
+#endif
+#ifndef SNAG_GEMM_PIPE
+#define SNAG_GEMM_PIPE 0
+#endif
+constexpr bool kSwz = SNAG_GEMM_SWZ != 0;
+constexpr bool kPipe = SNAG_GEMM_PIPE != 0;
+
+// LDS leading dimension of a tile: swizzled row-major tiles are dense; k-major tiles are padded (+2 makes the four
+// transposing ds_write_b32 of a float4 conflict-free, +4 keeps ds_write_b128 rows 16-byte aligned)
+template <int BR, bool KC>
+struct TileLd {
+    static constexpr int value = KC ? (kSwz ? kBK : BR + 2) : (kSwz ? BR : BR + 4);
+    static constexpr int floats = KC ? (kSwz ? BR * kBK : kBK * (BR + 2)) : (kSwz ? kBK * BR : kBK * (BR + 4));
+};
+
 struct GemmOperands {
     const float* A;
     const float* B;
     int64_t lda, ldb;
     int M, N, K;
     int a_vec, b_vec;    // 16-byte loads legal for this operand (base and ld aligned)
+    // the VEC kernel variant additionally needs: row-contiguous operands with a row count that is a multiple of 4
     int k_per_split;     // K range handled by one blockIdx.z (multiple of kBK); == K rounded up when no split
-    int dbg;             // tuning only: 1 = skip global loads after the first tile, 2 = also skip LDS restaging
+    int dbg;             // tuning only: nonzero = stop fetching after the first two k-tiles (compute-only ceiling)
 };
 
 // --- global -> register staging ---------------------------------------------------------------
@@ -47,9 +74,26 @@ struct Stager {
 
     // FULL: the whole k-tile lies inside [kbeg, kend) -> no k predicates; rows past the edge are clamped to the
     // last valid row (their products land in accumulator rows/cols the epilogue discards).
-    template <bool FULL>
+    template <bool FULL, bool VEC>
     __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int vec_ok, int row0, int nrows, int k0,
                                          int kend, int tid) {
+        if (FULL && VEC) {
+            // hot path: whole tile in range along k, 16-byte loads legal (decided on the host): no predicates at all.
+            // Rows past the edge are clamped to the last valid row; their products land in accumulator rows/cols the
+            // epilogue never stores.  (Row-contiguous operands: nrows % 4 == 0 is part of VEC.)
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int slot = tid + 256 * s;
+                if (KC) {
+                    const int row = min(row0 + slot / (kBK / 4), nrows - 1);
+                    r[s] = *reinterpret_cast<const float4*>(P + (int64_t)row * ld + k0 + (slot % (kBK / 4)) * 4);
+                } else {
+                    const int row = min(row0 + (slot % (BR / 4)) * 4, nrows - 4);
+                    r[s] = *reinterpret_cast<const float4*>(P + (int64_t)(k0 + slot / (BR / 4)) * ld + row);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int slot = tid + 256 * s;
@@ -95,19 +139,23 @@ struct Stager {
         }
     }
 
-    // tile is k-major: tile[k * LD + row]
-    template <int LD>
+    // SWZ & KC: tile[row][16] with swizzled 16-byte chunks; otherwise tile[k][LD]
     __device__ __forceinline__ void store(lds_float* tile, int tid) const {
+        constexpr int LD = TileLd<BR, KC>::value;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int slot = tid + 256 * s;
             if (KC) {
                 const int row = slot / (kBK / 4);
-                const int k = (slot % (kBK / 4)) * 4;
-                tile[(k + 0) * LD + row] = r[s].x;
-                tile[(k + 1) * LD + row] = r[s].y;
-                tile[(k + 2) * LD + row] = r[s].z;
-                tile[(k + 3) * LD + row] = r[s].w;
+                const int c = slot % (kBK / 4);
+                if (kSwz) {
+                    *reinterpret_cast<lds_float4*>(tile + row * kBK + 4 * (c ^ ((row >> 2) & 3))) = r[s];
+                } else {
+                    tile[(4 * c + 0) * LD + row] = r[s].x;
+                    tile[(4 * c + 1) * LD + row] = r[s].y;
+                    tile[(4 * c + 2) * LD + row] = r[s].z;
+                    tile[(4 * c + 3) * LD + row] = r[s].w;
+                }
             } else {
                 const int row = (slot % (BR / 4)) * 4;
                 const int k = slot / (BR / 4);
@@ -117,18 +165,44 @@ struct Stager {
     }
 };
 
-template <int BR, bool KC>
-struct TileLd {
-    static constexpr int value = KC ? BR + 2 : BR + 4;
-};
+// operand fragments of one k-tile for NF 32-row fragments: f[t][n] feeds MFMA k-step t.
+// SWZ: t = 4*cp + j <-> k = 8cp + 4h + j (a permutation of k shared by both operands); else k = 2t + h.
+template <int BR, bool KC, int NF>
+__device__ __forceinline__ void load_fragments(const lds_float* tile, int row0, int li, int lh, float (&f)[kBK / 2][NF]) {
+    static_assert(kBK == 16, "two chunk pairs per k-tile");
+    constexpr int LD = TileLd<BR, KC>::value;
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+        const int row = row0 + 32 * n + li;
+        if (kSwz) {
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                if (KC) {
+                    const int c = 2 * cp + lh;
+                    const float4 v = *reinterpret_cast<const lds_float4*>(tile + row * kBK + 4 * (c ^ ((li >> 2) & 3)));
+                    f[4 * cp + 0][n] = v.x;
+                    f[4 * cp + 1][n] = v.y;
+                    f[4 * cp + 2][n] = v.z;
+                    f[4 * cp + 3][n] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[4 * cp + j][n] = tile[(8 * cp + 4 * lh + j) * LD + row];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < kBK / 2; ++t) f[t][n] = tile[(2 * t + lh) * LD + row];
+        }
+    }
+}
 
 // Main loop.  acc[mi][ni] is the 32x32 tile (mi, ni) of this wave's WM x WN patch:
 //   row = wm0 + 32*mi + (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5),  col = wn0 + 32*ni + (lane & 31).
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC>
 struct GemmCore {
     static constexpr int TM = WM / 32, TN = WN / 32;
-    static constexpr int LDA = TileLd<BM, A_KC>::value, LDB = TileLd<BN, B_KC>::value;
-    static constexpr int TILE_FLOATS = 2 * kBK * (LDA + LDB);
+    static constexpr int A_BUF = TileLd<BM, A_KC>::floats, B_BUF = TileLd<BN, B_KC>::floats, B_BASE = 2 * A_BUF;
+    static constexpr int TILE_FLOATS = 2 * (A_BUF + B_BUF);
     static constexpr int STAGE_FLOATS = 4 * 32 * WN;   // epilogue staging, 32 rows x WN per wave
     static constexpr int SMEM_FLOATS = TILE_FLOATS > STAGE_FLOATS ? TILE_FLOATS : STAGE_FLOATS;
     static_assert((BM / WM) * (BN / WN) == 4, "four waves per block");
@@ -141,7 +215,6 @@ struct GemmCore {
         const int wave = wave_id_uniform();
         const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
         lds_float* const sm = (lds_float*)smem;
-        constexpr int A_BUF = kBK * LDA, B_BUF = kBK * LDB, B_BASE = 2 * kBK * LDA;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -153,39 +226,69 @@ struct GemmCore {
         Stager<BN, B_KC> sb;
         const int nk = (kend - kbeg + kBK - 1) / kBK;
         if (nk <= 0) return;
-        if (kbeg + kBK <= kend) {
-            sa.template load<true>(p.A, p.lda, p.a_vec, m0, p.M, kbeg, kend, tid);
-            sb.template load<true>(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, kend, tid);
-        } else {
-            sa.template load<false>(p.A, p.lda, p.a_vec, m0, p.M, kbeg, kend, tid);
-            sb.template load<false>(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, kend, tid);
-        }
-        sa.template store<LDA>(sm, tid);
-        sb.template store<LDB>(sm + B_BASE, tid);
-        __syncthreads();
         const int li = lane & 31, lh = lane >> 5;
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk && p.dbg == 0) {
-                const int k0 = kbeg + (kt + 1) * kBK;
-                if (k0 + kBK <= kend) {             // wave-uniform: only the last tile of a ragged K takes the slow path
-                    sa.template load<true>(p.A, p.lda, p.a_vec, m0, p.M, k0, kend, tid);
-                    sb.template load<true>(p.B, p.ldb, p.b_vec, n0, p.N, k0, kend, tid);
-                } else {
-                    sa.template load<false>(p.A, p.lda, p.a_vec, m0, p.M, k0, kend, tid);
-                    sb.template load<false>(p.B, p.ldb, p.b_vec, n0, p.N, k0, kend, tid);
-                }
+
+        // wave-uniform choice between the predicate-free loader and the ragged-K one (last tile only)
+        auto fetch = [&](int kt) {
+            const int k0 = kbeg + kt * kBK;
+            if (k0 + kBK <= kend) {
+                sa.template load<true, VEC>(p.A, p.lda, p.a_vec, m0, p.M, k0, kend, tid);
+                sb.template load<true, VEC>(p.B, p.ldb, p.b_vec, n0, p.N, k0, kend, tid);
+            } else {
+                sa.template load<false, false>(p.A, p.lda, p.a_vec, m0, p.M, k0, kend, tid);
+                sb.template load<false, false>(p.B, p.ldb, p.b_vec, n0, p.N, k0, kend, tid);
             }
-            const lds_float* a = sm + cur * A_BUF + lh * LDA + wm0 + li;
-            const lds_float* b = sm + B_BASE + cur * B_BUF + lh * LDB + wn0 + li;
-            // all operand fragments of the k-tile first (one burst of ds_reads), then the MFMA chain
-            float av[kBK / 2][TM], bv[kBK / 2][TN];
+        };
+        auto stage = [&](int buf) {
+            sa.store(sm + buf * A_BUF, tid);
+            sb.store(sm + B_BASE + buf * B_BUF, tid);
+        };
+
+        float av[kBK / 2][TM], bv[kBK / 2][TN];
+        if (!kPipe) {
+            fetch(0);
+            stage(0);
+            __syncthreads();
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                const bool more = (kt + 1 < nk) && p.dbg == 0;
+                if (more) fetch(kt + 1);
+                load_fragments<BM, A_KC, TM>(sm + cur * A_BUF, wm0, li, lh, av);
+                load_fragments<BN, B_KC, TN>(sm + B_BASE + cur * B_BUF, wn0, li, lh, bv);
 #pragma unroll
-            for (int s = 0; s < kBK / 2; ++s) {
+                for (int s = 0; s < kBK / 2; ++s)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) av[s][i] = a[2 * s * LDA + 32 * i];
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bv[s][j] = b[2 * s * LDB + 32 * j];
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[i][j], 0, 0, 0);
+                if (more) stage(cur ^ 1);
+                __syncthreads();
+            }
+            return;
+        }
+        // Software pipeline, one barrier per k-tile.  At the top of iteration kt: av/bv hold the operand fragments of
+        // tile kt, LDS buffer (kt+1)&1 holds tile kt+1.  The iteration issues the global loads of tile kt+2 and the LDS
+        // fragment reads of tile kt+1 BEFORE its MFMA chain, so a wave covers both latencies with its own matrix work
+        // instead of relying on other waves; tile kt+2 is written to LDS after the chain.
+        fetch(0);
+        stage(0);
+        __syncthreads();
+        load_fragments<BM, A_KC, TM>(sm, wm0, li, lh, av);
+        load_fragments<BN, B_KC, TN>(sm + B_BASE, wn0, li, lh, bv);
+        if (nk > 1) {
+            fetch(1);
+            stage(1);
+        }
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int nxt = (kt + 1) & 1;
+            const bool more2 = (kt + 2 < nk) && p.dbg == 0;
+            if (more2) fetch(kt + 2);
+            float an[kBK / 2][TM], bn[kBK / 2][TN];
+            if (kt + 1 < nk) {
+                load_fragments<BM, A_KC, TM>(sm + nxt * A_BUF, wm0, li, lh, an);
+                load_fragments<BN, B_KC, TN>(sm + B_BASE + nxt * B_BUF, wn0, li, lh, bn);
             }
 #pragma unroll
             for (int s = 0; s < kBK / 2; ++s)
@@ -194,11 +297,17 @@ struct GemmCore {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[i][j], 0, 0, 0);
-            if (kt + 1 < nk && p.dbg < 2) {
-                sa.template store<LDA>(sm + (cur ^ 1) * A_BUF, tid);
-                sb.template store<LDB>(sm + B_BASE + (cur ^ 1) * B_BUF, tid);
-            }
+            if (more2) stage(kt & 1);
             __syncthreads();
+            if (kt + 1 < nk) {
+#pragma unroll
+                for (int s = 0; s < kBK / 2; ++s) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) av[s][i] = an[s][i];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bv[s][j] = bn[s][j];
+                }
+            }
         }
     }
 
@@ -237,9 +346,9 @@ struct GemmCore {
 
 // One block = one BM x BN output tile (x one K split): main loop, then either the epilogue functor
 // epi(row, col, float4) or, for split-K, a raw store into this split's slab.
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, class Epi>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmOperands p, Epi epi, float* __restrict__ slab) {
-    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC>;
+    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
     __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
