@@ -71,6 +71,21 @@ struct Stager {
     static constexpr int SLOTS = BR * kBK / 4 / 256;   // float4 per thread per tile
     static_assert(BR * kBK % 1024 == 0, "tile must split evenly over 256 threads");
     float4 r[SLOTS];
+    const float* base[SLOTS];      // per-slot address of k = 0, rows clamped (hot-path loader only)
+
+    __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, int row0, int nrows, int tid) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int slot = tid + 256 * s;
+            if (KC) {
+                const int row = min(row0 + slot / (kBK / 4), nrows - 1);
+                base[s] = P + (int64_t)row * ld + (slot % (kBK / 4)) * 4;
+            } else {
+                const int row = max(0, min(row0 + (slot % (BR / 4)) * 4, nrows - 4));
+                base[s] = P + (int64_t)(slot / (BR / 4)) * ld + row;
+            }
+        }
+    }
 
     // FULL: the whole k-tile lies inside [kbeg, kend) -> no k predicates; rows past the edge are clamped to the
     // last valid row (their products land in accumulator rows/cols the epilogue discards).
@@ -78,20 +93,12 @@ struct Stager {
     __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int vec_ok, int row0, int nrows, int k0,
                                          int kend, int tid) {
         if (FULL && VEC) {
-            // hot path: whole tile in range along k, 16-byte loads legal (decided on the host): no predicates at all.
-            // Rows past the edge are clamped to the last valid row; their products land in accumulator rows/cols the
-            // epilogue never stores.  (Row-contiguous operands: nrows % 4 == 0 is part of VEC.)
+            // hot path: whole tile in range along k, 16-byte loads legal (decided on the host): no predicates, and the
+            // only per-tile address arithmetic is one wave-uniform offset.  Rows past the edge were clamped in init();
+            // their products land in accumulator rows/cols the epilogue never stores.
+            const int64_t off = KC ? (int64_t)k0 : (int64_t)k0 * ld;
 #pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const int slot = tid + 256 * s;
-                if (KC) {
-                    const int row = min(row0 + slot / (kBK / 4), nrows - 1);
-                    r[s] = *reinterpret_cast<const float4*>(P + (int64_t)row * ld + k0 + (slot % (kBK / 4)) * 4);
-                } else {
-                    const int row = min(row0 + (slot % (BR / 4)) * 4, nrows - 4);
-                    r[s] = *reinterpret_cast<const float4*>(P + (int64_t)(k0 + slot / (BR / 4)) * ld + row);
-                }
-            }
+            for (int s = 0; s < SLOTS; ++s) r[s] = *reinterpret_cast<const float4*>(base[s] + off);
             return;
         }
 #pragma unroll
@@ -227,6 +234,10 @@ struct GemmCore {
         const int nk = (kend - kbeg + kBK - 1) / kBK;
         if (nk <= 0) return;
         const int li = lane & 31, lh = lane >> 5;
+        if (VEC) {
+            sa.init(p.A, p.lda, m0, p.M, tid);
+            sb.init(p.B, p.ldb, n0, p.N, tid);
+        }
 
         // wave-uniform choice between the predicate-free loader and the ragged-K one (last tile only)
         auto fetch = [&](int kt) {
