@@ -71,6 +71,82 @@ class KernelTimer:
         return sum(v) / max(1, len(v)), len(v)
 
 
+def score_bytes(cfg, n_triples):
+    """SURVEY.md par. 8(d): reads (K+3) rows of D fp32 + (K+3) int32 ids, writes (K+1) fp32 scores per triple."""
+    return n_triples * ((cfg.neg_num + 3) * cfg.dim * 4 + (cfg.neg_num + 3) * 4 + (cfg.neg_num + 1) * 4)
+
+
+def roofline_dominant(cfg, timer):
+    """The launch that takes the largest share of the step: the visual projection l1 GEMM (exact-f32 MFMA)."""
+    us, n = timer.mean_us()
+    flops = 2.0 * cfg.n_ent * cfg.feat_dims[0] * cfg.dim
+    ach = flops / (us * 1e-6) / 1e12 if us else 0.0
+    return {"kernel": f"gemm_tile_kernel (visual projection: [{cfg.n_ent},{cfg.feat_dims[0]}]x[{cfg.feat_dims[0]},{cfg.dim}], exact-f32 MFMA)",
+            "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
+            "traffic": None, "avg_us": us, "launches_timed": n, "algorithmic_flops_per_launch": flops}
+
+
+def roofline_score(cfg, batch, timer):
+    """north_star's kernel: the negative-sampled scoring forward, one launch per 1024-triple batch, vs the 8 TB/s HBM figure."""
+    us, n = timer.mean_us()
+    by = score_bytes(cfg, batch)
+    ach = by / (us * 1e-6) / 1e9 if us else 0.0
+    return {"kernel": "score_fwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "avg_us": us, "launches_timed": n, "algorithmic_bytes_per_launch": by}
+
+
+def score_epoch_fused(eng, cfg, batch, device):
+    """The same kernel on a whole epoch of triples in ONE launch (78 batches).  The per-batch launch above is launch-latency-bound
+    (18.6 MB of gathers is ~2.3 us at 8 TB/s, SURVEY.md par. 7 "hard parts"); the 7.7 MB table is cache-resident, so this can exceed 1."""
+    from snag_amd._lib import call, ptr, stream
+    N, D, K = cfg.n_ent, cfg.dim, cfg.neg_num
+    Bep = STEPS_PER_EPOCH * batch
+    ge = torch.Generator().manual_seed(7)
+    hh, rr, tt, nn = (torch.randint(0, hi, sz, generator=ge, dtype=torch.int32).to(device)
+                      for hi, sz in ((N, (Bep,)), (cfg.n_rel, (Bep,)), (N, (Bep,)), (N, (Bep, K))))
+    table = eng.entity_representation()
+    pos, neg, part = torch.empty(Bep, device=device), torch.empty(Bep, K, device=device), torch.empty(Bep, device=device)
+
+    def launch():
+        call("snag_score_margin_fwd", ptr(table), table.stride(0), N, ptr(eng.p["rel"]), cfg.n_rel, D, ptr(hh), ptr(rr), ptr(tt), ptr(nn),
+             4, Bep, K, float(cfg.margin), ptr(pos), ptr(neg), ptr(part), stream())
+
+    for _ in range(3):
+        launch()
+    tm = KernelTimer()
+    timed = tm.wrap(launch)
+    for _ in range(10):
+        timed()
+    torch.cuda.synchronize()
+    us, _ = tm.mean_us()
+    by = score_bytes(cfg, Bep)
+    return {"triples_per_launch": Bep, "avg_us": us, "achieved": by / (us * 1e-6) / 1e9, "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": by}
+
+
+def untimed_extras(eng, batches, args, device):
+    """Reported next to the headline, measured after the timed region: forward-only rate (SURVEY.md par. 8d asks for both) and the
+    device-to-device copy ceiling of this GPU next to the nominal 8 TB/s."""
+    out = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.forward(*batches[i % len(batches)])
+    torch.cuda.synchronize()
+    out["forward_only"] = {"value": args.batch * args.steps / (time.perf_counter() - t0), "unit": "triples/s"}
+    src = torch.empty(1 << 28, device=device)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    out["measured_copy_GBs"] = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return out
+
+
 def cpu_baseline(cfg, feats, batch, budget_s, seed):
     """The CPU oracle (plain PyTorch restatement of the reference path) on this host's cores: same step definition."""
     from oracle import ref_cpu as O
@@ -155,6 +231,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="positives per GPU per step (NUM_BATCH)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU-baseline leg (0 = skip)")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--config", default="db15k", choices=["db15k", "mkgw"],
+                    help="db15k = BASELINE configs[1] (Mformer_hd_graph, num_proj=2, 558 relations); mkgw = configs[2] (Mformer_hd_mean, num_proj=1, 338 relations)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (forward-only rate, copy ceiling, epoch-fused score probe)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,6 +252,8 @@ def main():
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
     from snag_amd.parallel import GradAllReduce
     cfg = MKGCConfig()                                     # DB15K-shaped defaults (configs[1])
+    if args.config == "mkgw":                              # configs[2]: README "MKG-W 1 0 Mformer_hd_mean 0.2 0.7 epoch 1 2"
+        cfg.joint_way, cfg.num_proj, cfg.n_rel = "Mformer_hd_mean", 1, 338
     feats, batches = synth(cfg, args.batch, 8, cfg.seed, device)
     eng = MKGCHotPath(cfg, feats, device=device)
     reducer = GradAllReduce(world) if world > 1 else None
@@ -235,51 +316,20 @@ def main():
             "metric": "triples/sec (fusion+score) at |E|=15k dim=128 neg=32", "value": value, "unit": "triples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: DB15K-shaped MKGC train step (proj num_proj=2 over 4096/768-wide features, "
-                                   "noise 0.2/0.7, Mformer 1-layer/2-head over all 15000 entities, Mformer_hd_graph, "
+            "config": {"workload": ("configs[1]: DB15K-shaped" if args.config == "db15k" else "configs[2]: MKG-W-shaped") +
+                                   f" MKGC train step (proj num_proj={cfg.num_proj} over 4096/768-wide features, "
+                                   f"noise 0.2/0.7, Mformer 1-layer/2-head over all 15000 entities, {cfg.joint_way}, "
                                    "margin 12, fwd+bwd+AdamW" + ("+RCCL all-reduce" if world > 1 else "") + ")",
                        "n_ent": cfg.n_ent, "n_rel": cfg.n_rel, "dim": cfg.dim, "neg": cfg.neg_num, "batch_per_gpu": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": loss},
         }
+        if not args.no_extras and world == 1:
+            out.update(untimed_extras(eng, batches, args, device))
         if timers:
-            N, D = cfg.n_ent, cfg.dim
-            us, n = timers["proj_l1_fwd"].mean_us()
-            flops = 2.0 * N * cfg.feat_dims[0] * D
-            ach = flops / (us * 1e-6) / 1e12 if us else 0.0
-            out["roofline"] = {"kernel": "gemm_tile_kernel (visual projection l1: [15000,4096]x[4096,128], exact-f32 MFMA)",
-                               "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_us": us, "launches_timed": n,
-                               "algorithmic_flops_per_launch": flops}
-            us, n = timers["score_fwd"].mean_us()
-            bytes_ = args.batch * ((cfg.neg_num + 3) * D * 4 + (cfg.neg_num + 3) * 4 + (cfg.neg_num + 1) * 4)
-            ach = bytes_ / (us * 1e-6) / 1e9 if us else 0.0
-            out["score_kernel"] = {"kernel": "score_fwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": ach / HBM_PEAK_GBS, "avg_us": us, "launches_timed": n, "algorithmic_bytes_per_launch": bytes_}
-            # the same kernel on a whole epoch of triples in ONE launch (78 batches): the B=1024 launch above is
-            # launch-latency-bound (18.6 MB of gathers is ~2.3 us at 8 TB/s), see SURVEY.md par. 7 "hard parts"
-            from snag_amd import ops
-            Bep = STEPS_PER_EPOCH * args.batch
-            ge = torch.Generator().manual_seed(7)
-            hh, rr, tt, nn = (torch.randint(0, hi, sz, generator=ge, dtype=torch.int32).to(device)
-                              for hi, sz in ((N, (Bep,)), (cfg.n_rel, (Bep,)), (N, (Bep,)), (N, (Bep, cfg.neg_num))))
-            table = eng.hidden[:, eng.g_slot, :]
-            for _ in range(3):
-                ops.score_margin_fwd(table, eng.p["rel"], hh, rr, tt, nn, cfg.margin)
-            evs = []
-            for _ in range(10):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                pos_b = torch.empty(Bep, device=device); neg_b = torch.empty(Bep, cfg.neg_num, device=device); lp_b = torch.empty(Bep, device=device)
-                e0.record()
-                from snag_amd._lib import call as _call, ptr as _ptr, stream as _stream
-                _call("snag_score_margin_fwd", _ptr(table), table.stride(0), N, _ptr(eng.p["rel"]), cfg.n_rel, D, _ptr(hh), _ptr(rr), _ptr(tt),
-                      _ptr(nn), 4, Bep, cfg.neg_num, float(cfg.margin), _ptr(pos_b), _ptr(neg_b), _ptr(lp_b), _stream())
-                e1.record()
-                evs.append((e0, e1))
-            torch.cuda.synchronize()
-            us_ep = sum(a.elapsed_time(b) for a, b in evs) * 1e3 / len(evs)
-            by_ep = Bep * ((cfg.neg_num + 3) * D * 4 + (cfg.neg_num + 3) * 4 + (cfg.neg_num + 1) * 4)
-            out["score_kernel"]["epoch_fused"] = {"triples_per_launch": Bep, "avg_us": us_ep, "achieved": by_ep / (us_ep * 1e-6) / 1e9,
-                                                  "frac": by_ep / (us_ep * 1e-6) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": by_ep}
+            out["roofline"] = roofline_dominant(cfg, timers["proj_l1_fwd"])
+            out["score_kernel"] = roofline_score(cfg, args.batch, timers["score_fwd"])
+            if not args.no_extras:
+                out["score_kernel"]["epoch_fused"] = score_epoch_fused(eng, cfg, args.batch, device)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, [f.cpu() for f in feats], args.batch, args.cpu_seconds, cfg.seed)
         print(json.dumps(out))

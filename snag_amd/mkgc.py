@@ -286,7 +286,8 @@ class MKGCHotPath:
             feat = self.noisy[i] if noisy else self.feats[i]
             slot = x0p + 4 * i * D
             if cfg.num_proj == 1:
-                self._gemm(N, D, fd, ptr(feat), fd, 1, ptr(self.p[f"proj{i}.weight"]), fd, 1, slot, MD, bias=ptr(self.p[f"proj{i}.bias"]))
+                self._probed("proj_l1_fwd" if i == 0 else "", self._gemm, N, D, fd, ptr(feat), fd, 1, ptr(self.p[f"proj{i}.weight"]), fd, 1,
+                             slot, MD, bias=ptr(self.p[f"proj{i}.bias"]))
             else:   # ProjectionHead: Linear(no bias) -> ReLU -> Linear(no bias)   (model/layers.py:135-148)
                 self._probed("proj_l1_fwd" if i == 0 else "", self._gemm, N, D, fd, ptr(feat), fd, 1, ptr(self.p[f"proj{i}.l1"]), fd, 1,
                              ptr(self.mid[i]), D, act=1)
