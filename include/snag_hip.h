@@ -285,6 +285,23 @@ SNAG_API int snag_rank_summary(const int32_t* rank, int n, const int32_t* topk, 
 SNAG_API int snag_argmin_rows_cols(const float* dist, int64_t ld, int n, int m, int32_t* row_argmin, int32_t* col_argmin,
                                    float* work, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * SURVEY par. 8(f) "next" #1: the MMEA contrastive objective.
+ * Replaces the non-GEMM device work of icl_loss.forward / softXEnt (model/SNAG_loss.py:42-128); the four B x B logit
+ * blocks and the eight gradient products are snag_gemm_f32 launches issued by the host module.
+ * snag_gather_normalize_fwd: z[b,:] = x / max(|x|, 1e-12) (normalize != 0) or x, x = emb[idx[b], :]; den[b] = that
+ *   denominator (F.normalize(emb) then emb[train_links[:, s]], :59-64).   _bwd scatters into d_emb with fp32 atomics.
+ * snag_infonce_rows: logits [B, 2B] = [cross | self]: lse[i] = logsumexp_j over j != B + i (the reference's
+ *   "- masks * 1e9" on the self block, :99-103), rowloss[i] = lse[i] - logits[i, i]  (-log_softmax at the target, :45-53).
+ * snag_infonce_grad: in place, logits[i,j] <- coef * w[i] * (softmax[i,j] - [j == i]), 0 at the masked entry.
+ */
+SNAG_API int snag_gather_normalize_fwd(const float* emb, int64_t ld, int64_t n_rows, int d, const void* idx, int idx_bytes, int64_t B,
+                                       int normalize, float* z, float* den, void* stream);
+SNAG_API int snag_gather_normalize_bwd(const float* dz, const float* z, const float* den, int d, const void* idx, int idx_bytes,
+                                       int64_t B, int normalize, float* d_emb, int64_t ld, void* stream);
+SNAG_API int snag_infonce_rows(const float* logits, int64_t ld, int B, float* lse, float* rowloss, void* stream);
+SNAG_API int snag_infonce_grad(float* logits, int64_t ld, int B, const float* lse, const float* w, float coef, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

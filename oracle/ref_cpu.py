@@ -333,6 +333,43 @@ def mutual_nearest(final_emb: Tensor, left: Tensor, right: Tensor, chunk: int = 
 
 
 # --------------------------------------------------------------------------
+# (f) next #1: MMEA contrastive objective
+# --------------------------------------------------------------------------
+
+
+def icl_loss(emb: Tensor, links: Tensor, tau: float, ab_weight: float = 0.5, weight_norm: Optional[Tensor] = None,
+             norm: bool = True) -> Tensor:
+    """Bidirectional in-batch InfoNCE over aligned pairs.  reference: icl_loss.forward model/SNAG_loss.py:58-128
+    (neg_l / neg_r / inversion unused by SNAG: model/SNAG.py:50-51,106-112,143-162).
+
+    z1 = nrm(emb)[links[:,0]], z2 = nrm(emb)[links[:,1]];  logits_a = [z1 z2^T | z1 z1^T - 1e9 I] / tau, logits_b likewise
+    with the roles swapped; loss = alpha * CE_a + (1 - alpha) * CE_b, CE = -mean_i w_i log_softmax(logits)[i, i],
+    w_i = min(weight_norm[l_i], weight_norm[r_i]) when weight_norm is given (:66-70, softXEnt :42-56).
+    """
+    if norm:
+        emb = nrm(emb)
+    li, ri = links[:, 0].long(), links[:, 1].long()
+    z1, z2 = emb[li], emb[ri]
+    B = z1.shape[0]
+    eye = torch.eye(B, dtype=emb.dtype)
+    la = torch.cat([z1 @ z2.t() / tau, z1 @ z1.t() / tau - eye * 1e9], dim=1)
+    lb = torch.cat([z2 @ z1.t() / tau, z2 @ z2.t() / tau - eye * 1e9], dim=1)
+    w = torch.minimum(weight_norm[li], weight_norm[ri]) if weight_norm is not None else torch.ones(B, dtype=emb.dtype)
+    idx = torch.arange(B)
+    ce_a = -(torch.log_softmax(la, dim=1)[idx, idx] * w).sum() / B
+    ce_b = -(torch.log_softmax(lb, dim=1)[idx, idx] * w).sum() / B
+    return ab_weight * ce_a + (1.0 - ab_weight) * ce_b
+
+
+def multi_loss(losses: Sequence[Tensor], log_vars: Tensor) -> Tensor:
+    """CustomMultiLossLayer: sum_i exp(-s_i) L_i + s_i.  reference: model/SNAG_loss.py:12-29"""
+    tot = 0
+    for i, l in enumerate(losses):
+        tot = tot + torch.exp(-log_vars[i]) * l + log_vars[i]
+    return tot
+
+
+# --------------------------------------------------------------------------
 # whole MKGC step (fusion + score), used by the CPU baseline and end-to-end tests
 # --------------------------------------------------------------------------
 

@@ -16,6 +16,7 @@ Vectors (SURVEY.md par. 8c):
   g5_il.npz          SNAG.Iter_new_links mutual nearest neighbours
   g6_proj.npz        nn.Linear projections + ProjectionHead fwd/grads
   g7_encoder.npz     MultiModalEncoder.forward (projections + entity noise blend + fusion), GAT stubbed to identity
+  g8_icl_loss.npz    icl_loss (bidirectional InfoNCE, model/SNAG_loss.py:31-128) + CustomMultiLossLayer, loss and grads
 """
 import csv
 import io
@@ -406,6 +407,35 @@ def gen_g7():
     save("g7_encoder.npz", d)
 
 
+def gen_g8():
+    """icl_loss (model/SNAG_loss.py:31-128): bidirectional InfoNCE over in-batch pairs, optional per-entity weight."""
+    from model.SNAG_loss import icl_loss, CustomMultiLossLayer
+    g = torch.Generator().manual_seed(88)
+    N, d, B = 260, 96, 70
+    emb = (torch.randn(N, d, generator=g) * 1.7).requires_grad_(True)
+    perm = torch.randperm(N, generator=g)
+    links = torch.stack([perm[:B], perm[B:2 * B]], dim=1).numpy().astype(np.int32)
+    wn = torch.rand(N, generator=g) * 3
+    out = {"emb": emb, "links": links, "weight_norm": wn}
+    for tag, tau, ab, w in (("plain", 0.1, 0.5, None), ("weighted", 0.1, 0.5, wn), ("asym", 0.05, 0.3, None)):
+        crit = icl_loss(tau=tau, ab_weight=ab, n_view=2)
+        emb.grad = None
+        loss = crit(emb, links, weight_norm=w)
+        loss.backward()
+        out[f"{tag}.tau"], out[f"{tag}.ab"] = tau, ab
+        out[f"{tag}.loss"], out[f"{tag}.g.emb"] = loss, emb.grad.clone()
+    # CustomMultiLossLayer (model/SNAG_loss.py:12-29)
+    ml = CustomMultiLossLayer(loss_num=6)
+    with torch.no_grad():
+        ml.log_vars.copy_(torch.randn(6, generator=g) * 0.3)
+    ls = [torch.tensor(float(x), requires_grad=True) for x in (1.5, 0.2, 3.0, 0.7)]
+    tot = ml(ls)
+    tot.backward()
+    out["ml.log_vars"], out["ml.losses"], out["ml.total"] = ml.log_vars, torch.stack([l.detach() for l in ls]), tot
+    out["ml.g.log_vars"], out["ml.g.losses"] = ml.log_vars.grad, torch.stack([l.grad for l in ls])
+    save("g8_icl_loss.npz", out)
+
+
 if __name__ == "__main__":
     gen_g1()
     gen_g2()
@@ -413,3 +443,4 @@ if __name__ == "__main__":
     gen_g4_g5()
     gen_g6()
     gen_g7()
+    gen_g8()

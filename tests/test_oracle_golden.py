@@ -152,3 +152,25 @@ def test_encoder(tag):
         assert_close(o, z[f"{tag}.{nm}"], atol=3e-6, what=nm)
     outs[2][:, 3, :].sum().backward()
     assert_close(ent.grad, z[f"{tag}.g.entity_emb"], atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["plain", "weighted", "asym"])
+def test_icl_loss(tag):
+    z = load("g8_icl_loss.npz")
+    emb = T(z["emb"]).requires_grad_(True)
+    w = T(z["weight_norm"]) if tag == "weighted" else None
+    loss = O.icl_loss(emb, T(z["links"]), float(z[f"{tag}.tau"]), float(z[f"{tag}.ab"]), weight_norm=w)
+    assert_close(loss, z[f"{tag}.loss"], atol=2e-6, rtol=2e-6)
+    loss.backward()
+    assert_close(emb.grad, z[f"{tag}.g.emb"], atol=2e-6, rtol=1e-4)
+
+
+def test_multi_loss_layer():
+    z = load("g8_icl_loss.npz")
+    lv = T(z["ml.log_vars"]).requires_grad_(True)
+    ls = [l.clone().requires_grad_(True) for l in T(z["ml.losses"])]
+    tot = O.multi_loss(ls, lv)
+    assert_close(tot, z["ml.total"], atol=1e-6)
+    tot.backward()
+    assert_close(lv.grad, z["ml.g.log_vars"], atol=1e-6)
+    assert_close(torch.stack([l.grad for l in ls]), z["ml.g.losses"], atol=1e-6)
