@@ -9,8 +9,8 @@ One "step" = one pass of the hot path over one batch of B=1024 synthetic DB15K-s
 GPU (BASELINE.json configs[1]): per-modality projections (num_proj=2) of the noisy feature tables ->
 modality tokens -> 1-layer/2-head Mformer over ALL 15,000 entities (as the reference's
 joint_emb_generat does each step, model/SNAG.py:166-181) -> Mformer_hd_graph read-out -> margin
-score of 1 positive + 32 negative tails, its backward through the whole chain, the gradient
-all-reduce (N>1, RCCL) and a fused AdamW update.  The epoch-level noise refresh (README "noise-level:
+score of 1 positive + 32 negative tails (drawn on the device each step, filtered against the known triples), its
+backward through the whole chain, the gradient all-reduce (N>1, RCCL) and a fused AdamW update.  The epoch-level noise refresh (README "noise-level:
 epoch") runs inside the timed region every 78th step.  All inputs are resident in HBM before the
 timed region.  Rank 0 prints ONE JSON line.
 """
@@ -39,14 +39,15 @@ def synth(cfg, batch, n_batches, seed, device):
     vis = vis / vis.norm(dim=1, keepdim=True)
     txt = torch.randn(N, cfg.feat_dims[1], generator=g)
     gi = torch.Generator().manual_seed(seed + 1 + int(os.environ.get("RANK", "0")))      # sampling differs per rank, weights do not
-    batches = []
-    for _ in range(n_batches):
-        h = torch.randint(0, N, (batch,), generator=gi, dtype=torch.int32)
-        r = torch.randint(0, cfg.n_rel, (batch,), generator=gi, dtype=torch.int32)
-        t = torch.randint(0, N, (batch,), generator=gi, dtype=torch.int32)
-        neg = torch.randint(0, N, (batch, cfg.neg_num), generator=gi, dtype=torch.int32)
-        batches.append(tuple(x.to(device) for x in (h, r, t, neg)))
-    return [vis, txt], batches
+    # one epoch of positives (78 batches ~ 79,222 DB15K training triples), resident on the device; negatives are drawn on the
+    # device every step (snag_sample_negatives, known-triple filter over this rank's positives)
+    h = torch.randint(0, N, (n_batches * batch,), generator=gi, dtype=torch.int32).to(device)
+    r = torch.randint(0, cfg.n_rel, (n_batches * batch,), generator=gi, dtype=torch.int32).to(device)
+    t = torch.randint(0, N, (n_batches * batch,), generator=gi, dtype=torch.int32).to(device)
+    batches = [tuple(x[i * batch:(i + 1) * batch] for x in (h, r, t)) for i in range(n_batches)]
+    from snag_amd import ops
+    known = ops.triple_keys(h, r, t, N, cfg.n_rel)
+    return [vis, txt], batches, known
 
 
 class KernelTimer:
@@ -130,8 +131,9 @@ def untimed_extras(eng, batches, args, device):
     out = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    neg = torch.randint(0, eng.cfg.n_ent, (args.batch, eng.cfg.neg_num), device=device, dtype=torch.int32)
     for i in range(args.steps):
-        eng.forward(*batches[i % len(batches)])
+        eng.forward(*batches[i % len(batches)], neg)
     torch.cuda.synchronize()
     out["forward_only"] = {"value": args.batch * args.steps / (time.perf_counter() - t0), "unit": "triples/s"}
     src = torch.empty(1 << 28, device=device)
@@ -254,7 +256,10 @@ def main():
     cfg = MKGCConfig()                                     # DB15K-shaped defaults (configs[1])
     if args.config == "mkgw":                              # configs[2]: README "MKG-W 1 0 Mformer_hd_mean 0.2 0.7 epoch 1 2"
         cfg.joint_way, cfg.num_proj, cfg.n_rel = "Mformer_hd_mean", 1, 338
-    feats, batches = synth(cfg, args.batch, 8, cfg.seed, device)
+    feats, batches, known = synth(cfg, args.batch, STEPS_PER_EPOCH, cfg.seed, device)
+    from snag_amd import ops
+    neg_buf = torch.empty(args.batch, cfg.neg_num, device=device, dtype=torch.int32)
+    rank_seed = cfg.seed * 7919 + int(os.environ.get("RANK", "0"))
     eng = MKGCHotPath(cfg, feats, device=device)
     reducer = GradAllReduce(world) if world > 1 else None
     if os.environ.get("BENCH_FORCE_ALLREDUCE") and reducer is None:          # exercise the collective on a 1-GPU box
@@ -277,8 +282,9 @@ def main():
     def one_step(i):
         if cfg.add_noise and i % STEPS_PER_EPOCH == 0:
             eng.update_noise()
-        b = batches[i % len(batches)]
-        eng.forward(*b)
+        h, r, t = batches[i % len(batches)]
+        ops.sample_negatives(h, r, t, cfg.neg_num, cfg.n_ent, cfg.n_rel, rank_seed, known_sorted=known, tick=eng.tick, out=neg_buf)
+        eng.forward(h, r, t, neg_buf)
         eng.backward(gscale)
         if reducer is not None:
             reducer(eng.gflat)

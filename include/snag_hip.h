@@ -302,6 +302,17 @@ SNAG_API int snag_gather_normalize_bwd(const float* dz, const float* z, const fl
 SNAG_API int snag_infonce_rows(const float* logits, int64_t ld, int B, float* lse, float* rowloss, void* stream);
 SNAG_API int snag_infonce_grad(float* logits, int64_t ld, int B, const float* lse, const float* w, float coef, void* stream);
 
+/* SURVEY par. 8(f) "next" #3: negative sampling on the device (no Python sampler, no H2D index copies).
+ * Follows generate_neg_triples_fast (model/MSNEA_tools.py:59-90): a candidate that forms a known triple is redrawn, up to
+ * 10 tries, the last one kept regardless.  mode 0: n_neg negative TAILS per positive (the MKGC shape of BASELINE.json);
+ * mode 1: per positive a Bernoulli(0.5) choice between corrupting the head and the tail (the in-tree behaviour), heads in
+ * neg_h, tails in neg_t.  known_sorted: ascending int64 keys (h * n_rel + r) * n_ent + t of all known triples, or NULL.
+ * Deviations (parity unpinned, RNG streams cannot match): candidates are drawn WITH replacement (random.sample draws
+ * without), from 0..n_ent-1 (the reference samples the KG's own entity list).  tick: see snag_tick. int32 indices. */
+SNAG_API int snag_sample_negatives(uint64_t seed, const uint64_t* tick, const int32_t* h, const int32_t* r, const int32_t* t,
+                                   int64_t batch, int n_neg, int n_ent, int n_rel, int mode, const int64_t* known_sorted,
+                                   int64_t n_known, int32_t* neg_h, int32_t* neg_t, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -193,6 +193,45 @@ __global__ __launch_bounds__(256) void entity_token_fwd_kernel(const float* __re
     }
 }
 
+// On-device negative sampling (in-tree sampler: generate_neg_triples_fast, model/MSNEA_tools.py:59-90).
+// One thread per (positive b, slot k).  mode 0 corrupts the tail only (MKGC: NEG_NUM negative tails); mode 1 flips a
+// Bernoulli(0.5) coin per POSITIVE (as the reference does, :68) between corrupting the head and the tail.  A candidate
+// that forms a known triple is rejected and redrawn, up to 10 tries, the last try is kept whatever it is (:66-76).
+// known: sorted int64 keys (h * n_rel + r) * n_ent + t, or NULL for no filtering.
+__device__ __forceinline__ bool key_known(const int64_t* __restrict__ keys, int64_t n, int64_t key) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int64_t v = keys[mid];
+        if (v == key) return true;
+        if (v < key) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void sample_negatives_kernel(uint64_t seed, const uint64_t* __restrict__ tick, const int32_t* __restrict__ h,
+                                                               const int32_t* __restrict__ r, const int32_t* __restrict__ t, int64_t B, int K,
+                                                               int n_ent, int n_rel, int mode, const int64_t* __restrict__ known, int64_t n_known,
+                                                               int32_t* __restrict__ neg_h, int32_t* __restrict__ neg_t) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * K) return;
+    if (tick != nullptr) seed += tick[0] * 0x9E3779B97F4A7C15ull;
+    const int64_t b = i / K;
+    const int hb = h[b], rb = r[b], tb = t[b];
+    bool corrupt_head = false;
+    if (mode == 1) corrupt_head = (philox4x32_10(seed ^ 0xC0FFEEull, (uint64_t)b).x & 1u) != 0;
+    int cand = 0;
+    for (int attempt = 0; attempt < 10; ++attempt) {
+        const Philox4 p = philox4x32_10(seed, (uint64_t)i * 16 + attempt);
+        cand = (int)(((uint64_t)p.x * (uint64_t)n_ent) >> 32);             // uniform in [0, n_ent), no modulo bias to speak of
+        if (known == nullptr || attempt == 9) break;
+        const int64_t key = corrupt_head ? ((int64_t)cand * n_rel + rb) * n_ent + tb : ((int64_t)hb * n_rel + rb) * n_ent + cand;
+        if (!key_known(known, n_known, key)) break;
+    }
+    if (neg_h != nullptr) neg_h[i] = corrupt_head ? cand : hb;
+    neg_t[i] = corrupt_head ? tb : cand;
+}
+
 static int grid_for(int64_t n) { return (int)std::min<int64_t>(4096, (n + 255) / 256); }
 
 }  // namespace snag
@@ -294,4 +333,20 @@ extern "C" SNAG_API int snag_entity_token_fwd(const float* table, int64_t N, int
     hipLaunchKernelGGL(entity_token_fwd_kernel, dim3(grid_for(N * (int64_t)D)), dim3(256), 0, (hipStream_t)stream, table, N, D, noise,
                        noise_mask, half_mask_ratio, out, out_ld);
     return check_launch("snag_entity_token_fwd");
+}
+
+extern "C" SNAG_API int snag_sample_negatives(uint64_t seed, const uint64_t* tick, const int32_t* h, const int32_t* r, const int32_t* t, int64_t batch,
+                                              int n_neg, int n_ent, int n_rel, int mode, const int64_t* known_sorted, int64_t n_known,
+                                              int32_t* neg_h, int32_t* neg_t, void* stream) {
+    SNAG_REQUIRE(batch >= 0 && n_neg >= 0 && n_ent >= 1 && n_rel >= 1, SNAG_ERR_ARG, "sample_negatives: bad sizes");
+    SNAG_REQUIRE(mode == 0 || mode == 1, SNAG_ERR_ARG, "sample_negatives: mode=%d (0 = tails, 1 = head-or-tail)", mode);
+    if (batch == 0 || n_neg == 0) return SNAG_OK;
+    SNAG_REQUIRE(h && r && t && neg_t, SNAG_ERR_ARG, "sample_negatives: null pointer");
+    SNAG_REQUIRE(mode == 0 || neg_h != nullptr, SNAG_ERR_ARG, "sample_negatives: head-or-tail mode needs neg_h");
+    SNAG_REQUIRE((known_sorted != nullptr) == (n_known > 0), SNAG_ERR_ARG, "sample_negatives: known_sorted and n_known go together");
+    SNAG_REQUIRE((int64_t)n_ent * n_rel < (1LL << 62) / n_ent, SNAG_ERR_UNSUPPORTED, "sample_negatives: triple key overflows int64");
+    const int64_t total = batch * n_neg;
+    hipLaunchKernelGGL(sample_negatives_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, tick, h, r, t, batch,
+                       n_neg, n_ent, n_rel, mode, known_sorted, n_known, neg_h, neg_t);
+    return check_launch("snag_sample_negatives");
 }

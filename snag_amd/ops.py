@@ -258,3 +258,23 @@ def pack_tokens(embs, g_slot=-1, noise=None, noise_mask=None, mask_ratio=0.0, ou
     call("snag_pack_tokens", arr, M, N, D, g_slot % M if M else 0, ptr(noise), ptr(noise_mask), float(mask_ratio) * 0.5,
          ptr(out), stream())
     return out
+
+
+def triple_keys(h, r, t, n_ent, n_rel):
+    """Sorted int64 keys (h * n_rel + r) * n_ent + t of a triple set, for the sampler's known-triple filter."""
+    k = (h.long() * n_rel + r.long()) * n_ent + t.long()
+    return torch.sort(k)[0].contiguous()
+
+
+def sample_negatives(h, r, t, n_neg, n_ent, n_rel, seed, known_sorted=None, head_or_tail=False, tick=None, out=None):
+    """neg_t [B, n_neg] (and neg_h when head_or_tail) drawn on the device.  C ABI: snag_sample_negatives."""
+    for x, nm in ((h, "h"), (r, "r"), (t, "t")):
+        _chk(x, nm, dtype=torch.int32, ndim=1)
+    B = h.shape[0]
+    neg_t = out if out is not None else torch.empty(B, n_neg, device=h.device, dtype=torch.int32)
+    neg_h = torch.empty(B, n_neg, device=h.device, dtype=torch.int32) if head_or_tail else None
+    if known_sorted is not None:
+        _chk(known_sorted, "known_sorted", dtype=torch.int64, ndim=1)
+    call("snag_sample_negatives", int(seed), ptr(tick), ptr(h), ptr(r), ptr(t), B, int(n_neg), int(n_ent), int(n_rel), int(head_or_tail),
+         ptr(known_sorted), known_sorted.numel() if known_sorted is not None else 0, ptr(neg_h), ptr(neg_t), stream())
+    return (neg_h, neg_t) if head_or_tail else neg_t

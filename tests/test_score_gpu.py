@@ -127,3 +127,33 @@ def test_score_bf16_tables(D, K, B):
     assert_close(pos_g, pos, atol=1e-5)
     assert_close(neg_g, ng, atol=1e-5)
     assert_close(ops.reduce_sum(lp), loss, atol=1e-3, rtol=2e-6)
+
+
+def test_device_negative_sampler():
+    """Unpinned by the reference (RNG streams differ): check the sampler's contract instead."""
+    from snag_amd import ops
+    N, R, B, K = 2000, 7, 4096, 32
+    g = torch.Generator().manual_seed(3)
+    h = torch.randint(0, N, (B,), generator=g, dtype=torch.int32).to(DEV)
+    r = torch.randint(0, R, (B,), generator=g, dtype=torch.int32).to(DEV)
+    t = torch.randint(0, N, (B,), generator=g, dtype=torch.int32).to(DEV)
+    neg = ops.sample_negatives(h, r, t, K, N, R, seed=11)
+    assert neg.shape == (B, K) and int(neg.min()) >= 0 and int(neg.max()) < N
+    assert torch.equal(neg, ops.sample_negatives(h, r, t, K, N, R, seed=11))          # counter-based: reproducible
+    assert not torch.equal(neg, ops.sample_negatives(h, r, t, K, N, R, seed=12))
+    counts = torch.bincount(neg.flatten().long(), minlength=N).float()
+    assert abs(float(counts.mean()) - B * K / N) < 1e-3 and float(counts.std()) < 1.5 * (B * K / N) ** 0.5     # ~Poisson
+    # filter: make EVERY (h, r, x) with x even a known triple for the first 64 positives -> their negatives must be odd
+    hh, rr = h[:64].cpu(), r[:64].cpu()
+    ev = torch.arange(0, N, 2)
+    kh = hh.repeat_interleave(ev.numel()); kr = rr.repeat_interleave(ev.numel()); kt = ev.repeat(64)
+    keys = ops.triple_keys(kh.to(DEV), kr.to(DEV), kt.to(DEV), N, R)
+    negf = ops.sample_negatives(h[:64], r[:64], t[:64], K, N, R, seed=5, known_sorted=keys)
+    frac_even = float((negf % 2 == 0).float().mean())
+    assert frac_even < 0.01, frac_even                     # only the "10th try is kept" escape (p = 2^-10) may leak
+    # in-tree mode: per positive either all heads or all tails are corrupted, about half each
+    nh, nt = ops.sample_negatives(h, r, t, K, N, R, seed=9, head_or_tail=True)
+    head_rows = (nt == t.view(-1, 1)).all(1)
+    tail_rows = (nh == h.view(-1, 1)).all(1)
+    assert bool((head_rows | tail_rows).all())
+    assert 0.45 < float(head_rows.float().mean()) < 0.55

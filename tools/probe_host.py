@@ -4,7 +4,9 @@ sys.path.insert(0, '.')
 import bench
 from snag_amd.mkgc import MKGCConfig, MKGCHotPath
 cfg = MKGCConfig()
-feats, batches = bench.synth(cfg, 1024, 4, cfg.seed, torch.device('cuda'))
+feats, batches, known = bench.synth(cfg, 1024, 4, cfg.seed, torch.device('cuda'))
+neg = torch.randint(0, cfg.n_ent, (1024, 32), device='cuda', dtype=torch.int32)
+batches = [b + (neg,) for b in batches]
 eng = MKGCHotPath(cfg, feats)
 eng.update_noise()
 for i in range(10): eng.train_step(*batches[i % 4])
