@@ -70,7 +70,22 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(
     const int sub = lane & 15;
     const int grp = lane >> 4;
 
+    // Two dependent memory round trips in total: (1) every index this wave needs -- the three scalar ids and one coalesced
+    // read of up to 64 negative-tail ids -- (2) every row: head, relation, positive tail and the first 32 negatives
+    // (22 dwordx4 per lane in flight).  Only then does arithmetic start.
     const int64_t hi = (int64_t)h[b], ri = (int64_t)r[b], ti = (int64_t)t[b];
+    const IdxT* nrow = neg_t + b * (int64_t)n_neg;
+    float* out = neg + b * (int64_t)n_neg;
+    int my = (lane < n_neg) ? (neg_t != nullptr ? (int)nrow[lane] : lane) : 0;
+    // keep the three scalar ids and the id vector in ONE wait: nothing below may be scheduled above this point
+    asm volatile("" : "+v"(my) : "s"((int)hi), "s"((int)ri), "s"((int)ti) : "memory");
+    constexpr int kFirst = (NV <= 2) ? 8 : 4;                 // rounds of 4 rows prefetched with the positive (register budget)
+    const bool first_block = n_neg >= 4 * kFirst;
+    RowV4<NV> x0[kFirst];
+    if (first_block) {
+#pragma unroll
+        for (int u = 0; u < kFirst; ++u) x0[u] = load_row_v4<NV>(ent, __shfl(my, 4 * u + grp), eld, dim, sub);
+    }
     RowV4<NV> q = load_row_v4<NV>(ent, hi, eld, dim, sub);
     RowV4<NV> rr = load_row_v4<NV>(rel, ri, dim, dim, sub);
     const RowV4<NV> tt = load_row_v4<NV>(ent, ti, eld, dim, sub);
@@ -89,13 +104,18 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(
     if (lane == 0) pos[b] = s_pos;
 
     float hinge = 0.f;
-    const IdxT* nrow = neg_t + b * (int64_t)n_neg;
-    float* out = neg + b * (int64_t)n_neg;
+    if (first_block) {
+#pragma unroll
+        for (int u = 0; u < kFirst; ++u) {
+            const float s = score_row<NV>(q, x0[u]);
+            hinge += fmaxf(margin + s_pos - s, 0.f);
+            if (sub == 0) out[4 * u + grp] = s;
+        }
+    }
     for (int k0 = 0; k0 < n_neg; k0 += 64) {
-        // one coalesced read of up to 64 negative-tail ids, handed to the lane groups by bpermute
-        const int my = (k0 + lane < n_neg) ? (neg_t != nullptr ? (int)nrow[k0 + lane] : k0 + lane) : 0;
+        if (k0 > 0) my = (k0 + lane < n_neg) ? (neg_t != nullptr ? (int)nrow[k0 + lane] : k0 + lane) : 0;
         const int cnt = min(64, n_neg - k0);
-        int it = 0;
+        int it = (k0 == 0 && first_block) ? 4 * kFirst : 0;
         // full blocks: 8 rounds x 4 rows, all 16 gathers of the block issued before the first use
         for (; it + 32 <= cnt; it += 32) {
             RowV4<NV> x[8];
@@ -209,9 +229,8 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(
 
     float c_pos = hinge_mode ? 0.f : gscale * dpos[b];
     const IdxT* nrow = neg_t + b * (int64_t)n_neg;
-    for (int k = 0; k < n_neg; ++k) {
-        const int64_t xi = (int64_t)nrow[k];
-        RowS<NS> x = load_row_s<NS>(ent, xi, eld, dim, lane);
+    // one negative: recompute its score (hinge mode), fold its contribution into dq, scatter its own gradient
+    auto one_negative = [&](int k, int64_t xi, RowS<NS>& x) {
         const float den_x = normalize_s<NS>(x);
         float c;
         if (hinge_mode) {
@@ -237,6 +256,23 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(
             }
             normalize_bwd_atomic<NS>(x, den_x, dx, d_ent + xi * dld, dim, lane);
         }
+    };
+    int k = 0;
+    constexpr int kAhead = (NS <= 2) ? 8 : 4;        // rows gathered before the first is consumed: hides the table latency
+    for (; k + kAhead <= n_neg; k += kAhead) {
+        int64_t xi[kAhead];
+        RowS<NS> x[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) xi[u] = (int64_t)nrow[k + u];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) x[u] = load_row_s<NS>(ent, xi[u], eld, dim, lane);
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) one_negative(k + u, xi[u], x[u]);
+    }
+    for (; k < n_neg; ++k) {
+        const int64_t xi = (int64_t)nrow[k];
+        RowS<NS> x = load_row_s<NS>(ent, xi, eld, dim, lane);
+        one_negative(k, xi, x);
     }
     if (c_pos != 0.f) {
         RowS<NS> dx;
