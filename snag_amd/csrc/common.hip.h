@@ -35,12 +35,20 @@ __device__ __forceinline__ float sum16(float v) {
     return v;
 }
 
-// all-reduce over the whole 64-lane wave
+// DPP with explicit row mask: rows whose bit is clear receive `old`
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32_rows(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+
+// all-reduce over the whole 64-lane wave, no LDS traffic: four row rotations give every lane its row's sum, row_bcast:15
+// folds row 0 into 1 and row 2 into 3, row_bcast:31 folds rows 0+1 into 2 and 3, lane 63 then holds the total and a
+// v_readlane hands it to every lane through an SGPR.
 __device__ __forceinline__ float sum64(float v) {
     v = sum16(v);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    v += dpp_f32_rows<0x142, 0xa>(0.f, v);   // row_bcast:15 -> rows 1, 3
+    v += dpp_f32_rows<0x143, 0xc>(0.f, v);   // row_bcast:31 -> rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ float max16(float v) {
@@ -53,9 +61,9 @@ __device__ __forceinline__ float max16(float v) {
 
 __device__ __forceinline__ float max64(float v) {
     v = max16(v);
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
+    v = fmaxf(v, dpp_f32_rows<0x142, 0xa>(v, v));
+    v = fmaxf(v, dpp_f32_rows<0x143, 0xc>(v, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ int wave_id_uniform() {

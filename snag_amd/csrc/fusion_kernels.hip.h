@@ -76,6 +76,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     const int lane = threadIdx.x & 63;
     const int d = D / H;
     Cols<NU> q[M], k[M], v[M], o[M];
+    // the entity's H*M*M keep flags in one coalesced read (lanes 0..63, 64..127), handed out by v_readlane below:
+    // a per-(i,j) global load inside the head loop would be a dependent memory round trip each
+    const int HMM = H * M * M;
+    int kb0 = 1, kb1 = 1;
+    if (keep != nullptr) {
+        kb0 = lane < HMM ? (int)keep[n * HMM + lane] : 1;
+        kb1 = lane + 64 < HMM ? (int)keep[n * HMM + 64 + lane] : 1;
+    }
 #pragma unroll
     for (int i = 0; i < M; ++i) {
         const float* row = qkv + (n * M + i) * (int64_t)(3 * D);
@@ -94,7 +102,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < M; ++i)
 #pragma unroll
-                for (int j = 0; j < M; ++j) p[i][j] = keep[pbase + i * M + j] ? p[i][j] * kscale : 0.f;
+                for (int j = 0; j < M; ++j) {
+                    const int e = h * M * M + i * M + j;
+                    const int kf = e < 64 ? __builtin_amdgcn_readlane(kb0, e) : __builtin_amdgcn_readlane(kb1, e - 64);
+                    p[i][j] = kf ? p[i][j] * kscale : 0.f;
+                }
         }
         // lanes 0..M*M-1 store one probability each (select chain keeps p[][] in registers)
         {
@@ -137,6 +149,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     for (int u = 0; u < NU; ++u) sq.v[u] = sk.v[u] = sv.v[u] = 0.f;
   for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
     Cols<NU> q[M], k[M], v[M], go[M], dq[M], dk[M], dv[M];
+    const int HMM = H * M * M;
+    int kb0 = 1, kb1 = 1;
+    float ex0 = 0.f, ex1 = 0.f;
+    if (keep != nullptr) {
+        kb0 = lane < HMM ? (int)keep[n * HMM + lane] : 1;
+        kb1 = lane + 64 < HMM ? (int)keep[n * HMM + 64 + lane] : 1;
+    }
+    if (dprobs_extra != nullptr) {
+        ex0 = lane < HMM ? dprobs_extra[n * HMM + lane] : 0.f;
+        ex1 = lane + 64 < HMM ? dprobs_extra[n * HMM + 64 + lane] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < M; ++i) {
         const float* row = qkv + (n * M + i) * (int64_t)(3 * D);
@@ -151,7 +174,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         const int lo = h * d, hi = lo + d;
         float p[M][M], ds[M][M];
         head_scores<M, NU>(q, k, lo, hi, lane, inv_sqrt_d, p);
-        const int64_t pbase = (n * H + h) * (int64_t)(M * M);
 #pragma unroll
         for (int i = 0; i < M; ++i) {
             float dp[M];
@@ -165,8 +187,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                     part += (c >= lo && c < hi) ? go[i].v[u] * v[j].v[u] : 0.f;
                 }
                 float g = sum64(part);                                   // d loss / d P~[i][j] through ctx
-                if (dprobs_extra != nullptr) g += dprobs_extra[pbase + i * M + j];
-                const float km = (keep == nullptr) ? 1.f : (keep[pbase + i * M + j] ? kscale : 0.f);
+                const int e = h * M * M + i * M + j;
+                if (dprobs_extra != nullptr)
+                    g += __int_as_float(e < 64 ? __builtin_amdgcn_readlane(__float_as_int(ex0), e) : __builtin_amdgcn_readlane(__float_as_int(ex1), e - 64));
+                const int kf = e < 64 ? __builtin_amdgcn_readlane(kb0, e) : __builtin_amdgcn_readlane(kb1, e - 64);
+                const float km = (keep == nullptr) ? 1.f : (kf ? kscale : 0.f);
                 // dV_j += P~[i][j] * dctx_i
                 const float pt = p[i][j] * km;
 #pragma unroll
