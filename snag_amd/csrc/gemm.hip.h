@@ -42,6 +42,12 @@ constexpr int kBK = 16;
 #ifndef SNAG_GEMM_PIPE
 #define SNAG_GEMM_PIPE 0
 #endif
+//   SNAG_GEMM_DMA  1: the unpredicated (VEC) kernels fetch full k-tiles with global_load_lds_dwordx4 (LDS-DMA: no VGPR
+//                  staging, no ds_write); needs SNAG_GEMM_SWZ=1 (dense tiles: the DMA writes 64 lanes x 16 B linearly)
+#ifndef SNAG_GEMM_DMA
+#define SNAG_GEMM_DMA 1
+#endif
+constexpr bool kDma = (SNAG_GEMM_DMA != 0) && (SNAG_GEMM_SWZ != 0);
 constexpr bool kSwz = SNAG_GEMM_SWZ != 0;
 constexpr bool kPipe = SNAG_GEMM_PIPE != 0;
 
@@ -84,6 +90,35 @@ struct Stager {
                 const int row = max(0, min(row0 + (slot % (BR / 4)) * 4, nrows - 4));
                 base[s] = P + (int64_t)(slot / (BR / 4)) * ld + row;
             }
+        }
+    }
+
+    // LDS-DMA fetch of one full k-tile: lane L of wave w writes the 16-byte chunk at tile position 256*s + 64*w + L, so
+    // it must READ the chunk that belongs there.  Row-contiguous tiles are linear in slot order already; K-contiguous
+    // tiles store chunk c of a row at position c ^ ((row >> 2) & 3), an involution, so position p holds chunk p ^ swz.
+    __device__ __forceinline__ void init_dma(const float* __restrict__ P, int64_t ld, int row0, int nrows, int tid) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int slot = tid + 256 * s;
+            if (KC) {
+                const int lrow = slot / (kBK / 4);
+                const int c = (slot % (kBK / 4)) ^ ((lrow >> 2) & 3);
+                base[s] = P + (int64_t)min(row0 + lrow, nrows - 1) * ld + 4 * c;
+            } else {
+                const int row = max(0, min(row0 + (slot % (BR / 4)) * 4, nrows - 4));
+                base[s] = P + (int64_t)(slot / (BR / 4)) * ld + row;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void dma(lds_float* tile, int64_t ld, int k0, int wave) const {
+        const int64_t off = KC ? (int64_t)k0 : (int64_t)k0 * ld;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base[s] + off),
+                                             (__attribute__((address_space(3))) void*)(tile + (256 * s + 64 * wave) * 4), 16, 0, 0);
+#endif
         }
     }
 
@@ -238,7 +273,6 @@ struct GemmCore {
             sa.init(p.A, p.lda, m0, p.M, tid);
             sb.init(p.B, p.ldb, n0, p.N, tid);
         }
-
         // wave-uniform choice between the predicate-free loader and the ragged-K one (last tile only)
         auto fetch = [&](int kt) {
             const int k0 = kbeg + kt * kBK;
@@ -256,6 +290,45 @@ struct GemmCore {
         };
 
         float av[kBK / 2][TM], bv[kBK / 2][TN];
+        if (kDma && VEC) {
+            // LDS-DMA main loop: the copy of tile kt+1 runs while tile kt feeds the matrix pipe; the only wait is the
+            // vmcnt(0) in front of the barrier that publishes it.  A ragged last tile takes the register path.
+            sa.init_dma(p.A, p.lda, m0, p.M, tid);
+            sb.init_dma(p.B, p.ldb, n0, p.N, tid);
+            auto full = [&](int kt) { return kbeg + (kt + 1) * kBK <= kend; };
+            auto bring = [&](int kt, int buf) {        // returns true when the tile went through registers
+                if (full(kt)) {
+                    sa.dma(sm + buf * A_BUF, p.lda, kbeg + kt * kBK, wave);
+                    sb.dma(sm + B_BASE + buf * B_BUF, p.ldb, kbeg + kt * kBK, wave);
+                    return false;
+                }
+                sa.template load<false, false>(p.A, p.lda, p.a_vec, m0, p.M, kbeg + kt * kBK, kend, tid);
+                sb.template load<false, false>(p.B, p.ldb, p.b_vec, n0, p.N, kbeg + kt * kBK, kend, tid);
+                return true;
+            };
+            if (bring(0, 0)) stage(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                const bool more = (kt + 1 < nk) && p.dbg == 0;
+                bool via_regs = false;
+                if (more) via_regs = bring(kt + 1, cur ^ 1);
+                load_fragments<BM, A_KC, TM>(sm + cur * A_BUF, wm0, li, lh, av);
+                load_fragments<BN, B_KC, TN>(sm + B_BASE + cur * B_BUF, wn0, li, lh, bv);
+#pragma unroll
+                for (int s = 0; s < kBK / 2; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[i][j], 0, 0, 0);
+                if (via_regs) stage(cur ^ 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            return;
+        }
         if (!kPipe) {
             fetch(0);
             stage(0);
