@@ -131,7 +131,6 @@ def untimed_extras(eng, batches, args, device):
     out = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    neg = torch.randint(0, eng.cfg.n_ent, (args.batch, eng.cfg.neg_num), device=device, dtype=torch.int32)
     for i in range(args.steps):
         eng.forward(*batches[i % len(batches)], neg)
     torch.cuda.synchronize()
