@@ -74,6 +74,11 @@ class MKGCHotPath:
             if tuple(f.shape) != (N, fd) or f.dtype != f32:
                 raise ValueError(f"feature table must be fp32 [{N}, {fd}], got {tuple(f.shape)}")
             self.feats.append(f.to(self.dev).contiguous())
+        # The first projection of every modality is X W^T with X [N, F] and F in the thousands.  As a GEMM with both
+        # operands K-contiguous it measures 81 TF; with both row-contiguous (X^T [F, N], W^T [F, D]) the LDS-DMA loop
+        # reaches 93 TF, so the engine keeps a transposed copy of each (static / once-per-epoch) feature table and
+        # stores that weight transposed.  The weight gradient dW^T = X^T-shaped product needs no extra copy.
+        self.feats_t = [f.t().contiguous() for f in self.feats]
         self.g_slot = M - 1                                   # structural token last
         I, L, ffn = cfg.intermediate_size, cfg.num_layers, bool(cfg.use_intermediate)
 
@@ -91,10 +96,10 @@ class MKGCHotPath:
         add("rel", R, D)
         for i, fd in enumerate(cfg.feat_dims):
             if cfg.num_proj == 1:
-                add(f"proj{i}.weight", D, fd)
+                add(f"proj{i}.weight", fd, D)      # stored TRANSPOSED ([in, out]): see _first_proj
                 add(f"proj{i}.bias", D)
             else:
-                add(f"proj{i}.l1", D, fd)
+                add(f"proj{i}.l1", fd, D)          # stored TRANSPOSED
                 add(f"proj{i}.l2", D, D)
         add("weight_raw", 6)
         for l in range(L):
@@ -128,7 +133,7 @@ class MKGCHotPath:
         self.save = torch.empty(lib.snag_fusion_save_floats(N, M, D, cfg.num_heads, I, L, int(ffn)), device=dev)
         ws = lib.snag_fusion_work_floats(N, M, D, cfg.num_heads, I, L, int(ffn))
         for fd in cfg.feat_dims:
-            ws = max(ws, lib.snag_gemm_workspace_floats(D, fd, N) + 64, lib.snag_gemm_workspace_floats(N, D, fd) + 64, 256 * max(D, fd))
+            ws = max(ws, lib.snag_gemm_workspace_floats(fd, D, N) + 64, lib.snag_gemm_workspace_floats(N, D, fd) + 64, 256 * max(D, fd))
         ws = max(ws, lib.snag_gemm_workspace_floats(D, D, N) + 64, lib.snag_gemm_workspace_floats(N, D, D) + 64)
         self.work = torch.empty(ws, device=dev)
         H = cfg.num_heads
@@ -138,6 +143,7 @@ class MKGCHotPath:
         self.tick = torch.zeros(1, device=dev, dtype=torch.int64)      # device-side step counter
         # noise state (model/SNAG.py:86-98)
         self.noisy = [f.clone() for f in self.feats]
+        self.noisy_t = [f.clone() for f in self.feats_t]
         self.feat_stats = None
         self.ent_noise = torch.zeros(N, D, device=dev)
         self.ent_noise_mask = torch.zeros(N, device=dev, dtype=torch.uint8)
@@ -168,10 +174,10 @@ class MKGCHotPath:
         self.p["rel"].copy_(torch.randn(cfg.n_rel, D, generator=g) * math.sqrt(2.0 / (cfg.n_rel + D)))   # xavier normal
         for i, fd in enumerate(cfg.feat_dims):
             if cfg.num_proj == 1:
-                self.p[f"proj{i}.weight"].copy_(lin((D, fd)))
+                self.p[f"proj{i}.weight"].copy_(lin((D, fd)).t())
                 self.p[f"proj{i}.bias"].copy_(bias(D, fd))
             else:
-                self.p[f"proj{i}.l1"].copy_(lin((D, fd)))
+                self.p[f"proj{i}.l1"].copy_(lin((D, fd)).t())
                 self.p[f"proj{i}.l2"].copy_(lin((D, D)))
         self.p["weight_raw"].fill_(1.0)
         I = cfg.intermediate_size
@@ -267,6 +273,7 @@ class MKGCHotPath:
             mean, std = self.feat_stats[i]
             call("snag_noise_apply", ptr(f), N, f.shape[1], ptr(mean), ptr(std), ptr(self.row_mask), None, None,
                  base + 11 * i + 2, float(cfg.mask_ratio), ptr(self.noisy[i]), st)
+            self.noisy_t[i].copy_(self.noisy[i].t())            # once per epoch
         mean, std = ops.colstats(self.p["ent"])
         call("snag_gaussian_fill", base + 101, N, D, ptr(mean), ptr(std), ptr(self.ent_noise), st)
         call("snag_dropout_keep_mask", base + 102, None, N, float(cfg.noise_ratio) * 0.5, ptr(self.ent_noise_mask), st)
@@ -283,14 +290,14 @@ class MKGCHotPath:
         MD = M * D
         x0p = self.x0.data_ptr()
         for i, fd in enumerate(cfg.feat_dims):
-            feat = self.noisy[i] if noisy else self.feats[i]
+            feat_t = self.noisy_t[i] if noisy else self.feats_t[i]          # [fd, N]
             slot = x0p + 4 * i * D
+            tag = "proj_l1_fwd" if i == 0 else ""
             if cfg.num_proj == 1:
-                self._probed("proj_l1_fwd" if i == 0 else "", self._gemm, N, D, fd, ptr(feat), fd, 1, ptr(self.p[f"proj{i}.weight"]), fd, 1,
-                             slot, MD, bias=ptr(self.p[f"proj{i}.bias"]))
+                self._probed(tag, self._gemm, N, D, fd, ptr(feat_t), N, 0, ptr(self.p[f"proj{i}.weight"]), D, 0, slot, MD,
+                             bias=ptr(self.p[f"proj{i}.bias"]))
             else:   # ProjectionHead: Linear(no bias) -> ReLU -> Linear(no bias)   (model/layers.py:135-148)
-                self._probed("proj_l1_fwd" if i == 0 else "", self._gemm, N, D, fd, ptr(feat), fd, 1, ptr(self.p[f"proj{i}.l1"]), fd, 1,
-                             ptr(self.mid[i]), D, act=1)
+                self._probed(tag, self._gemm, N, D, fd, ptr(feat_t), N, 0, ptr(self.p[f"proj{i}.l1"]), D, 0, ptr(self.mid[i]), D, act=1)
                 self._gemm(N, D, D, ptr(self.mid[i]), D, 1, ptr(self.p[f"proj{i}.l2"]), D, 1, slot, MD)
         call("snag_entity_token_fwd", ptr(self.p["ent"]), N, D, ptr(self.ent_noise) if noisy else None,
              ptr(self.ent_noise_mask) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD, st)
@@ -346,14 +353,14 @@ class MKGCHotPath:
             feat = self.noisy[i] if noisy else self.feats[i]
             dslot = dx0 + 4 * i * D
             if cfg.num_proj == 1:
-                # dW = dTok^T feat ; db = colsum(dTok)
-                self._gemm(D, fd, N, dslot, MD, 0, ptr(feat), fd, 0, ptr(self.g[f"proj{i}.weight"]), fd, splitk=True)
+                # dW^T [fd, D] = feat^T dTok ; db = colsum(dTok)
+                self._gemm(fd, D, N, ptr(feat), fd, 0, dslot, MD, 0, ptr(self.g[f"proj{i}.weight"]), D, splitk=True)
                 call("snag_colsum", dslot, N, D, MD, ptr(self.g[f"proj{i}.bias"]), 0, wk, st)
             else:
                 self._gemm(D, D, N, dslot, MD, 0, ptr(self.mid[i]), D, 0, ptr(self.g[f"proj{i}.l2"]), D, splitk=True)
                 # d mid = (dTok l2) * [mid > 0]
                 self._gemm(N, D, D, dslot, MD, 1, ptr(self.p[f"proj{i}.l2"]), D, 0, ptr(self.d_mid), D, act=4, aux=ptr(self.mid[i]), ldaux=D)
-                self._gemm(D, fd, N, ptr(self.d_mid), D, 0, ptr(feat), fd, 0, ptr(self.g[f"proj{i}.l1"]), fd, splitk=True)
+                self._gemm(fd, D, N, ptr(feat), fd, 0, ptr(self.d_mid), D, 0, ptr(self.g[f"proj{i}.l1"]), D, splitk=True)   # dl1^T [fd, D]
         call("snag_entity_token_bwd", dx0 + 4 * self.g_slot * D, MD, N, D, ptr(self.ent_noise_mask) if noisy else None,
              float(cfg.mask_ratio) * 0.5, ptr(self.g["ent"]), 0, st)
 
@@ -389,9 +396,16 @@ class MKGCHotPath:
         self.train(was)
         return out
 
-    # parameters as a name -> tensor dict (for tests / checkpoints)
+    # parameters as a name -> tensor dict in the LOGICAL nn.Linear layout [out, in] (for tests / checkpoints);
+    # the transposed-storage projection weights come back as transposed views of the flat buffer
+    def _logical(self, d):
+        out = {}
+        for k, v in d.items():
+            out[k] = v.t() if (k.startswith("proj") and (k.endswith(".l1") or k.endswith(".weight"))) else v
+        return out
+
     def named_parameters(self):
-        return dict(self.p)
+        return self._logical(self.p)
 
     def named_gradients(self):
-        return dict(self.g)
+        return self._logical(self.g)

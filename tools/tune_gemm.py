@@ -6,7 +6,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from snag_amd import ops
     N = 15000
     shapes = {"l1_fwd": ((N, 4096), (128, 4096), True, True), "l1_fwd_xT": ((4096, N), (128, 4096), False, True),
-              "txt_fwd_xT": ((768, N), (128, 768), False, True), "txt_fwd": ((N, 768), (128, 768), True, True), "l1_bwd": ((N, 128), (N, 4096), False, False),
+              "l1_fwd_TT": ((4096, N), (4096, 128), False, False), "qkv_TT": ((128, 45000), (128, 384), False, False), "txt_fwd": ((N, 768), (128, 768), True, True), "l1_bwd": ((N, 128), (N, 4096), False, False),
               "qkv": ((45000, 128), (384, 128), True, True), "dx": ((45000, 384), (384, 128), True, False),
               "dwqkv": ((45000, 384), (45000, 128), False, False)}
     res = {}
