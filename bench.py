@@ -266,13 +266,12 @@ def main():
     rank_seed = cfg.seed * 7919 + int(os.environ.get("RANK", "0"))
     eng = MKGCHotPath(cfg, feats, device=device)
     reducer = GradAllReduce(world) if world > 1 else None
-    if os.environ.get("BENCH_FORCE_ALLREDUCE") and reducer is None:          # exercise the collective on a 1-GPU box
+    if os.environ.get("BENCH_FORCE_ALLREDUCE") and reducer is None:          # exercise the collective path on a 1-GPU box
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-        _g = GradAllReduce(2)
-        reducer = lambda flat: (dist.all_reduce(flat), flat)[1]
+        reducer = GradAllReduce(1, force=True)
     gscale = 1.0                                           # loss is a SUM over triples (MSNEA.py:122): sharded sum needs no division
 
     timers = {}
@@ -289,9 +288,9 @@ def main():
         h, r, t = batches[i % len(batches)]
         ops.sample_negatives(h, r, t, cfg.neg_num, cfg.n_ent, cfg.n_rel, rank_seed, known_sorted=known, tick=eng.tick, out=neg_buf)
         eng.forward(h, r, t, neg_buf)
-        eng.backward(gscale)
+        eng.backward(gscale, reducer=reducer)         # buckets go out as they become final (overlaps the projection backward)
         if reducer is not None:
-            reducer(eng.gflat)
+            reducer.finish()
         eng.optimizer_step()
 
     step_no = 0

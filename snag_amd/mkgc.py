@@ -327,8 +327,17 @@ class MKGCHotPath:
             return self.loss, self._pos, self._neg
         return self.loss
 
-    def backward(self, grad_scale=1.0):
-        """Gradient of grad_scale * loss w.r.t. every parameter, written (not added) into the flat gradient buffer."""
+    def grad_buckets(self):
+        """Two contiguous slices of the flat gradient buffer in the order the backward finishes them: the entity table
+        (most of the bytes; final right after the fusion backward) and everything else (final after the projection backward)."""
+        end = self.slices["rel"][0]
+        return self.gflat[:end], self.gflat[end:]
+
+    def backward(self, grad_scale=1.0, reducer=None):
+        """Gradient of grad_scale * loss w.r.t. every parameter, written (not added) into the flat gradient buffer.
+
+        ``reducer`` (snag_amd.parallel.GradAllReduce) gets ``start(bucket)`` as soon as a bucket is final, so that the
+        all-reduce of the 7.7 MB entity-table gradient overlaps the projection backward GEMMs; ``finish()`` is the caller's."""
         cfg = self.cfg
         N, D, M = cfg.n_ent, cfg.dim, cfg.n_tokens
         st = self._st
@@ -349,6 +358,10 @@ class MKGCHotPath:
         call("snag_fusion_bwd", ctypes.byref(self._bdesc), st)
         dx0 = self.d_x0.data_ptr()
         wk = ptr(self.work)
+        call("snag_entity_token_bwd", dx0 + 4 * self.g_slot * D, MD, N, D, ptr(self.ent_noise_mask) if noisy else None,
+             float(cfg.mask_ratio) * 0.5, ptr(self.g["ent"]), 0, st)
+        if reducer is not None:
+            reducer.start(self.grad_buckets()[0])
         for i, fd in enumerate(cfg.feat_dims):
             feat = self.noisy[i] if noisy else self.feats[i]
             dslot = dx0 + 4 * i * D
@@ -361,8 +374,8 @@ class MKGCHotPath:
                 # d mid = (dTok l2) * [mid > 0]
                 self._gemm(N, D, D, dslot, MD, 1, ptr(self.p[f"proj{i}.l2"]), D, 0, ptr(self.d_mid), D, act=4, aux=ptr(self.mid[i]), ldaux=D)
                 self._gemm(fd, D, N, ptr(feat), fd, 0, ptr(self.d_mid), D, 0, ptr(self.g[f"proj{i}.l1"]), D, splitk=True)   # dl1^T [fd, D]
-        call("snag_entity_token_bwd", dx0 + 4 * self.g_slot * D, MD, N, D, ptr(self.ent_noise_mask) if noisy else None,
-             float(cfg.mask_ratio) * 0.5, ptr(self.g["ent"]), 0, st)
+        if reducer is not None:
+            reducer.start(self.grad_buckets()[1])
 
     def optimizer_step(self, grad_scale=1.0):
         cfg = self.cfg
@@ -373,9 +386,13 @@ class MKGCHotPath:
     def train_step(self, h, r, t, neg_t, allreduce=None):
         """forward + backward (+ gradient exchange) + AdamW.  ``allreduce(gflat)`` sums gradients across ranks."""
         self.forward(h, r, t, neg_t)
-        self.backward()
-        if allreduce is not None:
-            allreduce(self.gflat)
+        if allreduce is not None and hasattr(allreduce, "start"):
+            self.backward(reducer=allreduce)
+            allreduce.finish()
+        else:
+            self.backward()
+            if allreduce is not None:
+                allreduce(self.gflat)
         self.optimizer_step()
         return self.loss
 

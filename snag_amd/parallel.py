@@ -36,10 +36,30 @@ class GradAllReduce:
     consecutive buckets overlap on the links.
     """
 
-    def __init__(self, world: int, bucket_bytes: int = 256 << 20, group=None):
+    def __init__(self, world: int, bucket_bytes: int = 256 << 20, group=None, force: bool = False):
         self.world = world
+        self.force = force          # run the collectives even with one rank (exercises the path on a 1-GPU box)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.group = group
+
+    # --- overlapped form: start() a bucket as soon as its gradients are final, finish() before the optimiser ------------
+    def start(self, bucket: torch.Tensor):
+        """Enqueue the summed all-reduce of one contiguous slice of the flat gradient buffer without blocking the
+        compute stream: the collective runs on the backend's own stream behind everything enqueued so far, while the
+        kernels launched after this call (the rest of the backward) keep the CUs busy."""
+        if self.world <= 1 and not self.force:
+            return
+        if not hasattr(self, "_pending"):
+            self._pending = []
+        n = bucket.numel()
+        for lo in range(0, n, self.bucket_elems):
+            self._pending.append(dist.all_reduce(bucket[lo:lo + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Make the compute stream wait for every started bucket (no host synchronisation on the GPU backends)."""
+        for w in getattr(self, "_pending", []):
+            w.wait()
+        self._pending = []
 
     def __call__(self, flat: torch.Tensor):
         if self.world <= 1:

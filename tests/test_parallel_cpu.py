@@ -50,7 +50,7 @@ def _flat_grad(ent, rel, batch):
     return torch.cat([e.grad.flatten(), r.grad.flatten()]), float(loss)
 
 
-def _worker(rank, world, port, bucket_bytes, out):
+def _worker(rank, world, port, bucket_bytes, overlapped, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -58,7 +58,14 @@ def _worker(rank, world, port, bucket_bytes, out):
         ent, rel, batch = _make()
         local = shard_batch(batch, rank, world)
         flat, loss = _flat_grad(ent, rel, local)
-        GradAllReduce(world, bucket_bytes=bucket_bytes)(flat)
+        red = GradAllReduce(world, bucket_bytes=bucket_bytes)
+        if overlapped:                       # the two-bucket start()/finish() form the training step uses
+            cut = flat.numel() // 3
+            red.start(flat[:cut])
+            red.start(flat[cut:])
+            red.finish()
+        else:
+            red(flat)
         lt = torch.tensor([loss], dtype=torch.float64)
         dist.all_reduce(lt)
         if rank == 0:
@@ -67,10 +74,10 @@ def _worker(rank, world, port, bucket_bytes, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bucket_bytes", [1 << 20, 256])          # one collective / many async buckets
-def test_two_rank_allreduce_matches_single_process(tmp_path, bucket_bytes):
+@pytest.mark.parametrize("bucket_bytes,overlapped", [(1 << 20, False), (256, False), (1 << 20, True), (512, True)])
+def test_two_rank_allreduce_matches_single_process(tmp_path, bucket_bytes, overlapped):
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(2, _free_port(), bucket_bytes, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), bucket_bytes, overlapped, out), nprocs=2, join=True)
     got = torch.load(out)
     ent, rel, batch = _make()
     ref, ref_loss = _flat_grad(ent, rel, batch)
