@@ -370,6 +370,38 @@ def multi_loss(losses: Sequence[Tensor], log_vars: Tensor) -> Tensor:
 
 
 # --------------------------------------------------------------------------
+# (f) next #2: structural encoder (sparse GAT, diag variant)
+# --------------------------------------------------------------------------
+
+
+def gat_forward(x: Tensor, edges: Tensor, layers: Sequence[Dict[str, Tensor]]) -> Tensor:
+    """GAT(diag=True) in eval mode / zero dropout (the SNAG configuration: run_snag.sh sets neither --dropout nor --attn_dropout).
+
+    reference: MultiHeadGraphAttention.forward model/layers.py:68-94 and GAT.forward model/Tool_model.py:75-94.
+    Per layer and head i: h = x * w_i ; e = exp(-leaky_relu_0.2([h_u | h_v] . a_i)) per edge (u, v) ; h'_u = sum_e e h_v / sum_e e ;
+    heads are averaged; ELU between layers.  ``edges`` is the [2, E] index list of the COO adjacency as stored (duplicates and
+    self loops included, values unused); ``layers[l]`` holds ``w`` [H,1,f] and ``a_src_dst`` [H,2f,1].
+    """
+    src, dst = edges[0].long(), edges[1].long()
+    N = x.shape[0]
+    for li, p in enumerate(layers):
+        w, a = p["w"], p["a_src_dst"]
+        H, f = w.shape[0], w.shape[2]
+        outs = []
+        for i in range(H):
+            h = x * w[i]                                                     # :74
+            z = torch.cat([h[src], h[dst]], dim=1) @ a[i]                    # :78-79
+            e = torch.exp(-F.leaky_relu(z.squeeze(1), 0.2))                  # :79
+            rowsum = torch.zeros(N, dtype=x.dtype).index_add(0, src, e)      # :81 (spmm with ones)
+            hp = torch.zeros(N, f, dtype=x.dtype).index_add(0, src, e.unsqueeze(1) * h[dst])      # :85
+            outs.append(hp / rowsum.unsqueeze(1))                            # :86
+        x = torch.stack(outs, 0).mean(dim=0)                                 # Tool_model.py:84-85
+        if li + 1 < len(layers):
+            x = F.elu(x)                                                     # :87-88
+    return x
+
+
+# --------------------------------------------------------------------------
 # whole MKGC step (fusion + score), used by the CPU baseline and end-to-end tests
 # --------------------------------------------------------------------------
 

@@ -78,6 +78,8 @@ SIGNATURES = {
     "snag_entity_token_bwd": [_P, _L, _L, _I, _P, _F, _P, _I, _P],
     "snag_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _P, _F, _P],
     "snag_tick": [_P, _P],
+    "snag_gat_layer_fwd": [_P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "snag_gat_layer_bwd": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P],
     "snag_sample_negatives": [_U64, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P, _P, _P],
     "snag_gather_normalize_fwd": [_P, _L, _L, _I, _P, _I, _L, _I, _P, _P, _P],
     "snag_gather_normalize_bwd": [_P, _P, _P, _I, _P, _I, _L, _I, _P, _L, _P],
@@ -95,7 +97,8 @@ SIGNATURES = {
 _SPECIAL = {"snag_version": ([], _I), "snag_last_error": ([], _c.c_char_p),
             "snag_gemm_workspace_floats": ([_I, _I, _I], _L),
             "snag_fusion_save_floats": ([_I] * 7, _L), "snag_fusion_work_floats": ([_I] * 7, _L),
-            "snag_colstats_work_floats": ([_I], _L), "snag_eval_work_floats": ([_I, _I], _L)}
+            "snag_colstats_work_floats": ([_I], _L), "snag_eval_work_floats": ([_I, _I], _L),
+            "snag_gat_work_floats": ([_L, _I, _I], _L)}
 
 _lib = None
 

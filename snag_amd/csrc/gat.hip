@@ -1,0 +1,309 @@
+// SURVEY.md par. 8(f) "next" #2: the sparse GAT structural encoder, diag variant, as SNAG instantiates it
+// (MultiHeadGraphAttention model/layers.py:35-100; GAT model/Tool_model.py:61-94; eval / zero-dropout configuration).
+//
+// One layer, H heads (averaged), input x [N, f]:
+//   h_i = x * w_i                       (w_i [f], the diag weight)
+//   e_i(u,v) = exp(-leaky_relu_0.2(a_src_i . h_i[u] + a_dst_i . h_i[v]))          per stored edge (u, v)
+//   A_i[u,:] = sum_{(u,v)} e_i(u,v) x[v,:] ,  r_i[u] = sum_{(u,v)} e_i(u,v)
+//   pre[u,:] = (1/H) sum_i w_i * A_i[u,:] / r_i[u] ;  out = elu(pre) between layers, pre after the last.
+//
+// Edges arrive as CSR over the source node (duplicates and self loops preserved, values unused).  One wave per source
+// node; a feature row is spread over the wave as col = lane + 64*u (256-byte segments).  The backward scatters into
+// neighbour rows with fp32 atomics and reduces parameter gradients through fixed-order per-block partial sums.
+#include <algorithm>
+
+#include "fusion_kernels.hip.h"
+
+namespace snag {
+
+constexpr int kGatMaxH = 4;
+
+// s_src[n,i] = sum_c x[n,c] w_i[c] a_i[c] ; s_dst[n,i] = sum_c x[n,c] w_i[c] a_i[f + c]
+template <int NU>
+__global__ __launch_bounds__(256) void gat_node_scores_kernel(const float* __restrict__ x, int64_t N, int f, int H, const float* __restrict__ w,
+                                                              const float* __restrict__ a, float* __restrict__ s_src, float* __restrict__ s_dst) {
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (n >= N) return;
+    const int lane = threadIdx.x & 63;
+    const Cols<NU> xr = ld_cols<NU>(x + n * f, f, lane);
+    for (int i = 0; i < H; ++i) {
+        const Cols<NU> wi = ld_cols<NU>(w + i * f, f, lane);
+        const Cols<NU> as = ld_cols<NU>(a + i * 2 * f, f, lane), ad = ld_cols<NU>(a + i * 2 * f + f, f, lane);
+        float ps = 0.f, pd = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const float h = xr.v[u] * wi.v[u];
+            ps = fmaf(h, as.v[u], ps);
+            pd = fmaf(h, ad.v[u], pd);
+        }
+        ps = sum64(ps);
+        pd = sum64(pd);
+        if (lane == 0) {
+            s_src[n * H + i] = ps;
+            s_dst[n * H + i] = pd;
+        }
+    }
+}
+
+__device__ __forceinline__ float gat_edge_weight(float z) { return expf(-(z > 0.f ? z : 0.2f * z)); }
+
+// forward aggregation; agg [N,H,f] and rsum [N,H] are kept for the backward
+template <int NU>
+__global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(const float* __restrict__ x, int64_t N, int f, int H, const float* __restrict__ w,
+                                                                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                const float* __restrict__ s_src, const float* __restrict__ s_dst, int apply_elu,
+                                                                float* __restrict__ agg, float* __restrict__ rsum, float* __restrict__ pre,
+                                                                float* __restrict__ out) {
+    const int64_t u = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (u >= N) return;
+    const int lane = threadIdx.x & 63;
+    Cols<NU> acc[kGatMaxH];
+    float rs[kGatMaxH], ss[kGatMaxH];
+#pragma unroll
+    for (int i = 0; i < kGatMaxH; ++i) {
+        rs[i] = 0.f;
+        ss[i] = i < H ? s_src[u * H + i] : 0.f;
+#pragma unroll
+        for (int q = 0; q < NU; ++q) acc[i].v[q] = 0.f;
+    }
+    const int e0 = rowptr[u], e1 = rowptr[u + 1];
+    for (int e = e0; e < e1; ++e) {
+        const int64_t v = col[e];
+        const Cols<NU> xv = ld_cols<NU>(x + v * f, f, lane);
+#pragma unroll
+        for (int i = 0; i < kGatMaxH; ++i) {
+            if (i < H) {
+                const float al = gat_edge_weight(ss[i] + s_dst[v * H + i]);
+                rs[i] += al;
+#pragma unroll
+                for (int q = 0; q < NU; ++q) acc[i].v[q] = fmaf(al, xv.v[q], acc[i].v[q]);
+            }
+        }
+    }
+    Cols<NU> o;
+#pragma unroll
+    for (int q = 0; q < NU; ++q) o.v[q] = 0.f;
+#pragma unroll
+    for (int i = 0; i < kGatMaxH; ++i) {
+        if (i < H) {
+            st_cols<NU>(agg + (u * H + i) * f, acc[i], f, lane);
+            if (lane == 0) rsum[u * H + i] = rs[i];
+            const Cols<NU> wi = ld_cols<NU>(w + i * f, f, lane);
+            const float inv = 1.0f / rs[i];
+#pragma unroll
+            for (int q = 0; q < NU; ++q) o.v[q] += wi.v[q] * acc[i].v[q] * inv;       // h'_i = (w_i * A_i) / r_i   (:85-86)
+        }
+    }
+    const float invH = 1.0f / (float)H;
+    Cols<NU> y;
+#pragma unroll
+    for (int q = 0; q < NU; ++q) {
+        o.v[q] *= invH;                                                                // mean over heads (Tool_model.py:84-85)
+        y.v[q] = (apply_elu && o.v[q] <= 0.f) ? expm1f(o.v[q]) : o.v[q];               // F.elu (:87-88)
+    }
+    if (pre != nullptr) st_cols<NU>(pre + u * f, o, f, lane);
+    st_cols<NU>(out + u * f, y, f, lane);
+}
+
+// Edge pass of the backward, one wave per source node u.
+// part[block][H][f] receives the block's partial of sum_u g[u,:] * A_i[u,:] / r_i[u]  (the aggregation route into d w_i).
+template <int NU>
+__global__ __launch_bounds__(256) void gat_aggregate_bwd_kernel(const float* __restrict__ x, int64_t N, int f, int H, const float* __restrict__ w,
+                                                                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                const float* __restrict__ s_src, const float* __restrict__ s_dst,
+                                                                const float* __restrict__ agg, const float* __restrict__ rsum,
+                                                                const float* __restrict__ pre, int had_elu, const float* __restrict__ d_out,
+                                                                float* __restrict__ d_x, float* __restrict__ ds_src, float* __restrict__ ds_dst,
+                                                                float* __restrict__ part) {
+    __shared__ float red[4][64 * NU];
+    const int lane = threadIdx.x & 63, wave = wave_id_uniform();
+    Cols<NU> pw[kGatMaxH];
+#pragma unroll
+    for (int i = 0; i < kGatMaxH; ++i)
+#pragma unroll
+        for (int q = 0; q < NU; ++q) pw[i].v[q] = 0.f;
+    for (int64_t u = (int64_t)blockIdx.x * 4 + wave; u < N; u += (int64_t)gridDim.x * 4) {
+        Cols<NU> g = ld_cols<NU>(d_out + u * f, f, lane);
+        if (had_elu) {
+            const Cols<NU> p = ld_cols<NU>(pre + u * f, f, lane);
+#pragma unroll
+            for (int q = 0; q < NU; ++q) g.v[q] *= (p.v[q] > 0.f) ? 1.0f : expf(p.v[q]);      // elu'
+        }
+        const float invH = 1.0f / (float)H;
+        const int e0 = rowptr[u], e1 = rowptr[u + 1];
+#pragma unroll
+        for (int i = 0; i < kGatMaxH; ++i) {
+            if (i < H) {
+                const Cols<NU> wi = ld_cols<NU>(w + i * f, f, lane);
+                const Cols<NU> A = ld_cols<NU>(agg + (u * H + i) * f, f, lane);
+                const float r = rsum[u * H + i], inv = 1.0f / r;
+                Cols<NU> dA;                          // d loss / d A_i[u,:] = g w_i / (H r)
+                float drs = 0.f;                      // d loss / d r_i[u]   = -sum_c g w_i A_i / (H r^2)
+#pragma unroll
+                for (int q = 0; q < NU; ++q) {
+                    const float gw = g.v[q] * invH * wi.v[q] * inv;
+                    dA.v[q] = gw;
+                    drs = fmaf(-gw * inv, A.v[q], drs);
+                    pw[i].v[q] = fmaf(g.v[q] * invH * inv, A.v[q], pw[i].v[q]);
+                }
+                drs = sum64(drs);
+                const float ssu = s_src[u * H + i];
+                float dsu = 0.f;
+                for (int e = e0; e < e1; ++e) {
+                    const int64_t v = col[e];
+                    const Cols<NU> xv = ld_cols<NU>(x + v * f, f, lane);
+                    const float z = ssu + s_dst[v * H + i];
+                    const float al = gat_edge_weight(z);
+                    float dal = 0.f;
+#pragma unroll
+                    for (int q = 0; q < NU; ++q) dal = fmaf(dA.v[q], xv.v[q], dal);
+                    dal = sum64(dal) + drs;                                   // through A_i and through r_i
+                    const float dz = -al * (z > 0.f ? 1.0f : 0.2f) * dal;
+                    dsu += dz;
+                    if (lane == 0) atomicAdd(ds_dst + v * H + i, dz);
+#pragma unroll
+                    for (int q = 0; q < NU; ++q) {
+                        const int c = lane + 64 * q;
+                        if (c < f) atomicAdd(d_x + v * f + c, al * dA.v[q]);
+                    }
+                }
+                if (lane == 0) ds_src[u * H + i] = dsu;
+            }
+        }
+    }
+    for (int i = 0; i < H; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NU; ++q) {
+            float val = 0.f;
+#pragma unroll
+            for (int j = 0; j < kGatMaxH; ++j) val = (j == i) ? pw[j].v[q] : val;
+            red[wave][lane + 64 * q] = val;
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < f; c += 256) part[((int64_t)blockIdx.x * H + i) * f + c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+    }
+}
+
+// Node pass of the backward: s_src/s_dst -> x, w, a.  part2[block][H][3][f]: partials of d w_i (score route), d a_src_i, d a_dst_i.
+template <int NU>
+__global__ __launch_bounds__(256) void gat_node_scores_bwd_kernel(const float* __restrict__ x, int64_t N, int f, int H, const float* __restrict__ w,
+                                                                  const float* __restrict__ a, const float* __restrict__ ds_src,
+                                                                  const float* __restrict__ ds_dst, float* __restrict__ d_x,
+                                                                  float* __restrict__ part2) {
+    __shared__ float red[4][3][64 * NU];
+    const int lane = threadIdx.x & 63, wave = wave_id_uniform();
+    for (int i = 0; i < H; ++i) {
+        const Cols<NU> wi = ld_cols<NU>(w + i * f, f, lane);
+        const Cols<NU> as = ld_cols<NU>(a + i * 2 * f, f, lane), ad = ld_cols<NU>(a + i * 2 * f + f, f, lane);
+        Cols<NU> pw, pas, pad;
+#pragma unroll
+        for (int q = 0; q < NU; ++q) pw.v[q] = pas.v[q] = pad.v[q] = 0.f;
+        for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
+            const Cols<NU> xr = ld_cols<NU>(x + n * f, f, lane);
+            const float gs = ds_src[n * H + i], gd = ds_dst[n * H + i];
+#pragma unroll
+            for (int q = 0; q < NU; ++q) {
+                const int c = lane + 64 * q;
+                const float t = gs * as.v[q] + gd * ad.v[q];
+                if (c < f) d_x[n * f + c] += t * wi.v[q];                 // this wave owns row n in this kernel: plain read-modify-write
+                pw.v[q] = fmaf(t, xr.v[q], pw.v[q]);
+                pas.v[q] = fmaf(gs * xr.v[q], wi.v[q], pas.v[q]);
+                pad.v[q] = fmaf(gd * xr.v[q], wi.v[q], pad.v[q]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NU; ++q) {
+            red[wave][0][lane + 64 * q] = pw.v[q];
+            red[wave][1][lane + 64 * q] = pas.v[q];
+            red[wave][2][lane + 64 * q] = pad.v[q];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 3 * f; idx += 256) {
+            const int k = idx / f, c = idx % f;
+            part2[(((int64_t)blockIdx.x * H + i) * 3 + k) * f + c] = ((red[0][k][c] + red[1][k][c]) + red[2][k][c]) + red[3][k][c];
+        }
+    }
+}
+
+// d w[i,c] = sum_blocks part[b][i][c] + part2[b][i][0][c] ; d a[i, c] = sum part2[b][i][1][c] ; d a[i, f + c] = sum part2[b][i][2][c]
+__global__ __launch_bounds__(256) void gat_param_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part2, int nb1, int nb2, int H,
+                                                               int f, float* __restrict__ d_w, float* __restrict__ d_a, int accumulate) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= H * f) return;
+    const int i = idx / f, c = idx % f;
+    float sw = 0.f, sa = 0.f, sd = 0.f;
+    for (int b = 0; b < nb1; ++b) sw += part[((int64_t)b * H + i) * f + c];
+    for (int b = 0; b < nb2; ++b) {
+        const float* q = part2 + (((int64_t)b * H + i) * 3) * f + c;
+        sw += q[0];
+        sa += q[f];
+        sd += q[2 * f];
+    }
+    d_w[idx] = accumulate ? d_w[idx] + sw : sw;
+    float* pa = d_a + (int64_t)i * 2 * f + c;
+    pa[0] = accumulate ? pa[0] + sa : sa;
+    pa[f] = accumulate ? pa[f] + sd : sd;
+}
+
+static constexpr int kGatBlocks = 256;
+
+}  // namespace snag
+
+using namespace snag;
+
+#define SNAG_GAT_NU(KERNEL, f, grid, st, ...)                                                        \
+    do {                                                                                             \
+        if ((f) <= 128) hipLaunchKernelGGL((KERNEL<2>), grid, dim3(256), 0, st, __VA_ARGS__);        \
+        else if ((f) <= 320) hipLaunchKernelGGL((KERNEL<5>), grid, dim3(256), 0, st, __VA_ARGS__);   \
+        else hipLaunchKernelGGL((KERNEL<8>), grid, dim3(256), 0, st, __VA_ARGS__);                   \
+    } while (0)
+
+static int gat_check(int64_t N, int f, int H, const void* x, const void* w, const void* a, const void* rowptr, const void* col) {
+    SNAG_REQUIRE(N >= 0 && f >= 1 && H >= 1, SNAG_ERR_ARG, "gat: bad sizes N=%ld f=%d H=%d", (long)N, f, H);
+    SNAG_REQUIRE(H <= kGatMaxH, SNAG_ERR_UNSUPPORTED, "gat: %d heads > %d", H, kGatMaxH);
+    SNAG_REQUIRE(f <= 512, SNAG_ERR_UNSUPPORTED, "gat: feature width %d > 512", f);
+    SNAG_REQUIRE(N < (1LL << 31), SNAG_ERR_UNSUPPORTED, "gat: N >= 2^31");
+    if (N == 0) return SNAG_OK;
+    SNAG_REQUIRE(x && w && a && rowptr && col, SNAG_ERR_ARG, "gat: null pointer");
+    return SNAG_OK;
+}
+
+extern "C" SNAG_API int64_t snag_gat_work_floats(int64_t N, int f, int H) { return (int64_t)kGatBlocks * H * f * 4 + 2 * N * H + 64; }
+
+extern "C" SNAG_API int snag_gat_layer_fwd(const float* x, int64_t N, int f, int H, const float* w, const float* a_src_dst, const int32_t* rowptr,
+                                           const int32_t* col, int apply_elu, float* s_src, float* s_dst, float* agg, float* rsum, float* pre,
+                                           float* out, void* stream) {
+    int rc = gat_check(N, f, H, x, w, a_src_dst, rowptr, col);
+    if (rc || N == 0) return rc;
+    SNAG_REQUIRE(s_src && s_dst && agg && rsum && out, SNAG_ERR_ARG, "gat_layer_fwd: null output");
+    SNAG_REQUIRE(!apply_elu || pre, SNAG_ERR_ARG, "gat_layer_fwd: the ELU layer needs the pre-activation buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)ceil_div(N, 4));
+    SNAG_GAT_NU(gat_node_scores_kernel, f, grid, st, x, N, f, H, w, a_src_dst, s_src, s_dst);
+    SNAG_GAT_NU(gat_aggregate_fwd_kernel, f, grid, st, x, N, f, H, w, rowptr, col, (const float*)s_src, (const float*)s_dst, apply_elu, agg, rsum, pre, out);
+    return check_launch("snag_gat_layer_fwd");
+}
+
+extern "C" SNAG_API int snag_gat_layer_bwd(const float* x, int64_t N, int f, int H, const float* w, const float* a_src_dst, const int32_t* rowptr,
+                                           const int32_t* col, const float* s_src, const float* s_dst, const float* agg, const float* rsum,
+                                           const float* pre, int had_elu, const float* d_out, float* d_x, float* d_w, float* d_a, int accumulate,
+                                           float* work, void* stream) {
+    int rc = gat_check(N, f, H, x, w, a_src_dst, rowptr, col);
+    if (rc || N == 0) return rc;
+    SNAG_REQUIRE(s_src && s_dst && agg && rsum && d_out && d_x && d_w && d_a && work, SNAG_ERR_ARG, "gat_layer_bwd: null pointer");
+    SNAG_REQUIRE(!had_elu || pre, SNAG_ERR_ARG, "gat_layer_bwd: the ELU layer needs the saved pre-activation");
+    hipStream_t st = (hipStream_t)stream;
+    float* ds_src = work;
+    float* ds_dst = ds_src + N * H;
+    float* part = ds_dst + N * H;
+    float* part2 = part + (int64_t)kGatBlocks * H * f;
+    if (hipMemsetAsync(d_x, 0, sizeof(float) * N * f, st) != hipSuccess || hipMemsetAsync(ds_dst, 0, sizeof(float) * N * H, st) != hipSuccess)
+        return fail(SNAG_ERR_LAUNCH, "gat_layer_bwd: memset failed");
+    const int nb = (int)std::min<int64_t>(kGatBlocks, (N + 3) / 4);
+    SNAG_GAT_NU(gat_aggregate_bwd_kernel, f, dim3(nb), st, x, N, f, H, w, rowptr, col, s_src, s_dst, agg, rsum, pre, had_elu, d_out, d_x, ds_src, ds_dst, part);
+    SNAG_GAT_NU(gat_node_scores_bwd_kernel, f, dim3(nb), st, x, N, f, H, w, a_src_dst, (const float*)ds_src, (const float*)ds_dst, d_x, part2);
+    hipLaunchKernelGGL(gat_param_reduce_kernel, dim3(ceil_div(H * f, 256)), dim3(256), 0, st, (const float*)part, (const float*)part2, nb, nb, H, f, d_w, d_a, accumulate);
+    return check_launch("snag_gat_layer_bwd");
+}

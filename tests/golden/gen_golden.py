@@ -16,6 +16,7 @@ Vectors (SURVEY.md par. 8c):
   g5_il.npz          SNAG.Iter_new_links mutual nearest neighbours
   g6_proj.npz        nn.Linear projections + ProjectionHead fwd/grads
   g7_encoder.npz     MultiModalEncoder.forward (projections + entity noise blend + fusion), GAT stubbed to identity
+  g9_gat.npz         GAT(diag=True) structural encoder (model/layers.py:35-100, model/Tool_model.py:61-94), output and grads
   g8_icl_loss.npz    icl_loss (bidirectional InfoNCE, model/SNAG_loss.py:31-128) + CustomMultiLossLayer, loss and grads
 """
 import csv
@@ -436,6 +437,33 @@ def gen_g8():
     save("g8_icl_loss.npz", out)
 
 
+def gen_g9():
+    """Sparse GAT (diag) as SNAG builds it: GAT(n_units, n_heads, dropout=0, attn_dropout=0, instance_normalization=False, diag=True)."""
+    from model.Tool_model import GAT
+    from src.utils import get_adjr
+    g = torch.Generator().manual_seed(99)
+    N, f = 180, 64
+    triples = [(int(a), 0, int(b)) for a, b in zip(torch.randint(0, N, (700,), generator=g), torch.randint(0, N, (700,), generator=g))]
+    adj = get_adjr(N, triples, norm=True)
+    gat = GAT(n_units=[f, f, f], n_heads=[2, 2], dropout=0.0, attn_dropout=0.0, instance_normalization=False, diag=True)
+    randomize_(gat, g)
+    with torch.no_grad():
+        for l in gat.layer_stack:
+            l.w.copy_(1.0 + 0.3 * torch.randn(l.w.shape, generator=g))
+            l.a_src_dst.copy_(torch.randn(l.a_src_dst.shape, generator=g) * 0.4)
+    gat.eval()
+    x = (torch.randn(N, f, generator=g) * 0.8).requires_grad_(True)
+    cw = torch.randn(N, f, generator=g)
+    y = gat(x, adj)
+    (y * cw).sum().backward()
+    d = {"x": x, "edges": adj._indices(), "cw": cw, "y": y, "g.x": x.grad, "n_heads": np.array([2, 2])}
+    for k, v in gat.state_dict().items():
+        d["p." + k] = v
+    for k, p in gat.named_parameters():
+        d["g.p." + k] = p.grad
+    save("g9_gat.npz", d)
+
+
 if __name__ == "__main__":
     gen_g1()
     gen_g2()
@@ -444,3 +472,4 @@ if __name__ == "__main__":
     gen_g6()
     gen_g7()
     gen_g8()
+    gen_g9()

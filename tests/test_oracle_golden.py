@@ -174,3 +174,17 @@ def test_multi_loss_layer():
     tot.backward()
     assert_close(lv.grad, z["ml.g.log_vars"], atol=1e-6)
     assert_close(torch.stack([l.grad for l in ls]), z["ml.g.losses"], atol=1e-6)
+
+
+def test_gat():
+    z = load("g9_gat.npz")
+    x = T(z["x"]).requires_grad_(True)
+    layers = [{"w": T(z[f"p.layer_stack.{l}.w"]).requires_grad_(True), "a_src_dst": T(z[f"p.layer_stack.{l}.a_src_dst"]).requires_grad_(True)}
+              for l in range(2)]
+    y = O.gat_forward(x, T(z["edges"]), layers)
+    assert_close(y, z["y"], atol=2e-6, rtol=1e-5)
+    (y * T(z["cw"])).sum().backward()
+    assert_close(x.grad, z["g.x"], atol=2e-6, rtol=1e-4)
+    for l in range(2):
+        assert_close(layers[l]["w"].grad, z[f"g.p.layer_stack.{l}.w"], atol=2e-5, rtol=1e-4)
+        assert_close(layers[l]["a_src_dst"].grad, z[f"g.p.layer_stack.{l}.a_src_dst"], atol=2e-5, rtol=1e-4)
