@@ -17,6 +17,7 @@ Vectors (SURVEY.md par. 8c):
   g6_proj.npz        nn.Linear projections + ProjectionHead fwd/grads
   g7_encoder.npz     MultiModalEncoder.forward (projections + entity noise blend + fusion), GAT stubbed to identity
   g9_gat.npz         GAT(diag=True) structural encoder (model/layers.py:35-100, model/Tool_model.py:61-94), output and grads
+  g10_snag_model.npz the whole in-tree SNAG model: SNAG.forward/update_noise/joint_emb_generat (model/SNAG.py) loss + grads
   g8_icl_loss.npz    icl_loss (bidirectional InfoNCE, model/SNAG_loss.py:31-128) + CustomMultiLossLayer, loss and grads
 """
 import csv
@@ -464,6 +465,72 @@ def gen_g9():
     save("g9_gat.npz", d)
 
 
+def snag_args(D=64, add_noise=1):
+    """The flags SNAG / MultiModalEncoder / MformerFusion read (config.py:16-141), run_snag.sh values scaled down to D."""
+    return types.SimpleNamespace(
+        attr_dim=D, img_dim=D, name_dim=D, char_dim=D, dropout=0.0, attn_dropout=0.0, hidden_units=f"{D},{D},{D}", heads="2,2",
+        structure_encoder="gat", instance_normalization=False, inner_view_num=4, with_weight=1,
+        w_gcn=True, w_img=True, w_rel=True, w_attr=True, w_name=False, w_char=False, use_project_head=False,
+        hidden_size=D, num_attention_heads=1, num_hidden_layers=1, use_intermediate=1, intermediate_size=96,
+        add_noise=add_noise, noise_ratio=0.2, mask_ratio=0.7, tau=0.1, tau2=4.0, ab_weight=0.5, neg_cross_kg=0, zoom=0.1,
+        reduction="mean", batch_size=60, awloss=0, semi_learn_step=5, modal_num=3)
+
+
+def gen_g10():
+    """The whole in-tree model: SNAG.forward (model/SNAG.py:101-122) on a synthetic KG, eval-mode fusion dropout avoided by
+    recording the Bert dropout masks; loss, the three loss groups, joint embeddings and gradients."""
+    from src.utils import get_adjr
+    g = torch.Generator().manual_seed(1010)
+    N, D, F_img, F_att, B = 240, 64, 80, 56, 60
+    args = snag_args(D)
+    triples = [(int(a), 0, int(b)) for a, b in zip(torch.randint(0, N, (900,), generator=g), torch.randint(0, N, (900,), generator=g))]
+    perm = torch.randperm(N, generator=g)
+    train_ill = torch.stack([perm[:B], perm[B:2 * B]], 1).numpy().astype(np.int32)
+    ent_wo_img = sorted(set(torch.randint(0, N, (20,), generator=g).tolist()))
+    kgs = {"ent_num": N, "images_list": torch.rand(N, F_img, generator=g).numpy(),
+           "rel_features": (torch.rand(N, 1000, generator=g) < 0.02).float().numpy(),
+           "att_features": (torch.rand(N, F_att, generator=g) < 0.2).float().numpy(),
+           "name_features": None, "char_features": None, "input_idx": torch.arange(N),
+           "ent_wo_img": ent_wo_img, "ent_w_img": [i for i in range(N) if i not in ent_wo_img],
+           "adj": get_adjr(N, triples, norm=True), "train_ill": train_ill}
+    torch.manual_seed(7)
+    model = SNAG(kgs, args)
+    randomize_(model.multimodal_encoder.fusion, g)
+    with torch.no_grad():
+        model.multi_loss_layer.log_vars.copy_(torch.randn(6, generator=g) * 0.2)
+        for l in model.multimodal_encoder.cross_graph_model.layer_stack:
+            l.w.copy_(1.0 + 0.2 * torch.randn(l.w.shape, generator=g))
+    d = {"N": N, "D": D, "train_ill": train_ill, "edges": kgs["adj"]._indices(), "images_list": kgs["images_list"],
+         "rel_features": kgs["rel_features"], "att_features": kgs["att_features"], "ent_wo_img": np.array(ent_wo_img)}
+    for k, v in model.state_dict().items():
+        d["p." + k] = v
+    # eval-mode (clean tables, no dropout): joint embedding used by Runner._test
+    model.eval()
+    with torch.no_grad():
+        final, wn = model.joint_emb_generat()
+    d["eval.joint_emb_fz"], d["eval.weight_norm"] = final, wn
+    # train mode: noise from a seeded global RNG + recorded Bert dropout masks
+    model.train()
+    torch.manual_seed(4321)
+    model.update_noise()
+    d["noise_seed"] = 4321
+    d["img_noisy"], d["rel_noisy"], d["att_noisy"] = model.img_noisy_features, model.rel_noisy_features, model.att_noisy_features
+    d["entity_noise"], d["entity_noise_mask"] = model.entity_noise, model.entity_noise_mask
+    with DropoutRecorder(torch.Generator().manual_seed(5)) as rec:
+        loss, out = model(train_ill)
+    loss.backward()
+    assert len(rec.masks) == 3, len(rec.masks)
+    d["mask.probs"], d["mask.attn_out"], d["mask.ffn_out"] = rec.masks
+    d["train.loss"] = loss
+    for k, v in out["loss_dic"].items():
+        d["train.loss." + k] = v
+    d["train.joint_emb"] = out["emb"]
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            d["g.p." + k] = p.grad
+    save("g10_snag_model.npz", d)
+
+
 if __name__ == "__main__":
     gen_g1()
     gen_g2()
@@ -473,3 +540,4 @@ if __name__ == "__main__":
     gen_g7()
     gen_g8()
     gen_g9()
+    gen_g10()

@@ -1,0 +1,100 @@
+"""GPU parity: the whole in-tree SNAG model (encoder + GAT + fusion + contrastive losses) vs golden G10 (reference SNAG.forward)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import T, assert_close, load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def snag_args(D=64, add_noise=1):
+    return types.SimpleNamespace(
+        attr_dim=D, img_dim=D, name_dim=D, char_dim=D, dropout=0.0, attn_dropout=0.0, hidden_units=f"{D},{D},{D}", heads="2,2",
+        structure_encoder="gat", instance_normalization=False, inner_view_num=4, with_weight=1,
+        w_gcn=True, w_img=True, w_rel=True, w_attr=True, w_name=False, w_char=False, use_project_head=False,
+        hidden_size=D, num_attention_heads=1, num_hidden_layers=1, use_intermediate=1, intermediate_size=96,
+        add_noise=add_noise, noise_ratio=0.2, mask_ratio=0.7, tau=0.1, tau2=4.0, ab_weight=0.5, neg_cross_kg=0, zoom=0.1,
+        reduction="mean", batch_size=60, awloss=0, semi_learn_step=5, modal_num=3)
+
+
+def build(z):
+    from snag_amd.mmea import SNAG
+    N = int(z["N"])
+    adj = torch.sparse_coo_tensor(T(z["edges"]), torch.ones(z["edges"].shape[1]), (N, N))
+    wo = z["ent_wo_img"].tolist()
+    kgs = {"ent_num": N, "images_list": z["images_list"], "rel_features": z["rel_features"], "att_features": z["att_features"],
+           "name_features": None, "char_features": None, "input_idx": torch.arange(N), "ent_wo_img": wo,
+           "ent_w_img": [i for i in range(N) if i not in set(wo)], "adj": adj, "train_ill": z["train_ill"]}
+    model = SNAG(kgs, snag_args(int(z["D"])), device=DEV)
+    sd = {k[2:]: T(v) for k, v in z.items() if k.startswith("p.")}
+    assert set(model.state_dict()) == set(sd), sorted(set(model.state_dict()) ^ set(sd))        # checkpoint compatibility
+    model.load_state_dict(sd, strict=True)
+    return model
+
+
+def test_snag_model_golden():
+    z = load("g10_snag_model.npz")
+    model = build(z)
+    # eval: the embedding Runner._test consumes (main.py:376)
+    model.eval()
+    with torch.no_grad():
+        final, wn = model.joint_emb_generat()
+    assert_close(final, z["eval.joint_emb_fz"], atol=2e-5, rtol=1e-5)
+    assert_close(wn, z["eval.weight_norm"], atol=2e-5)
+    # train: update_noise() replays the reference's RNG stream, then one forward/backward with the recorded Bert dropout masks
+    model.train()
+    torch.manual_seed(int(z["noise_seed"]))
+    model.update_noise()
+    for nm in ("img", "rel", "att"):
+        assert_close(getattr(model, f"{nm}_noisy_features"), z[f"{nm}_noisy"], atol=2e-6, what=f"{nm}_noisy")
+    assert_close(model.entity_noise, z["entity_noise"], atol=1e-6)
+    assert np.array_equal(model.entity_noise_mask.cpu().numpy().astype(bool), z["entity_noise_mask"])
+    masks = [{"probs": T(z["mask.probs"], DEV), "attn_out": T(z["mask.attn_out"], DEV), "ffn_out": T(z["mask.ffn_out"], DEV)}]
+    loss, out = model(z["train_ill"], drop_masks=masks)
+    assert_close(loss, z["train.loss"], atol=2e-3, rtol=2e-5)
+    for k in ("joint_Intra_modal", "Intra_modal", "IIR_loss"):
+        assert abs(out["loss_dic"][k] - float(z["train.loss." + k])) < 1e-3 * max(1.0, abs(float(z["train.loss." + k]))), k
+    assert_close(out["emb"], z["train.joint_emb"], atol=2e-5)
+    loss.backward()
+    checked = 0
+    for k, p in model.named_parameters():
+        key = "g.p." + k
+        if key in z:
+            ref = z[key]
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            assert_close(g, ref, atol=3e-4 * max(1.0, float(np.abs(ref).max())), rtol=2e-3, what=key)
+            checked += 1
+    assert checked >= 25, checked
+
+
+def test_snag_model_trains_and_evaluates():
+    """A few optimiser steps on the golden KG lower the loss; the eval path returns sane Hits@k; IL returns mutual pairs."""
+    from snag_amd import evalsim
+    z = load("g10_snag_model.npz")
+    model = build(z)
+    model.noise_mode = "philox"
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3)
+    model.train()
+    model.update_noise(seed=1)
+    first = None
+    for it in range(12):
+        loss, _ = model(z["train_ill"])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        first = float(loss) if first is None else first
+    assert float(loss) < first
+    model.eval()
+    with torch.no_grad():
+        final, _ = model.joint_emb_generat()
+        from snag_amd.mmea import normalize_rows
+        final = normalize_rows(final)
+        left, right = T(z["train_ill"][:, 0].astype(np.int64), DEV), T(z["train_ill"][:, 1].astype(np.int64), DEV)
+        res = evalsim.rank_metrics(final[left].contiguous(), final[right].contiguous(), csls_k=3)
+    assert res["hits_l2r"][1] > 0.5                     # training pairs rank well after training on them
+    links = model.Iter_new_links(4, left.cpu().tolist(), final, right.cpu().tolist(), new_links=[])
+    assert len(links) > 0 and all(len(p) == 2 for p in links)
