@@ -42,19 +42,22 @@ def oracle_params(eng):
     return p, proj, fp
 
 
-@pytest.mark.parametrize("num_proj,joint_way,ffn,noise,idt", [
-    (2, "Mformer_hd_graph", 0, False, torch.int32),
-    (1, "Mformer_hd_mean", 0, False, torch.int64),
-    (2, "Mformer_hd_graph", 1, True, torch.int32),
-    (1, "Mformer_hd_mean", 0, True, torch.int32),
+@pytest.mark.parametrize("num_proj,joint_way,ffn,noise,idt,shape", [
+    (2, "Mformer_hd_graph", 0, False, torch.int32, (700, 23, 128, 96, 32, 200, 72)),
+    (1, "Mformer_hd_mean", 0, False, torch.int64, (700, 23, 128, 96, 32, 200, 72)),
+    (2, "Mformer_hd_graph", 1, True, torch.int32, (700, 23, 128, 96, 32, 200, 72)),
+    (1, "Mformer_hd_mean", 0, True, torch.int32, (700, 23, 128, 96, 32, 200, 72)),
+    # ragged everything: entity count, feature widths and hidden size that are not multiples of 4 / 64 (checked GEMM loaders, padded rows)
+    (2, "Mformer_hd_graph", 0, True, torch.int32, (701, 5, 100, 33, 5, 37, 10)),
+    (1, "Mformer_hd_mean", 1, False, torch.int64, (333, 3, 36, 17, 3, 13, 9)),
 ])
-def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt):
+def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape):
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
-    N, R, D, B, K = 700, 23, 128, 96, 32
-    cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[200, 72], num_proj=num_proj, joint_way=joint_way,
+    N, R, D, B, K, F0, F1 = shape
+    cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[F0, F1], num_proj=num_proj, joint_way=joint_way,
                      use_intermediate=ffn, intermediate_size=96, margin=6.0, neg_num=K, dropout=0.0, add_noise=int(noise), seed=7)
     g = torch.Generator().manual_seed(99)
-    feats = [torch.rand(N, 200, generator=g), torch.randn(N, 72, generator=g)]
+    feats = [torch.rand(N, F0, generator=g), torch.randn(N, F1, generator=g)]
     eng = MKGCHotPath(cfg, feats, device=DEV)
     # make the entity table and relations O(1) so scores are not degenerate
     eng.p["ent"].copy_(torch.randn(N, D, generator=g).to(DEV))
