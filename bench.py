@@ -82,9 +82,19 @@ def roofline_dominant(cfg, timer):
     us, n = timer.mean_us()
     flops = 2.0 * cfg.n_ent * cfg.feat_dims[0] * cfg.dim
     ach = flops / (us * 1e-6) / 1e12 if us else 0.0
+    traffic, src = None, None
+    try:  # PMC passes cannot run inside this process; the committed per-launch figure is quoted when it is for this very shape
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_dominant.json")) as f:
+            pmc = json.load(f)
+        if (pmc["n_ent"], pmc["feat0"], pmc["dim"]) == (cfg.n_ent, cfg.feat_dims[0], cfg.dim):
+            traffic, src = pmc["fetch_bytes"] + pmc["write_bytes"], pmc["source"]
+    except (OSError, KeyError, ValueError):
+        pass
     return {"kernel": f"gemm_tile_kernel (visual projection: [{cfg.n_ent},{cfg.feat_dims[0]}]x[{cfg.feat_dims[0]},{cfg.dim}], exact-f32 MFMA)",
             "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
-            "traffic": None, "avg_us": us, "launches_timed": n, "algorithmic_flops_per_launch": flops}
+            "traffic": traffic, "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC)", "traffic_source": src,
+            "algorithmic_bytes_per_launch": 4 * (cfg.n_ent * cfg.feat_dims[0] + cfg.feat_dims[0] * cfg.dim + cfg.n_ent * cfg.dim),
+            "avg_us": us, "launches_timed": n, "algorithmic_flops_per_launch": flops}
 
 
 def roofline_score(cfg, batch, timer):
