@@ -291,16 +291,20 @@ SNAG_API int snag_argmin_rows_cols(const float* dist, int64_t ld, int n, int m, 
  * blocks and the eight gradient products are snag_gemm_f32 launches issued by the host module.
  * snag_gather_normalize_fwd: z[b,:] = x / max(|x|, 1e-12) (normalize != 0) or x, x = emb[idx[b], :]; den[b] = that
  *   denominator (F.normalize(emb) then emb[train_links[:, s]], :59-64).   _bwd scatters into d_emb with fp32 atomics.
- * snag_infonce_rows: logits [B, 2B] = [cross | self]: lse[i] = logsumexp_j over j != B + i (the reference's
- *   "- masks * 1e9" on the self block, :99-103), rowloss[i] = lse[i] - logits[i, i]  (-log_softmax at the target, :45-53).
- * snag_infonce_grad: in place, logits[i,j] <- coef * w[i] * (softmax[i,j] - [j == i]), 0 at the masked entry.
+ * snag_infonce_rows: S [2B, 2B] = Z Z^T / tau for the stacked views Z = [z1; z2] (one GEMM holds the reference's four blocks
+ *   ab, aa, ba, bb of :99-110).  lse[r] = logsumexp_j S[r, j] over j != r (the reference's "- masks * 1e9" on the self block),
+ *   rowloss[r] = lse[r] - S[r, (r + B) mod 2B]  (-log_softmax at the target, :45-53); rows 0..B-1 are loss_a's, B..2B-1 loss_b's.
+ * snag_infonce_grad: in place S <- G + G^T, G[r, j] = c_r (softmax_r[j] - [j == target(r)]), 0 on the diagonal,
+ *   c_r = (r < B ? coef_a : coef_b) * (w ? w[r mod B] : 1) * (scale ? *scale : 1)
+ *   (scale: the upstream gradient as a device scalar, so the backward needs no host sync); then d loss / d Z = (G + G^T) Z / tau is one GEMM.
  */
 SNAG_API int snag_gather_normalize_fwd(const float* emb, int64_t ld, int64_t n_rows, int d, const void* idx, int idx_bytes, int64_t B,
                                        int normalize, float* z, float* den, void* stream);
 SNAG_API int snag_gather_normalize_bwd(const float* dz, const float* z, const float* den, int d, const void* idx, int idx_bytes,
                                        int64_t B, int normalize, float* d_emb, int64_t ld, void* stream);
-SNAG_API int snag_infonce_rows(const float* logits, int64_t ld, int B, float* lse, float* rowloss, void* stream);
-SNAG_API int snag_infonce_grad(float* logits, int64_t ld, int B, const float* lse, const float* w, float coef, void* stream);
+SNAG_API int snag_infonce_rows(const float* S, int64_t ld, int B, float* lse, float* rowloss, void* stream);
+SNAG_API int snag_infonce_grad(float* S, int64_t ld, int B, const float* lse, const float* w, float coef_a, float coef_b,
+                               const float* scale, void* stream);
 
 /* SURVEY par. 8(f) "next" #3: negative sampling on the device (no Python sampler, no H2D index copies).
  * Follows generate_neg_triples_fast (model/MSNEA_tools.py:59-90): a candidate that forms a known triple is redrawn, up to

@@ -1,5 +1,6 @@
 // snag_gemm_f32: the dense contraction behind the projections (a5), the Mformer linears (a2-a4),
 // their backward passes, and (with the distance epilogue in eval.hip) the similarity GEMM (a8).
+#include <cstdio>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -176,6 +177,10 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     splits = ceil_div(p.K, kps);
     p.k_per_split = kps;
     float* slab = splits > 1 ? d->workspace : nullptr;
+    static const int log_shapes = env_int("SNAG_GEMM_LOG");    // tuning: one line per launch on stderr
+    if (log_shapes)
+        fprintf(stderr, "snag_gemm M=%d N=%d K=%d a_kc=%d b_kc=%d tile=%s splits=%d fast=%d acc=%d\n", p.M, p.N, p.K, (int)d->a_kcontig,
+                (int)d->b_kcontig, big ? "128x128" : "64x128", splits, (int)e.fast, (int)d->accumulate);
     if (big) launch_cfg<128, 128, 64, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else launch_cfg<64, 128, 32, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     int rc = check_launch("snag_gemm_f32");

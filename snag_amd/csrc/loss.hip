@@ -1,6 +1,7 @@
 // SURVEY.md par. 8(f) "next" #1: the MMEA contrastive objective icl_loss (model/SNAG_loss.py:31-128).
 //   z1 = nrm(emb)[left], z2 = nrm(emb)[right]
-//   logits_a = [z1 z2^T | z1 z1^T - 1e9 I] / tau       (the four B x B blocks are snag_gemm_f32 launches)
+//   logits_a = [z1 z2^T | z1 z1^T - 1e9 I] / tau, logits_b = [z2 z1^T | z2 z2^T - 1e9 I] / tau: all four B x B blocks are
+//   the 2B x 2B matrix S = Z Z^T / tau of the stacked views Z = [z1; z2] -- one snag_gemm_f32 launch
 //   CE_a = -(1/B) sum_i w_i log_softmax(logits_a)[i, i]
 // This file holds what is not a GEMM: gather + L2-normalise (fwd/bwd), the masked row log-sum-exp, and the in-place
 // transformation of the logits into their gradient.
@@ -45,44 +46,69 @@ __global__ __launch_bounds__(256) void gather_normalize_bwd_kernel(const float* 
     for (int c = lane; c < d; c += 64) atomicAdd(g + c, (dz[b * d + c] - z[b * d + c] * dot) * inv);
 }
 
-// One block per row of logits [B, 2B]: lse over all columns except the masked self-similarity (i, B+i) (its -1e9 makes
-// exp underflow to exactly 0 in the reference); rowloss = lse - logits[i, i].
-__global__ __launch_bounds__(256) void infonce_rows_kernel(const float* __restrict__ L, int64_t ld, int B, float* __restrict__ lse,
+// S [2B, 2B] = Z Z^T / tau over the stacked views Z = [z1; z2].  Row r < B is the reference's logits_a row r with its two
+// column blocks swapped ([aa | ab] instead of [ab | aa], :99-110), row B + r is logits_b ([ba | bb]); softmax does not care
+// about column order.  The masked self-similarity is the diagonal (its -1e9 makes exp underflow to exactly 0 in the
+// reference), the target is column (r + B) mod 2B.  One block per row, single read: online max/sum per thread.
+__global__ __launch_bounds__(256) void infonce_rows_kernel(const float* __restrict__ S, int64_t ld, int B, float* __restrict__ lse,
                                                            float* __restrict__ rowloss) {
-    __shared__ float red[4];
-    const int i = blockIdx.x;
-    const float* row = L + (int64_t)i * ld;
-    float mx = -INFINITY;
-    for (int j = threadIdx.x; j < 2 * B; j += 256)
-        if (j != B + i) mx = fmaxf(mx, row[j]);
-    mx = max64(mx);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float s = 0.f;
-    for (int j = threadIdx.x; j < 2 * B; j += 256)
-        if (j != B + i) s += expf(row[j] - mx);
-    s = sum64(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __shared__ float red_m[4], red_s[4];
+    const int i = blockIdx.x, n = 2 * B;
+    const float* row = S + (int64_t)i * ld;
+    float mx = -INFINITY, sm = 0.f;
+    auto push = [&](float x) {
+        const float m2 = fmaxf(mx, x);
+        sm = sm * __expf(mx - m2) + __expf(x - m2);
+        mx = m2;
+    };
+    if ((ld & 3) == 0 && (((uintptr_t)S) & 15) == 0) {
+        const int n4 = n >> 2;
+        for (int q = threadIdx.x; q < n4; q += 256) {
+            const float4 v = reinterpret_cast<const float4*>(row)[q];
+            const int j = q * 4;
+            if (j + 0 != i) push(v.x);
+            if (j + 1 != i) push(v.y);
+            if (j + 2 != i) push(v.z);
+            if (j + 3 != i) push(v.w);
+        }
+        for (int j = n4 * 4 + threadIdx.x; j < n; j += 256)
+            if (j != i) push(row[j]);
+    } else {
+        for (int j = threadIdx.x; j < n; j += 256)
+            if (j != i) push(row[j]);
+    }
+    const float wm = max64(mx);
+    sm = (mx == -INFINITY) ? 0.f : sm * __expf(mx - wm);
+    sm = sum64(sm);
+    if ((threadIdx.x & 63) == 0) { red_m[threadIdx.x >> 6] = wm; red_s[threadIdx.x >> 6] = sm; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float l = mx + logf(((red[0] + red[1]) + red[2]) + red[3]);
+        const float m = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+        float t = 0.f;
+        for (int k = 0; k < 4; ++k) t += (red_m[k] == -INFINITY) ? 0.f : red_s[k] * expf(red_m[k] - m);
+        const float l = m + logf(t);
         lse[i] = l;
-        rowloss[i] = l - row[i];
+        rowloss[i] = l - row[i < B ? i + B : i - B];
     }
 }
 
-// in place: L[i,j] <- c_i (softmax(L)[i,j] - [j == i]), masked entry -> 0;  c_i = coef * (w ? w[i] : 1)
-__global__ __launch_bounds__(256) void infonce_grad_kernel(float* __restrict__ L, int64_t ld, int B, const float* __restrict__ lse,
-                                                           const float* __restrict__ w, float coef) {
-    const int i = blockIdx.x;
-    float* row = L + (int64_t)i * ld;
-    const float c = coef * (w ? w[i] : 1.0f), l = lse[i];
-    for (int j = threadIdx.x; j < 2 * B; j += 256) {
-        float p = (j == B + i) ? 0.f : expf(row[j] - l);
-        if (j == i) p -= 1.0f;
-        row[j] = c * p;
+// in place: S <- G + G^T with G[r,j] = c_r (softmax_r[j] - [j == target(r)]) off the diagonal, 0 on it; c_r = (r < B ? ca : cb) * w[r mod B].
+// S is symmetric bit for bit (every entry is the same k-ordered sum), so G^T needs no transposed read:
+//   (G + G^T)[r,j] = c_r (e^{S_rj - lse_r} - [j == target(r)]) + c_j (e^{S_rj - lse_j} - [r == target(j)])
+// and d loss / d Z = (G + G^T) Z / tau is then ONE product.
+__global__ __launch_bounds__(256) void infonce_grad_kernel(float* __restrict__ S, int64_t ld, int B, const float* __restrict__ lse,
+                                                           const float* __restrict__ w, float ca, float cb, const float* __restrict__ scale) {
+    const int r = blockIdx.x, n = 2 * B;
+    if (scale) { ca *= scale[0]; cb *= scale[0]; }
+    float* row = S + (int64_t)r * ld;
+    const float cr = (r < B ? ca : cb) * (w ? w[r < B ? r : r - B] : 1.0f), lr = lse[r];
+    const int tgt = r < B ? r + B : r - B;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const float cj = (j < B ? ca : cb) * (w ? w[j < B ? j : j - B] : 1.0f);
+        const float x = row[j];
+        float g = cr * __expf(x - lr) + cj * __expf(x - lse[j]);
+        if (j == tgt) g -= cr + cj;
+        row[j] = (j == r) ? 0.f : g;
     }
 }
 
@@ -116,14 +142,15 @@ extern "C" SNAG_API int snag_gather_normalize_bwd(const float* dz, const float* 
     return check_launch("snag_gather_normalize_bwd");
 }
 
-extern "C" SNAG_API int snag_infonce_rows(const float* logits, int64_t ld, int B, float* lse, float* rowloss, void* stream) {
-    SNAG_REQUIRE(B >= 1 && ld >= 2 * (int64_t)B && logits && lse && rowloss, SNAG_ERR_ARG, "infonce_rows: bad arguments");
-    hipLaunchKernelGGL(infonce_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ld, B, lse, rowloss);
+extern "C" SNAG_API int snag_infonce_rows(const float* S, int64_t ld, int B, float* lse, float* rowloss, void* stream) {
+    SNAG_REQUIRE(B >= 1 && ld >= 2 * (int64_t)B && S && lse && rowloss, SNAG_ERR_ARG, "infonce_rows: bad arguments");
+    hipLaunchKernelGGL(infonce_rows_kernel, dim3(2 * B), dim3(256), 0, (hipStream_t)stream, S, ld, B, lse, rowloss);
     return check_launch("snag_infonce_rows");
 }
 
-extern "C" SNAG_API int snag_infonce_grad(float* logits, int64_t ld, int B, const float* lse, const float* w, float coef, void* stream) {
-    SNAG_REQUIRE(B >= 1 && ld >= 2 * (int64_t)B && logits && lse, SNAG_ERR_ARG, "infonce_grad: bad arguments");
-    hipLaunchKernelGGL(infonce_grad_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ld, B, lse, w, coef);
+extern "C" SNAG_API int snag_infonce_grad(float* S, int64_t ld, int B, const float* lse, const float* w, float coef_a, float coef_b,
+                                          const float* scale, void* stream) {
+    SNAG_REQUIRE(B >= 1 && ld >= 2 * (int64_t)B && S && lse, SNAG_ERR_ARG, "infonce_grad: bad arguments");
+    hipLaunchKernelGGL(infonce_grad_kernel, dim3(2 * B), dim3(256), 0, (hipStream_t)stream, S, ld, B, lse, w, coef_a, coef_b, scale);
     return check_launch("snag_infonce_grad");
 }
