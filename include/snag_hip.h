@@ -325,15 +325,17 @@ SNAG_API int snag_sample_negatives(uint64_t seed, const uint64_t* tick, const in
  * rowptr [N+1], col [E], int32.  w [H, f] (the reference's [H,1,f]), a_src_dst [H, 2f] ([H,2f,1]).  H <= 4, f <= 512.
  * fwd keeps s_src, s_dst [N,H], agg [N,H,f], rsum [N,H] (and pre [N,f] when apply_elu) for the backward.
  * bwd: d_x is overwritten; d_w / d_a are overwritten or accumulated; work: snag_gat_work_floats(N, f, H) floats.
- * Neighbour scatters use fp32 atomics; parameter gradients use fixed-order partial sums.
+ * The backward also takes the same edge set grouped by DESTINATION (t_rowptr [N+1], t_col [E] = sources): it runs as two gather
+ * passes (out-edges per source, in-edges per destination) with no atomics, and parameter gradients use fixed-order partial
+ * sums, so it is deterministic.
  */
 SNAG_API int64_t snag_gat_work_floats(int64_t N, int f, int H);
 SNAG_API int snag_gat_layer_fwd(const float* x, int64_t N, int f, int H, const float* w, const float* a_src_dst,
                                 const int32_t* rowptr, const int32_t* col, int apply_elu,
                                 float* s_src, float* s_dst, float* agg, float* rsum, float* pre, float* out, void* stream);
 SNAG_API int snag_gat_layer_bwd(const float* x, int64_t N, int f, int H, const float* w, const float* a_src_dst,
-                                const int32_t* rowptr, const int32_t* col, const float* s_src, const float* s_dst,
-                                const float* agg, const float* rsum, const float* pre, int had_elu, const float* d_out,
+                                const int32_t* rowptr, const int32_t* col, const int32_t* t_rowptr, const int32_t* t_col,
+                                const float* s_src, const float* s_dst, const float* agg, const float* rsum, const float* pre, int had_elu, const float* d_out,
                                 float* d_x, float* d_w, float* d_a, int accumulate, float* work, void* stream);
 
 #ifdef __cplusplus

@@ -8,8 +8,8 @@
 //   pre[u,:] = (1/H) sum_i w_i * A_i[u,:] / r_i[u] ;  out = elu(pre) between layers, pre after the last.
 //
 // Edges arrive as CSR over the source node (duplicates and self loops preserved, values unused).  One wave per source
-// node; a feature row is spread over the wave as col = lane + 64*u (256-byte segments).  The backward scatters into
-// neighbour rows with fp32 atomics and reduces parameter gradients through fixed-order per-block partial sums.
+// node; a feature row is spread over the wave as col = lane + 64*u (256-byte segments).  The backward is two gather passes (out-edges per
+// source, in-edges per destination) with no atomics; parameter gradients go through fixed-order per-block partial sums.
 #include <algorithm>
 
 #include "fusion_kernels.hip.h"
@@ -105,23 +105,29 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(const float* __r
     st_cols<NU>(out + u * f, y, f, lane);
 }
 
-// Edge pass of the backward, one wave per source node u.
-// part[block][H][f] receives the block's partial of sum_u g[u,:] * A_i[u,:] / r_i[u]  (the aggregation route into d w_i).
+// Backward, pass 1: one wave per source node u over its OUT-edges (persistent blocks, fixed-order partials).
+//   gq[u,:]   = d_out[u,:] * elu'(pre[u,:])                      (kept for pass 2)
+//   drs[u,i]  = d loss / d r_i[u] = -sum_c gq w_i A_i / (H r^2)   (kept for pass 2)
+//   ds_src[u,i] = sum_{(u,v)} dz_i(u,v),  dz = -e * lrelu'(z) * (dA_i[u,:] . x[v,:] + drs),  dA_i[u,:] = gq w_i / (H r_i[u])
+//   part[block][H][f]: the block's partial of sum_u gq[u,:] A_i[u,:] / (H r_i[u])   (the aggregation route into d w_i)
 template <int NU>
-__global__ __launch_bounds__(256) void gat_aggregate_bwd_kernel(const float* __restrict__ x, int64_t N, int f, int H, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void gat_bwd_out_edges_kernel(const float* __restrict__ x, int64_t N, int f, int H, const float* __restrict__ w,
                                                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                                 const float* __restrict__ s_src, const float* __restrict__ s_dst,
                                                                 const float* __restrict__ agg, const float* __restrict__ rsum,
                                                                 const float* __restrict__ pre, int had_elu, const float* __restrict__ d_out,
-                                                                float* __restrict__ d_x, float* __restrict__ ds_src, float* __restrict__ ds_dst,
+                                                                float* __restrict__ gq, float* __restrict__ drs_out, float* __restrict__ ds_src,
                                                                 float* __restrict__ part) {
     __shared__ float red[4][64 * NU];
     const int lane = threadIdx.x & 63, wave = wave_id_uniform();
-    Cols<NU> pw[kGatMaxH];
+    Cols<NU> pw[kGatMaxH], wi[kGatMaxH];
 #pragma unroll
-    for (int i = 0; i < kGatMaxH; ++i)
+    for (int i = 0; i < kGatMaxH; ++i) {
+        if (i < H) wi[i] = ld_cols<NU>(w + i * f, f, lane);
 #pragma unroll
         for (int q = 0; q < NU; ++q) pw[i].v[q] = 0.f;
+    }
+    const float invH = 1.0f / (float)H;
     for (int64_t u = (int64_t)blockIdx.x * 4 + wave; u < N; u += (int64_t)gridDim.x * 4) {
         Cols<NU> g = ld_cols<NU>(d_out + u * f, f, lane);
         if (had_elu) {
@@ -129,47 +135,47 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_kernel(const float* __r
 #pragma unroll
             for (int q = 0; q < NU; ++q) g.v[q] *= (p.v[q] > 0.f) ? 1.0f : expf(p.v[q]);      // elu'
         }
-        const float invH = 1.0f / (float)H;
-        const int e0 = rowptr[u], e1 = rowptr[u + 1];
+        st_cols<NU>(gq + u * f, g, f, lane);
+        Cols<NU> dA[kGatMaxH];                        // d loss / d A_i[u,:] = g w_i / (H r)
+        float drs[kGatMaxH], ssu[kGatMaxH], dsu[kGatMaxH];
 #pragma unroll
         for (int i = 0; i < kGatMaxH; ++i) {
+            drs[i] = ssu[i] = dsu[i] = 0.f;
             if (i < H) {
-                const Cols<NU> wi = ld_cols<NU>(w + i * f, f, lane);
                 const Cols<NU> A = ld_cols<NU>(agg + (u * H + i) * f, f, lane);
-                const float r = rsum[u * H + i], inv = 1.0f / r;
-                Cols<NU> dA;                          // d loss / d A_i[u,:] = g w_i / (H r)
-                float drs = 0.f;                      // d loss / d r_i[u]   = -sum_c g w_i A_i / (H r^2)
+                const float inv = 1.0f / rsum[u * H + i];
+                float t = 0.f;
 #pragma unroll
                 for (int q = 0; q < NU; ++q) {
-                    const float gw = g.v[q] * invH * wi.v[q] * inv;
-                    dA.v[q] = gw;
-                    drs = fmaf(-gw * inv, A.v[q], drs);
+                    const float gw = g.v[q] * invH * wi[i].v[q] * inv;
+                    dA[i].v[q] = gw;
+                    t = fmaf(-gw * inv, A.v[q], t);
                     pw[i].v[q] = fmaf(g.v[q] * invH * inv, A.v[q], pw[i].v[q]);
                 }
-                drs = sum64(drs);
-                const float ssu = s_src[u * H + i];
-                float dsu = 0.f;
-                for (int e = e0; e < e1; ++e) {
-                    const int64_t v = col[e];
-                    const Cols<NU> xv = ld_cols<NU>(x + v * f, f, lane);
-                    const float z = ssu + s_dst[v * H + i];
-                    const float al = gat_edge_weight(z);
-                    float dal = 0.f;
-#pragma unroll
-                    for (int q = 0; q < NU; ++q) dal = fmaf(dA.v[q], xv.v[q], dal);
-                    dal = sum64(dal) + drs;                                   // through A_i and through r_i
-                    const float dz = -al * (z > 0.f ? 1.0f : 0.2f) * dal;
-                    dsu += dz;
-                    if (lane == 0) atomicAdd(ds_dst + v * H + i, dz);
-#pragma unroll
-                    for (int q = 0; q < NU; ++q) {
-                        const int c = lane + 64 * q;
-                        if (c < f) atomicAdd(d_x + v * f + c, al * dA.v[q]);
-                    }
-                }
-                if (lane == 0) ds_src[u * H + i] = dsu;
+                drs[i] = sum64(t);
+                ssu[i] = s_src[u * H + i];
+                if (lane == 0) drs_out[u * H + i] = drs[i];
             }
         }
+        const int e0 = rowptr[u], e1 = rowptr[u + 1];
+        for (int e = e0; e < e1; ++e) {
+            const int64_t v = col[e];
+            const Cols<NU> xv = ld_cols<NU>(x + v * f, f, lane);
+#pragma unroll
+            for (int i = 0; i < kGatMaxH; ++i) {
+                if (i < H) {
+                    const float z = ssu[i] + s_dst[v * H + i];
+                    float dal = 0.f;
+#pragma unroll
+                    for (int q = 0; q < NU; ++q) dal = fmaf(dA[i].v[q], xv.v[q], dal);
+                    dal = sum64(dal) + drs[i];                                // through A_i and through r_i
+                    dsu[i] += -gat_edge_weight(z) * (z > 0.f ? 1.0f : 0.2f) * dal;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kGatMaxH; ++i)
+            if (i < H && lane == 0) ds_src[u * H + i] = dsu[i];
     }
     for (int i = 0; i < H; ++i) {
         __syncthreads();
@@ -183,6 +189,68 @@ __global__ __launch_bounds__(256) void gat_aggregate_bwd_kernel(const float* __r
         __syncthreads();
         for (int c = threadIdx.x; c < f; c += 256) part[((int64_t)blockIdx.x * H + i) * f + c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
     }
+}
+
+// Backward, pass 2: one wave per destination node v over its IN-edges (t_rowptr/t_col: the same edge set, grouped by destination).
+// No atomics: d_x[v,:] = sum_i w_i * sum_{(u,v)} e_i(u,v) gq[u,:] / (H r_i[u]) and ds_dst[v,i] = sum_{(u,v)} dz_i(u,v) are owned by this wave.
+template <int NU>
+__global__ __launch_bounds__(256) void gat_bwd_in_edges_kernel(const float* __restrict__ x, int64_t N, int f, int H, const float* __restrict__ w,
+                                                               const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_col,
+                                                               const float* __restrict__ s_src, const float* __restrict__ s_dst,
+                                                               const float* __restrict__ rsum, const float* __restrict__ gq,
+                                                               const float* __restrict__ drs, float* __restrict__ d_x, float* __restrict__ ds_dst) {
+    const int64_t v = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (v >= N) return;
+    const int lane = threadIdx.x & 63;
+    const float invH = 1.0f / (float)H;
+    const Cols<NU> xv = ld_cols<NU>(x + v * f, f, lane);
+    Cols<NU> xw[kGatMaxH], acc[kGatMaxH];
+    float sd[kGatMaxH], dsd[kGatMaxH];
+#pragma unroll
+    for (int i = 0; i < kGatMaxH; ++i) {
+        sd[i] = dsd[i] = 0.f;
+        if (i < H) {
+            const Cols<NU> wi = ld_cols<NU>(w + i * f, f, lane);
+            sd[i] = s_dst[v * H + i];
+#pragma unroll
+            for (int q = 0; q < NU; ++q) xw[i].v[q] = xv.v[q] * wi.v[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NU; ++q) acc[i].v[q] = 0.f;
+    }
+    const int e0 = t_rowptr[v], e1 = t_rowptr[v + 1];
+    for (int e = e0; e < e1; ++e) {
+        const int64_t u = t_col[e];
+        const Cols<NU> g = ld_cols<NU>(gq + u * f, f, lane);
+#pragma unroll
+        for (int i = 0; i < kGatMaxH; ++i) {
+            if (i < H) {
+                const float z = s_src[u * H + i] + sd[i];
+                const float al = gat_edge_weight(z), c = invH / rsum[u * H + i];
+                float dot = 0.f;
+#pragma unroll
+                for (int q = 0; q < NU; ++q) {
+                    acc[i].v[q] = fmaf(al * c, g.v[q], acc[i].v[q]);
+                    dot = fmaf(g.v[q], xw[i].v[q], dot);
+                }
+                const float dal = c * sum64(dot) + drs[u * H + i];
+                dsd[i] += -al * (z > 0.f ? 1.0f : 0.2f) * dal;
+            }
+        }
+    }
+    Cols<NU> o;
+#pragma unroll
+    for (int q = 0; q < NU; ++q) o.v[q] = 0.f;
+#pragma unroll
+    for (int i = 0; i < kGatMaxH; ++i) {
+        if (i < H) {
+            const Cols<NU> wi = ld_cols<NU>(w + i * f, f, lane);
+#pragma unroll
+            for (int q = 0; q < NU; ++q) o.v[q] = fmaf(wi.v[q], acc[i].v[q], o.v[q]);
+            if (lane == 0) ds_dst[v * H + i] = dsd[i];
+        }
+    }
+    st_cols<NU>(d_x + v * f, o, f, lane);
 }
 
 // Node pass of the backward: s_src/s_dst -> x, w, a.  part2[block][H][3][f]: partials of d w_i (score route), d a_src_i, d a_dst_i.
@@ -247,7 +315,7 @@ __global__ __launch_bounds__(256) void gat_param_reduce_kernel(const float* __re
     pa[f] = accumulate ? pa[f] + sd : sd;
 }
 
-static constexpr int kGatBlocks = 256;
+static constexpr int kGatBlocks = 1024;
 
 }  // namespace snag
 
@@ -270,7 +338,7 @@ static int gat_check(int64_t N, int f, int H, const void* x, const void* w, cons
     return SNAG_OK;
 }
 
-extern "C" SNAG_API int64_t snag_gat_work_floats(int64_t N, int f, int H) { return (int64_t)kGatBlocks * H * f * 4 + 2 * N * H + 64; }
+extern "C" SNAG_API int64_t snag_gat_work_floats(int64_t N, int f, int H) { return (int64_t)kGatBlocks * H * f * 4 + 3 * N * H + N * f + 64; }
 
 extern "C" SNAG_API int snag_gat_layer_fwd(const float* x, int64_t N, int f, int H, const float* w, const float* a_src_dst, const int32_t* rowptr,
                                            const int32_t* col, int apply_elu, float* s_src, float* s_dst, float* agg, float* rsum, float* pre,
@@ -287,22 +355,25 @@ extern "C" SNAG_API int snag_gat_layer_fwd(const float* x, int64_t N, int f, int
 }
 
 extern "C" SNAG_API int snag_gat_layer_bwd(const float* x, int64_t N, int f, int H, const float* w, const float* a_src_dst, const int32_t* rowptr,
-                                           const int32_t* col, const float* s_src, const float* s_dst, const float* agg, const float* rsum,
-                                           const float* pre, int had_elu, const float* d_out, float* d_x, float* d_w, float* d_a, int accumulate,
-                                           float* work, void* stream) {
+                                           const int32_t* col, const int32_t* t_rowptr, const int32_t* t_col, const float* s_src,
+                                           const float* s_dst, const float* agg, const float* rsum, const float* pre, int had_elu,
+                                           const float* d_out, float* d_x, float* d_w, float* d_a, int accumulate, float* work, void* stream) {
     int rc = gat_check(N, f, H, x, w, a_src_dst, rowptr, col);
     if (rc || N == 0) return rc;
     SNAG_REQUIRE(s_src && s_dst && agg && rsum && d_out && d_x && d_w && d_a && work, SNAG_ERR_ARG, "gat_layer_bwd: null pointer");
+    SNAG_REQUIRE(t_rowptr && t_col, SNAG_ERR_ARG, "gat_layer_bwd: the destination-grouped edge list (t_rowptr, t_col) is required");
     SNAG_REQUIRE(!had_elu || pre, SNAG_ERR_ARG, "gat_layer_bwd: the ELU layer needs the saved pre-activation");
     hipStream_t st = (hipStream_t)stream;
     float* ds_src = work;
     float* ds_dst = ds_src + N * H;
-    float* part = ds_dst + N * H;
+    float* drs = ds_dst + N * H;
+    float* gq = drs + N * H;
+    float* part = gq + N * f;
     float* part2 = part + (int64_t)kGatBlocks * H * f;
-    if (hipMemsetAsync(d_x, 0, sizeof(float) * N * f, st) != hipSuccess || hipMemsetAsync(ds_dst, 0, sizeof(float) * N * H, st) != hipSuccess)
-        return fail(SNAG_ERR_LAUNCH, "gat_layer_bwd: memset failed");
     const int nb = (int)std::min<int64_t>(kGatBlocks, (N + 3) / 4);
-    SNAG_GAT_NU(gat_aggregate_bwd_kernel, f, dim3(nb), st, x, N, f, H, w, rowptr, col, s_src, s_dst, agg, rsum, pre, had_elu, d_out, d_x, ds_src, ds_dst, part);
+    SNAG_GAT_NU(gat_bwd_out_edges_kernel, f, dim3(nb), st, x, N, f, H, w, rowptr, col, s_src, s_dst, agg, rsum, pre, had_elu, d_out, gq, drs, ds_src, part);
+    SNAG_GAT_NU(gat_bwd_in_edges_kernel, f, dim3((unsigned)ceil_div(N, 4)), st, x, N, f, H, w, t_rowptr, t_col, s_src, s_dst, rsum, (const float*)gq,
+                (const float*)drs, d_x, ds_dst);
     SNAG_GAT_NU(gat_node_scores_bwd_kernel, f, dim3(nb), st, x, N, f, H, w, a_src_dst, (const float*)ds_src, (const float*)ds_dst, d_x, part2);
     hipLaunchKernelGGL(gat_param_reduce_kernel, dim3(ceil_div(H * f, 256)), dim3(256), 0, st, (const float*)part, (const float*)part2, nb, nb, H, f, d_w, d_a, accumulate);
     return check_launch("snag_gat_layer_bwd");

@@ -35,21 +35,26 @@ class MultiHeadGraphAttention(nn.Module):
             nn.init.xavier_uniform_(self.a_src_dst)
 
 
-def build_csr(adj_or_edges, n_nodes):
-    """COO index list [2, E] (or a sparse COO tensor) -> (rowptr [N+1] int32, col [E] int32), stable in the stored edge order."""
-    edges = adj_or_edges._indices() if adj_or_edges.layout != torch.strided else adj_or_edges
-    src, dst = edges[0].long(), edges[1].long()
-    order = torch.sort(src, stable=True)[1]
-    col = dst[order].to(torch.int32).contiguous()
-    counts = torch.bincount(src, minlength=n_nodes)
-    rowptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=src.device)
+def _group(key, other, n_nodes):
+    order = torch.sort(key, stable=True)[1]
+    col = other[order].to(torch.int32).contiguous()
+    counts = torch.bincount(key, minlength=n_nodes)
+    rowptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=key.device)
     rowptr[1:] = torch.cumsum(counts, 0)
     return rowptr.to(torch.int32).contiguous(), col
 
 
+def build_csr(adj_or_edges, n_nodes):
+    """COO index list [2, E] (or a sparse COO tensor) -> (rowptr [N+1], col [E], t_rowptr [N+1], t_col [E]) int32: the edges grouped by
+    source (col = destinations) and, for the backward, by destination (t_col = sources); both stable in the stored edge order."""
+    edges = adj_or_edges._indices() if adj_or_edges.layout != torch.strided else adj_or_edges
+    src, dst = edges[0].long(), edges[1].long()
+    return _group(src, dst, n_nodes) + _group(dst, src, n_nodes)
+
+
 class _GatLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, a, rowptr, col, apply_elu):
+    def forward(ctx, x, w, a, rowptr, col, t_rowptr, t_col, apply_elu):
         ops._chk(x, "x", ndim=2)
         N, f = x.shape
         H = w.shape[0]
@@ -64,14 +69,14 @@ class _GatLayerFn(torch.autograd.Function):
         out = torch.empty(N, f, device=dev, dtype=f32)
         call("snag_gat_layer_fwd", ptr(x), N, f, H, ptr(w2), ptr(a2), ptr(rowptr), ptr(col), int(apply_elu), ptr(s_src), ptr(s_dst), ptr(agg),
              ptr(rsum), ptr(pre), ptr(out), stream())
-        ctx.save_for_backward(x, w2, a2, rowptr, col, s_src, s_dst, agg, rsum, pre)
+        ctx.save_for_backward(x, w2, a2, rowptr, col, t_rowptr, t_col, s_src, s_dst, agg, rsum, pre)
         ctx.apply_elu = apply_elu
         ctx.shapes = (tuple(w.shape), tuple(a.shape))
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        x, w2, a2, rowptr, col, s_src, s_dst, agg, rsum, pre = ctx.saved_tensors
+        x, w2, a2, rowptr, col, t_rowptr, t_col, s_src, s_dst, agg, rsum, pre = ctx.saved_tensors
         N, f = x.shape
         H = w2.shape[0]
         dev = x.device
@@ -79,9 +84,9 @@ class _GatLayerFn(torch.autograd.Function):
         d_w = torch.empty(H, f, device=dev, dtype=f32)
         d_a = torch.empty(H, 2 * f, device=dev, dtype=f32)
         work = torch.empty(_lib.load().snag_gat_work_floats(N, f, H), device=dev, dtype=f32)
-        call("snag_gat_layer_bwd", ptr(x), N, f, H, ptr(w2), ptr(a2), ptr(rowptr), ptr(col), ptr(s_src), ptr(s_dst), ptr(agg), ptr(rsum), ptr(pre),
-             int(ctx.apply_elu), ptr(d_out.contiguous()), ptr(d_x), ptr(d_w), ptr(d_a), 0, ptr(work), stream())
-        return d_x, d_w.view(ctx.shapes[0]), d_a.view(ctx.shapes[1]), None, None, None
+        call("snag_gat_layer_bwd", ptr(x), N, f, H, ptr(w2), ptr(a2), ptr(rowptr), ptr(col), ptr(t_rowptr), ptr(t_col), ptr(s_src), ptr(s_dst), ptr(agg), ptr(rsum),
+             ptr(pre), int(ctx.apply_elu), ptr(d_out.contiguous()), ptr(d_x), ptr(d_w), ptr(d_a), 0, ptr(work), stream())
+        return d_x, d_w.view(ctx.shapes[0]), d_a.view(ctx.shapes[1]), None, None, None, None, None
 
 
 class GAT(nn.Module):
@@ -109,10 +114,10 @@ class GAT(nn.Module):
 
     def forward(self, x, adj):
         _lib.require_gpu()
-        rowptr, col = self._graph(adj, x.shape[0])
+        rowptr, col, t_rowptr, t_col = self._graph(adj, x.shape[0])
         x = x.contiguous()
         for i, layer in enumerate(self.layer_stack):
             if layer.w.shape[2] != x.shape[1]:
                 raise ValueError(f"diag GAT layer {i} expects width {layer.w.shape[2]}, got {x.shape[1]}")
-            x = _GatLayerFn.apply(x, layer.w, layer.a_src_dst, rowptr, col, i + 1 < self.num_layer)
+            x = _GatLayerFn.apply(x, layer.w, layer.a_src_dst, rowptr, col, t_rowptr, t_col, i + 1 < self.num_layer)
         return x
