@@ -135,12 +135,13 @@ static int pick_splits(int64_t tiles, int K, bool both_kc = false) {
     return (int)std::min(want, cap);
 }
 
-static int force_tile() { static const int v = env_int("SNAG_GEMM_TILE"); return v; }        // tuning hooks: 1 = 64x128, 2 = 128x128
+static int force_tile() { static const int v = env_int("SNAG_GEMM_TILE"); return v; }        // tuning hooks: 1 = 64x128, 2 = 128x128, 3 = 128x160
 static int force_splits() { static const int v = env_int("SNAG_GEMM_SPLITS"); return v; }
 
 int64_t gemm_workspace_floats(int M, int N, int K) {
-    const int64_t tiles = (int64_t)ceil_div(M, 64) * ceil_div(N, 128);
-    const int splits = force_splits() > 0 ? force_splits() : pick_splits(tiles, K);
+    // the largest fan-out any tile configuration may pick for this shape (the dispatcher clamps to what it is given)
+    const int64_t t64 = (int64_t)ceil_div(M, 64) * ceil_div(N, 128), t160 = (int64_t)ceil_div(M, 128) * ceil_div(N, 160);
+    const int splits = force_splits() > 0 ? force_splits() : std::max(pick_splits(t64, K), pick_splits(t160, K));
     return splits > 1 ? (int64_t)splits * M * N : 0;
 }
 
@@ -159,12 +160,24 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     e.fast = !d->pre_act && !d->keep_mask && !d->add2 && !d->accumulate && d->act <= 1 && (d->ldc % 4 == 0) && al16(d->C) &&
              (!d->bias || al16(d->bias)) && (!d->add1 || (al16(d->add1) && d->ld1 % 4 == 0));
 
-    // tile choice: 128x128 when that already fills the chip, else 64x128 for twice the blocks
-    const int64_t big_tiles = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128);
-    bool big = big_tiles >= 512;
-    if (force_tile() == 1) big = false;
-    if (force_tile() == 2) big = true;
-    const int64_t tiles = big ? big_tiles : (int64_t)ceil_div(p.M, 64) * ceil_div(p.N, 128);
+    // Tile choice by padded work x a measured per-configuration factor (tools/tune_gemm.py, tools/tune_gemm_mmea.py, one device):
+    //   128x128  when its tiles alone fill the chip; the best loop when both operands are K-contiguous;
+    //   128x160  (one wave = 32 x 160) pads N = 300 to 320 instead of 384 and is the fastest loop whenever an operand is
+    //            row-contiguous (LDS-DMA path); with both K-contiguous its checked loader costs ~18 %;
+    //   64x128   otherwise (twice the blocks for small outputs).
+    const bool kk = d->a_kcontig && d->b_kcontig;
+    const int64_t pm64 = (int64_t)ceil_div(p.M, 64) * 64, pm128 = (int64_t)ceil_div(p.M, 128) * 128;
+    const int64_t pn128 = (int64_t)ceil_div(p.N, 128) * 128, pn160 = (int64_t)ceil_div(p.N, 160) * 160;
+    const int64_t big_tiles = (pm128 / 128) * (pn128 / 128), wide_tiles = (pm128 / 128) * (pn160 / 160);
+    const double c_small = (double)pm64 * pn128 * (kk ? 1.08 : 1.10);
+    const double c_big = (double)pm128 * pn128 * (kk ? 1.00 : 1.05);
+    const double c_wide = (double)pm128 * pn160 * (kk ? 1.18 : 1.00);
+    const int64_t max_splits = d->workspace ? std::max<int64_t>(1, p.K / (kMinKTiles * kBK)) : 1;
+    bool big = big_tiles >= 512 && c_big <= c_small;
+    bool wide = wide_tiles * max_splits >= 512 && c_wide < (big ? c_big : c_small);
+    if (force_tile() != 0) { big = force_tile() == 2; wide = force_tile() == 3; }
+    if (wide) big = false;
+    const int64_t tiles = wide ? wide_tiles : big ? big_tiles : (pm64 / 64) * (pn128 / 128);
     // split K when the output alone cannot fill 256 CUs (the dW = dY^T X shapes: tiny output, long K)
     int splits = 1;
     if (d->workspace != nullptr) {
@@ -180,8 +193,9 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     static const int log_shapes = env_int("SNAG_GEMM_LOG");    // tuning: one line per launch on stderr
     if (log_shapes)
         fprintf(stderr, "snag_gemm M=%d N=%d K=%d a_kc=%d b_kc=%d tile=%s splits=%d fast=%d acc=%d\n", p.M, p.N, p.K, (int)d->a_kcontig,
-                (int)d->b_kcontig, big ? "128x128" : "64x128", splits, (int)e.fast, (int)d->accumulate);
-    if (big) launch_cfg<128, 128, 64, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
+                (int)d->b_kcontig, wide ? "128x160" : big ? "128x128" : "64x128", splits, (int)e.fast, (int)d->accumulate);
+    if (wide) launch_cfg<128, 160, 32, 160>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
+    else if (big) launch_cfg<128, 128, 64, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else launch_cfg<64, 128, 32, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     int rc = check_launch("snag_gemm_f32");
     if (rc) return rc;

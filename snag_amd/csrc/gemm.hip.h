@@ -74,15 +74,17 @@ struct GemmOperands {
 // One "slot" is a float4: along k for K-contiguous operands, along the row index otherwise.
 template <int BR, bool KC>
 struct Stager {
-    static constexpr int SLOTS = BR * kBK / 4 / 256;   // float4 per thread per tile
-    static_assert(BR * kBK % 1024 == 0, "tile must split evenly over 256 threads");
+    static constexpr int TOTAL = BR * kBK / 4;                 // float4 slots per tile
+    static constexpr int SLOTS = (TOTAL + 255) / 256;          // per thread; the last one may be half used (BR = 160: waves 0-1 only)
+    static_assert(TOTAL % 128 == 0, "a partly used slot must still split on a wave boundary");
+    static constexpr bool used(int s, int slot) { return (s + 1) * 256 <= TOTAL || slot < TOTAL; }
     float4 r[SLOTS];
     const float* base[SLOTS];      // per-slot address of k = 0, rows clamped (hot-path loader only)
 
     __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, int row0, int nrows, int tid) {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const int slot = tid + 256 * s;
+            const int slot = min(tid + 256 * s, TOTAL - 1);
             if (KC) {
                 const int row = min(row0 + slot / (kBK / 4), nrows - 1);
                 base[s] = P + (int64_t)row * ld + (slot % (kBK / 4)) * 4;
@@ -99,7 +101,7 @@ struct Stager {
     __device__ __forceinline__ void init_dma(const float* __restrict__ P, int64_t ld, int row0, int nrows, int tid) {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const int slot = tid + 256 * s;
+            const int slot = min(tid + 256 * s, TOTAL - 1);
             if (KC) {
                 const int lrow = slot / (kBK / 4);
                 const int c = (slot % (kBK / 4)) ^ ((lrow >> 2) & 3);
@@ -115,6 +117,7 @@ struct Stager {
         const int64_t off = KC ? (int64_t)k0 : (int64_t)k0 * ld;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
+            if (!used(s, 256 * s + 64 * wave)) continue;        // wave-uniform
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base[s] + off),
                                              (__attribute__((address_space(3))) void*)(tile + (256 * s + 64 * wave) * 4), 16, 0, 0);
@@ -133,12 +136,14 @@ struct Stager {
             // their products land in accumulator rows/cols the epilogue never stores.
             const int64_t off = KC ? (int64_t)k0 : (int64_t)k0 * ld;
 #pragma unroll
-            for (int s = 0; s < SLOTS; ++s) r[s] = *reinterpret_cast<const float4*>(base[s] + off);
+            for (int s = 0; s < SLOTS; ++s)
+                if (used(s, tid + 256 * s)) r[s] = *reinterpret_cast<const float4*>(base[s] + off);
             return;
         }
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int slot = tid + 256 * s;
+            if (!used(s, slot)) continue;
             int row, k;
             if (KC) {
                 row = row0 + slot / (kBK / 4);
@@ -187,6 +192,7 @@ struct Stager {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int slot = tid + 256 * s;
+            if (!used(s, slot)) continue;
             if (KC) {
                 const int row = slot / (kBK / 4);
                 const int c = slot % (kBK / 4);
@@ -245,7 +251,8 @@ struct GemmCore {
     static constexpr int TM = WM / 32, TN = WN / 32;
     static constexpr int A_BUF = TileLd<BM, A_KC>::floats, B_BUF = TileLd<BN, B_KC>::floats, B_BASE = 2 * A_BUF;
     static constexpr int TILE_FLOATS = 2 * (A_BUF + B_BUF);
-    static constexpr int STAGE_FLOATS = 4 * 32 * WN;   // epilogue staging, 32 rows x WN per wave
+    static constexpr int CW = (WN % 64 == 0) ? 64 : 32;   // epilogue staging chunk: 32 rows x CW columns per wave at a time
+    static constexpr int STAGE_FLOATS = 4 * 32 * CW;
     static constexpr int SMEM_FLOATS = TILE_FLOATS > STAGE_FLOATS ? TILE_FLOATS : STAGE_FLOATS;
     static_assert((BM / WM) * (BN / WN) == 4, "four waves per block");
 
@@ -401,28 +408,32 @@ struct GemmCore {
     // static (a runtime-indexed f32x16 would be demoted to scratch).
     template <class F>
     __device__ __forceinline__ void for_each(float* __restrict__ smem, int m0, int n0, F&& f) const {
-        static_assert(WN == 64, "sixteen float4 lanes per row of the wave patch");
-        static_assert(4 * 32 * WN <= SMEM_FLOATS, "staging fits in the tile buffers");
+        static_assert(WN % CW == 0 && STAGE_FLOATS <= SMEM_FLOATS, "staging fits in the tile buffers");
+        constexpr int LPR = CW / 4;            // lanes per staged row (float4 each)
+        constexpr int RPP = 64 / LPR;          // rows per pass
         const int lane = threadIdx.x & 63;
         const int wave = wave_id_uniform();
         const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
-        lds_float* stage = (lds_float*)smem + wave * (32 * WN);
+        lds_float* stage = (lds_float*)smem + wave * (32 * CW);
         const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            __syncthreads();
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int c = 0; c < WN / CW; ++c) {
+                __syncthreads();
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    stage[((e & 3) + 8 * (e >> 2) + 4 * lh) * WN + 32 * j + li] = acc[i][j][e];
-            __syncthreads();
-            const int row0 = m0 + wm0 + 32 * i + (lane >> 4);
-            const int col = n0 + wn0 + (lane & 15) * 4;
+                for (int j = 0; j < CW / 32; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        stage[((e & 3) + 8 * (e >> 2) + 4 * lh) * CW + 32 * j + li] = acc[i][c * (CW / 32) + j][e];
+                __syncthreads();
+                const int row0 = m0 + wm0 + 32 * i + lane / LPR;
+                const int col = n0 + wn0 + c * CW + (lane % LPR) * 4;
 #pragma unroll 2
-            for (int r = 0; r < 32; r += 4) {
-                const float4 v = *reinterpret_cast<const lds_float4*>(stage + (r + (lane >> 4)) * WN + (lane & 15) * 4);
-                f(row0 + r, col, v);
+                for (int r = 0; r < 32; r += RPP) {
+                    const float4 v = *reinterpret_cast<const lds_float4*>(stage + (r + lane / LPR) * CW + (lane % LPR) * 4);
+                    f(row0 + r, col, v);
+                }
             }
         }
     }
