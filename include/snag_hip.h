@@ -131,6 +131,11 @@ typedef struct snag_gemm_desc {
 SNAG_API int snag_gemm_f32(const snag_gemm_desc* desc, void* stream);
 SNAG_API int64_t snag_gemm_workspace_floats(int M, int N, int K);
 
+/* Gram matrix S [n, n] = alpha * Z Z^T for Z [n, k] (row stride ldz), exact-f32 MFMA.  Only the tiles on or above the diagonal are
+ * computed; each is also stored transposed, so S is symmetric bit for bit.  Used for the stacked InfoNCE logits
+ * (icl_loss, model/SNAG_loss.py:99-110: the four z_a z_b^T blocks are one Gram matrix of [z1; z2]).  k == 0 gives zeros. */
+SNAG_API int snag_gram_f32(const float* Z, int64_t ldz, int n, int k, float alpha, float* S, int64_t lds, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * a1-a4, a9  Mformer modality fusion.
  * Replaces MformerFusion.forward (model/SNAG_tools.py:32-51) and the BertLayer stack under it

@@ -565,10 +565,17 @@ __global__ __launch_bounds__(256) void fuse_out_bwd_kernel(const float* __restri
 }
 
 // d weight_raw = softmax backward over the 6 raw weights (reference softmaxes all 6, SNAG_tools.py:46)
-static __global__ void weight_raw_bwd_kernel(const float* __restrict__ part, int nblocks, const float* __restrict__ weight_raw,
-                                      float* __restrict__ d_weight_raw, int accumulate) {
+static __global__ __launch_bounds__(64) void weight_raw_bwd_kernel(const float* __restrict__ part, int nblocks, const float* __restrict__ weight_raw,
+                                                                   float* __restrict__ d_weight_raw, int accumulate) {
+    // one wave: lane l sums blocks l, l+64, ... in order, then a fixed-pattern wave reduction (deterministic)
+    float g[6];
+    for (int j = 0; j < 6; ++j) {
+        float s = 0.f;
+        for (int b = threadIdx.x; b < nblocks; b += 64) s += part[(int64_t)b * 6 + j];
+        g[j] = sum64(s);
+    }
     if (threadIdx.x != 0) return;
-    float wf[6], g[6];
+    float wf[6];
     float mx = -INFINITY, den = 0.f;
     for (int j = 0; j < 6; ++j) mx = fmaxf(mx, weight_raw[j]);
     for (int j = 0; j < 6; ++j) {
@@ -578,10 +585,7 @@ static __global__ void weight_raw_bwd_kernel(const float* __restrict__ part, int
     float sdot = 0.f;
     for (int j = 0; j < 6; ++j) {
         wf[j] /= den;
-        float s = 0.f;
-        for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * 6 + j];
-        g[j] = s;
-        sdot += wf[j] * s;
+        sdot += wf[j] * g[j];
     }
     for (int j = 0; j < 6; ++j) {
         const float v = wf[j] * (g[j] - sdot);

@@ -298,17 +298,34 @@ __global__ __launch_bounds__(256) void gat_node_scores_bwd_kernel(const float* _
 // d w[i,c] = sum_blocks part[b][i][c] + part2[b][i][0][c] ; d a[i, c] = sum part2[b][i][1][c] ; d a[i, f + c] = sum part2[b][i][2][c]
 __global__ __launch_bounds__(256) void gat_param_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part2, int nb1, int nb2, int H,
                                                                int f, float* __restrict__ d_w, float* __restrict__ d_a, int accumulate) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= H * f) return;
-    const int i = idx / f, c = idx % f;
+    // 16 columns x 16 groups of partial blocks per workgroup; group g sums blocks g, g+16, ... in order, then the groups are
+    // folded in a fixed order through LDS.
+    __shared__ float red[3][16][16];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + cl;
     float sw = 0.f, sa = 0.f, sd = 0.f;
-    for (int b = 0; b < nb1; ++b) sw += part[((int64_t)b * H + i) * f + c];
-    for (int b = 0; b < nb2; ++b) {
-        const float* q = part2 + (((int64_t)b * H + i) * 3) * f + c;
-        sw += q[0];
-        sa += q[f];
-        sd += q[2 * f];
+    if (idx < H * f) {
+        const int i = idx / f, c = idx % f;
+        for (int b = g; b < nb1; b += 16) sw += part[((int64_t)b * H + i) * f + c];
+        for (int b = g; b < nb2; b += 16) {
+            const float* q = part2 + (((int64_t)b * H + i) * 3) * f + c;
+            sw += q[0];
+            sa += q[f];
+            sd += q[2 * f];
+        }
     }
+    red[0][g][cl] = sw;
+    red[1][g][cl] = sa;
+    red[2][g][cl] = sd;
+    __syncthreads();
+    if (g != 0 || idx >= H * f) return;
+    sw = sa = sd = 0.f;
+    for (int k = 0; k < 16; ++k) {
+        sw += red[0][k][cl];
+        sa += red[1][k][cl];
+        sd += red[2][k][cl];
+    }
+    const int i = idx / f, c = idx % f;
     d_w[idx] = accumulate ? d_w[idx] + sw : sw;
     float* pa = d_a + (int64_t)i * 2 * f + c;
     pa[0] = accumulate ? pa[0] + sa : sa;
@@ -375,6 +392,6 @@ extern "C" SNAG_API int snag_gat_layer_bwd(const float* x, int64_t N, int f, int
     SNAG_GAT_NU(gat_bwd_in_edges_kernel, f, dim3((unsigned)ceil_div(N, 4)), st, x, N, f, H, w, t_rowptr, t_col, s_src, s_dst, rsum, (const float*)gq,
                 (const float*)drs, d_x, ds_dst);
     SNAG_GAT_NU(gat_node_scores_bwd_kernel, f, dim3(nb), st, x, N, f, H, w, a_src_dst, (const float*)ds_src, (const float*)ds_dst, d_x, part2);
-    hipLaunchKernelGGL(gat_param_reduce_kernel, dim3(ceil_div(H * f, 256)), dim3(256), 0, st, (const float*)part, (const float*)part2, nb, nb, H, f, d_w, d_a, accumulate);
+    hipLaunchKernelGGL(gat_param_reduce_kernel, dim3(ceil_div(H * f, 16)), dim3(256), 0, st, (const float*)part, (const float*)part2, nb, nb, H, f, d_w, d_a, accumulate);
     return check_launch("snag_gat_layer_bwd");
 }

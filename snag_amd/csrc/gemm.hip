@@ -97,6 +97,33 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// S = alpha * Z Z^T (Z [n, k], K-contiguous).  Only tiles on or above the diagonal run the main loop; each also writes its
+// transpose, so S is symmetric bit for bit and the MFMA work is (almost) halved.
+__global__ __launch_bounds__(256) void gram_tile_kernel(GemmOperands p, float alpha, float* __restrict__ C, int64_t ldc) {
+    if (blockIdx.x < blockIdx.y) return;
+    using Core = GemmCore<128, 128, 64, 64, true, true, false>;
+    __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    Core core;
+    core.run(p, smem, m0, n0, 0, p.K);
+    const int n = p.M;
+    const bool vec = (ldc % 4 == 0) && ((((uintptr_t)C) & 15) == 0);
+    core.for_each(smem, m0, n0, [=](int r, int c, float4 v) {
+        if (r >= n || c >= n) return;
+        float* o = C + (int64_t)r * ldc + c;
+        v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+        if (vec && c + 3 < n) {
+            *reinterpret_cast<float4*>(o) = v;
+        } else {
+            o[0] = v.x;
+            if (c + 1 < n) o[1] = v.y;
+            if (c + 2 < n) o[2] = v.z;
+            if (c + 3 < n) o[3] = v.w;
+        }
+    });
+    if (blockIdx.x != blockIdx.y) core.store_transposed(C, ldc, alpha, m0, n0, n, n);
+}
+
 static int env_int(const char* name) {
     const char* v = getenv(name);
     return v ? atoi(v) : 0;
@@ -233,6 +260,20 @@ extern "C" SNAG_API int snag_gemm_f32(const snag_gemm_desc* d, void* stream) {
     if (rc) return rc;
     if (d->M == 0 || d->N == 0) return SNAG_OK;
     return gemm_dispatch(d, (hipStream_t)stream);
+}
+
+extern "C" SNAG_API int snag_gram_f32(const float* Z, int64_t ldz, int n, int k, float alpha, float* S, int64_t lds, void* stream) {
+    SNAG_REQUIRE(n >= 0 && k >= 0 && ldz >= k && lds >= n, SNAG_ERR_ARG, "gram: bad sizes n=%d k=%d ldz=%ld lds=%ld", n, k, (long)ldz, (long)lds);
+    if (n == 0) return SNAG_OK;
+    SNAG_REQUIRE((Z || k == 0) && S, SNAG_ERR_ARG, "gram: null pointer");
+    GemmOperands p;
+    p.A = Z; p.B = Z; p.lda = ldz; p.ldb = ldz; p.M = n; p.N = n; p.K = k;
+    p.a_vec = p.b_vec = (ldz % 4 == 0) && (((uintptr_t)Z & 15) == 0);
+    p.k_per_split = ceil_div(std::max(k, 1), kBK) * kBK;
+    p.dbg = 0;
+    const int t = ceil_div(n, 128);
+    hipLaunchKernelGGL(gram_tile_kernel, dim3(t, t), dim3(256), 0, (hipStream_t)stream, p, alpha, S, lds);
+    return check_launch("snag_gram_f32");
 }
 
 extern "C" SNAG_API int64_t snag_gemm_workspace_floats(int M, int N, int K) { return gemm_workspace_floats(M, N, K); }

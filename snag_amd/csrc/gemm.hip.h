@@ -437,6 +437,39 @@ struct GemmCore {
             }
         }
     }
+
+    // Transposed store straight from the accumulators: C[col, row] = alpha * acc(row, col).  Registers 4k..4k+3 of a 32x32 tile are
+    // four consecutive rows, i.e. 16 contiguous bytes of the transposed row; lane pairs (lh) and the four k cover a full 128-byte
+    // line per column.  Used by the Gram kernel to fill the lower triangle from the upper one.
+    __device__ __forceinline__ void store_transposed(float* __restrict__ C, int64_t ldc, float alpha, int m0, int n0, int M, int N) const {
+        const int lane = threadIdx.x & 63;
+        const int wave = wave_id_uniform();
+        const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
+        const int li = lane & 31, lh = lane >> 5;
+        const bool vec_ok = (ldc % 4 == 0) && ((((uintptr_t)C) & 15) == 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn0 + 32 * j + li;
+                if (col >= N) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = m0 + wm0 + 32 * i + 8 * k + 4 * lh;
+                    float* dst = C + (int64_t)col * ldc + row;
+                    const float4 v = make_float4(alpha * acc[i][j][4 * k], alpha * acc[i][j][4 * k + 1], alpha * acc[i][j][4 * k + 2],
+                                                 alpha * acc[i][j][4 * k + 3]);
+                    if (vec_ok && row + 3 < M) {
+                        *reinterpret_cast<float4*>(dst) = v;
+                    } else {
+                        if (row + 0 < M) dst[0] = v.x;
+                        if (row + 1 < M) dst[1] = v.y;
+                        if (row + 2 < M) dst[2] = v.z;
+                        if (row + 3 < M) dst[3] = v.w;
+                    }
+                }
+            }
+    }
 };
 
 // One block = one BM x BN output tile (x one K split): main loop, then either the epilogue functor

@@ -123,6 +123,19 @@ def reduce_sum(x):
 ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "gelu_grad": 3, "relu_grad": 4}
 
 
+def gram(z, alpha=1.0, out=None):
+    """S = alpha * Z Z^T, symmetric bit for bit, upper-triangle tiles only (C ABI: snag_gram_f32)."""
+    if not (torch.is_tensor(z) and z.is_cuda and z.dtype == f32 and z.dim() == 2 and z.stride(1) == 1):
+        raise ValueError("gram: z must be a 2-D fp32 CUDA tensor with unit inner stride")
+    n, k = z.shape
+    if out is None:
+        out = torch.empty(n, n, device=z.device, dtype=f32)
+    if tuple(out.shape) != (n, n) or out.stride(1) != 1 or out.dtype != f32:
+        raise ValueError("gram: out has the wrong shape")
+    call("snag_gram_f32", ptr(z), z.stride(0), n, k, float(alpha), ptr(out), out.stride(0), stream())
+    return out
+
+
 def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, alpha=1.0, act=None, want_pre_act=False,
          keep_mask=None, keep_p=0.0, add1=None, add2=None, out=None, accumulate=False, splitk=True, aux=None):
     """C = add1 + add2 + keep * act(alpha * A.B + bias)   (C ABI: snag_gemm_f32; exact-f32 MFMA).

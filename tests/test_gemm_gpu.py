@@ -79,3 +79,20 @@ def test_gemm_splitk_long_k_deterministic():
     assert_close(c1, dy.double().t() @ x.double(), atol=8e-3, rtol=1e-5)
     c3 = ops.gemm(dyd, xd, a_kcontig=False, b_kcontig=False, splitk=False)
     assert_close(c3, c1, atol=3e-2)      # one 45,000-long fp32 chain vs 86 short ones
+
+
+@pytest.mark.parametrize("n,k,pad", [(7, 3, 0), (129, 16, 0), (300, 37, 3), (301, 300, 0), (1000, 300, 4), (64, 0, 0)])
+def test_gram_is_symmetric_and_matches_gemm(n, k, pad):
+    """snag_gram_f32: upper-triangle tiles + transposed stores.  S == S^T bit for bit; equals the plain GEMM's values."""
+    from snag_amd import ops
+    g = torch.Generator().manual_seed(n * 31 + k)
+    zfull = torch.randn(n, k + pad, generator=g).to(DEV)
+    z = zfull[:, :k] if k else torch.empty(n, 0, device=DEV)
+    s = ops.gram(z, alpha=0.25)
+    assert torch.equal(s, s.t().contiguous())
+    if k:
+        assert_close(s, 0.25 * (z.double().cpu() @ z.double().cpu().t()), atol=1e-5 * max(1.0, k ** 0.5))
+        full = ops.gemm(z, z, alpha=0.25)
+        assert torch.equal(torch.triu(s), torch.triu(full))
+    else:
+        assert float(s.abs().max()) == 0.0
