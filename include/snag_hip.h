@@ -83,6 +83,15 @@ SNAG_API int snag_score_margin_bwd(const float* ent, int64_t ent_ld, int64_t n_e
                           const float* dpos, const float* dneg,
                           float* d_ent, int64_t d_ent_ld, float* d_rel, void* stream);
 
+/* Optional loss epilogue over the scores of snag_score_margin_fwd: self-adversarial negative sampling (SURVEY par. 8 a7; the only
+ * in-tree traces are the unused flags --adv_temp / --emb_dim, config.py:53-54, so PARITY IS UNPINNED: oracle/ref_cpu.py selfadv_loss
+ * restates the published formula).  Lower score = more plausible:
+ *   p_k = softmax_k(-adv_temp * neg[b,k]) (constant),  loss_part[b] = -log sigmoid(margin - pos[b]) - sum_k p_k log sigmoid(neg[b,k] - margin)
+ *   dpos[b] = sigmoid(pos[b] - margin), dneg[b,k] = -p_k sigmoid(margin - neg[b,k])   (either may be NULL); feed them to
+ *   snag_score_margin_bwd in explicit mode. */
+SNAG_API int snag_selfadv_loss(const float* pos, const float* neg, int64_t batch, int n_neg, float margin, float adv_temp,
+                               float* loss_part, float* dpos, float* dneg, void* stream);
+
 /* MKGC link prediction (the "Hits@1/10" half of BASELINE.json's metric; PARITY UNPINNED: the MKGC eval is not in the
  * reference tree).  Score every entity as a candidate tail by calling snag_score_margin_fwd with neg_t == NULL and
  * n_neg == n_ent (candidate k = entity k), then

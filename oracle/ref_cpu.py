@@ -256,6 +256,19 @@ def score_margin(e: Tensor, r: Tensor, h: Tensor, rel: Tensor, t: Tensor, neg_t:
     return loss, pos, neg
 
 
+def selfadv_loss(e: Tensor, r: Tensor, h: Tensor, rel: Tensor, t: Tensor, neg_t: Tensor, margin: float, adv_temp: float):
+    """Self-adversarial negative-sampling loss over the same scores (optional epilogue of SURVEY.md par. 8 a7).
+
+    PARITY UNPINNED: the reference tree only carries the unused flags --adv_temp / --emb_dim (config.py:53-54); this restates the
+    published formula with distances (lower = more plausible): p = softmax(-adv_temp * neg).detach();
+    loss = sum_b [-logsigmoid(margin - pos) - sum_k p_k logsigmoid(neg_k - margin)].  Returns (loss, pos, neg).
+    """
+    _, pos, neg = score_margin(e, r, h, rel, t, neg_t, 0.0)
+    p = torch.softmax(-adv_temp * neg, dim=1).detach()
+    loss = (-torch.nn.functional.logsigmoid(margin - pos) - (p * torch.nn.functional.logsigmoid(neg - margin)).sum(1)).sum()
+    return loss, pos, neg
+
+
 def rank_full_table(e: Tensor, r: Tensor, h: Tensor, rel: Tensor, t: Tensor,
                     filter_mask: Optional[Tensor] = None) -> Tensor:
     """Link-prediction rank of the true tail against all N entities (count-less-than).
@@ -412,7 +425,7 @@ def mkgc_forward(feats: Sequence[Tensor], proj: Sequence[Dict[str, Tensor]], ent
                  num_heads: int, margin: float, joint_way: str = "Mformer_hd_graph",
                  use_intermediate: bool = False, num_layers: int = 1,
                  ent_noise: Optional[Tensor] = None, ent_noise_mask: Optional[Tensor] = None,
-                 mask_ratio: float = 0.0):
+                 mask_ratio: float = 0.0, loss_kind: str = "hinge", adv_temp: float = 1.0):
     """One MKGC hot-path step: projections -> tokens -> Mformer -> read-out -> margin score.
 
     Token order is [modality_0, ..., modality_{P-1}, structural]; the structural token is the
@@ -433,5 +446,8 @@ def mkgc_forward(feats: Sequence[Tensor], proj: Sequence[Dict[str, Tensor]], ent
     toks.append(e)
     joint, joint_fz, hidden, w = fusion_forward(toks, fusion_params, num_heads, num_layers, use_intermediate)
     ent = readout(joint_way, joint, joint_fz, hidden, graph_index=len(toks) - 1)
-    loss, pos, neg = score_margin(ent, rel_table, h, rel, t, neg_t, margin)
+    if loss_kind == "self_adversarial":
+        loss, pos, neg = selfadv_loss(ent, rel_table, h, rel, t, neg_t, margin, adv_temp)
+    else:
+        loss, pos, neg = score_margin(ent, rel_table, h, rel, t, neg_t, margin)
     return loss, pos, neg, ent

@@ -544,6 +544,55 @@ extern "C" SNAG_API int snag_score_margin_bwd(const float* ent, int64_t ent_ld, 
                : launch_bwd<int64_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, d_ent, d_ent_ld, d_rel, st);
 }
 
+namespace snag {
+// Self-adversarial negative-sampling loss over precomputed scores (SURVEY.md par. 8 a7 "pluggable epilogue"; the in-tree hints
+// are the unused flags --adv_temp / --emb_dim, config.py:53-54, and MARGIN=12; PARITY UNPINNED, oracle = its own restatement):
+//   p_k = softmax_k(-adv_temp * neg[b,k])  (treated as a constant),  lower score = more plausible
+//   loss_b = -log sigmoid(margin - pos[b]) - sum_k p_k log sigmoid(neg[b,k] - margin)
+//   dpos[b] = sigmoid(pos - margin),  dneg[b,k] = -p_k sigmoid(margin - neg[b,k])
+// One wave per triple.
+__device__ __forceinline__ float log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void selfadv_loss_kernel(const float* __restrict__ pos, const float* __restrict__ neg, int64_t B, int K,
+                                                           float margin, float adv_temp, float* __restrict__ loss_part,
+                                                           float* __restrict__ dpos, float* __restrict__ dneg) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const float* nb = neg + b * K;
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, -adv_temp * nb[k]);
+    mx = max64(mx);
+    float den = 0.f;
+    for (int k = lane; k < K; k += 64) den += expf(-adv_temp * nb[k] - mx);
+    den = sum64(den);
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float n = nb[k];
+        const float p = expf(-adv_temp * n - mx) / den;
+        acc += p * log_sigmoid(n - margin);
+        if (dneg) dneg[b * K + k] = -p * sigmoid(margin - n);
+    }
+    acc = sum64(acc);
+    if (lane == 0) {
+        const float sp = pos[b];
+        loss_part[b] = -log_sigmoid(margin - sp) - acc;
+        if (dpos) dpos[b] = sigmoid(sp - margin);
+    }
+}
+}  // namespace snag
+
+extern "C" SNAG_API int snag_selfadv_loss(const float* pos, const float* neg, int64_t batch, int n_neg, float margin, float adv_temp,
+                                          float* loss_part, float* dpos, float* dneg, void* stream) {
+    SNAG_REQUIRE(batch >= 0 && n_neg >= 0, SNAG_ERR_ARG, "selfadv_loss: negative size");
+    if (batch == 0) return SNAG_OK;
+    SNAG_REQUIRE(pos && loss_part && (neg || n_neg == 0), SNAG_ERR_ARG, "selfadv_loss: null pointer");
+    hipLaunchKernelGGL(selfadv_loss_kernel, dim3((unsigned)ceil_div(batch, 4)), dim3(256), 0, (hipStream_t)stream, pos, neg, batch, n_neg, margin,
+                       adv_temp, loss_part, dpos, dneg);
+    return check_launch("snag_selfadv_loss");
+}
+
 extern "C" SNAG_API int snag_reduce_sum(const float* x, int64_t n, float* out, void* stream) {
     SNAG_REQUIRE(out && (x || n == 0) && n >= 0, SNAG_ERR_ARG, "reduce_sum: bad arguments (n=%ld)", (long)n);
     hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);

@@ -38,6 +38,8 @@ class MKGCConfig:
     use_intermediate: int = 0
     intermediate_size: int = 400
     margin: float = 12.0                # MARGIN
+    loss: str = "hinge"                 # "hinge" (north_star) | "self_adversarial" (optional a7 epilogue, --adv_temp)
+    adv_temp: float = 1.0
     neg_num: int = 32                   # NEG_NUM
     add_noise: int = 1                  # NOISE
     noise_ratio: float = 0.2
@@ -321,6 +323,13 @@ class MKGCHotPath:
         ib = 4 if h.dtype == torch.int32 else 8
         self._probed("score_fwd", call, "snag_score_margin_fwd", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r),
                      ptr(t), ptr(neg_t), ib, B, K, float(cfg.margin), ptr(self._pos), ptr(self._neg), ptr(self._loss_part), st)
+        if cfg.loss == "self_adversarial":
+            if getattr(self, "_dpos", None) is None or self._dpos.shape[0] != B or self._dneg.shape[1] != K:
+                self._dpos, self._dneg = torch.empty(B, device=self.dev), torch.empty(B, K, device=self.dev)
+            call("snag_selfadv_loss", ptr(self._pos), ptr(self._neg), B, K, float(cfg.margin), float(cfg.adv_temp), ptr(self._loss_part),
+                 ptr(self._dpos), ptr(self._dneg), st)
+        elif cfg.loss != "hinge":
+            raise ValueError(f"unknown loss {cfg.loss!r}")
         call("snag_reduce_sum", ptr(self._loss_part), B, ptr(self.loss), st)
         self._batch = (h, r, t, neg_t, ib, B, K)
         if want_scores:
@@ -352,7 +361,8 @@ class MKGCHotPath:
             self.d_hidden.zero_()
             d_repr, d_ld = self.d_hidden.data_ptr() + 4 * self.g_slot * D, MD
         call("snag_score_margin_bwd", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r), ptr(t), ptr(neg_t),
-             ib, B, K, float(cfg.margin), float(grad_scale), None, None, d_repr, d_ld, ptr(self.g["rel"]), st)
+             ib, B, K, float(cfg.margin), float(grad_scale), *((ptr(self._dpos), ptr(self._dneg)) if cfg.loss == "self_adversarial" else (None, None)),
+             d_repr, d_ld, ptr(self.g["rel"]), st)
         if cfg.joint_way == "Mformer_hd_mean":
             call("snag_token_mean_bwd", ptr(self.d_repr), N, M, D, ptr(self.d_hidden), st)
         call("snag_fusion_bwd", ctypes.byref(self._bdesc), st)

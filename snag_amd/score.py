@@ -45,6 +45,36 @@ class _MarginLossFn(torch.autograd.Function):
         return d_ent, d_rel, None, None, None, None, None
 
 
+class _SelfAdvLossFn(torch.autograd.Function):
+    """(ent, rel) -> scalar self-adversarial loss; the epilogue kernel emits d loss / d scores, the scorer's explicit backward does the rest."""
+
+    @staticmethod
+    def forward(ctx, ent, rel, h, r, t, neg_t, margin, adv_temp):
+        from ._lib import call, ptr, stream
+        pos, neg, _ = ops.score_margin_fwd(ent, rel, h, r, t, neg_t, 0.0, want_loss=False)
+        B, K = neg.shape
+        part = torch.empty(B, device=ent.device, dtype=torch.float32)
+        dpos, dneg = torch.empty_like(pos), torch.empty_like(neg)
+        call("snag_selfadv_loss", ptr(pos), ptr(neg), B, K, float(margin), float(adv_temp), ptr(part), ptr(dpos), ptr(dneg), stream())
+        ctx.save_for_backward(ent, rel, h, r, t, neg_t, dpos, dneg)
+        ctx.mark_non_differentiable(pos, neg)
+        return ops.reduce_sum(part), pos, neg
+
+    @staticmethod
+    def backward(ctx, dloss, _dp, _dn):
+        ent, rel, h, r, t, neg_t, dpos, dneg = ctx.saved_tensors
+        d_ent, d_rel = ops.score_margin_bwd(ent, rel, h, r, t, neg_t, 0.0, float(dloss), dpos=dpos, dneg=dneg)
+        return d_ent, d_rel, None, None, None, None, None, None
+
+
+def self_adversarial_loss(ent, rel, h, r, t, neg_t, margin, adv_temp=1.0):
+    """sum_b [-log sigmoid(margin - s_pos) - sum_k softmax_k(-adv_temp s_neg)_k log sigmoid(s_neg_k - margin)] -> (loss, pos, neg).
+
+    The optional epilogue of SURVEY.md par. 8 a7 (``--adv_temp``, config.py:54); parity unpinned, see include/snag_hip.h.
+    """
+    return _SelfAdvLossFn.apply(ent, rel, h, r, t, neg_t, float(margin), float(adv_temp))
+
+
 def score(ent, rel, h, r, t, neg_t=None):
     """s(h,r,t) and s(h,r,neg_t[b,k]) (TransE, squared L2 on L2-normalised rows).  Differentiable."""
     return _MarginScoreFn.apply(ent, rel, h, r, t, neg_t)

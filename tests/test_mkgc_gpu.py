@@ -42,6 +42,7 @@ def oracle_params(eng):
     return p, proj, fp
 
 
+@pytest.mark.parametrize("loss_kind", ["hinge", "self_adversarial"])
 @pytest.mark.parametrize("num_proj,joint_way,ffn,noise,idt,shape", [
     (2, "Mformer_hd_graph", 0, False, torch.int32, (700, 23, 128, 96, 32, 200, 72)),
     (1, "Mformer_hd_mean", 0, False, torch.int64, (700, 23, 128, 96, 32, 200, 72)),
@@ -51,11 +52,12 @@ def oracle_params(eng):
     (2, "Mformer_hd_graph", 0, True, torch.int32, (701, 5, 100, 33, 5, 37, 10)),
     (1, "Mformer_hd_mean", 1, False, torch.int64, (333, 3, 36, 17, 3, 13, 9)),
 ])
-def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape):
+def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape, loss_kind):
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
     N, R, D, B, K, F0, F1 = shape
     cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[F0, F1], num_proj=num_proj, joint_way=joint_way,
-                     use_intermediate=ffn, intermediate_size=96, margin=6.0, neg_num=K, dropout=0.0, add_noise=int(noise), seed=7)
+                     use_intermediate=ffn, intermediate_size=96, margin=6.0, neg_num=K, dropout=0.0, add_noise=int(noise), seed=7,
+                     loss=loss_kind, adv_temp=0.7)
     g = torch.Generator().manual_seed(99)
     feats = [torch.rand(N, F0, generator=g), torch.randn(N, F1, generator=g)]
     eng = MKGCHotPath(cfg, feats, device=DEV)
@@ -78,7 +80,7 @@ def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape):
         ofeats, proj, p["ent"], fp, p["rel"], h, r, t, neg, num_heads=cfg.num_heads, margin=cfg.margin, joint_way=joint_way,
         use_intermediate=bool(ffn), num_layers=cfg.num_layers,
         ent_noise=eng.ent_noise.cpu() if noise else None, ent_noise_mask=eng.ent_noise_mask.cpu().bool() if noise else None,
-        mask_ratio=cfg.mask_ratio)
+        mask_ratio=cfg.mask_ratio, loss_kind=loss_kind, adv_temp=cfg.adv_temp)
     oloss.backward()
     assert_close(pos, opos, atol=1e-4, what="pos")                      # north_star: scores within 1e-4
     assert_close(ng, oneg, atol=1e-4, what="neg")

@@ -66,6 +66,26 @@ def test_score_bwd_explicit_mode():
     assert_close(dr, r_.grad, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("K,B,margin,temp", [(32, 257, 12.0, 1.0), (5, 33, 2.0, 0.5), (70, 19, 6.0, 2.0), (1, 9, 1.0, 1.0)])
+def test_self_adversarial_loss_vs_oracle(K, B, margin, temp):
+    """Optional a7 epilogue (parity unpinned: the oracle restates the published formula)."""
+    from snag_amd.score import self_adversarial_loss
+    ent, rel, h, r, t, neg = _mk(400, 11, 128, B, K, seed=K * 7 + B)
+    e_ = ent.clone().requires_grad_(True)
+    r_ = rel.clone().requires_grad_(True)
+    loss, pos, ng = O.selfadv_loss(e_, r_, h, r, t, neg, margin, temp)
+    loss.backward()
+    eg = ent.to(DEV).requires_grad_(True)
+    rg = rel.to(DEV).requires_grad_(True)
+    lg, pg, ngg = self_adversarial_loss(eg, rg, h.to(DEV), r.to(DEV), t.to(DEV), neg.to(DEV), margin, temp)
+    lg.backward()
+    assert_close(pg, pos.detach(), atol=1e-5)
+    assert_close(ngg, ng.detach(), atol=1e-5)
+    assert_close(lg, loss.detach(), atol=1e-3, rtol=1e-5, what="loss")
+    assert_close(eg.grad, e_.grad, atol=1e-4, rtol=1e-4, what="d_ent")
+    assert_close(rg.grad, r_.grad, atol=1e-4, rtol=1e-4, what="d_rel")
+
+
 def test_score_golden_intree_kge():
     """golden G3: MSNEA.kge term 1 (model/MSNEA.py:110-122), head-or-tail corruption, one negative per positive."""
     from snag_amd.score import kge_relation_loss
