@@ -18,6 +18,8 @@ Vectors (SURVEY.md par. 8c):
   g7_encoder.npz     MultiModalEncoder.forward (projections + entity noise blend + fusion), GAT stubbed to identity
   g9_gat.npz         GAT(diag=True) structural encoder (model/layers.py:35-100, model/Tool_model.py:61-94), output and grads
   g10_snag_model.npz the whole in-tree SNAG model: SNAG.forward/update_noise/joint_emb_generat (model/SNAG.py) loss + grads
+  g11_data.npz       dataset readers on a tiny synthetic DBP15K-layout directory: read_raw_data / load_relation / load_attr / load_img /
+                     get_adjr / load_eva_data (src/data.py, src/utils.py:327-362); the fixture holds the synthetic files and the outputs
   g8_icl_loss.npz    icl_loss (bidirectional InfoNCE, model/SNAG_loss.py:31-128) + CustomMultiLossLayer, loss and grads
 """
 import csv
@@ -531,7 +533,75 @@ def gen_g10():
     save("g10_snag_model.npz", d)
 
 
+def gen_g11():
+    import pickle
+    import src.data as ref_data
+    from src.utils import get_adjr
+    rng = np.random.RandomState(2024)
+    n1, n2, n_rel, F = 40, 45, 12, 16
+    N = n1 + n2
+    files = {}
+    files["ent_ids_1"] = "".join(f"{i}\thttp://kg1/e{i}\n" for i in range(n1))
+    files["ent_ids_2"] = "".join(f"{i}\thttp://kg2/e{i}\n" for i in range(n1, N))
+
+    def triples(lo, hi, n):
+        rows = []
+        for _ in range(n):
+            h, t = rng.randint(lo, hi, 2)
+            rows.append((h, rng.randint(0, n_rel) if rng.rand() < 0.8 else 3, t))     # relation 3 is frequent, some h == t occur
+        rows += [(rows[0][2], rows[0][1], rows[0][0]), rows[1], rows[1]]               # a reverse pair and duplicates
+        return "".join(f"{h}\t{r}\t{t}\n" for h, r, t in rows)
+    files["triples_1"] = triples(0, n1, 150)
+    files["triples_2"] = triples(n1, N, 160)
+    left = rng.permutation(n1)[:30]
+    right = n1 + rng.permutation(n2)[:30]
+    files["ill_ent_ids"] = "".join(f"{a}\t{b}\n" for a, b in zip(left, right))
+    for k, (lo, hi, tag) in enumerate(((0, n1, "kg1"), (n1, N, "kg2")), 1):
+        lines = []
+        for i in range(lo, hi):
+            if rng.rand() < 0.85:
+                attrs = [f"attr{a}" for a in rng.randint(0, 30, rng.randint(1, 9))]
+                lines.append("\t".join([f"http://{tag}/e{i}"] + attrs))
+        lines.append("http://elsewhere/unknown\tattr1\tattr2")                       # a name that is not in ent2id
+        files[f"training_attrs_{k}"] = "\n".join(lines) + "\n"
+    img_ids = rng.permutation(N)[:60]
+    img_vecs = rng.randn(60, F).astype(np.float32)
+
+    with tempfile.TemporaryDirectory() as root:
+        file_dir = os.path.join(root, "DBP15K", "zh_en")
+        os.makedirs(file_dir)
+        os.makedirs(os.path.join(root, "pkls"))
+        for name, text in files.items():
+            with open(os.path.join(file_dir, name), "w", encoding="utf-8") as f:
+                f.write(text)
+        with open(os.path.join(root, "pkls", "zh_en_GA_id_img_feature_dict.pkl"), "wb") as f:
+            pickle.dump({int(i): v for i, v in zip(img_ids, img_vecs)}, f)
+        ent2id, ills, tri, r_hs, r_ts, ids = ref_data.read_raw_data(file_dir, [1, 2])
+        d = {"file_names": np.array(sorted(files)), "img_ids": img_ids, "img_vecs": img_vecs,
+             "raw_ills": np.array(ills), "raw_triples": np.array(tri), "n_rel": len(r_hs),
+             "ent_names": np.array(sorted(ent2id)), "ent_ids": np.array([ent2id[k] for k in sorted(ent2id)]),
+             "left_ids": np.array(ref_data.get_ids(os.path.join(file_dir, "ent_ids_1")))}
+        for name in files:
+            d["file." + name] = np.frombuffer(files[name].encode("utf-8"), dtype=np.uint8)
+        adj0 = get_adjr(N, tri, norm=False)
+        d["adj0_indices"], d["adj0_values"] = adj0._indices(), adj0._values()
+        args = types.SimpleNamespace(data_path=root, data_choice="DBP15K", data_split="zh_en", ratio="1.0", data_rate=0.3, word_embedding="glove",
+                                     w_name=0, w_char=0, unsup=0)
+        np.random.seed(123)
+        kgs, non_train, train_ds, test_ds, eval_ill, test_ill_ = ref_data.load_eva_data(logging.getLogger("g11"), args)
+        d.update({"seed": 123, "data_rate": 0.3, "ent_num": kgs["ent_num"], "rel_num": kgs["rel_num"], "images_list": kgs["images_list"],
+                  "rel_features": kgs["rel_features"], "att_features": kgs["att_features"], "ent_wo_img": np.array(kgs["ent_wo_img"]),
+                  "ent_w_img": np.array(kgs["ent_w_img"]), "adj_indices": kgs["adj"]._indices(), "adj_values": kgs["adj"]._values(),
+                  "train_ill": kgs["train_ill"], "test_ill": np.array(test_ill_), "left_non_train": np.array(non_train["left"]),
+                  "right_non_train": np.array(non_train["right"]), "input_idx": kgs["input_idx"]})
+    save("g11_data.npz", d)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:          # regenerate selected vectors only: gen_golden.py g11 g8 ...
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
     gen_g1()
     gen_g2()
     gen_g3()
