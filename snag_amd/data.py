@@ -39,6 +39,16 @@ class EADataset(torch.utils.data.Dataset):
         return self.data[index]
 
 
+class Collator_base(object):
+    """DataLoader collate_fn: a batch of pairs -> one int array [B, 2] (src/data.py:37-44)."""
+
+    def __init__(self, args):
+        self.args = args
+
+    def __call__(self, batch):
+        return np.array(batch)
+
+
 def _int_rows(path, ncols=None):
     rows = []
     with open(path, "r", encoding="utf-8") as f:

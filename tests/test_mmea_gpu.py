@@ -86,8 +86,8 @@ def test_snag_model_trains_and_evaluates():
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
-        first = float(loss) if first is None else first
-    assert float(loss) < first
+        first = float(loss.detach()) if first is None else first
+    assert float(loss.detach()) < first
     model.eval()
     with torch.no_grad():
         final, _ = model.joint_emb_generat()
@@ -98,3 +98,55 @@ def test_snag_model_trains_and_evaluates():
     assert res["hits_l2r"][1] > 0.5                     # training pairs rank well after training on them
     links = model.Iter_new_links(4, left.cpu().tolist(), final, right.cpu().tolist(), new_links=[])
     assert len(links) > 0 and all(len(p) == 2 for p in links)
+
+
+def test_dataset_directory_to_trained_model(tmp_path):
+    """SURVEY 8(f) #4 end to end: a DBP15K-layout directory (golden G11's synthetic files) -> snag_amd.data.load_data -> the HIP SNAG model ->
+    optimiser steps through a DataLoader with the reference's collator -> checkpoint round trip -> eval on the test split."""
+    import logging
+    import os
+    import pickle
+    from snag_amd import data as D, evalsim
+    from snag_amd.mmea import SNAG, normalize_rows
+    z = load("g11_data.npz")
+    root = str(tmp_path)
+    file_dir = os.path.join(root, "DBP15K", "zh_en")
+    os.makedirs(file_dir)
+    os.makedirs(os.path.join(root, "pkls"))
+    for name in z["file_names"]:
+        with open(os.path.join(file_dir, str(name)), "wb") as f:
+            f.write(z["file." + str(name)].tobytes())
+    with open(os.path.join(root, "pkls", "zh_en_GA_id_img_feature_dict.pkl"), "wb") as f:
+        pickle.dump({int(i): v for i, v in zip(z["img_ids"], z["img_vecs"])}, f)
+    args = snag_args(32)
+    args.__dict__.update(data_path=root, data_choice="DBP15K", data_split="zh_en", ratio="1.0", data_rate=0.3, word_embedding="glove", unsup=0,
+                         batch_size=8, intermediate_size=48)
+    np.random.seed(int(z["seed"]))
+    kgs, non_train, train_set, test_set, _, test_ill_ = D.load_data(logging.getLogger("t"), args)
+    model = SNAG(kgs, args, device=DEV)
+    model.noise_mode = "philox"
+    loader = torch.utils.data.DataLoader(train_set, batch_size=args.batch_size, shuffle=False, collate_fn=D.Collator_base(args))
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-3)
+    model.train()
+    losses = []
+    for epoch in range(6):
+        model.update_noise(seed=epoch)
+        tot = 0.0
+        for batch in loader:
+            loss, _ = model(batch)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            tot += float(loss.detach())
+        losses.append(tot)
+    assert losses[-1] < losses[0], losses
+    path = D.save_model(model, os.path.join(root, "SNAG", "save", "m.pkl"))
+    clone = SNAG(kgs, args, device=DEV)
+    D.load_model(clone, path, map_location=DEV)
+    model.eval(), clone.eval()
+    with torch.no_grad():
+        fa, fb = normalize_rows(model.joint_emb_generat()[0]), normalize_rows(clone.joint_emb_generat()[0])
+        assert torch.equal(fa, fb)
+        test = np.array(test_ill_)
+        res = evalsim.rank_metrics(fa[T(test[:, 0].astype(np.int64), DEV)].contiguous(), fa[T(test[:, 1].astype(np.int64), DEV)].contiguous(), csls_k=3)
+    assert 0.0 <= res["hits_l2r"][0] <= 1.0 and res["mr_l2r"] >= 1.0
