@@ -352,7 +352,7 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, [f.cpu() for f in feats], args.batch, args.cpu_seconds, cfg.seed)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

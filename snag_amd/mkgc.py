@@ -337,16 +337,23 @@ class MKGCHotPath:
         return self.loss
 
     def grad_buckets(self):
-        """Two contiguous slices of the flat gradient buffer in the order the backward finishes them: the entity table
-        (most of the bytes; final right after the fusion backward) and everything else (final after the projection backward)."""
-        end = self.slices["rel"][0]
-        return self.gflat[:end], self.gflat[end:]
+        """Contiguous slices of the flat gradient buffer in the order the backward finishes them:
+        [entity + relation tables] and [fusion parameters] (both final right after the fusion backward), then one slice per
+        modality's projection weights (final after that modality's backward GEMMs; the 4096-wide visual one comes first so its
+        2 MB exchange hides behind the remaining modalities' GEMMs)."""
+        first_proj = self.slices["proj0.weight" if self.cfg.num_proj == 1 else "proj0.l1"][0]
+        fusion0 = self.slices["weight_raw"][0]
+        out = [self.gflat[:first_proj], self.gflat[fusion0:]]
+        starts = [self.slices[f"proj{i}.weight" if self.cfg.num_proj == 1 else f"proj{i}.l1"][0] for i in range(len(self.cfg.feat_dims))] + [fusion0]
+        out += [self.gflat[starts[i]:starts[i + 1]] for i in range(len(self.cfg.feat_dims))]
+        return out
 
     def backward(self, grad_scale=1.0, reducer=None):
         """Gradient of grad_scale * loss w.r.t. every parameter, written (not added) into the flat gradient buffer.
 
-        ``reducer`` (snag_amd.parallel.GradAllReduce) gets ``start(bucket)`` as soon as a bucket is final, so that the
-        all-reduce of the 7.7 MB entity-table gradient overlaps the projection backward GEMMs; ``finish()`` is the caller's."""
+        ``reducer`` (snag_amd.parallel.GradAllReduce) gets ``start(bucket)`` as soon as a bucket is final (see grad_buckets), so
+        that the exchange of the 7.7 MB entity-table gradient overlaps the projection backward GEMMs and only the last, smallest
+        modality's weights are exchanged after the compute has finished; ``finish()`` is the caller's."""
         cfg = self.cfg
         N, D, M = cfg.n_ent, cfg.dim, cfg.n_tokens
         st = self._st
@@ -370,8 +377,10 @@ class MKGCHotPath:
         wk = ptr(self.work)
         call("snag_entity_token_bwd", dx0 + 4 * self.g_slot * D, MD, N, D, ptr(self.ent_noise_mask) if noisy else None,
              float(cfg.mask_ratio) * 0.5, ptr(self.g["ent"]), 0, st)
+        buckets = self.grad_buckets() if reducer is not None else None
         if reducer is not None:
-            reducer.start(self.grad_buckets()[0])
+            reducer.start(buckets[0])
+            reducer.start(buckets[1])
         for i, fd in enumerate(cfg.feat_dims):
             feat = self.noisy[i] if noisy else self.feats[i]
             dslot = dx0 + 4 * i * D
@@ -384,8 +393,8 @@ class MKGCHotPath:
                 # d mid = (dTok l2) * [mid > 0]
                 self._gemm(N, D, D, dslot, MD, 1, ptr(self.p[f"proj{i}.l2"]), D, 0, ptr(self.d_mid), D, act=4, aux=ptr(self.mid[i]), ldaux=D)
                 self._gemm(fd, D, N, ptr(feat), fd, 0, ptr(self.d_mid), D, 0, ptr(self.g[f"proj{i}.l1"]), D, splitk=True)   # dl1^T [fd, D]
-        if reducer is not None:
-            reducer.start(self.grad_buckets()[1])
+            if reducer is not None:
+                reducer.start(buckets[2 + i])
 
     def optimizer_step(self, grad_scale=1.0):
         cfg = self.cfg

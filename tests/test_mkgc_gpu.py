@@ -142,3 +142,32 @@ def test_mkgc_hits_at_k_equal_oracle():
         ref_hits = round(float((oref < k).float().mean()), 4)
         assert abs(hk - ref_hits) <= float((near > 0).float().mean()) + 1e-9, (k, hk, ref_hits)
     assert res["hits"][1] > 0.2          # training on these triples must have made them rank well
+
+
+@pytest.mark.parametrize("num_proj", [1, 2])
+def test_grad_buckets_partition_the_flat_buffer(num_proj):
+    """The overlapped gradient exchange walks grad_buckets(): together they must cover every gradient exactly once."""
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    cfg = MKGCConfig(n_ent=300, n_rel=7, dim=64, feat_dims=[40, 24, 12], num_proj=num_proj, use_intermediate=1, intermediate_size=32)
+    eng = MKGCHotPath(cfg, [torch.rand(300, f) for f in cfg.feat_dims], device=DEV)
+    spans = sorted((b.data_ptr(), b.numel()) for b in eng.grad_buckets())
+    assert len(spans) == 2 + len(cfg.feat_dims)
+    assert spans[0][0] == eng.gflat.data_ptr()
+    for (p0, n0), (p1, _) in zip(spans, spans[1:]):
+        assert p0 + 4 * n0 == p1
+    assert sum(n for _, n in spans) == eng.n_params
+
+    class Recorder:
+        def __init__(self):
+            self.seen = []
+
+        def start(self, b):
+            self.seen.append((b.data_ptr(), b.numel()))
+
+        def finish(self):
+            pass
+    rec = Recorder()
+    g = torch.Generator().manual_seed(0)
+    idx = [torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(DEV) for hi, sz in ((300, (16,)), (7, (16,)), (300, (16,)), (300, (16, 32)))]
+    eng.train_step(*idx, allreduce=rec)
+    assert sorted(rec.seen) == spans
