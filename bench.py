@@ -90,7 +90,7 @@ def roofline_dominant(cfg, timer):
             traffic, src = pmc["fetch_bytes"] + pmc["write_bytes"], pmc["source"]
     except (OSError, KeyError, ValueError):
         pass
-    return {"kernel": f"gemm_tile_kernel (visual projection: [{cfg.n_ent},{cfg.feat_dims[0]}]x[{cfg.feat_dims[0]},{cfg.dim}], exact-f32 MFMA)",
+    return {"kernel": f"gemm_streamk_kernel<64,128,..> (visual projection: [{cfg.n_ent},{cfg.feat_dims[0]}]x[{cfg.feat_dims[0]},{cfg.dim}], exact-f32 MFMA)",
             "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
             "traffic": traffic, "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC)", "traffic_source": src,
             "algorithmic_bytes_per_launch": 4 * (cfg.n_ent * cfg.feat_dims[0] + cfg.feat_dims[0] * cfg.dim + cfg.n_ent * cfg.dim),

@@ -149,6 +149,52 @@ static void launch_cfg(const GemmOperands& p, const Epilogue& e, float* slab, in
 #undef SNAG_GEMM
 }
 
+static int streamk_blocks() { static const int v = env_int("SNAG_GEMM_SK_BLOCKS"); return v > 0 ? v : 1024; }   // 4 per CU
+static int streamk_mode() { static const int v = env_int("SNAG_GEMM_SK"); return v; }                          // tuning: 1 = never, 2 = whenever splitting
+
+struct StreamKChoice {
+    int G;
+    StreamKPlan plan;
+    int64_t slab_floats;
+};
+// G persistent blocks over tiles x nkt iterations; each block keeps at least kMinKTiles iterations
+static StreamKChoice plan_streamk(int M, int N, int K, int BM, int BN) {
+    StreamKChoice c;
+    const int tiles_m = ceil_div(M, BM);
+    c.plan.tiles_n = ceil_div(N, BN);
+    c.plan.nkt = ceil_div(K, kBK);
+    c.plan.total = (int64_t)tiles_m * c.plan.tiles_n * c.plan.nkt;
+    int64_t G = streamk_blocks();
+    while (G > 256 && c.plan.total / G < 16) G -= 256;
+    c.G = (int)std::min<int64_t>(G, std::max<int64_t>(1, c.plan.total));
+    const int64_t len = ceil_div(c.plan.total, (int64_t)c.G);
+    c.plan.max_seg = (int)(ceil_div(len, (int64_t)c.plan.nkt) + 1);
+    c.slab_floats = (int64_t)c.G * c.plan.max_seg * BM * BN;
+    return c;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_streamk(const GemmOperands& p, const Epilogue& e, float* slab, const StreamKChoice& c, bool a_kc, bool b_kc, hipStream_t st) {
+    const bool legal = p.a_vec && p.b_vec && (a_kc || p.M % 4 == 0) && (b_kc || p.N % 4 == 0) && p.M >= 4 && p.N >= 4;
+    const bool vec = legal && !(a_kc && b_kc);
+    dim3 grid(c.G), block(256);
+#define SNAG_SK(AK, BK_)                                                                                                           \
+    do {                                                                                                                           \
+        if (vec) hipLaunchKernelGGL((gemm_streamk_kernel<BM, BN, WM, WN, AK, BK_, true, Epilogue>), grid, block, 0, st, p, e, slab, c.plan);  \
+        else hipLaunchKernelGGL((gemm_streamk_kernel<BM, BN, WM, WN, AK, BK_, false, Epilogue>), grid, block, 0, st, p, e, slab, c.plan);     \
+    } while (0)
+    if (a_kc && b_kc) SNAG_SK(true, true);
+    else if (a_kc && !b_kc) SNAG_SK(true, false);
+    else if (!a_kc && b_kc) SNAG_SK(false, true);
+    else SNAG_SK(false, false);
+#undef SNAG_SK
+    int rc = check_launch("snag_gemm_f32(stream-K)");
+    if (rc) return rc;
+    const int tiles = ceil_div(p.M, BM) * c.plan.tiles_n;
+    hipLaunchKernelGGL((streamk_fixup_kernel<BM, BN, Epilogue>), dim3(tiles, BM * BN / 1024), dim3(256), 0, st, (const float*)slab, e, c.plan, c.G);
+    return check_launch("snag_gemm_f32(stream-K fix-up)");
+}
+
 // Split K when the output tiles alone leave the chip under-filled: with one 4-wave block per CU only one
 // 12-16 KB tile is in flight per CU and the loop runs at HBM latency, not bandwidth; ~4 co-resident
 // blocks per CU hide it.  Each split keeps at least kMinKTiles k-tiles of work.
@@ -162,6 +208,7 @@ static int pick_splits(int64_t tiles, int K, bool both_kc = false) {
     return (int)std::min(want, cap);
 }
 
+static int log_shapes() { static const int v = env_int("SNAG_GEMM_LOG"); return v; }          // tuning: one line per launch on stderr
 static int force_tile() { static const int v = env_int("SNAG_GEMM_TILE"); return v; }        // tuning hooks: 1 = 64x128, 2 = 128x128, 3 = 128x160
 static int force_splits() { static const int v = env_int("SNAG_GEMM_SPLITS"); return v; }
 
@@ -169,7 +216,8 @@ int64_t gemm_workspace_floats(int M, int N, int K) {
     // the largest fan-out any tile configuration may pick for this shape (the dispatcher clamps to what it is given)
     const int64_t t64 = (int64_t)ceil_div(M, 64) * ceil_div(N, 128), t160 = (int64_t)ceil_div(M, 128) * ceil_div(N, 160);
     const int splits = force_splits() > 0 ? force_splits() : std::max(pick_splits(t64, K), pick_splits(t160, K));
-    return splits > 1 ? (int64_t)splits * M * N : 0;
+    const int64_t sk = plan_streamk(M, N, K, 64, 128).slab_floats;
+    return splits > 1 ? std::max((int64_t)splits * M * N, sk) : 0;
 }
 
 int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
@@ -213,12 +261,25 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
         if (splits > cap) splits = (int)cap;
         if (splits < 1) splits = 1;
     }
+    if (splits > 1 && !big && !wide && streamk_mode() != 1) {
+        // blocks per CU of the split grid vs what the slowest CU gets
+        const double per_cu = (double)tiles * splits / 256.0;
+        const double balance = per_cu / std::ceil(per_cu);
+        const StreamKChoice c = plan_streamk(p.M, p.N, p.K, 64, 128);
+        // few tiles shared by many blocks (the dW shapes) keep split-K: their slabs reduce in parallel over the whole output
+        if ((balance < 0.95 || streamk_mode() == 2) && c.G >= 256 && tiles * 8 >= c.G && c.slab_floats <= d->workspace_floats) {
+            p.k_per_split = 0;
+            if (log_shapes())
+                fprintf(stderr, "snag_gemm M=%d N=%d K=%d a_kc=%d b_kc=%d tile=64x128 streamk=%d fast=%d acc=%d\n", p.M, p.N, p.K, (int)d->a_kcontig,
+                        (int)d->b_kcontig, c.G, (int)e.fast, (int)d->accumulate);
+            return launch_streamk<64, 128, 32, 64>(p, e, d->workspace, c, d->a_kcontig, d->b_kcontig, st);
+        }
+    }
     const int kps = ceil_div(ceil_div(p.K, splits), kBK) * kBK;
     splits = ceil_div(p.K, kps);
     p.k_per_split = kps;
     float* slab = splits > 1 ? d->workspace : nullptr;
-    static const int log_shapes = env_int("SNAG_GEMM_LOG");    // tuning: one line per launch on stderr
-    if (log_shapes)
+    if (log_shapes())
         fprintf(stderr, "snag_gemm M=%d N=%d K=%d a_kc=%d b_kc=%d tile=%s splits=%d fast=%d acc=%d\n", p.M, p.N, p.K, (int)d->a_kcontig,
                 (int)d->b_kcontig, wide ? "128x160" : big ? "128x128" : "64x128", splits, (int)e.fast, (int)d->accumulate);
     if (wide) launch_cfg<128, 160, 32, 160>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);

@@ -504,4 +504,60 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmOperands p, Epi epi,
     }
 }
 
+// Stream-K: G persistent blocks share the (tile, k-tile) iteration space evenly, so every CU gets the same MFMA work whatever
+// tiles x splits would have been modulo the CU count (235 tiles x 5 splits = 4.59 blocks per CU otherwise runs at the pace of
+// the CUs that got 5).  Block b owns iterations [total*b/G, total*(b+1)/G) of the tile-major order; a tile it covers completely
+// goes straight through the epilogue, a partial one is parked as a raw BM x BN tile in slab[(b*max_seg + seg)] and summed in
+// block order by streamk_fixup_kernel (deterministic).
+struct StreamKPlan {
+    int tiles_n;        // output tiles along N
+    int nkt;            // k-tiles per output tile
+    int64_t total;      // tiles * nkt
+    int max_seg;        // slab slots per block
+};
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
+__global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmOperands p, Epi epi, float* __restrict__ slab, StreamKPlan plan) {
+    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
+    __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
+    const int64_t G = gridDim.x, b = blockIdx.x;
+    int64_t it = plan.total * b / G;
+    const int64_t it_end = plan.total * (b + 1) / G;
+    Core core;
+    for (int seg = 0; it < it_end; ++seg) {
+        const int tile = (int)(it / plan.nkt), kt0 = (int)(it % plan.nkt);
+        const int kt1 = (int)min<int64_t>(plan.nkt, kt0 + (it_end - it));
+        const int m0 = (tile / plan.tiles_n) * BM, n0 = (tile % plan.tiles_n) * BN;
+        core.run(p, smem, m0, n0, kt0 * kBK, min(p.K, kt1 * kBK));
+        if (kt0 == 0 && kt1 == plan.nkt) {
+            core.for_each(smem, m0, n0, epi);
+        } else {
+            float* dst = slab + ((int64_t)b * plan.max_seg + seg) * (BM * BN);
+            core.for_each(smem, m0, n0, [=](int m, int n, float4 v) { *reinterpret_cast<float4*>(dst + (m - m0) * BN + (n - n0)) = v; });
+        }
+        it += kt1 - kt0;
+        __syncthreads();        // the staging area of for_each is the next segment's tile buffer
+    }
+}
+
+// gridDim.y blocks per output tile: sum the parked partial tiles of the blocks that touched it (ascending block index) and run the epilogue.
+template <int BM, int BN, class Epi>
+__global__ __launch_bounds__(256) void streamk_fixup_kernel(const float* __restrict__ slab, Epi epi, StreamKPlan plan, int G) {
+    const int tile = blockIdx.x;
+    const int64_t i0 = (int64_t)tile * plan.nkt, i1 = i0 + plan.nkt - 1;
+    const int b_first = (int)(((i0 + 1) * G + plan.total - 1) / plan.total) - 1;
+    const int b_last = (int)(((i1 + 1) * G + plan.total - 1) / plan.total) - 1;
+    if (b_first == b_last) return;       // one block covered the whole tile and already ran the epilogue
+    const int m0 = (tile / plan.tiles_n) * BM, n0 = (tile % plan.tiles_n) * BN;
+    for (int q = blockIdx.y * 256 + threadIdx.x; q < BM * BN / 4; q += 256 * gridDim.y) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = b_first; b <= b_last; ++b) {
+            const int seg = tile - (int)((plan.total * b / G) / plan.nkt);
+            const float4 v = reinterpret_cast<const float4*>(slab + ((int64_t)b * plan.max_seg + seg) * (BM * BN))[q];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        epi(m0 + (q * 4) / BN, n0 + (q * 4) % BN, acc);
+    }
+}
+
 }  // namespace snag

@@ -80,7 +80,16 @@ class MKGCHotPath:
         # operands K-contiguous it measures 81 TF; with both row-contiguous (X^T [F, N], W^T [F, D]) the LDS-DMA loop
         # reaches 93 TF, so the engine keeps a transposed copy of each (static / once-per-epoch) feature table and
         # stores that weight transposed.  The weight gradient dW^T = X^T-shaped product needs no extra copy.
-        self.feats_t = [f.t().contiguous() for f in self.feats]
+        # Rows of the transposed copies are padded to a multiple of 32 floats: with N = 15000 a row is 60,000 B, not a multiple of
+        # the 128-B line, so every 256-B tile segment would straddle three lines instead of two (PMC: 1.7x the algorithmic fetch).
+        self.ld_t = _align(N, 32)
+
+        def transposed(f):
+            buf = torch.zeros(f.shape[1], self.ld_t, device=self.dev, dtype=f32)
+            buf[:, :N].copy_(f.t())
+            return buf[:, :N]
+        self._transposed = transposed
+        self.feats_t = [transposed(f) for f in self.feats]
         self.g_slot = M - 1                                   # structural token last
         I, L, ffn = cfg.intermediate_size, cfg.num_layers, bool(cfg.use_intermediate)
 
@@ -145,7 +154,7 @@ class MKGCHotPath:
         self.tick = torch.zeros(1, device=dev, dtype=torch.int64)      # device-side step counter
         # noise state (model/SNAG.py:86-98)
         self.noisy = [f.clone() for f in self.feats]
-        self.noisy_t = [f.clone() for f in self.feats_t]
+        self.noisy_t = [self._transposed(f) for f in self.feats]
         self.feat_stats = None
         self.ent_noise = torch.zeros(N, D, device=dev)
         self.ent_noise_mask = torch.zeros(N, device=dev, dtype=torch.uint8)
@@ -296,10 +305,10 @@ class MKGCHotPath:
             slot = x0p + 4 * i * D
             tag = "proj_l1_fwd" if i == 0 else ""
             if cfg.num_proj == 1:
-                self._probed(tag, self._gemm, N, D, fd, ptr(feat_t), N, 0, ptr(self.p[f"proj{i}.weight"]), D, 0, slot, MD,
+                self._probed(tag, self._gemm, N, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.weight"]), D, 0, slot, MD,
                              bias=ptr(self.p[f"proj{i}.bias"]))
             else:   # ProjectionHead: Linear(no bias) -> ReLU -> Linear(no bias)   (model/layers.py:135-148)
-                self._probed(tag, self._gemm, N, D, fd, ptr(feat_t), N, 0, ptr(self.p[f"proj{i}.l1"]), D, 0, ptr(self.mid[i]), D, act=1)
+                self._probed(tag, self._gemm, N, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.l1"]), D, 0, ptr(self.mid[i]), D, act=1)
                 self._gemm(N, D, D, ptr(self.mid[i]), D, 1, ptr(self.p[f"proj{i}.l2"]), D, 1, slot, MD)
         call("snag_entity_token_fwd", ptr(self.p["ent"]), N, D, ptr(self.ent_noise) if noisy else None,
              ptr(self.ent_noise_mask) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD, st)
