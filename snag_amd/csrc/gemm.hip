@@ -58,18 +58,50 @@ struct Epilogue {
     __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
         if (m >= M || n >= N) return;
         if (fast && n + 3 < N) {
-            // fast: only bias / relu / one residual, 16-byte aligned rows (decided on the host)
-            v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+            // every operand present is 16-byte addressable (decided on the host): one dwordx4 per operand instead of four
+            // scalar passes; per component the operation order is exactly one()'s, so both paths give the same bits
+            float x[4] = {v.x * alpha, v.y * alpha, v.z * alpha, v.w * alpha};
             if (bias) {
                 const float4 b = *reinterpret_cast<const float4*>(bias + n);
-                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
             }
-            if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (pre) *reinterpret_cast<float4*>(pre + (int64_t)m * ldc + n) = make_float4(x[0], x[1], x[2], x[3]);
+            if (act == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = fmaxf(x[i], 0.f);
+            } else if (act == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = 0.5f * x[i] * (1.0f + erff(x[i] * 0.70710678118654752440f));
+            } else if (act == 3 || act == 4) {
+                const float4 u4 = *reinterpret_cast<const float4*>(aux + (int64_t)m * ldaux + n);
+                const float u[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (act == 3) x[i] *= 0.5f * (1.0f + erff(u[i] * 0.70710678118654752440f)) + u[i] * expf(-0.5f * u[i] * u[i]) * 0.39894228040143267794f;
+                    else x[i] = u[i] > 0.f ? x[i] : 0.f;
+                }
+            }
+            if (mask) {
+                const uchar4 k = *reinterpret_cast<const uchar4*>(mask + (int64_t)m * N + n);
+                x[0] = k.x ? x[0] * mscale : 0.f;
+                x[1] = k.y ? x[1] * mscale : 0.f;
+                x[2] = k.z ? x[2] * mscale : 0.f;
+                x[3] = k.w ? x[3] * mscale : 0.f;
+            }
             if (add1) {
                 const float4 a = *reinterpret_cast<const float4*>(add1 + (int64_t)m * ld1 + n);
-                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                x[0] += a.x; x[1] += a.y; x[2] += a.z; x[3] += a.w;
             }
-            *reinterpret_cast<float4*>(C + (int64_t)m * ldc + n) = v;
+            if (add2) {
+                const float4 a = *reinterpret_cast<const float4*>(add2 + (int64_t)m * ld2 + n);
+                x[0] += a.x; x[1] += a.y; x[2] += a.z; x[3] += a.w;
+            }
+            float4* c = reinterpret_cast<float4*>(C + (int64_t)m * ldc + n);
+            if (accumulate) {
+                const float4 o = *c;
+                x[0] = o.x + x[0]; x[1] = o.y + x[1]; x[2] = o.z + x[2]; x[3] = o.w + x[3];
+            }
+            *c = make_float4(x[0], x[1], x[2], x[3]);
             return;
         }
         (*this)(m, n + 0, v.x);
@@ -232,8 +264,9 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     e.mask = d->keep_mask; e.mscale = d->keep_scale; e.add1 = d->add1; e.ld1 = d->ld1; e.add2 = d->add2; e.ld2 = d->ld2;
     e.accumulate = d->accumulate; e.M = d->M; e.N = d->N; e.aux = d->aux; e.ldaux = d->ldaux;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    e.fast = !d->pre_act && !d->keep_mask && !d->add2 && !d->accumulate && d->act <= 1 && (d->ldc % 4 == 0) && al16(d->C) &&
-             (!d->bias || al16(d->bias)) && (!d->add1 || (al16(d->add1) && d->ld1 % 4 == 0));
+    e.fast = (d->ldc % 4 == 0) && al16(d->C) && (!d->bias || al16(d->bias)) && (!d->pre_act || al16(d->pre_act)) &&
+             (!d->add1 || (al16(d->add1) && d->ld1 % 4 == 0)) && (!d->add2 || (al16(d->add2) && d->ld2 % 4 == 0)) &&
+             (d->act < 3 || (al16(d->aux) && d->ldaux % 4 == 0)) && (!d->keep_mask || (d->N % 4 == 0 && ((uintptr_t)d->keep_mask & 3) == 0));
 
     // Tile choice by padded work x a measured per-configuration factor (tools/tune_gemm.py, tools/tune_gemm_mmea.py, one device):
     //   128x128  when its tiles alone fill the chip; the best loop when both operands are K-contiguous;
