@@ -250,6 +250,10 @@ SNAG_API int snag_gaussian_fill(uint64_t seed, int64_t N, int F, const float* me
  *   snag_entity_token_fwd is the forward blend written straight into a token slot (row stride out_ld). */
 SNAG_API int snag_colsum(const float* x, int64_t R, int C, int64_t ld, float* out, int accumulate,
                          float* work, void* stream);
+/* dst [cols, rows] (row stride ld_dst) = transpose of src [rows, cols] (row stride ld_src).  The MKGC engine keeps each raw feature
+ * table in both layouts so that the first projection X W^T (a5, model/SNAG_tools.py:134-150) and its weight gradient both stream
+ * row-contiguous operands; the transposed copy is refreshed once per noise epoch (model/SNAG.py:86-98). */
+SNAG_API int snag_transpose_f32(const float* src, int64_t ld_src, int64_t rows, int64_t cols, float* dst, int64_t ld_dst, void* stream);
 SNAG_API int snag_token_mean_bwd(const float* d_out, int64_t N, int M, int D, float* d_hidden, void* stream);
 SNAG_API int snag_entity_token_fwd(const float* table, int64_t N, int D, const float* noise, const uint8_t* noise_mask,
                                    float half_mask_ratio, float* out, int64_t out_ld, void* stream);

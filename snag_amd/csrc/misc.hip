@@ -292,6 +292,30 @@ extern "C" SNAG_API int snag_colsum(const float* x, int64_t R, int C, int64_t ld
     return check_launch("snag_colsum");
 }
 
+namespace snag {
+// dst[c, r] = src[r, c]: 64 x 64 tiles through LDS (pitch 65: conflict-free both ways), 256-byte runs on both sides.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int64_t ld_src, int64_t R, int64_t C,
+                                                        float* __restrict__ dst, int64_t ld_dst) {
+    __shared__ float tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4)
+        if (r0 + i < R && c0 + tx < C) tile[i][tx] = src[(r0 + i) * ld_src + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4)
+        if (c0 + i < C && r0 + tx < R) dst[(c0 + i) * ld_dst + r0 + tx] = tile[tx][i];
+}
+}  // namespace snag
+
+extern "C" SNAG_API int snag_transpose_f32(const float* src, int64_t ld_src, int64_t rows, int64_t cols, float* dst, int64_t ld_dst, void* stream) {
+    SNAG_REQUIRE(rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= rows, SNAG_ERR_ARG, "transpose: bad sizes");
+    if (rows == 0 || cols == 0) return SNAG_OK;
+    SNAG_REQUIRE(src && dst, SNAG_ERR_ARG, "transpose: null pointer");
+    SNAG_REQUIRE(ceil_div(rows, 64) <= 65535, SNAG_ERR_UNSUPPORTED, "transpose: more than 4M rows");
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows, cols, dst, ld_dst);
+    return check_launch("snag_transpose_f32");
+}
+
 extern "C" SNAG_API int snag_token_mean_bwd(const float* d_out, int64_t N, int M, int D, float* d_hidden, void* stream) {
     SNAG_REQUIRE(d_out && d_hidden && N >= 0 && M >= 1 && D >= 1, SNAG_ERR_ARG, "token_mean_bwd: bad arguments");
     if (N == 0) return SNAG_OK;

@@ -84,10 +84,11 @@ class MKGCHotPath:
         # the 128-B line, so every 256-B tile segment would straddle three lines instead of two (PMC: 1.7x the algorithmic fetch).
         self.ld_t = _align(N, 32)
 
-        def transposed(f):
-            buf = torch.zeros(f.shape[1], self.ld_t, device=self.dev, dtype=f32)
-            buf[:, :N].copy_(f.t())
-            return buf[:, :N]
+        def transposed(f, out=None):
+            if out is None:
+                out = torch.zeros(f.shape[1], self.ld_t, device=self.dev, dtype=f32)[:, :N]
+            call("snag_transpose_f32", ptr(f), f.stride(0), N, f.shape[1], ptr(out), out.stride(0), stream())
+            return out
         self._transposed = transposed
         self.feats_t = [transposed(f) for f in self.feats]
         self.g_slot = M - 1                                   # structural token last
@@ -284,7 +285,7 @@ class MKGCHotPath:
             mean, std = self.feat_stats[i]
             call("snag_noise_apply", ptr(f), N, f.shape[1], ptr(mean), ptr(std), ptr(self.row_mask), None, None,
                  base + 11 * i + 2, float(cfg.mask_ratio), ptr(self.noisy[i]), st)
-            self.noisy_t[i].copy_(self.noisy[i].t())            # once per epoch
+            self._transposed(self.noisy[i], self.noisy_t[i])     # once per epoch
         mean, std = ops.colstats(self.p["ent"])
         call("snag_gaussian_fill", base + 101, N, D, ptr(mean), ptr(std), ptr(self.ent_noise), st)
         call("snag_dropout_keep_mask", base + 102, None, N, float(cfg.noise_ratio) * 0.5, ptr(self.ent_noise_mask), st)

@@ -110,3 +110,15 @@ def test_encoder_slice_golden(tag):
     outs = fus.forward_stacked(x0)
     for nm, o in zip(("joint", "joint_fz", "hidden", "weight_norm"), outs):
         assert_close(o, z[f"{tag}.{nm}"], atol=2e-5, what=nm)
+
+
+@pytest.mark.parametrize("R,C,pad", [(1, 1, 0), (63, 65, 0), (700, 37, 5), (15000, 768, 8), (129, 4096, 0)])
+def test_transpose_kernel(R, C, pad):
+    """snag_transpose_f32 (the per-epoch refresh of the transposed feature copies) is an exact copy, strides honoured."""
+    from snag_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(R + C)
+    src = torch.randn(R, C + pad, generator=g).to(DEV)[:, :C]
+    dst = torch.full((C, R + pad), -7.0, device=DEV)
+    call("snag_transpose_f32", ptr(src), src.stride(0), R, C, ptr(dst), dst.stride(0), stream())
+    assert torch.equal(dst[:, :R], src.t())
+    assert float((dst[:, R:] + 7.0).abs().sum()) == 0.0          # padding untouched
