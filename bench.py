@@ -258,6 +258,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs the torch.distributed.run launcher (WORLD_SIZE is 1)")
+    from snag_amd.build import ensure_built
+    ensure_built(local)                  # no-op when the prebuilt libsnag_hip.so travelled with the tree
     import torch.distributed as dist
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)

@@ -64,5 +64,22 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def ensure_built(local_rank=0, timeout_s=900.0):
+    """Make sure the library file exists before anything loads it: the first local rank builds it when it is missing (a fresh
+    checkout on the GPU box; normally the prebuilt file travels with the tree), the others wait for the file to appear."""
+    import time
+    if os.path.exists(LIB):
+        return LIB
+    if local_rank == 0:
+        return build(force=False, verbose=False)
+    t0 = time.time()
+    while not os.path.exists(LIB):
+        if time.time() - t0 > timeout_s:
+            raise RuntimeError(f"{LIB} did not appear within {timeout_s:.0f} s")
+        time.sleep(1.0)
+    time.sleep(2.0)          # let the linker finish writing
+    return LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)

@@ -12,6 +12,12 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The C-ABI library is git-ignored; build it when a fresh checkout has none (hipcc cross-compiles without a GPU)."""
+    from snag_amd.build import ensure_built
+    ensure_built()
+
+
 def pytest_collection_modifyitems(config, items):
     """GPU tests are skipped (not failed) when no device is visible, e.g. a plain `pytest tests/` here."""
     import torch
