@@ -356,6 +356,12 @@ SNAG_API int snag_gat_layer_bwd(const float* x, int64_t N, int f, int H, const f
                                 const float* s_src, const float* s_dst, const float* agg, const float* rsum, const float* pre, int had_elu, const float* d_out,
                                 float* d_x, float* d_w, float* d_a, int accumulate, float* work, void* stream);
 
+/* GCN structural encoder option (structure_encoder == "gcn": GraphConvolution model/layers.py:102-130, GCN model/Tool_model.py:98-110):
+ * out [N, f] = A x (+ bias) with A given as CSR (rowptr [N+1], col/val [E]; duplicate coordinates add up) -- the torch.spmm of
+ * GraphConvolution.forward.  The backward w.r.t. x is the same call on the transposed CSR.  f <= 512. */
+SNAG_API int snag_spmm_csr(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t N, int f,
+                           const float* bias, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

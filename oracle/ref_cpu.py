@@ -419,6 +419,17 @@ def gat_forward(x: Tensor, edges: Tensor, layers: Sequence[Dict[str, Tensor]]) -
 # --------------------------------------------------------------------------
 
 
+def gcn_forward(x: Tensor, adj: Tensor, p: Dict[str, Tensor]) -> Tensor:
+    """Two-layer GCN, dropout 0: gc2(relu(gc1(x, adj)), adj) with gc(x, adj) = spmm(adj, x @ W) + b.
+
+    reference: GraphConvolution.forward model/layers.py:124-130, GCN.forward model/Tool_model.py:106-110.  ``p`` uses the reference's
+    state_dict keys (gc1.weight [in, out], gc1.bias, gc2.weight, gc2.bias); ``adj`` is a sparse COO tensor (values used).
+    """
+    h = torch.sparse.mm(adj, x @ p["gc1.weight"]) + p["gc1.bias"]
+    h = torch.relu(h)
+    return torch.sparse.mm(adj, h @ p["gc2.weight"]) + p["gc2.bias"]
+
+
 def mkgc_forward(feats: Sequence[Tensor], proj: Sequence[Dict[str, Tensor]], ent_table: Tensor,
                  fusion_params: Dict[str, Tensor], rel_table: Tensor,
                  h: Tensor, rel: Tensor, t: Tensor, neg_t: Tensor, *,

@@ -83,6 +83,7 @@ SIGNATURES = {
     "snag_sample_negatives": [_U64, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P, _P, _P],
     "snag_gather_normalize_fwd": [_P, _L, _L, _I, _P, _I, _L, _I, _P, _P, _P],
     "snag_gather_normalize_bwd": [_P, _P, _P, _I, _P, _I, _L, _I, _P, _L, _P],
+    "snag_spmm_csr": [_P, _P, _P, _P, _L, _I, _P, _P, _P],
     "snag_transpose_f32": [_P, _L, _L, _L, _P, _L, _P],
     "snag_selfadv_loss": [_P, _P, _L, _I, _F, _F, _P, _P, _P, _P],
     "snag_gram_f32": [_P, _L, _I, _I, _F, _P, _L, _P],

@@ -332,6 +332,33 @@ __global__ __launch_bounds__(256) void gat_param_reduce_kernel(const float* __re
     pa[f] = accumulate ? pa[f] + sd : sd;
 }
 
+// out[u,:] = sum_{e in row u} val[e] * x[col[e],:]  (+ bias): the torch.spmm(adj, support) of GraphConvolution.forward
+// (model/layers.py:124-130).  One wave per row, a feature row spread over the wave; duplicates in the edge list simply add up.
+template <int NU>
+__global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                       const float* __restrict__ val, const float* __restrict__ x, int64_t N, int f,
+                                                       const float* __restrict__ bias, float* __restrict__ out) {
+    const int64_t u = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (u >= N) return;
+    const int lane = threadIdx.x & 63;
+    Cols<NU> acc;
+#pragma unroll
+    for (int q = 0; q < NU; ++q) acc.v[q] = 0.f;
+    const int e0 = rowptr[u], e1 = rowptr[u + 1];
+    for (int e = e0; e < e1; ++e) {
+        const float a = val[e];
+        const Cols<NU> xv = ld_cols<NU>(x + (int64_t)col[e] * f, f, lane);
+#pragma unroll
+        for (int q = 0; q < NU; ++q) acc.v[q] = fmaf(a, xv.v[q], acc.v[q]);
+    }
+    if (bias) {
+        const Cols<NU> b = ld_cols<NU>(bias, f, lane);
+#pragma unroll
+        for (int q = 0; q < NU; ++q) acc.v[q] += b.v[q];
+    }
+    st_cols<NU>(out + u * f, acc, f, lane);
+}
+
 static constexpr int kGatBlocks = 1024;
 
 }  // namespace snag
@@ -394,4 +421,14 @@ extern "C" SNAG_API int snag_gat_layer_bwd(const float* x, int64_t N, int f, int
     SNAG_GAT_NU(gat_node_scores_bwd_kernel, f, dim3(nb), st, x, N, f, H, w, a_src_dst, (const float*)ds_src, (const float*)ds_dst, d_x, part2);
     hipLaunchKernelGGL(gat_param_reduce_kernel, dim3(ceil_div(H * f, 16)), dim3(256), 0, st, (const float*)part, (const float*)part2, nb, nb, H, f, d_w, d_a, accumulate);
     return check_launch("snag_gat_layer_bwd");
+}
+
+extern "C" SNAG_API int snag_spmm_csr(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t N, int f,
+                                      const float* bias, float* out, void* stream) {
+    SNAG_REQUIRE(N >= 0 && f >= 1 && f <= 512, SNAG_ERR_ARG, "spmm_csr: bad sizes N=%ld f=%d (f <= 512)", (long)N, f);
+    if (N == 0) return SNAG_OK;
+    SNAG_REQUIRE(rowptr && x && out, SNAG_ERR_ARG, "spmm_csr: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    SNAG_GAT_NU(spmm_csr_kernel, f, dim3((unsigned)ceil_div(N, 4)), st, rowptr, col, val, x, N, f, bias, out);
+    return check_launch("snag_spmm_csr");
 }

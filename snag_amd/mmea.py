@@ -110,10 +110,14 @@ class MultiModalEncoder(nn.Module):
         self.img_fc = Linear(img_feature_dim, args.img_dim)
         self.name_fc = Linear(300, args.char_dim)
         self.char_fc = Linear(char_feature_dim, args.char_dim)
-        if args.structure_encoder != "gat":
-            raise NotImplementedError("only the GAT structural encoder (run_snag.sh:28) is built")
-        self.cross_graph_model = GAT(n_units=self.n_units, n_heads=self.n_heads, dropout=args.dropout, attn_dropout=args.attn_dropout,
-                                     instance_normalization=args.instance_normalization, diag=True)   # :101-104
+        if args.structure_encoder == "gcn":                                                        # :98-100
+            from .gcn import GCN
+            self.cross_graph_model = GCN(self.n_units[0], self.n_units[1], self.n_units[2], dropout=args.dropout)
+        elif args.structure_encoder != "gat":
+            raise NotImplementedError(f"structure_encoder {args.structure_encoder!r} is not a reference option")
+        else:
+            self.cross_graph_model = GAT(n_units=self.n_units, n_heads=self.n_heads, dropout=args.dropout, attn_dropout=args.attn_dropout,
+                                         instance_normalization=args.instance_normalization, diag=True)   # :101-104
         self.fusion = MformerFusion(args, modal_num=args.inner_view_num, with_weight=args.with_weight)  # :105-106
 
     def forward(self, input_idx, adj, img_features=None, rel_features=None, att_features=None, name_features=None, char_features=None,

@@ -20,6 +20,7 @@ Vectors (SURVEY.md par. 8c):
   g10_snag_model.npz the whole in-tree SNAG model: SNAG.forward/update_noise/joint_emb_generat (model/SNAG.py) loss + grads
   g11_data.npz       dataset readers on a tiny synthetic DBP15K-layout directory: read_raw_data / load_relation / load_attr / load_img /
                      get_adjr / load_eva_data (src/data.py, src/utils.py:327-362); the fixture holds the synthetic files and the outputs
+  g12_gcn.npz        GCN structural encoder option (model/Tool_model.py:98-110, model/layers.py:102-130), output and grads
   g8_icl_loss.npz    icl_loss (bidirectional InfoNCE, model/SNAG_loss.py:31-128) + CustomMultiLossLayer, loss and grads
 """
 import csv
@@ -465,6 +466,29 @@ def gen_g9():
     for k, p in gat.named_parameters():
         d["g.p." + k] = p.grad
     save("g9_gat.npz", d)
+
+
+def gen_g12():
+    """GCN structural encoder option: GCN(nfeat, nhid, nout, dropout=0) over the normalised adjacency (values used by torch.spmm)."""
+    from model.Tool_model import GCN
+    from src.utils import get_adjr
+    g = torch.Generator().manual_seed(1212)
+    N, f = 150, 48
+    triples = [(int(a), 0, int(b)) for a, b in zip(torch.randint(0, N, (600,), generator=g), torch.randint(0, N, (600,), generator=g))]
+    adj = get_adjr(N, triples, norm=True)
+    gcn = GCN(f, 40, 36, dropout=0.0)
+    randomize_(gcn, g, scale=0.5)
+    gcn.eval()
+    x = (torch.randn(N, f, generator=g) * 0.8).requires_grad_(True)
+    cw = torch.randn(N, 36, generator=g)
+    y = gcn(x, adj)
+    (y * cw).sum().backward()
+    d = {"x": x, "adj_indices": adj._indices(), "adj_values": adj._values(), "cw": cw, "y": y, "g.x": x.grad}
+    for k, v in gcn.state_dict().items():
+        d["p." + k] = v
+    for k, p in gcn.named_parameters():
+        d["g.p." + k] = p.grad
+    save("g12_gcn.npz", d)
 
 
 def snag_args(D=64, add_noise=1):

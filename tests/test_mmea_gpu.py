@@ -150,3 +150,33 @@ def test_dataset_directory_to_trained_model(tmp_path):
         test = np.array(test_ill_)
         res = evalsim.rank_metrics(fa[T(test[:, 0].astype(np.int64), DEV)].contiguous(), fa[T(test[:, 1].astype(np.int64), DEV)].contiguous(), csls_k=3)
     assert 0.0 <= res["hits_l2r"][0] <= 1.0 and res["mr_l2r"] >= 1.0
+
+
+def test_snag_model_with_gcn_structure_encoder():
+    """structure_encoder == "gcn" (model/SNAG_tools.py:98-100): the whole model builds on the GCN drop-in and trains."""
+    from snag_amd.mmea import SNAG
+    z = load("g10_snag_model.npz")
+    N = int(z["N"])
+    g = torch.Generator().manual_seed(4)
+    adj = torch.sparse_coo_tensor(T(z["edges"]), torch.rand(z["edges"].shape[1], generator=g) * 0.2, (N, N))
+    wo = z["ent_wo_img"].tolist()
+    kgs = {"ent_num": N, "images_list": z["images_list"], "rel_features": z["rel_features"], "att_features": z["att_features"],
+           "name_features": None, "char_features": None, "input_idx": torch.arange(N), "ent_wo_img": wo,
+           "ent_w_img": [i for i in range(N) if i not in set(wo)], "adj": adj, "train_ill": z["train_ill"]}
+    args = snag_args(int(z["D"]))
+    args.structure_encoder = "gcn"
+    model = SNAG(kgs, args, device=DEV)
+    assert {"multimodal_encoder.cross_graph_model.gc1.weight", "multimodal_encoder.cross_graph_model.gc2.bias"} <= set(model.state_dict())
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3)
+    model.train()
+    model.noise_mode = "philox"
+    model.update_noise(seed=1)
+    losses = []
+    for _ in range(10):
+        loss, _ = model(z["train_ill"])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0], losses
+    assert model.multimodal_encoder.cross_graph_model.gc1.weight.grad.abs().sum() > 0

@@ -188,3 +188,17 @@ def test_gat():
     for l in range(2):
         assert_close(layers[l]["w"].grad, z[f"g.p.layer_stack.{l}.w"], atol=2e-5, rtol=1e-4)
         assert_close(layers[l]["a_src_dst"].grad, z[f"g.p.layer_stack.{l}.a_src_dst"], atol=2e-5, rtol=1e-4)
+
+
+def test_gcn():
+    """Golden G12: the reference GCN (structure_encoder == "gcn") forward and autograd."""
+    z = load("g12_gcn.npz")
+    x = T(z["x"]).requires_grad_(True)
+    adj = torch.sparse_coo_tensor(T(z["adj_indices"]), T(z["adj_values"]), (x.shape[0], x.shape[0]))
+    p = {k[2:]: T(v).requires_grad_(True) for k, v in z.items() if k.startswith("p.")}
+    y = O.gcn_forward(x, adj, p)
+    assert_close(y, z["y"], atol=1e-6, rtol=1e-5)
+    (y * T(z["cw"])).sum().backward()
+    assert_close(x.grad, z["g.x"], atol=1e-6, rtol=1e-5)
+    for k, v in p.items():
+        assert_close(v.grad, z["g.p." + k], atol=1e-5, rtol=1e-5, what=k)
