@@ -325,6 +325,7 @@ extern "C" SNAG_API int snag_pairwise_dist(const float* x, int64_t ldx, int n, c
     p.b_vec = (ldy % 4 == 0) && (((uintptr_t)y & 15) == 0);
     p.k_per_split = ceil_div(d, kBK) * kBK;
     p.dbg = 0;
+    p.xcd = 1;
     DistEpilogue e{out, ld_out, xn, yn, n, m, as_similarity, (int)((ld_out % 4 == 0) && (((uintptr_t)out & 15) == 0))};
     launch_dist_gemm(p, e, (hipStream_t)stream);
     return check_launch("snag_pairwise_dist");

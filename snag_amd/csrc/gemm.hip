@@ -130,12 +130,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // S = alpha * Z Z^T (Z [n, k], K-contiguous).  Only tiles on or above the diagonal run the main loop; each also writes its
-// transpose, so S is symmetric bit for bit and the MFMA work is (almost) halved.
-__global__ __launch_bounds__(256) void gram_tile_kernel(GemmOperands p, float alpha, float* __restrict__ C, int64_t ldc) {
-    if (blockIdx.x < blockIdx.y) return;
+// transpose (staged through LDS so that both copies leave in full 128-byte lines), so S is symmetric bit for bit and the MFMA
+// work is (almost) halved.
+__global__ __launch_bounds__(256) void gram_tile_kernel(GemmOperands p, float alpha, float* __restrict__ C, int64_t ldc, int T) {
+    // 1-D grid over the T (T + 1) / 2 tiles on or above the diagonal, row-major; the XCD remap hands each L2 a contiguous run
+    const int k = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
+    int by = (int)(((2.0f * T + 1.0f) - sqrtf((2.0f * T + 1.0f) * (2.0f * T + 1.0f) - 8.0f * k)) * 0.5f);
+    by = max(0, min(by, T - 1));
+    while (by > 0 && by * T - by * (by - 1) / 2 > k) --by;
+    while (by + 1 < T && (by + 1) * T - (by + 1) * by / 2 <= k) ++by;
+    const int bx = by + (k - (by * T - by * (by - 1) / 2));
     using Core = GemmCore<128, 128, 64, 64, true, true, false>;
-    __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    constexpr int kSmem = Core::SMEM_FLOATS > Core::kTransposeStageFloats ? Core::SMEM_FLOATS : Core::kTransposeStageFloats;
+    __shared__ __attribute__((aligned(16))) float smem[kSmem];
+    const int m0 = by * 128, n0 = bx * 128;
     Core core;
     core.run(p, smem, m0, n0, 0, p.K);
     const int n = p.M;
@@ -153,7 +161,10 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(GemmOperands p, float al
             if (c + 3 < n) o[3] = v.w;
         }
     });
-    if (blockIdx.x != blockIdx.y) core.store_transposed(C, ldc, alpha, m0, n0, n, n);
+    if (bx != by)      // the mirror tile: C[col, row], 128-byte runs along the transposed rows
+        core.for_each_transposed(smem, m0, n0, [=](int c, int r, float v) {
+            if (r < n && c < n) C[(int64_t)c * ldc + r] = alpha * v;
+        });
 }
 
 static int env_int(const char* name) {
@@ -240,6 +251,7 @@ static int pick_splits(int64_t tiles, int K, bool both_kc = false) {
     return (int)std::min(want, cap);
 }
 
+static int xcd_mode() { static const int v = env_int("SNAG_GEMM_XCD"); return v == 2 ? 0 : 1; }   // tuning: SNAG_GEMM_XCD=2 switches the remap off
 static int log_shapes() { static const int v = env_int("SNAG_GEMM_LOG"); return v; }          // tuning: one line per launch on stderr
 static int force_tile() { static const int v = env_int("SNAG_GEMM_TILE"); return v; }        // tuning hooks: 1 = 64x128, 2 = 128x128, 3 = 128x160
 static int force_splits() { static const int v = env_int("SNAG_GEMM_SPLITS"); return v; }
@@ -259,6 +271,7 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     p.b_vec = (d->ldb % 4 == 0) && (((uintptr_t)d->B & 15) == 0);
     static const int dbg = env_int("SNAG_GEMM_DBG");
     p.dbg = dbg;
+    p.xcd = xcd_mode();
     Epilogue e;
     e.C = d->C; e.ldc = d->ldc; e.bias = d->bias; e.alpha = d->alpha; e.act = d->act; e.pre = d->pre_act;
     e.mask = d->keep_mask; e.mscale = d->keep_scale; e.add1 = d->add1; e.ld1 = d->ld1; e.add2 = d->add2; e.ld2 = d->ld2;
@@ -366,7 +379,8 @@ extern "C" SNAG_API int snag_gram_f32(const float* Z, int64_t ldz, int n, int k,
     p.k_per_split = ceil_div(std::max(k, 1), kBK) * kBK;
     p.dbg = 0;
     const int t = ceil_div(n, 128);
-    hipLaunchKernelGGL(gram_tile_kernel, dim3(t, t), dim3(256), 0, (hipStream_t)stream, p, alpha, S, lds);
+    p.xcd = xcd_mode();
+    hipLaunchKernelGGL(gram_tile_kernel, dim3(t * (t + 1) / 2), dim3(256), 0, (hipStream_t)stream, p, alpha, S, lds, t);
     return check_launch("snag_gram_f32");
 }
 

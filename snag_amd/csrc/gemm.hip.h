@@ -68,7 +68,16 @@ struct GemmOperands {
     // the VEC kernel variant additionally needs: row-contiguous operands with a row count that is a multiple of 4
     int k_per_split;     // K range handled by one blockIdx.z (multiple of kBK); == K rounded up when no split
     int dbg;             // tuning only: nonzero = stop fetching after the first two k-tiles (compute-only ceiling)
+    int xcd;             // 1: XCD-aware workgroup -> tile mapping (xcd_swizzle)
 };
+
+// Workgroups are dealt round-robin over the 8 XCDs (observed, never relied on for correctness): ids b and b + 8 share an L2.
+// The bijective remap below gives each of the 8 groups a CONTIGUOUS range of tile indices, so tiles that share an operand panel
+// -- and, for row pitches that are not a multiple of 128 B, the cache lines straddling a tile boundary -- stay in one L2.
+__device__ __forceinline__ int xcd_swizzle(int orig, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = orig & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (orig >> 3);
+}
 
 // --- global -> register staging ---------------------------------------------------------------
 // One "slot" is a float4: along k for K-contiguous operands, along the row index otherwise.
@@ -438,37 +447,37 @@ struct GemmCore {
         }
     }
 
-    // Transposed store straight from the accumulators: C[col, row] = alpha * acc(row, col).  Registers 4k..4k+3 of a 32x32 tile are
-    // four consecutive rows, i.e. 16 contiguous bytes of the transposed row; lane pairs (lh) and the four k cover a full 128-byte
-    // line per column.  Used by the Gram kernel to fill the lower triangle from the upper one.
-    __device__ __forceinline__ void store_transposed(float* __restrict__ C, int64_t ldc, float alpha, int m0, int n0, int M, int N) const {
+    // Visit the block tile TRANSPOSED, one element per lane: f(col, row, value) with the 32 lanes of a half-wave on 32 consecutive
+    // rows of one column, i.e. 128 contiguous bytes of the transposed matrix per half-wave.  The accumulators go through LDS with a
+    // padded pitch (CW + 1: the column-wise reads are conflict-free).  smem must hold kTransposeStageFloats.
+    static constexpr int kTransposeStageFloats = 4 * 32 * (CW + 1);
+    template <class F>
+    __device__ __forceinline__ void for_each_transposed(float* __restrict__ smem, int m0, int n0, F&& f) const {
+        constexpr int P = CW + 1;
         const int lane = threadIdx.x & 63;
         const int wave = wave_id_uniform();
         const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
+        lds_float* stage = (lds_float*)smem + wave * (32 * P);
         const int li = lane & 31, lh = lane >> 5;
-        const bool vec_ok = (ldc % 4 == 0) && ((((uintptr_t)C) & 15) == 0);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn0 + 32 * j + li;
-                if (col >= N) continue;
+            for (int c = 0; c < WN / CW; ++c) {
+                __syncthreads();
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int row = m0 + wm0 + 32 * i + 8 * k + 4 * lh;
-                    float* dst = C + (int64_t)col * ldc + row;
-                    const float4 v = make_float4(alpha * acc[i][j][4 * k], alpha * acc[i][j][4 * k + 1], alpha * acc[i][j][4 * k + 2],
-                                                 alpha * acc[i][j][4 * k + 3]);
-                    if (vec_ok && row + 3 < M) {
-                        *reinterpret_cast<float4*>(dst) = v;
-                    } else {
-                        if (row + 0 < M) dst[0] = v.x;
-                        if (row + 1 < M) dst[1] = v.y;
-                        if (row + 2 < M) dst[2] = v.z;
-                        if (row + 3 < M) dst[3] = v.w;
-                    }
+                for (int j = 0; j < CW / 32; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        stage[((e & 3) + 8 * (e >> 2) + 4 * lh) * P + 32 * j + li] = acc[i][c * (CW / 32) + j][e];
+                __syncthreads();
+                const int row = m0 + wm0 + 32 * i + li;
+#pragma unroll 4
+                for (int it = 0; it < CW / 2; ++it) {
+                    const int cc = 2 * it + lh;
+                    f(n0 + wn0 + c * CW + cc, row, stage[li * P + cc]);
                 }
             }
+        }
     }
 };
 
@@ -478,7 +487,13 @@ template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class 
 __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmOperands p, Epi epi, float* __restrict__ slab) {
     using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
     __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd) {
+        const int id = xcd_swizzle(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+        bx = id % gridDim.x;
+        by = id / gridDim.x;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     Core core;
@@ -520,7 +535,7 @@ template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class 
 __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmOperands p, Epi epi, float* __restrict__ slab, StreamKPlan plan) {
     using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
     __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
-    const int64_t G = gridDim.x, b = blockIdx.x;
+    const int64_t G = gridDim.x, b = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;   // virtual block id: slab slots and the fix-up use it too
     int64_t it = plan.total * b / G;
     const int64_t it_end = plan.total * (b + 1) / G;
     Core core;

@@ -13,3 +13,7 @@ for k in (300, 1200):
     z = torch.randn(7000, k, device='cuda')
     out = torch.empty(7000, 7000, device='cuda')
     print(k, "gemm", t(lambda: ops.gemm(z, z, alpha=10.0, out=out)), "gram", t(lambda: ops.gram(z, alpha=10.0, out=out)))
+for k in (300, 1200):
+    z = torch.randn(7000, k, device='cuda')
+    outp = torch.empty(7000, 7008, device='cuda')[:, :7000]
+    print(k, "padded ld 7008: gemm", t(lambda: ops.gemm(z, z, alpha=10.0, out=outp)), "gram", t(lambda: ops.gram(z, alpha=10.0, out=outp)))
