@@ -267,6 +267,15 @@ SNAG_API int snag_adamw_step(float* param, const float* grad, float* exp_avg, fl
                              float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                              const uint64_t* tick, float grad_scale, void* stream);
 
+/* The same update with the reference's parameter groups (set_optim, src/utils.py:47-55: no weight decay for names containing
+ * 'bias' / 'weight_raw' / 'multi_loss_layer', 5x learning rate for 'multi_loss_layer'): the flat buffer is cut into n_seg
+ * consecutive segments, segment s = [seg_end[s-1], seg_end[s]) (seg_end[n_seg-1] >= n), each with its own weight decay and
+ * learning-rate multiplier.  seg_* are DEVICE arrays. */
+SNAG_API int snag_adamw_step_groups(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                    float lr, float beta1, float beta2, float eps, const int64_t* seg_end,
+                                    const float* seg_weight_decay, const float* seg_lr_scale, int n_seg, int64_t step,
+                                    const uint64_t* tick, float grad_scale, void* stream);
+
 /* Device-resident step counter: tick[0] += 1.  When `tick` is given to snag_adamw_step the bias
  * correction uses t = tick[0] + 1 instead of the host `step`, which lets a captured hipGraph of a
  * whole training step be replayed without re-recording. */

@@ -157,21 +157,33 @@ __global__ __launch_bounds__(256) void scaled_rows_kernel(const float* __restric
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2, float gscale,
-                                                    const uint64_t* __restrict__ tick) {
+                                                    const uint64_t* __restrict__ tick, const int64_t* __restrict__ seg_end,
+                                                    const float* __restrict__ seg_wd, const float* __restrict__ seg_lr, int n_seg) {
     if (tick != nullptr) {          // step number lives on the device (graph replay): t = tick + 1
         const float t = (float)(tick[0] + 1);
         bc1 = 1.0f - powf(b1, t);
         bc2 = 1.0f - powf(b2, t);
     }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float lr_i = lr, wd_i = wd;
+        if (n_seg > 0) {                    // parameter groups: segment s covers [seg_end[s-1], seg_end[s])
+            int lo = 0, hi = n_seg - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (i < seg_end[mid]) hi = mid;
+                else lo = mid + 1;
+            }
+            lr_i = lr * seg_lr[lo];
+            wd_i = seg_wd[lo];
+        }
         const float gi = g[i] * gscale;
-        float pi = p[i] * (1.0f - lr * wd);
+        float pi = p[i] * (1.0f - lr_i * wd_i);
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
         const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
         m[i] = mi;
         v[i] = vi;
         const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-        p[i] = pi - (lr / bc1) * (mi / denom);
+        p[i] = pi - (lr_i / bc1) * (mi / denom);
     }
 }
 
@@ -339,8 +351,22 @@ extern "C" SNAG_API int snag_adamw_step(float* param, const float* grad, float* 
     SNAG_REQUIRE(param && grad && exp_avg && exp_avg_sq, SNAG_ERR_ARG, "adamw_step: null pointer");
     const float bc1 = 1.0f - powf(beta1, (float)std::max<int64_t>(step, 1)), bc2 = 1.0f - powf(beta2, (float)std::max<int64_t>(step, 1));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
-                       eps, weight_decay, bc1, bc2, grad_scale, tick);
+                       eps, weight_decay, bc1, bc2, grad_scale, tick, (const int64_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0);
     return check_launch("snag_adamw_step");
+}
+
+extern "C" SNAG_API int snag_adamw_step_groups(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                                               float beta2, float eps, const int64_t* seg_end, const float* seg_weight_decay,
+                                               const float* seg_lr_scale, int n_seg, int64_t step, const uint64_t* tick, float grad_scale,
+                                               void* stream) {
+    SNAG_REQUIRE(n >= 0 && (step >= 1 || tick != nullptr), SNAG_ERR_ARG, "adamw_step_groups: n=%ld step=%ld", (long)n, (long)step);
+    SNAG_REQUIRE(n_seg >= 1 && seg_end && seg_weight_decay && seg_lr_scale, SNAG_ERR_ARG, "adamw_step_groups: segment table missing");
+    if (n == 0) return SNAG_OK;
+    SNAG_REQUIRE(param && grad && exp_avg && exp_avg_sq, SNAG_ERR_ARG, "adamw_step_groups: null pointer");
+    const float bc1 = 1.0f - powf(beta1, (float)std::max<int64_t>(step, 1)), bc2 = 1.0f - powf(beta2, (float)std::max<int64_t>(step, 1));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+                       eps, 0.0f, bc1, bc2, grad_scale, tick, seg_end, seg_weight_decay, seg_lr_scale, n_seg);
+    return check_launch("snag_adamw_step_groups");
 }
 
 extern "C" SNAG_API int snag_tick(uint64_t* tick, void* stream) {

@@ -123,6 +123,14 @@ class MKGCHotPath:
                 add(f"layer{l}.w2", D, I); add(f"layer{l}.b2", D)
                 add(f"layer{l}.ln2_g", D); add(f"layer{l}.ln2_b", D)
         self.n_params = off
+        # the reference's parameter groups (set_optim, src/utils.py:47-55): biases and weight_raw are not decayed
+        # (LayerNorm.weight is, as there: only the substrings 'bias' / 'weight_raw' / 'multi_loss_layer' opt out)
+        def undecayed(name):
+            leaf = name.split(".")[-1]
+            return name == "weight_raw" or leaf == "bias" or (leaf.startswith("b") and leaf[1:] in ("qkv", "o", "1", "2")) or leaf.endswith("_b")
+        names = sorted(self.slices, key=lambda k: self.slices[k][0])
+        ends = [self.slices[k][0] for k in names[1:]] + [off]
+        self.param_groups = [(k, e, 0.0 if undecayed(k) else cfg.weight_decay) for k, e in zip(names, ends)]
         self.flat = torch.zeros(off, device=self.dev, dtype=f32)
         self.gflat = torch.zeros(off, device=self.dev, dtype=f32)
         self.exp_avg = torch.zeros(off, device=self.dev, dtype=f32)
@@ -130,6 +138,9 @@ class MKGCHotPath:
         self.p = {k: self.flat[o:o + math.prod(s)].view(s) for k, (o, s) in self.slices.items()}
         self.g = {k: self.gflat[o:o + math.prod(s)].view(s) for k, (o, s) in self.slices.items()}
         self._init_params()
+        self._seg_end = torch.tensor([e for _, e, _ in self.param_groups], device=self.dev, dtype=torch.int64)
+        self._seg_wd = torch.tensor([w for _, _, w in self.param_groups], device=self.dev, dtype=f32)
+        self._seg_lr = torch.ones(len(self.param_groups), device=self.dev, dtype=f32)
 
         # ---- activations / scratch ---------------------------------------------------------------
         dev = self.dev
@@ -408,8 +419,9 @@ class MKGCHotPath:
 
     def optimizer_step(self, grad_scale=1.0):
         cfg = self.cfg
-        call("snag_adamw_step", ptr(self.flat), ptr(self.gflat), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n_params,
-             float(cfg.lr), 0.9, 0.999, 1e-8, float(cfg.weight_decay), 0, ptr(self.tick), float(grad_scale), self._st)
+        call("snag_adamw_step_groups", ptr(self.flat), ptr(self.gflat), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n_params,
+             float(cfg.lr), 0.9, 0.999, 1e-8, ptr(self._seg_end), ptr(self._seg_wd), ptr(self._seg_lr), len(self.param_groups), 0,
+             ptr(self.tick), float(grad_scale), self._st)
         call("snag_tick", ptr(self.tick), self._st)
 
     def train_step(self, h, r, t, neg_t, allreduce=None):

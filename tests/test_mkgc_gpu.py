@@ -171,3 +171,33 @@ def test_grad_buckets_partition_the_flat_buffer(num_proj):
     idx = [torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(DEV) for hi, sz in ((300, (16,)), (7, (16,)), (300, (16,)), (300, (16, 32)))]
     eng.train_step(*idx, allreduce=rec)
     assert sorted(rec.seen) == spans
+
+
+def test_optimizer_matches_torch_adamw_with_reference_param_groups():
+    """snag_adamw_step_groups over the flat buffer == torch.optim.AdamW with the reference's groups (set_optim, src/utils.py:47-55:
+    names containing 'bias' / 'weight_raw' are not decayed), over several steps with the device-side step counter."""
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    cfg = MKGCConfig(n_ent=200, n_rel=5, dim=64, feat_dims=[24, 16], num_proj=1, use_intermediate=1, intermediate_size=32, lr=3e-3, weight_decay=0.05)
+    eng = MKGCHotPath(cfg, [torch.rand(200, f) for f in cfg.feat_dims], device=DEV)
+    g = torch.Generator().manual_seed(8)
+    eng.flat.copy_(torch.randn(eng.n_params, generator=g).to(DEV) * 0.3)
+    names = [k for k, _, _ in eng.param_groups]
+    assert {"weight_raw", "proj0.bias", "proj1.bias", "layer0.bqkv", "layer0.bo", "layer0.b1", "layer0.b2", "layer0.ln1_b", "layer0.ln2_b"} == {k for k, _, w in eng.param_groups if w == 0.0}
+    assert all(w == cfg.weight_decay for k, _, w in eng.param_groups if k in ("ent", "rel", "proj0.weight", "layer0.wqkv", "layer0.ln1_g"))
+    ref = {k: eng.p[k].detach().cpu().clone().requires_grad_(True) for k in names}
+    decay = [ref[k] for k, _, w in eng.param_groups if w > 0]
+    plain = [ref[k] for k, _, w in eng.param_groups if w == 0]
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": cfg.weight_decay}, {"params": plain, "weight_decay": 0.0}], lr=cfg.lr, eps=1e-8)
+    for step in range(4):
+        grad = torch.randn(eng.n_params, generator=g) * (0.1 + step)
+        eng.gflat.copy_(grad.to(DEV))
+        for k in names:
+            o, shp = eng.slices[k]
+            ref[k].grad = grad[o:o + ref[k].numel()].view(shp).clone()
+        eng._st = torch.cuda.current_stream().cuda_stream
+        eng.optimizer_step()
+        opt.step()
+    got = eng.flat.cpu()
+    for k in names:
+        o, shp = eng.slices[k]
+        assert_close(got[o:o + ref[k].numel()].view(shp), ref[k].detach(), atol=2e-6, rtol=2e-6, what=k)
