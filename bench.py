@@ -340,7 +340,7 @@ def main():
             "config": {"workload": ("configs[1]: DB15K-shaped" if args.config == "db15k" else "configs[2]: MKG-W-shaped") +
                                    f" MKGC train step (proj num_proj={cfg.num_proj} over 4096/768-wide features, "
                                    f"noise 0.2/0.7, Mformer 1-layer/2-head over all 15000 entities, {cfg.joint_way}, "
-                                   "margin 12, fwd+bwd+AdamW" + ("+RCCL all-reduce" if world > 1 else "") + ")",
+                                   "margin 12, fwd+bwd+clip_grad_norm+AdamW" + ("+RCCL all-reduce" if world > 1 else "") + ")",
                        "n_ent": cfg.n_ent, "n_rel": cfg.n_rel, "dim": cfg.dim, "neg": cfg.neg_num, "batch_per_gpu": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": loss},
         }

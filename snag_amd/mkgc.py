@@ -47,6 +47,7 @@ class MKGCConfig:
     dropout: float = 0.1                # nn.Dropout(0.1) inside the Bert blocks (SNAG_tools.py:169,216)
     lr: float = 1e-4                    # LR
     weight_decay: float = 1e-4
+    clip: float = 1.0                   # torch.nn.utils.clip_grad_norm_ of the reference's train loop (main.py:266-268, --clip default 1.0); 0 = off
     seed: int = 1234
 
     @property
@@ -141,6 +142,8 @@ class MKGCHotPath:
         self._seg_end = torch.tensor([e for _, e, _ in self.param_groups], device=self.dev, dtype=torch.int64)
         self._seg_wd = torch.tensor([w for _, _, w in self.param_groups], device=self.dev, dtype=f32)
         self._seg_lr = torch.ones(len(self.param_groups), device=self.dev, dtype=f32)
+        self._clip = torch.ones(2, device=self.dev, dtype=f32)          # [clip coefficient, gradient norm] of the last step
+        self._clip_work = torch.empty(1024, device=self.dev, dtype=f32)
 
         # ---- activations / scratch ---------------------------------------------------------------
         dev = self.dev
@@ -419,9 +422,13 @@ class MKGCHotPath:
 
     def optimizer_step(self, grad_scale=1.0):
         cfg = self.cfg
+        coef = None
+        if cfg.clip > 0:                      # global-norm clipping, coefficient stays on the device
+            call("snag_clip_grad_norm", ptr(self.gflat), self.n_params, float(grad_scale), float(cfg.clip), ptr(self._clip), ptr(self._clip_work), self._st)
+            coef = ptr(self._clip)
         call("snag_adamw_step_groups", ptr(self.flat), ptr(self.gflat), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n_params,
              float(cfg.lr), 0.9, 0.999, 1e-8, ptr(self._seg_end), ptr(self._seg_wd), ptr(self._seg_lr), len(self.param_groups), 0,
-             ptr(self.tick), float(grad_scale), self._st)
+             ptr(self.tick), float(grad_scale), coef, self._st)
         call("snag_tick", ptr(self.tick), self._st)
 
     def train_step(self, h, r, t, neg_t, allreduce=None):

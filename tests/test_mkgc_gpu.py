@@ -173,11 +173,14 @@ def test_grad_buckets_partition_the_flat_buffer(num_proj):
     assert sorted(rec.seen) == spans
 
 
-def test_optimizer_matches_torch_adamw_with_reference_param_groups():
-    """snag_adamw_step_groups over the flat buffer == torch.optim.AdamW with the reference's groups (set_optim, src/utils.py:47-55:
+@pytest.mark.parametrize("clip", [0.0, 1.0, 25.0])
+def test_optimizer_matches_torch_adamw_with_reference_param_groups(clip):
+    """clip_grad_norm_ + AdamW as the reference's train loop runs them (main.py:266-270): snag_clip_grad_norm + snag_adamw_step_groups over
+    the flat buffer == torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW with the reference's groups (set_optim, src/utils.py:47-55:
     names containing 'bias' / 'weight_raw' are not decayed), over several steps with the device-side step counter."""
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
-    cfg = MKGCConfig(n_ent=200, n_rel=5, dim=64, feat_dims=[24, 16], num_proj=1, use_intermediate=1, intermediate_size=32, lr=3e-3, weight_decay=0.05)
+    cfg = MKGCConfig(n_ent=200, n_rel=5, dim=64, feat_dims=[24, 16], num_proj=1, use_intermediate=1, intermediate_size=32, lr=3e-3, weight_decay=0.05,
+                     clip=clip)
     eng = MKGCHotPath(cfg, [torch.rand(200, f) for f in cfg.feat_dims], device=DEV)
     g = torch.Generator().manual_seed(8)
     eng.flat.copy_(torch.randn(eng.n_params, generator=g).to(DEV) * 0.3)
@@ -189,13 +192,19 @@ def test_optimizer_matches_torch_adamw_with_reference_param_groups():
     plain = [ref[k] for k, _, w in eng.param_groups if w == 0]
     opt = torch.optim.AdamW([{"params": decay, "weight_decay": cfg.weight_decay}, {"params": plain, "weight_decay": 0.0}], lr=cfg.lr, eps=1e-8)
     for step in range(4):
-        grad = torch.randn(eng.n_params, generator=g) * (0.1 + step)
+        grad = torch.zeros(eng.n_params)                      # alignment padding between the slices carries no gradient
+        for k in names:
+            o, shp = eng.slices[k]
+            grad[o:o + ref[k].numel()] = torch.randn(ref[k].numel(), generator=g) * (0.1 + step)
         eng.gflat.copy_(grad.to(DEV))
         for k in names:
             o, shp = eng.slices[k]
             ref[k].grad = grad[o:o + ref[k].numel()].view(shp).clone()
         eng._st = torch.cuda.current_stream().cuda_stream
         eng.optimizer_step()
+        if clip > 0:
+            norm = torch.nn.utils.clip_grad_norm_(list(ref.values()), clip)
+            assert abs(float(eng._clip[1]) - float(norm)) <= 1e-5 * float(norm)
         opt.step()
     got = eng.flat.cpu()
     for k in names:
