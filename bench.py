@@ -191,7 +191,9 @@ def cpu_baseline(cfg, feats, batch, budget_s, seed):
     fp[pre + "attention.output.LayerNorm.weight"] = torch.ones(D, requires_grad=True)
     fp[pre + "attention.output.LayerNorm.bias"] = torch.zeros(D, requires_grad=True)
     params = [ent, rel] + [w for p in proj for w in p.values()] + list(fp.values())
-    opt = torch.optim.AdamW(params, lr=cfg.lr, weight_decay=cfg.weight_decay)
+    undecayed = [v for k, v in fp.items() if "bias" in k or k == "weight_raw"]                  # set_optim groups (src/utils.py:47-55)
+    decayed = [p for p in params if not any(p is u for u in undecayed)]
+    opt = torch.optim.AdamW([{"params": decayed, "weight_decay": cfg.weight_decay}, {"params": undecayed, "weight_decay": 0.0}], lr=cfg.lr)
     M = cfg.n_tokens
     noise = torch.randn(N, D, generator=g) * 0.01
     nmask = torch.rand(N, generator=g) < cfg.noise_ratio * 0.5
@@ -208,6 +210,8 @@ def cpu_baseline(cfg, feats, batch, budget_s, seed):
         loss, _, _ = O.score_margin(hidden[:, M - 1, :], rel, h, r, t, neg, cfg.margin)
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        if cfg.clip > 0:
+            torch.nn.utils.clip_grad_norm_(params, cfg.clip)
         opt.step()
         return float(loss.detach())
 
@@ -235,7 +239,7 @@ def cpu_baseline(cfg, feats, batch, budget_s, seed):
     times.sort()
     med = times[len(times) // 2]
     return {"value": batch / med, "unit": "triples/s", "cores": best_thr, "kind": "port",
-            "sample": f"{len(times)} steps of the same workload (N={N}, B={batch}, K={cfg.neg_num}, fwd+bwd+AdamW) at {best_thr} of "
+            "sample": f"{len(times)} steps of the same workload (N={N}, B={batch}, K={cfg.neg_num}, fwd+bwd+clip+AdamW) at {best_thr} of "
                       f"{avail} usable threads, median {med * 1e3:.0f} ms/step, torch {torch.__version__} CPU"}
 
 
