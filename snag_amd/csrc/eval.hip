@@ -59,40 +59,42 @@ struct DistEpilogue {
 };
 
 // ---- small sorted top-k buffer in registers ----------------------------------------------------------
+// KK >= k slots (compile-time: 3, 5, 10 or 16, so that csls_k = 3 pays for 3 compare-exchanges, not 16); the k largest are v[0..k-1].
+template <int KK>
 struct TopK {
-    float v[kMaxK];     // descending; slots >= k stay at -inf
+    float v[KK];        // descending
     __device__ __forceinline__ void init() {
 #pragma unroll
-        for (int i = 0; i < kMaxK; ++i) v[i] = -INFINITY;
+        for (int i = 0; i < KK; ++i) v[i] = -INFINITY;
     }
-    __device__ __forceinline__ void push(float x, int k) {
+    __device__ __forceinline__ void push(float x) {
+        if (!(x > v[KK - 1])) return;           // cannot enter the buffer
 #pragma unroll
-        for (int i = 0; i < kMaxK; ++i) {       // insertion by compare-exchange down the array
-            if (i < k) {
-                const float hi = fmaxf(v[i], x), lo = fminf(v[i], x);
-                v[i] = hi;
-                x = lo;
-            }
+        for (int i = 0; i < KK; ++i) {          // insertion by compare-exchange down the array
+            const float hi = fmaxf(v[i], x), lo = fminf(v[i], x);
+            v[i] = hi;
+            x = lo;
         }
     }
 };
 
 // mean of the k largest entries of each row of S (or of 1 - D when from_dist): one block per row
+template <int KK>
 __global__ __launch_bounds__(256) void row_topk_mean_kernel(const float* __restrict__ mat, int64_t ld, int n, int m, int k, int from_dist,
                                                             float* __restrict__ out) {
-    __shared__ float cand[256 * kMaxK];
+    __shared__ float cand[256 * KK];
     __shared__ float wmax[4];
     __shared__ int wpos[4];
     const int row = blockIdx.x;
-    TopK t;
+    TopK<KK> t;
     t.init();
     for (int c = threadIdx.x; c < m; c += 256) {
         float s = mat[(int64_t)row * ld + c];
         if (from_dist) s = 1.0f - s;
-        t.push(s, k);
+        t.push(s);
     }
 #pragma unroll
-    for (int i = 0; i < kMaxK; ++i)
+    for (int i = 0; i < KK; ++i)
         if (i < k) cand[threadIdx.x * k + i] = t.v[i];
     __syncthreads();
     // k rounds of block-wide arg-max over the 256*k candidates (ties: any equal value gives the same sum)
@@ -128,33 +130,35 @@ __global__ __launch_bounds__(256) void row_topk_mean_kernel(const float* __restr
 }
 
 // per-column partial top-k over a chunk of rows: part[chunk][i][col], i < k
+template <int KK>
 __global__ __launch_bounds__(256) void col_topk_part_kernel(const float* __restrict__ mat, int64_t ld, int n, int m, int k, int from_dist,
                                                             int rows_per_chunk, float* __restrict__ part) {
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= m) return;
     const int r0 = blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
-    TopK t;
+    TopK<KK> t;
     t.init();
     for (int r = r0; r < r1; ++r) {
         float s = mat[(int64_t)r * ld + col];
         if (from_dist) s = 1.0f - s;
-        t.push(s, k);
+        t.push(s);
     }
 #pragma unroll
-    for (int i = 0; i < kMaxK; ++i)
+    for (int i = 0; i < KK; ++i)
         if (i < k) part[((int64_t)blockIdx.y * k + i) * m + col] = t.v[i];
 }
 
+template <int KK>
 __global__ __launch_bounds__(256) void col_topk_merge_kernel(const float* __restrict__ part, int chunks, int m, int k, float* __restrict__ out) {
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= m) return;
-    TopK t;
+    TopK<KK> t;
     t.init();
     for (int c = 0; c < chunks; ++c)
-        for (int i = 0; i < k; ++i) t.push(part[((int64_t)c * k + i) * m + col], k);
+        for (int i = 0; i < k; ++i) t.push(part[((int64_t)c * k + i) * m + col]);
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxK; ++i)
+    for (int i = 0; i < KK; ++i)
         if (i < k) acc += t.v[i];
     out[col] = acc / (float)k;
 }
@@ -340,12 +344,20 @@ extern "C" SNAG_API int snag_csls_neighbourhood(const float* mat, int64_t ld, in
     SNAG_REQUIRE(k <= n && k <= m, SNAG_ERR_ARG, "csls: k=%d larger than the matrix (%d x %d)", k, n, m);   // torch.topk raises too
     SNAG_REQUIRE(mat && r1 && r2 && work, SNAG_ERR_ARG, "csls: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(row_topk_mean_kernel, dim3(n), dim3(256), 0, st, mat, ld, n, m, k, from_dist, r1);
     const int chunks = std::min(kColChunks, n);
     const int rpc = ceil_div(n, chunks);
     const int nch = ceil_div(n, rpc);
-    hipLaunchKernelGGL(col_topk_part_kernel, dim3(ceil_div(m, 256), nch), dim3(256), 0, st, mat, ld, n, m, k, from_dist, rpc, work);
-    hipLaunchKernelGGL(col_topk_merge_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, st, (const float*)work, nch, m, k, r2);
+#define SNAG_TOPK(KK)                                                                                                                       \
+    do {                                                                                                                                    \
+        hipLaunchKernelGGL((row_topk_mean_kernel<KK>), dim3(n), dim3(256), 0, st, mat, ld, n, m, k, from_dist, r1);                          \
+        hipLaunchKernelGGL((col_topk_part_kernel<KK>), dim3(ceil_div(m, 256), nch), dim3(256), 0, st, mat, ld, n, m, k, from_dist, rpc, work); \
+        hipLaunchKernelGGL((col_topk_merge_kernel<KK>), dim3(ceil_div(m, 256)), dim3(256), 0, st, (const float*)work, nch, m, k, r2);         \
+    } while (0)
+    if (k <= 3) SNAG_TOPK(3);
+    else if (k <= 5) SNAG_TOPK(5);
+    else if (k <= 10) SNAG_TOPK(10);
+    else SNAG_TOPK(16);
+#undef SNAG_TOPK
     return check_launch("snag_csls_neighbourhood");
 }
 
