@@ -45,3 +45,49 @@ def test_ops_refuse_cpu_tensors():
     i = torch.zeros(2, dtype=torch.int64)
     with pytest.raises(_lib.SnagHipError):
         ops.score_margin_fwd(e, e, i, i, i, None, 1.0)
+
+
+def _prototypes():
+    """name -> list of C parameter types, parsed from include/snag_hip.h."""
+    text = open(os.path.join(ROOT, "include", "snag_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"SNAG_API\s+([\w\s\*]+?)\b(snag_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = [a.strip() for a in m.group(3).replace("\n", " ").split(",")]
+        if args == ["void"] or args == [""]:
+            args = []
+        types = []
+        for a in args:
+            a = re.sub(r"\b\w+$", "", a).strip() if not a.endswith("*") else a        # drop the parameter name
+            types.append(re.sub(r"\s+", " ", a))
+        out[m.group(2)] = (m.group(1).strip(), types)
+    return out
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Argument count and class (pointer / int / int64 / uint64 / float) of every ctypes binding equal the C prototype: a drifted
+    binding would corrupt arguments silently."""
+    from snag_amd import _lib
+
+    def cls(ctype_or_c):
+        if isinstance(ctype_or_c, str):
+            t = ctype_or_c
+            if "*" in t:
+                return "ptr"
+            t = t.replace("const", "").strip()
+            return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "uint64_t": "u64", "float": "f32", "double": "f64"}[t]
+        c = ctype_or_c
+        if c in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(c, "_type_") and isinstance(c._type_, type):
+            return "ptr"
+        return {ctypes.c_int: "i32", ctypes.c_int32: "i32", ctypes.c_int64: "i64", ctypes.c_uint64: "u64", ctypes.c_float: "f32",
+                ctypes.c_double: "f64"}[c]
+
+    protos = _prototypes()
+    table = dict(_lib.SIGNATURES)
+    table.update({k: v[0] for k, v in _lib._SPECIAL.items()})
+    assert set(protos) == set(table)
+    for name, (ret, ctypes_list) in protos.items():
+        bound = table[name]
+        assert len(bound) == len(ctypes_list), f"{name}: header has {len(ctypes_list)} parameters, the binding {len(bound)}"
+        for i, (c_t, b_t) in enumerate(zip(ctypes_list, bound)):
+            assert cls(c_t) == cls(b_t), f"{name} argument {i}: header '{c_t}' vs binding {b_t}"
