@@ -91,3 +91,50 @@ def test_ctypes_signatures_match_the_header_prototypes():
         assert len(bound) == len(ctypes_list), f"{name}: header has {len(ctypes_list)} parameters, the binding {len(bound)}"
         for i, (c_t, b_t) in enumerate(zip(ctypes_list, bound)):
             assert cls(c_t) == cls(b_t), f"{name} argument {i}: header '{c_t}' vs binding {b_t}"
+
+
+def _structs():
+    """struct name -> [(field, class)] in declaration order, parsed from include/snag_hip.h."""
+    text = open(os.path.join(ROOT, "include", "snag_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"typedef struct (snag_\w+) \{(.*?)\} \1;", text, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            mm = re.match(r"((?:const\s+)?[\w]+(?:\s*\*)?)\s*(.*)", decl)
+            base, names = mm.group(1).strip(), mm.group(2)
+            for nm in names.split(","):
+                nm = nm.strip()
+                ptr = "*" in base or nm.startswith("*")
+                nm = nm.lstrip("* ")
+                if ptr:
+                    kind = "ptr"
+                elif base.replace("const", "").strip().startswith("snag_"):
+                    kind = "struct"
+                else:
+                    kind = {"int32_t": "i32", "int": "i32", "int64_t": "i64", "float": "f32"}[base.replace("const", "").strip()]
+                fields.append((nm, kind))
+        out[m.group(1)] = fields
+    return out
+
+
+def test_ctypes_structures_match_the_header_structs():
+    from snag_amd import _lib
+    pairs = {"snag_gemm_desc": _lib.GemmDesc, "snag_fusion_layer": _lib.FusionLayer, "snag_fusion_layer_grad": _lib.FusionLayerGrad,
+             "snag_fusion_desc": _lib.FusionDesc, "snag_fusion_bwd_desc": _lib.FusionBwdDesc}
+    structs = _structs()
+    assert set(structs) == set(pairs)
+
+    def kind(c):
+        if isinstance(c, type) and issubclass(c, ctypes.Structure):
+            return "struct"
+        if c in (ctypes.c_void_p,) or hasattr(c, "contents") or (hasattr(c, "_type_") and not isinstance(c._type_, str)):
+            return "ptr"
+        return {ctypes.c_int32: "i32", ctypes.c_int: "i32", ctypes.c_int64: "i64", ctypes.c_float: "f32"}[c]
+
+    for name, cls in pairs.items():
+        got = [(n, kind(t)) for n, t in cls._fields_]
+        assert got == structs[name], f"{name}:\n header  {structs[name]}\n binding {got}"
