@@ -138,3 +138,34 @@ def test_ctypes_structures_match_the_header_structs():
     for name, cls in pairs.items():
         got = [(n, kind(t)) for n, t in cls._fields_]
         assert got == structs[name], f"{name}:\n header  {structs[name]}\n binding {got}"
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """The boundary is a C ABI: include/snag_hip.h compiles as C99 (-pedantic), and a C program linked against the shared library
+    calls it (argument refusal needs no GPU)."""
+    import shutil
+    import subprocess
+    from snag_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    _lib.load()
+    src = tmp_path / "client.c"
+    src.write_text(
+        '#include "snag_hip.h"\n#include <stdio.h>\n#include <string.h>\n'
+        "int main(void) {\n"
+        "    if (snag_version() != 1) return 2;\n"
+        "    int rc = snag_score_margin_fwd(0, 128, 10, 0, 2, 128, 0, 0, 0, 0, 4, 8, 4, 1.0f, 0, 0, 0, 0);\n"
+        "    if (rc != SNAG_ERR_ARG || strlen(snag_last_error()) == 0) return 3;\n"
+        "    snag_gemm_desc d; memset(&d, 0, sizeof d); d.M = -1;\n"
+        "    if (snag_gemm_f32(&d, 0) != SNAG_ERR_ARG) return 4;\n"
+        '    printf("%s\\n", snag_last_error());\n'
+        "    return 0;\n}\n")
+    exe = tmp_path / "client"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+           "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "gemm" in r.stdout
