@@ -106,3 +106,26 @@ def test_fusion_rejects_bad_input():
         mod([None, None])
     with pytest.raises(ValueError):
         mod([torch.zeros(4, 64, device=DEV)])
+
+
+def test_fusion_at_config5_scale_has_no_index_overflow():
+    """BASELINE config 5 shape for the fusion: 1,000,000 entities x 3 tokens x 256 (2.3e9 qkv elements, past 2^31).  Slices of the
+    full result must equal the same module run on just those entities, forward and backward."""
+    import types
+    from snag_amd.fusion import MformerFusion
+    N, D = 1_000_000, 256
+    a = types.SimpleNamespace(hidden_size=D, num_attention_heads=2, num_hidden_layers=1, use_intermediate=0, intermediate_size=400)
+    m = MformerFusion(a, modal_num=3).to(DEV).eval()
+    g = torch.Generator().manual_seed(0)
+    embs = [torch.randn(N, D, generator=g).to(DEV).requires_grad_(True) for _ in range(3)]
+    joint, joint_fz, hidden, w = m(embs + [None] * 3)
+    (hidden.sum() + joint.sum()).backward()
+    for lo in (0, 499_000, N - 1000):
+        sub = [e[lo:lo + 1000].detach().clone().requires_grad_(True) for e in embs]
+        j2, jf2, h2, w2 = m(sub + [None] * 3)
+        (h2.sum() + j2.sum()).backward()
+        for got, ref in ((h2, hidden[lo:lo + 1000]), (j2, joint[lo:lo + 1000]), (jf2, joint_fz[lo:lo + 1000]), (w2, w[lo:lo + 1000]),
+                         (sub[0].grad, embs[0].grad[lo:lo + 1000]), (sub[2].grad, embs[2].grad[lo:lo + 1000])):
+            assert float((got.detach() - ref.detach()).abs().max()) < 1e-6
+    del embs, joint, joint_fz, hidden, w
+    torch.cuda.empty_cache()
