@@ -119,3 +119,26 @@ def test_link_prediction_ranks_vs_oracle(N, D, B, idt):
     assert bool((res_u["rank"].cpu().long() >= got).all())                  # filtering can only improve a rank
     assert int((res_u["rank"].cpu().long() - ref_u).abs().max()) <= 1
     assert 0.0 < res["hits"][1] < 1.0 and res["hits"][0] <= res["hits"][1]
+
+
+def test_eval_past_2_31_matrix_elements():
+    """48,000 x 48,000 distance matrix (2.3e9 elements): CSLS + ranks of sampled rows / columns equal a direct recomputation."""
+    from snag_amd import evalsim as E
+    n, d = 48000, 64
+    g = torch.Generator().manual_seed(1)
+    x = torch.nn.functional.normalize(torch.randn(n, d, generator=g)).to(DEV)
+    y = torch.nn.functional.normalize(x.cpu() + 1.5 * torch.nn.functional.normalize(torch.randn(n, d, generator=g))).to(DEV)
+    res = E.rank_metrics(x, y, csls_k=3)
+    assert 0.0 < res["hits_l2r"][0] < 1.0
+    sim = 1.0 - res["dist"]
+    r1 = sim.topk(3, dim=1)[0].mean(1)
+    r2 = sim.topk(3, dim=0)[0].mean(0)
+    for i in (0, 777, 44739, 44740, n - 1):               # 44,739 * 48,000 is the last row below 2^31 elements
+        drow = 1.0 - ((2.0 * sim[i] - r1[i]) - r2)
+        assert int((drow < drow[i]).sum()) == int(res["rank_l2r"][i])
+        dcol = 1.0 - ((2.0 * sim[:, i] - r1) - r2[i])
+        assert int((dcol < dcol[i]).sum()) == int(res["rank_r2l"][i])
+    rows = torch.tensor([0, 44740, n - 1], device=DEV)
+    assert torch.equal(E.pairwise_distances(x[rows].contiguous(), y), res["dist"][rows])
+    del res, sim
+    torch.cuda.empty_cache()
