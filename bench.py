@@ -253,6 +253,7 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--config", default="db15k", choices=["db15k", "mkgw"],
                     help="db15k = BASELINE configs[1] (Mformer_hd_graph, num_proj=2, 558 relations); mkgw = configs[2] (Mformer_hd_mean, num_proj=1, 338 relations)")
+    ap.add_argument("--graph", action="store_true", help="replay the whole step (sampling included) as one captured hipGraph (1 GPU; no per-kernel timers)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (forward-only rate, copy ceiling, epoch-fused score probe)")
     args = ap.parse_args()
 
@@ -308,6 +309,21 @@ def main():
         if reducer is not None:
             reducer.finish()
         eng.optimizer_step()
+
+    if args.graph:
+        if world > 1:
+            sys.exit("--graph is single-process (collectives are not captured)")
+        eng.probe = None
+        timers = {}
+        if cfg.add_noise:
+            eng.update_noise()
+        eng.capture_step(args.batch, cfg.neg_num, sampler=lambda h, r, t, out: ops.sample_negatives(
+            h, r, t, cfg.neg_num, cfg.n_ent, cfg.n_rel, rank_seed, known_sorted=known, tick=eng.tick, out=out))
+
+        def one_step(i):                                  # noqa: F811  (graph replay variant)
+            if cfg.add_noise and i % STEPS_PER_EPOCH == 0 and i > 0:
+                eng.update_noise()
+            eng.replay_step(*batches[i % len(batches)])
 
     step_no = 0
     for _ in range(args.warmup):

@@ -444,6 +444,55 @@ class MKGCHotPath:
         self.optimizer_step()
         return self.loss
 
+    # ---- hipGraph replay of the whole step ------------------------------------------------------------------------------
+    def capture_step(self, batch, n_neg, sampler=None):
+        """Record forward + backward + clip + AdamW (and, when ``sampler`` is given, the on-device negative sampling) ONCE as a
+        hipGraph over static index buffers; ``replay_step(h, r, t)`` then costs three small copies and one graph launch on the
+        host.  Everything that varies per step already lives on the device: dropout seeds and Adam's bias correction read the
+        tick counter, the clip coefficient never leaves HBM.  Single-process only (collectives are not captured); the epoch-level
+        ``update_noise`` stays outside the graph (it writes the same buffers the graph reads).
+        ``sampler(h, r, t, out)`` must enqueue on the current stream without allocating."""
+        dev = self.dev
+        self._g_h = torch.zeros(batch, device=dev, dtype=torch.int32)
+        self._g_r = torch.zeros(batch, device=dev, dtype=torch.int32)
+        self._g_t = torch.zeros(batch, device=dev, dtype=torch.int32)
+        self._g_neg = torch.zeros(batch, n_neg, device=dev, dtype=torch.int32)
+        self._g_sampler = sampler
+
+        def body():
+            if sampler is not None:
+                sampler(self._g_h, self._g_r, self._g_t, self._g_neg)
+            self.train_step(self._g_h, self._g_r, self._g_t, self._g_neg)
+
+        tick0 = self.tick.clone()
+        snap = (self.flat.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                  # warm-up off the capture: buffers sized, code objects loaded
+            body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for dst, src in zip((self.flat, self.exp_avg, self.exp_avg_sq), snap):      # the warm-up step must not count
+            dst.copy_(src)
+        self.tick.copy_(tick0)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            body()
+        for dst, src in zip((self.flat, self.exp_avg, self.exp_avg_sq), snap):      # capture does not execute, but be explicit
+            dst.copy_(src)
+        self.tick.copy_(tick0)
+        return self._graph
+
+    def replay_step(self, h, r, t, neg_t=None):
+        """One training step through the captured graph; returns the device scalar loss."""
+        self._g_h.copy_(h, non_blocking=True)
+        self._g_r.copy_(r, non_blocking=True)
+        self._g_t.copy_(t, non_blocking=True)
+        if neg_t is not None:
+            self._g_neg.copy_(neg_t, non_blocking=True)
+        self._graph.replay()
+        return self.loss
+
     def entity_representation(self):
         """[N, dim] fused entity read-out of the last forward (a strided view of ``hidden`` for Mformer_hd_graph)."""
         if self.cfg.joint_way == "Mformer_hd_mean":

@@ -210,3 +210,30 @@ def test_optimizer_matches_torch_adamw_with_reference_param_groups(clip):
     for k in names:
         o, shp = eng.slices[k]
         assert_close(got[o:o + ref[k].numel()].view(shp), ref[k].detach(), atol=2e-6, rtol=2e-6, what=k)
+
+
+def test_graph_replay_equals_eager_steps():
+    """hipGraph capture of the whole step (capture_step / replay_step): same parameters as the eager steps after several steps,
+    dropout and the Adam step counter included (both read the device tick)."""
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    N, R, D, B, K = 1500, 17, 128, 128, 16
+    g = torch.Generator().manual_seed(31)
+    feats = [torch.rand(N, 96, generator=g), torch.randn(N, 40, generator=g)]
+    batches = [[torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(DEV) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (N, (B, K)))]
+               for _ in range(5)]
+
+    def make():
+        cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[96, 40], neg_num=K, dropout=0.1, add_noise=1, seed=9, lr=1e-3)
+        eng = MKGCHotPath(cfg, feats, device=DEV)
+        eng.update_noise(seed=4)
+        return eng
+    eager, graphed = make(), make()
+    assert torch.equal(eager.flat, graphed.flat)
+    losses_e = [float(eager.train_step(*b)) for b in batches]
+    graphed.capture_step(B, K)
+    losses_g = [float(graphed.replay_step(*b)) for b in batches]
+    assert int(eager.tick) == int(graphed.tick) == len(batches)
+    for a, b in zip(losses_e, losses_g):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a))
+    # identical up to the atomics' summation order inside score_bwd
+    assert float((eager.flat - graphed.flat).abs().max()) <= 1e-5
