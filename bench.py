@@ -253,6 +253,7 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--config", default="db15k", choices=["db15k", "mkgw"],
                     help="db15k = BASELINE configs[1] (Mformer_hd_graph, num_proj=2, 558 relations); mkgw = configs[2] (Mformer_hd_mean, num_proj=1, 338 relations)")
+    ap.add_argument("--deterministic", action="store_true", help="bit-reproducible steps (fixed-point integer atomics in the scorer's backward)")
     ap.add_argument("--graph", action="store_true", help="replay the whole step (sampling included) as one captured hipGraph (1 GPU; no per-kernel timers)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (forward-only rate, copy ceiling, epoch-fused score probe)")
     args = ap.parse_args()
@@ -277,6 +278,7 @@ def main():
     cfg = MKGCConfig()                                     # DB15K-shaped defaults (configs[1])
     if args.config == "mkgw":                              # configs[2]: README "MKG-W 1 0 Mformer_hd_mean 0.2 0.7 epoch 1 2"
         cfg.joint_way, cfg.num_proj, cfg.n_rel = "Mformer_hd_mean", 1, 338
+    cfg.deterministic = bool(args.deterministic)
     feats, batches, known = synth(cfg, args.batch, STEPS_PER_EPOCH, cfg.seed, device)
     from snag_amd import ops
     neg_buf = torch.empty(args.batch, cfg.neg_num, device=device, dtype=torch.int32)

@@ -83,6 +83,16 @@ SNAG_API int snag_score_margin_bwd(const float* ent, int64_t ent_ld, int64_t n_e
                           const float* dpos, const float* dneg,
                           float* d_ent, int64_t d_ent_ld, float* d_rel, void* stream);
 
+/* Bit-reproducible variant of snag_score_margin_bwd: the same gradients accumulated with 64-bit INTEGER atomics in fixed point
+ * (32 fractional bits: sums are associative, so the result does not depend on the order the triples arrive in; |sum| < 2^31,
+ * resolution 2.3e-10).  acc_ent [n_ent, dim] and acc_rel [n_rel, dim] are dense int64 accumulators the caller zeroes;
+ * snag_fixed_to_float then writes (or adds) them into fp32 gradient rows with stride dst_ld. */
+SNAG_API int snag_score_margin_bwd_fixed(const float* ent, int64_t ent_ld, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+                          const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                          int64_t batch, int n_neg, float margin, float grad_scale,
+                          const float* dpos, const float* dneg, long long* acc_ent, long long* acc_rel, void* stream);
+SNAG_API int snag_fixed_to_float(const long long* acc, int64_t rows, int dim, float* dst, int64_t dst_ld, int accumulate, void* stream);
+
 /* Optional loss epilogue over the scores of snag_score_margin_fwd: self-adversarial negative sampling (SURVEY par. 8 a7; the only
  * in-tree traces are the unused flags --adv_temp / --emb_dim, config.py:53-54, so PARITY IS UNPINNED: oracle/ref_cpu.py selfadv_loss
  * restates the published formula).  Lower score = more plausible:

@@ -87,6 +87,8 @@ SIGNATURES = {
     "snag_gather_normalize_bwd": [_P, _P, _P, _I, _P, _I, _L, _I, _P, _L, _P],
     "snag_spmm_csr": [_P, _P, _P, _P, _L, _I, _P, _P, _P],
     "snag_transpose_f32": [_P, _L, _L, _L, _P, _L, _P],
+    "snag_score_margin_bwd_fixed": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P],
+    "snag_fixed_to_float": [_P, _L, _I, _P, _L, _I, _P],
     "snag_selfadv_loss": [_P, _P, _L, _I, _F, _F, _P, _P, _P, _P],
     "snag_gram_f32": [_P, _L, _I, _I, _F, _P, _L, _P],
     "snag_infonce_rows": [_P, _L, _I, _P, _P, _P],

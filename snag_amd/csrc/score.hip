@@ -180,9 +180,16 @@ __device__ __forceinline__ float normalize_s(RowS<NS>& x) {
 }
 
 // backward of F.normalize: dx = (dy - yhat (yhat . dy)) / ||x||   (clamped branch: dx = dy / eps)
-template <int NS>
+// Accumulators: float (fp32 atomics: fast, the last bits depend on the arrival order) or 64-bit fixed point with 32 fractional bits
+// (integer atomics: associative, so the sums are bit-reproducible whatever the order; |sum| < 2^31, resolution 2.3e-10).
+__device__ __forceinline__ void grad_add(float* p, float v) { atomicAdd(p, v); }
+__device__ __forceinline__ void grad_add(long long* p, float v) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn((double)v * 4294967296.0));
+}
+
+template <int NS, typename AccT>
 __device__ __forceinline__ void normalize_bwd_atomic(const RowS<NS>& yhat, float den, const RowS<NS>& dy,
-                                                     float* __restrict__ grad_row, int dim, int lane) {
+                                                     AccT* __restrict__ grad_row, int dim, int lane) {
     float dot = 0.f;
     if (den > 1e-12f) {
 #pragma unroll
@@ -193,17 +200,17 @@ __device__ __forceinline__ void normalize_bwd_atomic(const RowS<NS>& yhat, float
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int c = lane + 64 * i;
-        if (c < dim) atomicAdd(grad_row + c, (dy.v[i] - yhat.v[i] * dot) * inv);
+        if (c < dim) grad_add(grad_row + c, (dy.v[i] - yhat.v[i] * dot) * inv);
     }
 }
 
-template <typename IdxT, int NS>
+template <typename IdxT, int NS, typename AccT>
 __global__ __launch_bounds__(256) void score_bwd_kernel(
     const float* __restrict__ ent, int64_t eld, const float* __restrict__ rel, int dim,
     const IdxT* __restrict__ h, const IdxT* __restrict__ r, const IdxT* __restrict__ t,
     const IdxT* __restrict__ neg_t, int64_t batch, int n_neg, float margin, float gscale,
     const float* __restrict__ dpos, const float* __restrict__ dneg,
-    float* __restrict__ d_ent, int64_t dld, float* __restrict__ d_rel) {
+    AccT* __restrict__ d_ent, int64_t dld, AccT* __restrict__ d_rel) {
     const int64_t b = (int64_t)blockIdx.x * 4 + wave_id_uniform();
     if (b >= batch) return;
     const int lane = threadIdx.x & 63;
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(
                 dq.v[i] += e2;
                 dx.v[i] = -e2;
             }
-            normalize_bwd_atomic<NS>(x, den_x, dx, d_ent + xi * dld, dim, lane);
+            normalize_bwd_atomic<NS, AccT>(x, den_x, dx, d_ent + xi * dld, dim, lane);
         }
     };
     int k = 0;
@@ -282,10 +289,10 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(
             dq.v[i] += e2;
             dx.v[i] = -e2;
         }
-        normalize_bwd_atomic<NS>(tt, den_t, dx, d_ent + ti * dld, dim, lane);
+        normalize_bwd_atomic<NS, AccT>(tt, den_t, dx, d_ent + ti * dld, dim, lane);
     }
-    normalize_bwd_atomic<NS>(hh, den_h, dq, d_ent + hi * dld, dim, lane);
-    normalize_bwd_atomic<NS>(rr, den_r, dq, d_rel + ri * (int64_t)dim, dim, lane);
+    normalize_bwd_atomic<NS, AccT>(hh, den_h, dq, d_ent + hi * dld, dim, lane);
+    normalize_bwd_atomic<NS, AccT>(rr, den_r, dq, d_rel + ri * (int64_t)dim, dim, lane);
 }
 
 // rank[b] = #{n : score[b,n] < score[b, t_b], n not filtered}: the filtered link-prediction rank of the true tail
@@ -345,14 +352,14 @@ static int launch_fwd(const float* ent, int64_t eld, const float* rel, int dim, 
     return check_launch("snag_score_margin_fwd");
 }
 
-template <typename IdxT>
+template <typename IdxT, typename AccT>
 static int launch_bwd(const float* ent, int64_t eld, const float* rel, int dim, const void* h, const void* r, const void* t,
                       const void* neg_t, int64_t batch, int n_neg, float margin, float gscale, const float* dpos,
-                      const float* dneg, float* d_ent, int64_t dld, float* d_rel, hipStream_t st) {
+                      const float* dneg, AccT* d_ent, int64_t dld, AccT* d_rel, hipStream_t st) {
     const dim3 grid((unsigned)ceil_div(batch, 4)), block(256);
     const int ns = (dim + 63) / 64;
 #define SNAG_BWD(NS)                                                                                           \
-    hipLaunchKernelGGL((score_bwd_kernel<IdxT, NS>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h,        \
+    hipLaunchKernelGGL((score_bwd_kernel<IdxT, NS, AccT>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h,  \
                        (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, gscale, dpos, \
                        dneg, d_ent, dld, d_rel)
     switch (ns) {
@@ -540,8 +547,50 @@ extern "C" SNAG_API int snag_score_margin_bwd(const float* ent, int64_t ent_ld, 
     if (batch == 0) return SNAG_OK;
     hipStream_t st = (hipStream_t)stream;
     return idx_bytes == 4
-               ? launch_bwd<int32_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, d_ent, d_ent_ld, d_rel, st)
-               : launch_bwd<int64_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, d_ent, d_ent_ld, d_rel, st);
+               ? launch_bwd<int32_t, float>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, d_ent, d_ent_ld, d_rel, st)
+               : launch_bwd<int64_t, float>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, d_ent, d_ent_ld, d_rel, st);
+}
+
+extern "C" SNAG_API int snag_score_margin_bwd_fixed(const float* ent, int64_t ent_ld, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+                                                    const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes, int64_t batch,
+                                                    int n_neg, float margin, float grad_scale, const float* dpos, const float* dneg,
+                                                    long long* acc_ent, long long* acc_rel, void* stream) {
+    if (batch == 0) return SNAG_OK;
+    int rc = check_score_args(ent, n_ent, rel, n_rel, dim, h, r, t, neg_t, idx_bytes, batch, n_neg);
+    if (rc) return rc;
+    SNAG_REQUIRE(acc_ent && acc_rel, SNAG_ERR_ARG, "score_bwd_fixed: null accumulator");
+    SNAG_REQUIRE(n_neg == 0 || neg_t, SNAG_ERR_ARG, "score_bwd_fixed: neg_t is null but n_neg=%d", n_neg);
+    SNAG_REQUIRE(ent_ld >= dim, SNAG_ERR_ARG, "score_bwd_fixed: row stride smaller than dim=%d", dim);
+    SNAG_REQUIRE((dpos != nullptr) || (dneg == nullptr), SNAG_ERR_ARG, "score_bwd_fixed: dneg given without dpos");
+    SNAG_REQUIRE((dpos == nullptr) || (dneg != nullptr) || n_neg == 0, SNAG_ERR_ARG, "score_bwd_fixed: explicit mode needs both dpos and dneg");
+    hipStream_t st = (hipStream_t)stream;
+    return idx_bytes == 4
+               ? launch_bwd<int32_t, long long>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, acc_ent, dim, acc_rel, st)
+               : launch_bwd<int64_t, long long>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, acc_ent, dim, acc_rel, st);
+}
+
+namespace snag {
+__global__ __launch_bounds__(256) void fixed_to_float_kernel(const long long* __restrict__ acc, int64_t rows, int dim, float* __restrict__ dst,
+                                                             int64_t ld, int accumulate) {
+    const int64_t total = rows * dim;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / dim;
+        const int c = (int)(i % dim);
+        const float v = (float)((double)acc[i] * (1.0 / 4294967296.0));
+        float* o = dst + r * ld + c;
+        *o = accumulate ? *o + v : v;
+    }
+}
+}  // namespace snag
+
+extern "C" SNAG_API int snag_fixed_to_float(const long long* acc, int64_t rows, int dim, float* dst, int64_t dst_ld, int accumulate, void* stream) {
+    SNAG_REQUIRE(rows >= 0 && dim >= 1 && dst_ld >= dim, SNAG_ERR_ARG, "fixed_to_float: bad sizes");
+    if (rows == 0) return SNAG_OK;
+    SNAG_REQUIRE(acc && dst, SNAG_ERR_ARG, "fixed_to_float: null pointer");
+    const int64_t total = rows * dim;
+    hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)std::min<int64_t>(4096, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc, rows,
+                       dim, dst, dst_ld, accumulate);
+    return check_launch("snag_fixed_to_float");
 }
 
 namespace snag {

@@ -47,6 +47,7 @@ class MKGCConfig:
     dropout: float = 0.1                # nn.Dropout(0.1) inside the Bert blocks (SNAG_tools.py:169,216)
     lr: float = 1e-4                    # LR
     weight_decay: float = 1e-4
+    deterministic: bool = False         # bit-reproducible steps: the scorer's gradient scatter uses fixed-point integer atomics (+~10 us)
     clip: float = 1.0                   # torch.nn.utils.clip_grad_norm_ of the reference's train loop (main.py:266-268, --clip default 1.0); 0 = off
     seed: int = 1234
 
@@ -142,6 +143,9 @@ class MKGCHotPath:
         self._seg_end = torch.tensor([e for _, e, _ in self.param_groups], device=self.dev, dtype=torch.int64)
         self._seg_wd = torch.tensor([w for _, _, w in self.param_groups], device=self.dev, dtype=f32)
         self._seg_lr = torch.ones(len(self.param_groups), device=self.dev, dtype=f32)
+        if cfg.deterministic:
+            self._acc_ent = torch.zeros(N, D, device=self.dev, dtype=torch.int64)
+            self._acc_rel = torch.zeros(R, D, device=self.dev, dtype=torch.int64)
         self._clip = torch.ones(2, device=self.dev, dtype=f32)          # [clip coefficient, gradient norm] of the last step
         self._clip_work = torch.empty(1024, device=self.dev, dtype=f32)
 
@@ -391,9 +395,17 @@ class MKGCHotPath:
         else:
             self.d_hidden.zero_()
             d_repr, d_ld = self.d_hidden.data_ptr() + 4 * self.g_slot * D, MD
-        call("snag_score_margin_bwd", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r), ptr(t), ptr(neg_t),
-             ib, B, K, float(cfg.margin), float(grad_scale), *((ptr(self._dpos), ptr(self._dneg)) if cfg.loss == "self_adversarial" else (None, None)),
-             d_repr, d_ld, ptr(self.g["rel"]), st)
+        up = (ptr(self._dpos), ptr(self._dneg)) if cfg.loss == "self_adversarial" else (None, None)
+        if cfg.deterministic:
+            self._acc_ent.zero_()
+            self._acc_rel.zero_()
+            call("snag_score_margin_bwd_fixed", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r), ptr(t), ptr(neg_t),
+                 ib, B, K, float(cfg.margin), float(grad_scale), *up, ptr(self._acc_ent), ptr(self._acc_rel), st)
+            call("snag_fixed_to_float", ptr(self._acc_ent), N, D, d_repr, d_ld, 0, st)
+            call("snag_fixed_to_float", ptr(self._acc_rel), cfg.n_rel, D, ptr(self.g["rel"]), D, 0, st)
+        else:
+            call("snag_score_margin_bwd", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r), ptr(t), ptr(neg_t),
+                 ib, B, K, float(cfg.margin), float(grad_scale), *up, d_repr, d_ld, ptr(self.g["rel"]), st)
         if cfg.joint_way == "Mformer_hd_mean":
             call("snag_token_mean_bwd", ptr(self.d_repr), N, M, D, ptr(self.d_hidden), st)
         call("snag_fusion_bwd", ctypes.byref(self._bdesc), st)

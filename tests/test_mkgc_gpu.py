@@ -237,3 +237,30 @@ def test_graph_replay_equals_eager_steps():
         assert abs(a - b) <= 1e-5 * max(1.0, abs(a))
     # identical up to the atomics' summation order inside score_bwd
     assert float((eager.flat - graphed.flat).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("joint_way", ["Mformer_hd_graph", "Mformer_hd_mean"])
+def test_deterministic_mode_is_bit_reproducible_and_matches_the_default(joint_way):
+    """MKGCConfig.deterministic: the scorer's gradient scatter goes through fixed-point integer atomics, every other reduction is
+    fixed-order already, so two runs give identical bits; against the default (fp32 atomics) path the step agrees to rounding."""
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    N, R, D, B, K = 1200, 9, 128, 256, 32
+    g = torch.Generator().manual_seed(77)
+    feats = [torch.rand(N, 64, generator=g), torch.randn(N, 32, generator=g)]
+    batches = [[torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(DEV) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (60, (B, K)))]
+               for _ in range(6)]                        # negatives from 60 hub entities: hundreds of colliding scatter targets per row
+
+    def run(det):
+        cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[64, 32], joint_way=joint_way, neg_num=K, dropout=0.1, add_noise=1, seed=3, lr=1e-3,
+                         deterministic=det)
+        eng = MKGCHotPath(cfg, feats, device=DEV)
+        eng.update_noise(seed=2)
+        losses = [float(eng.train_step(*b)) for b in batches]
+        return eng.flat.clone(), eng.gflat.clone(), losses
+    a = run(True)
+    b = run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+    c = run(False)
+    scale = float(c[1].abs().max())
+    assert float((a[1] - c[1]).abs().max()) <= 1e-5 * scale
+    assert all(abs(x - y) <= 1e-5 * max(1.0, abs(y)) for x, y in zip(a[2], c[2]))

@@ -177,3 +177,31 @@ def test_device_negative_sampler():
     tail_rows = (nh == h.view(-1, 1)).all(1)
     assert bool((head_rows | tail_rows).all())
     assert 0.45 < float(head_rows.float().mean()) < 0.55
+
+
+def test_score_bwd_fixed_point_is_reproducible_and_equal_to_the_float_path():
+    """snag_score_margin_bwd_fixed + snag_fixed_to_float: integer atomics, so heavy collisions (every negative drawn from 8 rows)
+    give identical bits run after run; values equal the fp32-atomic kernel's to rounding."""
+    from snag_amd import ops
+    from snag_amd._lib import call, ptr, stream
+    N, R, D, B, K = 300, 5, 128, 512, 32
+    ent, rel, h, r, t, _ = _mk(N, R, D, B, K, seed=3, idt=torch.int32)
+    g = torch.Generator().manual_seed(4)
+    neg = torch.randint(0, 8, (B, K), generator=g, dtype=torch.int32)
+    d = [x.to(DEV) for x in (ent, rel, h, r, t, neg)]
+    de_ref, dr_ref = ops.score_margin_bwd(*d, 1.5)
+
+    def fixed():
+        acc_e = torch.zeros(N, D, device=DEV, dtype=torch.int64)
+        acc_r = torch.zeros(R, D, device=DEV, dtype=torch.int64)
+        call("snag_score_margin_bwd_fixed", ptr(d[0]), D, N, ptr(d[1]), R, D, ptr(d[2]), ptr(d[3]), ptr(d[4]), ptr(d[5]), 4, B, K, 1.5, 1.0, None, None,
+             ptr(acc_e), ptr(acc_r), stream())
+        de = torch.full((N, D + 8), 7.0, device=DEV)[:, :D]
+        dr = torch.empty(R, D, device=DEV)
+        call("snag_fixed_to_float", ptr(acc_e), N, D, ptr(de), de.stride(0), 0, stream())
+        call("snag_fixed_to_float", ptr(acc_r), R, D, ptr(dr), D, 0, stream())
+        return de.clone(), dr
+    a, b = fixed(), fixed()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert_close(a[0], de_ref, atol=1e-5 * float(de_ref.abs().max()), rtol=1e-5)
+    assert_close(a[1], dr_ref, atol=1e-5 * float(dr_ref.abs().max()), rtol=1e-5)
