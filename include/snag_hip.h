@@ -318,6 +318,9 @@ SNAG_API int snag_tick(uint64_t* tick, void* stream);
 SNAG_API int snag_row_sqnorm(const float* x, int64_t n, int d, int64_t ld, float* out, void* stream);
 SNAG_API int snag_pairwise_dist(const float* x, int64_t ldx, int n, const float* y, int64_t ldy, int m, int d,
                                 const float* xn, const float* yn, float* out, int64_t ld_out, int as_similarity, void* stream);
+/* --distance 1 of Runner._test (main.py:388-391: scipy cdist(..., metric="cityblock") on the CPU): out[i,j] = sum_k |x[i,k] - y[j,k]|. */
+SNAG_API int snag_cityblock_dist(const float* x, int64_t ldx, int n, const float* y, int64_t ldy, int m, int d, float* out, int64_t ld_out,
+                                 void* stream);
 SNAG_API int64_t snag_eval_work_floats(int n, int m);
 SNAG_API int snag_csls_neighbourhood(const float* mat, int64_t ld, int n, int m, int k, int from_dist,
                                      float* r1, float* r2, float* work, void* stream);

@@ -86,6 +86,7 @@ SIGNATURES = {
     "snag_gather_normalize_fwd": [_P, _L, _L, _I, _P, _I, _L, _I, _P, _P, _P],
     "snag_gather_normalize_bwd": [_P, _P, _P, _I, _P, _I, _L, _I, _P, _L, _P],
     "snag_spmm_csr": [_P, _P, _P, _P, _L, _I, _P, _P, _P],
+    "snag_cityblock_dist": [_P, _L, _I, _P, _L, _I, _I, _P, _L, _P],
     "snag_transpose_f32": [_P, _L, _L, _L, _P, _L, _P],
     "snag_score_margin_bwd_fixed": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P],
     "snag_fixed_to_float": [_P, _L, _I, _P, _L, _I, _P],

@@ -335,6 +335,60 @@ extern "C" SNAG_API int snag_pairwise_dist(const float* x, int64_t ldx, int n, c
     return check_launch("snag_pairwise_dist");
 }
 
+namespace snag {
+// out[i,j] = sum_k |x[i,k] - y[j,k]|  (--distance 1: scipy cdist(metric="cityblock") in Runner._test, main.py:388-391).
+// Not a GEMM: 64 x 64 output tile per block, 4 x 4 per thread, k staged through LDS in slabs of 32 (k-major, pitch 65).
+__global__ __launch_bounds__(256) void cityblock_kernel(const float* __restrict__ x, int64_t ldx, int n, const float* __restrict__ y, int64_t ldy, int m,
+                                                        int d, float* __restrict__ out, int64_t ldo) {
+    __shared__ float xs[32][65], ys[32][65];
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    for (int k0 = 0; k0 < d; k0 += 32) {
+        for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+            const int r = e >> 5, k = e & 31;
+            xs[k][r] = (i0 + r < n && k0 + k < d) ? x[(int64_t)(i0 + r) * ldx + k0 + k] : 0.f;
+            ys[k][r] = (j0 + r < m && k0 + k < d) ? y[(int64_t)(j0 + r) * ldy + k0 + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            float xv[4], yv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) xv[a] = xs[k][ty + 16 * a];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) yv[b] = ys[k][tx + 16 * b];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += fabsf(xv[a] - yv[b]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * b;
+            if (i < n && j < m) out[(int64_t)i * ldo + j] = acc[a][b];
+        }
+}
+}  // namespace snag
+
+extern "C" SNAG_API int snag_cityblock_dist(const float* x, int64_t ldx, int n, const float* y, int64_t ldy, int m, int d, float* out, int64_t ld_out,
+                                            void* stream) {
+    SNAG_REQUIRE(n >= 0 && m >= 0 && d >= 0 && ldx >= d && ldy >= d && ld_out >= m, SNAG_ERR_ARG, "cityblock_dist: bad sizes");
+    if (n == 0 || m == 0) return SNAG_OK;
+    SNAG_REQUIRE(out && ((x && y) || d == 0), SNAG_ERR_ARG, "cityblock_dist: null pointer");
+    SNAG_REQUIRE(ceil_div(n, 64) <= 65535, SNAG_ERR_UNSUPPORTED, "cityblock_dist: more than 4M rows");
+    hipLaunchKernelGGL(cityblock_kernel, dim3(ceil_div(m, 64), ceil_div(n, 64)), dim3(256), 0, (hipStream_t)stream, x, ldx, n, y, ldy, m, d, out, ld_out);
+    return check_launch("snag_cityblock_dist");
+}
+
 extern "C" SNAG_API int64_t snag_eval_work_floats(int n, int m) { return (int64_t)2 * kColChunks * kMaxK * std::max(n, m) + 64; }
 
 extern "C" SNAG_API int snag_csls_neighbourhood(const float* mat, int64_t ld, int n, int m, int k, int from_dist, float* r1, float* r2, float* work,

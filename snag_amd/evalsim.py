@@ -41,6 +41,20 @@ def pairwise_distances(x, y=None, as_similarity=False, _padded=False):
     return out
 
 
+def cityblock_distances(x, y=None, _padded=False):
+    """dist[i,j] = sum_k |x_i[k] - y_j[k]|: what ``--distance 1`` computes with scipy's cdist on the CPU (main.py:388-391)."""
+    ops._rows(x, "x")
+    if y is None:
+        y = x
+    ops._rows(y, "y")
+    if x.shape[1] != y.shape[1]:
+        raise ValueError(f"cityblock_distances: feature sizes differ ({x.shape[1]} vs {y.shape[1]})")
+    n, m, d = x.shape[0], y.shape[0], x.shape[1]
+    out = torch.empty(n, (m + 31) // 32 * 32, device=x.device, dtype=f32)[:, :m] if _padded else torch.empty(n, m, device=x.device, dtype=f32)
+    call("snag_cityblock_dist", ptr(x), x.stride(0), n, ptr(y), y.stride(0), m, d, ptr(out), out.stride(0), stream())
+    return out
+
+
 def _neighbourhood(mat, k, from_dist):
     n, m = mat.shape
     r1 = torch.empty(n, device=mat.device, dtype=f32)
@@ -60,13 +74,15 @@ def csls_sim(sim_mat, k):
     return out
 
 
-def rank_metrics(emb_left, emb_right, csls_k=0, top_k=(1, 10, 50)):
+def rank_metrics(emb_left, emb_right, csls_k=0, top_k=(1, 10, 50), distance=2):
     """Runner._test after the gather/normalise: ranks, Hits@k (rounded to 4 dp), MR, MRR in both directions.
 
     emb_left[i] and emb_right[i] are the i-th aligned test pair (``final_emb[test_left]``, ``final_emb[test_right]``,
-    main.py:386).  csls_k = 0 disables CSLS (``--csls`` off).
+    main.py:386).  csls_k = 0 disables CSLS (``--csls`` off); ``distance`` is ``--distance`` (2 = squared Euclidean, 1 = cityblock).
     """
-    dist = pairwise_distances(emb_left, emb_right, _padded=True)
+    if distance not in (1, 2):
+        raise ValueError("distance must be 1 (cityblock) or 2 (squared Euclidean), as --distance")
+    dist = pairwise_distances(emb_left, emb_right, _padded=True) if distance == 2 else cityblock_distances(emb_left, emb_right, _padded=True)
     n, m = dist.shape
     if n != m:
         raise ValueError("rank_metrics: left and right must hold the same number of aligned rows")

@@ -151,3 +151,19 @@ def test_eval_past_2_31_matrix_elements():
     assert torch.equal(E.pairwise_distances(x[rows].contiguous(), y), res["dist"][rows])
     del res, sim
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n,m,d", [(1, 1, 1), (65, 130, 33), (300, 257, 64), (500, 500, 1200)])
+def test_cityblock_distance_and_ranks(n, m, d):
+    """--distance 1 (main.py:388-391): sum_k |x - y| vs torch.cdist(p=1); ranks through the same count-less-than kernels."""
+    from snag_amd import evalsim as E
+    g = torch.Generator().manual_seed(n + m + d)
+    x, y = torch.randn(n, d, generator=g), torch.randn(m, d, generator=g)
+    got = E.cityblock_distances(x.to(DEV), y.to(DEV))
+    ref = torch.cdist(x.double(), y.double(), p=1)
+    assert_close(got, ref, atol=1e-5 * max(1.0, float(ref.max())))
+    if n == m and n > 1:
+        res = E.rank_metrics(x.to(DEV), (x + 0.7 * y).to(DEV), csls_k=0, distance=1)
+        dd = torch.cdist(x.double(), (x + 0.7 * y).double(), p=1)
+        rk = (dd < dd.diag().view(-1, 1)).sum(1)
+        assert float((res["rank_l2r"].cpu().long() != rk).float().mean()) < 0.01          # fp32 vs fp64 near-ties only
