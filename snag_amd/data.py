@@ -14,9 +14,11 @@ checkpoints it writes, restated with the reference's function names, argument me
   whole loader                                                              load_eva_data / load_data (src/data.py:46-76,135-272)
   checkpoints: torch.save(model.state_dict()) as <name>.pkl                 save_model / load_model   (main.py:457-500)
 
-Not built (never reached by run_snag.sh): name / char features (``w_name`` / ``w_char``: GloVe + bigram files) and the unsupervised
-visual-pivot split (``unsup``); both raise NotImplementedError.
+  surface forms (``--use_surface 1``): GloVe word vectors + character bigrams of the translated entity names
+      load_word2vec / load_char_bigram / load_word_char_features (src/data.py:274-365)
+  unsupervised seed links (``--unsup``): mutual-best visual pivots          visual_pivot_induction (src/data.py:367-404), get_topk_indices (src/utils.py:437-443)
 """
+import json
 import os
 import os.path as osp
 import pickle
@@ -175,6 +177,116 @@ def load_img(logger, e_num, path, ills):
     return img_embd, ent_wo_img, ent_w_img
 
 
+def load_word2vec(path, dim=300):
+    """GloVe / fastText text file -> {lower-cased word: float64 vector}; lines that do not have dim + 1 fields or do not parse are
+    skipped (src/data.py:274-298)."""
+    word2vec = {}
+    with open(path, "r", encoding="utf-8") as f:
+        for line in f:
+            parts = line.strip("\n").split(" ")
+            if len(parts) != dim + 1:
+                continue
+            try:
+                word2vec[parts[0].lower()] = np.array([float(x) for x in parts[1:]], dtype=np.float64)
+            except ValueError:
+                continue
+    return word2vec
+
+
+def load_char_bigram(path):
+    """translated entity names [[id, [word, ...]], ...] -> (names, {character bigram: index in first-seen order}) (src/data.py:300-316)."""
+    with open(path, "r") as f:
+        ent_names = json.load(f)
+    char2id = {}
+    for _, name in ent_names:
+        for word in name:
+            word = word.lower()
+            for i in range(len(word) - 1):
+                char2id.setdefault(word[i:i + 2], len(char2id))
+    return ent_names, char2id
+
+
+def load_word_char_features(node_size, word2vec_path, args, logger):
+    """Name features (mean GloVe vector of the name's known words) and character-bigram counts, both L2-normalised per entity
+    (src/data.py:318-365).  Entities without a known word / without a bigram get ``np.random.random(.) - 0.5`` from numpy's GLOBAL RNG,
+    in entity order, name draw before char draw.  The two arrays are cached as pickles under <data_path>/embedding/ exactly as the
+    reference does (and read back from there when present)."""
+    name_path = osp.join(args.data_path, "DBP15K", "translated_ent_name", "dbp_" + args.data_split + ".json")
+    if not osp.exists(name_path):
+        raise FileNotFoundError(name_path)
+    save_name = osp.join(args.data_path, "embedding", f"dbp_{args.data_split}_name.pkl")
+    save_char = osp.join(args.data_path, "embedding", f"dbp_{args.data_split}_char.pkl")
+    if osp.exists(save_name) and osp.exists(save_char):
+        with open(save_name, "rb") as f1, open(save_char, "rb") as f2:
+            return pickle.load(f1), pickle.load(f2)
+    word_vecs = load_word2vec(word2vec_path)
+    ent_names, char2id = load_char_bigram(name_path)
+    ent_vec = np.zeros((node_size, 300))
+    char_vec = np.zeros((node_size, len(char2id)))
+    for i, name in ent_names:
+        known = 0
+        for word in name:
+            word = word.lower()
+            if word in word_vecs:
+                ent_vec[i] += word_vecs[word]
+                known += 1
+            for j in range(len(word) - 1):
+                char_vec[i, char2id[word[j:j + 2]]] += 1
+        if known:
+            ent_vec[i] /= known
+        else:
+            ent_vec[i] = np.random.random(300) - 0.5
+        if np.sum(char_vec[i]) == 0:
+            char_vec[i] = np.random.random(len(char2id)) - 0.5
+        ent_vec[i] = ent_vec[i] / np.linalg.norm(ent_vec[i])
+        char_vec[i] = char_vec[i] / np.linalg.norm(char_vec[i])
+    os.makedirs(osp.dirname(save_name), exist_ok=True)
+    with open(save_name, "wb") as f:
+        pickle.dump(ent_vec, f)
+    with open(save_char, "wb") as f:
+        pickle.dump(char_vec, f)
+    if logger is not None:
+        logger.info("save entity emb done. ")
+    return ent_vec, char_vec
+
+
+def get_topk_indices(M, K=1000):
+    """(row, col) of the K largest entries of a matrix, best first (src/utils.py:437-443)."""
+    H, W = M.shape
+    vals, indices = M.reshape(-1).topk(K)
+    return torch.cat(((indices // W).unsqueeze(1), (indices % W).unsqueeze(1)), dim=1)
+
+
+def visual_pivot_induction(args, left_ents, right_ents, img_features, ills, logger):
+    """Unsupervised seed alignment (src/data.py:367-404): walk the unsup_k * 100 most similar (left, right) pairs best first and keep a
+    pair when neither entity is taken yet, until unsup_k pairs are found.  The similarity product runs wherever ``img_features`` lives
+    (on the GPU it is one exact-f32 MFMA GEMM through snag_amd.ops.gemm)."""
+    l_img, r_img = img_features[left_ents], img_features[right_ents]
+    if l_img.is_cuda:
+        from . import ops
+        sim = ops.gemm(l_img.contiguous().float(), r_img.contiguous().float())
+    else:
+        sim = l_img.mm(r_img.t())
+    topk = args.unsup_k
+    pairs = get_topk_indices(sim, min(topk * 100, sim.numel())).cpu().tolist()
+    del sim
+    used, links = set(), []
+    for li, ri in pairs:
+        a, b = left_ents[li], right_ents[ri]
+        if a in used or b in used:
+            continue
+        used.add(a)
+        used.add(b)
+        links.append((a, b))
+        if len(links) == topk:
+            break
+    if logger is not None and links:
+        truth = set(tuple(x) for x in ills)
+        logger.info(f"{(100.0 * sum(1 for l in links if l in truth) / len(links)):.2f}% in true links")
+        logger.info(f"visual links length: {len(links)}")
+    return np.array(links, dtype=np.int32)
+
+
 def normalize_adj(mx):
     """D^-1/2 A^T D^-1/2 with D = row sums (src/utils.py:220-226; the reference's product order transposes A)."""
     import scipy.sparse as sp
@@ -248,13 +360,26 @@ def load_eva_data(logger, args):
     if not osp.exists(img_vec_path):
         raise FileNotFoundError(img_vec_path)
     img_features, ent_wo_img, ent_w_img = load_img(logger, ent_num, img_vec_path, ills)
-    if getattr(args, "w_name", False) or getattr(args, "w_char", False):
-        if args.data_choice == "DBP15K":
-            raise NotImplementedError("name / char features (GloVe + bigram files, src/data.py:181-193) are not built")
-    if getattr(args, "unsup", False):
-        raise NotImplementedError("unsupervised visual-pivot split (src/data.py:195-205) is not built")
+    name_features = char_features = None
+    if args.data_choice == "DBP15K" and (getattr(args, "w_name", False) or getattr(args, "w_char", False)):      # :176-193
+        if getattr(args, "word_embedding", "glove") != "glove":
+            raise Exception("error word embedding")
+        word2vec_path = osp.join(args.data_path, "embedding", "glove.6B.300d.txt")
+        ent_vec, char_vec = load_word_char_features(ent_num, word2vec_path, args, logger)
+        name_features = torch.nn.functional.normalize(torch.Tensor(ent_vec))
+        char_features = torch.nn.functional.normalize(torch.Tensor(char_vec))
     cut = int(len(ills) // 1 * args.data_rate)
-    train_ill = np.array(ills[:cut], dtype=np.int32)
+    if getattr(args, "unsup", False):                                                                            # :195-205
+        mode = getattr(args, "unsup_mode", "img")
+        if mode == "char":
+            input_features = char_features
+        elif mode == "name":
+            input_features = name_features
+        else:
+            input_features = torch.nn.functional.normalize(torch.Tensor(img_features))
+        train_ill = visual_pivot_induction(args, left_ents, right_ents, input_features, ills, logger)
+    else:
+        train_ill = np.array(ills[:cut], dtype=np.int32)
     test_ill_ = ills[cut:]
     test_ill = np.array(test_ill_, dtype=np.int32)
     left_non_train = list(set(left_ents) - set(train_ill[:, 0].tolist()))
@@ -266,7 +391,7 @@ def load_eva_data(logger, args):
                     f"train ill: {train_ill.shape[0]}  test ill: {test_ill.shape[0]}  without image: {len(ent_wo_img)}")
     kgs = {
         "ent_num": ent_num, "rel_num": rel_num, "images_list": img_features, "rel_features": rel_features,
-        "att_features": att_features, "name_features": None, "char_features": None,
+        "att_features": att_features, "name_features": name_features, "char_features": char_features,
         "input_idx": torch.LongTensor(np.arange(ent_num)), "ent_wo_img": ent_wo_img, "ent_w_img": ent_w_img,
         "adj": get_adjr(ent_num, triples, norm=True), "train_ill": train_ill,
     }

@@ -20,6 +20,7 @@ Vectors (SURVEY.md par. 8c):
   g10_snag_model.npz the whole in-tree SNAG model: SNAG.forward/update_noise/joint_emb_generat (model/SNAG.py) loss + grads
   g11_data.npz       dataset readers on a tiny synthetic DBP15K-layout directory: read_raw_data / load_relation / load_attr / load_img /
                      get_adjr / load_eva_data (src/data.py, src/utils.py:327-362); the fixture holds the synthetic files and the outputs
+  g13_data_surface_unsup.npz  loader options: GloVe name / character-bigram features (--use_surface) and unsupervised visual pivots (--unsup)
   g12_gcn.npz        GCN structural encoder option (model/Tool_model.py:98-110, model/layers.py:102-130), output and grads
   g8_icl_loss.npz    icl_loss (bidirectional InfoNCE, model/SNAG_loss.py:31-128) + CustomMultiLossLayer, loss and grads
 """
@@ -619,6 +620,62 @@ def gen_g11():
                   "train_ill": kgs["train_ill"], "test_ill": np.array(test_ill_), "left_non_train": np.array(non_train["left"]),
                   "right_non_train": np.array(non_train["right"]), "input_idx": kgs["input_idx"]})
     save("g11_data.npz", d)
+
+
+def gen_g13():
+    """Surface-form features and the unsupervised split of the loader, on golden G11's synthetic dataset plus a synthetic 300-d GloVe
+    file and translated-name JSON: load_word_char_features / load_eva_data(w_name, w_char) / load_eva_data(unsup) (src/data.py)."""
+    import json
+    import pickle
+    import src.data as ref_data
+    z = dict(np.load(os.path.join(OUT, "g11_data.npz")))
+    rng = np.random.RandomState(77)
+    N = int(z["ent_num"])
+    vocab = [f"w{i}" for i in range(40)]
+    glove = "".join(w + " " + " ".join(f"{v:.5f}" for v in rng.randn(300)) + "\n" for w in vocab)
+    glove += "badline 1.0 2.0\n" + "w_nan " + " ".join(["x"] * 300) + "\n"                 # wrong width, unparsable: both skipped
+    names = []
+    for i in range(N):
+        kind = i % 9
+        if kind == 0:
+            words = ["zzunknown"]                                 # no GloVe hit: random name vector; still has bigrams
+        elif kind == 1:
+            words = ["q"]                                         # no hit and no bigram: both random
+        else:
+            words = [vocab[j] for j in rng.randint(0, 40, rng.randint(1, 4))] + (["Mixed" + vocab[i % 40].upper()] if kind == 2 else [])
+        names.append([i, words])
+    names_json = json.dumps(names)
+    with tempfile.TemporaryDirectory() as root:
+        file_dir = os.path.join(root, "DBP15K", "zh_en")
+        os.makedirs(file_dir)
+        os.makedirs(os.path.join(root, "pkls"))
+        os.makedirs(os.path.join(root, "embedding"))
+        os.makedirs(os.path.join(root, "DBP15K", "translated_ent_name"))
+        for name in z["file_names"]:
+            with open(os.path.join(file_dir, str(name)), "wb") as f:
+                f.write(z["file." + str(name)].tobytes())
+        with open(os.path.join(root, "pkls", "zh_en_GA_id_img_feature_dict.pkl"), "wb") as f:
+            pickle.dump({int(i): v for i, v in zip(z["img_ids"], z["img_vecs"])}, f)
+        with open(os.path.join(root, "embedding", "glove.6B.300d.txt"), "w", encoding="utf-8") as f:
+            f.write(glove)
+        with open(os.path.join(root, "DBP15K", "translated_ent_name", "dbp_zh_en.json"), "w") as f:
+            f.write(names_json)
+        args = types.SimpleNamespace(data_path=root, data_choice="DBP15K", data_split="zh_en", ratio="1.0", data_rate=0.3, word_embedding="glove",
+                                     w_name=1, w_char=1, unsup=0, unsup_mode="img", unsup_k=10)
+        np.random.seed(321)
+        kgs, non_train, _, _, _, test_ill_ = ref_data.load_eva_data(logging.getLogger("g13"), args)
+        d = {"glove": np.frombuffer(glove.encode("utf-8"), dtype=np.uint8), "names_json": np.frombuffer(names_json.encode("utf-8"), dtype=np.uint8),
+             "seed": 321, "name_features": kgs["name_features"], "char_features": kgs["char_features"], "images_list": kgs["images_list"],
+             "train_ill": kgs["train_ill"], "cached_name": pickle.load(open(os.path.join(root, "embedding", "dbp_zh_en_name.pkl"), "rb")),
+             "cached_char": pickle.load(open(os.path.join(root, "embedding", "dbp_zh_en_char.pkl"), "rb"))}
+        for mode in ("img", "name", "char"):
+            args.unsup, args.unsup_mode = 1, mode
+            np.random.seed(321)
+            kgs_u, non_u, _, _, _, test_u = ref_data.load_eva_data(logging.getLogger("g13"), args)
+            d[f"unsup_{mode}.train_ill"] = kgs_u["train_ill"]
+            d[f"unsup_{mode}.test_ill"] = np.array(test_u)
+            d[f"unsup_{mode}.left_non_train"] = np.array(non_u["left"])
+    save("g13_data_surface_unsup.npz", d)
 
 
 if __name__ == "__main__":

@@ -84,3 +84,40 @@ def test_checkpoint_round_trip_with_reference_keys(tmp_path):
     m3 = MformerFusion(a, modal_num=3)
     D.load_model(m3, path)
     assert all(torch.equal(v, m3.state_dict()[k]) for k, v in m1.state_dict().items())
+
+
+def _materialise_surface(z11, z13, root):
+    _materialise(z11, root)
+    os.makedirs(os.path.join(root, "embedding"))
+    os.makedirs(os.path.join(root, "DBP15K", "translated_ent_name"))
+    with open(os.path.join(root, "embedding", "glove.6B.300d.txt"), "wb") as f:
+        f.write(z13["glove"].tobytes())
+    with open(os.path.join(root, "DBP15K", "translated_ent_name", "dbp_zh_en.json"), "wb") as f:
+        f.write(z13["names_json"].tobytes())
+
+
+def test_surface_features_and_unsupervised_split_match_reference(tmp_path):
+    """--use_surface (GloVe name vectors + character bigrams, src/data.py:274-365) and --unsup (visual pivots, :367-404), golden G13."""
+    z11, z13 = load("g11_data.npz"), load("g13_data_surface_unsup.npz")
+    root = str(tmp_path)
+    _materialise_surface(z11, z13, root)
+    args = types.SimpleNamespace(data_path=root, data_choice="DBP15K", data_split="zh_en", ratio="1.0", data_rate=0.3, word_embedding="glove",
+                                 w_name=1, w_char=1, unsup=0, unsup_mode="img", unsup_k=10)
+    wv = D.load_word2vec(os.path.join(root, "embedding", "glove.6B.300d.txt"))
+    assert len(wv) == 40 and "badline" not in wv and "w_nan" not in wv
+    np.random.seed(int(z13["seed"]))
+    kgs, *_ = D.load_data(logging.getLogger("t"), args)
+    assert torch.equal(kgs["name_features"], torch.from_numpy(z13["name_features"]))
+    assert torch.equal(kgs["char_features"], torch.from_numpy(z13["char_features"]))
+    assert np.array_equal(kgs["images_list"], z13["images_list"]) and np.array_equal(kgs["train_ill"], z13["train_ill"])
+    with open(os.path.join(root, "embedding", "dbp_zh_en_name.pkl"), "rb") as f:          # the cache files the reference would read back
+        assert np.array_equal(pickle.load(f), z13["cached_name"])
+    with open(os.path.join(root, "embedding", "dbp_zh_en_char.pkl"), "rb") as f:
+        assert np.array_equal(pickle.load(f), z13["cached_char"])
+    for mode in ("img", "name", "char"):
+        args.unsup, args.unsup_mode = 1, mode
+        np.random.seed(int(z13["seed"]))
+        kgs_u, non_u, _, _, _, test_u = D.load_data(logging.getLogger("t"), args)
+        assert np.array_equal(kgs_u["train_ill"], z13[f"unsup_{mode}.train_ill"]), mode
+        assert np.array_equal(np.array(test_u), z13[f"unsup_{mode}.test_ill"])
+        assert non_u["left"] == z13[f"unsup_{mode}.left_non_train"].tolist()

@@ -180,3 +180,53 @@ def test_snag_model_with_gcn_structure_encoder():
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0], losses
     assert model.multimodal_encoder.cross_graph_model.gc1.weight.grad.abs().sum() > 0
+
+
+def test_surface_form_modalities_end_to_end(tmp_path):
+    """--use_surface 1 (run_snag.sh $6): the loader's GloVe name and character-bigram features become two more modality tokens
+    (6 in all: img, att, rel, gph, name, char); the HIP model trains on them."""
+    import logging
+    import os
+    import pickle
+    from snag_amd import data as D
+    from snag_amd.mmea import SNAG
+    z11, z13 = load("g11_data.npz"), load("g13_data_surface_unsup.npz")
+    root = str(tmp_path)
+    file_dir = os.path.join(root, "DBP15K", "zh_en")
+    for d in (file_dir, os.path.join(root, "pkls"), os.path.join(root, "embedding"), os.path.join(root, "DBP15K", "translated_ent_name")):
+        os.makedirs(d)
+    for name in z11["file_names"]:
+        with open(os.path.join(file_dir, str(name)), "wb") as f:
+            f.write(z11["file." + str(name)].tobytes())
+    with open(os.path.join(root, "pkls", "zh_en_GA_id_img_feature_dict.pkl"), "wb") as f:
+        pickle.dump({int(i): v for i, v in zip(z11["img_ids"], z11["img_vecs"])}, f)
+    with open(os.path.join(root, "embedding", "glove.6B.300d.txt"), "wb") as f:
+        f.write(z13["glove"].tobytes())
+    with open(os.path.join(root, "DBP15K", "translated_ent_name", "dbp_zh_en.json"), "wb") as f:
+        f.write(z13["names_json"].tobytes())
+    args = snag_args(32)
+    args.__dict__.update(data_path=root, data_choice="DBP15K", data_split="zh_en", ratio="1.0", data_rate=0.3, word_embedding="glove", unsup=0,
+                         batch_size=9, intermediate_size=48, w_name=True, w_char=True, inner_view_num=6)
+    np.random.seed(5)
+    kgs, _, train_set, _, _, _ = D.load_data(logging.getLogger("t"), args)
+    assert kgs["name_features"].shape == (kgs["ent_num"], 300) and kgs["char_features"].shape[0] == kgs["ent_num"]
+    model = SNAG(kgs, args, device=DEV)
+    model.noise_mode = "philox"
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-3)
+    model.train()
+    model.update_noise(seed=0)
+    batch = np.array(train_set.data)
+    losses = []
+    for _ in range(8):
+        loss, out = model(batch)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0], losses
+    enc = model.multimodal_encoder
+    assert enc.name_fc.weight.grad.abs().sum() > 0 and enc.char_fc.weight.grad.abs().sum() > 0
+    model.eval()
+    with torch.no_grad():
+        final, _ = model.joint_emb_generat()
+    assert final.shape[1] == 6 * 32
