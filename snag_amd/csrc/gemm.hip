@@ -247,7 +247,7 @@ static int pick_splits(int64_t tiles, int K, bool both_kc = false) {
     if (tiles >= kTargetBlocks / 2) return 1;
     if (both_kc && tiles >= 192) return 1;      // measured: X W^T shapes with ~1 tile per CU gain nothing from splitting
     const int64_t want = (kTargetBlocks + tiles - 1) / tiles;
-    const int64_t cap = std::max<int64_t>(1, K / (kMinKTiles * kBK));
+    const int64_t cap = std::max<int64_t>(1, K / (kMinKTiles * 16));
     return (int)std::min(want, cap);
 }
 
@@ -293,10 +293,11 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     const double c_small = (double)pm64 * pn128 * (kk ? 1.08 : 1.10);
     const double c_big = (double)pm128 * pn128 * (kk ? 1.00 : 1.05);
     const double c_wide = (double)pm128 * pn160 * (kk ? 1.18 : 1.00);
-    const int64_t max_splits = d->workspace ? std::max<int64_t>(1, p.K / (kMinKTiles * kBK)) : 1;
+    const int64_t max_splits = d->workspace ? std::max<int64_t>(1, p.K / (kMinKTiles * 16)) : 1;
     bool big = big_tiles >= 512 && c_big <= c_small;
     bool wide = wide_tiles * max_splits >= 512 && c_wide < (big ? c_big : c_small);
     if (force_tile() != 0) { big = force_tile() == 2; wide = force_tile() == 3; }
+    if (kBK != 16) wide = false;        // the 128x160 tiles of a 32-deep k-tile do not fit the 64 KB static LDS limit
     if (wide) big = false;
     const int64_t tiles = wide ? wide_tiles : big ? big_tiles : (pm64 / 64) * (pn128 / 128);
     // split K when the output alone cannot fill 256 CUs (the dW = dY^T X shapes: tiny output, long K)
@@ -328,8 +329,11 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     if (log_shapes())
         fprintf(stderr, "snag_gemm M=%d N=%d K=%d a_kc=%d b_kc=%d tile=%s splits=%d fast=%d acc=%d\n", p.M, p.N, p.K, (int)d->a_kcontig,
                 (int)d->b_kcontig, wide ? "128x160" : big ? "128x128" : "64x128", splits, (int)e.fast, (int)d->accumulate);
+#if SNAG_GEMM_BK == 16
     if (wide) launch_cfg<128, 160, 32, 160>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
-    else if (big) launch_cfg<128, 128, 64, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
+    else
+#endif
+    if (big) launch_cfg<128, 128, 64, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else launch_cfg<64, 128, 32, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     int rc = check_launch("snag_gemm_f32");
     if (rc) return rc;

@@ -29,7 +29,14 @@ using lds_float = float;
 using lds_float4 = float4;
 #endif
 
-constexpr int kBK = 16;
+#ifndef SNAG_GEMM_BK
+#define SNAG_GEMM_BK 16
+#endif
+constexpr int kBK = SNAG_GEMM_BK;          // k-tile depth: 16, or 32 (A/B switch: half the barriers per MFMA, twice the LDS)
+static_assert(kBK == 16 || kBK == 32, "k-tile depth");
+constexpr int kCPR = kBK / 4;               // 16-byte chunks per K-contiguous tile row
+// XOR swizzle of the chunk index: 16 consecutive rows x one chunk column must hit 16 distinct 16-byte bank slots
+__host__ __device__ constexpr int swz(int row) { return kBK == 16 ? ((row >> 2) & 3) : ((row >> 1) & 7); }
 
 // Build-time structure switches (A/B'ed on one device):
 //   SNAG_GEMM_SWZ  1: K-contiguous tiles stay row-major in LDS with XOR-swizzled 16-byte chunks (b128 in, b128 out)
@@ -113,7 +120,7 @@ struct Stager {
             const int slot = min(tid + 256 * s, TOTAL - 1);
             if (KC) {
                 const int lrow = slot / (kBK / 4);
-                const int c = (slot % (kBK / 4)) ^ ((lrow >> 2) & 3);
+                const int c = (slot % (kBK / 4)) ^ swz(lrow);
                 base[s] = P + (int64_t)min(row0 + lrow, nrows - 1) * ld + 4 * c;
             } else {
                 const int row = max(0, min(row0 + (slot % (BR / 4)) * 4, nrows - 4));
@@ -206,7 +213,7 @@ struct Stager {
                 const int row = slot / (kBK / 4);
                 const int c = slot % (kBK / 4);
                 if (kSwz) {
-                    *reinterpret_cast<lds_float4*>(tile + row * kBK + 4 * (c ^ ((row >> 2) & 3))) = r[s];
+                    *reinterpret_cast<lds_float4*>(tile + row * kBK + 4 * (c ^ swz(row))) = r[s];
                 } else {
                     tile[(4 * c + 0) * LD + row] = r[s].x;
                     tile[(4 * c + 1) * LD + row] = r[s].y;
@@ -226,17 +233,16 @@ struct Stager {
 // SWZ: t = 4*cp + j <-> k = 8cp + 4h + j (a permutation of k shared by both operands); else k = 2t + h.
 template <int BR, bool KC, int NF>
 __device__ __forceinline__ void load_fragments(const lds_float* tile, int row0, int li, int lh, float (&f)[kBK / 2][NF]) {
-    static_assert(kBK == 16, "two chunk pairs per k-tile");
     constexpr int LD = TileLd<BR, KC>::value;
 #pragma unroll
     for (int n = 0; n < NF; ++n) {
         const int row = row0 + 32 * n + li;
         if (kSwz) {
 #pragma unroll
-            for (int cp = 0; cp < 2; ++cp) {
+            for (int cp = 0; cp < kBK / 8; ++cp) {
                 if (KC) {
                     const int c = 2 * cp + lh;
-                    const float4 v = *reinterpret_cast<const lds_float4*>(tile + row * kBK + 4 * (c ^ ((li >> 2) & 3)));
+                    const float4 v = *reinterpret_cast<const lds_float4*>(tile + row * kBK + 4 * (c ^ swz(li)));
                     f[4 * cp + 0][n] = v.x;
                     f[4 * cp + 1][n] = v.y;
                     f[4 * cp + 2][n] = v.z;
