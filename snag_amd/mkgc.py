@@ -248,7 +248,9 @@ class MKGCHotPath:
         b.d_hidden = ptr(self.d_hidden)
         b.d_x0 = ptr(self.d_x0)
         b.grads = ctypes.cast(self._grads, ctypes.POINTER(_lib.FusionLayerGrad))
-        b.d_weight_raw = ptr(self.g["weight_raw"])
+        # the hd_* read-outs never touch joint_fz, so weight_raw has no gradient: its slice of the (zero-initialised) flat gradient
+        # buffer simply stays zero -- passing no pointer saves the library a 24-byte memset launch per step
+        b.d_weight_raw = None
         b.accumulate = 0
         self._bdesc = b
         self._set_dropout(self.training)
