@@ -167,9 +167,14 @@ class MKGCHotPath:
         ws = max(ws, lib.snag_gemm_workspace_floats(D, D, N) + 64, lib.snag_gemm_workspace_floats(N, D, D) + 64)
         self.work = torch.empty(ws, device=dev)
         H = cfg.num_heads
-        self.keep_probs = [torch.ones(N, H, M, M, device=dev, dtype=torch.uint8) for _ in range(L)]
-        self.keep_attn = [torch.ones(N * M, D, device=dev, dtype=torch.uint8) for _ in range(L)]
-        self.keep_ffn = [torch.ones(N * M, D, device=dev, dtype=torch.uint8) for _ in range(L)] if ffn else None
+        # all dropout keep-masks of the step live in ONE byte buffer (views below), so one Philox launch draws them all
+        n_probs, n_tok = _align(N * H * M * M), _align(N * M * D)
+        per_layer = n_probs + n_tok * (2 if ffn else 1)
+        self.keep_all = torch.ones(L * per_layer, device=dev, dtype=torch.uint8)
+        self.keep_probs = [self.keep_all[l * per_layer:l * per_layer + N * H * M * M].view(N, H, M, M) for l in range(L)]
+        self.keep_attn = [self.keep_all[l * per_layer + n_probs:l * per_layer + n_probs + N * M * D].view(N * M, D) for l in range(L)]
+        self.keep_ffn = ([self.keep_all[l * per_layer + n_probs + n_tok:l * per_layer + n_probs + n_tok + N * M * D].view(N * M, D) for l in range(L)]
+                         if ffn else None)
         self.tick = torch.zeros(1, device=dev, dtype=torch.int64)      # device-side step counter
         # noise state (model/SNAG.py:86-98)
         self.noisy = [f.clone() for f in self.feats]
@@ -334,11 +339,7 @@ class MKGCHotPath:
         call("snag_entity_token_fwd", ptr(self.p["ent"]), N, D, ptr(self.ent_noise) if noisy else None,
              ptr(self.ent_noise_mask) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD, st)
         if self.training and cfg.dropout > 0:
-            for l in range(cfg.num_layers):
-                call("snag_dropout_keep_mask", cfg.seed + 17 * l + 1, ptr(self.tick), self.keep_probs[l].numel(), cfg.dropout, ptr(self.keep_probs[l]), st)
-                call("snag_dropout_keep_mask", cfg.seed + 17 * l + 2, ptr(self.tick), self.keep_attn[l].numel(), cfg.dropout, ptr(self.keep_attn[l]), st)
-                if self.keep_ffn:
-                    call("snag_dropout_keep_mask", cfg.seed + 17 * l + 3, ptr(self.tick), self.keep_ffn[l].numel(), cfg.dropout, ptr(self.keep_ffn[l]), st)
+            call("snag_dropout_keep_mask", cfg.seed + 1, ptr(self.tick), self.keep_all.numel(), cfg.dropout, ptr(self.keep_all), st)
         call("snag_fusion_fwd", ctypes.byref(self._fdesc), st)
         if cfg.joint_way == "Mformer_hd_mean":
             call("snag_token_mean", ptr(self.hidden), N, M, D, ptr(self.repr_mean), st)
