@@ -284,13 +284,15 @@ SNAG_API int snag_adamw_step(float* param, const float* grad, float* exp_avg, fl
 SNAG_API int snag_adamw_step_groups(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                     float lr, float beta1, float beta2, float eps, const int64_t* seg_end,
                                     const float* seg_weight_decay, const float* seg_lr_scale, int n_seg, int64_t step,
-                                    const uint64_t* tick, float grad_scale, const float* grad_scale_dev, void* stream);
+                                    const uint64_t* tick, float grad_scale, const float* grad_scale_dev, int tick_advanced, void* stream);
 
 /* torch.nn.utils.clip_grad_norm_(parameters, max_norm) of the reference's training step (main.py:266-268, --clip default 1.0) for a
  * flat gradient buffer, without a host round trip: out2[0] = min(1, max_norm / (|grad_scale * grad|_2 + 1e-6)), out2[1] = that norm
  * (fixed-order two-level sum).  Pass out2 as grad_scale_dev of snag_adamw_step_groups: the update then uses the clipped gradient
- * (the gradient buffer itself is left as it is).  work: 1024 floats. */
-SNAG_API int snag_clip_grad_norm(const float* grad, int64_t n, float grad_scale, float max_norm, float* out2, float* work, void* stream);
+ * (the gradient buffer itself is left as it is).  work: 1024 floats.  advance_tick (optional): the device step counter is incremented
+ * by this call's single-block tail instead of a separate snag_tick launch; pass tick_advanced = 1 to the AdamW call that follows. */
+SNAG_API int snag_clip_grad_norm(const float* grad, int64_t n, float grad_scale, float max_norm, float* out2, float* work,
+                                uint64_t* advance_tick, void* stream);
 
 /* Device-resident step counter: tick[0] += 1.  When `tick` is given to snag_adamw_step the bias
  * correction uses t = tick[0] + 1 instead of the host `step`, which lets a captured hipGraph of a

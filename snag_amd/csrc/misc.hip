@@ -159,10 +159,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float wd, float bc1, float bc2, float gscale,
                                                     const uint64_t* __restrict__ tick, const int64_t* __restrict__ seg_end,
                                                     const float* __restrict__ seg_wd, const float* __restrict__ seg_lr, int n_seg,
-                                                    const float* __restrict__ gscale_dev) {
+                                                    const float* __restrict__ gscale_dev, int tick_advanced) {
     if (gscale_dev != nullptr) gscale *= gscale_dev[0];      // e.g. the clip coefficient of snag_clip_grad_norm
-    if (tick != nullptr) {          // step number lives on the device (graph replay): t = tick + 1
-        const float t = (float)(tick[0] + 1);
+    if (tick != nullptr) {          // step number lives on the device (graph replay): t = tick + 1 (tick itself when already advanced)
+        const float t = (float)(tick[0] + (tick_advanced ? 0 : 1));
         bc1 = 1.0f - powf(b1, t);
         bc2 = 1.0f - powf(b2, t);
     }
@@ -362,7 +362,8 @@ __global__ __launch_bounds__(256) void sumsq_part_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
-__global__ __launch_bounds__(1024) void clip_coef_kernel(const float* __restrict__ part, int nb, float max_norm, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void clip_coef_kernel(const float* __restrict__ part, int nb, float max_norm, float* __restrict__ out,
+                                                         uint64_t* __restrict__ advance) {
     __shared__ float red[16];
     float s = 0.f;
     for (int i = threadIdx.x; i < nb; i += 1024) s += part[i];
@@ -375,16 +376,18 @@ __global__ __launch_bounds__(1024) void clip_coef_kernel(const float* __restrict
         const float norm = sqrtf(tot);
         out[0] = fminf(1.0f, max_norm / (norm + 1e-6f));
         out[1] = norm;
+        if (advance) advance[0] += 1;          // single block, single thread: the step counter moves here instead of in its own launch
     }
 }
 }  // namespace snag
 
-extern "C" SNAG_API int snag_clip_grad_norm(const float* grad, int64_t n, float grad_scale, float max_norm, float* out2, float* work, void* stream) {
+extern "C" SNAG_API int snag_clip_grad_norm(const float* grad, int64_t n, float grad_scale, float max_norm, float* out2, float* work,
+                                            uint64_t* advance_tick, void* stream) {
     SNAG_REQUIRE(n >= 0 && max_norm > 0.f && out2 && work && (grad || n == 0), SNAG_ERR_ARG, "clip_grad_norm: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kNormBlocks, (n + 255) / 256));
     hipLaunchKernelGGL(sumsq_part_kernel, dim3(nb), dim3(256), 0, st, grad, n, grad_scale, work);
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1024), 0, st, (const float*)work, nb, max_norm, out2);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1024), 0, st, (const float*)work, nb, max_norm, out2, advance_tick);
     return check_launch("snag_clip_grad_norm");
 }
 
@@ -395,21 +398,21 @@ extern "C" SNAG_API int snag_adamw_step(float* param, const float* grad, float* 
     SNAG_REQUIRE(param && grad && exp_avg && exp_avg_sq, SNAG_ERR_ARG, "adamw_step: null pointer");
     const float bc1 = 1.0f - powf(beta1, (float)std::max<int64_t>(step, 1)), bc2 = 1.0f - powf(beta2, (float)std::max<int64_t>(step, 1));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
-                       eps, weight_decay, bc1, bc2, grad_scale, tick, (const int64_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr);
+                       eps, weight_decay, bc1, bc2, grad_scale, tick, (const int64_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0);
     return check_launch("snag_adamw_step");
 }
 
 extern "C" SNAG_API int snag_adamw_step_groups(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                                                float beta2, float eps, const int64_t* seg_end, const float* seg_weight_decay,
                                                const float* seg_lr_scale, int n_seg, int64_t step, const uint64_t* tick, float grad_scale,
-                                               const float* grad_scale_dev, void* stream) {
+                                               const float* grad_scale_dev, int tick_advanced, void* stream) {
     SNAG_REQUIRE(n >= 0 && (step >= 1 || tick != nullptr), SNAG_ERR_ARG, "adamw_step_groups: n=%ld step=%ld", (long)n, (long)step);
     SNAG_REQUIRE(n_seg >= 1 && seg_end && seg_weight_decay && seg_lr_scale, SNAG_ERR_ARG, "adamw_step_groups: segment table missing");
     if (n == 0) return SNAG_OK;
     SNAG_REQUIRE(param && grad && exp_avg && exp_avg_sq, SNAG_ERR_ARG, "adamw_step_groups: null pointer");
     const float bc1 = 1.0f - powf(beta1, (float)std::max<int64_t>(step, 1)), bc2 = 1.0f - powf(beta2, (float)std::max<int64_t>(step, 1));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
-                       eps, 0.0f, bc1, bc2, grad_scale, tick, seg_end, seg_weight_decay, seg_lr_scale, n_seg, grad_scale_dev);
+                       eps, 0.0f, bc1, bc2, grad_scale, tick, seg_end, seg_weight_decay, seg_lr_scale, n_seg, grad_scale_dev, tick_advanced);
     return check_launch("snag_adamw_step_groups");
 }
 

@@ -437,14 +437,16 @@ class MKGCHotPath:
 
     def optimizer_step(self, grad_scale=1.0):
         cfg = self.cfg
-        coef = None
-        if cfg.clip > 0:                      # global-norm clipping, coefficient stays on the device
-            call("snag_clip_grad_norm", ptr(self.gflat), self.n_params, float(grad_scale), float(cfg.clip), ptr(self._clip), ptr(self._clip_work), self._st)
-            coef = ptr(self._clip)
+        coef, advanced = None, 0
+        if cfg.clip > 0:                      # global-norm clipping, coefficient stays on the device; its single-block tail also advances tick
+            call("snag_clip_grad_norm", ptr(self.gflat), self.n_params, float(grad_scale), float(cfg.clip), ptr(self._clip), ptr(self._clip_work),
+                 ptr(self.tick), self._st)
+            coef, advanced = ptr(self._clip), 1
         call("snag_adamw_step_groups", ptr(self.flat), ptr(self.gflat), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n_params,
              float(cfg.lr), 0.9, 0.999, 1e-8, ptr(self._seg_end), ptr(self._seg_wd), ptr(self._seg_lr), len(self.param_groups), 0,
-             ptr(self.tick), float(grad_scale), coef, self._st)
-        call("snag_tick", ptr(self.tick), self._st)
+             ptr(self.tick), float(grad_scale), coef, advanced, self._st)
+        if not advanced:
+            call("snag_tick", ptr(self.tick), self._st)
 
     def train_step(self, h, r, t, neg_t, allreduce=None):
         """forward + backward (+ gradient exchange) + AdamW.  ``allreduce(gflat)`` sums gradients across ranks."""
