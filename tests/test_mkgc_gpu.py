@@ -51,11 +51,14 @@ def oracle_params(eng):
     # ragged everything: entity count, feature widths and hidden size that are not multiples of 4 / 64 (checked GEMM loaders, padded rows)
     (2, "Mformer_hd_graph", 0, True, torch.int32, (701, 5, 100, 33, 5, 37, 10)),
     (1, "Mformer_hd_mean", 1, False, torch.int64, (333, 3, 36, 17, 3, 13, 9)),
+    # two Mformer layers (num_hidden_layers = 2), with and without the FFN: shape tuple carries an 8th entry = layer count
+    (2, "Mformer_hd_graph", 1, True, torch.int32, (400, 7, 64, 48, 8, 40, 24, 2)),
+    (1, "Mformer_hd_mean", 0, False, torch.int32, (400, 7, 64, 48, 8, 40, 24, 2)),
 ])
 def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape, loss_kind):
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
-    N, R, D, B, K, F0, F1 = shape
-    cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[F0, F1], num_proj=num_proj, joint_way=joint_way,
+    N, R, D, B, K, F0, F1 = shape[:7]
+    cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[F0, F1], num_proj=num_proj, joint_way=joint_way, num_layers=shape[7] if len(shape) > 7 else 1,
                      use_intermediate=ffn, intermediate_size=96, margin=6.0, neg_num=K, dropout=0.0, add_noise=int(noise), seed=7,
                      loss=loss_kind, adv_temp=0.7)
     g = torch.Generator().manual_seed(99)
