@@ -347,7 +347,7 @@ struct GemmCore {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[i][j], 0, 0, 0);
                 if (via_regs) stage(cur ^ 1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                if (p.dbg != 2) __syncthreads();       // dbg 2: ablation without the per-k-tile barrier (results are wrong)
             }
             return;
         }
