@@ -516,14 +516,15 @@ class MKGCHotPath:
             return self.repr_mean
         return self.hidden[:, self.g_slot, :]
 
-    def link_prediction(self, h, r, t, filter_mask=None, top_k=(1, 10)):
-        """Eval-mode fusion of the whole table, then the rank of each true tail against all entities (Hits@1/10, MR, MRR)."""
+    def link_prediction(self, h, r, t, filter_mask=None, top_k=(1, 10), method="exact"):
+        """Eval-mode fusion of the whole table, then the rank of each true tail against all entities (Hits@1/10, MR, MRR);
+        ``method``: see snag_amd.evalsim.link_prediction."""
         from . import evalsim
         was = self.training
         self.eval()
         dummy = t.view(-1, 1)[:, :1].contiguous()
         self.forward(h, r, t, dummy)                     # fills hidden / read-out; the tiny score launch is discarded
-        out = evalsim.link_prediction(self.entity_representation(), self.p["rel"], h, r, t, filter_mask, top_k)
+        out = evalsim.link_prediction(self.entity_representation(), self.p["rel"], h, r, t, filter_mask, top_k, method=method)
         self.train(was)
         return out
 

@@ -167,3 +167,26 @@ def test_cityblock_distance_and_ranks(n, m, d):
         dd = torch.cdist(x.double(), (x + 0.7 * y).double(), p=1)
         rk = (dd < dd.diag().view(-1, 1)).sum(1)
         assert float((res["rank_l2r"].cpu().long() != rk).float().mean()) < 0.01          # fp32 vs fp64 near-ties only
+
+
+def test_link_prediction_gemm_method_agrees_with_exact():
+    """method="gemm": |q|^2 + |t|^2 - 2 q.t on the matrix cores; same ranks as the difference-form scorer up to near-ties."""
+    from snag_amd import evalsim as E
+    g = torch.Generator().manual_seed(12)
+    N, R, D, B = 3000, 11, 128, 700
+    ent = (torch.randn(N, D, generator=g) * 0.7).to(DEV)
+    ent[5].zero_()                                            # a zero row: normalises to zero in both forms
+    rel = (torch.randn(R, D, generator=g) * 0.3).to(DEV)
+    h = torch.randint(0, N, (B,), generator=g, dtype=torch.int32).to(DEV)
+    r = torch.randint(0, R, (B,), generator=g, dtype=torch.int32).to(DEV)
+    t = torch.randint(0, N, (B,), generator=g, dtype=torch.int32).to(DEV)
+    filt = (torch.rand(B, N, generator=g) < 0.002).to(torch.uint8).to(DEV)
+    a = E.link_prediction(ent, rel, h, r, t, filt, method="exact")
+    b = E.link_prediction(ent[:, :].contiguous(), rel, h, r, t, filt, method="gemm")
+    assert_close(b["scores"], a["scores"], atol=2e-5)
+    diff = (a["rank"].long() - b["rank"].long()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 0.01
+    for x, y in zip(a["hits"], b["hits"]):
+        assert abs(x - y) <= 2.0 / B
+    with pytest.raises(ValueError):
+        E.link_prediction(ent, rel, h, r, t, method="fast")
