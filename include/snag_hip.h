@@ -365,6 +365,12 @@ SNAG_API int snag_sample_negatives(uint64_t seed, const uint64_t* tick, const in
                                    int64_t batch, int n_neg, int n_ent, int n_rel, int mode, const int64_t* known_sorted,
                                    int64_t n_known, int32_t* neg_h, int32_t* neg_t, void* stream);
 
+/* The filtered setting of MKGC tail prediction (PARITY UNPINNED like the eval itself): mask [batch, n_ent] (uint8, overwritten) gets 1
+ * at every x for which (h_b, r_b, x) is a known triple, except x == t_b; known_sorted as for snag_sample_negatives.  The mask is
+ * what snag_rank_full_table takes as `filter`.  int32 indices. */
+SNAG_API int snag_build_filter_mask(const int32_t* h, const int32_t* r, const int32_t* t, int64_t batch, int n_ent, int n_rel,
+                                    const int64_t* known_sorted, int64_t n_known, uint8_t* mask, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * SURVEY par. 8(f) "next" #2: sparse GAT structural encoder, diag variant, eval / zero-dropout configuration.
  * Replaces one MultiHeadGraphAttention layer + the head mean (+ ELU) of GAT.forward (model/layers.py:68-94,

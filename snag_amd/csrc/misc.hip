@@ -432,6 +432,44 @@ extern "C" SNAG_API int snag_entity_token_fwd(const float* table, int64_t N, int
     return check_launch("snag_entity_token_fwd");
 }
 
+namespace snag {
+// Filtered-setting mask for tail prediction: mask[b, x] = 1 for every known triple (h_b, r_b, x) except the query's own tail.
+// known: ascending keys (h * n_rel + r) * n_ent + t (the sampler's table).  One wave per query: binary search of the (h, r) prefix,
+// then the lanes walk the run of keys.
+__global__ __launch_bounds__(256) void filter_mask_kernel(const int32_t* __restrict__ h, const int32_t* __restrict__ r, const int32_t* __restrict__ t,
+                                                          int64_t batch, int n_ent, int n_rel, const int64_t* __restrict__ known, int64_t n_known,
+                                                          uint8_t* __restrict__ mask) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (b >= batch) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t base = ((int64_t)h[b] * n_rel + r[b]) * n_ent;          // first key of the (h, r) run
+    int64_t lo = 0, hi = n_known;
+    while (lo < hi) {                                                       // lower_bound(base)
+        const int64_t mid = (lo + hi) >> 1;
+        if (known[mid] < base) lo = mid + 1;
+        else hi = mid;
+    }
+    const int64_t tb = t[b];
+    for (int64_t i = lo + lane; i < n_known; i += 64) {
+        const int64_t x = known[i] - base;
+        if (x >= n_ent) break;
+        if (x != tb) mask[b * n_ent + x] = 1;
+    }
+}
+}  // namespace snag
+
+extern "C" SNAG_API int snag_build_filter_mask(const int32_t* h, const int32_t* r, const int32_t* t, int64_t batch, int n_ent, int n_rel,
+                                               const int64_t* known_sorted, int64_t n_known, uint8_t* mask, void* stream) {
+    SNAG_REQUIRE(batch >= 0 && n_ent >= 1 && n_rel >= 1 && n_known >= 0, SNAG_ERR_ARG, "build_filter_mask: bad sizes");
+    if (batch == 0) return SNAG_OK;
+    SNAG_REQUIRE(h && r && t && mask && (known_sorted || n_known == 0), SNAG_ERR_ARG, "build_filter_mask: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(mask, 0, (size_t)batch * n_ent, st) != hipSuccess) return fail(SNAG_ERR_LAUNCH, "build_filter_mask: memset failed");
+    if (n_known > 0)
+        hipLaunchKernelGGL(filter_mask_kernel, dim3((unsigned)ceil_div(batch, 4)), dim3(256), 0, st, h, r, t, batch, n_ent, n_rel, known_sorted, n_known, mask);
+    return check_launch("snag_build_filter_mask");
+}
+
 extern "C" SNAG_API int snag_sample_negatives(uint64_t seed, const uint64_t* tick, const int32_t* h, const int32_t* r, const int32_t* t, int64_t batch,
                                               int n_neg, int n_ent, int n_rel, int mode, const int64_t* known_sorted, int64_t n_known,
                                               int32_t* neg_h, int32_t* neg_t, void* stream) {

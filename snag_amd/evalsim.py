@@ -127,7 +127,7 @@ def mutual_nearest(final_emb, left, right, chunk=None):
     return pl, pr, pairs
 
 
-def link_prediction(ent, rel, h, r, t, filter_mask=None, top_k=(1, 10), method="exact"):
+def link_prediction(ent, rel, h, r, t, filter_mask=None, top_k=(1, 10), method="exact", known_sorted=None):
     """MKGC tail prediction: rank of the true tail among ALL entities under s(h,r,x) (lower = better), optional filter.
 
     PARITY UNPINNED (no MKGC eval code in the reference tree): the score is the in-tree TransE-L2^2 of
@@ -137,6 +137,8 @@ def link_prediction(ent, rel, h, r, t, filter_mask=None, top_k=(1, 10), method="
     scores the model was trained on; 29 G scores/s).  ``method="gemm"`` expands it to |q|^2 + |t|^2 - 2 q.t and runs the B x N x D
     product on the exact-f32 matrix cores through the similarity-eval GEMM (about 8x faster at 16k queries x 15k entities); the
     scores differ from the exact ones by fp32 cancellation error (~1e-6), so ranks can move by one place on near-ties.
+    ``known_sorted`` (the sampler's sorted key table, ``ops.triple_keys``) builds the filtered protocol's mask on the device when no
+    ``filter_mask`` is given.
     """
     ops._rows(ent, "ent"), ops._chk(rel, "rel", ndim=2)
     B, N, dev = h.shape[0], ent.shape[0], ent.device
@@ -161,6 +163,8 @@ def link_prediction(ent, rel, h, r, t, filter_mask=None, top_k=(1, 10), method="
         scores = pairwise_distances(q, cand, _padded=True)
     else:
         raise ValueError("method must be 'exact' or 'gemm'")
+    if filter_mask is None and known_sorted is not None:
+        filter_mask = ops.build_filter_mask(h.to(torch.int32), r.to(torch.int32), t.to(torch.int32), N, rel.shape[0], known_sorted)
     if filter_mask is not None:
         ops._chk(filter_mask, "filter_mask", dtype=torch.uint8, ndim=2)
         if tuple(filter_mask.shape) != (B, N):

@@ -516,7 +516,7 @@ class MKGCHotPath:
             return self.repr_mean
         return self.hidden[:, self.g_slot, :]
 
-    def link_prediction(self, h, r, t, filter_mask=None, top_k=(1, 10), method="exact"):
+    def link_prediction(self, h, r, t, filter_mask=None, top_k=(1, 10), method="exact", known_sorted=None):
         """Eval-mode fusion of the whole table, then the rank of each true tail against all entities (Hits@1/10, MR, MRR);
         ``method``: see snag_amd.evalsim.link_prediction."""
         from . import evalsim
@@ -524,7 +524,7 @@ class MKGCHotPath:
         self.eval()
         dummy = t.view(-1, 1)[:, :1].contiguous()
         self.forward(h, r, t, dummy)                     # fills hidden / read-out; the tiny score launch is discarded
-        out = evalsim.link_prediction(self.entity_representation(), self.p["rel"], h, r, t, filter_mask, top_k, method=method)
+        out = evalsim.link_prediction(self.entity_representation(), self.p["rel"], h, r, t, filter_mask, top_k, method=method, known_sorted=known_sorted)
         self.train(was)
         return out
 

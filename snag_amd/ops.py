@@ -279,6 +279,17 @@ def triple_keys(h, r, t, n_ent, n_rel):
     return torch.sort(k)[0].contiguous()
 
 
+def build_filter_mask(h, r, t, n_ent, n_rel, known_sorted):
+    """uint8 [B, n_ent]: 1 where (h_b, r_b, x) is a known triple and x != t_b (the filtered ranking protocol).  C ABI: snag_build_filter_mask."""
+    for x, nm in ((h, "h"), (r, "r"), (t, "t")):
+        _chk(x, nm, dtype=torch.int32, ndim=1)
+    _chk(known_sorted, "known_sorted", dtype=torch.int64, ndim=1)
+    B = h.shape[0]
+    mask = torch.empty(B, n_ent, device=h.device, dtype=torch.uint8)
+    call("snag_build_filter_mask", ptr(h), ptr(r), ptr(t), B, int(n_ent), int(n_rel), ptr(known_sorted), known_sorted.numel(), ptr(mask), stream())
+    return mask
+
+
 def sample_negatives(h, r, t, n_neg, n_ent, n_rel, seed, known_sorted=None, head_or_tail=False, tick=None, out=None):
     """neg_t [B, n_neg] (and neg_h when head_or_tail) drawn on the device.  C ABI: snag_sample_negatives."""
     for x, nm in ((h, "h"), (r, "r"), (t, "t")):

@@ -190,3 +190,29 @@ def test_link_prediction_gemm_method_agrees_with_exact():
         assert abs(x - y) <= 2.0 / B
     with pytest.raises(ValueError):
         E.link_prediction(ent, rel, h, r, t, method="fast")
+
+
+def test_filter_mask_from_known_triples():
+    """snag_build_filter_mask: the filtered protocol's mask built on the device from the sorted key table."""
+    from snag_amd import ops
+    g = torch.Generator().manual_seed(2)
+    N, R, T, B = 500, 7, 6000, 300
+    kh, kr, kt = (torch.randint(0, hi, (T,), generator=g, dtype=torch.int32) for hi in (N, R, N))
+    kh[:50], kr[:50] = 3, 2                                   # a long (h, r) run (more than one wave stride)
+    kt[:50] = torch.randperm(N, generator=g)[:50].to(torch.int32)
+    known = ops.triple_keys(kh.to(DEV), kr.to(DEV), kt.to(DEV), N, R)
+    sel = torch.randint(0, T, (B,), generator=g)
+    h, r, t = kh[sel].clone(), kr[sel].clone(), kt[sel].clone()
+    h[0], r[0], t[0] = 3, 2, kt[0]
+    h[1], r[1] = N - 1, R - 1                                 # possibly no known triple at all for this pair
+    got = ops.build_filter_mask(h.to(DEV), r.to(DEV), t.to(DEV), N, R, known).cpu()
+    ref = torch.zeros(B, N, dtype=torch.uint8)
+    by_pair = {}
+    for a, b_, c in zip(kh.tolist(), kr.tolist(), kt.tolist()):
+        by_pair.setdefault((a, b_), set()).add(c)
+    for i, (a, b_, c) in enumerate(zip(h.tolist(), r.tolist(), t.tolist())):
+        for x in by_pair.get((a, b_), ()):
+            if x != c:
+                ref[i, x] = 1
+    assert torch.equal(got, ref)
+    assert int(got[0].sum()) >= 40
