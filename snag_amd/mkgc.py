@@ -461,6 +461,24 @@ class MKGCHotPath:
         self.optimizer_step()
         return self.loss
 
+    def train_epoch(self, h, r, t, batch_size, known_sorted=None, allreduce=None, seed=None):
+        """One epoch in the order the README's MKGC loop implies (noise refresh once per epoch -- "noise-level: epoch" --, then every
+        batch: NEG_NUM negative tails drawn on the device, forward, backward, exchange, clip, AdamW).  ``h, r, t``: this rank's int32
+        training triples on the device; the last ragged batch is kept.  Returns the summed loss as a device scalar."""
+        from . import ops
+        n = h.shape[0]
+        epoch_seed = self.cfg.seed * 104729 + self.noise_epoch if seed is None else seed
+        if self.cfg.add_noise:
+            self.update_noise()
+        perm = torch.randperm(n, device=self.dev, generator=torch.Generator(device=self.dev).manual_seed(epoch_seed))
+        total = torch.zeros((), device=self.dev, dtype=f32)
+        for lo in range(0, n, batch_size):
+            idx = perm[lo:lo + batch_size]
+            hb, rb, tb = h[idx].contiguous(), r[idx].contiguous(), t[idx].contiguous()
+            neg = ops.sample_negatives(hb, rb, tb, self.cfg.neg_num, self.cfg.n_ent, self.cfg.n_rel, epoch_seed, known_sorted=known_sorted, tick=self.tick)
+            total += self.train_step(hb, rb, tb, neg, allreduce=allreduce)
+        return total
+
     # ---- hipGraph replay of the whole step ------------------------------------------------------------------------------
     def capture_step(self, batch, n_neg, sampler=None):
         """Record forward + backward + clip + AdamW (and, when ``sampler`` is given, the on-device negative sampling) ONCE as a

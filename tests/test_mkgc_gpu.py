@@ -267,3 +267,27 @@ def test_deterministic_mode_is_bit_reproducible_and_matches_the_default(joint_wa
     scale = float(c[1].abs().max())
     assert float((a[1] - c[1]).abs().max()) <= 1e-5 * scale
     assert all(abs(x - y) <= 1e-5 * max(1.0, abs(y)) for x, y in zip(a[2], c[2]))
+
+
+def test_train_epoch_learns_a_planted_graph():
+    """train_epoch (noise refresh, on-device negative sampling with the known-triple filter, steps) + filtered link prediction:
+    on triples whose tail is a function of (head, relation) the loss falls and the filtered mean rank of the training triples improves."""
+    from snag_amd import ops
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    N, R, D, T_ = 400, 6, 64, 3000
+    g = torch.Generator().manual_seed(13)
+    h = torch.randint(0, N, (T_,), generator=g, dtype=torch.int32)
+    r = torch.randint(0, R, (T_,), generator=g, dtype=torch.int32)
+    t = ((h.long() * 7 + 31 * (r.long() + 1)) % N).to(torch.int32)            # tail is a function of (head, relation)
+    h, r, t = h.to(DEV), r.to(DEV), t.to(DEV)
+    cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[32, 16], neg_num=16, margin=4.0, lr=2e-2, dropout=0.0, add_noise=1, noise_ratio=0.1, seed=1)
+    feats = [torch.rand(N, 32, generator=g), torch.randn(N, 16, generator=g)]
+    eng = MKGCHotPath(cfg, feats, device=DEV)
+    known = ops.triple_keys(h, r, t, N, R)
+    before = eng.link_prediction(h[:500], r[:500], t[:500], known_sorted=known, top_k=(1, 10))
+    losses = [float(eng.train_epoch(h, r, t, 256, known_sorted=known)) for _ in range(30)]
+    after = eng.link_prediction(h[:500], r[:500], t[:500], known_sorted=known, top_k=(1, 10), method="gemm")
+    # (TransE over LayerNormed fused tokens memorises this non-translational map only slowly: measured MR 199 -> 111, Hits@10 0.03 -> 0.08)
+    assert losses[-1] < 0.85 * losses[0], losses
+    assert after["mr"] < 0.75 * before["mr"] and after["hits"][1] > before["hits"][1], (before["mr"], after["mr"], before["hits"], after["hits"])
+    assert eng.noise_epoch == 30
