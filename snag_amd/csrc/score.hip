@@ -58,14 +58,20 @@ __device__ __forceinline__ float score_row(const RowV4<NV>& q, const RowV4<NV>& 
     return sum16(s);
 }
 
-template <typename IdxT, int NV>
+// WPT waves per triple: see score_fwd_bf16_kernel.
+template <typename IdxT, int NV, int WPT>
 __global__ __launch_bounds__(256) void score_fwd_kernel(
     const float* __restrict__ ent, int64_t eld, const float* __restrict__ rel, int dim,
     const IdxT* __restrict__ h, const IdxT* __restrict__ r, const IdxT* __restrict__ t,
-    const IdxT* __restrict__ neg_t, int64_t batch, int n_neg, float margin,
+    const IdxT* __restrict__ neg_t, int64_t batch, int n_neg_all, float margin,
     float* __restrict__ pos, float* __restrict__ neg, float* __restrict__ loss_part) {
-    const int64_t b = (int64_t)blockIdx.x * 4 + wave_id_uniform();
-    if (b >= batch) return;
+    __shared__ float part_sum[4];
+    const int wave = wave_id_uniform();
+    const int64_t b_raw = (int64_t)blockIdx.x * (4 / WPT) + wave / WPT;
+    const int part = wave % WPT;
+    const bool live = b_raw < batch;
+    if (WPT == 1 && !live) return;
+    const int64_t b = live ? b_raw : 0;          // WPT > 1: dead waves still reach the barrier at the end, on triple 0 with no negatives
     const int lane = threadIdx.x & 63;
     const int sub = lane & 15;
     const int grp = lane >> 4;
@@ -74,9 +80,12 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(
     // read of up to 64 negative-tail ids -- (2) every row: head, relation, positive tail and the first 32 negatives
     // (22 dwordx4 per lane in flight).  Only then does arithmetic start.
     const int64_t hi = (int64_t)h[b], ri = (int64_t)r[b], ti = (int64_t)t[b];
-    const IdxT* nrow = neg_t + b * (int64_t)n_neg;
-    float* out = neg + b * (int64_t)n_neg;
-    int my = (lane < n_neg) ? (neg_t != nullptr ? (int)nrow[lane] : lane) : 0;
+    const int per_part = (WPT == 1) ? n_neg_all : ((n_neg_all + WPT - 1) / WPT + 31) / 32 * 32;
+    const int k_lo = min(n_neg_all, part * per_part);
+    const int n_neg = live ? min(n_neg_all - k_lo, per_part) : 0;       // this wave's share of the negatives: [k_lo, k_lo + n_neg)
+    const IdxT* nrow = neg_t + b * (int64_t)n_neg_all + k_lo;
+    float* out = neg + b * (int64_t)n_neg_all + k_lo;
+    int my = (lane < n_neg) ? (neg_t != nullptr ? (int)nrow[lane] : k_lo + lane) : 0;
     // keep the three scalar ids and the id vector in ONE wait: nothing below may be scheduled above this point
     asm volatile("" : "+v"(my) : "s"((int)hi), "s"((int)ri), "s"((int)ti) : "memory");
     constexpr int kFirst = (NV <= 2) ? 8 : 4;                 // rounds of 4 rows prefetched with the positive (register budget)
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(
         }
     }
     const float s_pos = score_row<NV>(q, tt);
-    if (lane == 0) pos[b] = s_pos;
+    if (lane == 0 && part == 0 && live) pos[b] = s_pos;
 
     float hinge = 0.f;
     if (first_block) {
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(
         }
     }
     for (int k0 = 0; k0 < n_neg; k0 += 64) {
-        if (k0 > 0) my = (k0 + lane < n_neg) ? (neg_t != nullptr ? (int)nrow[k0 + lane] : k0 + lane) : 0;
+        if (k0 > 0) my = (k0 + lane < n_neg) ? (neg_t != nullptr ? (int)nrow[k0 + lane] : k_lo + k0 + lane) : 0;
         const int cnt = min(64, n_neg - k0);
         int it = (k0 == 0 && first_block) ? 4 * kFirst : 0;
         // full blocks: 8 rounds x 4 rows, all 16 gathers of the block issued before the first use
@@ -141,10 +150,20 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(
             }
         }
     }
-    if (loss_part != nullptr) {
-        // every lane of a group holds the group's partial; combine the four groups in fixed order
-        const float g1 = __shfl(hinge, 16), g2 = __shfl(hinge, 32), g3 = __shfl(hinge, 48);
-        if (lane == 0) loss_part[b] = ((hinge + g1) + g2) + g3;
+    // every lane of a group holds the group's partial; combine the four groups in fixed order
+    const float g1 = __shfl(hinge, 16), g2 = __shfl(hinge, 32), g3 = __shfl(hinge, 48);
+    const float wsum = ((hinge + g1) + g2) + g3;
+    if (WPT == 1) {
+        if (loss_part != nullptr && lane == 0) loss_part[b] = wsum;
+        return;
+    }
+    if (lane == 0) part_sum[wave] = wsum;
+    __syncthreads();
+    if (loss_part != nullptr && lane == 0 && part == 0 && live) {
+        float tot = 0.f;
+#pragma unroll
+        for (int p = 0; p < WPT; ++p) tot += part_sum[wave + p];
+        loss_part[b] = tot;
     }
 }
 
@@ -335,11 +354,20 @@ template <typename IdxT>
 static int launch_fwd(const float* ent, int64_t eld, const float* rel, int dim, const void* h, const void* r, const void* t,
                       const void* neg_t, int64_t batch, int n_neg, float margin, float* pos, float* neg,
                       float* loss_part, hipStream_t st) {
-    const dim3 grid((unsigned)ceil_div(batch, 4)), block(256);
+    // several waves per triple while the batch alone cannot fill the chip with independent gather chains (K = 128 at B = 1024;
+    // not the all-entity ranking form, whose batch is small but whose rows are one long coalesced sweep)
+    const int wpt = (neg_t != nullptr && batch <= 4096 && n_neg >= 128) ? 4 : (neg_t != nullptr && batch <= 4096 && n_neg >= 96) ? 2 : 1;
+    const dim3 grid((unsigned)ceil_div(batch, 4 / wpt)), block(256);
     const int nv = (dim + 63) / 64;
-#define SNAG_FWD(NV)                                                                                           \
-    hipLaunchKernelGGL((score_fwd_kernel<IdxT, NV>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h,        \
-                       (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, pos, neg, loss_part)
+#define SNAG_FWD(NV)                                                                                                           \
+    do {                                                                                                                       \
+        if (wpt == 4) hipLaunchKernelGGL((score_fwd_kernel<IdxT, NV, 4>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h,  \
+                       (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, pos, neg, loss_part);         \
+        else if (wpt == 2) hipLaunchKernelGGL((score_fwd_kernel<IdxT, NV, 2>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h, \
+                       (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, pos, neg, loss_part);         \
+        else hipLaunchKernelGGL((score_fwd_kernel<IdxT, NV, 1>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h,       \
+                       (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, pos, neg, loss_part);         \
+    } while (0)
     switch (nv) {
         case 1: SNAG_FWD(1); break;
         case 2: SNAG_FWD(2); break;
@@ -421,20 +449,28 @@ __device__ __forceinline__ float score_row_b(const RowB<NC>& q, const RowB<NC>& 
     return sum16(s);
 }
 
-template <typename IdxT, int NC>
+// WPT waves share one triple: each takes a contiguous 1/WPT of the negatives (a multiple of 64), so that at small batches the
+// chain of dependent gather round trips per wave shrinks (K = 128: four passes -> one) and four times as many waves are in flight;
+// the per-triple hinge partials meet in LDS and are added in a fixed order.
+template <typename IdxT, int NC, int WPT>
 __global__ __launch_bounds__(256) void score_fwd_bf16_kernel(
     const uint16_t* __restrict__ ent, int64_t eld, const uint16_t* __restrict__ rel, int dim,
     const IdxT* __restrict__ h, const IdxT* __restrict__ r, const IdxT* __restrict__ t,
     const IdxT* __restrict__ neg_t, int64_t batch, int n_neg, float margin,
     float* __restrict__ pos, float* __restrict__ neg, float* __restrict__ loss_part) {
-    const int64_t b = (int64_t)blockIdx.x * 4 + wave_id_uniform();
-    if (b >= batch) return;
+    __shared__ float part_sum[4];
+    const int wave = wave_id_uniform();
+    const int64_t b = (int64_t)blockIdx.x * (4 / WPT) + wave / WPT;
+    const int part = wave % WPT;
+    const bool live = b < batch;
+    if (WPT == 1 && !live) return;
     const int lane = threadIdx.x & 63;
     const int sub = lane & 15;
     const int grp = lane >> 4;
-    RowB<NC> q = load_row_bf16<NC>(ent, (int64_t)h[b], eld, dim, sub);
-    const RowB<NC> rr = load_row_bf16<NC>(rel, (int64_t)r[b], dim, dim, sub);
-    const RowB<NC> tt = load_row_bf16<NC>(ent, (int64_t)t[b], eld, dim, sub);
+    const int64_t bb = live ? b : 0;          // WPT > 1: dead waves still reach the barrier below, on row 0
+    RowB<NC> q = load_row_bf16<NC>(ent, (int64_t)h[bb], eld, dim, sub);
+    const RowB<NC> rr = load_row_bf16<NC>(rel, (int64_t)r[bb], dim, dim, sub);
+    const RowB<NC> tt = load_row_bf16<NC>(ent, (int64_t)t[bb], eld, dim, sub);
     {
         const float ih = 1.0f / l2_denominator(sum16(sumsq_b<NC>(q)));
         const float ir = 1.0f / l2_denominator(sum16(sumsq_b<NC>(rr)));
@@ -442,20 +478,25 @@ __global__ __launch_bounds__(256) void score_fwd_bf16_kernel(
         for (int i = 0; i < 8 * NC; ++i) q.v[i] = q.v[i] * ih + rr.v[i] * ir;
     }
     const float s_pos = score_row_b<NC>(q, tt);
-    if (lane == 0) pos[b] = s_pos;
+    if (lane == 0 && part == 0 && live) pos[b] = s_pos;
     float hinge = 0.f;
-    const IdxT* nrow = neg_t + b * (int64_t)n_neg;
-    float* out = neg + b * (int64_t)n_neg;
-    for (int k0 = 0; k0 < n_neg; k0 += 64) {
-        const int my = (k0 + lane < n_neg) ? (neg_t != nullptr ? (int)nrow[k0 + lane] : k0 + lane) : 0;
-        const int cnt = min(64, n_neg - k0);
+    const IdxT* nrow = neg_t + bb * (int64_t)n_neg;
+    float* out = neg + bb * (int64_t)n_neg;
+    const int per_part = ((n_neg + WPT - 1) / WPT + 31) / 32 * 32;
+    const int k_lo = part * per_part, k_hi = live ? min(n_neg, k_lo + per_part) : 0;
+    for (int k0 = k_lo; k0 < k_hi; k0 += 64) {
+        const int my = (k0 + lane < k_hi) ? (neg_t != nullptr ? (int)nrow[k0 + lane] : k0 + lane) : 0;
+        const int cnt = min(64, k_hi - k0);
         int it = 0;
-        for (; it + 16 <= cnt; it += 16) {                       // 4 rounds x 4 rows in flight
-            RowB<NC> x[4];
+        // kRounds x 4 rows in flight per wave.  A bf16 row is half the bytes of an fp32 one, and at B = 1024 a CU holds one wave per
+        // SIMD, so the gather is latency-bound: 8 rounds (32 rows, 16 KB per wave) where the registers allow it
+        constexpr int kRounds = (NC <= 2) ? 8 : 4;
+        for (; it + 4 * kRounds <= cnt; it += 4 * kRounds) {
+            RowB<NC> x[kRounds];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = load_row_bf16<NC>(ent, __shfl(my, it + 4 * u + grp), eld, dim, sub);
+            for (int u = 0; u < kRounds; ++u) x[u] = load_row_bf16<NC>(ent, __shfl(my, it + 4 * u + grp), eld, dim, sub);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kRounds; ++u) {
                 const float s = score_row_b<NC>(q, x[u]);
                 hinge += fmaxf(margin + s_pos - s, 0.f);
                 if (sub == 0) out[k0 + it + 4 * u + grp] = s;
@@ -473,9 +514,19 @@ __global__ __launch_bounds__(256) void score_fwd_bf16_kernel(
             }
         }
     }
-    if (loss_part != nullptr) {
-        const float g1 = __shfl(hinge, 16), g2 = __shfl(hinge, 32), g3 = __shfl(hinge, 48);
-        if (lane == 0) loss_part[b] = ((hinge + g1) + g2) + g3;
+    const float g1 = __shfl(hinge, 16), g2 = __shfl(hinge, 32), g3 = __shfl(hinge, 48);
+    const float wsum = ((hinge + g1) + g2) + g3;
+    if (WPT == 1) {
+        if (loss_part != nullptr && lane == 0) loss_part[b] = wsum;
+        return;
+    }
+    if (lane == 0) part_sum[wave] = wsum;
+    __syncthreads();
+    if (loss_part != nullptr && lane == 0 && part == 0 && live) {
+        float tot = 0.f;
+#pragma unroll
+        for (int p = 0; p < WPT; ++p) tot += part_sum[wave + p];
+        loss_part[b] = tot;
     }
 }
 
@@ -483,11 +534,19 @@ template <typename IdxT>
 static int launch_fwd_bf16(const uint16_t* ent, int64_t eld, const uint16_t* rel, int dim, const void* h, const void* r, const void* t,
                            const void* neg_t, int64_t batch, int n_neg, float margin, float* pos, float* neg, float* loss_part,
                            hipStream_t st) {
-    const dim3 grid((unsigned)ceil_div(batch, 4)), block(256);
+    // several waves per triple while the batch alone cannot fill the chip with independent gather chains
+    const int wpt = (batch <= 4096 && n_neg >= 128) ? 4 : (batch <= 4096 && n_neg >= 96) ? 2 : 1;
+    const dim3 grid((unsigned)ceil_div(batch, 4 / wpt)), block(256);
     const int nc = (dim + 127) / 128;
-#define SNAG_FWDB(NC)                                                                                              \
-    hipLaunchKernelGGL((score_fwd_bf16_kernel<IdxT, NC>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h,  \
-                       (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, pos, neg, loss_part)
+#define SNAG_FWDB(NC)                                                                                                       \
+    do {                                                                                                                    \
+        if (wpt == 4) hipLaunchKernelGGL((score_fwd_bf16_kernel<IdxT, NC, 4>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h, \
+                       (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, pos, neg, loss_part);      \
+        else if (wpt == 2) hipLaunchKernelGGL((score_fwd_bf16_kernel<IdxT, NC, 2>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h, \
+                       (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, pos, neg, loss_part);      \
+        else hipLaunchKernelGGL((score_fwd_bf16_kernel<IdxT, NC, 1>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h, \
+                       (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, pos, neg, loss_part);      \
+    } while (0)
     switch (nc) {
         case 1: SNAG_FWDB(1); break;
         case 2: SNAG_FWDB(2); break;

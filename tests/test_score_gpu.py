@@ -26,6 +26,8 @@ def _mk(N, R, D, B, K, seed, idt=torch.int64, scale=0.5):
     (128, 3, 50, torch.int32), (128, 33, 40, torch.int64), (128, 70, 19, torch.int32), (128, 128, 16, torch.int32),
     (64, 32, 100, torch.int32), (256, 128, 48, torch.int32), (300, 7, 30, torch.int64), (100, 5, 21, torch.int32),
     (512, 9, 12, torch.int32), (4, 2, 9, torch.int32),
+    # several waves per triple (two at 96 <= K < 128, four from K = 128), ragged shares, a dead wave at the end of the grid
+    (128, 100, 37, torch.int32), (256, 130, 9, torch.int64), (128, 129, 3, torch.int32), (64, 97, 2, torch.int32),
 ])
 def test_score_fwd_bwd_vs_oracle(D, K, B, idt):
     from snag_amd import ops
@@ -136,7 +138,7 @@ def test_score_empty_batch():
     assert pos.numel() == 0 and ng.shape == (0, 4)
 
 
-@pytest.mark.parametrize("D,K,B", [(256, 128, 64), (128, 32, 100), (64, 5, 33), (512, 17, 9)])
+@pytest.mark.parametrize("D,K,B", [(256, 128, 64), (128, 32, 100), (64, 5, 33), (512, 17, 9), (128, 100, 33), (256, 130, 10), (128, 129, 3)])
 def test_score_bf16_tables(D, K, B):
     """Config-5 storage: bf16 tables, fp32 math.  The oracle runs on the same bf16-rounded values, so parity stays 1e-5."""
     from snag_amd import ops
