@@ -354,9 +354,9 @@ template <typename IdxT>
 static int launch_fwd(const float* ent, int64_t eld, const float* rel, int dim, const void* h, const void* r, const void* t,
                       const void* neg_t, int64_t batch, int n_neg, float margin, float* pos, float* neg,
                       float* loss_part, hipStream_t st) {
-    // several waves per triple while the batch alone cannot fill the chip with independent gather chains (K = 128 at B = 1024;
-    // not the all-entity ranking form, whose batch is small but whose rows are one long coalesced sweep)
-    const int wpt = (neg_t != nullptr && batch <= 4096 && n_neg >= 128) ? 4 : (neg_t != nullptr && batch <= 4096 && n_neg >= 96) ? 2 : 1;
+    // several waves per triple while the batch alone cannot fill the chip with independent gather chains (K = 128 at B = 1024,
+    // and the all-entity ranking form of link prediction at a few thousand queries)
+    const int wpt = (batch <= 4096 && n_neg >= 128) ? 4 : (batch <= 4096 && n_neg >= 96) ? 2 : 1;
     const dim3 grid((unsigned)ceil_div(batch, 4 / wpt)), block(256);
     const int nv = (dim + 63) / 64;
 #define SNAG_FWD(NV)                                                                                                           \
