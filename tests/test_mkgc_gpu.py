@@ -51,6 +51,8 @@ def oracle_params(eng):
     # ragged everything: entity count, feature widths and hidden size that are not multiples of 4 / 64 (checked GEMM loaders, padded rows)
     (2, "Mformer_hd_graph", 0, True, torch.int32, (701, 5, 100, 33, 5, 37, 10)),
     (1, "Mformer_hd_mean", 1, False, torch.int64, (333, 3, 36, 17, 3, 13, 9)),
+    # BASELINE configs[1] at its full size: 15,000 entities, 4096/768-wide features, 1,024 triples x 32 negative tails
+    (2, "Mformer_hd_graph", 0, True, torch.int32, (15000, 558, 128, 1024, 32, 4096, 768)),
     # two Mformer layers (num_hidden_layers = 2), with and without the FFN: shape tuple carries an 8th entry = layer count
     (2, "Mformer_hd_graph", 1, True, torch.int32, (400, 7, 64, 48, 8, 40, 24, 2)),
     (1, "Mformer_hd_mean", 0, False, torch.int32, (400, 7, 64, 48, 8, 40, 24, 2)),
