@@ -557,5 +557,84 @@ class MKGCHotPath:
     def named_parameters(self):
         return self._logical(self.p)
 
+    # ---- checkpoints ---------------------------------------------------------------------------------------------------------
+    def fusion_state_dict(self):
+        """The Mformer part under the REFERENCE's state_dict keys (``weight_raw``, ``fusion_layer.{l}.attention.self.query.weight`` ...,
+        model/SNAG_tools.py:159-298): loads into the reference's ``MformerFusion`` / ``snag_amd.fusion.MformerFusion`` unchanged."""
+        D, out = self.cfg.dim, {"weight_raw": self.p["weight_raw"].clone()}
+        for l in range(self.cfg.num_layers):
+            pre = f"fusion_layer.{l}."
+            for j, nm in enumerate(("query", "key", "value")):
+                out[pre + f"attention.self.{nm}.weight"] = self.p[f"layer{l}.wqkv"][j * D:(j + 1) * D].clone()
+                out[pre + f"attention.self.{nm}.bias"] = self.p[f"layer{l}.bqkv"][j * D:(j + 1) * D].clone()
+            out[pre + "attention.output.dense.weight"] = self.p[f"layer{l}.wo"].clone()
+            out[pre + "attention.output.dense.bias"] = self.p[f"layer{l}.bo"].clone()
+            out[pre + "attention.output.LayerNorm.weight"] = self.p[f"layer{l}.ln1_g"].clone()
+            out[pre + "attention.output.LayerNorm.bias"] = self.p[f"layer{l}.ln1_b"].clone()
+            if self.cfg.use_intermediate:
+                out[pre + "intermediate.dense.weight"] = self.p[f"layer{l}.w1"].clone()
+                out[pre + "intermediate.dense.bias"] = self.p[f"layer{l}.b1"].clone()
+                out[pre + "output.dense.weight"] = self.p[f"layer{l}.w2"].clone()
+                out[pre + "output.dense.bias"] = self.p[f"layer{l}.b2"].clone()
+                out[pre + "output.LayerNorm.weight"] = self.p[f"layer{l}.ln2_g"].clone()
+                out[pre + "output.LayerNorm.bias"] = self.p[f"layer{l}.ln2_b"].clone()
+        return out
+
+    def load_fusion_state_dict(self, sd):
+        """Inverse of ``fusion_state_dict`` (a reference checkpoint's fusion keys; unused ``output.*`` entries of FFN-less layers are ignored,
+        as the reference constructs but never calls them, SNAG_tools.py:277)."""
+        D = self.cfg.dim
+        with torch.no_grad():
+            self.p["weight_raw"].copy_(sd["weight_raw"])
+            for l in range(self.cfg.num_layers):
+                pre = f"fusion_layer.{l}."
+                for j, nm in enumerate(("query", "key", "value")):
+                    self.p[f"layer{l}.wqkv"][j * D:(j + 1) * D].copy_(sd[pre + f"attention.self.{nm}.weight"])
+                    self.p[f"layer{l}.bqkv"][j * D:(j + 1) * D].copy_(sd[pre + f"attention.self.{nm}.bias"])
+                for src, dst in (("attention.output.dense.weight", "wo"), ("attention.output.dense.bias", "bo"),
+                                 ("attention.output.LayerNorm.weight", "ln1_g"), ("attention.output.LayerNorm.bias", "ln1_b")):
+                    self.p[f"layer{l}.{dst}"].copy_(sd[pre + src])
+                if self.cfg.use_intermediate:
+                    for src, dst in (("intermediate.dense.weight", "w1"), ("intermediate.dense.bias", "b1"), ("output.dense.weight", "w2"),
+                                     ("output.dense.bias", "b2"), ("output.LayerNorm.weight", "ln2_g"), ("output.LayerNorm.bias", "ln2_b")):
+                        self.p[f"layer{l}.{dst}"].copy_(sd[pre + src])
+
+    def state_dict(self):
+        """Everything a resumed run needs: parameters (logical [out, in] layouts), both Adam moments, the device step counter, the
+        noise epoch and the cached noise tensors."""
+        from dataclasses import asdict
+        moments = {}
+        for name, buf in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+            views = {k: buf[o:o + math.prod(shp)].view(shp) for k, (o, shp) in self.slices.items()}
+            moments[name] = {k: v.clone() for k, v in self._logical(views).items()}
+        return {"cfg": asdict(self.cfg), "params": {k: v.clone() for k, v in self.named_parameters().items()}, **moments,
+                "tick": self.tick.clone(), "noise_epoch": self.noise_epoch, "noise_active": self.noise_active,
+                "noisy": [x.clone() for x in self.noisy], "ent_noise": self.ent_noise.clone(), "ent_noise_mask": self.ent_noise_mask.clone()}
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            for k, v in sd["params"].items():
+                self.named_parameters()[k].copy_(v)
+            for name, buf in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+                views = self._logical({k: buf[o:o + math.prod(shp)].view(shp) for k, (o, shp) in self.slices.items()})
+                for k, v in sd[name].items():
+                    views[k].copy_(v)
+            self.tick.copy_(sd["tick"])
+            self.noise_epoch, self.noise_active = int(sd["noise_epoch"]), bool(sd["noise_active"])
+            for i, x in enumerate(sd["noisy"]):
+                self.noisy[i].copy_(x)
+                self._transposed(self.noisy[i], self.noisy_t[i])
+            self.ent_noise.copy_(sd["ent_noise"])
+            self.ent_noise_mask.copy_(sd["ent_noise_mask"])
+
+    def save_checkpoint(self, path):
+        """``torch.save`` of ``state_dict()`` (the reference's checkpoints are ``torch.save(model.state_dict())`` too, main.py:482-500)."""
+        torch.save(self.state_dict(), path)
+        return path
+
+    def load_checkpoint(self, path):
+        self.load_state_dict(torch.load(path, map_location=self.dev))
+        return self
+
     def named_gradients(self):
         return self._logical(self.g)

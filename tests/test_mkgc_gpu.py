@@ -293,3 +293,42 @@ def test_train_epoch_learns_a_planted_graph():
     assert losses[-1] < 0.85 * losses[0], losses
     assert after["mr"] < 0.75 * before["mr"] and after["hits"][1] > before["hits"][1], (before["mr"], after["mr"], before["hits"], after["hits"])
     assert eng.noise_epoch == 30
+
+
+def test_checkpoint_resume_is_exact_and_fusion_keys_are_the_references(tmp_path):
+    """save / load: a run resumed from a checkpoint continues bit for bit (deterministic mode), and the Mformer part travels under the
+    reference's state_dict keys into the drop-in module and back."""
+    import os
+    import types
+    from snag_amd.fusion import MformerFusion
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    N, R, D, B, K = 600, 7, 64, 96, 8
+    g = torch.Generator().manual_seed(41)
+    feats = [torch.rand(N, 40, generator=g), torch.randn(N, 24, generator=g)]
+    batches = [[torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(DEV) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (N, (B, K)))]
+               for _ in range(6)]
+    mk = lambda: MKGCHotPath(MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[40, 24], neg_num=K, use_intermediate=1, intermediate_size=48,
+                                        dropout=0.1, add_noise=1, seed=6, lr=2e-3, deterministic=True), feats, device=DEV)
+    straight = mk()
+    straight.update_noise()
+    for b in batches:
+        straight.train_step(*b)
+    first = mk()
+    first.update_noise()
+    for b in batches[:3]:
+        first.train_step(*b)
+    path = first.save_checkpoint(os.path.join(str(tmp_path), "ckpt.pt"))
+    resumed = mk().load_checkpoint(path)
+    for b in batches[3:]:
+        resumed.train_step(*b)
+    assert torch.equal(resumed.flat, straight.flat) and torch.equal(resumed.exp_avg_sq, straight.exp_avg_sq)
+    assert int(resumed.tick[0]) == 6 and resumed.noise_epoch == 1
+    # the fusion part under the reference's keys
+    sd = straight.fusion_state_dict()
+    args = types.SimpleNamespace(hidden_size=D, num_attention_heads=2, num_hidden_layers=1, use_intermediate=1, intermediate_size=48)
+    mod = MformerFusion(args, modal_num=3)
+    mod.load_state_dict({k: v.cpu() for k, v in sd.items()}, strict=True)
+    other = mk()
+    other.load_fusion_state_dict({k: v.to(DEV) for k, v in mod.state_dict().items()})
+    for k in ("weight_raw", "layer0.wqkv", "layer0.bqkv", "layer0.wo", "layer0.ln1_g", "layer0.w1", "layer0.b2", "layer0.ln2_b"):
+        assert torch.equal(other.p[k], straight.p[k]), k
