@@ -56,6 +56,23 @@ class MKGCConfig:
         return len(self.feat_dims) + 1
 
 
+def cosine_lr(step, total_steps, warmup_steps, base_lr, num_cycles=0.5):
+    """Learning rate of the reference's ``--scheduler cos`` (run_snag.sh; src/utils.py:75-76 -> transformers'
+    ``get_cosine_schedule_with_warmup``) after ``step`` optimiser steps: linear warm-up, then half a cosine to zero.  The engine reads
+    ``cfg.lr`` at every ``optimizer_step``, so ``eng.cfg.lr = cosine_lr(...)`` before the step is the whole integration."""
+    if step < warmup_steps:
+        return base_lr * step / max(1, warmup_steps)
+    progress = (step - warmup_steps) / max(1, total_steps - warmup_steps)
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * num_cycles * 2.0 * progress)))
+
+
+def linear_lr(step, total_steps, warmup_steps, base_lr):
+    """``--scheduler linear`` (src/utils.py:71-74 -> ``get_linear_schedule_with_warmup``)."""
+    if step < warmup_steps:
+        return base_lr * step / max(1, warmup_steps)
+    return base_lr * max(0.0, (total_steps - step) / max(1, total_steps - warmup_steps))
+
+
 def _align(n, a=64):
     return (n + a - 1) // a * a
 

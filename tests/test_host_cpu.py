@@ -85,3 +85,18 @@ def test_stacked_qkv_view_is_free_when_adjacent():
     assert s.data_ptr() == flat.data_ptr() and torch.equal(s, flat)
     s2 = _stacked([q.clone(), k.clone(), v.clone()])
     assert torch.equal(s2, flat)
+
+
+def test_lr_schedules_match_transformers():
+    """cosine_lr / linear_lr == transformers' get_*_schedule_with_warmup, which the reference's set_optim installs (src/utils.py:71-76)."""
+    import torch
+    from transformers import get_cosine_schedule_with_warmup, get_linear_schedule_with_warmup
+    from snag_amd.mkgc import cosine_lr, linear_lr
+    for make, mine in ((get_cosine_schedule_with_warmup, cosine_lr), (get_linear_schedule_with_warmup, linear_lr)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=5e-4)
+        sch = make(opt, num_warmup_steps=7, num_training_steps=50)
+        for step in range(55):
+            assert abs(sch.get_last_lr()[0] - mine(step, 50, 7, 5e-4)) < 1e-12, (make.__name__, step)
+            opt.step()
+            sch.step()
