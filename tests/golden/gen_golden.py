@@ -21,6 +21,7 @@ Vectors (SURVEY.md par. 8c):
   g11_data.npz       dataset readers on a tiny synthetic DBP15K-layout directory: read_raw_data / load_relation / load_attr / load_img /
                      get_adjr / load_eva_data (src/data.py, src/utils.py:327-362); the fixture holds the synthetic files and the outputs
   g13_data_surface_unsup.npz  loader options: GloVe name / character-bigram features (--use_surface) and unsupervised visual pivots (--unsup)
+  g14_set_optim.npz  set_optim parameter groups / cosine schedule on the SNAG model (src/utils.py:25-86)
   g12_gcn.npz        GCN structural encoder option (model/Tool_model.py:98-110, model/layers.py:102-130), output and grads
   g8_icl_loss.npz    icl_loss (bidirectional InfoNCE, model/SNAG_loss.py:31-128) + CustomMultiLossLayer, loss and grads
 """
@@ -620,6 +621,36 @@ def gen_g11():
                   "train_ill": kgs["train_ill"], "test_ill": np.array(test_ill_), "left_non_train": np.array(non_train["left"]),
                   "right_non_train": np.array(non_train["right"]), "input_idx": kgs["input_idx"]})
     save("g11_data.npz", d)
+
+
+def gen_g14():
+    """set_optim (src/utils.py:25-86) on the reference SNAG model of golden G10: which parameter NAMES land in which group, with
+    which lr / weight decay, and the cosine schedule's first learning rates."""
+    from src.utils import set_optim
+    z = dict(np.load(os.path.join(OUT, "g10_snag_model.npz")))
+    N = int(z["N"])
+    adj = torch.sparse_coo_tensor(torch.from_numpy(z["edges"]), torch.ones(z["edges"].shape[1]), (N, N))
+    wo = z["ent_wo_img"].tolist()
+    kgs = {"ent_num": N, "images_list": z["images_list"], "rel_features": z["rel_features"], "att_features": z["att_features"],
+           "name_features": None, "char_features": None, "input_idx": torch.arange(N), "ent_wo_img": wo,
+           "ent_w_img": [i for i in range(N) if i not in set(wo)], "adj": adj, "train_ill": z["train_ill"]}
+    model = SNAG(kgs, snag_args(int(z["D"])))
+    opt = types.SimpleNamespace(model_name="SNAG", lr=5e-4, weight_decay=1e-4, adam_epsilon=1e-8, optim="adamw", scheduler="cos",
+                                warmup_steps=40, total_steps=400, accumulation_steps=2)
+    optimizer, scheduler = set_optim(opt, [model], [], [], None)
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    d = {}
+    for gi, gr in enumerate(optimizer.param_groups):
+        d[f"group{gi}.names"] = np.array([name_of[id(p)] for p in gr["params"]])
+        d[f"group{gi}.initial_lr"] = gr["initial_lr"]
+        d[f"group{gi}.weight_decay"] = gr["weight_decay"]
+    lrs = []
+    for _ in range(30):
+        lrs.append([g_["lr"] for g_ in optimizer.param_groups])
+        optimizer.step()
+        scheduler.step()
+    d["lrs"] = np.array(lrs)
+    save("g14_set_optim.npz", d)
 
 
 def gen_g13():

@@ -230,3 +230,23 @@ def test_surface_form_modalities_end_to_end(tmp_path):
     with torch.no_grad():
         final, _ = model.joint_emb_generat()
     assert final.shape[1] == 6 * 32
+
+
+def test_set_optim_groups_and_schedule_match_reference():
+    """snag_amd.optim.set_optim on the drop-in SNAG model == the reference's set_optim on its model (golden G14): the same parameter
+    names in the same three groups (decayed / undecayed / 5x-lr loss weights), the same cosine schedule."""
+    from snag_amd.optim import set_optim
+    z10, z14 = load("g10_snag_model.npz"), load("g14_set_optim.npz")
+    model = build(z10)
+    opt = types.SimpleNamespace(model_name="SNAG", lr=5e-4, weight_decay=1e-4, adam_epsilon=1e-8, optim="adamw", scheduler="cos",
+                                warmup_steps=40, total_steps=400, accumulation_steps=2)
+    optimizer, scheduler = set_optim(opt, [model], [], [], None)
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    assert len(optimizer.param_groups) == 3
+    for gi, gr in enumerate(optimizer.param_groups):
+        assert [name_of[id(p)] for p in gr["params"]] == [str(s) for s in z14[f"group{gi}.names"]], gi
+        assert gr["initial_lr"] == pytest.approx(float(z14[f"group{gi}.initial_lr"])) and gr["weight_decay"] == float(z14[f"group{gi}.weight_decay"])
+    for row in z14["lrs"]:
+        assert [g_["lr"] for g_ in optimizer.param_groups] == pytest.approx(row.tolist(), rel=1e-12, abs=1e-18)
+        optimizer.step()
+        scheduler.step()
