@@ -192,7 +192,7 @@ static void launch_cfg(const GemmOperands& p, const Epilogue& e, float* slab, in
 #undef SNAG_GEMM
 }
 
-static int streamk_blocks() { static const int v = env_int("SNAG_GEMM_SK_BLOCKS"); return v > 0 ? v : 1024; }   // 4 per CU
+static int streamk_blocks() { static const int v = env_int("SNAG_GEMM_SK_BLOCKS"); return v > 0 ? v : 512; }    // 2 per CU (measured: 512 < 768 < 1024 in time; 256 / 384 much worse)
 static int streamk_mode() { static const int v = env_int("SNAG_GEMM_SK"); return v; }                          // tuning: 1 = never, 2 = whenever splitting
 
 struct StreamKChoice {

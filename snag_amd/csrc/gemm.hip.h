@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmOperands p, Epi epi,
     }
 }
 
-// Stream-K: G persistent blocks share the (tile, k-tile) iteration space evenly, so every CU gets the same MFMA work whatever
+// Stream-K: G persistent blocks (512 = two per CU by default) share the (tile, k-tile) iteration space evenly, so every CU gets the same MFMA work whatever
 // tiles x splits would have been modulo the CU count (235 tiles x 5 splits = 4.59 blocks per CU otherwise runs at the pace of
 // the CUs that got 5).  Block b owns iterations [total*b/G, total*(b+1)/G) of the tile-major order; a tile it covers completely
 // goes straight through the epilogue, a partial one is parked as a raw BM x BN tile in slab[(b*max_seg + seg)] and summed in
