@@ -21,6 +21,16 @@ def short(name):
     return (name[:cut] if cut > 0 else name)[:78]
 
 
+def split_bimodal(vals):
+    """Two launches of one kernel with the same grid but different shapes (the visual and the text projection both run as 512
+    stream-K workgroups) share a (kernel, grid) key: split such a group at the geometric mean of its extremes."""
+    if len(vals) < 4 or min(vals) <= 0 or max(vals) / min(vals) < 2.5:
+        return None
+    cut = (min(vals) * max(vals)) ** 0.5
+    hi, lo = [v for v in vals if v >= cut], [v for v in vals if v < cut]
+    return (hi, lo) if hi and lo else None
+
+
 def main():
     out = open(sys.argv[-1], "w") if sys.argv[-1].endswith(".txt") else None
     dirs = [a for a in sys.argv[1:] if not a.endswith(".txt")]
@@ -35,6 +45,18 @@ def main():
             dur[(short(r["Kernel_Name"]), grid)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         for r in load(d + "/**/*counter_collection.csv"):
             ctr[(short(r["Kernel_Name"]), r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k in [k for k in dur if "gemm" in k[0]]:
+        sp = split_bimodal(dur[k])
+        if sp:
+            del dur[k]
+            dur[(k[0][:70] + " [long]", k[1])], dur[(k[0][:70] + " [short]", k[1])] = sp
+    for k in [k for k in ctr if "gemm" in k[0]]:
+        sps = {name: split_bimodal(vals) for name, vals in ctr[k].items()}
+        if sps and any(sps.values()):          # a counter that does not separate the two shapes is quoted as their mean on both rows
+            cs = ctr.pop(k)
+            for tag, idx in ((" [long]", 0), (" [short]", 1)):
+                for name in cs:
+                    ctr[(k[0][:70] + tag, k[1])][name] = sps[name][idx] if sps[name] else cs[name]
     lines = []
     if dur:
         tot = sum(sum(v) for v in dur.values())
