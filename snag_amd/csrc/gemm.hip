@@ -243,7 +243,9 @@ static int launch_streamk(const GemmOperands& p, const Epilogue& e, float* slab,
 // blocks per CU hide it.  Each split keeps at least kMinKTiles k-tiles of work.
 static constexpr int kTargetBlocks = 1024, kMinKTiles = 16;
 
+static int target_blocks() { static const int v = env_int("SNAG_GEMM_TARGET"); return v > 0 ? v : kTargetBlocks; }   // tuning
 static int pick_splits(int64_t tiles, int K, bool both_kc = false) {
+    const int kTargetBlocks = target_blocks();
     if (tiles >= kTargetBlocks / 2) return 1;
     if (both_kc && tiles >= 192) return 1;      // measured: X W^T shapes with ~1 tile per CU gain nothing from splitting
     const int64_t want = (kTargetBlocks + tiles - 1) / tiles;
