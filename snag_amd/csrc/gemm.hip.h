@@ -130,7 +130,7 @@ struct Stager {
     }
 
     __device__ __forceinline__ void dma(lds_float* tile, int64_t ld, int k0, int wave) const {
-        const int64_t off = KC ? (int64_t)k0 : (int64_t)k0 * ld;
+        [[maybe_unused]] const int64_t off = KC ? (int64_t)k0 : (int64_t)k0 * ld;      // (the host pass compiles the body away)
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             if (!used(s, 256 * s + 64 * wave)) continue;        // wave-uniform
