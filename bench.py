@@ -163,6 +163,36 @@ def untimed_extras(eng, batches, args, device):
     return out
 
 
+def score_hbm_resident(device):
+    """The scoring kernel where it IS HBM-bound (BASELINE configs[4]: |E| = 1M, D = 256, K = 128; a 1 GB fp32 / 512 MB bf16 table, far
+    beyond the 256 MB Infinity Cache), uniform indices, per launch: the north_star's "fraction of the HBM roofline on the neg-sampled
+    scoring kernel" without the launch-latency floor that dominates the 18.6 MB launch of the 15k-entity step."""
+    from snag_amd._lib import call, ptr, stream
+    N, R, D, K = 1_000_000, 1000, 256, 128
+    g = torch.Generator().manual_seed(5)
+    ent = torch.empty(N, D, device=device).normal_()
+    rel = torch.randn(R, D, generator=g).to(device)
+    tables = {"f32": (ent, rel, "snag_score_margin_fwd", 4), "bf16": (ent.to(torch.bfloat16), rel.to(torch.bfloat16), "snag_score_margin_fwd_bf16", 2)}
+    out = {"table": "|E|=1M x 256, K=128 negatives, uniform indices", "peak_GBs": HBM_PEAK_GBS}
+    for dt, (e, rl, fn, esz) in tables.items():
+        for B in (1024, 32768):
+            idx = [torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(device) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (N, (B, K)))]
+            pos, ng, lp = torch.empty(B, device=device), torch.empty(B, K, device=device), torch.empty(B, device=device)
+            run = lambda: call(fn, ptr(e), D, N, ptr(rl), R, D, ptr(idx[0]), ptr(idx[1]), ptr(idx[2]), ptr(idx[3]), 4, B, K, 12.0, ptr(pos), ptr(ng), ptr(lp), stream())
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 20
+            by = B * ((K + 3) * D * esz + (K + 3) * 4 + (K + 1) * 4)
+            out[f"{dt}_B{B}"] = {"avg_us": us, "achieved": by / us / 1e3, "unit": "GB/s", "frac": by / us / 1e3 / HBM_PEAK_GBS, "triples_per_s": B / us * 1e6}
+    return out
+
+
 def cpu_baseline(cfg, feats, batch, budget_s, seed):
     """The CPU oracle (plain PyTorch restatement of the reference path) on this host's cores: same step definition."""
     from oracle import ref_cpu as O
@@ -373,6 +403,7 @@ def main():
             out["score_kernel"] = roofline_score(cfg, args.batch, timers["score_fwd"])
             if not args.no_extras:
                 out["score_kernel"]["epoch_fused"] = score_epoch_fused(eng, cfg, args.batch, device)
+                out["score_kernel"]["hbm_resident"] = score_hbm_resident(device)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, [f.cpu() for f in feats], args.batch, args.cpu_seconds, cfg.seed)
         print(json.dumps(out))
