@@ -242,13 +242,21 @@ class MformerFusion(nn.Module):
         return c
 
     def _draw_masks(self, cfg, device):
+        """Inverted-dropout keep masks of a training forward: ONE Philox launch over one byte buffer (snag_dropout_keep_mask), seeded
+        from torch's CPU generator -- so ``torch.manual_seed`` makes a run reproducible, as it does for the reference's nn.Dropout."""
         p = cfg.drop_p
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        al = lambda n: (n + 63) // 64 * 64
+        n_probs, n_tok = al(cfg.N * cfg.H * cfg.M * cfg.M), al(cfg.N * cfg.M * cfg.D)
+        per_layer = n_probs + n_tok * (2 if cfg.ffn else 1)
+        buf = ops.dropout_keep_mask((cfg.L * per_layer,), p, seed, device=device)
         masks = []
-        for _ in range(cfg.L):
-            m = {"probs": (torch.rand(cfg.N, cfg.H, cfg.M, cfg.M, device=device) >= p).to(torch.uint8),
-                 "attn_out": (torch.rand(cfg.N, cfg.M, cfg.D, device=device) >= p).to(torch.uint8)}
+        for l in range(cfg.L):
+            o = l * per_layer
+            m = {"probs": buf[o:o + cfg.N * cfg.H * cfg.M * cfg.M].view(cfg.N, cfg.H, cfg.M, cfg.M),
+                 "attn_out": buf[o + n_probs:o + n_probs + cfg.N * cfg.M * cfg.D].view(cfg.N, cfg.M, cfg.D)}
             if cfg.ffn:
-                m["ffn_out"] = (torch.rand(cfg.N, cfg.M, cfg.D, device=device) >= p).to(torch.uint8)
+                m["ffn_out"] = buf[o + n_probs + n_tok:o + n_probs + n_tok + cfg.N * cfg.M * cfg.D].view(cfg.N, cfg.M, cfg.D)
             masks.append(m)
         return masks
 

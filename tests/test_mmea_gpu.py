@@ -250,3 +250,28 @@ def test_set_optim_groups_and_schedule_match_reference():
         assert [g_["lr"] for g_ in optimizer.param_groups] == pytest.approx(row.tolist(), rel=1e-12, abs=1e-18)
         optimizer.step()
         scheduler.step()
+
+
+def test_mmea_training_is_reproducible_run_to_run():
+    """Same seeds, same data: two runs of the drop-in SNAG model give identical parameters (alignment seeds name each entity once, so
+    the InfoNCE gradient scatter never has two adds to one address; every other reduction in the path is fixed-order)."""
+    z = load("g10_snag_model.npz")
+
+    def run():
+        torch.manual_seed(123)                       # seeds the Bert-dropout mask draws, as for the reference's nn.Dropout
+        model = build(z)
+        model.noise_mode = "philox"
+        opt = torch.optim.AdamW(model.parameters(), lr=2e-3)
+        model.train()
+        for it in range(5):
+            model.update_noise(seed=it)
+            loss, _ = model(z["train_ill"])
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        return {k: v.detach().clone() for k, v in model.state_dict().items()}, float(loss.detach())
+    a, la = run()
+    b, lb = run()
+    assert la == lb
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
