@@ -288,6 +288,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (forward-only rate, copy ceiling, epoch-fused score probe)")
     args = ap.parse_args()
 
+    # RCCL prints its version banner on STDOUT when the first communicator comes up; the contract is ONE JSON line there, so
+    # everything written to fd 1 before the result goes to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -406,7 +411,10 @@ def main():
                 out["score_kernel"]["hbm_resident"] = score_hbm_resident(device)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, [f.cpu() for f in feats], args.batch, args.cpu_seconds, cfg.seed)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist.is_initialized():
         dist.destroy_process_group()
 
