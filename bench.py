@@ -268,7 +268,16 @@ def cpu_baseline(cfg, feats, batch, budget_s, seed):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": batch / med, "unit": "triples/s", "cores": best_thr, "kind": "port",
+    model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": batch / med, "unit": "triples/s", "cores": best_thr, "kind": "port", "cpu": model,
             "sample": f"{len(times)} steps of the same workload (N={N}, B={batch}, K={cfg.neg_num}, fwd+bwd+clip+AdamW) at {best_thr} of "
                       f"{avail} usable threads, median {med * 1e3:.0f} ms/step, torch {torch.__version__} CPU"}
 
