@@ -97,42 +97,26 @@ def roofline_dominant(cfg, timer):
             "avg_us": us, "launches_timed": n, "algorithmic_flops_per_launch": flops}
 
 
+def score_train_bytes(cfg, n_triples):
+    """SURVEY.md par. 8(d), forward + hinge backward in one launch: the forward's bytes (rows read ONCE) plus the read-modify-write
+    of (K+3) gradient rows of D fp32 per triple (no upstream-gradient read in hinge mode)."""
+    return score_bytes(cfg, n_triples) + n_triples * (cfg.neg_num + 3) * cfg.dim * 4 * 2
+
+
 def roofline_score(cfg, batch, timer):
-    """north_star's kernel: the negative-sampled scoring forward, one launch per 1024-triple batch, vs the 8 TB/s HBM figure."""
+    """north_star's kernel in its training form: score_fused_kernel (snag_score_margin_fwd_bwd), ONE launch per 1024-triple batch
+    that gathers every row once, writes scores + losses and scatter-adds the gradients, vs the 8 TB/s HBM figure.  The 7.7 MB table
+    is cache-resident at this size: `achieved` is ALGORITHMIC bytes / time, and the binding resource is the memory-side fp32-atomic
+    rate (~1.3 TB/s of added bytes, MI355X_MICROARCH.md): atomic_floor_us is what that rate alone allows."""
     us, n = timer.mean_us()
-    by = score_bytes(cfg, batch)
+    by = score_train_bytes(cfg, batch)
     ach = by / (us * 1e-6) / 1e9 if us else 0.0
-    return {"kernel": "score_fwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "avg_us": us, "launches_timed": n, "algorithmic_bytes_per_launch": by}
-
-
-def score_epoch_fused(eng, cfg, batch, device):
-    """The same kernel on a whole epoch of triples in ONE launch (78 batches).  The per-batch launch above is launch-latency-bound
-    (18.6 MB of gathers is ~2.3 us at 8 TB/s, SURVEY.md par. 7 "hard parts"); the 7.7 MB table is cache-resident, so this can exceed 1."""
-    from snag_amd._lib import call, ptr, stream
-    N, D, K = cfg.n_ent, cfg.dim, cfg.neg_num
-    Bep = STEPS_PER_EPOCH * batch
-    ge = torch.Generator().manual_seed(7)
-    hh, rr, tt, nn = (torch.randint(0, hi, sz, generator=ge, dtype=torch.int32).to(device)
-                      for hi, sz in ((N, (Bep,)), (cfg.n_rel, (Bep,)), (N, (Bep,)), (N, (Bep, K))))
-    table = eng.entity_representation()
-    pos, neg, part = torch.empty(Bep, device=device), torch.empty(Bep, K, device=device), torch.empty(Bep, device=device)
-
-    def launch():
-        call("snag_score_margin_fwd", ptr(table), table.stride(0), N, ptr(eng.p["rel"]), cfg.n_rel, D, ptr(hh), ptr(rr), ptr(tt), ptr(nn),
-             4, Bep, K, float(cfg.margin), ptr(pos), ptr(neg), ptr(part), stream())
-
-    for _ in range(3):
-        launch()
-    tm = KernelTimer()
-    timed = tm.wrap(launch)
-    for _ in range(10):
-        timed()
-    torch.cuda.synchronize()
-    us, _ = tm.mean_us()
-    by = score_bytes(cfg, Bep)
-    return {"triples_per_launch": Bep, "avg_us": us, "achieved": by / (us * 1e-6) / 1e9, "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-            "algorithmic_bytes_per_launch": by}
+    atomic_bytes = batch * (cfg.neg_num + 3) * cfg.dim * 4
+    return {"kernel": "score_fused_kernel (snag_score_margin_fwd_bwd: fwd + hinge bwd + summed loss, one launch)", "bound": "hbm",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_us": us, "launches_timed": n,
+            "algorithmic_bytes_per_launch": by, "forward_only_bytes_per_launch": score_bytes(cfg, batch),
+            "atomic_bytes_per_launch": atomic_bytes, "atomic_floor_us": atomic_bytes / 1.3e12 * 1e6,
+            "timed": "HIP events around the launch, inside the timed region"}
 
 
 def untimed_extras(eng, batches, args, device):
@@ -164,7 +148,7 @@ def untimed_extras(eng, batches, args, device):
 
 
 def score_hbm_resident(device):
-    """The scoring kernel where it IS HBM-bound (BASELINE configs[4]: |E| = 1M, D = 256, K = 128; a 1 GB fp32 / 512 MB bf16 table, far
+    """The scoring kernel where it IS HBM-bound (BASELINE.json configs[4], the 1M-entity stress shape: |E| = 1M, D = 256, K = 128; a 1 GB fp32 / 512 MB bf16 table, far
     beyond the 256 MB Infinity Cache), uniform indices, per launch: the north_star's "fraction of the HBM roofline on the neg-sampled
     scoring kernel" without the launch-latency floor that dominates the 18.6 MB launch of the 15k-entity step."""
     from snag_amd._lib import call, ptr, stream
@@ -294,7 +278,7 @@ def main():
                     help="db15k = BASELINE configs[1] (Mformer_hd_graph, num_proj=2, 558 relations); mkgw = configs[2] (Mformer_hd_mean, num_proj=1, 338 relations)")
     ap.add_argument("--deterministic", action="store_true", help="bit-reproducible steps (fixed-point integer atomics in the scorer's backward)")
     ap.add_argument("--graph", action="store_true", help="replay the whole step (sampling included) as one captured hipGraph (1 GPU; no per-kernel timers)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (forward-only rate, copy ceiling, epoch-fused score probe)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (forward-only rate, copy ceiling, HBM-resident score probe)")
     args = ap.parse_args()
 
     # RCCL prints its version banner on STDOUT when the first communicator comes up; the contract is ONE JSON line there, so
@@ -341,7 +325,7 @@ def main():
     if not args.no_kernel_timers:
         import snag_amd.mkgc as mk
         # time the two launches the roofline objects describe: projection l1 GEMM (dominant) and the score forward
-        timers["score_fwd"] = KernelTimer()
+        timers["score_fwd_bwd"] = KernelTimer()
         timers["proj_l1_fwd"] = KernelTimer()
         eng.probe = timers
 
@@ -350,7 +334,7 @@ def main():
             eng.update_noise()
         h, r, t = batches[i % len(batches)]
         ops.sample_negatives(h, r, t, cfg.neg_num, cfg.n_ent, cfg.n_rel, rank_seed, known_sorted=known, tick=eng.tick, out=neg_buf)
-        eng.forward(h, r, t, neg_buf)
+        eng.forward(h, r, t, neg_buf, with_backward=True, grad_scale=gscale)   # the scorer runs fwd+bwd as one launch here
         eng.backward(gscale, reducer=reducer)         # buckets go out as they become final (overlaps the projection backward)
         if reducer is not None:
             reducer.finish()
@@ -414,10 +398,9 @@ def main():
             out.update(untimed_extras(eng, batches, args, device))
         if timers:
             out["roofline"] = roofline_dominant(cfg, timers["proj_l1_fwd"])
-            out["score_kernel"] = roofline_score(cfg, args.batch, timers["score_fwd"])
+            out["roofline_score"] = roofline_score(cfg, args.batch, timers["score_fwd_bwd"])
             if not args.no_extras:
-                out["score_kernel"]["epoch_fused"] = score_epoch_fused(eng, cfg, args.batch, device)
-                out["score_kernel"]["hbm_resident"] = score_hbm_resident(device)
+                out["roofline_score"]["hbm_resident"] = score_hbm_resident(device)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, [f.cpu() for f in feats], args.batch, args.cpu_seconds, cfg.seed)
         sys.stdout.flush()

@@ -83,6 +83,22 @@ SNAG_API int snag_score_margin_bwd(const float* ent, int64_t ent_ld, int64_t n_e
                           const float* dpos, const float* dneg,
                           float* d_ent, int64_t d_ent_ld, float* d_rel, void* stream);
 
+/* Training form of the hinge scorer: forward AND backward in one launch (replaces MSNEA.kge term 1 model/MSNEA.py:110-122 together
+ * with its autograd, and the scalar sum :122).  Per triple the K+3 table rows are gathered ONCE; the launch writes
+ *   pos [batch], neg [batch, n_neg], loss_part [batch]           exactly as snag_score_margin_fwd does,
+ *   loss[0] = sum_b loss_part[b]  (optional; summed in a fixed order by the block that finishes last: bit-reproducible)
+ * and ACCUMULATES grad_scale * d(sum_b loss_part[b]) / d ent, d rel into d_ent (row stride d_ent_ld) / d_rel with fp32 atomics
+ * (caller zeroes them), exactly as snag_score_margin_bwd does in hinge mode.
+ * loss != NULL needs loss_part and `ticket`: SNAG_SCORE_TICKET_WORDS uint32 the caller zeroes ONCE (every launch leaves them
+ * zero again; launches that share a ticket buffer must be stream-ordered).
+ * neg_t must be given when n_neg > 0 (no implicit candidates here). */
+#define SNAG_SCORE_TICKET_WORDS 1056
+SNAG_API int snag_score_margin_fwd_bwd(const float* ent, int64_t ent_ld, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+                          const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                          int64_t batch, int n_neg, float margin, float grad_scale,
+                          float* pos, float* neg, float* loss_part, float* loss, uint32_t* ticket,
+                          float* d_ent, int64_t d_ent_ld, float* d_rel, void* stream);
+
 /* Bit-reproducible variant of snag_score_margin_bwd: the same gradients accumulated with 64-bit INTEGER atomics in fixed point
  * (32 fractional bits: sums are associative, so the result does not depend on the order the triples arrive in; |sum| < 2^31,
  * resolution 2.3e-10).  acc_ent [n_ent, dim] and acc_rel [n_rel, dim] are dense int64 accumulators the caller zeroes;

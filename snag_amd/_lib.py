@@ -16,6 +16,7 @@ _I = _c.c_int
 _L = _c.c_int64
 _F = _c.c_float
 _U64 = _c.c_uint64
+SCORE_TICKET_WORDS = 1056      # SNAG_SCORE_TICKET_WORDS (include/snag_hip.h)
 
 
 
@@ -62,6 +63,7 @@ SIGNATURES = {
     "snag_score_margin_fwd": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _P, _P, _P, _P],
     "snag_score_margin_fwd_bf16": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _P, _P, _P, _P],
     "snag_score_margin_bwd": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _L, _P, _P],
+    "snag_score_margin_fwd_bwd": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "snag_reduce_sum": [_P, _L, _P, _P],
     "snag_rank_full_table": [_P, _L, _L, _P, _I, _P, _P, _P],
     "snag_gemm_f32": [_c.POINTER(GemmDesc), _P],

@@ -53,10 +53,16 @@ def build(force=False, verbose=True):
         res = list(ex.map(lambda s: _compile(s, force), srcs))
     objs = [o for o, _ in res]
     if any(c for _, c in res) or not os.path.exists(LIB):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        # link to a private name and rename: the library appears atomically, so a rank that polls for it (ensure_built) can never
+        # dlopen a half-written file
+        tmp = f"{LIB}.tmp.{os.getpid()}"
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        os.replace(tmp, LIB)
         if verbose:
             print(f"built {LIB} from {len(objs)} objects")
     elif verbose:
@@ -76,9 +82,8 @@ def ensure_built(local_rank=0, timeout_s=900.0):
     while not os.path.exists(LIB):
         if time.time() - t0 > timeout_s:
             raise RuntimeError(f"{LIB} did not appear within {timeout_s:.0f} s")
-        time.sleep(1.0)
-    time.sleep(2.0)          # let the linker finish writing
-    return LIB
+        time.sleep(0.5)
+    return LIB               # build() renames the finished file into place, so existing means complete
 
 
 if __name__ == "__main__":

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/snag_hip.h"
 
@@ -74,6 +75,12 @@ __device__ __forceinline__ int wave_id_uniform() {
 __device__ __forceinline__ float l2_denominator(float ss) { return fmaxf(sqrtf(ss), 1e-12f); }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// tuning switches read once from the environment (0 when unset)
+static inline int env_int(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
 
 // gemm.hip
 int gemm_check(const snag_gemm_desc* d);

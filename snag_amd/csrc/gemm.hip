@@ -167,10 +167,6 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(GemmOperands p, float al
         });
 }
 
-static int env_int(const char* name) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : 0;
-}
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(const GemmOperands& p, const Epilogue& e, float* slab, int splits, bool a_kc, bool b_kc, hipStream_t st) {
     dim3 grid(ceil_div(p.N, BN), ceil_div(p.M, BM), splits), block(256);
@@ -205,7 +201,7 @@ static StreamKChoice plan_streamk(int M, int N, int K, int BM, int BN) {
     StreamKChoice c;
     const int tiles_m = ceil_div(M, BM);
     c.plan.tiles_n = ceil_div(N, BN);
-    c.plan.nkt = ceil_div(K, kBK);
+    c.plan.nkt = std::max(1, ceil_div(K, kBK));          // K == 0 never takes this route; keep the arithmetic below defined
     c.plan.total = (int64_t)tiles_m * c.plan.tiles_n * c.plan.nkt;
     int64_t G = streamk_blocks();
     while (G > 256 && c.plan.total / G < 16) G -= 256;
@@ -259,6 +255,7 @@ static int force_tile() { static const int v = env_int("SNAG_GEMM_TILE"); return
 static int force_splits() { static const int v = env_int("SNAG_GEMM_SPLITS"); return v; }
 
 int64_t gemm_workspace_floats(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
     // the largest fan-out any tile configuration may pick for this shape (the dispatcher clamps to what it is given)
     const int64_t t64 = (int64_t)ceil_div(M, 64) * ceil_div(N, 128), t160 = (int64_t)ceil_div(M, 128) * ceil_div(N, 160);
     const int splits = force_splits() > 0 ? force_splits() : std::max(pick_splits(t64, K), pick_splits(t160, K));
@@ -310,6 +307,9 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
         if (splits > cap) splits = (int)cap;
         if (splits < 1) splits = 1;
     }
+    // K == 0 is legal (C = epilogue(0): bias / add1 / accumulate still apply): one split with an empty k-range; the split
+    // arithmetic below would otherwise divide by zero
+    if (p.K == 0) splits = 1;
     if (splits > 1 && !big && !wide && streamk_mode() != 1) {
         // blocks per CU of the split grid vs what the slowest CU gets
         const double per_cu = (double)tiles * splits / 256.0;
@@ -324,8 +324,8 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
             return launch_streamk<64, 128, 32, 64>(p, e, d->workspace, c, d->a_kcontig, d->b_kcontig, st);
         }
     }
-    const int kps = ceil_div(ceil_div(p.K, splits), kBK) * kBK;
-    splits = ceil_div(p.K, kps);
+    const int kps = std::max(kBK, ceil_div(ceil_div(p.K, splits), kBK) * kBK);
+    splits = std::max(1, ceil_div(p.K, kps));
     p.k_per_split = kps;
     float* slab = splits > 1 ? d->workspace : nullptr;
     if (log_shapes())

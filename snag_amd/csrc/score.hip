@@ -9,6 +9,7 @@
 // Backward: one wave per triple, a row spread over the whole wave (col = lane + 64*i) so that every
 // fp32 atomic wave-instruction adds 256 contiguous bytes of one gradient row (the full-rate shape).
 #include "common.hip.h"
+#include "score_rows.hip.h"
 
 namespace snag {
 
@@ -164,62 +165,6 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(
 #pragma unroll
         for (int p = 0; p < WPT; ++p) tot += part_sum[wave + p];
         loss_part[b] = tot;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-template <int NS>
-struct RowS {
-    float v[NS];
-};
-
-template <int NS>
-__device__ __forceinline__ RowS<NS> load_row_s(const float* __restrict__ base, int64_t row, int64_t ld, int dim, int lane) {
-    RowS<NS> r;
-    const float* p = base + row * ld;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const int c = lane + 64 * i;
-        r.v[i] = (c < dim) ? p[c] : 0.f;
-    }
-    return r;
-}
-
-// x -> xhat = x / max(||x||, eps); returns the denominator
-template <int NS>
-__device__ __forceinline__ float normalize_s(RowS<NS>& x) {
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) ss = fmaf(x.v[i], x.v[i], ss);
-    const float den = l2_denominator(sum64(ss));
-    const float inv = 1.0f / den;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) x.v[i] *= inv;
-    return den;
-}
-
-// backward of F.normalize: dx = (dy - yhat (yhat . dy)) / ||x||   (clamped branch: dx = dy / eps)
-// Accumulators: float (fp32 atomics: fast, the last bits depend on the arrival order) or 64-bit fixed point with 32 fractional bits
-// (integer atomics: associative, so the sums are bit-reproducible whatever the order; |sum| < 2^31, resolution 2.3e-10).
-__device__ __forceinline__ void grad_add(float* p, float v) { atomicAdd(p, v); }
-__device__ __forceinline__ void grad_add(long long* p, float v) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn((double)v * 4294967296.0));
-}
-
-template <int NS, typename AccT>
-__device__ __forceinline__ void normalize_bwd_atomic(const RowS<NS>& yhat, float den, const RowS<NS>& dy,
-                                                     AccT* __restrict__ grad_row, int dim, int lane) {
-    float dot = 0.f;
-    if (den > 1e-12f) {
-#pragma unroll
-        for (int i = 0; i < NS; ++i) dot = fmaf(yhat.v[i], dy.v[i], dot);
-        dot = sum64(dot);
-    }
-    const float inv = 1.0f / den;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const int c = lane + 64 * i;
-        if (c < dim) grad_add(grad_row + c, (dy.v[i] - yhat.v[i] * dot) * inv);
     }
 }
 
@@ -557,7 +502,7 @@ static int launch_fwd_bf16(const uint16_t* ent, int64_t eld, const uint16_t* rel
     return check_launch("snag_score_margin_fwd_bf16");
 }
 
-static int check_score_args(const void* ent, int64_t n_ent, const void* rel, int64_t n_rel, int dim, const void* h,
+int check_score_args(const void* ent, int64_t n_ent, const void* rel, int64_t n_rel, int dim, const void* h,
                             const void* r, const void* t, const void* neg_t, int idx_bytes, int64_t batch, int n_neg) {
     SNAG_REQUIRE(ent && rel && h && r && t, SNAG_ERR_ARG, "score: null table or index pointer");
     SNAG_REQUIRE(n_ent > 0 && n_rel > 0 && dim > 0, SNAG_ERR_ARG, "score: n_ent=%ld n_rel=%ld dim=%d must be positive",

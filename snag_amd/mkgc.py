@@ -205,6 +205,8 @@ class MKGCHotPath:
         self.training = True
         self.probe = None                # optional {tag: timer with .wrap(fn)}: bench.py's per-kernel HIP-event timers
         self._loss_part = None
+        self._score_bwd_scale = None
+        self._ticket = torch.zeros(_lib.SCORE_TICKET_WORDS, device=dev, dtype=torch.int32)      # last-block ticket of the fused scorer (self-resetting)
         self.loss = torch.zeros((), device=dev)
         self._build_descs()
 
@@ -335,8 +337,21 @@ class MKGCHotPath:
         self.noise_active = True
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, h, r, t, neg_t, want_scores=False):
-        """Projections -> tokens -> fusion -> read-out -> scores/loss.  Returns the device scalar loss."""
+    def _zero_score_grads(self):
+        """Zero the scorer's scatter targets; returns (pointer, row stride) of the [N, dim] read-out gradient."""
+        cfg = self.cfg
+        self.g["rel"].zero_()
+        if cfg.joint_way == "Mformer_hd_mean":
+            self.d_repr.zero_()
+            return self.d_repr.data_ptr(), cfg.dim
+        self.d_hidden.zero_()
+        return self.d_hidden.data_ptr() + 4 * self.g_slot * cfg.dim, cfg.n_tokens * cfg.dim
+
+    def forward(self, h, r, t, neg_t, want_scores=False, with_backward=False, grad_scale=1.0):
+        """Projections -> tokens -> fusion -> read-out -> scores/loss.  Returns the device scalar loss.
+
+        ``with_backward``: a ``backward(grad_scale)`` follows (training).  The hinge scorer then runs forward and backward as ONE
+        launch here (snag_score_margin_fwd_bwd) and ``backward`` starts at the read-out gradient."""
         cfg = self.cfg
         N, D, M = cfg.n_ent, cfg.dim, cfg.n_tokens
         st = self._st = stream()
@@ -369,6 +384,18 @@ class MKGCHotPath:
             self._pos = torch.empty(B, device=self.dev)
             self._neg = torch.empty(B, K, device=self.dev)
         ib = 4 if h.dtype == torch.int32 else 8
+        self._batch = (h, r, t, neg_t, ib, B, K)
+        self._score_bwd_scale = None
+        if with_backward and cfg.loss == "hinge" and not cfg.deterministic and K > 0:
+            # training: the scorer's forward AND backward in one launch (every row gathered once, summed loss included)
+            d_repr, d_ld = self._zero_score_grads()
+            self._probed("score_fwd_bwd", call, "snag_score_margin_fwd_bwd", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D,
+                         ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K, float(cfg.margin), float(grad_scale), ptr(self._pos), ptr(self._neg),
+                         ptr(self._loss_part), ptr(self.loss), ptr(self._ticket), d_repr, d_ld, ptr(self.g["rel"]), st)
+            self._score_bwd_scale = float(grad_scale)
+            if want_scores:
+                return self.loss, self._pos, self._neg
+            return self.loss
         self._probed("score_fwd", call, "snag_score_margin_fwd", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r),
                      ptr(t), ptr(neg_t), ib, B, K, float(cfg.margin), ptr(self._pos), ptr(self._neg), ptr(self._loss_part), st)
         if cfg.loss == "self_adversarial":
@@ -379,7 +406,6 @@ class MKGCHotPath:
         elif cfg.loss != "hinge":
             raise ValueError(f"unknown loss {cfg.loss!r}")
         call("snag_reduce_sum", ptr(self._loss_part), B, ptr(self.loss), st)
-        self._batch = (h, r, t, neg_t, ib, B, K)
         if want_scores:
             return self.loss, self._pos, self._neg
         return self.loss
@@ -408,15 +434,16 @@ class MKGCHotPath:
         MD = M * D
         h, r, t, neg_t, ib, B, K = self._batch
         noisy = self.training and cfg.add_noise and self.noise_active
-        self.g["rel"].zero_()
-        if cfg.joint_way == "Mformer_hd_mean":
-            self.d_repr.zero_()
-            d_repr, d_ld = self.d_repr.data_ptr(), D
-        else:
-            self.d_hidden.zero_()
-            d_repr, d_ld = self.d_hidden.data_ptr() + 4 * self.g_slot * D, MD
+        fused_done = self._score_bwd_scale is not None
+        if fused_done and self._score_bwd_scale != float(grad_scale):
+            raise ValueError(f"forward(with_backward=True, grad_scale={self._score_bwd_scale}) was followed by backward(grad_scale={grad_scale})")
+        self._score_bwd_scale = None
+        if not fused_done:
+            d_repr, d_ld = self._zero_score_grads()
         up = (ptr(self._dpos), ptr(self._dneg)) if cfg.loss == "self_adversarial" else (None, None)
-        if cfg.deterministic:
+        if fused_done:
+            pass                                       # the scorer's gradients were scattered by the fused launch in forward()
+        elif cfg.deterministic:
             self._acc_ent.zero_()
             self._acc_rel.zero_()
             call("snag_score_margin_bwd_fixed", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r), ptr(t), ptr(neg_t),
@@ -467,7 +494,7 @@ class MKGCHotPath:
 
     def train_step(self, h, r, t, neg_t, allreduce=None):
         """forward + backward (+ gradient exchange) + AdamW.  ``allreduce(gflat)`` sums gradients across ranks."""
-        self.forward(h, r, t, neg_t)
+        self.forward(h, r, t, neg_t, with_backward=True)
         if allreduce is not None and hasattr(allreduce, "start"):
             self.backward(reducer=allreduce)
             allreduce.finish()
@@ -478,21 +505,38 @@ class MKGCHotPath:
         self.optimizer_step()
         return self.loss
 
-    def train_epoch(self, h, r, t, batch_size, known_sorted=None, allreduce=None, seed=None):
+    def train_epoch(self, h, r, t, batch_size, known_sorted=None, allreduce=None, seed=None, rank=None, world=None):
         """One epoch in the order the README's MKGC loop implies (noise refresh once per epoch -- "noise-level: epoch" --, then every
         batch: NEG_NUM negative tails drawn on the device, forward, backward, exchange, clip, AdamW).  ``h, r, t``: this rank's int32
-        training triples on the device; the last ragged batch is kept.  Returns the summed loss as a device scalar."""
+        training triples on the device.  Returns the summed loss as a device scalar.
+
+        Under data parallelism (``allreduce`` given and a process group up) every rank runs the SAME number of steps
+        (``parallel.common_step_count``; its own triples are cut into that many near-equal batches), and the rank is folded into the
+        sampler's seed so that the ranks do not draw the identical negative-candidate stream."""
+        import torch.distributed as dist
         from . import ops
+        from .parallel import common_step_count, step_bounds
         n = h.shape[0]
+        dp = allreduce is not None and dist.is_available() and dist.is_initialized()
+        if rank is None:
+            rank = dist.get_rank() if dp else 0
+        if world is None:
+            world = dist.get_world_size() if dp else 1
         epoch_seed = self.cfg.seed * 104729 + self.noise_epoch if seed is None else seed
+        sample_seed = epoch_seed * world + rank
         if self.cfg.add_noise:
             self.update_noise()
-        perm = torch.randperm(n, device=self.dev, generator=torch.Generator(device=self.dev).manual_seed(epoch_seed))
+        # the permutation is per rank too: every rank shuffles its OWN shard
+        perm = torch.randperm(n, device=self.dev, generator=torch.Generator(device=self.dev).manual_seed(sample_seed))
+        steps = common_step_count(n, batch_size) if dp else -(-n // batch_size)
         total = torch.zeros((), device=self.dev, dtype=f32)
-        for lo in range(0, n, batch_size):
-            idx = perm[lo:lo + batch_size]
+        for lo, hi in (step_bounds(n, steps) if dp else [(lo, min(n, lo + batch_size)) for lo in range(0, n, batch_size)]):
+            idx = perm[lo:hi]
             hb, rb, tb = h[idx].contiguous(), r[idx].contiguous(), t[idx].contiguous()
-            neg = ops.sample_negatives(hb, rb, tb, self.cfg.neg_num, self.cfg.n_ent, self.cfg.n_rel, epoch_seed, known_sorted=known_sorted, tick=self.tick)
+            if hi > lo:
+                neg = ops.sample_negatives(hb, rb, tb, self.cfg.neg_num, self.cfg.n_ent, self.cfg.n_rel, sample_seed, known_sorted=known_sorted, tick=self.tick)
+            else:       # a rank with fewer items than steps: zero-gradient step, still part of every collective
+                neg = torch.empty(0, self.cfg.neg_num, device=self.dev, dtype=torch.int32)
             total += self.train_step(hb, rb, tb, neg, allreduce=allreduce)
         return total
 

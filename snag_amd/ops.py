@@ -112,6 +112,43 @@ def score_margin_bwd(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, dpos=None
     return d_ent, d_rel
 
 
+_TICKETS = {}
+
+
+def _ticket(device):
+    """SNAG_SCORE_TICKET_WORDS zeroed uint32 per device for the fused scorer's last-block reduction (the kernel leaves it zero again)."""
+    key = (device.type, device.index)
+    if key not in _TICKETS:
+        _TICKETS[key] = torch.zeros(_lib.SCORE_TICKET_WORDS, device=device, dtype=torch.int32)
+    return _TICKETS[key]
+
+
+def score_margin_fwd_bwd(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, d_ent=None, d_rel=None, want_loss=True):
+    """Hinge scorer, forward and backward in one launch -> (loss 0-dim or None, pos [B], neg [B,K], loss_part [B], d_ent, d_rel).
+    Accumulates into d_ent / d_rel (allocated zeroed when None).  C ABI: snag_score_margin_fwd_bwd."""
+    _rows(ent, "ent"), _chk(rel, "rel", ndim=2)
+    if ent.shape[1] != rel.shape[1]:
+        raise ValueError(f"ent dim {ent.shape[1]} != rel dim {rel.shape[1]}")
+    if neg_t is None:
+        raise ValueError("score_margin_fwd_bwd needs explicit negative tails")
+    B, K, ib = _idx_group(h, r, t, neg_t)
+    if d_ent is None:
+        d_ent = torch.zeros(ent.shape, device=ent.device, dtype=f32)
+    if d_rel is None:
+        d_rel = torch.zeros_like(rel)
+    _rows(d_ent, "d_ent"), _chk(d_rel, "d_rel", ndim=2)
+    if d_ent.shape != ent.shape or d_rel.shape != rel.shape:
+        raise ValueError("gradient buffers must match the table shapes")
+    pos = torch.empty(B, device=ent.device, dtype=f32)
+    neg = torch.empty(B, K, device=ent.device, dtype=f32)
+    loss_part = torch.empty(B, device=ent.device, dtype=f32)
+    loss = torch.empty((), device=ent.device, dtype=f32) if want_loss else None
+    call("snag_score_margin_fwd_bwd", ptr(ent), ent.stride(0), ent.shape[0], ptr(rel), rel.shape[0], ent.shape[1],
+         ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K, float(margin), float(grad_scale), ptr(pos), ptr(neg), ptr(loss_part),
+         ptr(loss), ptr(_ticket(ent.device)) if want_loss else None, ptr(d_ent), d_ent.stride(0), ptr(d_rel), stream())
+    return loss, pos, neg, loss_part, d_ent, d_rel
+
+
 def reduce_sum(x):
     """Deterministic sum of a float tensor -> 0-dim tensor.  C ABI: snag_reduce_sum."""
     _chk(x, "x")

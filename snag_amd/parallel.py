@@ -26,6 +26,29 @@ def shard_batch(tensors, rank: int, world: int):
     return tuple(t[lo:hi].contiguous() for t in tensors)
 
 
+def common_step_count(n_local: int, batch_size: int, group=None) -> int:
+    """Number of optimiser steps EVERY rank runs this epoch: ceil(max over ranks of n_local / batch_size).
+
+    Shards handed out by ``shard_range`` differ by one item, so ``range(0, n_local, batch_size)`` can differ by one step between
+    ranks (1025 vs 1024 items at batch 1024): the rank with the extra step would then wait for ever in a gradient all-reduce
+    nobody else enters.  One tiny MAX all-reduce per epoch settles the count."""
+    if batch_size < 1:
+        raise ValueError(f"batch_size={batch_size}")
+    steps = -(-max(0, int(n_local)) // batch_size)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor([steps], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        steps = int(t.item())
+    return steps
+
+
+def step_bounds(n_local: int, steps: int):
+    """Split this rank's n_local items into exactly ``steps`` contiguous batches whose sizes differ by at most one
+    (empty batches only when n_local < steps: the rank then runs a zero-gradient step and still joins the exchange)."""
+    return [shard_range(n_local, i, steps) for i in range(steps)] if steps > 0 else []
+
+
 class GradAllReduce:
     """Sum a flat gradient buffer across ranks.
 

@@ -28,21 +28,30 @@ class _MarginScoreFn(torch.autograd.Function):
 
 
 class _MarginLossFn(torch.autograd.Function):
-    """(ent, rel) -> scalar hinge loss over 1 positive + K negative tails; fused hinge backward."""
+    """(ent, rel) -> scalar hinge loss over 1 positive + K negative tails.
+
+    When a gradient will be asked for, forward AND backward run as ONE launch (snag_score_margin_fwd_bwd: every table row is
+    gathered once) and ``backward`` only scales the stored gradients by the upstream scalar -- on the device, no host
+    synchronisation.  Without grad (evaluation) only the forward kernel runs."""
 
     @staticmethod
-    def forward(ctx, ent, rel, h, r, t, neg_t, margin):
-        pos, neg, part = ops.score_margin_fwd(ent, rel, h, r, t, neg_t, margin, want_loss=True)
-        ctx.save_for_backward(ent, rel, h, r, t, neg_t)
-        ctx.margin = margin
+    def forward(ctx, ent, rel, h, r, t, neg_t, margin, want_grad):
+        ctx.fused = bool(want_grad and neg_t is not None)
+        if ctx.fused:
+            loss, pos, neg, _, d_ent, d_rel = ops.score_margin_fwd_bwd(ent, rel, h, r, t, neg_t, margin)
+            ctx.save_for_backward(d_ent, d_rel)
+        else:
+            pos, neg, part = ops.score_margin_fwd(ent, rel, h, r, t, neg_t, margin, want_loss=True)
+            loss = ops.reduce_sum(part)
         ctx.mark_non_differentiable(pos, neg)
-        return ops.reduce_sum(part), pos, neg
+        return loss, pos, neg
 
     @staticmethod
     def backward(ctx, dloss, _dp, _dn):
-        ent, rel, h, r, t, neg_t = ctx.saved_tensors
-        d_ent, d_rel = ops.score_margin_bwd(ent, rel, h, r, t, neg_t, ctx.margin, float(dloss))
-        return d_ent, d_rel, None, None, None, None, None
+        if not ctx.fused:
+            raise RuntimeError("margin_loss: no input required a gradient in the forward")
+        d_ent, d_rel = ctx.saved_tensors
+        return d_ent * dloss, d_rel * dloss, None, None, None, None, None, None
 
 
 class _SelfAdvLossFn(torch.autograd.Function):
@@ -63,8 +72,8 @@ class _SelfAdvLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss, _dp, _dn):
         ent, rel, h, r, t, neg_t, dpos, dneg = ctx.saved_tensors
-        d_ent, d_rel = ops.score_margin_bwd(ent, rel, h, r, t, neg_t, 0.0, float(dloss), dpos=dpos, dneg=dneg)
-        return d_ent, d_rel, None, None, None, None, None, None
+        d_ent, d_rel = ops.score_margin_bwd(ent, rel, h, r, t, neg_t, 0.0, 1.0, dpos=dpos, dneg=dneg)
+        return d_ent * dloss, d_rel * dloss, None, None, None, None, None, None      # upstream scalar applied on the device: no host sync
 
 
 def self_adversarial_loss(ent, rel, h, r, t, neg_t, margin, adv_temp=1.0):
@@ -83,10 +92,10 @@ def score(ent, rel, h, r, t, neg_t=None):
 def margin_loss(ent, rel, h, r, t, neg_t, margin):
     """sum_b sum_k relu(margin + s(h,r,t) - s(h,r,neg_t[b,k])) -> (loss, pos, neg).
 
-    The MKGC shape of BASELINE.json (NEG_NUM negative tails per positive).  ``float(dloss)`` in the
-    backward synchronises only when the upstream gradient is not the usual python 1.0.
+    The MKGC shape of BASELINE.json (NEG_NUM negative tails per positive).
     """
-    return _MarginLossFn.apply(ent, rel, h, r, t, neg_t, float(margin))
+    want_grad = torch.is_grad_enabled() and (ent.requires_grad or rel.requires_grad)
+    return _MarginLossFn.apply(ent, rel, h, r, t, neg_t, float(margin), want_grad)
 
 
 def kge_relation_loss(ent, rel, p_h, p_r, p_t, n_h, n_r, n_t, margin):

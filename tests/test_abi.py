@@ -169,3 +169,26 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "gemm" in r.stdout
+
+
+def test_gemm_k_zero_does_not_crash_the_host():
+    """K = 0 passes gemm_check (C = epilogue(0)); the dispatcher's split arithmetic once divided by zero on the HOST (SIGFPE, the
+    process died).  Without a GPU the call must come back with the launch error, not kill the interpreter."""
+    from snag_amd import _lib
+    lib = _lib.load()
+    assert lib.snag_gemm_workspace_floats(70, 132, 0) == 0
+    buf = (ctypes.c_float * 64)()
+    for with_ws in (False, True):
+        d = _lib.GemmDesc()
+        d.M, d.N, d.K, d.a_kcontig, d.b_kcontig = 4, 4, 0, 1, 1
+        d.C, d.ldc, d.alpha = ctypes.addressof(buf), 4, 1.0
+        if with_ws:
+            d.workspace, d.workspace_floats = ctypes.addressof(buf), 64
+        rc = lib.snag_gemm_f32(ctypes.byref(d), None)
+        assert rc in (0, -3), (rc, _lib.last_error())
+
+
+def test_ticket_words_constant_matches_header():
+    from snag_amd import _lib
+    text = open(os.path.join(ROOT, "include", "snag_hip.h")).read()
+    assert int(re.search(r"#define\s+SNAG_SCORE_TICKET_WORDS\s+(\d+)", text).group(1)) == _lib.SCORE_TICKET_WORDS

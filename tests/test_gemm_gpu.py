@@ -66,6 +66,24 @@ def test_gemm_epilogue_chain():
     assert float(stacked[:, 0, :].abs().max()) == 0 and float(stacked[:, 2, :].abs().max()) == 0
 
 
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (False, False)])
+@pytest.mark.parametrize("splitk", [True, False])
+def test_gemm_k_zero_applies_epilogue_only(a_kc, b_kc, splitk):
+    """K = 0 is legal (gemm_check admits it): C = epilogue(0), so bias / add1 / accumulate still apply.  The dispatcher's split
+    arithmetic once divided by zero here (host SIGFPE)."""
+    from snag_amd import ops
+    g = torch.Generator().manual_seed(2)
+    M, N = 70, 132
+    a = torch.empty((M, 0) if a_kc else (0, M), device=DEV)
+    b = torch.empty((N, 0) if b_kc else (0, N), device=DEV)
+    bias, r1 = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    c = ops.gemm(a, b, a_kcontig=a_kc, b_kcontig=b_kc, bias=bias, add1=r1, splitk=splitk)
+    assert torch.equal(c, bias[None, :] + r1)
+    out = torch.full((M, N), 2.0, device=DEV)
+    ops.gemm(a, b, a_kcontig=a_kc, b_kcontig=b_kc, out=out, accumulate=True, splitk=splitk)
+    assert torch.equal(out, torch.full((M, N), 2.0, device=DEV))
+
+
 def test_gemm_splitk_long_k_deterministic():
     """dW = dY^T X shape: tiny output, long reduction; split-K slabs are summed in a fixed order."""
     from snag_amd import ops

@@ -42,7 +42,7 @@ def oracle_params(eng):
     return p, proj, fp
 
 
-@pytest.mark.parametrize("loss_kind", ["hinge", "self_adversarial"])
+@pytest.mark.parametrize("loss_kind", ["hinge", "hinge_fused", "self_adversarial"])
 @pytest.mark.parametrize("num_proj,joint_way,ffn,noise,idt,shape", [
     (2, "Mformer_hd_graph", 0, False, torch.int32, (700, 23, 128, 96, 32, 200, 72)),
     (1, "Mformer_hd_mean", 0, False, torch.int64, (700, 23, 128, 96, 32, 200, 72)),
@@ -60,6 +60,8 @@ def oracle_params(eng):
 def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape, loss_kind):
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
     N, R, D, B, K, F0, F1 = shape[:7]
+    # "hinge_fused": the training form -- the scorer's forward and backward as ONE launch inside forward(with_backward=True)
+    fused, loss_kind = loss_kind == "hinge_fused", loss_kind.replace("_fused", "")
     cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[F0, F1], num_proj=num_proj, joint_way=joint_way, num_layers=shape[7] if len(shape) > 7 else 1,
                      use_intermediate=ffn, intermediate_size=96, margin=6.0, neg_num=K, dropout=0.0, add_noise=int(noise), seed=7,
                      loss=loss_kind, adv_temp=0.7)
@@ -75,7 +77,8 @@ def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape, loss_k
     r = torch.randint(0, R, (B,), generator=g).to(idt)
     t = torch.randint(0, N, (B,), generator=g).to(idt)
     neg = torch.randint(0, N, (B, K), generator=g).to(idt)
-    loss, pos, ng = eng.forward(h.to(DEV), r.to(DEV), t.to(DEV), neg.to(DEV), want_scores=True)
+    loss, pos, ng = eng.forward(h.to(DEV), r.to(DEV), t.to(DEV), neg.to(DEV), want_scores=True, with_backward=fused)
+    assert (eng._score_bwd_scale is not None) == fused
     eng.backward()
     torch.cuda.synchronize()
 

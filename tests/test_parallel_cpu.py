@@ -84,3 +84,35 @@ def test_two_rank_allreduce_matches_single_process(tmp_path, bucket_bytes, overl
     # the margin loss is a SUM over triples (MSNEA.py:122): summed shard gradients == full-batch gradient, no division
     assert torch.allclose(got["flat"], ref, atol=1e-5, rtol=1e-5)
     assert abs(got["loss"] - ref_loss) < 1e-3 * max(1.0, abs(ref_loss))
+
+
+def _steps_worker(rank, world, port, n_total, bs, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from snag_amd.parallel import common_step_count, step_bounds
+        lo, hi = shard_range(n_total, rank, world)
+        steps = common_step_count(hi - lo, bs)
+        bounds = step_bounds(hi - lo, steps)
+        # every rank enters exactly `steps` all-reduces: a mismatch would hang here, not fail
+        for a, b in bounds:
+            t = torch.tensor([float(b - a)])
+            dist.all_reduce(t)
+        torch.save({"steps": steps, "bounds": bounds, "n": hi - lo}, f"{out}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total,bs", [(2049, 1024), (2048, 1024), (5, 4), (3, 1024)])
+def test_ranks_agree_on_steps_per_epoch(tmp_path, n_total, bs):
+    """Shards differ by one item (1025 vs 1024 at bs=1024): a per-rank range(0, n_local, bs) would issue 2 vs 1 bucketed
+    all-reduces and hang.  Every rank must run the same number of steps and still cover each of its items exactly once."""
+    out = str(tmp_path / "steps")
+    mp.spawn(_steps_worker, args=(2, _free_port(), n_total, bs, out), nprocs=2, join=True)
+    got = [torch.load(f"{out}.{r}") for r in range(2)]
+    assert got[0]["steps"] == got[1]["steps"] == -(-max(g["n"] for g in got) // bs)
+    for g in got:
+        b = g["bounds"]
+        assert len(b) == g["steps"] and b[0][0] == 0 and b[-1][1] == g["n"]
+        assert all(x[1] == y[0] for x, y in zip(b, b[1:]))
+        assert max(hi - lo for lo, hi in b) <= bs

@@ -53,6 +53,107 @@ def test_score_fwd_bwd_vs_oracle(D, K, B, idt):
     assert_close(dr, r_.grad, atol=2e-4, rtol=1e-4, what="d_rel")
 
 
+_FUSED_SHAPES = [
+    (128, 32, 1024, torch.int32), (128, 32, 257, torch.int64), (128, 1, 64, torch.int64), (128, 0, 33, torch.int32),
+    (128, 3, 50, torch.int32), (128, 33, 40, torch.int64), (128, 70, 19, torch.int32), (128, 128, 16, torch.int32),
+    (64, 32, 100, torch.int32), (256, 128, 48, torch.int32), (300, 7, 30, torch.int64), (100, 5, 21, torch.int32),
+    (512, 9, 12, torch.int32), (4, 2, 9, torch.int32), (128, 100, 37, torch.int32), (256, 130, 9, torch.int64),
+    (128, 129, 3, torch.int32), (64, 97, 2, torch.int32), (128, 16, 5, torch.int32), (128, 17, 6, torch.int32),
+]
+
+
+@pytest.mark.parametrize("D,K,B,idt", _FUSED_SHAPES)
+@pytest.mark.parametrize("margin", [1.2, 12.0])
+def test_score_fused_entry_vs_oracle(D, K, B, idt, margin):
+    """snag_score_margin_fwd_bwd (one launch: scores + per-triple losses + summed loss + scattered gradients) on the same cases as
+    the two-launch form.  margin 1.2 leaves part of the hinges inactive (their negatives must get NO gradient); margin 12 is the
+    README value, every hinge active (scores of unit rows are <= 9)."""
+    from snag_amd import ops
+    ent, rel, h, r, t, neg = _mk(501, 13, D, B, K, seed=D * 1000 + K, idt=idt)
+    ent[7].zero_()                                   # normalize eps branch
+    h[0] = 7
+    if K:
+        neg[1, 0] = 7
+    e_ = ent.clone().requires_grad_(True)
+    r_ = rel.clone().requires_grad_(True)
+    loss, pos, ng = O.score_margin(e_, r_, h, r, t, neg, margin)
+    (0.5 * loss).backward()
+    d = [x.to(DEV) for x in (ent, rel, h, r, t, neg)]
+    lg, pos_g, neg_g, lp, de, dr = ops.score_margin_fwd_bwd(*d, margin, grad_scale=0.5)
+    assert_close(pos_g, pos, atol=1e-5, what="pos")
+    assert_close(neg_g, ng, atol=1e-5, what="neg")
+    assert_close(lp, torch.relu(margin + pos.unsqueeze(1) - ng).sum(1), atol=1e-4, rtol=2e-6, what="loss_part")
+    assert_close(lg, loss, atol=1e-4, rtol=1e-5, what="loss")
+    # the in-kernel sum is the fixed-order sum of loss_part: identical to the separate reduction kernel over the same values
+    assert_close(lg, lp.double().sum(), atol=0, rtol=2e-6, what="loss == sum(loss_part)")
+    assert_close(de, e_.grad, atol=2e-4, rtol=1e-4, what="d_ent")
+    assert_close(dr, r_.grad, atol=2e-4, rtol=1e-4, what="d_rel")
+    # same scores as the forward-only kernel (different lane layout and summation order: equal to rounding)
+    pos_f, neg_f, _ = ops.score_margin_fwd(*d, margin)
+    assert_close(pos_g, pos_f, atol=3e-6)
+    assert_close(neg_g, neg_f, atol=3e-6)
+
+
+def test_score_fused_accumulates_into_strided_rows_and_resets_its_ticket():
+    """The engine's use: the table is the slot hidden[:, g, :] of a stacked [N, M, D] tensor (row stride M*D) and the gradient is
+    scatter-added into the same slot of d_hidden; two launches in a row accumulate; the ticket word is zero again after each."""
+    from snag_amd import ops
+    from snag_amd._lib import call, ptr, stream
+    N, R, D, B, K, M = 400, 9, 128, 300, 32, 3
+    ent, rel, h, r, t, neg = _mk(N, R, D, B, K, seed=77, idt=torch.int32)
+    hidden = torch.randn(N, M, D, generator=torch.Generator().manual_seed(1))
+    hidden[:, 2, :] = ent
+    hd = hidden.to(DEV)
+    table = hd[:, 2, :]
+    d_hidden = torch.zeros(N, M, D, device=DEV)
+    d_rel = torch.zeros(R, D, device=DEV)
+    e_ = ent.clone().requires_grad_(True)
+    r_ = rel.clone().requires_grad_(True)
+    loss, _, _ = O.score_margin(e_, r_, h, r, t, neg, 12.0)
+    loss.backward()
+    d = [x.to(DEV) for x in (rel, h, r, t, neg)]
+    tick = ops._ticket(torch.device(DEV, torch.cuda.current_device()))
+    for rep in (1, 2):
+        lg, *_ = ops.score_margin_fwd_bwd(table, *d, 12.0, d_ent=d_hidden[:, 2, :], d_rel=d_rel)
+        assert int(tick.abs().sum().item()) == 0
+        assert_close(lg, loss, atol=1e-3, rtol=1e-5)
+        assert_close(d_hidden[:, 2, :], rep * e_.grad, atol=4e-4, rtol=1e-4, what=f"d_hidden slot after {rep} launches")
+        assert float(d_hidden[:, :2, :].abs().max()) == 0.0
+        assert_close(d_rel, rep * r_.grad, atol=4e-4, rtol=1e-4)
+
+
+def test_score_fused_loss_reduction_under_load():
+    """The last-finishing block sums loss_part written by every other block (write-through stores + ticket).  Large uneven grids,
+    many repeats, an L2-warming read of loss_part in between: the sum must equal the fixed-order sum of what is in memory."""
+    from snag_amd import ops
+    ent, rel, h, r, t, neg = [x.to(DEV) for x in _mk(15000, 558, 128, 20000 + 3, 32, seed=3, idt=torch.int32)]
+    for rep in range(12):
+        B = (20003, 1024, 4099, 257)[rep % 4]
+        lg, _, _, lp, _, _ = ops.score_margin_fwd_bwd(ent, rel, h[:B], r[:B], t[:B], neg[:B], 12.0)
+        ref = ops.reduce_sum(lp)
+        assert abs(float(lg) - float(ref)) <= 2e-6 * abs(float(ref)), (rep, B, float(lg), float(ref))
+        assert abs(float(lg) - float(lp.double().sum())) <= 1e-5 * abs(float(ref))
+
+
+def test_margin_loss_autograd_runs_the_fused_launch():
+    """snag_amd.score.margin_loss under autograd: one launch in forward, device-side scaling by the upstream gradient."""
+    from snag_amd.score import margin_loss
+    ent, rel, h, r, t, neg = _mk(300, 7, 128, 90, 32, seed=21)
+    e_ = ent.clone().requires_grad_(True)
+    r_ = rel.clone().requires_grad_(True)
+    loss, _, _ = O.score_margin(e_, r_, h, r, t, neg, 12.0)
+    (loss * 0.25).backward()
+    eg, rg = ent.to(DEV).requires_grad_(True), rel.to(DEV).requires_grad_(True)
+    lg, pg, ngg = margin_loss(eg, rg, h.to(DEV), r.to(DEV), t.to(DEV), neg.to(DEV), 12.0)
+    (lg * 0.25).backward()
+    assert_close(lg, loss, atol=1e-3, rtol=1e-5)
+    assert_close(eg.grad, e_.grad, atol=1e-4, rtol=1e-4)
+    assert_close(rg.grad, r_.grad, atol=1e-4, rtol=1e-4)
+    with torch.no_grad():                                     # evaluation: forward kernel only
+        l2, _, _ = margin_loss(eg, rg, h.to(DEV), r.to(DEV), t.to(DEV), neg.to(DEV), 12.0)
+    assert_close(l2, loss, atol=1e-3, rtol=1e-5)
+
+
 def test_score_bwd_explicit_mode():
     from snag_amd import ops
     ent, rel, h, r, t, neg = _mk(300, 7, 128, 77, 5, seed=5)
