@@ -12,7 +12,7 @@ Vectors (SURVEY.md par. 8c):
   g1_fusion_*.npz    MformerFusion.forward eval / train(dropout masks) + autograd grads
   g2_noise.npz       SNAG.add_noise_to_embeddings / get_mean_std / update_noise
   g3_score.npz       MSNEA.kge relation loss (term 1) + grads
-  g4_eval_*.npz      pairwise_distances / csls_sim / Runner._test metrics + l2r ranks
+  g4_eval_*.npz      pairwise_distances / csls_sim / Runner._test metrics + per-row (l2r) and per-column (r2l) ranks, MR / MRR unrounded
   g5_il.npz          SNAG.Iter_new_links mutual nearest neighbours
   g6_proj.npz        nn.Linear projections + ProjectionHead fwd/grads
   g7_encoder.npz     MultiModalEncoder.forward (projections + entity noise blend + fusion), GAT stubbed to identity
@@ -285,7 +285,23 @@ def run_ref_test(final_emb, left, right, csls, csls_k):
     model = types.SimpleNamespace(joint_emb_generat=lambda: (final_emb, None), state_dict=lambda: {})
     fake = types.SimpleNamespace(args=args, model=model, logger=lg, epoch=0, loss_item=0.0,
                                  early_stop_count=3, early_stop_init=3, loss_log=Loss_log())
-    ref_main.Runner._test(fake, left, right, last_epoch=True, save_name="g")
+    # Runner._test prints r2l only as rounded aggregates.  Its per-column ranks come from its OWN torch.sort calls (main.py:400-401
+    # rows, :422-423 columns): record every sort it makes, nothing is recomputed here.
+    sorted_indices = []
+    real_sort = torch.sort
+
+    def recording_sort(*a, **k):
+        out = real_sort(*a, **k)
+        sorted_indices.append(out[1].clone())
+        return out
+
+    torch.sort = recording_sort
+    try:
+        ref_main.Runner._test(fake, left, right, last_epoch=True, save_name="g")
+    finally:
+        torch.sort = real_sort
+    n_l, n_r = len(left), len(right)
+    assert len(sorted_indices) == n_l + n_r, (len(sorted_indices), n_l, n_r)
     ranks = []
     with open(os.path.join(tmp, "SNAG", "g_pred", "GOLD_pred.txt")) as f:
         rd = csv.reader(f)
@@ -293,6 +309,16 @@ def run_ref_test(final_emb, left, right, csls, csls_k):
         for row in rd:
             ranks.append(int(row[1]))
     out = {"rank_l2r": np.array(ranks)}
+    sort_l2r = np.array([int((ind == i).nonzero(as_tuple=False).squeeze().item()) for i, ind in enumerate(sorted_indices[:n_l])])
+    assert np.array_equal(sort_l2r, out["rank_l2r"])                 # the recorded sorts ARE the ones behind the csv ranks
+    out["rank_r2l"] = np.array([int((ind == i).nonzero(as_tuple=False).squeeze().item()) for i, ind in enumerate(sorted_indices[n_l:])])
+    for name, rk in (("l2r", out["rank_l2r"]), ("r2l", out["rank_r2l"])):
+        mr = mrr = 0.0                                               # the reference's own accumulation order (main.py:403-404,425-426,430-433)
+        for v in rk.tolist():
+            mr += (v + 1)
+            mrr += 1.0 / (v + 1)
+        out[f"mr_{name}"] = mr / len(rk)
+        out[f"mrr_{name}"] = mrr / len(rk)
     for line in h.lines:
         m = re.search(r"\| (l2r|r2l): acc of top \[1, 10, 50\] = \[([^\]]*)\], mr = ([\d.]+), mrr = ([\d.]+)", line)
         if m:
@@ -300,6 +326,8 @@ def run_ref_test(final_emb, left, right, csls, csls_k):
             out[f"mr_{m.group(1)}_3dp"] = float(m.group(3))
             out[f"mrr_{m.group(1)}_3dp"] = float(m.group(4))
     assert "hits_l2r" in out and "hits_r2l" in out, h.lines
+    for name in ("l2r", "r2l"):                                      # the unrounded values reproduce the log line's 3 decimals
+        assert f"{out[f'mr_{name}']:.3f}" == f"{out[f'mr_{name}_3dp']:.3f}" and f"{out[f'mrr_{name}']:.3f}" == f"{out[f'mrr_{name}_3dp']:.3f}"
     return out
 
 
@@ -714,12 +742,5 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()["gen_" + name]()
         sys.exit(0)
-    gen_g1()
-    gen_g2()
-    gen_g3()
-    gen_g4_g5()
-    gen_g6()
-    gen_g7()
-    gen_g8()
-    gen_g9()
-    gen_g10()
+    for fn in (gen_g1, gen_g2, gen_g3, gen_g4_g5, gen_g6, gen_g7, gen_g8, gen_g9, gen_g10, gen_g11, gen_g12, gen_g13, gen_g14):
+        fn()                        # "regenerate all" means ALL: G11-G14 included

@@ -22,11 +22,13 @@ def test_eval_golden(name):
     if k:
         assert_close(E.csls_sim(1 - T(z["dist"], DEV), k), z["csls"], atol=1e-5, what="csls")
     res = E.rank_metrics(xl, xr, csls_k=k)
-    assert np.array_equal(res["rank_l2r"].cpu().numpy(), z["rank_l2r"])                     # ranking indices: bit-exact
+    assert np.array_equal(res["rank_l2r"].cpu().numpy(), z["rank_l2r"])                     # ranking indices: bit-exact, both directions
+    assert np.array_equal(res["rank_r2l"].cpu().numpy(), z["rank_r2l"])                     # (r2l = the reference's own per-column sorts, main.py:422-424)
     for d in ("l2r", "r2l"):
-        assert np.allclose(res[f"hits_{d}"], z[f"hits_{d}"], atol=1e-7), (res[f"hits_{d}"], z[f"hits_{d}"])
-        assert round(res[f"mr_{d}"], 3) == pytest.approx(float(z[f"mr_{d}_3dp"]), abs=1.1e-3)
-        assert round(res[f"mrr_{d}"], 3) == pytest.approx(float(z[f"mrr_{d}_3dp"]), abs=1.1e-3)
+        assert np.array_equal(np.asarray(res[f"hits_{d}"]), z[f"hits_{d}"]), (res[f"hits_{d}"], z[f"hits_{d}"])
+        assert res[f"mr_{d}"] == pytest.approx(float(z[f"mr_{d}"]), rel=1e-12)             # unrounded
+        assert res[f"mrr_{d}"] == pytest.approx(float(z[f"mrr_{d}"]), rel=1e-12)
+        assert f"{res[f'mr_{d}']:.3f}" == f"{float(z[f'mr_{d}_3dp']):.3f}" and f"{res[f'mrr_{d}']:.3f}" == f"{float(z[f'mrr_{d}_3dp']):.3f}"
 
 
 def test_mutual_nearest_golden():
@@ -74,15 +76,31 @@ def test_config4_shape_properties():
     rows = torch.arange(0, n, n // 64)[:64]
     ref = (dd[rows] < dd[rows, rows].view(-1, 1)).sum(1)
     assert torch.equal(rl[rows].long(), ref)
-    # the whole problem against the oracle (its own CPU GEMM, a different fp32 summation order): Hits@k agree to the 4th decimal's
-    # last unit, and the few ranks that differ are exact near-ties off by one place
+    # the whole problem against the oracle (its own CPU GEMM: a different fp32 summation order over the 1,200 products).
+    # north_star: "bit-exact for ranking indices" -- so every rank that differs must be PROVEN a near-tie: with
+    # delta = max |Dist'_gpu - Dist'_oracle| over the whole 10,500 x 10,500 matrix, candidate j can change sides of the true match i
+    # only if |Dist'[i,j] - Dist'[i,i]| <= 2 delta; a row's (column's) rank may differ by at most the number of such candidates.
     torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
     ro = O.rank_metrics(xl.cpu(), xr.cpu(), csls_k=3)
-    for a, b in zip(ro["hits_l2r"] + ro["hits_r2l"], res["hits_l2r"] + res["hits_r2l"]):
-        assert abs(a - b) <= 2e-4
-    for ref_rank, got in ((ro["rank_l2r"], rl), (ro["rank_r2l"], rr)):
+    d_o = ro["dist"]                                              # the oracle's CSLS-adjusted distances
+    delta = float((dd - d_o).abs().max())
+    eps = 5e-6                                                    # stated tie window; must cover 2 delta
+    assert 2 * delta <= eps, f"GPU and oracle CSLS distances differ by {delta:.3e}: the tie window {eps:g} does not cover it"
+    diag = d_o.diagonal()
+    unexplained = 0
+    for ref_rank, got, dim in ((ro["rank_l2r"], rl, 1), (ro["rank_r2l"], rr, 0)):
         diff = (ref_rank.long() - got.long()).abs()
-        assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 2e-3
+        for i in diff.nonzero().flatten().tolist():
+            line = d_o[i] if dim == 1 else d_o[:, i]
+            near_ties = int(((line - diag[i]).abs() <= eps).sum()) - 1          # candidates within the window, the match itself excluded
+            if int(diff[i]) > near_ties:
+                unexplained += 1
+    assert unexplained == 0, f"{unexplained} rank differences are not near-ties (window {eps:g}, delta {delta:.2e})"
+    # Hits@k can then differ only through those proven near-tie rows
+    for name, ref_rank, got in (("l2r", ro["rank_l2r"], rl), ("r2l", ro["rank_r2l"], rr)):
+        n_diff = int((ref_rank.long() != got.long()).sum())
+        for a, b in zip(ro[f"hits_{name}"], res[f"hits_{name}"]):
+            assert abs(a - b) <= n_diff / n + 0.5e-4, (name, a, b, n_diff)
     # MR/MRR consistent with ranks
     assert res["mr_l2r"] == pytest.approx(float((rl.double() + 1).mean()), rel=1e-12)
     assert res["mrr_r2l"] == pytest.approx(float((1 / (rr.double() + 1)).mean()), rel=1e-12)

@@ -96,11 +96,13 @@ def test_eval(name):
     if k:
         assert_close(O.csls_sim(1 - T(z["dist"]), k), z["csls"], atol=1e-6)
     res = O.rank_metrics(final[left], final[right], csls_k=k)
-    assert np.array_equal(res["rank_l2r"].numpy(), z["rank_l2r"])           # ranking indices: bit-exact
+    assert np.array_equal(res["rank_l2r"].numpy(), z["rank_l2r"])           # ranking indices: bit-exact, both directions
+    assert np.array_equal(res["rank_r2l"].numpy(), z["rank_r2l"])           # (r2l = the reference's own per-column sorts, main.py:422-424)
     for d in ("l2r", "r2l"):
-        assert np.allclose(res[f"hits_{d}"], z[f"hits_{d}"], atol=1e-7), (res[f"hits_{d}"], z[f"hits_{d}"])
-        assert round(res[f"mr_{d}"], 3) == pytest.approx(float(z[f"mr_{d}_3dp"]), abs=1.1e-3)
-        assert round(res[f"mrr_{d}"], 3) == pytest.approx(float(z[f"mrr_{d}_3dp"]), abs=1.1e-3)
+        assert np.array_equal(np.asarray(res[f"hits_{d}"]), z[f"hits_{d}"]), (res[f"hits_{d}"], z[f"hits_{d}"])
+        assert res[f"mr_{d}"] == pytest.approx(float(z[f"mr_{d}"]), rel=1e-13)         # unrounded; only the fp64 summation order differs
+        assert res[f"mrr_{d}"] == pytest.approx(float(z[f"mrr_{d}"]), rel=1e-13)
+        assert f"{res[f'mr_{d}']:.3f}" == f"{float(z[f'mr_{d}_3dp']):.3f}" and f"{res[f'mrr_{d}']:.3f}" == f"{float(z[f'mrr_{d}_3dp']):.3f}"
     assert 0.05 < res["hits_l2r"][0] < 0.999        # the fixture is informative
 
 
