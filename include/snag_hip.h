@@ -381,6 +381,17 @@ SNAG_API int snag_sample_negatives(uint64_t seed, const uint64_t* tick, const in
                                    int64_t batch, int n_neg, int n_ent, int n_rel, int mode, const int64_t* known_sorted,
                                    int64_t n_known, int32_t* neg_h, int32_t* neg_t, void* stream);
 
+/* The same sampler with the two in-tree properties snag_sample_negatives gives up: candidates are drawn from the KG's OWN entity
+ * list ent_list [n_list] (int32 ids; NULL = 0..n_ent-1; model/MSNEA_tools.py:64-65) and the n_neg negatives of one positive are
+ * DISTINCT (random.sample draws without replacement, :69,:72).  Rounds = the reference's 10 tries: in round a slot k of positive
+ * b draws ent_list[(philox4x32_10(seed, (b*n_neg + k)*16 + a).x * n_list) >> 32]; it is accepted unless it forms a known triple,
+ * was already accepted for this positive, or a lower slot accepted the same value in this round; round 9 accepts whatever it
+ * drew (:76-78).  n_neg <= 1024 and <= n_list.  oracle/sampler.py restates rule and stream bit for bit; the python `random` stream of
+ * the reference cannot be matched, so parity with the reference itself stays unpinned. */
+SNAG_API int snag_sample_negatives_distinct(uint64_t seed, const uint64_t* tick, const int32_t* h, const int32_t* r, const int32_t* t,
+                                   int64_t batch, int n_neg, int n_ent, int n_rel, int mode, const int64_t* known_sorted,
+                                   int64_t n_known, const int32_t* ent_list, int n_list, int32_t* neg_h, int32_t* neg_t, void* stream);
+
 /* The filtered setting of MKGC tail prediction (PARITY UNPINNED like the eval itself): mask [batch, n_ent] (uint8, overwritten) gets 1
  * at every x for which (h_b, r_b, x) is a known triple, except x == t_b; known_sorted as for snag_sample_negatives.  The mask is
  * what snag_rank_full_table takes as `filter`.  int32 indices. */

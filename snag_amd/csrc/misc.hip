@@ -4,26 +4,9 @@
 #include <algorithm>
 
 #include "fusion_kernels.hip.h"
+#include "philox.hip.h"
 
 namespace snag {
-
-// ---- Philox4x32-10 (counter-based: element i of stream `seed` is a pure function of (seed, i)) ----
-struct Philox4 {
-    uint32_t x, y, z, w;
-};
-
-__device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t ctr) {
-    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x5a17c0deu, c3 = 0x9e3779b9u;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return {c0, c1, c2, c3};
-}
 
 __device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0,1)
 
@@ -212,17 +195,6 @@ __global__ __launch_bounds__(256) void entity_token_fwd_kernel(const float* __re
 // Bernoulli(0.5) coin per POSITIVE (as the reference does, :68) between corrupting the head and the tail.  A candidate
 // that forms a known triple is rejected and redrawn, up to 10 tries, the last try is kept whatever it is (:66-76).
 // known: sorted int64 keys (h * n_rel + r) * n_ent + t, or NULL for no filtering.
-__device__ __forceinline__ bool key_known(const int64_t* __restrict__ keys, int64_t n, int64_t key) {
-    int64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        const int64_t v = keys[mid];
-        if (v == key) return true;
-        if (v < key) lo = mid + 1; else hi = mid;
-    }
-    return false;
-}
-
 __global__ __launch_bounds__(256) void sample_negatives_kernel(uint64_t seed, const uint64_t* __restrict__ tick, const int32_t* __restrict__ h,
                                                                const int32_t* __restrict__ r, const int32_t* __restrict__ t, int64_t B, int K,
                                                                int n_ent, int n_rel, int mode, const int64_t* __restrict__ known, int64_t n_known,

@@ -327,8 +327,25 @@ def build_filter_mask(h, r, t, n_ent, n_rel, known_sorted):
     return mask
 
 
-def sample_negatives(h, r, t, n_neg, n_ent, n_rel, seed, known_sorted=None, head_or_tail=False, tick=None, out=None):
-    """neg_t [B, n_neg] (and neg_h when head_or_tail) drawn on the device.  C ABI: snag_sample_negatives."""
+def sample_negatives(h, r, t, n_neg, n_ent, n_rel, seed, known_sorted=None, head_or_tail=False, tick=None, out=None, distinct=False,
+                     ent_list=None):
+    """neg_t [B, n_neg] (and neg_h when head_or_tail) drawn on the device.  C ABI: snag_sample_negatives, or -- ``distinct=True``:
+    the negatives of a positive are distinct and come from ``ent_list`` (the in-tree sampler's random.sample over the KG's own entity
+    list, model/MSNEA_tools.py:59-90) -- snag_sample_negatives_distinct."""
+    if distinct or ent_list is not None:
+        for x, nm in ((h, "h"), (r, "r"), (t, "t")):
+            _chk(x, nm, dtype=torch.int32, ndim=1)
+        B = h.shape[0]
+        neg_t = out if out is not None else torch.empty(B, n_neg, device=h.device, dtype=torch.int32)
+        neg_h = torch.empty(B, n_neg, device=h.device, dtype=torch.int32) if head_or_tail else None
+        if known_sorted is not None:
+            _chk(known_sorted, "known_sorted", dtype=torch.int64, ndim=1)
+        if ent_list is not None:
+            _chk(ent_list, "ent_list", dtype=torch.int32, ndim=1)
+        call("snag_sample_negatives_distinct", int(seed), ptr(tick), ptr(h), ptr(r), ptr(t), B, int(n_neg), int(n_ent), int(n_rel), int(head_or_tail),
+             ptr(known_sorted), known_sorted.numel() if known_sorted is not None else 0, ptr(ent_list),
+             ent_list.numel() if ent_list is not None else 0, ptr(neg_h), ptr(neg_t), stream())
+        return (neg_h, neg_t) if head_or_tail else neg_t
     for x, nm in ((h, "h"), (r, "r"), (t, "t")):
         _chk(x, nm, dtype=torch.int32, ndim=1)
     B = h.shape[0]

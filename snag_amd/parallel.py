@@ -35,7 +35,7 @@ def common_step_count(n_local: int, batch_size: int, group=None) -> int:
     if batch_size < 1:
         raise ValueError(f"batch_size={batch_size}")
     steps = -(-max(0, int(n_local)) // batch_size)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():       # also with one rank: the same collective on the backend that ships
         dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
         t = torch.tensor([steps], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
