@@ -141,7 +141,7 @@ SNAG_API int snag_reduce_sum(const float* x, int64_t n, float* out, void* stream
  * act: 0 none, 1 relu, 2 gelu(erf), 3 multiply by gelu'(aux[m,n]), 4 multiply by (aux[m,n] > 0)
  * (3/4 are the backward of 2/1 with aux = the saved pre-activation / activation).
  * pre_act (optional, ld = ldc) receives alpha*acc + bias.
- * keep_mask (optional) is a dense uint8 [M,N] inverted-dropout mask, keep_scale = 1/(1-p).
+ * keep_mask (optional) is a uint8 [M,N] inverted-dropout mask with row stride ldmask bytes (0 = dense, N), keep_scale = 1/(1-p).
  * workspace (optional, workspace_floats long) enables deterministic split-K for small-output /
  * long-K shapes; snag_gemm_workspace_floats(M,N,K) is the size that never limits the split.
  */
@@ -161,6 +161,7 @@ typedef struct snag_gemm_desc {
     int32_t accumulate;
     float* workspace; int64_t workspace_floats;
     const float* aux; int64_t ldaux;
+    int64_t ldmask;
 } snag_gemm_desc;
 
 SNAG_API int snag_gemm_f32(const snag_gemm_desc* desc, void* stream);
@@ -210,6 +211,11 @@ typedef struct snag_fusion_desc {
     float *joint, *joint_fz, *hidden, *weight_norm;
     float* save; int64_t save_floats;
     float* work; int64_t work_floats;
+    /* 0: every token of every layer (the reference's computation).  g + 1: the caller consumes hidden[:, g, :] ONLY (README
+     * joint_way Mformer_hd_graph): the LAST layer computes keys / values for all M tokens but the query, attention row, output
+     * projection, LayerNorm (and FFN) for token g alone -- same values, (2M+2)/(4M) of the GEMM work -- and `hidden` is [N, D].
+     * joint / joint_fz / weight_norm must be NULL in that mode. */
+    int32_t readout_slot_p1;
 } snag_fusion_desc;
 
 SNAG_API int64_t snag_fusion_save_floats(int N, int M, int D, int H, int I, int L, int use_intermediate);
@@ -228,6 +234,8 @@ typedef struct snag_fusion_bwd_desc {
     const snag_fusion_layer_grad* grads;  /* host array [L] */
     float* d_weight_raw;                  /* [6] */
     int32_t accumulate;
+    int32_t zero_d_hidden;                /* 1: d_hidden is overwritten with zeros once it has been read (a scatter-add target is
+                                             clean for the next step without a fill launch); d_hidden is [N, D] in read-out mode */
 } snag_fusion_bwd_desc;
 
 SNAG_API int snag_fusion_bwd(const snag_fusion_bwd_desc* desc, void* stream);
@@ -270,7 +278,8 @@ SNAG_API int snag_gaussian_fill(uint64_t seed, int64_t N, int F, const float* me
 /* Pieces of the projection / read-out backward that are not GEMMs.
  * snag_colsum: out[c] (=|+=) sum_r x[r*ld + c]  (nn.Linear bias gradient), fixed-order partial sums;
  *   work: 256*C floats.
- * snag_token_mean_bwd: d_hidden[n,m,:] = d_out[n,:] / M  (backward of snag_token_mean).
+ * snag_token_mean_bwd: d_hidden[n,m,:] = d_out[n,:] / M  (backward of snag_token_mean); zero_src = 1 clears d_out once read
+ *   (d_out is the scorer's scatter-add target: clean for the next step without a fill launch).
  * snag_entity_token_bwd: gradient of the entity table through the noise blend of
  *   model/SNAG_tools.py:127-128: d_table[n,:] (=|+=) (noise_mask[n] ? 1 - a : 1) * d_tok[n*ld + :];
  *   snag_entity_token_fwd is the forward blend written straight into a token slot (row stride out_ld). */
@@ -280,7 +289,7 @@ SNAG_API int snag_colsum(const float* x, int64_t R, int C, int64_t ld, float* ou
  * table in both layouts so that the first projection X W^T (a5, model/SNAG_tools.py:134-150) and its weight gradient both stream
  * row-contiguous operands; the transposed copy is refreshed once per noise epoch (model/SNAG.py:86-98). */
 SNAG_API int snag_transpose_f32(const float* src, int64_t ld_src, int64_t rows, int64_t cols, float* dst, int64_t ld_dst, void* stream);
-SNAG_API int snag_token_mean_bwd(const float* d_out, int64_t N, int M, int D, float* d_hidden, void* stream);
+SNAG_API int snag_token_mean_bwd(float* d_out, int64_t N, int M, int D, float* d_hidden, int zero_src, void* stream);
 SNAG_API int snag_entity_token_fwd(const float* table, int64_t N, int D, const float* noise, const uint8_t* noise_mask,
                                    float half_mask_ratio, float* out, int64_t out_ld, void* stream);
 SNAG_API int snag_entity_token_bwd(const float* d_tok, int64_t ld, int64_t N, int D, const uint8_t* noise_mask,

@@ -29,7 +29,7 @@ class GemmDesc(_c.Structure):
                 ("keep_mask", _P), ("keep_scale", _F),
                 ("add1", _P), ("ld1", _L), ("add2", _P), ("ld2", _L),
                 ("accumulate", _c.c_int32), ("workspace", _P), ("workspace_floats", _L),
-                ("aux", _P), ("ldaux", _L)]
+                ("aux", _P), ("ldaux", _L), ("ldmask", _L)]
 
 
 class FusionLayer(_c.Structure):
@@ -49,13 +49,14 @@ class FusionDesc(_c.Structure):
                 ("L", _c.c_int32), ("use_intermediate", _c.c_int32), ("drop_p", _F),
                 ("layers", _c.POINTER(FusionLayer)), ("weight_raw", _P), ("x0", _P),
                 ("joint", _P), ("joint_fz", _P), ("hidden", _P), ("weight_norm", _P),
-                ("save", _P), ("save_floats", _L), ("work", _P), ("work_floats", _L)]
+                ("save", _P), ("save_floats", _L), ("work", _P), ("work_floats", _L), ("readout_slot_p1", _c.c_int32)]
 
 
 class FusionBwdDesc(_c.Structure):
     """struct snag_fusion_bwd_desc."""
     _fields_ = [("f", FusionDesc), ("d_joint", _P), ("d_joint_fz", _P), ("d_hidden", _P), ("d_weight_norm", _P),
-                ("d_x0", _P), ("grads", _c.POINTER(FusionLayerGrad)), ("d_weight_raw", _P), ("accumulate", _c.c_int32)]
+                ("d_x0", _P), ("grads", _c.POINTER(FusionLayerGrad)), ("d_weight_raw", _P), ("accumulate", _c.c_int32),
+                ("zero_d_hidden", _c.c_int32)]
 
 
 # name -> argtypes; every entry returns int (0 = enqueued) except the two listed in _SPECIAL
@@ -76,7 +77,7 @@ SIGNATURES = {
     "snag_dropout_keep_mask": [_U64, _P, _L, _F, _P, _P],
     "snag_gaussian_fill": [_U64, _L, _I, _P, _P, _P, _P],
     "snag_colsum": [_P, _L, _I, _L, _P, _I, _P, _P],
-    "snag_token_mean_bwd": [_P, _L, _I, _I, _P, _P],
+    "snag_token_mean_bwd": [_P, _L, _I, _I, _P, _I, _P],
     "snag_entity_token_bwd": [_P, _L, _L, _I, _P, _F, _P, _I, _P],
     "snag_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _P, _F, _P],
     "snag_adamw_step_groups": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P, _P, _I, _L, _P, _F, _P, _I, _P],

@@ -100,6 +100,9 @@ static int check_fusion(const snag_fusion_desc* f) {
     SNAG_REQUIRE(f->D % f->H == 0, SNAG_ERR_ARG, "fusion: hidden_size %d not divisible by num_attention_heads %d", f->D, f->H);
     SNAG_REQUIRE(!f->use_intermediate || f->I >= 1, SNAG_ERR_ARG, "fusion: use_intermediate needs intermediate_size >= 1");
     SNAG_REQUIRE(f->drop_p >= 0.f && f->drop_p < 1.f, SNAG_ERR_ARG, "fusion: drop_p=%g outside [0,1)", f->drop_p);
+    SNAG_REQUIRE(f->readout_slot_p1 >= 0 && f->readout_slot_p1 <= f->M, SNAG_ERR_ARG, "fusion: readout_slot_p1=%d outside [0, M=%d]", f->readout_slot_p1, f->M);
+    SNAG_REQUIRE(f->readout_slot_p1 == 0 || !(f->joint || f->joint_fz || f->weight_norm), SNAG_ERR_UNSUPPORTED,
+                 "fusion: the read-out-only last layer computes attention for one token only; joint / joint_fz / weight_norm need all of it");
     if (f->N == 0) return SNAG_OK;
     SNAG_REQUIRE(f->layers && f->weight_raw && f->x0 && f->save, SNAG_ERR_ARG, "fusion: null layers / weight_raw / x0 / save");
     const int64_t need = snag_fusion_save_floats(f->N, f->M, f->D, f->H, f->I, f->L, f->use_intermediate);
@@ -109,6 +112,47 @@ static int check_fusion(const snag_fusion_desc* f) {
         SNAG_REQUIRE(P.wqkv && P.bqkv && P.wo && P.bo && P.ln1_g && P.ln1_b, SNAG_ERR_ARG, "fusion: layer %d has a null attention parameter", l);
         SNAG_REQUIRE(!f->use_intermediate || (P.w1 && P.b1 && P.w2 && P.b2 && P.ln2_g && P.ln2_b), SNAG_ERR_ARG,
                      "fusion: layer %d has a null FFN parameter", l);
+    }
+    return SNAG_OK;
+}
+
+// Last layer when only token g = readout_slot_p1 - 1 is consumed (joint_way Mformer_hd_graph): keys / values for all M tokens, but
+// the query, the attention row, the output projection, the LayerNorm (and the FFN) for token g only.  hidden is then [N, D].
+// Compact [N, D] activations reuse the first N*D floats of the [N*M, D] save regions.
+static int fusion_fwd_readout(const snag_fusion_desc* f, const snag_fusion_layer& P, const LayerSave& S, const float* xin, hipStream_t st) {
+    const int N = f->N, M = f->M, D = f->D, H = f->H, I = f->I, g = f->readout_slot_p1 - 1;
+    const bool ffn = f->use_intermediate != 0;
+    const int64_t NM = (int64_t)N * M, MD = (int64_t)M * D;
+    const float kscale = 1.0f / (1.0f - f->drop_p);
+    const dim3 egrid((unsigned)ceil_div(N, 4));
+    int rc;
+    // K,V of every token: columns D..3D of the stacked projection
+    snag_gemm_desc gd = gemm_desc((int)NM, 2 * D, D, xin, D, true, P.wqkv + (int64_t)D * D, D, true, S.qkv + D, 3 * D);
+    gd.bias = P.bqkv + D;
+    if ((rc = gemm_dispatch(&gd, st))) return rc;
+    // Q of token g only: rows n*M + g of x (stride M*D) -> the q part of the same rows of qkv
+    gd = gemm_desc(N, D, D, xin + (int64_t)g * D, MD, true, P.wqkv, D, true, S.qkv + (int64_t)g * 3 * D, 3 * MD);
+    gd.bias = P.bqkv;
+    if ((rc = gemm_dispatch(&gd, st))) return rc;
+    SNAG_MNU(attn_ro_fwd_kernel, M, D, egrid, st, (const float*)S.qkv, N, D, H, g, 1.0f / sqrtf((float)(D / H)), P.keep_probs, kscale, S.probs, S.ctx);
+    if ((rc = check_launch("fusion attention (read-out)"))) return rc;
+    gd = gemm_desc(N, D, D, S.ctx, D, true, P.wo, D, true, S.t1, D);
+    gd.bias = P.bo; gd.keep_scale = kscale; gd.add1 = xin + (int64_t)g * D; gd.ld1 = MD;
+    if (P.keep_attn_out) { gd.keep_mask = P.keep_attn_out + (int64_t)g * D; gd.ldmask = MD; }
+    if ((rc = gemm_dispatch(&gd, st))) return rc;
+    float* y1 = ffn ? S.y1 : f->hidden;
+    SNAG_NU(ln_fwd_kernel, D, egrid, st, (const float*)S.t1, (int64_t)N, D, P.ln1_g, P.ln1_b, 1e-12f, y1, S.st1);
+    if ((rc = check_launch("fusion LayerNorm (read-out)"))) return rc;
+    if (ffn) {
+        gd = gemm_desc(N, I, D, y1, D, true, P.w1, D, true, S.g, I);
+        gd.bias = P.b1; gd.act = 2; gd.pre_act = S.u;
+        if ((rc = gemm_dispatch(&gd, st))) return rc;
+        gd = gemm_desc(N, D, I, S.g, I, true, P.w2, I, true, S.t2, D);
+        gd.bias = P.b2; gd.keep_scale = kscale; gd.add1 = y1; gd.ld1 = D;
+        if (P.keep_ffn_out) { gd.keep_mask = P.keep_ffn_out + (int64_t)g * D; gd.ldmask = MD; }
+        if ((rc = gemm_dispatch(&gd, st))) return rc;
+        SNAG_NU(ln_fwd_kernel, D, egrid, st, (const float*)S.t2, (int64_t)N, D, P.ln2_g, P.ln2_b, 1e-12f, f->hidden, S.st2);
+        if ((rc = check_launch("fusion LayerNorm 2 (read-out)"))) return rc;
     }
     return SNAG_OK;
 }
@@ -128,6 +172,7 @@ int fusion_fwd(const snag_fusion_desc* f, hipStream_t st) {
         const snag_fusion_layer& P = f->layers[l];
         const LayerSave S = lay.at(f->save, l);
         const bool last = (l == f->L - 1);
+        if (last && f->readout_slot_p1 > 0) return fusion_fwd_readout(f, P, S, xin, st);
         // Q,K,V = X W^T + b                                   (:183-186)
         snag_gemm_desc g = gemm_desc((int)NM, 3 * D, D, xin, D, true, P.wqkv, D, true, S.qkv, 3 * D);
         g.bias = P.bqkv;
@@ -215,9 +260,10 @@ static int colsum(const float* x, int64_t R, int C, float* part, float* out, int
 // LayerNorm backward + the bias gradient of the dense layer in front of it (colsum of what flows into that dense)
 static int ln_bwd(const float* dy, const float* t, const float* stats, const float* g, int64_t R, int D, const uint8_t* keep,
                   float kscale, float* dt, float* dtm, float* part, float* dgamma, float* dbeta, float* dbias, int accumulate,
-                  hipStream_t st) {
+                  hipStream_t st, int64_t keep_ld = 0, bool zero_dy = false) {
     const int blocks = (int)std::min<int64_t>(kRedBlocks, (R + 3) / 4);
-    SNAG_NU(ln_bwd_kernel, D, dim3(blocks), st, dy, t, stats, g, R, D, keep, kscale, dt, dtm, part);
+    SNAG_NU(ln_bwd_kernel, D, dim3(blocks), st, dy, t, stats, g, R, D, keep, keep_ld > 0 ? keep_ld : (int64_t)D, kscale, dt, dtm, part,
+            zero_dy ? const_cast<float*>(dy) : (float*)nullptr);
     // part is [blocks][3][D]: one launch reduces the three rows as 3*D "columns" of stride 3*D into a staging row
     float* stage = part + (int64_t)blocks * 3 * D;
     hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(3 * D, 64)), dim3(1024), 0, st, (const float*)part, blocks, (int64_t)3 * D, 3 * D, stage, 0);
@@ -257,22 +303,87 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
         if (hipMemsetAsync(b->d_weight_raw, 0, 6 * sizeof(float), st) != hipSuccess) return fail(SNAG_ERR_LAUNCH, "fusion_bwd: memset failed");
     }
 
-    // 2. layers, last to first.  dout = gradient w.r.t. the layer's output.
+    // 2. layers, last to first.  dout = gradient w.r.t. the layer's output ([N, D] in read-out mode).
     const float* dout = b->d_hidden;
     if (dout == nullptr) {
         if (hipMemsetAsync(W.dC, 0, NM * D * sizeof(float), st) != hipSuccess) return fail(SNAG_ERR_LAUNCH, "fusion_bwd: memset failed");
         dout = W.dC;
     }
+    // the full layers read d_hidden through ln_bwd as well: its first call clears it when asked to
+    bool zero_up_full = b->zero_d_hidden != 0 && b->d_hidden != nullptr && f->readout_slot_p1 == 0;
     for (int l = L - 1; l >= 0; --l) {
         const snag_fusion_layer& P = f->layers[l];
         const snag_fusion_layer_grad& G = b->grads[l];
         const LayerSave S = lay.at(f->save, l);
         const float* xin = (l == 0) ? f->x0 : (ffn ? lay.at(f->save, l - 1).y2 : lay.at(f->save, l - 1).y1);
         snag_gemm_desc g;
+        if (l == L - 1 && f->readout_slot_p1 > 0) {
+            // ---- last layer, token ro only (see fusion_fwd_readout); dout is [N, D] --------------------------------------------
+            const int ro = f->readout_slot_p1 - 1;
+            const int64_t MD = (int64_t)M * D;
+            bool zero_up = b->zero_d_hidden != 0 && b->d_hidden != nullptr;      // the first consumer of d_hidden clears it
+            if (ffn) {
+                float* dtm = P.keep_ffn_out ? W.dB : nullptr;
+                if ((rc = ln_bwd(dout, S.t2, S.st2, P.ln2_g, N, D, P.keep_ffn_out ? P.keep_ffn_out + (int64_t)ro * D : nullptr, kscale, W.dA, dtm, W.part,
+                                 G.ln2_g, G.ln2_b, G.b2, acc, st, MD, zero_up))) return rc;
+                zero_up = false;
+                const float* dz = dtm ? dtm : W.dA;
+                g = gemm_desc(D, I, N, dz, D, false, S.g, I, false, G.w2, I);
+                g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
+                if ((rc = gemm_dispatch(&g, st))) return rc;
+                g = gemm_desc(N, I, D, dz, D, true, P.w2, I, false, W.dU, I);
+                g.act = 3; g.aux = S.u; g.ldaux = I;
+                if ((rc = gemm_dispatch(&g, st))) return rc;
+                g = gemm_desc(I, D, N, W.dU, I, false, S.y1, D, false, G.w1, D);
+                g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
+                if ((rc = gemm_dispatch(&g, st))) return rc;
+                if ((rc = colsum(W.dU, N, I, W.part, G.b1, acc, st))) return rc;
+                g = gemm_desc(N, D, I, W.dU, I, true, P.w1, D, false, W.dC, D);
+                g.add1 = W.dA; g.ld1 = D;
+                if ((rc = gemm_dispatch(&g, st))) return rc;
+                dout = W.dC;
+            }
+            float* dtm = P.keep_attn_out ? W.dB : nullptr;
+            if ((rc = ln_bwd(dout, S.t1, S.st1, P.ln1_g, N, D, P.keep_attn_out ? P.keep_attn_out + (int64_t)ro * D : nullptr, kscale, W.dA, dtm, W.part,
+                             G.ln1_g, G.ln1_b, G.bo, acc, st, MD, zero_up))) return rc;
+            const float* dz = dtm ? dtm : W.dA;
+            // dWo = dz^T ctx_g
+            g = gemm_desc(D, D, N, dz, D, false, S.ctx, D, false, G.wo, D);
+            g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
+            if ((rc = gemm_dispatch(&g, st))) return rc;
+            // dctx_g = dz Wo -> dC
+            g = gemm_desc(N, D, D, dz, D, true, P.wo, D, false, W.dC, D);
+            if ((rc = gemm_dispatch(&g, st))) return rc;
+            // attention backward: dq_g [N, D] (behind dkv in the dqkv region), dkv [N*M, 2D]
+            float* dkv = W.dqkv;
+            float* dq_g = W.dqkv + NM * 2 * D;
+            const int ablocks = (int)std::min<int64_t>(kRedBlocks, (N + 3) / 4);
+            SNAG_MNU(attn_ro_bwd_kernel, M, D, dim3(ablocks), st, (const float*)S.qkv, (const float*)W.dC, N, D, H, ro, 1.0f / sqrtf((float)(D / H)),
+                     P.keep_probs, kscale, dq_g, dkv, W.part);
+            hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(3 * D, 64)), dim3(1024), 0, st, (const float*)W.part, ablocks, (int64_t)3 * D, 3 * D, G.bqkv, acc);
+            if ((rc = check_launch("fusion attention backward (read-out)"))) return rc;
+            // dWq = dq_g^T x_g (rows 0..D of wqkv) ; dWkv = dkv^T x (rows D..3D)
+            g = gemm_desc(D, D, N, dq_g, D, false, xin + (int64_t)ro * D, MD, false, G.wqkv, D);
+            g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
+            if ((rc = gemm_dispatch(&g, st))) return rc;
+            g = gemm_desc(2 * D, D, (int)NM, dkv, 2 * D, false, xin, D, false, G.wqkv + (int64_t)D * D, D);
+            g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
+            if ((rc = gemm_dispatch(&g, st))) return rc;
+            // d(layer input) = dkv Wkv for every token, + dq_g Wq + dT1 into the rows of token ro
+            float* dxin = (l == 0) ? b->d_x0 : W.dC;
+            g = gemm_desc((int)NM, D, 2 * D, dkv, 2 * D, true, P.wqkv + (int64_t)D * D, D, false, dxin, D);
+            if ((rc = gemm_dispatch(&g, st))) return rc;
+            g = gemm_desc(N, D, D, dq_g, D, true, P.wqkv, D, false, dxin + (int64_t)ro * D, MD);
+            g.add1 = W.dA; g.ld1 = D; g.accumulate = 1;
+            if ((rc = gemm_dispatch(&g, st))) return rc;
+            dout = W.dC;
+            continue;
+        }
         if (ffn) {
             // LN2 backward -> dA = dT2 (residual route to y1), dB = dT2 * keep (route into output.dense)
             float* dtm = P.keep_ffn_out ? W.dB : nullptr;
-            if ((rc = ln_bwd(dout, S.t2, S.st2, P.ln2_g, NM, D, P.keep_ffn_out, kscale, W.dA, dtm, W.part, G.ln2_g, G.ln2_b, G.b2, acc, st))) return rc;
+            if ((rc = ln_bwd(dout, S.t2, S.st2, P.ln2_g, NM, D, P.keep_ffn_out, kscale, W.dA, dtm, W.part, G.ln2_g, G.ln2_b, G.b2, acc, st, 0, zero_up_full))) return rc;
+            zero_up_full = false;
             const float* dz = dtm ? dtm : W.dA;
             // dW2 = dz^T G ; db2 = colsum(dz)
             g = gemm_desc(D, I, (int)NM, dz, D, false, S.g, I, false, G.w2, I);
@@ -295,7 +406,8 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
         }
         // LN1 backward -> dA = dT1 (residual route to the layer input), dB = dT1 * keep
         float* dtm = P.keep_attn_out ? W.dB : nullptr;
-        if ((rc = ln_bwd(dout, S.t1, S.st1, P.ln1_g, NM, D, P.keep_attn_out, kscale, W.dA, dtm, W.part, G.ln1_g, G.ln1_b, G.bo, acc, st))) return rc;
+        if ((rc = ln_bwd(dout, S.t1, S.st1, P.ln1_g, NM, D, P.keep_attn_out, kscale, W.dA, dtm, W.part, G.ln1_g, G.ln1_b, G.bo, acc, st, 0, zero_up_full))) return rc;
+        zero_up_full = false;
         const float* dz = dtm ? dtm : W.dA;
         // dWo = dz^T ctx ; dbo
         g = gemm_desc(D, D, (int)NM, dz, D, false, S.ctx, D, false, G.wo, D);
@@ -352,6 +464,8 @@ extern "C" SNAG_API int snag_fusion_bwd(const snag_fusion_bwd_desc* b, void* str
     if (rc) return rc;
     if (b->f.N == 0) return SNAG_OK;
     SNAG_REQUIRE(b->d_x0 && b->grads && b->f.work, SNAG_ERR_ARG, "fusion_bwd: null d_x0 / grads / work");
+    SNAG_REQUIRE(b->f.readout_slot_p1 == 0 || !(b->d_joint || b->d_joint_fz || b->d_weight_norm), SNAG_ERR_UNSUPPORTED,
+                 "fusion_bwd: read-out-only mode takes d_hidden [N, D] alone");
     const int64_t need = snag_fusion_work_floats(b->f.N, b->f.M, b->f.D, b->f.H, b->f.I, b->f.L, b->f.use_intermediate);
     SNAG_REQUIRE(b->f.work_floats >= need, SNAG_ERR_ARG, "fusion_bwd: work buffer holds %ld floats, need %ld", (long)b->f.work_floats, (long)need);
     for (int l = 0; l < b->f.L; ++l) {

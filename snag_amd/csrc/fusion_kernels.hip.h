@@ -249,6 +249,196 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Read-out-only form of the two kernels above, for the LAST layer when only one token's output is consumed
+// (joint_way Mformer_hd_graph reads hidden[:, g, :] alone): the query row, the attention row, the context and everything behind
+// them exist for token g only; keys and values still come from all M tokens.  Same arithmetic per element as the full kernels
+// (same summation order inside a row), so hidden[:, g, :] is the full computation's, and the gradients differ from it only by the
+// summation order of the weight-gradient GEMMs (N rows instead of N*M rows of which 2/3 are exact zeros).
+//   qkv [N*M, 3D] as above (the q part is valid in the rows of token g only), ctx_g [N, D] compact,
+//   probs / keep [N,H,M,M] in the full layout (row g of each head read / written).
+template <int M, int NU>
+__device__ __forceinline__ void head_scores_row(const Cols<NU>& q, const Cols<NU> (&k)[M], int lo, int hi, int lane, float inv_sqrt_d,
+                                                float (&p)[M]) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int c = lane + 64 * u;
+            part += (c >= lo && c < hi) ? q.v[u] * k[j].v[u] : 0.f;
+        }
+        p[j] = sum64(part) * inv_sqrt_d;
+    }
+    float mx = p[0];
+#pragma unroll
+    for (int j = 1; j < M; ++j) mx = fmaxf(mx, p[j]);
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        p[j] = expf(p[j] - mx);
+        den += p[j];
+    }
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int j = 0; j < M; ++j) p[j] *= inv;
+}
+
+template <int M, int NU>
+__global__ __launch_bounds__(256) void attn_ro_fwd_kernel(const float* __restrict__ qkv, int N, int D, int H, int g, float inv_sqrt_d,
+                                                          const uint8_t* __restrict__ keep, float kscale,
+                                                          float* __restrict__ probs, float* __restrict__ ctx_g) {
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave_id_uniform();
+    if (n >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int d = D / H;
+    const int HMM = H * M * M;
+    int kb0 = 1, kb1 = 1;
+    if (keep != nullptr) {
+        kb0 = lane < HMM ? (int)keep[n * HMM + lane] : 1;
+        kb1 = lane + 64 < HMM ? (int)keep[n * HMM + 64 + lane] : 1;
+    }
+    Cols<NU> k[M], v[M], o;
+    const Cols<NU> q = ld_cols<NU>(qkv + (n * M + g) * (int64_t)(3 * D), D, lane);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const float* row = qkv + (n * M + i) * (int64_t)(3 * D);
+        k[i] = ld_cols<NU>(row + D, D, lane);
+        v[i] = ld_cols<NU>(row + 2 * D, D, lane);
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) o.v[u] = 0.f;
+    for (int h = 0; h < H; ++h) {
+        const int lo = h * d, hi = lo + d;
+        float p[M];
+        head_scores_row<M, NU>(q, k, lo, hi, lane, inv_sqrt_d, p);
+        if (keep != nullptr) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const int e = h * M * M + g * M + j;
+                const int kf = e < 64 ? __builtin_amdgcn_readlane(kb0, e) : __builtin_amdgcn_readlane(kb1, e - 64);
+                p[j] = kf ? p[j] * kscale : 0.f;
+            }
+        }
+        {
+            float mine = 0.f;
+#pragma unroll
+            for (int j = 0; j < M; ++j) mine = (lane == j) ? p[j] : mine;
+            if (lane < M) probs[(n * H + h) * (int64_t)(M * M) + g * M + lane] = mine;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int c = lane + 64 * u;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < M; ++j) acc += p[j] * v[j].v[u];
+            o.v[u] += (c >= lo && c < hi) ? acc : 0.f;
+        }
+    }
+    st_cols<NU>(ctx_g + n * (int64_t)D, o, D, lane);
+}
+
+//   dctx_g [N, D] -> dq_g [N, D] (compact) and dkv [N*M, 2D] (k then v); bias_part [block][3][D] = column sums of dq_g, dk, dv.
+template <int M, int NU>
+__global__ __launch_bounds__(256) void attn_ro_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx_g, int N, int D,
+                                                          int H, int g, float inv_sqrt_d, const uint8_t* __restrict__ keep, float kscale,
+                                                          float* __restrict__ dq_g, float* __restrict__ dkv, float* __restrict__ bias_part) {
+    __shared__ float red[4][3][64 * NU];
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id_uniform();
+    const int d = D / H;
+    Cols<NU> sq, sk, sv;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) sq.v[u] = sk.v[u] = sv.v[u] = 0.f;
+    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
+        const int HMM = H * M * M;
+        int kb0 = 1, kb1 = 1;
+        if (keep != nullptr) {
+            kb0 = lane < HMM ? (int)keep[n * HMM + lane] : 1;
+            kb1 = lane + 64 < HMM ? (int)keep[n * HMM + 64 + lane] : 1;
+        }
+        Cols<NU> k[M], v[M], dk[M], dv[M], dq;
+        const Cols<NU> q = ld_cols<NU>(qkv + (n * M + g) * (int64_t)(3 * D), D, lane);
+        const Cols<NU> go = ld_cols<NU>(dctx_g + n * (int64_t)D, D, lane);
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            const float* row = qkv + (n * M + i) * (int64_t)(3 * D);
+            k[i] = ld_cols<NU>(row + D, D, lane);
+            v[i] = ld_cols<NU>(row + 2 * D, D, lane);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) dk[i].v[u] = dv[i].v[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) dq.v[u] = 0.f;
+        for (int h = 0; h < H; ++h) {
+            const int lo = h * d, hi = lo + d;
+            float p[M], dp[M], ds[M];
+            head_scores_row<M, NU>(q, k, lo, hi, lane, inv_sqrt_d, p);
+            float rowdot = 0.f;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                float part = 0.f;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int c = lane + 64 * u;
+                    part += (c >= lo && c < hi) ? go.v[u] * v[j].v[u] : 0.f;
+                }
+                const float gg = sum64(part);
+                const int e = h * M * M + g * M + j;
+                const int kf = e < 64 ? __builtin_amdgcn_readlane(kb0, e) : __builtin_amdgcn_readlane(kb1, e - 64);
+                const float km = (keep == nullptr) ? 1.f : (kf ? kscale : 0.f);
+                const float pt = p[j] * km;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int c = lane + 64 * u;
+                    dv[j].v[u] += (c >= lo && c < hi) ? pt * go.v[u] : 0.f;
+                }
+                dp[j] = gg * km;
+                rowdot += dp[j] * p[j];
+            }
+#pragma unroll
+            for (int j = 0; j < M; ++j) ds[j] = p[j] * (dp[j] - rowdot) * inv_sqrt_d;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int c = lane + 64 * u;
+                const bool in = (c >= lo && c < hi);
+                float aq = 0.f;
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    aq += ds[j] * k[j].v[u];
+                    dk[j].v[u] += in ? ds[j] * q.v[u] : 0.f;
+                }
+                dq.v[u] += in ? aq : 0.f;
+            }
+        }
+        st_cols<NU>(dq_g + n * (int64_t)D, dq, D, lane);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) sq.v[u] += dq.v[u];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            float* row = dkv + (n * M + i) * (int64_t)(2 * D);
+            st_cols<NU>(row, dk[i], D, lane);
+            st_cols<NU>(row + D, dv[i], D, lane);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                sk.v[u] += dk[i].v[u];
+                sv.v[u] += dv[i].v[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        red[wave][0][lane + 64 * u] = sq.v[u];
+        red[wave][1][lane + 64 * u] = sk.v[u];
+        red[wave][2][lane + 64 * u] = sv.v[u];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * 64 * NU; i += 256) {
+        const int which = i / (64 * NU), c = i % (64 * NU);
+        if (c < D) bias_part[(int64_t)blockIdx.x * 3 * D + which * D + c] = ((red[0][which][c] + red[1][which][c]) + red[2][which][c]) + red[3][which][c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LayerNorm over the last dim, eps inside the sqrt, biased variance (nn.LayerNorm(eps=1e-12)).
 // reference: model/SNAG_tools.py:215,221 and :259,265.   stats[row] = (mean, rstd)
 template <int NU>
@@ -288,8 +478,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ t
 template <int NU>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ t,
                                                      const float* __restrict__ stats, const float* __restrict__ g, int64_t R,
-                                                     int D, const uint8_t* __restrict__ keep, float kscale,
-                                                     float* __restrict__ dt, float* __restrict__ dtm, float* __restrict__ part) {
+                                                     int D, const uint8_t* __restrict__ keep, int64_t keep_ld, float kscale,
+                                                     float* __restrict__ dt, float* __restrict__ dtm, float* __restrict__ part,
+                                                     float* __restrict__ dy_zero) {
+    // keep: row r of the mask starts at keep + r * keep_ld (keep_ld = D dense; M*D when the rows are one token slot of a
+    // stacked [N,M,D] mask).  dy_zero (= dy, or NULL): every row of dy is overwritten with zeros once it has been read, so a
+    // scatter-add target is clean for the next step without a separate fill launch.
     __shared__ float red[4][3][64 * NU];
     const int lane = threadIdx.x & 63;
     const int wave = wave_id_uniform();
@@ -300,6 +494,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < R; row += (int64_t)gridDim.x * 4) {
         const Cols<NU> x = ld_cols<NU>(t + row * D, D, lane);
         const Cols<NU> gy = ld_cols<NU>(dy + row * D, D, lane);
+        if (dy_zero != nullptr) {
+            Cols<NU> z;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) z.v[u] = 0.f;
+            st_cols<NU>(dy_zero + row * D, z, D, lane);
+        }
         const float mean = stats[2 * row], rstd = stats[2 * row + 1];
         Cols<NU> xh, dxh;
         float s1 = 0.f, s2 = 0.f;
@@ -323,7 +523,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int c = lane + 64 * u;
-                const float z = (c < D && keep[row * D + c]) ? o.v[u] * kscale : 0.f;
+                const float z = (c < D && keep[row * keep_ld + c]) ? o.v[u] * kscale : 0.f;
                 if (c < D) dtm[row * D + c] = z;
                 az.v[u] += z;
             }

@@ -18,7 +18,8 @@ struct Epilogue {
     const float* aux;       // [M,N] ld = ldaux, for act 3/4 (backward through an activation)
     int64_t ldaux;
     float* pre;             // optional copy of alpha*acc + bias (before activation), same ld as C
-    const uint8_t* mask;    // optional keep mask [M, N] dense (ld = N)
+    const uint8_t* mask;    // optional keep mask [M, N], row stride ldm bytes
+    int64_t ldm;
     float mscale;
     const float* add1;
     int64_t ld1;
@@ -41,7 +42,7 @@ struct Epilogue {
         } else if (act == 4) {
             v = aux[(int64_t)m * ldaux + n] > 0.f ? v : 0.f;
         }
-        if (mask) v = mask[(int64_t)m * N + n] ? v * mscale : 0.f;
+        if (mask) v = mask[(int64_t)m * ldm + n] ? v * mscale : 0.f;
         if (add1) v += add1[(int64_t)m * ld1 + n];
         if (add2) v += add2[(int64_t)m * ld2 + n];
         return v;
@@ -82,7 +83,7 @@ struct Epilogue {
                 }
             }
             if (mask) {
-                const uchar4 k = *reinterpret_cast<const uchar4*>(mask + (int64_t)m * N + n);
+                const uchar4 k = *reinterpret_cast<const uchar4*>(mask + (int64_t)m * ldm + n);
                 x[0] = k.x ? x[0] * mscale : 0.f;
                 x[1] = k.y ? x[1] * mscale : 0.f;
                 x[2] = k.z ? x[2] * mscale : 0.f;
@@ -273,12 +274,12 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     p.xcd = xcd_mode();
     Epilogue e;
     e.C = d->C; e.ldc = d->ldc; e.bias = d->bias; e.alpha = d->alpha; e.act = d->act; e.pre = d->pre_act;
-    e.mask = d->keep_mask; e.mscale = d->keep_scale; e.add1 = d->add1; e.ld1 = d->ld1; e.add2 = d->add2; e.ld2 = d->ld2;
+    e.mask = d->keep_mask; e.ldm = d->ldmask > 0 ? d->ldmask : d->N; e.mscale = d->keep_scale; e.add1 = d->add1; e.ld1 = d->ld1; e.add2 = d->add2; e.ld2 = d->ld2;
     e.accumulate = d->accumulate; e.M = d->M; e.N = d->N; e.aux = d->aux; e.ldaux = d->ldaux;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     e.fast = (d->ldc % 4 == 0) && al16(d->C) && (!d->bias || al16(d->bias)) && (!d->pre_act || al16(d->pre_act)) &&
              (!d->add1 || (al16(d->add1) && d->ld1 % 4 == 0)) && (!d->add2 || (al16(d->add2) && d->ld2 % 4 == 0)) &&
-             (d->act < 3 || (al16(d->aux) && d->ldaux % 4 == 0)) && (!d->keep_mask || (d->N % 4 == 0 && ((uintptr_t)d->keep_mask & 3) == 0));
+             (d->act < 3 || (al16(d->aux) && d->ldaux % 4 == 0)) && (!d->keep_mask || (e.ldm % 4 == 0 && ((uintptr_t)d->keep_mask & 3) == 0));
 
     // Tile choice by padded work x a measured per-configuration factor (tools/tune_gemm.py, tools/tune_gemm_mmea.py, one device):
     //   128x128  when its tiles alone fill the chip; the best loop when both operands are K-contiguous;
@@ -361,6 +362,7 @@ int gemm_check(const snag_gemm_desc* d) {
     SNAG_REQUIRE(d->act < 3 || (d->aux && d->ldaux >= d->N), SNAG_ERR_ARG, "gemm: act=%d needs aux [M,N]", d->act);
     SNAG_REQUIRE(!d->add1 || d->ld1 >= d->N, SNAG_ERR_ARG, "gemm: ld1 too small");
     SNAG_REQUIRE(!d->add2 || d->ld2 >= d->N, SNAG_ERR_ARG, "gemm: ld2 too small");
+    SNAG_REQUIRE(d->ldmask == 0 || d->ldmask >= d->N, SNAG_ERR_ARG, "gemm: ldmask=%ld < N=%d", (long)d->ldmask, d->N);
     return SNAG_OK;
 }
 

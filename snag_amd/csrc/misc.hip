@@ -110,15 +110,17 @@ __global__ __launch_bounds__(256) void colstat_finish_kernel(const float* __rest
     out[c] = mode == 0 ? s / n : sqrtf(s / (n - 1.0f));
 }
 
-// d hidden[n, m, :] = d_out[n, :] / M
-__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float* __restrict__ d_out, int64_t N, int M, int D,
-                                                             float* __restrict__ d_hidden) {
-    const int64_t total = N * M * (int64_t)D;
+// d hidden[n, m, :] = d_out[n, :] / M ; zero_src: d_out is overwritten with zeros once read (it is the scorer's scatter-add target)
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(float* __restrict__ d_out, int64_t N, int M, int D,
+                                                             float* __restrict__ d_hidden, int zero_src) {
+    const int64_t total = N * (int64_t)D;
     const float inv = 1.0f / (float)M;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % D);
-        const int64_t n = i / ((int64_t)M * D);
-        d_hidden[i] = d_out[n * D + c] * inv;
+        const int64_t n = i / D;
+        const float v = d_out[i] * inv;
+        if (zero_src) d_out[i] = 0.f;
+        for (int m = 0; m < M; ++m) d_hidden[(n * M + m) * D + c] = v;
     }
 }
 
@@ -302,10 +304,10 @@ extern "C" SNAG_API int snag_transpose_f32(const float* src, int64_t ld_src, int
     return check_launch("snag_transpose_f32");
 }
 
-extern "C" SNAG_API int snag_token_mean_bwd(const float* d_out, int64_t N, int M, int D, float* d_hidden, void* stream) {
+extern "C" SNAG_API int snag_token_mean_bwd(float* d_out, int64_t N, int M, int D, float* d_hidden, int zero_src, void* stream) {
     SNAG_REQUIRE(d_out && d_hidden && N >= 0 && M >= 1 && D >= 1, SNAG_ERR_ARG, "token_mean_bwd: bad arguments");
     if (N == 0) return SNAG_OK;
-    hipLaunchKernelGGL(token_mean_bwd_kernel, dim3(grid_for(N * M * (int64_t)D)), dim3(256), 0, (hipStream_t)stream, d_out, N, M, D, d_hidden);
+    hipLaunchKernelGGL(token_mean_bwd_kernel, dim3(grid_for(N * (int64_t)D)), dim3(256), 0, (hipStream_t)stream, d_out, N, M, D, d_hidden, zero_src);
     return check_launch("snag_token_mean_bwd");
 }
 

@@ -47,6 +47,8 @@ class MKGCConfig:
     dropout: float = 0.1                # nn.Dropout(0.1) inside the Bert blocks (SNAG_tools.py:169,216)
     lr: float = 1e-4                    # LR
     weight_decay: float = 1e-4
+    readout_only: bool = True           # Mformer_hd_graph consumes hidden[:, g, :] alone: the last layer computes the query / attention row /
+                                        # output projection / LayerNorm (/ FFN) for the structural token only (same values, 2/3 of the GEMM work)
     deterministic: bool = False         # bit-reproducible steps: the scorer's gradient scatter uses fixed-point integer atomics (+~10 us)
     clip: float = 1.0                   # torch.nn.utils.clip_grad_norm_ of the reference's train loop (main.py:266-268, --clip default 1.0); 0 = off
     seed: int = 1234
@@ -169,13 +171,19 @@ class MKGCHotPath:
         # ---- activations / scratch ---------------------------------------------------------------
         dev = self.dev
         self.x0 = torch.empty(N, M, D, device=dev)
-        self.hidden = torch.empty(N, M, D, device=dev)
-        self.d_hidden = torch.empty(N, M, D, device=dev)
+        # read-out-only last layer: hidden IS the [N, D] read-out, and its gradient the compact scatter target of the scorer
+        self.ro = bool(cfg.readout_only) and cfg.joint_way == "Mformer_hd_graph"
+        self.hidden = torch.empty((N, D) if self.ro else (N, M, D), device=dev)
+        self.d_hidden = None if self.ro else torch.empty(N, M, D, device=dev)
         self.d_x0 = torch.empty(N, M, D, device=dev)
         self.mid = [torch.empty(N, D, device=dev) for _ in cfg.feat_dims] if cfg.num_proj == 2 else []
         self.d_mid = torch.empty(N, D, device=dev) if cfg.num_proj == 2 else None
         self.repr_mean = torch.empty(N, D, device=dev) if cfg.joint_way == "Mformer_hd_mean" else None
-        self.d_repr = torch.empty(N, D, device=dev) if cfg.joint_way == "Mformer_hd_mean" else None
+        # compact [N, D] gradient of the read-out (hd_mean, read-out-only hd_graph): zeroed once here; afterwards whoever READS it
+        # in the backward clears it behind itself (snag_fusion_bwd zero_d_hidden / snag_token_mean_bwd zero_src), so the fused
+        # scorer of the next step finds it clean without a fill launch
+        self.d_repr = torch.zeros(N, D, device=dev) if (self.ro or cfg.joint_way == "Mformer_hd_mean") else None
+        self._d_repr_clean = True
         lib = self.lib
         self.save = torch.empty(lib.snag_fusion_save_floats(N, M, D, cfg.num_heads, I, L, int(ffn)), device=dev)
         ws = lib.snag_fusion_work_floats(N, M, D, cfg.num_heads, I, L, int(ffn))
@@ -265,11 +273,13 @@ class MKGCHotPath:
         d.weight_raw = ptr(self.p["weight_raw"])
         d.x0 = ptr(self.x0)
         d.hidden = ptr(self.hidden)          # joint / joint_fz / weight_norm are not needed by the hd_* read-outs
+        d.readout_slot_p1 = self.g_slot + 1 if self.ro else 0
         d.save, d.save_floats = ptr(self.save), self.save.numel()
         d.work, d.work_floats = ptr(self.work), self.work.numel()
         self._fdesc = d
         b = _lib.FusionBwdDesc()
-        b.d_hidden = ptr(self.d_hidden)
+        b.d_hidden = ptr(self.d_repr) if self.ro else ptr(self.d_hidden)
+        b.zero_d_hidden = 1 if self.ro else 0
         b.d_x0 = ptr(self.d_x0)
         b.grads = ctypes.cast(self._grads, ctypes.POINTER(_lib.FusionLayerGrad))
         # the hd_* read-outs never touch joint_fz, so weight_raw has no gradient: its slice of the (zero-initialised) flat gradient
@@ -341,8 +351,10 @@ class MKGCHotPath:
         """Zero the scorer's scatter targets; returns (pointer, row stride) of the [N, dim] read-out gradient."""
         cfg = self.cfg
         self.g["rel"].zero_()
-        if cfg.joint_way == "Mformer_hd_mean":
-            self.d_repr.zero_()
+        if self.d_repr is not None:
+            if not self._d_repr_clean:       # only after a forward(with_backward=True) that no backward() followed
+                self.d_repr.zero_()
+            self._d_repr_clean = False
             return self.d_repr.data_ptr(), cfg.dim
         self.d_hidden.zero_()
         return self.d_hidden.data_ptr() + 4 * self.g_slot * cfg.dim, cfg.n_tokens * cfg.dim
@@ -376,6 +388,8 @@ class MKGCHotPath:
         if cfg.joint_way == "Mformer_hd_mean":
             call("snag_token_mean", ptr(self.hidden), N, M, D, ptr(self.repr_mean), st)
             self._repr, self._repr_ld = self.repr_mean.data_ptr(), D
+        elif self.ro:
+            self._repr, self._repr_ld = self.hidden.data_ptr(), D
         else:
             self._repr, self._repr_ld = self.hidden.data_ptr() + 4 * self.g_slot * D, MD
         B, K = neg_t.shape
@@ -454,8 +468,9 @@ class MKGCHotPath:
             call("snag_score_margin_bwd", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r), ptr(t), ptr(neg_t),
                  ib, B, K, float(cfg.margin), float(grad_scale), *up, d_repr, d_ld, ptr(self.g["rel"]), st)
         if cfg.joint_way == "Mformer_hd_mean":
-            call("snag_token_mean_bwd", ptr(self.d_repr), N, M, D, ptr(self.d_hidden), st)
+            call("snag_token_mean_bwd", ptr(self.d_repr), N, M, D, ptr(self.d_hidden), 1, st)
         call("snag_fusion_bwd", ctypes.byref(self._bdesc), st)
+        self._d_repr_clean = True                      # its reader cleared it behind itself
         dx0 = self.d_x0.data_ptr()
         wk = ptr(self.work)
         call("snag_entity_token_bwd", dx0 + 4 * self.g_slot * D, MD, N, D, ptr(self.ent_noise_mask) if noisy else None,
@@ -593,7 +608,7 @@ class MKGCHotPath:
         """[N, dim] fused entity read-out of the last forward (a strided view of ``hidden`` for Mformer_hd_graph)."""
         if self.cfg.joint_way == "Mformer_hd_mean":
             return self.repr_mean
-        return self.hidden[:, self.g_slot, :]
+        return self.hidden if self.ro else self.hidden[:, self.g_slot, :]
 
     def link_prediction(self, h, r, t, filter_mask=None, top_k=(1, 10), method="exact", known_sorted=None):
         """Eval-mode fusion of the whole table, then the rank of each true tail against all entities (Hits@1/10, MR, MRR);

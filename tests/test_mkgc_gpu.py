@@ -45,6 +45,7 @@ def oracle_params(eng):
 @pytest.mark.parametrize("loss_kind", ["hinge", "hinge_fused", "self_adversarial"])
 @pytest.mark.parametrize("num_proj,joint_way,ffn,noise,idt,shape", [
     (2, "Mformer_hd_graph", 0, False, torch.int32, (700, 23, 128, 96, 32, 200, 72)),
+    (2, "Mformer_hd_graph_full", 1, True, torch.int32, (700, 23, 128, 96, 32, 200, 72)),       # readout_only switched off
     (1, "Mformer_hd_mean", 0, False, torch.int64, (700, 23, 128, 96, 32, 200, 72)),
     (2, "Mformer_hd_graph", 1, True, torch.int32, (700, 23, 128, 96, 32, 200, 72)),
     (1, "Mformer_hd_mean", 0, True, torch.int32, (700, 23, 128, 96, 32, 200, 72)),
@@ -62,7 +63,8 @@ def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape, loss_k
     N, R, D, B, K, F0, F1 = shape[:7]
     # "hinge_fused": the training form -- the scorer's forward and backward as ONE launch inside forward(with_backward=True)
     fused, loss_kind = loss_kind == "hinge_fused", loss_kind.replace("_fused", "")
-    cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[F0, F1], num_proj=num_proj, joint_way=joint_way, num_layers=shape[7] if len(shape) > 7 else 1,
+    full_layer, joint_way = joint_way.endswith("_full"), joint_way.replace("_full", "")
+    cfg = MKGCConfig(readout_only=not full_layer, n_ent=N, n_rel=R, dim=D, feat_dims=[F0, F1], num_proj=num_proj, joint_way=joint_way, num_layers=shape[7] if len(shape) > 7 else 1,
                      use_intermediate=ffn, intermediate_size=96, margin=6.0, neg_num=K, dropout=0.0, add_noise=int(noise), seed=7,
                      loss=loss_kind, adv_temp=0.7)
     g = torch.Generator().manual_seed(99)
@@ -98,6 +100,38 @@ def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape, loss_k
         gref = ref.grad if ref.grad is not None else torch.zeros_like(ref)
         scale = max(1.0, float(gref.abs().max()))
         assert_close(grads[k], gref, atol=2e-4 * scale, rtol=1e-4, what=f"grad {k}")
+
+
+@pytest.mark.parametrize("ffn,layers,dropout", [(0, 1, 0.1), (1, 1, 0.1), (0, 2, 0.0), (1, 2, 0.1)])
+def test_readout_only_last_layer_equals_the_full_layer(ffn, layers, dropout):
+    """joint_way Mformer_hd_graph consumes hidden[:, g, :] alone.  The engine's default computes the LAST layer's query, attention
+    row, output projection, LayerNorm (and FFN) for token g only (MKGCConfig.readout_only); the read-out must be the full
+    computation's bit for bit (same per-row arithmetic, same dropout masks), scores and loss too, and every gradient equal up to
+    the summation order of the weight-gradient GEMMs."""
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    N, R, D, B, K = 1500, 9, 128, 200, 16
+    g = torch.Generator().manual_seed(31)
+    feats = [torch.rand(N, 96, generator=g), torch.randn(N, 40, generator=g)]
+    idx = [torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(DEV) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (N, (B, K)))]
+    ent0 = torch.randn(N, D, generator=g).to(DEV)
+    out = {}
+    for ro in (True, False):
+        cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[96, 40], num_proj=2, joint_way="Mformer_hd_graph", num_layers=layers,
+                         use_intermediate=ffn, intermediate_size=96, margin=6.0, neg_num=K, dropout=dropout, add_noise=1, seed=7,
+                         readout_only=ro, deterministic=True)
+        eng = MKGCHotPath(cfg, feats, device=DEV)
+        assert eng.ro == ro
+        eng.p["ent"].copy_(ent0)
+        eng.update_noise()
+        loss, pos, ng = eng.forward(*idx, want_scores=True, with_backward=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        out[ro] = (eng.entity_representation().clone(), loss.clone(), pos.clone(), ng.clone(), {k: v.clone() for k, v in eng.named_gradients().items()})
+    a, b = out[True], out[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[1], b[1])
+    for k in a[4]:
+        scale = max(1e-6, float(b[4][k].abs().max()))
+        assert float((a[4][k] - b[4][k]).abs().max()) <= 2e-5 * scale, k
 
 
 def test_mkgc_train_step_reduces_loss_and_is_deterministic_in_eval():
