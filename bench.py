@@ -26,6 +26,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Share of the 1-GPU step (profiles/r02_step_timeline.txt, 874 us) that every rank repeats identically at N > 1:
+#   replicated fusion: everything except sampling + scoring (~36 us) is full-table work done N times;
+#   row-sharded: only clip + AdamW over the full 10.9 MB flat buffer (~40 us) is repeated.
+REPLICATED_FRACTION_REPLICATED = 0.96
+REPLICATED_FRACTION_SHARDED = 0.05
 STEPS_PER_EPOCH = 78          # 79,222 DB15K training triples / 1024  (SURVEY.md par. 8d)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
@@ -278,6 +283,10 @@ def main():
                     help="db15k = BASELINE configs[1] (Mformer_hd_graph, num_proj=2, 558 relations); mkgw = configs[2] (Mformer_hd_mean, num_proj=1, 338 relations)")
     ap.add_argument("--deterministic", action="store_true", help="bit-reproducible steps (fixed-point integer atomics in the scorer's backward)")
     ap.add_argument("--graph", action="store_true", help="replay the whole step (sampling included) as one captured hipGraph (1 GPU; no per-kernel timers)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch positives PER GPU (default); strong: --batch is the GLOBAL batch, split over the GPUs")
+    ap.add_argument("--replicate-fusion", action="store_true",
+                    help="N > 1: every rank projects and fuses ALL entities (round-1 behaviour) instead of owning 1/N of the rows")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (forward-only rate, copy ceiling, HBM-resident score probe)")
     args = ap.parse_args()
 
@@ -295,14 +304,25 @@ def main():
     from snag_amd.build import ensure_built
     ensure_built(local)                  # no-op when the prebuilt libsnag_hip.so travelled with the tree
     import torch.distributed as dist
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    # BENCH_BACKEND=gloo: dry run of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices, gloo carries the
+    # collectives through host buffers) -- a functional check only, used by tests/test_bench_gpu.py; the real thing is "nccl" = RCCL
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    local_dev = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
+    torch.cuda.set_device(local_dev)
+    device = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
-    from snag_amd.parallel import GradAllReduce
+    from snag_amd.parallel import GradAllReduce, RowShard
+    if args.scaling == "strong":
+        if args.batch % world:
+            sys.exit(f"--scaling strong: the global batch {args.batch} must divide over {world} GPUs")
+        args.batch //= world                               # from here on: positives per GPU
     cfg = MKGCConfig()                                     # DB15K-shaped defaults (configs[1])
     if args.config == "mkgw":                              # configs[2]: README "MKG-W 1 0 Mformer_hd_mean 0.2 0.7 epoch 1 2"
         cfg.joint_way, cfg.num_proj, cfg.n_rel = "Mformer_hd_mean", 1, 338
@@ -311,7 +331,11 @@ def main():
     from snag_amd import ops
     neg_buf = torch.empty(args.batch, cfg.neg_num, device=device, dtype=torch.int32)
     rank_seed = cfg.seed * 7919 + int(os.environ.get("RANK", "0"))
-    eng = MKGCHotPath(cfg, feats, device=device)
+    # N > 1: the entity rows are owned in equal shards -- each rank projects + fuses 1/N of the table, the [N, D] read-outs are
+    # all-gathered before scoring and their gradient reduce-scattered back (SURVEY.md par. 8e); --replicate-fusion keeps full replicas
+    row_sharded = world > 1 and not args.replicate_fusion
+    shard = RowShard(cfg.n_ent, rank, world) if row_sharded else None
+    eng = MKGCHotPath(cfg, feats, device=device, shard=shard)
     reducer = GradAllReduce(world) if world > 1 else None
     if os.environ.get("BENCH_FORCE_ALLREDUCE") and reducer is None:          # exercise the collective path on a 1-GPU box
         if not dist.is_initialized():
@@ -375,7 +399,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     loss = float(eng.loss)
@@ -386,13 +410,18 @@ def main():
         out = {
             "metric": "triples/sec (fusion+score) at |E|=15k dim=128 neg=32", "value": value, "unit": "triples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("configs[1]: DB15K-shaped" if args.config == "db15k" else "configs[2]: MKG-W-shaped") +
                                    f" MKGC train step (proj num_proj={cfg.num_proj} over 4096/768-wide features, "
                                    f"noise 0.2/0.7, Mformer 1-layer/2-head over all 15000 entities, {cfg.joint_way}, "
                                    "margin 12, fwd+bwd+clip_grad_norm+AdamW" + ("+RCCL all-reduce" if world > 1 else "") + ")",
                        "n_ent": cfg.n_ent, "n_rel": cfg.n_rel, "dim": cfg.dim, "neg": cfg.neg_num, "batch_per_gpu": args.batch,
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": loss},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": loss,
+                       # what each rank computes per step: its batch shard's sampling + scoring always; projections + Mformer over
+                       # ALL entities when replicated, over its 1/N of the rows when row-sharded; clip + AdamW on the full flat buffer
+                       "fusion": "single rank" if world == 1 else ("row-sharded: each rank owns 1/N of the entity rows (all-gather of read-outs, "
+                                 "reduce-scatter of their gradient)" if row_sharded else "replicated on every rank"),
+                       "replicated_fraction": None if world == 1 else (REPLICATED_FRACTION_SHARDED if row_sharded else REPLICATED_FRACTION_REPLICATED)},
         }
         if not args.no_extras and world == 1:
             out.update(untimed_extras(eng, batches, args, device))

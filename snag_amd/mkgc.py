@@ -82,20 +82,38 @@ def _align(n, a=64):
 class MKGCHotPath:
     """Owns parameters, activations and the launch sequence of one training / scoring step."""
 
-    def __init__(self, cfg: MKGCConfig, feats: List[torch.Tensor], device="cuda"):
+    def __init__(self, cfg: MKGCConfig, feats: List[torch.Tensor], device="cuda", shard=None):
+        """``shard`` (snag_amd.parallel.RowShard): data-parallel runs own the entity ROWS in equal shards -- this rank projects and
+        fuses rows [shard.lo, shard.lo + shard.n_loc) only, the [N, dim] read-out table is all-gathered before scoring and its
+        gradient reduce-scattered back (SURVEY.md par. 8e).  Default: one rank owning every row.  ``feats``: the full [N, F_m]
+        tables (sliced here) or this rank's rows only."""
         _lib.require_gpu()
+        from .parallel import RowShard
         self.cfg = cfg
         self.dev = torch.device(device)
         self.lib = _lib.load()
         N, R, D, M = cfg.n_ent, cfg.n_rel, cfg.dim, cfg.n_tokens
+        self.shard = shard if shard is not None else RowShard(N)
+        if self.shard.n_rows != N:
+            raise ValueError(f"shard covers {self.shard.n_rows} rows, the entity table has {N}")
+        Nl, Ns, lo = self.shard.n_loc, self.shard.n_shard, self.shard.lo
         if cfg.joint_way not in ("Mformer_hd_graph", "Mformer_hd_mean"):
             raise ValueError("the scoring step reads an [N, dim] read-out: joint_way must be Mformer_hd_graph or Mformer_hd_mean")
         if len(feats) != len(cfg.feat_dims):
             raise ValueError("one feature table per entry of feat_dims")
         self.feats = []
+        self.feat_stats = None
         for f, fd in zip(feats, cfg.feat_dims):
-            if tuple(f.shape) != (N, fd) or f.dtype != f32:
-                raise ValueError(f"feature table must be fp32 [{N}, {fd}], got {tuple(f.shape)}")
+            if f.dtype != f32 or tuple(f.shape) not in ((N, fd), (Nl, fd)):
+                raise ValueError(f"feature table must be fp32 [{N}, {fd}] (or this rank's [{Nl}, {fd}]), got {tuple(f.shape)}")
+            if self.shard.sharded and cfg.add_noise and tuple(f.shape) != (N, fd):
+                raise ValueError("the noise statistics are those of the WHOLE clean table (model/SNAG.py:77-84): pass the full feature tables")
+        if self.shard.sharded and cfg.add_noise:
+            from . import ops
+            self.feat_stats = [ops.colstats(f.to(self.dev).contiguous()) for f in feats]      # before slicing: every rank holds the same constants
+        for f, fd in zip(feats, cfg.feat_dims):
+            if tuple(f.shape) == (N, fd) and Nl != N:
+                f = f[lo:lo + Nl]
             self.feats.append(f.to(self.dev).contiguous())
         # The first projection of every modality is X W^T with X [N, F] and F in the thousands.  As a GEMM with both
         # operands K-contiguous it measures 81 TF; with both row-contiguous (X^T [F, N], W^T [F, D]) the LDS-DMA loop
@@ -103,12 +121,12 @@ class MKGCHotPath:
         # stores that weight transposed.  The weight gradient dW^T = X^T-shaped product needs no extra copy.
         # Rows of the transposed copies are padded to a multiple of 32 floats: with N = 15000 a row is 60,000 B, not a multiple of
         # the 128-B line, so every 256-B tile segment would straddle three lines instead of two (PMC: 1.7x the algorithmic fetch).
-        self.ld_t = _align(N, 32)
+        self.ld_t = _align(max(Nl, 1), 32)
 
         def transposed(f, out=None):
             if out is None:
-                out = torch.zeros(f.shape[1], self.ld_t, device=self.dev, dtype=f32)[:, :N]
-            call("snag_transpose_f32", ptr(f), f.stride(0), N, f.shape[1], ptr(out), out.stride(0), stream())
+                out = torch.zeros(f.shape[1], self.ld_t, device=self.dev, dtype=f32)[:, :Nl]
+            call("snag_transpose_f32", ptr(f), f.stride(0), Nl, f.shape[1], ptr(out), out.stride(0), stream())
             return out
         self._transposed = transposed
         self.feats_t = [transposed(f) for f in self.feats]
@@ -170,44 +188,50 @@ class MKGCHotPath:
 
         # ---- activations / scratch ---------------------------------------------------------------
         dev = self.dev
-        self.x0 = torch.empty(N, M, D, device=dev)
-        # read-out-only last layer: hidden IS the [N, D] read-out, and its gradient the compact scatter target of the scorer
+        # Everything between the raw features and the read-out lives on this rank's Nl rows (Nl = N with one rank)
+        self.x0 = torch.empty(Nl, M, D, device=dev)
+        # read-out-only last layer: hidden IS the [rows, D] read-out, and its gradient the compact scatter target of the scorer
         self.ro = bool(cfg.readout_only) and cfg.joint_way == "Mformer_hd_graph"
-        self.hidden = torch.empty((N, D) if self.ro else (N, M, D), device=dev)
-        self.d_hidden = None if self.ro else torch.empty(N, M, D, device=dev)
-        self.d_x0 = torch.empty(N, M, D, device=dev)
-        self.mid = [torch.empty(N, D, device=dev) for _ in cfg.feat_dims] if cfg.num_proj == 2 else []
-        self.d_mid = torch.empty(N, D, device=dev) if cfg.num_proj == 2 else None
-        self.repr_mean = torch.empty(N, D, device=dev) if cfg.joint_way == "Mformer_hd_mean" else None
-        # compact [N, D] gradient of the read-out (hd_mean, read-out-only hd_graph): zeroed once here; afterwards whoever READS it
+        if self.shard.sharded and not (self.ro or cfg.joint_way == "Mformer_hd_mean"):
+            raise ValueError("row-sharded fusion exchanges a compact [rows, dim] read-out: use readout_only=True with Mformer_hd_graph")
+        # compact read-outs hold Ns = shard.n_shard rows (the collectives move equal chunks; rows past Nl stay zero)
+        self.hidden = torch.zeros((Ns, D) if self.ro else (Nl, M, D), device=dev)
+        self.d_hidden = None if self.ro else torch.empty(Nl, M, D, device=dev)
+        self.d_x0 = torch.empty(Nl, M, D, device=dev)
+        self.mid = [torch.empty(Nl, D, device=dev) for _ in cfg.feat_dims] if cfg.num_proj == 2 else []
+        self.d_mid = torch.empty(Nl, D, device=dev) if cfg.num_proj == 2 else None
+        self.repr_mean = torch.zeros(Ns, D, device=dev) if cfg.joint_way == "Mformer_hd_mean" else None
+        # compact [rows, D] gradient of the read-out (hd_mean, read-out-only hd_graph): zeroed once here; afterwards whoever READS it
         # in the backward clears it behind itself (snag_fusion_bwd zero_d_hidden / snag_token_mean_bwd zero_src), so the fused
         # scorer of the next step finds it clean without a fill launch
-        self.d_repr = torch.zeros(N, D, device=dev) if (self.ro or cfg.joint_way == "Mformer_hd_mean") else None
+        self.d_repr = torch.zeros(Ns, D, device=dev) if (self.ro or cfg.joint_way == "Mformer_hd_mean") else None
         self._d_repr_clean = True
+        # row-sharded: the table the scorer reads is the all-gather of every rank's read-outs, its gradient is reduce-scattered back
+        self.repr_full = torch.zeros(self.shard.n_pad, D, device=dev) if self.shard.sharded else None
+        self.d_repr_full = torch.zeros(self.shard.n_pad, D, device=dev) if self.shard.sharded else None
         lib = self.lib
-        self.save = torch.empty(lib.snag_fusion_save_floats(N, M, D, cfg.num_heads, I, L, int(ffn)), device=dev)
-        ws = lib.snag_fusion_work_floats(N, M, D, cfg.num_heads, I, L, int(ffn))
+        self.save = torch.empty(lib.snag_fusion_save_floats(Nl, M, D, cfg.num_heads, I, L, int(ffn)), device=dev)
+        ws = lib.snag_fusion_work_floats(Nl, M, D, cfg.num_heads, I, L, int(ffn))
         for fd in cfg.feat_dims:
-            ws = max(ws, lib.snag_gemm_workspace_floats(fd, D, N) + 64, lib.snag_gemm_workspace_floats(N, D, fd) + 64, 256 * max(D, fd))
-        ws = max(ws, lib.snag_gemm_workspace_floats(D, D, N) + 64, lib.snag_gemm_workspace_floats(N, D, D) + 64)
+            ws = max(ws, lib.snag_gemm_workspace_floats(fd, D, Nl) + 64, lib.snag_gemm_workspace_floats(Nl, D, fd) + 64, 256 * max(D, fd))
+        ws = max(ws, lib.snag_gemm_workspace_floats(D, D, Nl) + 64, lib.snag_gemm_workspace_floats(Nl, D, D) + 64)
         self.work = torch.empty(ws, device=dev)
         H = cfg.num_heads
         # all dropout keep-masks of the step live in ONE byte buffer (views below), so one Philox launch draws them all
-        n_probs, n_tok = _align(N * H * M * M), _align(N * M * D)
+        n_probs, n_tok = _align(Nl * H * M * M), _align(Nl * M * D)
         per_layer = n_probs + n_tok * (2 if ffn else 1)
-        self.keep_all = torch.ones(L * per_layer, device=dev, dtype=torch.uint8)
-        self.keep_probs = [self.keep_all[l * per_layer:l * per_layer + N * H * M * M].view(N, H, M, M) for l in range(L)]
-        self.keep_attn = [self.keep_all[l * per_layer + n_probs:l * per_layer + n_probs + N * M * D].view(N * M, D) for l in range(L)]
-        self.keep_ffn = ([self.keep_all[l * per_layer + n_probs + n_tok:l * per_layer + n_probs + n_tok + N * M * D].view(N * M, D) for l in range(L)]
+        self.keep_all = torch.ones(max(1, L * per_layer), device=dev, dtype=torch.uint8)
+        self.keep_probs = [self.keep_all[l * per_layer:l * per_layer + Nl * H * M * M].view(Nl, H, M, M) for l in range(L)]
+        self.keep_attn = [self.keep_all[l * per_layer + n_probs:l * per_layer + n_probs + Nl * M * D].view(Nl * M, D) for l in range(L)]
+        self.keep_ffn = ([self.keep_all[l * per_layer + n_probs + n_tok:l * per_layer + n_probs + n_tok + Nl * M * D].view(Nl * M, D) for l in range(L)]
                          if ffn else None)
         self.tick = torch.zeros(1, device=dev, dtype=torch.int64)      # device-side step counter
         # noise state (model/SNAG.py:86-98)
         self.noisy = [f.clone() for f in self.feats]
         self.noisy_t = [self._transposed(f) for f in self.feats]
-        self.feat_stats = None
-        self.ent_noise = torch.zeros(N, D, device=dev)
+        self.ent_noise = torch.zeros(N, D, device=dev)                 # whole table on every rank (same seed): a rank reads its rows
         self.ent_noise_mask = torch.zeros(N, device=dev, dtype=torch.uint8)
-        self.row_mask = torch.zeros(N, device=dev, dtype=torch.uint8)
+        self.row_mask = torch.zeros(max(Nl, 1), device=dev, dtype=torch.uint8)
         self.noise_active = False
         self.noise_epoch = 0
         self.training = True
@@ -266,7 +290,7 @@ class MKGCHotPath:
                 setattr(self._layers[l], nm, ptr(self.p[f"layer{l}.{nm}"]))
                 setattr(self._grads[l], nm, ptr(self.g[f"layer{l}.{nm}"]))
         d = _lib.FusionDesc()
-        d.N, d.M, d.D, d.H, d.I, d.L = cfg.n_ent, cfg.n_tokens, cfg.dim, cfg.num_heads, cfg.intermediate_size, L
+        d.N, d.M, d.D, d.H, d.I, d.L = self.shard.n_loc, cfg.n_tokens, cfg.dim, cfg.num_heads, cfg.intermediate_size, L
         d.use_intermediate = int(ffn)
         d.drop_p = cfg.dropout
         d.layers = ctypes.cast(self._layers, ctypes.POINTER(_lib.FusionLayer))
@@ -331,14 +355,15 @@ class MKGCHotPath:
             self.feat_stats = [ops.colstats(f) for f in self.feats]
         self.noise_epoch += 1
         base = (cfg.seed if seed is None else seed) * 1000003 + self.noise_epoch * 7919
-        N, D = cfg.n_ent, cfg.dim
+        N, D, Nl = cfg.n_ent, cfg.dim, self.shard.n_loc
+        fbase = base + 104723 * self.shard.rank               # feature rows are this rank's own: its own stream
         for i, f in enumerate(self.feats):
             # row mask = rand(N) < noise_ratio  ==  NOT keep with keep = (u >= noise_ratio)
-            call("snag_dropout_keep_mask", base + 11 * i + 1, None, N, float(cfg.noise_ratio), ptr(self.row_mask), st)
+            call("snag_dropout_keep_mask", fbase + 11 * i + 1, None, Nl, float(cfg.noise_ratio), ptr(self.row_mask), st)
             self.row_mask.bitwise_xor_(1)
             mean, std = self.feat_stats[i]
-            call("snag_noise_apply", ptr(f), N, f.shape[1], ptr(mean), ptr(std), ptr(self.row_mask), None, None,
-                 base + 11 * i + 2, float(cfg.mask_ratio), ptr(self.noisy[i]), st)
+            call("snag_noise_apply", ptr(f), Nl, f.shape[1], ptr(mean), ptr(std), ptr(self.row_mask), None, None,
+                 fbase + 11 * i + 2, float(cfg.mask_ratio), ptr(self.noisy[i]), st)
             self._transposed(self.noisy[i], self.noisy_t[i])     # once per epoch
         mean, std = ops.colstats(self.p["ent"])
         call("snag_gaussian_fill", base + 101, N, D, ptr(mean), ptr(std), ptr(self.ent_noise), st)
@@ -351,6 +376,9 @@ class MKGCHotPath:
         """Zero the scorer's scatter targets; returns (pointer, row stride) of the [N, dim] read-out gradient."""
         cfg = self.cfg
         self.g["rel"].zero_()
+        if self.shard.sharded:               # the scorer scatters over ALL entity rows; the owners get their sums by reduce-scatter
+            self.d_repr_full.zero_()
+            return self.d_repr_full.data_ptr(), cfg.dim
         if self.d_repr is not None:
             if not self._d_repr_clean:       # only after a forward(with_backward=True) that no backward() followed
                 self.d_repr.zero_()
@@ -366,32 +394,38 @@ class MKGCHotPath:
         launch here (snag_score_margin_fwd_bwd) and ``backward`` starts at the read-out gradient."""
         cfg = self.cfg
         N, D, M = cfg.n_ent, cfg.dim, cfg.n_tokens
+        Nl, lo = self.shard.n_loc, self.shard.lo               # this rank's entity rows (all of them with one rank)
         st = self._st = stream()
         noisy = self.training and cfg.add_noise and self.noise_active
         MD = M * D
         x0p = self.x0.data_ptr()
         for i, fd in enumerate(cfg.feat_dims):
-            feat_t = self.noisy_t[i] if noisy else self.feats_t[i]          # [fd, N]
+            feat_t = self.noisy_t[i] if noisy else self.feats_t[i]          # [fd, Nl]
             slot = x0p + 4 * i * D
             tag = "proj_l1_fwd" if i == 0 else ""
             if cfg.num_proj == 1:
-                self._probed(tag, self._gemm, N, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.weight"]), D, 0, slot, MD,
+                self._probed(tag, self._gemm, Nl, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.weight"]), D, 0, slot, MD,
                              bias=ptr(self.p[f"proj{i}.bias"]))
             else:   # ProjectionHead: Linear(no bias) -> ReLU -> Linear(no bias)   (model/layers.py:135-148)
-                self._probed(tag, self._gemm, N, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.l1"]), D, 0, ptr(self.mid[i]), D, act=1)
-                self._gemm(N, D, D, ptr(self.mid[i]), D, 1, ptr(self.p[f"proj{i}.l2"]), D, 1, slot, MD)
-        call("snag_entity_token_fwd", ptr(self.p["ent"]), N, D, ptr(self.ent_noise) if noisy else None,
-             ptr(self.ent_noise_mask) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD, st)
+                self._probed(tag, self._gemm, Nl, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.l1"]), D, 0, ptr(self.mid[i]), D, act=1)
+                self._gemm(Nl, D, D, ptr(self.mid[i]), D, 1, ptr(self.p[f"proj{i}.l2"]), D, 1, slot, MD)
+        call("snag_entity_token_fwd", self.p["ent"].data_ptr() + 4 * lo * D, Nl, D, (self.ent_noise.data_ptr() + 4 * lo * D) if noisy else None,
+             (self.ent_noise_mask.data_ptr() + lo) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD, st)
         if self.training and cfg.dropout > 0:
-            call("snag_dropout_keep_mask", cfg.seed + 1, ptr(self.tick), self.keep_all.numel(), cfg.dropout, ptr(self.keep_all), st)
+            call("snag_dropout_keep_mask", cfg.seed + 1 + 7919 * self.shard.rank, ptr(self.tick), self.keep_all.numel(), cfg.dropout, ptr(self.keep_all), st)
         call("snag_fusion_fwd", ctypes.byref(self._fdesc), st)
         if cfg.joint_way == "Mformer_hd_mean":
-            call("snag_token_mean", ptr(self.hidden), N, M, D, ptr(self.repr_mean), st)
+            call("snag_token_mean", ptr(self.hidden), Nl, M, D, ptr(self.repr_mean), st)
             self._repr, self._repr_ld = self.repr_mean.data_ptr(), D
         elif self.ro:
             self._repr, self._repr_ld = self.hidden.data_ptr(), D
         else:
             self._repr, self._repr_ld = self.hidden.data_ptr() + 4 * self.g_slot * D, MD
+        if self.shard.sharded:
+            # every rank's compact read-outs -> the one [N, D] table all ranks score against (the only data-path collective of the
+            # forward; stream-ordered: the compute stream waits for it, the host does not)
+            self.shard.all_gather(self.repr_full, self.repr_mean if cfg.joint_way == "Mformer_hd_mean" else self.hidden)
+            self._repr, self._repr_ld = self.repr_full.data_ptr(), D
         B, K = neg_t.shape
         if self._loss_part is None or self._loss_part.shape[0] != B:
             self._loss_part = torch.empty(B, device=self.dev)
@@ -431,7 +465,7 @@ class MKGCHotPath:
         2 MB exchange hides behind the remaining modalities' GEMMs)."""
         first_proj = self.slices["proj0.weight" if self.cfg.num_proj == 1 else "proj0.l1"][0]
         fusion0 = self.slices["weight_raw"][0]
-        out = [self.gflat[:first_proj], self.gflat[fusion0:]]
+        out = [self.gflat[:first_proj], self.gflat[fusion0:]]          # (row-sharded runs split the first one: see backward)
         starts = [self.slices[f"proj{i}.weight" if self.cfg.num_proj == 1 else f"proj{i}.l1"][0] for i in range(len(self.cfg.feat_dims))] + [fusion0]
         out += [self.gflat[starts[i]:starts[i + 1]] for i in range(len(self.cfg.feat_dims))]
         return out
@@ -444,6 +478,7 @@ class MKGCHotPath:
         modality's weights are exchanged after the compute has finished; ``finish()`` is the caller's."""
         cfg = self.cfg
         N, D, M = cfg.n_ent, cfg.dim, cfg.n_tokens
+        Nl, lo = self.shard.n_loc, self.shard.lo
         st = self._st
         MD = M * D
         h, r, t, neg_t, ib, B, K = self._batch
@@ -467,30 +502,38 @@ class MKGCHotPath:
         else:
             call("snag_score_margin_bwd", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r), ptr(t), ptr(neg_t),
                  ib, B, K, float(cfg.margin), float(grad_scale), *up, d_repr, d_ld, ptr(self.g["rel"]), st)
+        if self.shard.sharded:
+            # every rank scattered its triples' gradients over ALL entity rows: the owners get the sums of their rows
+            self.shard.reduce_scatter(self.d_repr, self.d_repr_full)
         if cfg.joint_way == "Mformer_hd_mean":
-            call("snag_token_mean_bwd", ptr(self.d_repr), N, M, D, ptr(self.d_hidden), 1, st)
+            call("snag_token_mean_bwd", ptr(self.d_repr), Nl, M, D, ptr(self.d_hidden), 1, st)
         call("snag_fusion_bwd", ctypes.byref(self._bdesc), st)
         self._d_repr_clean = True                      # its reader cleared it behind itself
         dx0 = self.d_x0.data_ptr()
         wk = ptr(self.work)
-        call("snag_entity_token_bwd", dx0 + 4 * self.g_slot * D, MD, N, D, ptr(self.ent_noise_mask) if noisy else None,
-             float(cfg.mask_ratio) * 0.5, ptr(self.g["ent"]), 0, st)
+        # the entity table's gradient: this rank's rows only (the others stay zero from construction)
+        call("snag_entity_token_bwd", dx0 + 4 * self.g_slot * D, MD, Nl, D, (self.ent_noise_mask.data_ptr() + lo) if noisy else None,
+             float(cfg.mask_ratio) * 0.5, self.g["ent"].data_ptr() + 4 * lo * D, 0, st)
         buckets = self.grad_buckets() if reducer is not None else None
         if reducer is not None:
-            reducer.start(buckets[0])
+            if self.shard.sharded:       # entity rows: each rank holds its own slice -> all-gather; relations: summed
+                reducer.start_gather(self.g["ent"], self.shard)
+                reducer.start(self.g["rel"].reshape(-1))
+            else:
+                reducer.start(buckets[0])
             reducer.start(buckets[1])
         for i, fd in enumerate(cfg.feat_dims):
             feat = self.noisy[i] if noisy else self.feats[i]
             dslot = dx0 + 4 * i * D
             if cfg.num_proj == 1:
                 # dW^T [fd, D] = feat^T dTok ; db = colsum(dTok)
-                self._gemm(fd, D, N, ptr(feat), fd, 0, dslot, MD, 0, ptr(self.g[f"proj{i}.weight"]), D, splitk=True)
-                call("snag_colsum", dslot, N, D, MD, ptr(self.g[f"proj{i}.bias"]), 0, wk, st)
+                self._gemm(fd, D, Nl, ptr(feat), fd, 0, dslot, MD, 0, ptr(self.g[f"proj{i}.weight"]), D, splitk=True)
+                call("snag_colsum", dslot, Nl, D, MD, ptr(self.g[f"proj{i}.bias"]), 0, wk, st)
             else:
-                self._gemm(D, D, N, dslot, MD, 0, ptr(self.mid[i]), D, 0, ptr(self.g[f"proj{i}.l2"]), D, splitk=True)
+                self._gemm(D, D, Nl, dslot, MD, 0, ptr(self.mid[i]), D, 0, ptr(self.g[f"proj{i}.l2"]), D, splitk=True)
                 # d mid = (dTok l2) * [mid > 0]
-                self._gemm(N, D, D, dslot, MD, 1, ptr(self.p[f"proj{i}.l2"]), D, 0, ptr(self.d_mid), D, act=4, aux=ptr(self.mid[i]), ldaux=D)
-                self._gemm(fd, D, N, ptr(feat), fd, 0, ptr(self.d_mid), D, 0, ptr(self.g[f"proj{i}.l1"]), D, splitk=True)   # dl1^T [fd, D]
+                self._gemm(Nl, D, D, dslot, MD, 1, ptr(self.p[f"proj{i}.l2"]), D, 0, ptr(self.d_mid), D, act=4, aux=ptr(self.mid[i]), ldaux=D)
+                self._gemm(fd, D, Nl, ptr(feat), fd, 0, ptr(self.d_mid), D, 0, ptr(self.g[f"proj{i}.l1"]), D, splitk=True)   # dl1^T [fd, D]
             if reducer is not None:
                 reducer.start(buckets[2 + i])
 
@@ -606,6 +649,8 @@ class MKGCHotPath:
 
     def entity_representation(self):
         """[N, dim] fused entity read-out of the last forward (a strided view of ``hidden`` for Mformer_hd_graph)."""
+        if self.shard.sharded:
+            return self.repr_full[:self.cfg.n_ent]
         if self.cfg.joint_way == "Mformer_hd_mean":
             return self.repr_mean
         return self.hidden if self.ro else self.hidden[:, self.g_slot, :]

@@ -26,6 +26,52 @@ def shard_batch(tensors, rank: int, world: int):
     return tuple(t[lo:hi].contiguous() for t in tensors)
 
 
+class RowShard:
+    """Ownership of the N entity rows by `world` ranks in equal padded shards: rank g owns rows [g*n_shard, g*n_shard + n_loc).
+
+    SURVEY.md par. 8(e): "row-sharded N/G + all-gather of [N,D] read-outs".  Every rank projects and fuses ITS rows only, the
+    compact [n_shard, D] read-outs are all-gathered into one [n_pad, D] table the scorer reads, and the scorer's [n_pad, D]
+    gradient is reduce-scattered back to the owners.  Shards are padded to a common size (the collectives need equal chunks);
+    pad rows (>= N) are never indexed by a triple."""
+
+    def __init__(self, n_rows: int, rank: int = 0, world: int = 1, group=None, force: bool = False):
+        if world < 1 or not (0 <= rank < world):
+            raise ValueError(f"bad rank/world {rank}/{world}")
+        self.n_rows, self.rank, self.world, self.group = int(n_rows), int(rank), int(world), group
+        self.force = bool(force)       # run the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
+        self.n_shard = -(-self.n_rows // self.world)
+        self.n_pad = self.n_shard * self.world
+        self.lo = self.rank * self.n_shard
+        self.n_loc = max(0, min(self.n_rows, self.lo + self.n_shard) - self.lo)
+
+    @property
+    def sharded(self):
+        return self.world > 1 or self.force
+
+    def all_gather(self, full: torch.Tensor, local: torch.Tensor):
+        """full [n_pad, D] <- every rank's local [n_shard, D] (stream-ordered on the GPU backends: the compute stream waits for
+        the collective, the host does not)."""
+        if tuple(full.shape[:1]) != (self.n_pad,) or local.shape[0] != self.n_shard:
+            raise ValueError(f"all_gather: full {tuple(full.shape)} / local {tuple(local.shape)} do not match shards of {self.n_shard}")
+        if full.is_cuda and dist.get_backend(self.group) == "gloo":      # test transport only (two ranks sharing one GPU): gloo moves host buffers
+            host = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(host, local.cpu(), group=self.group)
+            full.copy_(host)
+            return
+        dist.all_gather_into_tensor(full, local, group=self.group)
+
+    def reduce_scatter(self, local: torch.Tensor, full: torch.Tensor):
+        """local [n_shard, D] <- sum over ranks of their full [n_pad, D], rows of this rank's shard."""
+        if tuple(full.shape[:1]) != (self.n_pad,) or local.shape[0] != self.n_shard:
+            raise ValueError(f"reduce_scatter: full {tuple(full.shape)} / local {tuple(local.shape)} do not match shards of {self.n_shard}")
+        if full.is_cuda and dist.get_backend(self.group) == "gloo":      # test transport only, as above
+            host = torch.empty(local.shape, dtype=local.dtype)
+            dist.reduce_scatter_tensor(host, full.cpu(), op=dist.ReduceOp.SUM, group=self.group)
+            local.copy_(host)
+            return
+        dist.reduce_scatter_tensor(local, full, op=dist.ReduceOp.SUM, group=self.group)
+
+
 def common_step_count(n_local: int, batch_size: int, group=None) -> int:
     """Number of optimiser steps EVERY rank runs this epoch: ceil(max over ranks of n_local / batch_size).
 
@@ -77,6 +123,24 @@ class GradAllReduce:
         n = bucket.numel()
         for lo in range(0, n, self.bucket_elems):
             self._pending.append(dist.all_reduce(bucket[lo:lo + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def start_gather(self, full: torch.Tensor, shard: RowShard):
+        """A gradient region in which every rank wrote ONLY the rows it owns (the entity table under row-sharded fusion): an
+        in-place all-gather moves 1/world of what the summed all-reduce of the same region would.  Needs equal unpadded shards
+        (n_rows divisible by world); otherwise the region goes through the all-reduce (the foreign rows are zeros)."""
+        if self.world <= 1 and not self.force:
+            return
+        if shard.n_pad != shard.n_rows or full.shape[0] != shard.n_rows:
+            return self.start(full.reshape(-1))
+        if not hasattr(self, "_pending"):
+            self._pending = []
+        mine = full[shard.lo:shard.lo + shard.n_shard]
+        if full.is_cuda and dist.get_backend(self.group) == "gloo":      # test transport only, as in RowShard.all_gather
+            host = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(host, mine.cpu(), group=self.group)
+            full.copy_(host)
+            return
+        self._pending.append(dist.all_gather_into_tensor(full, mine, group=self.group, async_op=True))
 
     def finish(self):
         """Make the compute stream wait for every started bucket (no host synchronisation on the GPU backends)."""

@@ -24,12 +24,12 @@ def main():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     out = {"backend": dist.get_backend()}
 
-    def engine(joint_way, deterministic):
+    def engine(joint_way, deterministic, shard=None):
         cfg = MKGCConfig(n_ent=2000, n_rel=13, dim=128, feat_dims=[160, 96], num_proj=2, joint_way=joint_way, margin=12.0, neg_num=16, dropout=0.1,
                          add_noise=1, seed=5, lr=1e-3, deterministic=deterministic)
         g = torch.Generator().manual_seed(17)
         feats = [torch.rand(2000, 160, generator=g), torch.randn(2000, 96, generator=g)]
-        eng = MKGCHotPath(cfg, feats, device=dev)
+        eng = MKGCHotPath(cfg, feats, device=dev, shard=shard)
         eng.p["ent"].copy_(torch.randn(2000, 128, generator=g).to(dev))
         B = 256
         batch = [torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(dev) for hi, sz in ((2000, (B,)), (13, (B,)), (2000, (B,)), (2000, (B, 16)))]
@@ -37,15 +37,21 @@ def main():
 
     for joint_way in ("Mformer_hd_graph", "Mformer_hd_mean"):
         res = {}
-        for name, reducer in (("plain", None), ("rccl", GradAllReduce(1, force=True, bucket_bytes=1 << 20))):
-            eng, batch = engine(joint_way, deterministic=True)       # fixed-point scatter: steps are bit-reproducible, so "equal" means bit-equal
+        from snag_amd.parallel import RowShard
+        for name, reducer, shard in (("plain", None, None), ("rccl", GradAllReduce(1, force=True, bucket_bytes=1 << 20), None),
+                                     ("rccl_rows", GradAllReduce(1, force=True), RowShard(2000, 0, 1, force=True))):
+            # "rccl_rows": the row-sharded data path too -- all-gather of the read-outs, reduce-scatter of their gradient, in-place
+            # gather of the entity-table gradient -- as RCCL collectives of one rank (identities, so bit-equality still holds)
+            eng, batch = engine(joint_way, deterministic=True, shard=shard)       # fixed-point scatter: steps are bit-reproducible, so "equal" means bit-equal
             eng.update_noise()
             losses = [float(eng.train_step(*batch, allreduce=reducer)) for _ in range(4)]
             torch.cuda.synchronize()
             res[name] = (eng.flat.clone(), eng.gflat.clone(), eng.exp_avg_sq.clone(), losses)
-        a, b = res["plain"], res["rccl"]
+        a, b, c = res["plain"], res["rccl"], res["rccl_rows"]
         out[joint_way] = {"params_bit_equal": bool(torch.equal(a[0], b[0])), "grads_bit_equal": bool(torch.equal(a[1], b[1])),
-                          "moments_bit_equal": bool(torch.equal(a[2], b[2])), "losses_equal": a[3] == b[3], "loss0": a[3][0], "loss3": a[3][3]}
+                          "moments_bit_equal": bool(torch.equal(a[2], b[2])), "losses_equal": a[3] == b[3], "loss0": a[3][0], "loss3": a[3][3],
+                          "rows_params_bit_equal": bool(torch.equal(a[0], c[0])), "rows_grads_bit_equal": bool(torch.equal(a[1], c[1])),
+                          "rows_losses_equal": a[3] == c[3]}
     # the default (fp32-atomic, fused scorer) step through the same collectives: equal up to the atomics' arrival order
     eng_a, batch = engine("Mformer_hd_graph", deterministic=False)
     eng_b, _ = engine("Mformer_hd_graph", deterministic=False)

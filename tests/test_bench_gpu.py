@@ -1,0 +1,54 @@
+"""GPU: bench.py's contract.  One JSON line on stdout with the required keys at N = 1; and the N > 1 code path (torch.distributed.run,
+row-sharded fusion, strong and weak scaling, max-over-ranks timing) as a two-rank dry run sharing the one device over gloo
+(BENCH_BACKEND=gloo -- functional only; on a multi-GPU node the same code runs over RCCL)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3", "--cpu-seconds", "0", "--no-extras"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    o = _json_line(p.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "roofline_score"):
+        assert k in o, k
+    assert o["n_gpus"] == 1 and o["steps"] == 6 and o["dtype"] == "f32" and o["value"] > 1e5 and "workload" in o["config"]
+    for rf in (o["roofline"], o["roofline_score"]):
+        assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1.5 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+
+
+@pytest.mark.parametrize("extra,scaling,per_gpu", [([], "weak", 256), (["--scaling", "strong"], "strong", 128), (["--replicate-fusion"], "weak", 256)])
+def test_bench_two_rank_dry_run(extra, scaling, per_gpu):
+    env = dict(os.environ, BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "256", "--cpu-seconds", "0",
+           "--no-extras", "--no-kernel-timers"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    o = _json_line(p.stdout)
+    assert o["n_gpus"] == 2 and o["scaling"] == scaling and o["config"]["batch_per_gpu"] == per_gpu and o["config"]["global_batch"] == 2 * per_gpu
+    assert ("row-sharded" in o["config"]["fusion"]) == ("--replicate-fusion" not in extra)
+    assert o["value"] == pytest.approx(2 * per_gpu * 4 / (o["ms_per_step"] * 4e-3), rel=1e-6) and o["config"]["final_loss"] > 0

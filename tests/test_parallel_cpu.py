@@ -116,3 +116,74 @@ def test_ranks_agree_on_steps_per_epoch(tmp_path, n_total, bs):
         assert len(b) == g["steps"] and b[0][0] == 0 and b[-1][1] == g["n"]
         assert all(x[1] == y[0] for x, y in zip(b, b[1:]))
         assert max(hi - lo for lo, hi in b) <= bs
+
+
+def _rowshard_worker(rank, world, port, n_rows, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from snag_amd.parallel import RowShard
+        torch.set_num_threads(1)
+        g = torch.Generator().manual_seed(3)
+        N, R, D, B, K = n_rows, 5, 16, 24, 4
+        table = torch.randn(N, D, generator=g)                    # stands for the entity-side input of the per-row fusion
+        w = torch.randn(D, D, generator=g).requires_grad_(True)   # stands for the dense (replicated) fusion parameters
+        rel = torch.randn(R, D, generator=g).requires_grad_(True)
+        batch = (torch.randint(0, N, (B,), generator=g), torch.randint(0, R, (B,), generator=g),
+                 torch.randint(0, N, (B,), generator=g), torch.randint(0, N, (B, K), generator=g))
+        sh = RowShard(N, rank, world)
+        assert sh.n_pad >= N and sh.n_pad - N < world and 0 <= sh.n_loc <= sh.n_shard
+        # this rank "fuses" ITS rows only: a per-row function of the table and the dense parameters
+        mine = table[sh.lo:sh.lo + sh.n_loc].clone().requires_grad_(True)
+        local = torch.zeros(sh.n_shard, D)
+        local[:sh.n_loc] = torch.tanh(mine @ w)
+        full = torch.zeros(sh.n_pad, D)
+        sh.all_gather(full, local.detach())
+        # score this rank's share of the batch against the WHOLE gathered table; its gradient lands on all rows
+        shard_b = shard_batch(batch, rank, world)
+        tab = full.clone().requires_grad_(True)
+        loss, _, _ = O.score_margin(tab[:N], rel, *shard_b, 2.0)
+        loss.backward()
+        d_full = torch.zeros(sh.n_pad, D)
+        d_full[:N] = tab.grad[:N]
+        d_local = torch.zeros(sh.n_shard, D)
+        sh.reduce_scatter(d_local, d_full)
+        # owners back-propagate the summed gradient of their rows through their part of the fusion
+        local.backward(d_local)
+        gw, grel = w.grad.clone(), rel.grad.clone()
+        dist.all_reduce(gw)                                       # dense parameters: summed partial gradients
+        dist.all_reduce(grel)
+        d_table = torch.zeros(sh.n_pad, D)                        # table gradient: every rank holds its own rows -> gathered
+        d_rows = torch.zeros(sh.n_shard, D)
+        d_rows[:sh.n_loc] = mine.grad
+        sh.all_gather(d_table, d_rows)
+        lt = torch.tensor([float(loss)], dtype=torch.float64)
+        dist.all_reduce(lt)
+        if rank == 0:
+            torch.save({"gw": gw, "grel": grel, "d_table": d_table[:N], "loss": float(lt), "full": full[:N]}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows", [60, 61])
+def test_row_sharded_fusion_algebra(tmp_path, n_rows):
+    """Row ownership (SURVEY par. 8e "row-sharded N/G + all-gather of [N,D] read-outs"): fuse own rows -> all-gather -> score the local
+    batch shard on the whole table -> reduce-scatter the table gradient -> own rows' backward; dense gradients all-reduced.  Equals the
+    single-process computation, also when N does not divide over the ranks (padded shards)."""
+    out = str(tmp_path / "rs.pt")
+    mp.spawn(_rowshard_worker, args=(2, _free_port(), n_rows, out), nprocs=2, join=True)
+    got = torch.load(out)
+    g = torch.Generator().manual_seed(3)
+    N, R, D, B, K = n_rows, 5, 16, 24, 4
+    table = torch.randn(N, D, generator=g).requires_grad_(True)
+    w = torch.randn(D, D, generator=g).requires_grad_(True)
+    rel = torch.randn(R, D, generator=g).requires_grad_(True)
+    batch = (torch.randint(0, N, (B,), generator=g), torch.randint(0, R, (B,), generator=g),
+             torch.randint(0, N, (B,), generator=g), torch.randint(0, N, (B, K), generator=g))
+    full = torch.tanh(table @ w)
+    loss, _, _ = O.score_margin(full, rel, *batch, 2.0)
+    loss.backward()
+    assert torch.allclose(got["full"], full.detach(), atol=1e-6)
+    assert abs(got["loss"] - float(loss)) < 1e-4 * max(1.0, abs(float(loss)))
+    for a, b in ((got["gw"], w.grad), (got["grel"], rel.grad), (got["d_table"], table.grad)):
+        assert torch.allclose(a, b, atol=1e-4, rtol=1e-4)

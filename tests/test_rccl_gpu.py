@@ -33,6 +33,7 @@ def test_engine_step_through_rccl_equals_the_plain_step_bit_for_bit():
         # stream) and the clip / AdamW kernels (compute stream), or a bucket exchanged before its gradients were final, shows up as a bit
         assert o["params_bit_equal"] and o["grads_bit_equal"] and o["moments_bit_equal"] and o["losses_equal"], o
         assert o["loss3"] < o["loss0"]
+        assert o["rows_params_bit_equal"] and o["rows_grads_bit_equal"] and o["rows_losses_equal"], o      # row-sharded data path over RCCL
     la, lb = out["fused_losses"]                  # default step (fused scorer, fp32 atomics): equal up to the atomics' arrival order
     assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(la, lb)) and la[2] < la[0], (la, lb)
     assert out["steps_agreed"] == 4 and out["epoch_loss_finite"]
