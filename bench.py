@@ -271,6 +271,126 @@ def cpu_baseline(cfg, feats, batch, budget_s, seed):
                       f"{avail} usable threads, median {med * 1e3:.0f} ms/step, torch {torch.__version__} CPU"}
 
 
+def run_stress(args, world, rank, device, backend, real_stdout):
+    """BASELINE.json configs[4]: |E| = 1M, dim 256, 128 negative tails, bf16 tables, B = 1024 per GPU (snag_amd.stress).  One step =
+    on-device sampling -> fused bf16 scorer (scores + loss + scattered fp32 gradients) -> reduce-scatter of the table gradient to the
+    row owners (N > 1) -> AdamW on the owned fp32 rows + their bf16 copy -> all-gather of the updated bf16 rows (N > 1).
+    Communication and compute are reported separately (HIP events on the compute stream, which waits for every collective)."""
+    import torch.distributed as dist
+    from snag_amd import ops
+    from snag_amd.parallel import RowShard
+    from snag_amd.stress import StressConfig, StressHotPath
+    cfg = StressConfig()
+    shard = RowShard(cfg.n_ent, rank, world) if world > 1 else None
+    eng = StressHotPath(cfg, device=device, shard=shard)
+    B, K, N, R, D = args.batch, cfg.neg_num, cfg.n_ent, cfg.n_rel, cfg.dim
+    gi = torch.Generator().manual_seed(cfg.seed + 1 + rank)
+    n_batches = 16
+    idx = [[torch.randint(0, hi, (B,), generator=gi, dtype=torch.int32).to(device) for hi in (N, R, N)] for _ in range(n_batches)]
+    neg = torch.empty(B, K, device=device, dtype=torch.int32)
+    seed = cfg.seed * 7919 + rank
+    timers = {}
+
+    def one_step(i, tm=None):
+        h, r, t = idx[i % n_batches]
+        ops.sample_negatives(h, r, t, K, N, R, seed, tick=eng.tick, out=neg)
+        eng.train_step(h, r, t, neg, timers=tm)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i, timers)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        return
+
+    def span(a, b):
+        v = [x.elapsed_time(y) * 1e3 for x, y in zip(timers[a], timers[b])]
+        return sum(v) / len(v)
+
+    score_us, rs_us, adam_us, ag_us = span("t0", "t1"), span("t1", "t2"), span("t2", "t3"), span("t3", "t4")
+    rows = B * (K + 3)
+    fwd_bytes = rows * D * 2 + B * ((K + 3) * 4 + (K + 1) * 4)            # bf16 rows read once + ids + scores (SURVEY par. 8d, s = 2)
+    alg_bytes = fwd_bytes + rows * D * 4 * 2                              # + read-modify-write of the fp32 gradient rows
+    ach = alg_bytes / (score_us * 1e-6) / 1e9
+    shard_rows = -(-N // world)
+    out = {
+        "metric": "triples/sec (negative-sampled margin scoring fwd+bwd + row-owned AdamW) at |E|=1M dim=256 neg=128, bf16 tables",
+        "value": B * world * args.steps / elapsed, "unit": "triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 tables, f32 arithmetic",
+        "data": "synthetic",
+        "config": {"workload": "configs[4]: stress, |E|=1M x 256 bf16 entity table (512 MB, replicated), 128 negative tails, uniform indices, "
+                               "fp32 master rows + Adam moments owned 1/N per rank", "n_ent": N, "n_rel": R, "dim": D, "neg": K, "batch_per_gpu": B,
+                   "global_batch": B * world, "parallelism": f"dp{world} + row-owned optimiser state", "final_loss": float(eng.loss)},
+        "phases_us": {"score_fwd_bwd (+ zeroing the relation gradient)": score_us, "reduce_scatter(table grad) + all_reduce(rel grad)": rs_us,
+                      "adamw(owned rows) + bf16 copy + clear touched rows": adam_us, "all_gather(updated bf16 rows)": ag_us,
+                      "compute_us": score_us + adam_us, "comm_us": rs_us + ag_us,
+                      "comm_bytes_per_rank": {"reduce_scatter_fp32": (world - 1) * shard_rows * D * 4, "all_gather_bf16": (world - 1) * shard_rows * D * 2}},
+        "roofline": {"kernel": "score_fused_kernel<bf16 tables> (snag_score_margin_fwd_bwd_bf16), HBM-resident 512 MB table", "bound": "hbm",
+                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_us": score_us,
+                     "algorithmic_bytes_per_launch": alg_bytes, "atomic_bytes_per_launch": rows * D * 4, "atomic_floor_us": rows * D * 4 / 1.3e12 * 1e6,
+                     "timed": "HIP events around the launch (+ a 1 MB fill), inside the timed region"},
+    }
+    if world == 1 and args.cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline_stress(cfg, B, min(args.cpu_seconds, 30.0))
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
+
+
+def cpu_baseline_stress(cfg, batch, budget_s):
+    """The oracle's scorer + torch.optim.AdamW on this host: same step (bf16-rounded tables, fp32 arithmetic, dense AdamW over 1M x 256)."""
+    from oracle import ref_cpu as O
+    N, R, D, K = cfg.n_ent, cfg.n_rel, cfg.dim, cfg.neg_num
+    g = torch.Generator().manual_seed(cfg.seed)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    thr = min(16, avail)
+    torch.set_num_threads(thr)
+    em = torch.nn.Parameter(torch.randn(N, D, generator=g) * cfg.init_scale)
+    rm = torch.nn.Parameter(torch.randn(R, D, generator=g) * cfg.init_scale)
+    opt = torch.optim.AdamW([em, rm], lr=cfg.lr, weight_decay=cfg.weight_decay)
+    h, r, t = (torch.randint(0, hi, (batch,), generator=g) for hi in (N, R, N))
+    neg = torch.randint(0, N, (batch, K), generator=g)
+
+    def step():
+        e16 = em.detach().bfloat16().float().requires_grad_(True)
+        r16 = rm.detach().bfloat16().float().requires_grad_(True)
+        loss, _, _ = O.score_margin(e16, r16, h, r, t, neg, cfg.margin)
+        loss.backward()
+        em.grad, rm.grad = e16.grad, r16.grad
+        opt.step()
+
+    step()
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end and len(times) < 10:
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": batch / med, "unit": "triples/s", "cores": thr, "kind": "port",
+            "sample": f"{len(times)} steps of the same workload (|E|={N}, D={D}, K={K}, B={batch}: oracle scorer fwd+bwd + torch.optim.AdamW over the whole "
+                      f"table) at {thr} of {avail} usable threads, median {med * 1e3:.0f} ms/step"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -279,8 +399,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="positives per GPU per step (NUM_BATCH)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU-baseline leg (0 = skip)")
     ap.add_argument("--no-kernel-timers", action="store_true")
-    ap.add_argument("--config", default="db15k", choices=["db15k", "mkgw"],
-                    help="db15k = BASELINE configs[1] (Mformer_hd_graph, num_proj=2, 558 relations); mkgw = configs[2] (Mformer_hd_mean, num_proj=1, 338 relations)")
+    ap.add_argument("--config", default="db15k", choices=["db15k", "mkgw", "stress"],
+                    help="db15k = BASELINE configs[1] (Mformer_hd_graph, num_proj=2, 558 relations); mkgw = configs[2] (Mformer_hd_mean, num_proj=1, 338 relations); "
+                         "stress = configs[4] (|E|=1M, dim 256, 128 negatives, bf16 tables: scorer + row-owned AdamW, comm and compute reported separately)")
     ap.add_argument("--deterministic", action="store_true", help="bit-reproducible steps (fixed-point integer atomics in the scorer's backward)")
     ap.add_argument("--graph", action="store_true", help="replay the whole step (sampling included) as one captured hipGraph (1 GPU; no per-kernel timers)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -317,6 +438,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.config == "stress":
+        run_stress(args, world, rank, device, backend, real_stdout)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
     from snag_amd.parallel import GradAllReduce, RowShard
     if args.scaling == "strong":

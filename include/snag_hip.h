@@ -63,7 +63,7 @@ SNAG_API int snag_score_margin_fwd(const float* ent, int64_t ent_ld, int64_t n_e
 
 /* Same scores from bf16 tables (raw bfloat16 bit patterns), fp32 arithmetic and outputs: the storage format of
  * BASELINE config 5 (|E| = 1M, dim 256, 128 negatives: a 512 MB table that does not fit the Infinity Cache).
- * dim and ent_ld (in elements) multiples of 8, dim <= 1024.  Forward only this round. */
+ * dim and ent_ld (in elements) multiples of 8, dim <= 1024. */
 SNAG_API int snag_score_margin_fwd_bf16(const uint16_t* ent, int64_t ent_ld, int64_t n_ent, const uint16_t* rel, int64_t n_rel, int dim,
                           const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
                           int64_t batch, int n_neg, float margin,
@@ -98,6 +98,36 @@ SNAG_API int snag_score_margin_fwd_bwd(const float* ent, int64_t ent_ld, int64_t
                           int64_t batch, int n_neg, float margin, float grad_scale,
                           float* pos, float* neg, float* loss_part, float* loss, uint32_t* ticket,
                           float* d_ent, int64_t d_ent_ld, float* d_rel, void* stream);
+
+/* The same three training entries over bf16 TABLES (raw bfloat16 bit patterns; BASELINE config 5: |E| = 1M, dim 256, 128 negatives):
+ * fp32 arithmetic, fp32 scores, fp32 gradient accumulation -- only the gathered rows are 2-byte.  d_ent / d_rel stay fp32. */
+SNAG_API int snag_score_margin_fwd_bwd_bf16(const uint16_t* ent, int64_t ent_ld, int64_t n_ent, const uint16_t* rel, int64_t n_rel, int dim,
+                          const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                          int64_t batch, int n_neg, float margin, float grad_scale,
+                          float* pos, float* neg, float* loss_part, float* loss, uint32_t* ticket,
+                          float* d_ent, int64_t d_ent_ld, float* d_rel, void* stream);
+SNAG_API int snag_score_margin_bwd_bf16(const uint16_t* ent, int64_t ent_ld, int64_t n_ent, const uint16_t* rel, int64_t n_rel, int dim,
+                          const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                          int64_t batch, int n_neg, float margin, float grad_scale,
+                          const float* dpos, const float* dneg,
+                          float* d_ent, int64_t d_ent_ld, float* d_rel, void* stream);
+SNAG_API int snag_score_margin_bwd_fixed_bf16(const uint16_t* ent, int64_t ent_ld, int64_t n_ent, const uint16_t* rel, int64_t n_rel, int dim,
+                          const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                          int64_t batch, int n_neg, float margin, float grad_scale,
+                          const float* dpos, const float* dneg, long long* acc_ent, long long* acc_rel, void* stream);
+
+/* Config-5 optimiser pieces: torch.optim.AdamW on a slice of fp32 MASTER weights (the rows of the entity table this rank owns,
+ * SURVEY par. 8e "row-sharded ownership of the entity table + optimizer state") that also writes the bf16 copy of the updated weights
+ * (bf16_out, optional) -- the slice of the replicated bf16 table the scorer gathers from, all-gathered afterwards.  n % 4 == 0.
+ * snag_f32_to_bf16: round-to-nearest-even conversion of a whole table (initialisation). */
+SNAG_API int snag_adamw_step_bf16(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                  const uint64_t* tick, float grad_scale, uint16_t* bf16_out, void* stream);
+SNAG_API int snag_f32_to_bf16(const float* src, int64_t n, uint16_t* dst, void* stream);
+/* Clear exactly the rows of an [n_ent, dim] gradient buffer that one batch scatter-added into (h[b], t[b], neg_t[b, :]): 136 MB of
+ * stores per 1,024 x 130 rows at dim 256 instead of a 1 GB memset of the whole config-5 buffer.  dim % 4 == 0. */
+SNAG_API int snag_zero_touched_rows(float* d_ent, int64_t d_ent_ld, int dim, const void* h, const void* t, const void* neg_t, int idx_bytes,
+                                    int64_t batch, int n_neg, void* stream);
 
 /* Bit-reproducible variant of snag_score_margin_bwd: the same gradients accumulated with 64-bit INTEGER atomics in fixed point
  * (32 fractional bits: sums are associative, so the result does not depend on the order the triples arrive in; |sum| < 2^31,

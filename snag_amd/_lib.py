@@ -65,6 +65,12 @@ SIGNATURES = {
     "snag_score_margin_fwd_bf16": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _P, _P, _P, _P],
     "snag_score_margin_bwd": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _L, _P, _P],
     "snag_score_margin_fwd_bwd": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _L, _P, _P],
+    "snag_score_margin_fwd_bwd_bf16": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _L, _P, _P],
+    "snag_score_margin_bwd_bf16": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _L, _P, _P],
+    "snag_score_margin_bwd_fixed_bf16": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P],
+    "snag_adamw_step_bf16": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _P, _F, _P, _P],
+    "snag_f32_to_bf16": [_P, _L, _P, _P],
+    "snag_zero_touched_rows": [_P, _L, _I, _P, _P, _P, _I, _L, _I, _P],
     "snag_reduce_sum": [_P, _L, _P, _P],
     "snag_rank_full_table": [_P, _L, _L, _P, _I, _P, _P, _P],
     "snag_gemm_f32": [_c.POINTER(GemmDesc), _P],

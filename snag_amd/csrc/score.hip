@@ -168,9 +168,9 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(
     }
 }
 
-template <typename IdxT, int NS, typename AccT>
+template <typename IdxT, int NS, typename AccT, typename ElemT>
 __global__ __launch_bounds__(256) void score_bwd_kernel(
-    const float* __restrict__ ent, int64_t eld, const float* __restrict__ rel, int dim,
+    const ElemT* __restrict__ ent, int64_t eld, const ElemT* __restrict__ rel, int dim,
     const IdxT* __restrict__ h, const IdxT* __restrict__ r, const IdxT* __restrict__ t,
     const IdxT* __restrict__ neg_t, int64_t batch, int n_neg, float margin, float gscale,
     const float* __restrict__ dpos, const float* __restrict__ dneg,
@@ -325,14 +325,14 @@ static int launch_fwd(const float* ent, int64_t eld, const float* rel, int dim, 
     return check_launch("snag_score_margin_fwd");
 }
 
-template <typename IdxT, typename AccT>
-static int launch_bwd(const float* ent, int64_t eld, const float* rel, int dim, const void* h, const void* r, const void* t,
+template <typename IdxT, typename AccT, typename ElemT = float>
+static int launch_bwd(const ElemT* ent, int64_t eld, const ElemT* rel, int dim, const void* h, const void* r, const void* t,
                       const void* neg_t, int64_t batch, int n_neg, float margin, float gscale, const float* dpos,
                       const float* dneg, AccT* d_ent, int64_t dld, AccT* d_rel, hipStream_t st) {
     const dim3 grid((unsigned)ceil_div(batch, 4)), block(256);
     const int ns = (dim + 63) / 64;
 #define SNAG_BWD(NS)                                                                                           \
-    hipLaunchKernelGGL((score_bwd_kernel<IdxT, NS, AccT>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h,  \
+    hipLaunchKernelGGL((score_bwd_kernel<IdxT, NS, AccT, ElemT>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h,  \
                        (const IdxT*)r, (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, gscale, dpos, \
                        dneg, d_ent, dld, d_rel)
     switch (ns) {
@@ -503,7 +503,7 @@ static int launch_fwd_bf16(const uint16_t* ent, int64_t eld, const uint16_t* rel
 }
 
 int check_score_args(const void* ent, int64_t n_ent, const void* rel, int64_t n_rel, int dim, const void* h,
-                            const void* r, const void* t, const void* neg_t, int idx_bytes, int64_t batch, int n_neg) {
+                     const void* r, const void* t, const void* neg_t, int idx_bytes, int64_t batch, int n_neg) {
     SNAG_REQUIRE(ent && rel && h && r && t, SNAG_ERR_ARG, "score: null table or index pointer");
     SNAG_REQUIRE(n_ent > 0 && n_rel > 0 && dim > 0, SNAG_ERR_ARG, "score: n_ent=%ld n_rel=%ld dim=%d must be positive",
                  (long)n_ent, (long)n_rel, dim);
@@ -679,4 +679,42 @@ extern "C" SNAG_API int snag_score_margin_fwd_bf16(const uint16_t* ent, int64_t 
     hipStream_t st = (hipStream_t)stream;
     return idx_bytes == 4 ? launch_fwd_bf16<int32_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, pos, neg, loss_part, st)
                           : launch_fwd_bf16<int64_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, pos, neg, loss_part, st);
+}
+
+// ---- bf16 tables (BASELINE config 5), backward in its two-launch forms: explicit upstream gradients, and the bit-reproducible
+// fixed-point scatter.  fp32 arithmetic and accumulation, exactly as the fp32-table entries above.
+extern "C" SNAG_API int snag_score_margin_bwd_bf16(const uint16_t* ent, int64_t ent_ld, int64_t n_ent, const uint16_t* rel, int64_t n_rel, int dim,
+                                                   const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                                                   int64_t batch, int n_neg, float margin, float grad_scale, const float* dpos,
+                                                   const float* dneg, float* d_ent, int64_t d_ent_ld, float* d_rel, void* stream) {
+    if (batch == 0) return SNAG_OK;
+    int rc = check_score_args(ent, n_ent, rel, n_rel, dim, h, r, t, neg_t, idx_bytes, batch, n_neg);
+    if (rc) return rc;
+    SNAG_REQUIRE(d_ent && d_rel, SNAG_ERR_ARG, "score_bwd_bf16: null gradient pointer");
+    SNAG_REQUIRE(n_neg == 0 || neg_t, SNAG_ERR_ARG, "score_bwd_bf16: neg_t is null but n_neg=%d", n_neg);
+    SNAG_REQUIRE(ent_ld >= dim && d_ent_ld >= dim, SNAG_ERR_ARG, "score_bwd_bf16: row stride smaller than dim=%d", dim);
+    SNAG_REQUIRE((dpos != nullptr) || (dneg == nullptr), SNAG_ERR_ARG, "score_bwd_bf16: dneg given without dpos");
+    SNAG_REQUIRE((dpos == nullptr) || (dneg != nullptr) || n_neg == 0, SNAG_ERR_ARG, "score_bwd_bf16: explicit mode needs both dpos and dneg");
+    hipStream_t st = (hipStream_t)stream;
+    return idx_bytes == 4
+               ? launch_bwd<int32_t, float, uint16_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, d_ent, d_ent_ld, d_rel, st)
+               : launch_bwd<int64_t, float, uint16_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, d_ent, d_ent_ld, d_rel, st);
+}
+
+extern "C" SNAG_API int snag_score_margin_bwd_fixed_bf16(const uint16_t* ent, int64_t ent_ld, int64_t n_ent, const uint16_t* rel, int64_t n_rel, int dim,
+                                                         const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes, int64_t batch,
+                                                         int n_neg, float margin, float grad_scale, const float* dpos, const float* dneg,
+                                                         long long* acc_ent, long long* acc_rel, void* stream) {
+    if (batch == 0) return SNAG_OK;
+    int rc = check_score_args(ent, n_ent, rel, n_rel, dim, h, r, t, neg_t, idx_bytes, batch, n_neg);
+    if (rc) return rc;
+    SNAG_REQUIRE(acc_ent && acc_rel, SNAG_ERR_ARG, "score_bwd_fixed_bf16: null accumulator");
+    SNAG_REQUIRE(n_neg == 0 || neg_t, SNAG_ERR_ARG, "score_bwd_fixed_bf16: neg_t is null but n_neg=%d", n_neg);
+    SNAG_REQUIRE(ent_ld >= dim, SNAG_ERR_ARG, "score_bwd_fixed_bf16: row stride smaller than dim=%d", dim);
+    SNAG_REQUIRE((dpos != nullptr) || (dneg == nullptr), SNAG_ERR_ARG, "score_bwd_fixed_bf16: dneg given without dpos");
+    SNAG_REQUIRE((dpos == nullptr) || (dneg != nullptr) || n_neg == 0, SNAG_ERR_ARG, "score_bwd_fixed_bf16: explicit mode needs both dpos and dneg");
+    hipStream_t st = (hipStream_t)stream;
+    return idx_bytes == 4
+               ? launch_bwd<int32_t, long long, uint16_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, acc_ent, dim, acc_rel, st)
+               : launch_bwd<int64_t, long long, uint16_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, dpos, dneg, acc_ent, dim, acc_rel, st);
 }

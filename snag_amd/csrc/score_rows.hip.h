@@ -15,14 +15,18 @@ struct RowS {
     float v[NS];
 };
 
-template <int NS>
-__device__ __forceinline__ RowS<NS> load_row_s(const float* __restrict__ base, int64_t row, int64_t ld, int dim, int lane) {
+// table element -> fp32: float tables as they are, bf16 tables (raw bit patterns, BASELINE config 5) widened exactly
+__device__ __forceinline__ float elem_to_float(float v) { return v; }
+__device__ __forceinline__ float elem_to_float(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+
+template <int NS, typename ElemT>
+__device__ __forceinline__ RowS<NS> load_row_s(const ElemT* __restrict__ base, int64_t row, int64_t ld, int dim, int lane) {
     RowS<NS> r;
-    const float* p = base + row * ld;
+    const ElemT* p = base + row * ld;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int c = lane + 64 * i;
-        r.v[i] = (c < dim) ? p[c] : 0.f;
+        r.v[i] = (c < dim) ? elem_to_float(p[c]) : 0.f;
     }
     return r;
 }

@@ -24,9 +24,9 @@ namespace snag {
 constexpr int kTicketShards = 32;
 static_assert(32 * (kTicketShards + 1) == SNAG_SCORE_TICKET_WORDS, "ticket layout: one 128-byte line per shard word + the top word");
 
-template <typename IdxT, int NS, int WPT>
+template <typename IdxT, int NS, int WPT, typename ElemT>
 __global__ __launch_bounds__(256) void score_fused_kernel(
-    const float* __restrict__ ent, int64_t eld, const float* __restrict__ rel, int dim,
+    const ElemT* __restrict__ ent, int64_t eld, const ElemT* __restrict__ rel, int dim,
     const IdxT* __restrict__ h, const IdxT* __restrict__ r, const IdxT* __restrict__ t,
     const IdxT* __restrict__ neg_t, int64_t batch, int n_neg_all, float margin, float gscale,
     float* __restrict__ pos, float* __restrict__ neg, float* __restrict__ loss_part, float* __restrict__ loss,
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256) void score_fused_kernel(
     if (threadIdx.x == 0) loss[0] = ((hinge_part[0] + hinge_part[1]) + hinge_part[2]) + hinge_part[3];
 }
 
-template <typename IdxT>
-static int launch_fused(const float* ent, int64_t eld, const float* rel, int dim, const void* h, const void* r, const void* t,
+template <typename IdxT, typename ElemT>
+static int launch_fused(const ElemT* ent, int64_t eld, const ElemT* rel, int dim, const void* h, const void* r, const void* t,
                         const void* neg_t, int64_t batch, int n_neg, float margin, float gscale, float* pos, float* neg,
                         float* loss_part, float* loss, unsigned* ticket, float* d_ent, int64_t dld, float* d_rel, hipStream_t st) {
     // waves per triple: enough short waves to keep ~16 per CU (256 CUs) while a triple still has >= 8 negatives per wave
@@ -195,7 +195,7 @@ static int launch_fused(const float* ent, int64_t eld, const float* rel, int dim
     const dim3 grid((unsigned)ceil_div(batch, 4 / wpt)), block(256);
     const int ns = (dim + 63) / 64;
 #define SNAG_FUSED_W(NS, W)                                                                                                      \
-    hipLaunchKernelGGL((score_fused_kernel<IdxT, NS, W>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h, (const IdxT*)r, \
+    hipLaunchKernelGGL((score_fused_kernel<IdxT, NS, W, ElemT>), grid, block, 0, st, ent, eld, rel, dim, (const IdxT*)h, (const IdxT*)r, \
                        (const IdxT*)t, (const IdxT*)neg_t, batch, n_neg, margin, gscale, pos, neg, loss_part, loss, ticket,     \
                        d_ent, dld, d_rel)
 #define SNAG_FUSED(NS)                                \
@@ -238,8 +238,31 @@ extern "C" SNAG_API int snag_score_margin_fwd_bwd(const float* ent, int64_t ent_
     SNAG_REQUIRE(pos && (n_neg == 0 || (neg && neg_t)), SNAG_ERR_ARG, "score_fwd_bwd: null score output or negative-tail ids");
     SNAG_REQUIRE(d_ent && d_rel, SNAG_ERR_ARG, "score_fwd_bwd: null gradient pointer");
     SNAG_REQUIRE(ent_ld >= dim && d_ent_ld >= dim, SNAG_ERR_ARG, "score_fwd_bwd: row stride smaller than dim=%d", dim);
-    return idx_bytes == 4 ? launch_fused<int32_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, pos, neg, loss_part,
-                                                  loss, ticket, d_ent, d_ent_ld, d_rel, st)
-                          : launch_fused<int64_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, pos, neg, loss_part,
-                                                  loss, ticket, d_ent, d_ent_ld, d_rel, st);
+    return idx_bytes == 4 ? launch_fused<int32_t, float>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, pos, neg, loss_part,
+                                                         loss, ticket, d_ent, d_ent_ld, d_rel, st)
+                          : launch_fused<int64_t, float>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, pos, neg, loss_part,
+                                                         loss, ticket, d_ent, d_ent_ld, d_rel, st);
+}
+
+extern "C" SNAG_API int snag_score_margin_fwd_bwd_bf16(const uint16_t* ent, int64_t ent_ld, int64_t n_ent, const uint16_t* rel, int64_t n_rel, int dim,
+                                                       const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                                                       int64_t batch, int n_neg, float margin, float grad_scale, float* pos, float* neg,
+                                                       float* loss_part, float* loss, uint32_t* ticket, float* d_ent, int64_t d_ent_ld,
+                                                       float* d_rel, void* stream) {
+    SNAG_REQUIRE((loss == nullptr) || (loss_part != nullptr && ticket != nullptr), SNAG_ERR_ARG,
+                 "score_fwd_bwd_bf16: the summed loss needs loss_part and a ticket buffer");
+    hipStream_t st = (hipStream_t)stream;
+    if (batch == 0) {
+        if (loss != nullptr) return hipMemsetAsync(loss, 0, sizeof(float), st) == hipSuccess ? SNAG_OK : fail(SNAG_ERR_LAUNCH, "score_fwd_bwd_bf16: memset failed");
+        return SNAG_OK;
+    }
+    int rc = check_score_args(ent, n_ent, rel, n_rel, dim, h, r, t, neg_t, idx_bytes, batch, n_neg);
+    if (rc) return rc;
+    SNAG_REQUIRE(pos && (n_neg == 0 || (neg && neg_t)), SNAG_ERR_ARG, "score_fwd_bwd_bf16: null score output or negative-tail ids");
+    SNAG_REQUIRE(d_ent && d_rel, SNAG_ERR_ARG, "score_fwd_bwd_bf16: null gradient pointer");
+    SNAG_REQUIRE(ent_ld >= dim && d_ent_ld >= dim, SNAG_ERR_ARG, "score_fwd_bwd_bf16: row stride smaller than dim=%d", dim);
+    return idx_bytes == 4 ? launch_fused<int32_t, uint16_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, pos, neg, loss_part,
+                                                            loss, ticket, d_ent, d_ent_ld, d_rel, st)
+                          : launch_fused<int64_t, uint16_t>(ent, ent_ld, rel, dim, h, r, t, neg_t, batch, n_neg, margin, grad_scale, pos, neg, loss_part,
+                                                            loss, ticket, d_ent, d_ent_ld, d_rel, st);
 }

@@ -187,3 +187,52 @@ def test_row_sharded_fusion_algebra(tmp_path, n_rows):
     assert abs(got["loss"] - float(loss)) < 1e-4 * max(1.0, abs(float(loss)))
     for a, b in ((got["gw"], w.grad), (got["grel"], rel.grad), (got["d_table"], table.grad)):
         assert torch.allclose(a, b, atol=1e-4, rtol=1e-4)
+
+
+def _zero_worker(rank, world, port, n_rows, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from snag_amd.parallel import RowShard
+        torch.set_num_threads(1)
+        g = torch.Generator().manual_seed(8)
+        D = 8
+        table = torch.randn(n_rows, D, generator=g)
+        sh = RowShard(n_rows, rank, world)
+        full16 = torch.zeros(sh.n_pad, D, dtype=torch.bfloat16)
+        full16[:n_rows] = table.bfloat16()
+        master = torch.zeros(sh.n_shard, D)
+        master[:sh.n_loc] = table[sh.lo:sh.lo + sh.n_loc]
+        p = torch.nn.Parameter(master.clone())
+        opt = torch.optim.AdamW([p], lr=1e-2, weight_decay=1e-2)
+        for step in range(3):
+            gl = torch.Generator().manual_seed(100 * step + rank)
+            d_full = torch.zeros(sh.n_pad, D)
+            d_full[:n_rows] = torch.randn(n_rows, D, generator=gl)        # this rank's scatter of table gradients
+            d_mine = torch.zeros(sh.n_shard, D)
+            sh.reduce_scatter(d_mine, d_full)
+            p.grad = d_mine
+            opt.step()
+            full16[sh.lo:sh.lo + sh.n_shard] = p.detach().bfloat16()
+            sh.all_gather(full16, full16[sh.lo:sh.lo + sh.n_shard].clone())
+        torch.save({"full16": full16[:n_rows].float(), "rows": p.detach()[:sh.n_loc].clone(), "lo": sh.lo}, f"{out}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows", [40, 41])
+def test_row_owned_optimizer_state_equals_dense_adamw(tmp_path, n_rows):
+    """Config-5 partition logic (SURVEY par. 8e option 2): reduce-scatter of the table gradient to the row owners, AdamW on the owned rows
+    with moments sharded the same way, all-gather of the updated bf16 rows == dense AdamW on the summed gradient of the whole table."""
+    out = str(tmp_path / "z")
+    mp.spawn(_zero_worker, args=(2, _free_port(), n_rows, out), nprocs=2, join=True)
+    got = [torch.load(f"{out}.{r}") for r in range(2)]
+    g = torch.Generator().manual_seed(8)
+    table = torch.randn(n_rows, 8, generator=g)
+    p = torch.nn.Parameter(table.clone())
+    opt = torch.optim.AdamW([p], lr=1e-2, weight_decay=1e-2)
+    for step in range(3):
+        p.grad = sum(torch.randn(n_rows, 8, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(2))
+        opt.step()
+    assert torch.allclose(torch.cat([x["rows"] for x in got], 0), p.detach(), atol=1e-6)
+    assert torch.equal(got[0]["full16"], got[1]["full16"]) and torch.equal(got[0]["full16"], p.detach().bfloat16().float())
