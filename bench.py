@@ -257,6 +257,18 @@ def cpu_baseline(cfg, feats, batch, budget_s, seed):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
+    # SURVEY.md par. 8(d) also asks for the two ends of the thread range: one thread, and every usable core
+    ends = {}
+    # (capped at 64 threads: with all 256 hardware threads of the GPU box's two EPYC 9575F this many-small-ops step was measured at
+    # 38 s -- 280x slower than at 16 threads --, which would turn the baseline leg into minutes for a data point nobody can use)
+    for name, n_thr in (("one_thread", 1), ("all_cores", min(avail, 64))):
+        torch.set_num_threads(n_thr)
+        step()                                  # warm-up at this thread count
+        t0 = time.perf_counter()
+        step()
+        dt = time.perf_counter() - t0
+        ends[name] = {"value": batch / dt, "unit": "triples/s", "cores": n_thr, "usable_threads": avail, "ms_per_step": dt * 1e3}
+    torch.set_num_threads(best_thr)
     model = "unknown CPU"
     try:
         with open("/proc/cpuinfo") as f:
@@ -266,7 +278,7 @@ def cpu_baseline(cfg, feats, batch, budget_s, seed):
                     break
     except OSError:
         pass
-    return {"value": batch / med, "unit": "triples/s", "cores": best_thr, "kind": "port", "cpu": model,
+    return {"value": batch / med, "unit": "triples/s", "cores": best_thr, "kind": "port", "cpu": model, **ends,
             "sample": f"{len(times)} steps of the same workload (N={N}, B={batch}, K={cfg.neg_num}, fwd+bwd+clip+AdamW) at {best_thr} of "
                       f"{avail} usable threads, median {med * 1e3:.0f} ms/step, torch {torch.__version__} CPU"}
 

@@ -78,15 +78,6 @@ static snag_gemm_desc gemm_desc(int M, int N, int K, const float* A, int64_t lda
     return d;
 }
 
-// stage[0:D] -> a, stage[D:2D] -> b, stage[2D:3D] -> c  (=|+=)
-static __global__ __launch_bounds__(256) void scatter3_kernel(const float* __restrict__ stage, int D, float* __restrict__ a, float* __restrict__ b,
-                                                              float* __restrict__ c, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 3 * D) return;
-    float* dst = i < D ? a + i : (i < 2 * D ? b + (i - D) : c + (i - 2 * D));
-    *dst = accumulate ? *dst + stage[i] : stage[i];
-}
-
 static constexpr int kRedBlocks = 1024;  // fixed partial-sum fan-in for LayerNorm / bias / weight_raw gradients
 
 static int check_fusion(const snag_fusion_desc* f) {
@@ -264,10 +255,8 @@ static int ln_bwd(const float* dy, const float* t, const float* stats, const flo
     const int blocks = (int)std::min<int64_t>(kRedBlocks, (R + 3) / 4);
     SNAG_NU(ln_bwd_kernel, D, dim3(blocks), st, dy, t, stats, g, R, D, keep, keep_ld > 0 ? keep_ld : (int64_t)D, kscale, dt, dtm, part,
             zero_dy ? const_cast<float*>(dy) : (float*)nullptr);
-    // part is [blocks][3][D]: one launch reduces the three rows as 3*D "columns" of stride 3*D into a staging row
-    float* stage = part + (int64_t)blocks * 3 * D;
-    hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(3 * D, 64)), dim3(1024), 0, st, (const float*)part, blocks, (int64_t)3 * D, 3 * D, stage, 0);
-    hipLaunchKernelGGL(scatter3_kernel, dim3(ceil_div(3 * D, 256)), dim3(256), 0, st, (const float*)stage, D, dgamma, dbeta, dbias, accumulate);
+    // part is [blocks][3][D]: one launch reduces the three rows as 3*D "columns" of stride 3*D, each into its own destination
+    hipLaunchKernelGGL(slab_colsum3_kernel, dim3(ceil_div(3 * D, 64)), dim3(1024), 0, st, (const float*)part, blocks, D, dgamma, dbeta, dbias, accumulate);
     return check_launch("fusion LayerNorm backward");
 }
 

@@ -577,6 +577,40 @@ static __global__ __launch_bounds__(1024) void slab_colsum_kernel(const float* _
     }
 }
 
+// The same reduction for LayerNorm's [blocks][3][D] partials, written straight to their three destinations (dgamma, dbeta and the
+// bias gradient of the dense layer in front of the LayerNorm): column c of the 3D-wide slab goes to a[c], b[c - D] or c_[c - 2D].
+static __global__ __launch_bounds__(1024) void slab_colsum3_kernel(const float* __restrict__ part, int nblocks, int D, float* __restrict__ a,
+                                                                    float* __restrict__ b, float* __restrict__ c_, int accumulate) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wave = wave_id_uniform();
+    const int c = blockIdx.x * 64 + lane;
+    const int ncol = 3 * D;
+    const int64_t stride = ncol;
+    const int per = (nblocks + 15) / 16;
+    const int b0 = wave * per, b1 = min(nblocks, b0 + per);
+    float s = 0.f;
+    if (c < ncol) {
+        int blk = b0;
+        for (; blk + 8 <= b1; blk += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = part[(int64_t)(blk + u) * stride + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; blk < b1; ++blk) s += part[(int64_t)blk * stride + c];
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < ncol) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w][lane];
+        float* dst = c < D ? a + c : (c < 2 * D ? b + (c - D) : c_ + (c - 2 * D));
+        *dst = accumulate ? *dst + t : t;
+    }
+}
+
 // column sums of a [R, C] matrix (bias gradients): part[blockIdx.y][c]
 static __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, int64_t R, int C, int64_t ld,
                                                           float* __restrict__ part) {

@@ -144,15 +144,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float wd, float bc1, float bc2, float gscale,
                                                     const uint64_t* __restrict__ tick, const int64_t* __restrict__ seg_end,
                                                     const float* __restrict__ seg_wd, const float* __restrict__ seg_lr, int n_seg,
-                                                    const float* __restrict__ gscale_dev, int tick_advanced) {
+                                                    const float* __restrict__ gscale_dev, int tick_advanced, int vec) {
     if (gscale_dev != nullptr) gscale *= gscale_dev[0];      // e.g. the clip coefficient of snag_clip_grad_norm
     if (tick != nullptr) {          // step number lives on the device (graph replay): t = tick + 1 (tick itself when already advanced)
         const float t = (float)(tick[0] + (tick_advanced ? 0 : 1));
         bc1 = 1.0f - powf(b1, t);
         bc2 = 1.0f - powf(b2, t);
     }
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float lr_i = lr, wd_i = wd;
+    // four consecutive elements per lane (one dwordx4 per operand); a segment boundary inside a quad is honoured per element
+    auto group_of = [&](int64_t i, float& lr_i, float& wd_i) {
+        lr_i = lr; wd_i = wd;
         if (n_seg > 0) {                    // parameter groups: segment s covers [seg_end[s-1], seg_end[s])
             int lo = 0, hi = n_seg - 1;
             while (lo < hi) {
@@ -163,14 +164,43 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             lr_i = lr * seg_lr[lo];
             wd_i = seg_wd[lo];
         }
-        const float gi = g[i] * gscale;
-        float pi = p[i] * (1.0f - lr_i * wd_i);
-        const float mi = b1 * m[i] + (1.0f - b1) * gi;
-        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
+    };
+    auto update = [&](float& pi, float gi, float& mi, float& vi, float lr_i, float wd_i) {
+        gi *= gscale;
+        const float pd = pi * (1.0f - lr_i * wd_i);
+        mi = b1 * mi + (1.0f - b1) * gi;
+        vi = b2 * vi + (1.0f - b2) * gi * gi;
         const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-        p[i] = pi - (lr_i / bc1) * (mi / denom);
+        pi = pd - (lr_i / bc1) * (mi / denom);
+    };
+    const int64_t n4 = vec ? n / 4 : 0;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+        const float4 g4 = reinterpret_cast<const float4*>(g)[q];
+        float4 p4 = reinterpret_cast<const float4*>(p)[q], m4 = reinterpret_cast<const float4*>(m)[q], v4 = reinterpret_cast<const float4*>(v)[q];
+        float lr0, wd0, lr3, wd3;
+        group_of(4 * q, lr0, wd0);
+        group_of(4 * q + 3, lr3, wd3);
+        float* pp = &p4.x; float* mm = &m4.x; float* vv = &v4.x; const float* gg = &g4.x;
+        if (lr0 == lr3 && wd0 == wd3) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) update(pp[e], gg[e], mm[e], vv[e], lr0, wd0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float lr_e, wd_e;
+                group_of(4 * q + e, lr_e, wd_e);
+                update(pp[e], gg[e], mm[e], vv[e], lr_e, wd_e);
+            }
+        }
+        reinterpret_cast<float4*>(p)[q] = p4;
+        reinterpret_cast<float4*>(m)[q] = m4;
+        reinterpret_cast<float4*>(v)[q] = v4;
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float lr_i, wd_i, pi = p[i], mi = m[i], vi = v[i];
+        group_of(i, lr_i, wd_i);
+        update(pi, g[i], mi, vi, lr_i, wd_i);
+        p[i] = pi; m[i] = mi; v[i] = vi;
     }
 }
 
@@ -365,14 +395,20 @@ extern "C" SNAG_API int snag_clip_grad_norm(const float* grad, int64_t n, float 
     return check_launch("snag_clip_grad_norm");
 }
 
+// dwordx4 path: all four buffers 16-byte aligned
+static int adamw_vec_ok(const void* a, const void* b, const void* c, const void* d) {
+    return ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0) ? 1 : 0;
+}
+
 extern "C" SNAG_API int snag_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                                         float beta2, float eps, float weight_decay, int64_t step, const uint64_t* tick, float grad_scale, void* stream) {
     SNAG_REQUIRE(n >= 0 && (step >= 1 || tick != nullptr), SNAG_ERR_ARG, "adamw_step: n=%ld step=%ld", (long)n, (long)step);
     if (n == 0) return SNAG_OK;
     SNAG_REQUIRE(param && grad && exp_avg && exp_avg_sq, SNAG_ERR_ARG, "adamw_step: null pointer");
     const float bc1 = 1.0f - powf(beta1, (float)std::max<int64_t>(step, 1)), bc2 = 1.0f - powf(beta2, (float)std::max<int64_t>(step, 1));
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
-                       eps, weight_decay, bc1, bc2, grad_scale, tick, (const int64_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+                       eps, weight_decay, bc1, bc2, grad_scale, tick, (const int64_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0,
+                       adamw_vec_ok(param, grad, exp_avg, exp_avg_sq));
     return check_launch("snag_adamw_step");
 }
 
@@ -385,8 +421,9 @@ extern "C" SNAG_API int snag_adamw_step_groups(float* param, const float* grad, 
     if (n == 0) return SNAG_OK;
     SNAG_REQUIRE(param && grad && exp_avg && exp_avg_sq, SNAG_ERR_ARG, "adamw_step_groups: null pointer");
     const float bc1 = 1.0f - powf(beta1, (float)std::max<int64_t>(step, 1)), bc2 = 1.0f - powf(beta2, (float)std::max<int64_t>(step, 1));
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
-                       eps, 0.0f, bc1, bc2, grad_scale, tick, seg_end, seg_weight_decay, seg_lr_scale, n_seg, grad_scale_dev, tick_advanced);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+                       eps, 0.0f, bc1, bc2, grad_scale, tick, seg_end, seg_weight_decay, seg_lr_scale, n_seg, grad_scale_dev, tick_advanced,
+                       adamw_vec_ok(param, grad, exp_avg, exp_avg_sq));
     return check_launch("snag_adamw_step_groups");
 }
 
