@@ -216,7 +216,8 @@ SNAG_API int snag_gram_f32(const float* Z, int64_t ldz, int n, int k, float alph
  *
  * Outputs: hidden [N,M,D]; joint, joint_fz [N, M*D]; weight_norm [N,M]  (any of the last three may
  * be NULL to skip them).  `save` receives the activations the backward needs; `work` is scratch.
- * Sizes: snag_fusion_save_floats / snag_fusion_work_floats.  M <= 6, D <= 512, D % H == 0.
+ * Sizes: snag_fusion_save_floats / snag_fusion_work_floats.  M <= 6, D <= 512, D % H == 0, H*M*M <= 192 (the reference's default
+ * 5 heads with all 6 modalities is 180).
  */
 typedef struct snag_fusion_layer {
     const float *wqkv, *bqkv;

@@ -86,8 +86,10 @@ static int check_fusion(const snag_fusion_desc* f) {
                  "fusion: bad sizes N=%d M=%d D=%d H=%d L=%d", f->N, f->M, f->D, f->H, f->L);
     SNAG_REQUIRE(f->M <= 6, SNAG_ERR_UNSUPPORTED, "fusion: M=%d modalities > 6", f->M);
     SNAG_REQUIRE(f->D <= 512, SNAG_ERR_UNSUPPORTED, "fusion: hidden_size=%d > 512", f->D);
+    // the attention kernels keep an entity's H*M*M entries in three registers per lane (192: covers the reference's default
+    // num_attention_heads = 5, config.py:108, with all six modalities = 180)
+    SNAG_REQUIRE(f->H * f->M * f->M <= kMaxAttnEntries, SNAG_ERR_UNSUPPORTED, "fusion: H*M*M=%d attention entries per entity > %d", f->H * f->M * f->M, kMaxAttnEntries);
     // same condition as the reference's assert at model/SNAG_tools.py:161
-    SNAG_REQUIRE(f->H * f->M * f->M <= 128, SNAG_ERR_UNSUPPORTED, "fusion: H*M*M=%d attention entries per entity > 128", f->H * f->M * f->M);
     SNAG_REQUIRE(f->D % f->H == 0, SNAG_ERR_ARG, "fusion: hidden_size %d not divisible by num_attention_heads %d", f->D, f->H);
     SNAG_REQUIRE(!f->use_intermediate || f->I >= 1, SNAG_ERR_ARG, "fusion: use_intermediate needs intermediate_size >= 1");
     SNAG_REQUIRE(f->drop_p >= 0.f && f->drop_p < 1.f, SNAG_ERR_ARG, "fusion: drop_p=%g outside [0,1)", f->drop_p);

@@ -31,6 +31,35 @@ __device__ __forceinline__ void st_cols(float* __restrict__ p, const Cols<NU>& r
     }
 }
 
+// The H*M*M per-entity attention entries (keep flags, extra probability gradients) live in up to three registers per lane:
+// entry e sits in lane e % 64 of register e / 64 (192 entries: the reference's default 5 heads with all 6 modalities is 180).
+constexpr int kMaxAttnEntries = 192;
+struct Entries3 {
+    int a, b, c;
+};
+__device__ __forceinline__ Entries3 load_keep3(const uint8_t* __restrict__ keep, int64_t base, int HMM, int lane) {
+    Entries3 r{1, 1, 1};
+    if (keep != nullptr) {
+        r.a = lane < HMM ? (int)keep[base + lane] : 1;
+        r.b = lane + 64 < HMM ? (int)keep[base + 64 + lane] : 1;
+        r.c = lane + 128 < HMM ? (int)keep[base + 128 + lane] : 1;
+    }
+    return r;
+}
+__device__ __forceinline__ Entries3 load_f32x3(const float* __restrict__ x, int64_t base, int HMM, int lane) {
+    Entries3 r{0, 0, 0};
+    if (x != nullptr) {
+        r.a = lane < HMM ? __float_as_int(x[base + lane]) : 0;
+        r.b = lane + 64 < HMM ? __float_as_int(x[base + 64 + lane]) : 0;
+        r.c = lane + 128 < HMM ? __float_as_int(x[base + 128 + lane]) : 0;
+    }
+    return r;
+}
+// e is wave-uniform
+__device__ __forceinline__ int entry_at(const Entries3& r, int e) {
+    return e < 64 ? __builtin_amdgcn_readlane(r.a, e) : (e < 128 ? __builtin_amdgcn_readlane(r.b, e - 64) : __builtin_amdgcn_readlane(r.c, e - 128));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Self-attention over the M modality tokens of one entity.
 // reference: BertSelfAttention.forward, model/SNAG_tools.py:178-209
@@ -79,11 +108,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     // the entity's H*M*M keep flags in one coalesced read (lanes 0..63, 64..127), handed out by v_readlane below:
     // a per-(i,j) global load inside the head loop would be a dependent memory round trip each
     const int HMM = H * M * M;
-    int kb0 = 1, kb1 = 1;
-    if (keep != nullptr) {
-        kb0 = lane < HMM ? (int)keep[n * HMM + lane] : 1;
-        kb1 = lane + 64 < HMM ? (int)keep[n * HMM + 64 + lane] : 1;
-    }
+    const Entries3 kb = load_keep3(keep, n * HMM, HMM, lane);
 #pragma unroll
     for (int i = 0; i < M; ++i) {
         const float* row = qkv + (n * M + i) * (int64_t)(3 * D);
@@ -104,7 +129,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
                     const int e = h * M * M + i * M + j;
-                    const int kf = e < 64 ? __builtin_amdgcn_readlane(kb0, e) : __builtin_amdgcn_readlane(kb1, e - 64);
+                    const int kf = entry_at(kb, e);
                     p[i][j] = kf ? p[i][j] * kscale : 0.f;
                 }
         }
@@ -150,16 +175,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
     Cols<NU> q[M], k[M], v[M], go[M], dq[M], dk[M], dv[M];
     const int HMM = H * M * M;
-    int kb0 = 1, kb1 = 1;
-    float ex0 = 0.f, ex1 = 0.f;
-    if (keep != nullptr) {
-        kb0 = lane < HMM ? (int)keep[n * HMM + lane] : 1;
-        kb1 = lane + 64 < HMM ? (int)keep[n * HMM + 64 + lane] : 1;
-    }
-    if (dprobs_extra != nullptr) {
-        ex0 = lane < HMM ? dprobs_extra[n * HMM + lane] : 0.f;
-        ex1 = lane + 64 < HMM ? dprobs_extra[n * HMM + 64 + lane] : 0.f;
-    }
+    const Entries3 kb = load_keep3(keep, n * HMM, HMM, lane);
+    const Entries3 ex = load_f32x3(dprobs_extra, n * HMM, HMM, lane);
 #pragma unroll
     for (int i = 0; i < M; ++i) {
         const float* row = qkv + (n * M + i) * (int64_t)(3 * D);
@@ -189,8 +206,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 float g = sum64(part);                                   // d loss / d P~[i][j] through ctx
                 const int e = h * M * M + i * M + j;
                 if (dprobs_extra != nullptr)
-                    g += __int_as_float(e < 64 ? __builtin_amdgcn_readlane(__float_as_int(ex0), e) : __builtin_amdgcn_readlane(__float_as_int(ex1), e - 64));
-                const int kf = e < 64 ? __builtin_amdgcn_readlane(kb0, e) : __builtin_amdgcn_readlane(kb1, e - 64);
+                    g += __int_as_float(entry_at(ex, e));
+                const int kf = entry_at(kb, e);
                 const float km = (keep == nullptr) ? 1.f : (kf ? kscale : 0.f);
                 // dV_j += P~[i][j] * dctx_i
                 const float pt = p[i][j] * km;
@@ -292,11 +309,7 @@ __global__ __launch_bounds__(256) void attn_ro_fwd_kernel(const float* __restric
     const int lane = threadIdx.x & 63;
     const int d = D / H;
     const int HMM = H * M * M;
-    int kb0 = 1, kb1 = 1;
-    if (keep != nullptr) {
-        kb0 = lane < HMM ? (int)keep[n * HMM + lane] : 1;
-        kb1 = lane + 64 < HMM ? (int)keep[n * HMM + 64 + lane] : 1;
-    }
+    const Entries3 kb = load_keep3(keep, n * HMM, HMM, lane);
     Cols<NU> k[M], v[M], o;
     const Cols<NU> q = ld_cols<NU>(qkv + (n * M + g) * (int64_t)(3 * D), D, lane);
 #pragma unroll
@@ -315,7 +328,7 @@ __global__ __launch_bounds__(256) void attn_ro_fwd_kernel(const float* __restric
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 const int e = h * M * M + g * M + j;
-                const int kf = e < 64 ? __builtin_amdgcn_readlane(kb0, e) : __builtin_amdgcn_readlane(kb1, e - 64);
+                const int kf = entry_at(kb, e);
                 p[j] = kf ? p[j] * kscale : 0.f;
             }
         }
@@ -351,11 +364,7 @@ __global__ __launch_bounds__(256) void attn_ro_bwd_kernel(const float* __restric
     for (int u = 0; u < NU; ++u) sq.v[u] = sk.v[u] = sv.v[u] = 0.f;
     for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
         const int HMM = H * M * M;
-        int kb0 = 1, kb1 = 1;
-        if (keep != nullptr) {
-            kb0 = lane < HMM ? (int)keep[n * HMM + lane] : 1;
-            kb1 = lane + 64 < HMM ? (int)keep[n * HMM + 64 + lane] : 1;
-        }
+        const Entries3 kb = load_keep3(keep, n * HMM, HMM, lane);
         Cols<NU> k[M], v[M], dk[M], dv[M], dq;
         const Cols<NU> q = ld_cols<NU>(qkv + (n * M + g) * (int64_t)(3 * D), D, lane);
         const Cols<NU> go = ld_cols<NU>(dctx_g + n * (int64_t)D, D, lane);
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(256) void attn_ro_bwd_kernel(const float* __restric
                 }
                 const float gg = sum64(part);
                 const int e = h * M * M + g * M + j;
-                const int kf = e < 64 ? __builtin_amdgcn_readlane(kb0, e) : __builtin_amdgcn_readlane(kb1, e - 64);
+                const int kf = entry_at(kb, e);
                 const float km = (keep == nullptr) ? 1.f : (kf ? kscale : 0.f);
                 const float pt = p[j] * km;
 #pragma unroll

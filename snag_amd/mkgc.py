@@ -45,6 +45,8 @@ class MKGCConfig:
     noise_ratio: float = 0.2
     mask_ratio: float = 0.7
     dropout: float = 0.1                # nn.Dropout(0.1) inside the Bert blocks (SNAG_tools.py:169,216)
+    proj_dropout: float = 0.0           # num_proj=2: ProjectionHead's F.dropout between ReLU and l2 (model/layers.py:142-147); its rate is a
+                                        # constructor argument there and the MKGC README names none, hence off by default
     lr: float = 1e-4                    # LR
     weight_decay: float = 1e-4
     readout_only: bool = True           # Mformer_hd_graph consumes hidden[:, g, :] alone: the last layer computes the query / attention row /
@@ -97,8 +99,15 @@ class MKGCHotPath:
         if self.shard.n_rows != N:
             raise ValueError(f"shard covers {self.shard.n_rows} rows, the entity table has {N}")
         Nl, Ns, lo = self.shard.n_loc, self.shard.n_shard, self.shard.lo
-        if cfg.joint_way not in ("Mformer_hd_graph", "Mformer_hd_mean"):
-            raise ValueError("the scoring step reads an [N, dim] read-out: joint_way must be Mformer_hd_graph or Mformer_hd_mean")
+        # README.md:51 joint_way: the two hidden-state read-outs ([N, dim]) and the two weighted concatenations of the normalised INPUT
+        # tokens ([N, M*dim]: Mformer_weight = attention-derived weights, learnable_weight = softmax(weight_raw); a1's joint / joint_fz).
+        # "atten_weight" (non-transformer attention; only dead code in the tree, EVA_tools.py:190-232) is not built.
+        if cfg.joint_way not in ("Mformer_hd_graph", "Mformer_hd_mean", "Mformer_weight", "learnable_weight"):
+            raise ValueError("joint_way must be Mformer_hd_graph, Mformer_hd_mean, Mformer_weight or learnable_weight (atten_weight is not built)")
+        self.concat = cfg.joint_way in ("Mformer_weight", "learnable_weight")
+        self.sdim = M * D if self.concat else D               # width of the read-out the scorer gathers (and of the relation rows)
+        if self.sdim > 512:
+            raise ValueError(f"read-out width {self.sdim} > 512: the scorer's row registers stop there")
         if len(feats) != len(cfg.feat_dims):
             raise ValueError("one feature table per entry of feat_dims")
         self.feats = []
@@ -144,7 +153,7 @@ class MKGCHotPath:
             off = _align(off + n)
 
         add("ent", N, D)
-        add("rel", R, D)
+        add("rel", R, self.sdim)
         for i, fd in enumerate(cfg.feat_dims):
             if cfg.num_proj == 1:
                 add(f"proj{i}.weight", fd, D)      # stored TRANSPOSED ([in, out]): see _first_proj
@@ -181,8 +190,8 @@ class MKGCHotPath:
         self._seg_wd = torch.tensor([w for _, _, w in self.param_groups], device=self.dev, dtype=f32)
         self._seg_lr = torch.ones(len(self.param_groups), device=self.dev, dtype=f32)
         if cfg.deterministic:
-            self._acc_ent = torch.zeros(N, D, device=self.dev, dtype=torch.int64)
-            self._acc_rel = torch.zeros(R, D, device=self.dev, dtype=torch.int64)
+            self._acc_ent = torch.zeros(N, self.sdim, device=self.dev, dtype=torch.int64)
+            self._acc_rel = torch.zeros(R, self.sdim, device=self.dev, dtype=torch.int64)
         self._clip = torch.ones(2, device=self.dev, dtype=f32)          # [clip coefficient, gradient norm] of the last step
         self._clip_work = torch.empty(1024, device=self.dev, dtype=f32)
 
@@ -192,11 +201,13 @@ class MKGCHotPath:
         self.x0 = torch.empty(Nl, M, D, device=dev)
         # read-out-only last layer: hidden IS the [rows, D] read-out, and its gradient the compact scatter target of the scorer
         self.ro = bool(cfg.readout_only) and cfg.joint_way == "Mformer_hd_graph"
-        if self.shard.sharded and not (self.ro or cfg.joint_way == "Mformer_hd_mean"):
+        if self.shard.sharded and not (self.ro or self.concat or cfg.joint_way == "Mformer_hd_mean"):
             raise ValueError("row-sharded fusion exchanges a compact [rows, dim] read-out: use readout_only=True with Mformer_hd_graph")
         # compact read-outs hold Ns = shard.n_shard rows (the collectives move equal chunks; rows past Nl stay zero)
         self.hidden = torch.zeros((Ns, D) if self.ro else (Nl, M, D), device=dev)
-        self.d_hidden = None if self.ro else torch.empty(Nl, M, D, device=dev)
+        self.d_hidden = None if (self.ro or self.concat) else torch.empty(Nl, M, D, device=dev)
+        # concatenation read-outs: joint (or joint_fz) [rows, M*D] straight from the fusion epilogue, its gradient the scatter target
+        self.joint = torch.zeros(Ns, M * D, device=dev) if self.concat else None
         self.d_x0 = torch.empty(Nl, M, D, device=dev)
         self.mid = [torch.empty(Nl, D, device=dev) for _ in cfg.feat_dims] if cfg.num_proj == 2 else []
         self.d_mid = torch.empty(Nl, D, device=dev) if cfg.num_proj == 2 else None
@@ -204,11 +215,11 @@ class MKGCHotPath:
         # compact [rows, D] gradient of the read-out (hd_mean, read-out-only hd_graph): zeroed once here; afterwards whoever READS it
         # in the backward clears it behind itself (snag_fusion_bwd zero_d_hidden / snag_token_mean_bwd zero_src), so the fused
         # scorer of the next step finds it clean without a fill launch
-        self.d_repr = torch.zeros(Ns, D, device=dev) if (self.ro or cfg.joint_way == "Mformer_hd_mean") else None
+        self.d_repr = torch.zeros(Ns, self.sdim, device=dev) if (self.ro or self.concat or cfg.joint_way == "Mformer_hd_mean") else None
         self._d_repr_clean = True
         # row-sharded: the table the scorer reads is the all-gather of every rank's read-outs, its gradient is reduce-scattered back
-        self.repr_full = torch.zeros(self.shard.n_pad, D, device=dev) if self.shard.sharded else None
-        self.d_repr_full = torch.zeros(self.shard.n_pad, D, device=dev) if self.shard.sharded else None
+        self.repr_full = torch.zeros(self.shard.n_pad, self.sdim, device=dev) if self.shard.sharded else None
+        self.d_repr_full = torch.zeros(self.shard.n_pad, self.sdim, device=dev) if self.shard.sharded else None
         lib = self.lib
         self.save = torch.empty(lib.snag_fusion_save_floats(Nl, M, D, cfg.num_heads, I, L, int(ffn)), device=dev)
         ws = lib.snag_fusion_work_floats(Nl, M, D, cfg.num_heads, I, L, int(ffn))
@@ -225,6 +236,9 @@ class MKGCHotPath:
         self.keep_attn = [self.keep_all[l * per_layer + n_probs:l * per_layer + n_probs + Nl * M * D].view(Nl * M, D) for l in range(L)]
         self.keep_ffn = ([self.keep_all[l * per_layer + n_probs + n_tok:l * per_layer + n_probs + n_tok + Nl * M * D].view(Nl * M, D) for l in range(L)]
                          if ffn else None)
+        # ProjectionHead dropout masks (num_proj=2, proj_dropout > 0): one [rows, D] keep mask per modality, drawn per step
+        self.keep_proj = (torch.ones(len(cfg.feat_dims), max(Nl, 1), D, device=dev, dtype=torch.uint8)
+                          if (cfg.num_proj == 2 and cfg.proj_dropout > 0) else None)
         self.tick = torch.zeros(1, device=dev, dtype=torch.int64)      # device-side step counter
         # noise state (model/SNAG.py:86-98)
         self.noisy = [f.clone() for f in self.feats]
@@ -257,7 +271,7 @@ class MKGCHotPath:
             return (torch.rand(n, generator=g) * 2 - 1) / math.sqrt(fan_in)
 
         self.p["ent"].copy_(torch.randn(N, D, generator=g) / math.sqrt(N))
-        self.p["rel"].copy_(torch.randn(cfg.n_rel, D, generator=g) * math.sqrt(2.0 / (cfg.n_rel + D)))   # xavier normal
+        self.p["rel"].copy_(torch.randn(cfg.n_rel, self.sdim, generator=g) * math.sqrt(2.0 / (cfg.n_rel + self.sdim)))   # xavier normal
         for i, fd in enumerate(cfg.feat_dims):
             if cfg.num_proj == 1:
                 self.p[f"proj{i}.weight"].copy_(lin((D, fd)).t())
@@ -297,18 +311,26 @@ class MKGCHotPath:
         d.weight_raw = ptr(self.p["weight_raw"])
         d.x0 = ptr(self.x0)
         d.hidden = ptr(self.hidden)          # joint / joint_fz / weight_norm are not needed by the hd_* read-outs
+        if cfg.joint_way == "Mformer_weight":
+            d.joint = ptr(self.joint)
+        elif cfg.joint_way == "learnable_weight":
+            d.joint_fz = ptr(self.joint)
         d.readout_slot_p1 = self.g_slot + 1 if self.ro else 0
         d.save, d.save_floats = ptr(self.save), self.save.numel()
         d.work, d.work_floats = ptr(self.work), self.work.numel()
         self._fdesc = d
         b = _lib.FusionBwdDesc()
-        b.d_hidden = ptr(self.d_repr) if self.ro else ptr(self.d_hidden)
+        b.d_hidden = ptr(self.d_repr) if self.ro else ptr(self.d_hidden)      # None for the concatenation read-outs
         b.zero_d_hidden = 1 if self.ro else 0
+        if cfg.joint_way == "Mformer_weight":
+            b.d_joint = ptr(self.d_repr)
+        elif cfg.joint_way == "learnable_weight":
+            b.d_joint_fz = ptr(self.d_repr)
         b.d_x0 = ptr(self.d_x0)
         b.grads = ctypes.cast(self._grads, ctypes.POINTER(_lib.FusionLayerGrad))
         # the hd_* read-outs never touch joint_fz, so weight_raw has no gradient: its slice of the (zero-initialised) flat gradient
         # buffer simply stays zero -- passing no pointer saves the library a 24-byte memset launch per step
-        b.d_weight_raw = None
+        b.d_weight_raw = ptr(self.g["weight_raw"]) if cfg.joint_way == "learnable_weight" else None
         b.accumulate = 0
         self._bdesc = b
         self._set_dropout(self.training)
@@ -330,7 +352,7 @@ class MKGCHotPath:
 
     # ------------------------------------------------------------------------------------------
     def _gemm(self, M, N, K, A, lda, akc, B, ldb, bkc, C, ldc, *, bias=None, act=0, pre=None, add1=None, ld1=0,
-              aux=None, ldaux=0, splitk=True):
+              aux=None, ldaux=0, splitk=True, keep=None, keep_scale=1.0):
         d = _lib.GemmDesc()
         d.M, d.N, d.K = M, N, K
         d.a_kcontig, d.b_kcontig = int(akc), int(bkc)
@@ -338,9 +360,17 @@ class MKGCHotPath:
         d.bias, d.alpha, d.act, d.pre_act = bias, 1.0, act, pre
         d.add1, d.ld1 = add1, ld1
         d.aux, d.ldaux = aux, ldaux
+        if keep is not None:
+            d.keep_mask, d.keep_scale = keep, keep_scale
         if splitk:
             d.workspace, d.workspace_floats = ptr(self.work), self.work.numel()
         call("snag_gemm_f32", ctypes.byref(d), self._st)
+
+    def _proj_keep(self, i):
+        """Device pointer of modality i's ProjectionHead keep mask (None in eval mode / with proj_dropout = 0)."""
+        if self.keep_proj is None or not self.training:
+            return None
+        return self.keep_proj[i].data_ptr()
 
     def _probed(self, tag, fn, *a, **k):
         tm = self.probe.get(tag) if self.probe else None
@@ -378,12 +408,12 @@ class MKGCHotPath:
         self.g["rel"].zero_()
         if self.shard.sharded:               # the scorer scatters over ALL entity rows; the owners get their sums by reduce-scatter
             self.d_repr_full.zero_()
-            return self.d_repr_full.data_ptr(), cfg.dim
+            return self.d_repr_full.data_ptr(), self.sdim
         if self.d_repr is not None:
-            if not self._d_repr_clean:       # only after a forward(with_backward=True) that no backward() followed
+            if self.concat or not self._d_repr_clean:       # (hd_*: only after a forward(with_backward=True) that no backward() followed)
                 self.d_repr.zero_()
             self._d_repr_clean = False
-            return self.d_repr.data_ptr(), cfg.dim
+            return self.d_repr.data_ptr(), self.sdim
         self.d_hidden.zero_()
         return self.d_hidden.data_ptr() + 4 * self.g_slot * cfg.dim, cfg.n_tokens * cfg.dim
 
@@ -397,6 +427,8 @@ class MKGCHotPath:
         Nl, lo = self.shard.n_loc, self.shard.lo               # this rank's entity rows (all of them with one rank)
         st = self._st = stream()
         noisy = self.training and cfg.add_noise and self.noise_active
+        if self.keep_proj is not None and self.training:
+            call("snag_dropout_keep_mask", cfg.seed + 3 + 7919 * self.shard.rank, ptr(self.tick), self.keep_proj.numel(), cfg.proj_dropout, ptr(self.keep_proj), st)
         MD = M * D
         x0p = self.x0.data_ptr()
         for i, fd in enumerate(cfg.feat_dims):
@@ -406,8 +438,10 @@ class MKGCHotPath:
             if cfg.num_proj == 1:
                 self._probed(tag, self._gemm, Nl, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.weight"]), D, 0, slot, MD,
                              bias=ptr(self.p[f"proj{i}.bias"]))
-            else:   # ProjectionHead: Linear(no bias) -> ReLU -> Linear(no bias)   (model/layers.py:135-148)
-                self._probed(tag, self._gemm, Nl, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.l1"]), D, 0, ptr(self.mid[i]), D, act=1)
+            else:   # ProjectionHead: Linear(no bias) -> ReLU -> dropout -> Linear(no bias)   (model/layers.py:135-148)
+                pk = self._proj_keep(i)
+                self._probed(tag, self._gemm, Nl, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.l1"]), D, 0, ptr(self.mid[i]), D, act=1,
+                             keep=pk, keep_scale=1.0 / (1.0 - cfg.proj_dropout))
                 self._gemm(Nl, D, D, ptr(self.mid[i]), D, 1, ptr(self.p[f"proj{i}.l2"]), D, 1, slot, MD)
         call("snag_entity_token_fwd", self.p["ent"].data_ptr() + 4 * lo * D, Nl, D, (self.ent_noise.data_ptr() + 4 * lo * D) if noisy else None,
              (self.ent_noise_mask.data_ptr() + lo) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD, st)
@@ -419,12 +453,15 @@ class MKGCHotPath:
             self._repr, self._repr_ld = self.repr_mean.data_ptr(), D
         elif self.ro:
             self._repr, self._repr_ld = self.hidden.data_ptr(), D
+        elif self.concat:
+            self._repr, self._repr_ld = self.joint.data_ptr(), MD
         else:
             self._repr, self._repr_ld = self.hidden.data_ptr() + 4 * self.g_slot * D, MD
+        D = self.sdim                                          # from here on: the width the scorer works at
         if self.shard.sharded:
             # every rank's compact read-outs -> the one [N, D] table all ranks score against (the only data-path collective of the
             # forward; stream-ordered: the compute stream waits for it, the host does not)
-            self.shard.all_gather(self.repr_full, self.repr_mean if cfg.joint_way == "Mformer_hd_mean" else self.hidden)
+            self.shard.all_gather(self.repr_full, self.repr_mean if cfg.joint_way == "Mformer_hd_mean" else (self.joint if self.concat else self.hidden))
             self._repr, self._repr_ld = self.repr_full.data_ptr(), D
         B, K = neg_t.shape
         if self._loss_part is None or self._loss_part.shape[0] != B:
@@ -495,12 +532,13 @@ class MKGCHotPath:
         elif cfg.deterministic:
             self._acc_ent.zero_()
             self._acc_rel.zero_()
-            call("snag_score_margin_bwd_fixed", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r), ptr(t), ptr(neg_t),
+            Ds = self.sdim
+            call("snag_score_margin_bwd_fixed", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, Ds, ptr(h), ptr(r), ptr(t), ptr(neg_t),
                  ib, B, K, float(cfg.margin), float(grad_scale), *up, ptr(self._acc_ent), ptr(self._acc_rel), st)
-            call("snag_fixed_to_float", ptr(self._acc_ent), N, D, d_repr, d_ld, 0, st)
-            call("snag_fixed_to_float", ptr(self._acc_rel), cfg.n_rel, D, ptr(self.g["rel"]), D, 0, st)
+            call("snag_fixed_to_float", ptr(self._acc_ent), N, Ds, d_repr, d_ld, 0, st)
+            call("snag_fixed_to_float", ptr(self._acc_rel), cfg.n_rel, Ds, ptr(self.g["rel"]), Ds, 0, st)
         else:
-            call("snag_score_margin_bwd", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D, ptr(h), ptr(r), ptr(t), ptr(neg_t),
+            call("snag_score_margin_bwd", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, self.sdim, ptr(h), ptr(r), ptr(t), ptr(neg_t),
                  ib, B, K, float(cfg.margin), float(grad_scale), *up, d_repr, d_ld, ptr(self.g["rel"]), st)
         if self.shard.sharded:
             # every rank scattered its triples' gradients over ALL entity rows: the owners get the sums of their rows
@@ -532,7 +570,8 @@ class MKGCHotPath:
             else:
                 self._gemm(D, D, Nl, dslot, MD, 0, ptr(self.mid[i]), D, 0, ptr(self.g[f"proj{i}.l2"]), D, splitk=True)
                 # d mid = (dTok l2) * [mid > 0]
-                self._gemm(Nl, D, D, dslot, MD, 1, ptr(self.p[f"proj{i}.l2"]), D, 0, ptr(self.d_mid), D, act=4, aux=ptr(self.mid[i]), ldaux=D)
+                self._gemm(Nl, D, D, dslot, MD, 1, ptr(self.p[f"proj{i}.l2"]), D, 0, ptr(self.d_mid), D, act=4, aux=ptr(self.mid[i]), ldaux=D,
+                           keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout))
                 self._gemm(fd, D, Nl, ptr(feat), fd, 0, ptr(self.d_mid), D, 0, ptr(self.g[f"proj{i}.l1"]), D, splitk=True)   # dl1^T [fd, D]
             if reducer is not None:
                 reducer.start(buckets[2 + i])
@@ -653,6 +692,8 @@ class MKGCHotPath:
             return self.repr_full[:self.cfg.n_ent]
         if self.cfg.joint_way == "Mformer_hd_mean":
             return self.repr_mean
+        if self.concat:
+            return self.joint
         return self.hidden if self.ro else self.hidden[:, self.g_slot, :]
 
     def link_prediction(self, h, r, t, filter_mask=None, top_k=(1, 10), method="exact", known_sorted=None):

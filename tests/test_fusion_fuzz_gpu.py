@@ -15,6 +15,17 @@ DEV = "cuda"
 
 @pytest.mark.parametrize("seed", range(10))
 def test_fusion_random_configs(seed):
+    _run(seed)
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_fusion_reference_default_heads_with_all_six_modalities(train):
+    """config.py:108 defaults num_attention_heads to 5; with --use_surface all six modalities are stacked: H*M*M = 180 attention
+    entries per entity (the kernels keep them in three registers per lane; up to 192)."""
+    _run(77, forced=dict(H=5, D=300, M=6, L=1, ffn=True, I=400, N=63, train=train))
+
+
+def _run(seed, forced=None):
     from snag_amd.fusion import MformerFusion
     rng = random.Random(seed)
     g = torch.Generator().manual_seed(1000 + seed)
@@ -26,6 +37,8 @@ def test_fusion_random_configs(seed):
     I = rng.choice([24, 50, 96])
     N = rng.choice([1, 5, 63, 257])
     train = rng.random() < 0.6
+    if forced:
+        H, D, M, L, ffn, I, N, train = (forced[k] for k in ("H", "D", "M", "L", "ffn", "I", "N", "train"))
     args = types.SimpleNamespace(hidden_size=D, num_attention_heads=H, num_hidden_layers=L, use_intermediate=int(ffn), intermediate_size=I)
     mod = MformerFusion(args, modal_num=M)
     with torch.no_grad():

@@ -49,6 +49,10 @@ def oracle_params(eng):
     (1, "Mformer_hd_mean", 0, False, torch.int64, (700, 23, 128, 96, 32, 200, 72)),
     (2, "Mformer_hd_graph", 1, True, torch.int32, (700, 23, 128, 96, 32, 200, 72)),
     (1, "Mformer_hd_mean", 0, True, torch.int32, (700, 23, 128, 96, 32, 200, 72)),
+    # the two concatenation read-outs of README.md:51 (a1's joint / joint_fz, [N, M*dim] = 384-wide rows; weight_raw is learnt through joint_fz)
+    (2, "Mformer_weight", 0, True, torch.int32, (700, 23, 128, 96, 32, 200, 72)),
+    (1, "learnable_weight", 0, False, torch.int64, (700, 23, 128, 96, 32, 200, 72)),
+    (2, "learnable_weight", 1, True, torch.int32, (400, 7, 64, 48, 8, 40, 24, 2)),
     # ragged everything: entity count, feature widths and hidden size that are not multiples of 4 / 64 (checked GEMM loaders, padded rows)
     (2, "Mformer_hd_graph", 0, True, torch.int32, (701, 5, 100, 33, 5, 37, 10)),
     (1, "Mformer_hd_mean", 1, False, torch.int64, (333, 3, 36, 17, 3, 13, 9)),
@@ -132,6 +136,41 @@ def test_readout_only_last_layer_equals_the_full_layer(ffn, layers, dropout):
     for k in a[4]:
         scale = max(1e-6, float(b[4][k].abs().max()))
         assert float((a[4][k] - b[4][k]).abs().max()) <= 2e-5 * scale, k
+
+
+def test_projection_head_dropout_in_the_engine():
+    """num_proj=2 is the in-tree ProjectionHead, which drops between ReLU and l2 (model/layers.py:142-147): with proj_dropout > 0 the
+    engine's step must equal the oracle's projection_head fed with the very masks the engine drew; eval mode ignores them."""
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    N, R, D, B, K = 500, 7, 128, 64, 16
+    cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[96, 40], num_proj=2, margin=6.0, neg_num=K, dropout=0.0, proj_dropout=0.25, add_noise=0, seed=2)
+    g = torch.Generator().manual_seed(4)
+    feats = [torch.rand(N, 96, generator=g), torch.randn(N, 40, generator=g)]
+    eng = MKGCHotPath(cfg, feats, device=DEV)
+    eng.p["ent"].copy_(torch.randn(N, D, generator=g).to(DEV))
+    idx = [torch.randint(0, hi, sz, generator=g) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (N, (B, K)))]
+    loss, pos, ng = eng.forward(*[i.to(DEV) for i in idx], want_scores=True, with_backward=True)
+    eng.backward()
+    torch.cuda.synchronize()
+    keep = eng.keep_proj.cpu().bool()
+    assert 0.70 < float(keep.float().mean()) < 0.80
+    p, proj, fp = oracle_params(eng)
+    toks = [O.projection_head(f, pr["l1"], pr["l2"], keep_mask=keep[i], p=0.25) for i, (f, pr) in enumerate(zip(feats, proj))]
+    toks.append(p["ent"])
+    _, _, hidden, _ = O.fusion_forward(toks, fp, cfg.num_heads, 1, False)
+    oloss, opos, oneg = O.score_margin(hidden[:, 2, :], p["rel"], *idx, cfg.margin)
+    oloss.backward()
+    assert_close(pos, opos, atol=1e-4)
+    assert_close(loss, oloss, atol=1e-3, rtol=2e-6)
+    grads = eng.named_gradients()
+    for k in ("proj0.l1", "proj0.l2", "proj1.l1", "proj1.l2", "ent"):
+        scale = max(1.0, float(p[k].grad.abs().max()))
+        assert_close(grads[k], p[k].grad, atol=2e-4 * scale, rtol=1e-4, what=k)
+    eng.eval()
+    l_eval = eng.forward(*[i.to(DEV) for i in idx])
+    toks = [O.projection_head(f, pr["l1"], pr["l2"]) for f, pr in zip(feats, proj)] + [p["ent"]]
+    _, _, hidden, _ = O.fusion_forward(toks, fp, cfg.num_heads, 1, False)
+    assert_close(l_eval, O.score_margin(hidden[:, 2, :], p["rel"], *idx, cfg.margin)[0].detach(), atol=1e-3, rtol=2e-6)
 
 
 def test_mkgc_train_step_reduces_loss_and_is_deterministic_in_eval():
