@@ -99,6 +99,24 @@ SNAG_API int snag_score_margin_fwd_bwd(const float* ent, int64_t ent_ld, int64_t
                           float* pos, float* neg, float* loss_part, float* loss, uint32_t* ticket,
                           float* d_ent, int64_t d_ent_ld, float* d_rel, void* stream);
 
+/* The training form WITHOUT floating-point atomics (deterministic, and past the ~1.3 TB/s memory-side atomic rate that bounds
+ * snag_score_margin_fwd_bwd): pass A, one wave per triple, writes scores / losses, the 2*batch rows q_b = h^ + r^ and dq_b, and one
+ * 8-byte (row, weight) entry per touched destination; pass B, one 16-lane group per entity / relation, sums its entries' rows in
+ * 64-bit fixed point (order-free: bit-reproducible), applies the backward of F.normalize once and WRITES the gradient row.
+ * Same outputs as snag_score_margin_fwd_bwd, except that d_ent / d_rel are OVERWRITTEN, not accumulated into: with
+ * write_untouched = 1 every row of d_ent [n_ent, dim] and d_rel is written (zeros where nothing arrived: no fill launch needed),
+ * with 0 only the rows of the batch's own heads, tails and negative tails are written (a large, otherwise clean buffer: config 5).
+ * |grad_scale * 2 * n_neg * (occurrences of one entity in the batch)| must stay below 2^29 (fixed point with 32 fractional bits).
+ * work: snag_score_seg_work_bytes(...) bytes, 256-byte aligned, zeroed ONCE by the caller (every launch leaves it ready for the
+ * next); dim % 4 == 0, 16-byte aligned rows; launches sharing a workspace must be stream-ordered. */
+SNAG_API int64_t snag_score_seg_work_bytes(int64_t n_ent, int64_t n_rel, int64_t batch, int n_neg, int dim);
+SNAG_API int snag_score_margin_fwd_bwd_seg(const float* ent, int64_t ent_ld, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+                          const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                          int64_t batch, int n_neg, float margin, float grad_scale,
+                          float* pos, float* neg, float* loss_part, float* loss, uint32_t* ticket,
+                          float* d_ent, int64_t d_ent_ld, float* d_rel, int write_untouched,
+                          void* work, int64_t work_bytes, void* stream);
+
 /* The same three training entries over bf16 TABLES (raw bfloat16 bit patterns; BASELINE config 5: |E| = 1M, dim 256, 128 negatives):
  * fp32 arithmetic, fp32 scores, fp32 gradient accumulation -- only the gathered rows are 2-byte.  d_ent / d_rel stay fp32. */
 SNAG_API int snag_score_margin_fwd_bwd_bf16(const uint16_t* ent, int64_t ent_ld, int64_t n_ent, const uint16_t* rel, int64_t n_rel, int dim,

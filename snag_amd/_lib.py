@@ -65,6 +65,7 @@ SIGNATURES = {
     "snag_score_margin_fwd_bf16": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _P, _P, _P, _P],
     "snag_score_margin_bwd": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _L, _P, _P],
     "snag_score_margin_fwd_bwd": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _L, _P, _P],
+    "snag_score_margin_fwd_bwd_seg": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _L, _P, _I, _P, _L, _P],
     "snag_score_margin_fwd_bwd_bf16": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "snag_score_margin_bwd_bf16": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _L, _P, _P],
     "snag_score_margin_bwd_fixed_bf16": [_P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P],
@@ -118,7 +119,7 @@ _SPECIAL = {"snag_version": ([], _I), "snag_last_error": ([], _c.c_char_p),
             "snag_gemm_workspace_floats": ([_I, _I, _I], _L),
             "snag_fusion_save_floats": ([_I] * 7, _L), "snag_fusion_work_floats": ([_I] * 7, _L),
             "snag_colstats_work_floats": ([_I], _L), "snag_eval_work_floats": ([_I, _I], _L),
-            "snag_gat_work_floats": ([_L, _I, _I], _L)}
+            "snag_gat_work_floats": ([_L, _I, _I], _L), "snag_score_seg_work_bytes": ([_L, _L, _L, _I, _I], _L)}
 
 _lib = None
 

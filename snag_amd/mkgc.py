@@ -51,7 +51,10 @@ class MKGCConfig:
     weight_decay: float = 1e-4
     readout_only: bool = True           # Mformer_hd_graph consumes hidden[:, g, :] alone: the last layer computes the query / attention row /
                                         # output projection / LayerNorm (/ FFN) for the structural token only (same values, 2/3 of the GEMM work)
-    deterministic: bool = False         # bit-reproducible steps: the scorer's gradient scatter uses fixed-point integer atomics (+~10 us)
+    scorer: str = "segmented"           # training form of the hinge scorer: "segmented" = per-triple pass + per-destination pass, no float atomics,
+                                        # bit-reproducible, gradient rows written (snag_score_margin_fwd_bwd_seg); "atomic" = one launch that
+                                        # scatter-adds with fp32 atomics (snag_score_margin_fwd_bwd)
+    deterministic: bool = False         # with scorer="atomic": fixed-point integer atomics instead (bit-reproducible, two launches)
     clip: float = 1.0                   # torch.nn.utils.clip_grad_norm_ of the reference's train loop (main.py:266-268, --clip default 1.0); 0 = off
     seed: int = 1234
 
@@ -104,6 +107,8 @@ class MKGCHotPath:
         # "atten_weight" (non-transformer attention; only dead code in the tree, EVA_tools.py:190-232) is not built.
         if cfg.joint_way not in ("Mformer_hd_graph", "Mformer_hd_mean", "Mformer_weight", "learnable_weight"):
             raise ValueError("joint_way must be Mformer_hd_graph, Mformer_hd_mean, Mformer_weight or learnable_weight (atten_weight is not built)")
+        if cfg.scorer not in ("segmented", "atomic"):
+            raise ValueError(f"scorer must be 'segmented' or 'atomic', got {cfg.scorer!r}")
         self.concat = cfg.joint_way in ("Mformer_weight", "learnable_weight")
         self.sdim = M * D if self.concat else D               # width of the read-out the scorer gathers (and of the relation rows)
         if self.sdim > 512:
@@ -321,7 +326,7 @@ class MKGCHotPath:
         self._fdesc = d
         b = _lib.FusionBwdDesc()
         b.d_hidden = ptr(self.d_repr) if self.ro else ptr(self.d_hidden)      # None for the concatenation read-outs
-        b.zero_d_hidden = 1 if self.ro else 0
+        b.zero_d_hidden = 1 if (self.ro and cfg.scorer != "segmented") else 0      # the segmented scorer overwrites its target: nothing to clear
         if cfg.joint_way == "Mformer_weight":
             b.d_joint = ptr(self.d_repr)
         elif cfg.joint_way == "learnable_weight":
@@ -402,6 +407,18 @@ class MKGCHotPath:
         self.noise_active = True
 
     # ------------------------------------------------------------------------------------------
+    def _use_seg(self):
+        """The atomic-free scorer needs a compact [rows, width] gradient target it may overwrite whole, and 16-byte rows."""
+        return self.cfg.scorer == "segmented" and self.d_repr is not None and self.sdim % 4 == 0
+
+    def _seg_workspace(self, B, K):
+        key = (B, K)
+        if getattr(self, "_seg_key", None) != key:
+            n = self.lib.snag_score_seg_work_bytes(self.cfg.n_ent, self.cfg.n_rel, B, K, self.sdim)
+            self._seg_work = torch.zeros((n + 255) // 256 * 256, device=self.dev, dtype=torch.uint8)     # zeroed once; launches keep it ready
+            self._seg_key = key
+        return self._seg_work
+
     def _zero_score_grads(self):
         """Zero the scorer's scatter targets; returns (pointer, row stride) of the [N, dim] read-out gradient."""
         cfg = self.cfg
@@ -471,6 +488,22 @@ class MKGCHotPath:
         ib = 4 if h.dtype == torch.int32 else 8
         self._batch = (h, r, t, neg_t, ib, B, K)
         self._score_bwd_scale = None
+        if with_backward and cfg.loss == "hinge" and K > 0 and self._use_seg():
+            # training, default: scores, losses and ALL gradient rows of the read-out and the relation table without float atomics
+            # (no zero-fill of the targets: every row is written)
+            if self.shard.sharded:
+                tgt, tld = self.d_repr_full.data_ptr(), self.sdim
+            else:
+                tgt, tld = self.d_repr.data_ptr(), self.sdim
+            work = self._seg_workspace(B, K)
+            self._probed("score_fwd_bwd", call, "snag_score_margin_fwd_bwd_seg", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D,
+                         ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K, float(cfg.margin), float(grad_scale), ptr(self._pos), ptr(self._neg),
+                         ptr(self._loss_part), ptr(self.loss), ptr(self._ticket), tgt, tld, ptr(self.g["rel"]), 1, ptr(work), work.numel(), st)
+            self._score_bwd_scale = float(grad_scale)
+            self._d_repr_clean = False
+            if want_scores:
+                return self.loss, self._pos, self._neg
+            return self.loss
         if with_backward and cfg.loss == "hinge" and not cfg.deterministic and K > 0:
             # training: the scorer's forward AND backward in one launch (every row gathered once, summed loss included)
             d_repr, d_ld = self._zero_score_grads()
@@ -544,9 +577,9 @@ class MKGCHotPath:
             # every rank scattered its triples' gradients over ALL entity rows: the owners get the sums of their rows
             self.shard.reduce_scatter(self.d_repr, self.d_repr_full)
         if cfg.joint_way == "Mformer_hd_mean":
-            call("snag_token_mean_bwd", ptr(self.d_repr), Nl, M, D, ptr(self.d_hidden), 1, st)
+            call("snag_token_mean_bwd", ptr(self.d_repr), Nl, M, D, ptr(self.d_hidden), 0 if cfg.scorer == "segmented" else 1, st)
         call("snag_fusion_bwd", ctypes.byref(self._bdesc), st)
-        self._d_repr_clean = True                      # its reader cleared it behind itself
+        self._d_repr_clean = cfg.scorer != "segmented"     # (atomic scorer: its reader cleared it behind itself)
         dx0 = self.d_x0.data_ptr()
         wk = ptr(self.work)
         # the entity table's gradient: this rank's rows only (the others stay zero from construction)

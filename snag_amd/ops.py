@@ -149,6 +149,41 @@ def score_margin_fwd_bwd(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, d_ent
     return loss, pos, neg, loss_part, d_ent, d_rel
 
 
+_SEG_WORK = {}
+
+
+def score_margin_fwd_bwd_seg(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, d_ent=None, d_rel=None, write_untouched=True):
+    """Hinge scorer, forward and backward WITHOUT float atomics (per-triple pass + per-destination pass, bit-reproducible)
+    -> (loss, pos, neg, loss_part, d_ent, d_rel); d_ent / d_rel are overwritten.  C ABI: snag_score_margin_fwd_bwd_seg."""
+    _rows(ent, "ent"), _chk(rel, "rel", ndim=2)
+    if ent.shape[1] != rel.shape[1]:
+        raise ValueError(f"ent dim {ent.shape[1]} != rel dim {rel.shape[1]}")
+    if neg_t is None:
+        raise ValueError("score_margin_fwd_bwd_seg needs explicit negative tails")
+    B, K, ib = _idx_group(h, r, t, neg_t)
+    if d_ent is None:
+        d_ent = torch.empty(ent.shape, device=ent.device, dtype=f32) if write_untouched else torch.zeros(ent.shape, device=ent.device, dtype=f32)
+    if d_rel is None:
+        d_rel = torch.empty_like(rel) if write_untouched else torch.zeros_like(rel)
+    _rows(d_ent, "d_ent"), _chk(d_rel, "d_rel", ndim=2)
+    if d_ent.shape != ent.shape or d_rel.shape != rel.shape:
+        raise ValueError("gradient buffers must match the table shapes")
+    N, R, D = ent.shape[0], rel.shape[0], ent.shape[1]
+    nbytes = _lib.load().snag_score_seg_work_bytes(N, R, B, K, D)
+    key = (ent.device.type, ent.device.index, N, R, B, K, D)
+    if key not in _SEG_WORK:                     # zeroed ONCE; every launch leaves it ready for the next
+        _SEG_WORK[key] = torch.zeros((nbytes + 255) // 256 * 256, device=ent.device, dtype=torch.uint8)
+    work = _SEG_WORK[key]
+    pos = torch.empty(B, device=ent.device, dtype=f32)
+    neg = torch.empty(B, K, device=ent.device, dtype=f32)
+    loss_part = torch.empty(B, device=ent.device, dtype=f32)
+    loss = torch.empty((), device=ent.device, dtype=f32)
+    call("snag_score_margin_fwd_bwd_seg", ptr(ent), ent.stride(0), N, ptr(rel), R, D, ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K, float(margin),
+         float(grad_scale), ptr(pos), ptr(neg), ptr(loss_part), ptr(loss), ptr(_ticket(ent.device)), ptr(d_ent), d_ent.stride(0), ptr(d_rel),
+         int(write_untouched), ptr(work), work.numel(), stream())
+    return loss, pos, neg, loss_part, d_ent, d_rel
+
+
 def reduce_sum(x):
     """Deterministic sum of a float tensor -> 0-dim tensor.  C ABI: snag_reduce_sum."""
     _chk(x, "x")

@@ -42,7 +42,7 @@ def oracle_params(eng):
     return p, proj, fp
 
 
-@pytest.mark.parametrize("loss_kind", ["hinge", "hinge_fused", "self_adversarial"])
+@pytest.mark.parametrize("loss_kind", ["hinge", "hinge_fused", "hinge_atomic", "self_adversarial"])
 @pytest.mark.parametrize("num_proj,joint_way,ffn,noise,idt,shape", [
     (2, "Mformer_hd_graph", 0, False, torch.int32, (700, 23, 128, 96, 32, 200, 72)),
     (2, "Mformer_hd_graph_full", 1, True, torch.int32, (700, 23, 128, 96, 32, 200, 72)),       # readout_only switched off
@@ -66,9 +66,12 @@ def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape, loss_k
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
     N, R, D, B, K, F0, F1 = shape[:7]
     # "hinge_fused": the training form -- the scorer's forward and backward as ONE launch inside forward(with_backward=True)
-    fused, loss_kind = loss_kind == "hinge_fused", loss_kind.replace("_fused", "")
+    # "hinge_fused": the training form inside forward(with_backward=True) -- by default the atomic-free two-pass scorer;
+    # "hinge_atomic": the one-launch fp32-atomic form (MKGCConfig.scorer = "atomic"); plain "hinge": forward, then the two-launch backward
+    atomic = loss_kind == "hinge_atomic"
+    fused, loss_kind = loss_kind in ("hinge_fused", "hinge_atomic"), "hinge" if loss_kind.startswith("hinge") else loss_kind
     full_layer, joint_way = joint_way.endswith("_full"), joint_way.replace("_full", "")
-    cfg = MKGCConfig(readout_only=not full_layer, n_ent=N, n_rel=R, dim=D, feat_dims=[F0, F1], num_proj=num_proj, joint_way=joint_way, num_layers=shape[7] if len(shape) > 7 else 1,
+    cfg = MKGCConfig(readout_only=not full_layer, scorer="atomic" if atomic else "segmented", n_ent=N, n_rel=R, dim=D, feat_dims=[F0, F1], num_proj=num_proj, joint_way=joint_way, num_layers=shape[7] if len(shape) > 7 else 1,
                      use_intermediate=ffn, intermediate_size=96, margin=6.0, neg_num=K, dropout=0.0, add_noise=int(noise), seed=7,
                      loss=loss_kind, adv_temp=0.7)
     g = torch.Generator().manual_seed(99)
@@ -322,8 +325,10 @@ def test_graph_replay_equals_eager_steps():
 
 @pytest.mark.parametrize("joint_way", ["Mformer_hd_graph", "Mformer_hd_mean"])
 def test_deterministic_mode_is_bit_reproducible_and_matches_the_default(joint_way):
-    """MKGCConfig.deterministic: the scorer's gradient scatter goes through fixed-point integer atomics, every other reduction is
-    fixed-order already, so two runs give identical bits; against the default (fp32 atomics) path the step agrees to rounding."""
+    """Three training forms of the scorer: the default two-pass segmented form (no float atomics: bit-reproducible), the one-launch
+    fp32-atomic form (last bits depend on the arrival order) and that form with fixed-point integer atomics (MKGCConfig.deterministic,
+    bit-reproducible).  Every other reduction of the step is fixed-order, so a reproducible scorer makes the whole step reproducible;
+    across the three forms the steps agree to rounding."""
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
     N, R, D, B, K = 1200, 9, 128, 256, 32
     g = torch.Generator().manual_seed(77)
@@ -331,19 +336,23 @@ def test_deterministic_mode_is_bit_reproducible_and_matches_the_default(joint_wa
     batches = [[torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(DEV) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (60, (B, K)))]
                for _ in range(6)]                        # negatives from 60 hub entities: hundreds of colliding scatter targets per row
 
-    def run(det):
+    def run(det, scorer="atomic"):
         cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[64, 32], joint_way=joint_way, neg_num=K, dropout=0.1, add_noise=1, seed=3, lr=1e-3,
-                         deterministic=det)
+                         deterministic=det, scorer=scorer)
         eng = MKGCHotPath(cfg, feats, device=DEV)
         eng.update_noise(seed=2)
         losses = [float(eng.train_step(*b)) for b in batches]
         return eng.flat.clone(), eng.gflat.clone(), losses
+    s1 = run(False, "segmented")
+    s2 = run(False, "segmented")
+    assert torch.equal(s1[0], s2[0]) and torch.equal(s1[1], s2[1]) and s1[2] == s2[2]
     a = run(True)
     b = run(True)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
     c = run(False)
     scale = float(c[1].abs().max())
     assert float((a[1] - c[1]).abs().max()) <= 1e-5 * scale
+    assert float((s1[1] - c[1]).abs().max()) <= 1e-5 * scale
     assert all(abs(x - y) <= 1e-5 * max(1.0, abs(y)) for x, y in zip(a[2], c[2]))
 
 

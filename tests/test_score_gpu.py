@@ -94,6 +94,47 @@ def test_score_fused_entry_vs_oracle(D, K, B, idt, margin):
     assert_close(neg_g, neg_f, atol=3e-6)
 
 
+@pytest.mark.parametrize("D,K,B,idt", [c for c in _FUSED_SHAPES if c[0] % 4 == 0])
+@pytest.mark.parametrize("margin", [1.2, 12.0])
+def test_score_segmented_entry_vs_oracle(D, K, B, idt, margin):
+    """snag_score_margin_fwd_bwd_seg: no float atomics (per-triple pass + per-destination fixed-point sums).  Same cases as the
+    atomic form; in addition the outputs of two launches are identical BITS, and the gradient buffers are overwritten (stale
+    contents must not leak through)."""
+    from snag_amd import ops
+    ent, rel, h, r, t, neg = _mk(501, 13, D, B, K, seed=D * 1000 + K, idt=idt)
+    ent[7].zero_()                                   # normalize eps branch
+    h[0] = 7
+    if K:
+        neg[1, 0] = 7
+        if B > 2:
+            neg[2, :] = 3                            # one entity drawn K times by one triple, and ...
+        t[3:3 + max(0, min(B - 3, 40))] = 5          # ... a hub tail: more entries than a destination's bucket holds (overflow list)
+    e_ = ent.clone().requires_grad_(True)
+    r_ = rel.clone().requires_grad_(True)
+    loss, pos, ng = O.score_margin(e_, r_, h, r, t, neg, margin)
+    (0.5 * loss).backward()
+    d = [x.to(DEV) for x in (ent, rel, h, r, t, neg)]
+    stale_e, stale_r = torch.full((501, D), 7.0, device=DEV), torch.full((13, D), -3.0, device=DEV)
+    lg, pos_g, neg_g, lp, de, dr = ops.score_margin_fwd_bwd_seg(*d, margin, grad_scale=0.5, d_ent=stale_e, d_rel=stale_r)
+    assert_close(pos_g, pos, atol=1e-5, what="pos")
+    assert_close(neg_g, ng, atol=1e-5, what="neg")
+    assert_close(lg, loss, atol=1e-4, rtol=1e-5, what="loss")
+    assert_close(de, e_.grad, atol=2e-4, rtol=1e-4, what="d_ent")
+    assert_close(dr, r_.grad, atol=2e-4, rtol=1e-4, what="d_rel")
+    pos_f, neg_f, _ = ops.score_margin_fwd(*d, margin)
+    assert torch.equal(pos_g, pos_f) and torch.equal(neg_g, neg_f)            # pass A is the forward kernel's arithmetic
+    lg2, _, _, lp2, de2, dr2 = ops.score_margin_fwd_bwd_seg(*d, margin, grad_scale=0.5)
+    assert torch.equal(de2, de) and torch.equal(dr2, dr) and torch.equal(lp2, lp) and torch.equal(lg2, lg)
+    # sparse-write form: rows nothing arrived at keep what they held
+    keep_e = torch.full((501, D), 9.0, device=DEV)
+    _, _, _, _, de3, _ = ops.score_margin_fwd_bwd_seg(*d, margin, grad_scale=0.5, d_ent=keep_e, d_rel=torch.zeros(13, D, device=DEV), write_untouched=False)
+    touched = torch.zeros(501, dtype=torch.bool)                 # every head, tail and negative tail of the batch (active hinge or not)
+    touched[h.long()] = True
+    touched[t.long()] = True
+    touched[neg.flatten().long()] = True
+    assert torch.equal(de3[touched.to(DEV)], de[touched.to(DEV)]) and float((de3[~touched.to(DEV)] - 9.0).abs().max() if (~touched).any() else 0.0) == 0.0
+
+
 def test_score_fused_accumulates_into_strided_rows_and_resets_its_ticket():
     """The engine's use: the table is the slot hidden[:, g, :] of a stacked [N, M, D] tensor (row stride M*D) and the gradient is
     scatter-added into the same slot of d_hidden; two launches in a row accumulate; the ticket word is zero again after each."""

@@ -39,7 +39,13 @@ def main():
         fwd = lambda: call("snag_score_margin_fwd", *args, ptr(pos), ptr(ng), ptr(lp), stream())
         bwd = lambda: call("snag_score_margin_bwd", *args, 1.0, None, None, ptr(d_ent), D, ptr(d_rel), stream())
         red = lambda: call("snag_reduce_sum", ptr(lp), B, ptr(loss), stream())
+        from snag_amd import _lib
+        nb = _lib.load().snag_score_seg_work_bytes(N, 558, B, K, D)
+        work = torch.zeros(nb, device=dev, dtype=torch.uint8)
+        seg = lambda: call("snag_score_margin_fwd_bwd_seg", *args, 1.0, ptr(pos), ptr(ng), ptr(lp), ptr(loss), ptr(tick), ptr(d_ent), D, ptr(d_rel), 1, ptr(work), nb, stream())
+        t_seg = timed(seg)
         by = B * ((K + 3) * D * 4 * 3 + (K + 3) * 4 + (K + 1) * 4)
+        print(f"    segmented (no float atomics, overwrite): {t_seg:.2f} us = {by / t_seg / 8e6:.3f} of 8 TB/s on the same algorithmic bytes", flush=True)
         tf = timed(fused)
         print(f"N={N} D={D} K={K} B={B} WPT={os.environ.get('SNAG_SCORE_WPT', 'auto')}: fused {tf:.2f} us ({by / tf / 1e3:.0f} GB/s algorithmic = "
               f"{by / tf / 8e6:.3f} of 8 TB/s; atomic floor {B * (K + 3) * D * 4 / 1.3e6:.1f} us), fused without loss sum {timed(fused_noloss):.2f}, "
