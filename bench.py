@@ -82,23 +82,24 @@ def score_bytes(cfg, n_triples):
     return n_triples * ((cfg.neg_num + 3) * cfg.dim * 4 + (cfg.neg_num + 3) * 4 + (cfg.neg_num + 1) * 4)
 
 
-def roofline_dominant(cfg, timer):
-    """The launch that takes the largest share of the step: the visual projection l1 GEMM (exact-f32 MFMA)."""
+def roofline_dominant(cfg, timer, rows=None):
+    """The launch that takes the largest share of the step: the visual projection l1 GEMM (exact-f32 MFMA) over this rank's entity rows."""
     us, n = timer.mean_us()
-    flops = 2.0 * cfg.n_ent * cfg.feat_dims[0] * cfg.dim
+    rows = cfg.n_ent if rows is None else rows
+    flops = 2.0 * rows * cfg.feat_dims[0] * cfg.dim
     ach = flops / (us * 1e-6) / 1e12 if us else 0.0
     traffic, src = None, None
     try:  # PMC passes cannot run inside this process; the committed per-launch figure is quoted when it is for this very shape
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_dominant.json")) as f:
             pmc = json.load(f)
-        if (pmc["n_ent"], pmc["feat0"], pmc["dim"]) == (cfg.n_ent, cfg.feat_dims[0], cfg.dim):
+        if (pmc["n_ent"], pmc["feat0"], pmc["dim"]) == (rows, cfg.feat_dims[0], cfg.dim):
             traffic, src = pmc["fetch_bytes"] + pmc["write_bytes"], pmc["source"]
     except (OSError, KeyError, ValueError):
         pass
-    return {"kernel": f"gemm_streamk_kernel<64,128,..> (visual projection: [{cfg.n_ent},{cfg.feat_dims[0]}]x[{cfg.feat_dims[0]},{cfg.dim}], exact-f32 MFMA)",
+    return {"kernel": f"gemm_streamk_kernel<64,128,..> + streamk_fixup_kernel (visual projection: [{rows},{cfg.feat_dims[0]}]x[{cfg.feat_dims[0]},{cfg.dim}], exact-f32 MFMA)",
             "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
             "traffic": traffic, "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC)", "traffic_source": src,
-            "algorithmic_bytes_per_launch": 4 * (cfg.n_ent * cfg.feat_dims[0] + cfg.feat_dims[0] * cfg.dim + cfg.n_ent * cfg.dim),
+            "algorithmic_bytes_per_launch": 4 * (rows * cfg.feat_dims[0] + cfg.feat_dims[0] * cfg.dim + rows * cfg.dim),
             "avg_us": us, "launches_timed": n, "algorithmic_flops_per_launch": flops}
 
 
@@ -124,6 +125,37 @@ def roofline_score(cfg, batch, timer):
             "fp32_atomic_form": {"entry": "snag_score_margin_fwd_bwd (MKGCConfig.scorer='atomic')", "atomic_bytes_per_launch": atomic_bytes,
                                  "atomic_floor_us": atomic_bytes / 1.3e12 * 1e6},
             "timed": "HIP events around the entry (both passes), inside the timed region; rocprofv3 per-kernel times: profiles/"}
+
+
+def score_train_larger_batch(eng, cfg, device, B=8192):
+    """The training scorer (same entry, same 15k-entity read-out table) on 8 x the batch: at B = 1024 the two passes are launch- and
+    round-trip-bound (18.6 MB of gathers would take 2.3 us at 8 TB/s); this shows what the kernels do once there is work per launch."""
+    from snag_amd._lib import call, ptr, stream
+    from snag_amd import _lib
+    N, R, D, K = cfg.n_ent, cfg.n_rel, eng.sdim, cfg.neg_num
+    g = torch.Generator().manual_seed(11)
+    h, r, t = (torch.randint(0, hi, (B,), generator=g, dtype=torch.int32).to(device) for hi in (N, R, N))
+    neg = torch.randint(0, N, (B, K), generator=g, dtype=torch.int32).to(device)
+    table = eng.entity_representation().contiguous()
+    pos, ng, lp, loss = torch.empty(B, device=device), torch.empty(B, K, device=device), torch.empty(B, device=device), torch.empty((), device=device)
+    de, dr = torch.empty(N, D, device=device), torch.empty(R, D, device=device)
+    nb = _lib.load().snag_score_seg_work_bytes(N, R, B, K, D)
+    work = torch.zeros(nb, device=device, dtype=torch.uint8)
+    tick = torch.zeros(_lib.SCORE_TICKET_WORDS, device=device, dtype=torch.int32)
+    run = lambda: call("snag_score_margin_fwd_bwd_seg", ptr(table), D, N, ptr(eng.p["rel"]), R, D, ptr(h), ptr(r), ptr(t), ptr(neg), 4, B, K, float(cfg.margin), 1.0,
+                       ptr(pos), ptr(ng), ptr(lp), ptr(loss), ptr(tick), ptr(de), D, ptr(dr), 1, ptr(work), nb, stream())
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    by = B * ((K + 3) * D * 4 * 3 + (K + 3) * 4 + (K + 1) * 4)
+    return {"batch": B, "avg_us": us, "achieved": by / us / 1e3, "unit": "GB/s", "frac": by / us / 1e3 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": by,
+            "timed": "20 back-to-back calls of the entry (both passes), HIP events, after the timed region"}
 
 
 def untimed_extras(eng, batches, args, device):
@@ -566,9 +598,10 @@ def main():
         if not args.no_extras and world == 1:
             out.update(untimed_extras(eng, batches, args, device))
         if timers:
-            out["roofline"] = roofline_dominant(cfg, timers["proj_l1_fwd"])
+            out["roofline"] = roofline_dominant(cfg, timers["proj_l1_fwd"], rows=eng.shard.n_loc)
             out["roofline_score"] = roofline_score(cfg, args.batch, timers["score_fwd_bwd"])
             if not args.no_extras:
+                out["roofline_score"]["batch_8192"] = score_train_larger_batch(eng, cfg, device)
                 out["roofline_score"]["hbm_resident"] = score_hbm_resident(device)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, [f.cpu() for f in feats], args.batch, args.cpu_seconds, cfg.seed)
