@@ -214,6 +214,10 @@ typedef struct snag_gemm_desc {
 
 SNAG_API int snag_gemm_f32(const snag_gemm_desc* desc, void* stream);
 SNAG_API int64_t snag_gemm_workspace_floats(int M, int N, int K);
+/* Two independent problems; when they have the same shape, layouts and split decision they run as ONE launch (the step's many
+ * [rows x D x D]-sized GEMMs are grids of fewer workgroups than the chip has CUs: a pair fills it once instead of twice), otherwise
+ * one after the other.  Results are those of two snag_gemm_f32 calls, bit for bit.  Split-K workspaces must be distinct. */
+SNAG_API int snag_gemm_f32_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, void* stream);
 
 /* Gram matrix S [n, n] = alpha * Z Z^T for Z [n, k] (row stride ldz), exact-f32 MFMA.  Only the tiles on or above the diagonal are
  * computed; each is also stored transposed, so S is symmetric bit for bit.  Used for the stacked InfoNCE logits

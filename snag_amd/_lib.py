@@ -75,6 +75,7 @@ SIGNATURES = {
     "snag_reduce_sum": [_P, _L, _P, _P],
     "snag_rank_full_table": [_P, _L, _L, _P, _I, _P, _P, _P],
     "snag_gemm_f32": [_c.POINTER(GemmDesc), _P],
+    "snag_gemm_f32_pair": [_c.POINTER(GemmDesc), _c.POINTER(GemmDesc), _P],
     "snag_fusion_fwd": [_c.POINTER(FusionDesc), _P],
     "snag_fusion_bwd": [_c.POINTER(FusionBwdDesc), _P],
     "snag_pack_tokens": [_c.POINTER(_P), _I, _L, _I, _I, _P, _P, _F, _P, _P],

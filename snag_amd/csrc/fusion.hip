@@ -210,7 +210,7 @@ struct Work {
 
 static int64_t bwd_gemm_ws(int N, int M, int D, int I, bool ffn) {
     const int NM = N * M;
-    int64_t w = std::max(gemm_workspace_floats(3 * D, D, NM), gemm_workspace_floats(D, D, NM));
+    int64_t w = std::max(gemm_workspace_floats(3 * D, D, NM), 2 * (gemm_workspace_floats(D, D, NM) + 64));
     if (ffn) w = std::max({w, gemm_workspace_floats(D, I, NM), gemm_workspace_floats(I, D, NM)});
     return w;
 }
@@ -338,10 +338,7 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             if ((rc = ln_bwd(dout, S.t1, S.st1, P.ln1_g, N, D, P.keep_attn_out ? P.keep_attn_out + (int64_t)ro * D : nullptr, kscale, W.dA, dtm, W.part,
                              G.ln1_g, G.ln1_b, G.bo, acc, st, MD, zero_up))) return rc;
             const float* dz = dtm ? dtm : W.dA;
-            // dWo = dz^T ctx_g
-            g = gemm_desc(D, D, N, dz, D, false, S.ctx, D, false, G.wo, D);
-            g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
-            if ((rc = gemm_dispatch(&g, st))) return rc;
+            // (dWo = dz^T ctx_g is launched further down, paired with dWq)
             // dctx_g = dz Wo -> dC
             g = gemm_desc(N, D, D, dz, D, true, P.wo, D, false, W.dC, D);
             if ((rc = gemm_dispatch(&g, st))) return rc;
@@ -353,10 +350,16 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
                      P.keep_probs, kscale, dq_g, dkv, W.part);
             hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(3 * D, 64)), dim3(1024), 0, st, (const float*)W.part, ablocks, (int64_t)3 * D, 3 * D, G.bqkv, acc);
             if ((rc = check_launch("fusion attention backward (read-out)"))) return rc;
-            // dWq = dq_g^T x_g (rows 0..D of wqkv) ; dWkv = dkv^T x (rows D..3D)
-            g = gemm_desc(D, D, N, dq_g, D, false, xin + (int64_t)ro * D, MD, false, G.wqkv, D);
-            g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
-            if ((rc = gemm_dispatch(&g, st))) return rc;
+            // dWo = dz^T ctx_g and dWq = dq_g^T x_g (rows 0..D of wqkv): two D x D outputs over N rows -> ONE launch (+ one reduce)
+            {
+                snag_gemm_desc g0 = gemm_desc(D, D, N, dz, D, false, S.ctx, D, false, G.wo, D);
+                snag_gemm_desc g1 = gemm_desc(D, D, N, dq_g, D, false, xin + (int64_t)ro * D, MD, false, G.wqkv, D);
+                const int64_t halfws = W.gemm_ws_floats / 2 / 64 * 64;
+                g0.accumulate = acc; g0.workspace = W.gemm_ws; g0.workspace_floats = halfws;
+                g1.accumulate = acc; g1.workspace = W.gemm_ws + halfws; g1.workspace_floats = halfws;
+                if ((rc = gemm_dispatch_pair(&g0, &g1, st))) return rc;
+            }
+            // dWkv = dkv^T x (rows D..3D)
             g = gemm_desc(2 * D, D, (int)NM, dkv, 2 * D, false, xin, D, false, G.wqkv + (int64_t)D * D, D);
             g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
             if ((rc = gemm_dispatch(&g, st))) return rc;

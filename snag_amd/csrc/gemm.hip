@@ -130,6 +130,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// the same for the two problems of gemm_tile_pair_kernel (blockIdx.y = problem)
+__global__ __launch_bounds__(256) void splitk_reduce_pair_kernel(const float* __restrict__ slab0, Epilogue e0, const float* __restrict__ slab1, Epilogue e1,
+                                                                 int splits) {
+    const float* slab = blockIdx.y ? slab1 : slab0;
+    const Epilogue& epi = blockIdx.y ? e1 : e0;
+    const int64_t total = (int64_t)epi.M * epi.N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        int z = 0;
+        for (; z + 8 <= splits; z += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = slab[(int64_t)(z + u) * total + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; z < splits; ++z) v += slab[(int64_t)z * total + i];
+        epi((int)(i / epi.N), (int)(i % epi.N), v);
+    }
+}
+
 // S = alpha * Z Z^T (Z [n, k], K-contiguous).  Only tiles on or above the diagonal run the main loop; each also writes its
 // transpose (staged through LDS so that both copies leave in full 128-byte lines), so S is symmetric bit for bit and the MFMA
 // work is (almost) halved.
@@ -168,15 +189,35 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(GemmOperands p, float al
         });
 }
 
+// VEC: every fetch is an unpredicated dwordx4 (all shapes of the hot path); otherwise the checked loader
+// Measured on one device (tools/tune_gemm.py, A/B builds): the unpredicated loader wins 15-25 % whenever an operand is
+// row-contiguous, but loses 5-20 % when both are K-contiguous, so those keep the checked loader.
+static bool use_vec(const GemmOperands& p, bool a_kc, bool b_kc) {
+    static const int vec_mode = env_int("SNAG_GEMM_VEC");      // tuning: 1 = never, 2 = whenever legal
+    const bool legal = p.a_vec && p.b_vec && (a_kc || p.M % 4 == 0) && (b_kc || p.N % 4 == 0) && p.M >= 4 && p.N >= 4;
+    return legal && vec_mode != 1 && (vec_mode == 2 || !(a_kc && b_kc));
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_cfg_pair(const GemmOperands& p0, const Epilogue& e0, float* slab0, const GemmOperands& p1, const Epilogue& e1, float* slab1,
+                            int splits, bool a_kc, bool b_kc, bool vec, hipStream_t st) {
+    dim3 grid(ceil_div(p0.N, BN), ceil_div(p0.M, BM), 2 * splits), block(256);
+#define SNAG_GEMM2(AK, BK_)                                                                                        \
+    do {                                                                                                           \
+        if (vec) hipLaunchKernelGGL((gemm_tile_pair_kernel<BM, BN, WM, WN, AK, BK_, true, Epilogue>), grid, block, 0, st, p0, e0, slab0, p1, e1, slab1, splits);  \
+        else hipLaunchKernelGGL((gemm_tile_pair_kernel<BM, BN, WM, WN, AK, BK_, false, Epilogue>), grid, block, 0, st, p0, e0, slab0, p1, e1, slab1, splits);     \
+    } while (0)
+    if (a_kc && b_kc) SNAG_GEMM2(true, true);
+    else if (a_kc && !b_kc) SNAG_GEMM2(true, false);
+    else if (!a_kc && b_kc) SNAG_GEMM2(false, true);
+    else SNAG_GEMM2(false, false);
+#undef SNAG_GEMM2
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(const GemmOperands& p, const Epilogue& e, float* slab, int splits, bool a_kc, bool b_kc, hipStream_t st) {
     dim3 grid(ceil_div(p.N, BN), ceil_div(p.M, BM), splits), block(256);
-    // VEC: every fetch is an unpredicated dwordx4 (all shapes of the hot path); otherwise the checked loader
-    // Measured on one device (tools/tune_gemm.py, A/B builds): the unpredicated loader wins 15-25 % whenever an operand is
-    // row-contiguous, but loses 5-20 % when both are K-contiguous, so those keep the checked loader.
-    static const int vec_mode = env_int("SNAG_GEMM_VEC");      // tuning: 1 = never, 2 = whenever legal
-    const bool legal = p.a_vec && p.b_vec && (a_kc || p.M % 4 == 0) && (b_kc || p.N % 4 == 0) && p.M >= 4 && p.N >= 4;
-    const bool vec = legal && vec_mode != 1 && (vec_mode == 2 || !(a_kc && b_kc));
+    const bool vec = use_vec(p, a_kc, b_kc);
 #define SNAG_GEMM(AK, BK_)                                                                                        \
     do {                                                                                                          \
         if (vec) hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN, AK, BK_, true, Epilogue>), grid, block, 0, st, p, e, slab);  \
@@ -264,15 +305,25 @@ int64_t gemm_workspace_floats(int M, int N, int K) {
     return splits > 1 ? std::max((int64_t)splits * M * N, sk) : 0;
 }
 
-int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
+// What the dispatcher decided for one problem (everything the launch needs)
+struct GemmPlan {
     GemmOperands p;
+    Epilogue e;
+    bool big, wide, streamk;
+    int splits;
+    StreamKChoice sk;
+};
+
+static GemmPlan plan_gemm(const snag_gemm_desc* d) {
+    GemmPlan pl{};
+    GemmOperands& p = pl.p;
+    Epilogue& e = pl.e;
     p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb; p.M = d->M; p.N = d->N; p.K = d->K;
     p.a_vec = (d->lda % 4 == 0) && (((uintptr_t)d->A & 15) == 0);
     p.b_vec = (d->ldb % 4 == 0) && (((uintptr_t)d->B & 15) == 0);
     static const int dbg = env_int("SNAG_GEMM_DBG");
     p.dbg = dbg;
     p.xcd = xcd_mode();
-    Epilogue e;
     e.C = d->C; e.ldc = d->ldc; e.bias = d->bias; e.alpha = d->alpha; e.act = d->act; e.pre = d->pre_act;
     e.mask = d->keep_mask; e.ldm = d->ldmask > 0 ? d->ldmask : d->N; e.mscale = d->keep_scale; e.add1 = d->add1; e.ld1 = d->ld1; e.add2 = d->add2; e.ld2 = d->ld2;
     e.accumulate = d->accumulate; e.M = d->M; e.N = d->N; e.aux = d->aux; e.ldaux = d->ldaux;
@@ -311,6 +362,7 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     // K == 0 is legal (C = epilogue(0): bias / add1 / accumulate still apply): one split with an empty k-range; the split
     // arithmetic below would otherwise divide by zero
     if (p.K == 0) splits = 1;
+    pl.big = big; pl.wide = wide; pl.streamk = false;
     if (splits > 1 && !big && !wide && streamk_mode() != 1) {
         // blocks per CU of the split grid vs what the slowest CU gets
         const double per_cu = (double)tiles * splits / 256.0;
@@ -319,24 +371,39 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
         // few tiles shared by many blocks (the dW shapes) keep split-K: their slabs reduce in parallel over the whole output
         if ((balance < 0.95 || streamk_mode() == 2) && c.G >= 256 && tiles * 8 >= c.G && c.slab_floats <= d->workspace_floats) {
             p.k_per_split = 0;
-            if (log_shapes())
-                fprintf(stderr, "snag_gemm M=%d N=%d K=%d a_kc=%d b_kc=%d tile=64x128 streamk=%d fast=%d acc=%d\n", p.M, p.N, p.K, (int)d->a_kcontig,
-                        (int)d->b_kcontig, c.G, (int)e.fast, (int)d->accumulate);
-            return launch_streamk<64, 128, 32, 64>(p, e, d->workspace, c, d->a_kcontig, d->b_kcontig, st);
+            pl.streamk = true;
+            pl.sk = c;
+            pl.splits = splits;
+            return pl;
         }
     }
     const int kps = std::max(kBK, ceil_div(ceil_div(p.K, splits), kBK) * kBK);
     splits = std::max(1, ceil_div(p.K, kps));
     p.k_per_split = kps;
+    pl.splits = splits;
+    return pl;
+}
+
+int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
+    const GemmPlan pl = plan_gemm(d);
+    const GemmOperands& p = pl.p;
+    const Epilogue& e = pl.e;
+    if (pl.streamk) {
+        if (log_shapes())
+            fprintf(stderr, "snag_gemm M=%d N=%d K=%d a_kc=%d b_kc=%d tile=64x128 streamk=%d fast=%d acc=%d\n", p.M, p.N, p.K, (int)d->a_kcontig,
+                    (int)d->b_kcontig, pl.sk.G, (int)e.fast, (int)d->accumulate);
+        return launch_streamk<64, 128, 32, 64>(p, e, d->workspace, pl.sk, d->a_kcontig, d->b_kcontig, st);
+    }
+    const int splits = pl.splits;
     float* slab = splits > 1 ? d->workspace : nullptr;
     if (log_shapes())
         fprintf(stderr, "snag_gemm M=%d N=%d K=%d a_kc=%d b_kc=%d tile=%s splits=%d fast=%d acc=%d\n", p.M, p.N, p.K, (int)d->a_kcontig,
-                (int)d->b_kcontig, wide ? "128x160" : big ? "128x128" : "64x128", splits, (int)e.fast, (int)d->accumulate);
+                (int)d->b_kcontig, pl.wide ? "128x160" : pl.big ? "128x128" : "64x128", splits, (int)e.fast, (int)d->accumulate);
 #if SNAG_GEMM_BK == 16
-    if (wide) launch_cfg<128, 160, 32, 160>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
+    if (pl.wide) launch_cfg<128, 160, 32, 160>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else
 #endif
-    if (big) launch_cfg<128, 128, 64, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
+    if (pl.big) launch_cfg<128, 128, 64, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else launch_cfg<64, 128, 32, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     int rc = check_launch("snag_gemm_f32");
     if (rc) return rc;
@@ -345,6 +412,39 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
         const int blocks = (int)std::min<int64_t>(2048, (total + 255) / 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, splits, e);
         rc = check_launch("snag_gemm_f32(split-K reduce)");
+    }
+    return rc;
+}
+
+// Two problems in one launch when the dispatcher decides the same for both (same shape, layouts, tile, split count, loader);
+// anything else runs them one after the other.
+int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStream_t st) {
+    static const int off = env_int("SNAG_GEMM_PAIR_OFF");      // tuning / A-B
+    const GemmPlan a = plan_gemm(d0), b = plan_gemm(d1);
+    const bool same = !off && !a.streamk && !b.streamk && !a.wide && !b.wide && a.big == b.big && a.splits == b.splits && d0->M == d1->M && d0->N == d1->N &&
+                      d0->K == d1->K && d0->a_kcontig == d1->a_kcontig && d0->b_kcontig == d1->b_kcontig && a.p.k_per_split == b.p.k_per_split &&
+                      use_vec(a.p, d0->a_kcontig, d0->b_kcontig) == use_vec(b.p, d1->a_kcontig, d1->b_kcontig) &&
+                      (a.splits == 1 || (d0->workspace != d1->workspace));
+    if (!same) {
+        int rc = gemm_dispatch(d0, st);
+        return rc ? rc : gemm_dispatch(d1, st);
+    }
+    const int splits = a.splits;
+    float* s0 = splits > 1 ? d0->workspace : nullptr;
+    float* s1 = splits > 1 ? d1->workspace : nullptr;
+    const bool vec = use_vec(a.p, d0->a_kcontig, d0->b_kcontig);
+    if (log_shapes())
+        fprintf(stderr, "snag_gemm PAIR M=%d N=%d K=%d a_kc=%d b_kc=%d tile=%s splits=%d\n", a.p.M, a.p.N, a.p.K, (int)d0->a_kcontig, (int)d0->b_kcontig,
+                a.big ? "128x128" : "64x128", splits);
+    if (a.big) launch_cfg_pair<128, 128, 64, 64>(a.p, a.e, s0, b.p, b.e, s1, splits, d0->a_kcontig, d0->b_kcontig, vec, st);
+    else launch_cfg_pair<64, 128, 32, 64>(a.p, a.e, s0, b.p, b.e, s1, splits, d0->a_kcontig, d0->b_kcontig, vec, st);
+    int rc = check_launch("snag_gemm_f32_pair");
+    if (rc) return rc;
+    if (splits > 1) {
+        const int64_t total = (int64_t)a.p.M * a.p.N;
+        const int blocks = (int)std::min<int64_t>(1024, (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_pair_kernel, dim3(blocks, 2), dim3(256), 0, st, (const float*)s0, a.e, (const float*)s1, b.e, splits);
+        rc = check_launch("snag_gemm_f32_pair(split-K reduce)");
     }
     return rc;
 }
@@ -375,6 +475,19 @@ extern "C" SNAG_API int snag_gemm_f32(const snag_gemm_desc* d, void* stream) {
     if (rc) return rc;
     if (d->M == 0 || d->N == 0) return SNAG_OK;
     return gemm_dispatch(d, (hipStream_t)stream);
+}
+
+extern "C" SNAG_API int snag_gemm_f32_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, void* stream) {
+    int rc = gemm_check(d0);
+    if (rc) return rc;
+    if ((rc = gemm_check(d1))) return rc;
+    const bool e0 = d0->M == 0 || d0->N == 0, e1 = d1->M == 0 || d1->N == 0;
+    if (e0 || e1) {
+        if (!e0) return gemm_dispatch(d0, (hipStream_t)stream);
+        if (!e1) return gemm_dispatch(d1, (hipStream_t)stream);
+        return SNAG_OK;
+    }
+    return gemm_dispatch_pair(d0, d1, (hipStream_t)stream);
 }
 
 extern "C" SNAG_API int snag_gram_f32(const float* Z, int64_t ldz, int n, int k, float alpha, float* S, int64_t lds, void* stream) {

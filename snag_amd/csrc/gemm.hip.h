@@ -488,11 +488,10 @@ struct GemmCore {
 };
 
 // One block = one BM x BN output tile (x one K split): main loop, then either the epilogue functor
-// epi(row, col, float4) or, for split-K, a raw store into this split's slab.
+// epi(row, col, float4) or, for split-K, a raw store into this split's slab (split index z).
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
-__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmOperands p, Epi epi, float* __restrict__ slab) {
+__device__ __forceinline__ void gemm_tile_body(const GemmOperands& p, const Epi& epi, float* __restrict__ slab, int z, float* smem) {
     using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
-    __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
     int bx = blockIdx.x, by = blockIdx.y;
     if (p.xcd) {
         const int id = xcd_swizzle(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
@@ -500,14 +499,14 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmOperands p, Epi epi,
         by = id / gridDim.x;
     }
     const int m0 = by * BM, n0 = bx * BN;
-    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kbeg = z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     Core core;
     core.run(p, smem, m0, n0, kbeg, kend);
     if (slab == nullptr) {
         core.for_each(smem, m0, n0, epi);
     } else {
-        float* s = slab + (int64_t)blockIdx.z * p.M * p.N;
+        float* s = slab + (int64_t)z * p.M * p.N;
         const int M = p.M, N = p.N;
         const bool vec = (N % 4) == 0;
         core.for_each(smem, m0, n0, [=](int m, int n, float4 v) {
@@ -523,6 +522,27 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmOperands p, Epi epi,
             }
         });
     }
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmOperands p, Epi epi, float* __restrict__ slab) {
+    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
+    __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
+    gemm_tile_body<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi>(p, epi, slab, blockIdx.z, smem);
+}
+
+// TWO problems of the same shape and layout in one launch (blockIdx.z = problem * splits + split): the step's many
+// [15000 x 128 x 128]-sized GEMMs are launch / prologue-bound grids of 235 workgroups (< 1 per CU); a pair of them --
+// the two modalities' second projections, their backward, the two D x D weight gradients of the read-out token --
+// fills the chip once instead of twice.
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
+__global__ __launch_bounds__(256) void gemm_tile_pair_kernel(GemmOperands p0, Epi e0, float* __restrict__ slab0, GemmOperands p1, Epi e1,
+                                                             float* __restrict__ slab1, int splits) {
+    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
+    __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
+    const int z = blockIdx.z % splits;
+    if (blockIdx.z < splits) gemm_tile_body<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi>(p0, e0, slab0, z, smem);
+    else gemm_tile_body<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi>(p1, e1, slab1, z, smem);
 }
 
 // Stream-K: G persistent blocks (512 = two per CU by default) share the (tile, k-tile) iteration space evenly, so every CU gets the same MFMA work whatever

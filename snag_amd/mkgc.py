@@ -215,7 +215,7 @@ class MKGCHotPath:
         self.joint = torch.zeros(Ns, M * D, device=dev) if self.concat else None
         self.d_x0 = torch.empty(Nl, M, D, device=dev)
         self.mid = [torch.empty(Nl, D, device=dev) for _ in cfg.feat_dims] if cfg.num_proj == 2 else []
-        self.d_mid = torch.empty(Nl, D, device=dev) if cfg.num_proj == 2 else None
+        self.d_mid = [torch.empty(Nl, D, device=dev) for _ in cfg.feat_dims] if cfg.num_proj == 2 else None
         self.repr_mean = torch.zeros(Ns, D, device=dev) if cfg.joint_way == "Mformer_hd_mean" else None
         # compact [rows, D] gradient of the read-out (hd_mean, read-out-only hd_graph): zeroed once here; afterwards whoever READS it
         # in the backward clears it behind itself (snag_fusion_bwd zero_d_hidden / snag_token_mean_bwd zero_src), so the fused
@@ -230,7 +230,7 @@ class MKGCHotPath:
         ws = lib.snag_fusion_work_floats(Nl, M, D, cfg.num_heads, I, L, int(ffn))
         for fd in cfg.feat_dims:
             ws = max(ws, lib.snag_gemm_workspace_floats(fd, D, Nl) + 64, lib.snag_gemm_workspace_floats(Nl, D, fd) + 64, 256 * max(D, fd))
-        ws = max(ws, lib.snag_gemm_workspace_floats(D, D, Nl) + 64, lib.snag_gemm_workspace_floats(Nl, D, D) + 64)
+        ws = max(ws, 2 * (lib.snag_gemm_workspace_floats(D, D, Nl) + 64), lib.snag_gemm_workspace_floats(Nl, D, D) + 64)
         self.work = torch.empty(ws, device=dev)
         H = cfg.num_heads
         # all dropout keep-masks of the step live in ONE byte buffer (views below), so one Philox launch draws them all
@@ -356,8 +356,16 @@ class MKGCHotPath:
         return self.train(False)
 
     # ------------------------------------------------------------------------------------------
-    def _gemm(self, M, N, K, A, lda, akc, B, ldb, bkc, C, ldc, *, bias=None, act=0, pre=None, add1=None, ld1=0,
-              aux=None, ldaux=0, splitk=True, keep=None, keep_scale=1.0):
+    def _gemm(self, *a, **k):
+        call("snag_gemm_f32", ctypes.byref(self._gemm_desc(*a, **k)), self._st)
+
+    def _gemm_pair(self, d0, d1):
+        """Two same-shaped GEMMs (the two modalities' second projections / their backward) as ONE launch: each is a grid of fewer
+        workgroups than the chip has CUs.  Split-K workspaces: the two halves of the engine's scratch."""
+        call("snag_gemm_f32_pair", ctypes.byref(d0), ctypes.byref(d1), self._st)
+
+    def _gemm_desc(self, M, N, K, A, lda, akc, B, ldb, bkc, C, ldc, *, bias=None, act=0, pre=None, add1=None, ld1=0,
+                   aux=None, ldaux=0, splitk=True, keep=None, keep_scale=1.0, half=None):
         d = _lib.GemmDesc()
         d.M, d.N, d.K = M, N, K
         d.a_kcontig, d.b_kcontig = int(akc), int(bkc)
@@ -368,8 +376,12 @@ class MKGCHotPath:
         if keep is not None:
             d.keep_mask, d.keep_scale = keep, keep_scale
         if splitk:
-            d.workspace, d.workspace_floats = ptr(self.work), self.work.numel()
-        call("snag_gemm_f32", ctypes.byref(d), self._st)
+            if half is None:
+                d.workspace, d.workspace_floats = ptr(self.work), self.work.numel()
+            else:                         # member `half` (0 / 1) of a pair: its own half of the scratch
+                n = self.work.numel() // 2 // 64 * 64
+                d.workspace, d.workspace_floats = self.work.data_ptr() + 4 * n * half, n
+        return d
 
     def _proj_keep(self, i):
         """Device pointer of modality i's ProjectionHead keep mask (None in eval mode / with proj_dropout = 0)."""
@@ -459,7 +471,12 @@ class MKGCHotPath:
                 pk = self._proj_keep(i)
                 self._probed(tag, self._gemm, Nl, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.l1"]), D, 0, ptr(self.mid[i]), D, act=1,
                              keep=pk, keep_scale=1.0 / (1.0 - cfg.proj_dropout))
-                self._gemm(Nl, D, D, ptr(self.mid[i]), D, 1, ptr(self.p[f"proj{i}.l2"]), D, 1, slot, MD)
+        if cfg.num_proj == 2:       # the second projections, two modalities per launch
+            l2 = [self._gemm_desc(Nl, D, D, ptr(self.mid[i]), D, 1, ptr(self.p[f"proj{i}.l2"]), D, 1, x0p + 4 * i * D, MD) for i in range(len(cfg.feat_dims))]
+            for i in range(0, len(l2) - 1, 2):
+                self._gemm_pair(l2[i], l2[i + 1])
+            if len(l2) % 2:
+                call("snag_gemm_f32", ctypes.byref(l2[-1]), st)
         call("snag_entity_token_fwd", self.p["ent"].data_ptr() + 4 * lo * D, Nl, D, (self.ent_noise.data_ptr() + 4 * lo * D) if noisy else None,
              (self.ent_noise_mask.data_ptr() + lo) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD, st)
         if self.training and cfg.dropout > 0:
@@ -593,6 +610,18 @@ class MKGCHotPath:
             else:
                 reducer.start(buckets[0])
             reducer.start(buckets[1])
+        nmod = len(cfg.feat_dims)
+        if cfg.num_proj == 2:
+            # dl2 = dTok^T mid and d mid = (dTok l2) * [mid > 0] (* keep): same shapes for every modality -> two per launch
+            dl2 = [self._gemm_desc(D, D, Nl, dx0 + 4 * i * D, MD, 0, ptr(self.mid[i]), D, 0, ptr(self.g[f"proj{i}.l2"]), D, splitk=True, half=i % 2)
+                   for i in range(nmod)]
+            dmid = [self._gemm_desc(Nl, D, D, dx0 + 4 * i * D, MD, 1, ptr(self.p[f"proj{i}.l2"]), D, 0, ptr(self.d_mid[i]), D, act=4, aux=ptr(self.mid[i]),
+                                    ldaux=D, keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout), splitk=False) for i in range(nmod)]
+            for group in (dl2, dmid):
+                for i in range(0, nmod - 1, 2):
+                    self._gemm_pair(group[i], group[i + 1])
+                if nmod % 2:
+                    call("snag_gemm_f32", ctypes.byref(group[-1]), st)
         for i, fd in enumerate(cfg.feat_dims):
             feat = self.noisy[i] if noisy else self.feats[i]
             dslot = dx0 + 4 * i * D
@@ -601,11 +630,7 @@ class MKGCHotPath:
                 self._gemm(fd, D, Nl, ptr(feat), fd, 0, dslot, MD, 0, ptr(self.g[f"proj{i}.weight"]), D, splitk=True)
                 call("snag_colsum", dslot, Nl, D, MD, ptr(self.g[f"proj{i}.bias"]), 0, wk, st)
             else:
-                self._gemm(D, D, Nl, dslot, MD, 0, ptr(self.mid[i]), D, 0, ptr(self.g[f"proj{i}.l2"]), D, splitk=True)
-                # d mid = (dTok l2) * [mid > 0]
-                self._gemm(Nl, D, D, dslot, MD, 1, ptr(self.p[f"proj{i}.l2"]), D, 0, ptr(self.d_mid), D, act=4, aux=ptr(self.mid[i]), ldaux=D,
-                           keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout))
-                self._gemm(fd, D, Nl, ptr(feat), fd, 0, ptr(self.d_mid), D, 0, ptr(self.g[f"proj{i}.l1"]), D, splitk=True)   # dl1^T [fd, D]
+                self._gemm(fd, D, Nl, ptr(feat), fd, 0, ptr(self.d_mid[i]), D, 0, ptr(self.g[f"proj{i}.l1"]), D, splitk=True)   # dl1^T [fd, D]
             if reducer is not None:
                 reducer.start(buckets[2 + i])
 

@@ -114,3 +114,57 @@ def test_gram_is_symmetric_and_matches_gemm(n, k, pad):
         assert torch.equal(torch.triu(s), torch.triu(full))
     else:
         assert float(s.abs().max()) == 0.0
+
+
+def _desc(a, b, out, a_kc, b_kc, ws=None, **kw):
+    from snag_amd import _lib
+    from snag_amd._lib import ptr
+    M, K = (a.shape if a_kc else (a.shape[1], a.shape[0]))
+    N = b.shape[0] if b_kc else b.shape[1]
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K, d.a_kcontig, d.b_kcontig = M, N, K, int(a_kc), int(b_kc)
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc, d.alpha = ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0), 1.0
+    for k, v in kw.items():
+        setattr(d, k, v)
+    if ws is not None:
+        d.workspace, d.workspace_floats = ptr(ws), ws.numel()
+    return d
+
+
+@pytest.mark.parametrize("shape,a_kc,b_kc,split", [((15000, 128, 128), True, True, False), ((15000, 128, 128), True, False, False),
+                                                   ((128, 128, 15000), False, False, True), ((333, 100, 77), True, True, False)])
+def test_gemm_pair_equals_two_single_launches(shape, a_kc, b_kc, split):
+    """snag_gemm_f32_pair: two same-shaped problems in one launch give the bits of two snag_gemm_f32 calls (with and without
+    split-K, with different epilogues per problem); different shapes fall back to two launches."""
+    import ctypes
+    from snag_amd import _lib
+    from snag_amd._lib import call, ptr, stream
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    mk = lambda r, c: torch.randn(r, c, generator=g).to(DEV)
+    A = [mk(*((M, K) if a_kc else (K, M))) for _ in range(2)]
+    B = [mk(*((N, K) if b_kc else (K, N))) for _ in range(2)]
+    bias = mk(1, N).reshape(N)
+    nws = _lib.load().snag_gemm_workspace_floats(M, N, K) if split else 0
+    ref, got = [], []
+    for single in (True, False):
+        outs = [torch.zeros(M, N, device=DEV) for _ in range(2)]
+        ws = [torch.empty(max(nws, 1), device=DEV) for _ in range(2)] if split else [None, None]
+        d0 = _desc(A[0], B[0], outs[0], a_kc, b_kc, ws[0], bias=ptr(bias), act=1)
+        d1 = _desc(A[1], B[1], outs[1], a_kc, b_kc, ws[1])
+        if single:
+            call("snag_gemm_f32", ctypes.byref(d0), stream())
+            call("snag_gemm_f32", ctypes.byref(d1), stream())
+            ref = outs
+        else:
+            call("snag_gemm_f32_pair", ctypes.byref(d0), ctypes.byref(d1), stream())
+            got = outs
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    ra = (A[1].double() if a_kc else A[1].double().t()) @ (B[1].double().t() if b_kc else B[1].double())
+    assert_close(got[1], ra, atol=2e-6 * K + 1e-5, rtol=2e-5)
+    # different shapes: still correct (two launches)
+    o2, o3 = torch.zeros(M, N, device=DEV), torch.zeros(64, 128, device=DEV)
+    a3, b3 = mk(64, 32), mk(128, 32)
+    call("snag_gemm_f32_pair", ctypes.byref(_desc(A[1], B[1], o2, a_kc, b_kc)), ctypes.byref(_desc(a3, b3, o3, True, True)), stream())
+    assert_close(o2, ra, atol=2e-6 * K + 1e-5, rtol=2e-5)
+    assert_close(o3, a3.double() @ b3.double().t(), atol=1e-4)
