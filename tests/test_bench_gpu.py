@@ -52,3 +52,24 @@ def test_bench_two_rank_dry_run(extra, scaling, per_gpu):
     assert o["n_gpus"] == 2 and o["scaling"] == scaling and o["config"]["batch_per_gpu"] == per_gpu and o["config"]["global_batch"] == 2 * per_gpu
     assert ("row-sharded" in o["config"]["fusion"]) == ("--replicate-fusion" not in extra)
     assert o["value"] == pytest.approx(2 * per_gpu * 4 / (o["ms_per_step"] * 4e-3), rel=1e-6) and o["config"]["final_loss"] > 0
+
+
+def test_bench_stress_config_single_and_two_rank_dry_run():
+    """bench.py --config stress (BASELINE configs[4]: 1M x 256 bf16 table, 128 negatives): one rank, and two ranks sharing the device over gloo
+    (row-owned optimiser state, reduce-scatter / all-gather phases reported separately)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "stress", "--steps", "4", "--warmup", "2", "--cpu-seconds", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    o = _json_line(p.stdout)
+    assert o["n_gpus"] == 1 and o["config"]["n_ent"] == 1_000_000 and o["roofline"]["bound"] == "hbm" and 0 < o["roofline"]["frac"] < 1
+    assert o["phases_us"]["compute_us"] > 0 and o["phases_us"]["comm_bytes_per_rank"]["all_gather_bf16"] == 0
+    env["BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "stress", "--steps", "3", "--warmup", "1", "--batch", "256",
+           "--cpu-seconds", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    o = _json_line(p.stdout)
+    assert o["n_gpus"] == 2 and o["config"]["global_batch"] == 512
+    assert o["phases_us"]["comm_bytes_per_rank"]["reduce_scatter_fp32"] == 500_000 * 256 * 4 and o["phases_us"]["comm_us"] > 0
