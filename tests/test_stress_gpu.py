@@ -208,3 +208,39 @@ def test_two_rank_row_sharded_stress_step(tmp_path, N):
     same = (_bits(got[0]["ent16"][:N]) == _bits(eng.ent16[:N].cpu())).float().mean()
     assert float(same) > 0.9999                                                                  # bf16 rounding of fp32 values equal to ~1e-6
     assert_close(got[0]["rel"], eng.rel_master, atol=2e-6, rtol=1e-5)
+
+
+def test_stress_full_size_properties():
+    """BASELINE configs[4] at its full size (|E| = 1M, dim 256, 128 negative tails, B = 1024) through size-independent properties: scores
+    do not change when a table is scaled (rows are L2-normalised; a power of two is exact in bf16), a negative equal to the positive tail
+    scores like it, repeated steps on one batch lower its loss, rows no triple touched move by the decoupled weight decay alone (their
+    Adam moments stay zero), the bf16 table is the rounding of the master rows, and the scatter target is clean again after the step."""
+    from snag_amd.stress import StressConfig, StressHotPath
+    from snag_amd._lib import call, ptr, stream
+    cfg = StressConfig(lr=1e-3, weight_decay=1e-2)
+    eng = StressHotPath(cfg, device=DEV)
+    N, R, K, B = cfg.n_ent, cfg.n_rel, cfg.neg_num, 1024
+    g = torch.Generator().manual_seed(12)
+    h, r, t = (torch.randint(0, hi, (B,), generator=g, dtype=torch.int32).to(DEV) for hi in (N, R, N))
+    neg = torch.randint(0, N, (B, K), generator=g, dtype=torch.int32).to(DEV)
+    neg[:, 7] = t
+    pos, ng, loss0 = eng.score(h, r, t, neg)
+    pos, ng, loss0 = pos.clone(), ng.clone(), float(loss0)
+    assert torch.equal(ng[:, 7], pos) and float(pos.min()) >= 0.0 and float(ng.max()) <= 9.0 + 1e-4
+    saved = eng.ent16.clone()
+    eng.ent16.mul_(4.0)                                                    # exact in bf16
+    pos2, ng2, _ = eng.score(h, r, t, neg)
+    assert torch.equal(pos2, pos) and torch.equal(ng2, ng)
+    eng.ent16.copy_(saved)
+    master0 = eng.ent_master.clone()
+    touched = torch.zeros(N, dtype=torch.bool, device=DEV)
+    touched[torch.cat([h, t, neg.flatten()]).long()] = True
+    losses = [float(eng.train_step(h, r, t, neg)) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert abs(losses[0] - loss0) <= 1e-5 * loss0 and losses[2] < losses[0]
+    assert float(eng.d_ent_full.abs().max()) == 0.0
+    quiet = (~touched).nonzero().flatten()[:200_000]
+    decay = (1.0 - cfg.lr * cfg.weight_decay) ** 3
+    assert_close(eng.ent_master[quiet], master0[quiet] * decay, atol=1e-7, rtol=1e-6, what="untouched rows: weight decay only")
+    assert float((eng.ent_master[touched] - master0[touched] * decay).abs().max()) > 1e-5           # the touched ones did learn
+    assert torch.equal(_bits(eng.ent16[:N][quiet].cpu()), _bits(eng.ent_master[quiet].cpu().bfloat16()))
