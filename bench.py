@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 #   row-sharded: only clip + AdamW over the full 10.9 MB flat buffer (~40 us) is repeated.
 REPLICATED_FRACTION_REPLICATED = 0.96
 REPLICATED_FRACTION_SHARDED = 0.05
+SPLIT_PROLOGUE = bool(os.environ.get("BENCH_SPLIT_PROLOGUE"))
 STEPS_PER_EPOCH = 78          # 79,222 DB15K training triples / 1024  (SURVEY.md par. 8d)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
@@ -530,8 +531,10 @@ def main():
         if cfg.add_noise and i % STEPS_PER_EPOCH == 0:
             eng.update_noise()
         h, r, t = batches[i % len(batches)]
-        ops.sample_negatives(h, r, t, cfg.neg_num, cfg.n_ent, cfg.n_rel, rank_seed, known_sorted=known, tick=eng.tick, out=neg_buf)
-        eng.forward(h, r, t, neg_buf, with_backward=True, grad_scale=gscale)   # the scorer runs fwd+bwd as one launch here
+        # negatives are drawn by the step's first launch (snag_step_prologue); the scorer runs fwd+bwd as one launch
+        if SPLIT_PROLOGUE:      # A/B: the sampler as its own launch
+            ops.sample_negatives(h, r, t, cfg.neg_num, cfg.n_ent, cfg.n_rel, rank_seed, known_sorted=known, tick=eng.tick, out=neg_buf)
+        eng.forward(h, r, t, neg_buf, with_backward=True, grad_scale=gscale, sample=None if SPLIT_PROLOGUE else (rank_seed, known))
         eng.backward(gscale, reducer=reducer)         # buckets go out as they become final (overlaps the projection backward)
         if reducer is not None:
             reducer.finish()
@@ -544,8 +547,7 @@ def main():
         timers = {}
         if cfg.add_noise:
             eng.update_noise()
-        eng.capture_step(args.batch, cfg.neg_num, sampler=lambda h, r, t, out: ops.sample_negatives(
-            h, r, t, cfg.neg_num, cfg.n_ent, cfg.n_rel, rank_seed, known_sorted=known, tick=eng.tick, out=out))
+        eng.capture_step(args.batch, cfg.neg_num, sample=(rank_seed, known))
 
         def one_step(i):                                  # noqa: F811  (graph replay variant)
             if cfg.add_noise and i % STEPS_PER_EPOCH == 0 and i > 0:

@@ -443,6 +443,15 @@ SNAG_API int snag_sample_negatives(uint64_t seed, const uint64_t* tick, const in
                                    int64_t batch, int n_neg, int n_ent, int n_rel, int mode, const int64_t* known_sorted,
                                    int64_t n_known, int32_t* neg_h, int32_t* neg_t, void* stream);
 
+/* ONE launch for the three independent, small launches that open an MKGC training step: snag_sample_negatives (mode 0: negative
+ * tails; same Philox stream, same results), snag_entity_token_fwd (the structural token with the noise blend) and
+ * snag_dropout_keep_mask (the step's Bert dropout masks).  Workgroup ranges of the one grid run the three bodies side by side; any
+ * part is skipped when its size is zero (batch * n_neg, n_rows, drop_n). */
+SNAG_API int snag_step_prologue(uint64_t sample_seed, const uint64_t* tick, const int32_t* h, const int32_t* r, const int32_t* t, int64_t batch,
+                                int n_neg, int n_ent, int n_rel, const int64_t* known_sorted, int64_t n_known, int32_t* neg_t,
+                                const float* table, int64_t n_rows, int dim, const float* noise, const uint8_t* noise_mask, float half_mask_ratio,
+                                float* tok, int64_t tok_ld, uint64_t drop_seed, int64_t drop_n, float drop_p, uint8_t* drop_out, void* stream);
+
 /* The same sampler with the two in-tree properties snag_sample_negatives gives up: candidates are drawn from the KG's OWN entity
  * list ent_list [n_list] (int32 ids; NULL = 0..n_ent-1; model/MSNEA_tools.py:64-65) and the n_neg negatives of one positive are
  * DISTINCT (random.sample draws without replacement, :69,:72).  Rounds = the reference's 10 tries: in round a slot k of positive

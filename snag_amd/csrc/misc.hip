@@ -21,9 +21,9 @@ __device__ __forceinline__ float4 normal4(uint64_t seed, uint64_t ctr) {
 }
 
 // keep[i] = (u >= p): the inverted-dropout keep mask of nn.Dropout(p)
-__global__ __launch_bounds__(256) void bernoulli_keep_kernel(uint64_t seed, const uint64_t* __restrict__ tick, int64_t n, float p,
-                                                             uint8_t* __restrict__ out) {
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one Philox draw = 4 elements
+__device__ __forceinline__ void bernoulli_keep_body(int64_t vblock, uint64_t seed, const uint64_t* __restrict__ tick, int64_t n, float p,
+                                                    uint8_t* __restrict__ out) {
+    const int64_t q = vblock * 256 + threadIdx.x;       // one Philox draw = 4 elements
     if (q * 4 >= n) return;
     if (tick != nullptr) seed += tick[0] * 0x9E3779B97F4A7C15ull;    // a fresh stream per training step inside a replayed graph
     const Philox4 r = philox4x32_10(seed, (uint64_t)q);
@@ -31,6 +31,11 @@ __global__ __launch_bounds__(256) void bernoulli_keep_kernel(uint64_t seed, cons
 #pragma unroll
     for (int e = 0; e < 4; ++e)
         if (q * 4 + e < n) out[q * 4 + e] = u01(rr[e]) >= p ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void bernoulli_keep_kernel(uint64_t seed, const uint64_t* __restrict__ tick, int64_t n, float p,
+                                                             uint8_t* __restrict__ out) {
+    bernoulli_keep_body(blockIdx.x, seed, tick, n, p, out);
 }
 
 // out[n, c] = mean[c] + std[c] * z    (model/SNAG.py:96)
@@ -209,11 +214,11 @@ __global__ void tick_kernel(uint64_t* tick) {
 }
 
 // structural token: out[n*ld + :] = blend(table[n,:])   (model/SNAG_tools.py:127-128)
-__global__ __launch_bounds__(256) void entity_token_fwd_kernel(const float* __restrict__ table, int64_t N, int D,
-                                                               const float* __restrict__ noise, const uint8_t* __restrict__ nmask,
-                                                               float a, float* __restrict__ out, int64_t ld) {
+__device__ __forceinline__ void entity_token_fwd_body(int64_t vblock, int64_t vgrid, const float* __restrict__ table, int64_t N, int D,
+                                                      const float* __restrict__ noise, const uint8_t* __restrict__ nmask,
+                                                      float a, float* __restrict__ out, int64_t ld) {
     const int64_t total = N * (int64_t)D;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = vblock * 256 + threadIdx.x; i < total; i += vgrid * 256) {
         const int64_t n = i / D;
         const int c = (int)(i % D);
         float v = table[i];
@@ -222,16 +227,22 @@ __global__ __launch_bounds__(256) void entity_token_fwd_kernel(const float* __re
     }
 }
 
+__global__ __launch_bounds__(256) void entity_token_fwd_kernel(const float* __restrict__ table, int64_t N, int D,
+                                                               const float* __restrict__ noise, const uint8_t* __restrict__ nmask,
+                                                               float a, float* __restrict__ out, int64_t ld) {
+    entity_token_fwd_body(blockIdx.x, gridDim.x, table, N, D, noise, nmask, a, out, ld);
+}
+
 // On-device negative sampling (in-tree sampler: generate_neg_triples_fast, model/MSNEA_tools.py:59-90).
 // One thread per (positive b, slot k).  mode 0 corrupts the tail only (MKGC: NEG_NUM negative tails); mode 1 flips a
 // Bernoulli(0.5) coin per POSITIVE (as the reference does, :68) between corrupting the head and the tail.  A candidate
 // that forms a known triple is rejected and redrawn, up to 10 tries, the last try is kept whatever it is (:66-76).
 // known: sorted int64 keys (h * n_rel + r) * n_ent + t, or NULL for no filtering.
-__global__ __launch_bounds__(256) void sample_negatives_kernel(uint64_t seed, const uint64_t* __restrict__ tick, const int32_t* __restrict__ h,
-                                                               const int32_t* __restrict__ r, const int32_t* __restrict__ t, int64_t B, int K,
-                                                               int n_ent, int n_rel, int mode, const int64_t* __restrict__ known, int64_t n_known,
-                                                               int32_t* __restrict__ neg_h, int32_t* __restrict__ neg_t) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void sample_negatives_body(int64_t vblock, uint64_t seed, const uint64_t* __restrict__ tick, const int32_t* __restrict__ h,
+                                                      const int32_t* __restrict__ r, const int32_t* __restrict__ t, int64_t B, int K,
+                                                      int n_ent, int n_rel, int mode, const int64_t* __restrict__ known, int64_t n_known,
+                                                      int32_t* __restrict__ neg_h, int32_t* __restrict__ neg_t) {
+    const int64_t i = vblock * 256 + threadIdx.x;
     if (i >= B * K) return;
     if (tick != nullptr) seed += tick[0] * 0x9E3779B97F4A7C15ull;
     const int64_t b = i / K;
@@ -248,6 +259,35 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(uint64_t seed, co
     }
     if (neg_h != nullptr) neg_h[i] = corrupt_head ? cand : hb;
     neg_t[i] = corrupt_head ? tb : cand;
+}
+
+__global__ __launch_bounds__(256) void sample_negatives_kernel(uint64_t seed, const uint64_t* __restrict__ tick, const int32_t* __restrict__ h,
+                                                               const int32_t* __restrict__ r, const int32_t* __restrict__ t, int64_t B, int K,
+                                                               int n_ent, int n_rel, int mode, const int64_t* __restrict__ known, int64_t n_known,
+                                                               int32_t* __restrict__ neg_h, int32_t* __restrict__ neg_t) {
+    sample_negatives_body(blockIdx.x, seed, tick, h, r, t, B, K, n_ent, n_rel, mode, known, n_known, neg_h, neg_t);
+}
+
+// The three launches that open an MKGC training step -- negative sampling (a dependent chain of ~20 loads per thread in 128
+// workgroups), the structural token (7.7 MB copy + noise blend) and the Philox dropout masks -- are independent of each other and
+// each far too small to fill 256 CUs: ONE launch whose workgroup ranges run the three bodies side by side (11.9 + 6.7 + 5.8 us of
+// serial launches -> the longest of the three).  Same arithmetic, same Philox streams as the separate kernels.
+struct PrologueArgs {
+    // sampler (blocks [0, nb_s))
+    uint64_t s_seed; const uint64_t* tick; const int32_t *h, *r, *t; int64_t B; int K, n_ent, n_rel, mode; const int64_t* known; int64_t n_known;
+    int32_t *neg_h, *neg_t;
+    // structural token (blocks [nb_s, nb_s + nb_e))
+    const float* table; int64_t N; int D; const float* noise; const uint8_t* nmask; float a; float* tok; int64_t tok_ld;
+    // dropout masks (the rest)
+    uint64_t d_seed; int64_t d_n; float d_p; uint8_t* d_out;
+    int nb_s, nb_e;
+};
+
+__global__ __launch_bounds__(256) void step_prologue_kernel(PrologueArgs a) {
+    const int b = blockIdx.x;
+    if (b < a.nb_s) sample_negatives_body(b, a.s_seed, a.tick, a.h, a.r, a.t, a.B, a.K, a.n_ent, a.n_rel, a.mode, a.known, a.n_known, a.neg_h, a.neg_t);
+    else if (b < a.nb_s + a.nb_e) entity_token_fwd_body(b - a.nb_s, a.nb_e, a.table, a.N, a.D, a.noise, a.nmask, a.a, a.tok, a.tok_ld);
+    else bernoulli_keep_body(b - a.nb_s - a.nb_e, a.d_seed, a.tick, a.d_n, a.d_p, a.d_out);
 }
 
 static int grid_for(int64_t n) { return (int)std::min<int64_t>(4096, (n + 255) / 256); }
@@ -479,6 +519,31 @@ extern "C" SNAG_API int snag_build_filter_mask(const int32_t* h, const int32_t* 
     if (n_known > 0)
         hipLaunchKernelGGL(filter_mask_kernel, dim3((unsigned)ceil_div(batch, 4)), dim3(256), 0, st, h, r, t, batch, n_ent, n_rel, known_sorted, n_known, mask);
     return check_launch("snag_build_filter_mask");
+}
+
+extern "C" SNAG_API int snag_step_prologue(uint64_t sample_seed, const uint64_t* tick, const int32_t* h, const int32_t* r, const int32_t* t, int64_t batch,
+                                           int n_neg, int n_ent, int n_rel, const int64_t* known_sorted, int64_t n_known, int32_t* neg_t,
+                                           const float* table, int64_t n_rows, int dim, const float* noise, const uint8_t* noise_mask, float half_mask_ratio,
+                                           float* tok, int64_t tok_ld, uint64_t drop_seed, int64_t drop_n, float drop_p, uint8_t* drop_out, void* stream) {
+    SNAG_REQUIRE(batch >= 0 && n_neg >= 0 && n_ent >= 1 && n_rel >= 1 && n_rows >= 0 && dim >= 1 && drop_n >= 0, SNAG_ERR_ARG, "step_prologue: bad sizes");
+    SNAG_REQUIRE(batch * n_neg == 0 || (h && r && t && neg_t), SNAG_ERR_ARG, "step_prologue: null sampler pointer");
+    SNAG_REQUIRE((known_sorted != nullptr) == (n_known > 0), SNAG_ERR_ARG, "step_prologue: known_sorted and n_known go together");
+    SNAG_REQUIRE(n_rows == 0 || (table && tok && tok_ld >= dim), SNAG_ERR_ARG, "step_prologue: null structural-token pointer");
+    SNAG_REQUIRE((noise == nullptr) == (noise_mask == nullptr), SNAG_ERR_ARG, "step_prologue: noise and noise_mask go together");
+    SNAG_REQUIRE(drop_n == 0 || (drop_out && drop_p >= 0.f && drop_p < 1.f), SNAG_ERR_ARG, "step_prologue: bad dropout arguments");
+    SNAG_REQUIRE((int64_t)n_ent * n_rel < (1LL << 62) / n_ent, SNAG_ERR_UNSUPPORTED, "step_prologue: triple key overflows int64");
+    PrologueArgs a{};
+    a.s_seed = sample_seed; a.tick = tick; a.h = h; a.r = r; a.t = t; a.B = batch; a.K = n_neg; a.n_ent = n_ent; a.n_rel = n_rel; a.mode = 0;
+    a.known = known_sorted; a.n_known = n_known; a.neg_h = nullptr; a.neg_t = neg_t;
+    a.table = table; a.N = n_rows; a.D = dim; a.noise = noise; a.nmask = noise_mask; a.a = half_mask_ratio; a.tok = tok; a.tok_ld = tok_ld;
+    a.d_seed = drop_seed; a.d_n = drop_n; a.d_p = drop_p; a.d_out = drop_out;
+    a.nb_s = (int)((batch * n_neg + 255) / 256);
+    a.nb_e = n_rows > 0 ? grid_for(n_rows * (int64_t)dim) : 0;
+    const int nb_d = (int)((drop_n + 1023) / 1024);
+    const int total = a.nb_s + a.nb_e + nb_d;
+    if (total == 0) return SNAG_OK;
+    hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("snag_step_prologue");
 }
 
 extern "C" SNAG_API int snag_sample_negatives(uint64_t seed, const uint64_t* tick, const int32_t* h, const int32_t* r, const int32_t* t, int64_t batch,

@@ -446,11 +446,15 @@ class MKGCHotPath:
         self.d_hidden.zero_()
         return self.d_hidden.data_ptr() + 4 * self.g_slot * cfg.dim, cfg.n_tokens * cfg.dim
 
-    def forward(self, h, r, t, neg_t, want_scores=False, with_backward=False, grad_scale=1.0):
+    def forward(self, h, r, t, neg_t, want_scores=False, with_backward=False, grad_scale=1.0, sample=None):
         """Projections -> tokens -> fusion -> read-out -> scores/loss.  Returns the device scalar loss.
 
         ``with_backward``: a ``backward(grad_scale)`` follows (training).  The hinge scorer then runs forward and backward as ONE
-        launch here (snag_score_margin_fwd_bwd) and ``backward`` starts at the read-out gradient."""
+        launch here (snag_score_margin_fwd_bwd) and ``backward`` starts at the read-out gradient.
+
+        ``sample=(seed, known_sorted)``: ``neg_t`` is an OUTPUT -- the step's negative tails are drawn into it by the same launch
+        that writes the structural token and the dropout masks (snag_step_prologue; the draws are those of
+        ``ops.sample_negatives(h, r, t, ..., seed, known_sorted, tick=self.tick)``)."""
         cfg = self.cfg
         N, D, M = cfg.n_ent, cfg.dim, cfg.n_tokens
         Nl, lo = self.shard.n_loc, self.shard.lo               # this rank's entity rows (all of them with one rank)
@@ -460,6 +464,18 @@ class MKGCHotPath:
             call("snag_dropout_keep_mask", cfg.seed + 3 + 7919 * self.shard.rank, ptr(self.tick), self.keep_proj.numel(), cfg.proj_dropout, ptr(self.keep_proj), st)
         MD = M * D
         x0p = self.x0.data_ptr()
+        # one launch: (negative tails,) structural token, Bert dropout masks -- three independent, under-filled grids side by side
+        drop = self.training and cfg.dropout > 0
+        B = int(h.shape[0])
+        if sample is not None and B * cfg.neg_num > 0:
+            s_seed, known = sample
+            assert neg_t.dtype == torch.int32 and neg_t.is_contiguous() and tuple(neg_t.shape) == (B, cfg.neg_num)
+            s_args = (int(s_seed), ptr(self.tick), ptr(h), ptr(r), ptr(t), B, cfg.neg_num, N, cfg.n_rel, ptr(known), 0 if known is None else known.numel(), ptr(neg_t))
+        else:
+            s_args = (0, ptr(self.tick), None, None, None, 0, 0, N, cfg.n_rel, None, 0, None)
+        call("snag_step_prologue", *s_args, self.p["ent"].data_ptr() + 4 * lo * D, Nl, D, (self.ent_noise.data_ptr() + 4 * lo * D) if noisy else None,
+             (self.ent_noise_mask.data_ptr() + lo) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD,
+             cfg.seed + 1 + 7919 * self.shard.rank, self.keep_all.numel() if drop else 0, cfg.dropout if drop else 0.0, ptr(self.keep_all) if drop else None, st)
         for i, fd in enumerate(cfg.feat_dims):
             feat_t = self.noisy_t[i] if noisy else self.feats_t[i]          # [fd, Nl]
             slot = x0p + 4 * i * D
@@ -477,10 +493,6 @@ class MKGCHotPath:
                 self._gemm_pair(l2[i], l2[i + 1])
             if len(l2) % 2:
                 call("snag_gemm_f32", ctypes.byref(l2[-1]), st)
-        call("snag_entity_token_fwd", self.p["ent"].data_ptr() + 4 * lo * D, Nl, D, (self.ent_noise.data_ptr() + 4 * lo * D) if noisy else None,
-             (self.ent_noise_mask.data_ptr() + lo) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD, st)
-        if self.training and cfg.dropout > 0:
-            call("snag_dropout_keep_mask", cfg.seed + 1 + 7919 * self.shard.rank, ptr(self.tick), self.keep_all.numel(), cfg.dropout, ptr(self.keep_all), st)
         call("snag_fusion_fwd", ctypes.byref(self._fdesc), st)
         if cfg.joint_way == "Mformer_hd_mean":
             call("snag_token_mean", ptr(self.hidden), Nl, M, D, ptr(self.repr_mean), st)
@@ -647,9 +659,10 @@ class MKGCHotPath:
         if not advanced:
             call("snag_tick", ptr(self.tick), self._st)
 
-    def train_step(self, h, r, t, neg_t, allreduce=None):
-        """forward + backward (+ gradient exchange) + AdamW.  ``allreduce(gflat)`` sums gradients across ranks."""
-        self.forward(h, r, t, neg_t, with_backward=True)
+    def train_step(self, h, r, t, neg_t, allreduce=None, sample=None):
+        """forward + backward (+ gradient exchange) + AdamW.  ``allreduce(gflat)`` sums gradients across ranks.
+        ``sample=(seed, known_sorted)``: the negatives are drawn into ``neg_t`` by the step's first launch (see ``forward``)."""
+        self.forward(h, r, t, neg_t, with_backward=True, sample=sample)
         if allreduce is not None and hasattr(allreduce, "start"):
             self.backward(reducer=allreduce)
             allreduce.finish()
@@ -688,21 +701,20 @@ class MKGCHotPath:
         for lo, hi in (step_bounds(n, steps) if dp else [(lo, min(n, lo + batch_size)) for lo in range(0, n, batch_size)]):
             idx = perm[lo:hi]
             hb, rb, tb = h[idx].contiguous(), r[idx].contiguous(), t[idx].contiguous()
-            if hi > lo:
-                neg = ops.sample_negatives(hb, rb, tb, self.cfg.neg_num, self.cfg.n_ent, self.cfg.n_rel, sample_seed, known_sorted=known_sorted, tick=self.tick)
-            else:       # a rank with fewer items than steps: zero-gradient step, still part of every collective
-                neg = torch.empty(0, self.cfg.neg_num, device=self.dev, dtype=torch.int32)
-            total += self.train_step(hb, rb, tb, neg, allreduce=allreduce)
+            # drawn by the step's first launch; a rank with fewer items than steps runs a zero-gradient step, still part of every collective
+            neg = torch.empty(hi - lo, self.cfg.neg_num, device=self.dev, dtype=torch.int32)
+            total += self.train_step(hb, rb, tb, neg, allreduce=allreduce, sample=(sample_seed, known_sorted))
         return total
 
     # ---- hipGraph replay of the whole step ------------------------------------------------------------------------------
-    def capture_step(self, batch, n_neg, sampler=None):
+    def capture_step(self, batch, n_neg, sampler=None, sample=None):
         """Record forward + backward + clip + AdamW (and, when ``sampler`` is given, the on-device negative sampling) ONCE as a
         hipGraph over static index buffers; ``replay_step(h, r, t)`` then costs three small copies and one graph launch on the
         host.  Everything that varies per step already lives on the device: dropout seeds and Adam's bias correction read the
         tick counter, the clip coefficient never leaves HBM.  Single-process only (collectives are not captured); the epoch-level
         ``update_noise`` stays outside the graph (it writes the same buffers the graph reads).
-        ``sampler(h, r, t, out)`` must enqueue on the current stream without allocating."""
+        ``sampler(h, r, t, out)`` must enqueue on the current stream without allocating; ``sample=(seed, known_sorted)`` instead
+        draws the negatives in the step's first launch (see ``forward``)."""
         dev = self.dev
         self._g_h = torch.zeros(batch, device=dev, dtype=torch.int32)
         self._g_r = torch.zeros(batch, device=dev, dtype=torch.int32)
@@ -713,7 +725,7 @@ class MKGCHotPath:
         def body():
             if sampler is not None:
                 sampler(self._g_h, self._g_r, self._g_t, self._g_neg)
-            self.train_step(self._g_h, self._g_r, self._g_t, self._g_neg)
+            self.train_step(self._g_h, self._g_r, self._g_t, self._g_neg, sample=sample)
 
         tick0 = self.tick.clone()
         snap = (self.flat.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone())

@@ -417,3 +417,31 @@ def test_checkpoint_resume_is_exact_and_fusion_keys_are_the_references(tmp_path)
     other.load_fusion_state_dict({k: v.to(DEV) for k, v in mod.state_dict().items()})
     for k in ("weight_raw", "layer0.wqkv", "layer0.bqkv", "layer0.wo", "layer0.ln1_g", "layer0.w1", "layer0.b2", "layer0.ln2_b"):
         assert torch.equal(other.p[k], straight.p[k]), k
+
+
+def test_step_prologue_draws_the_sampler_stream():
+    """forward(sample=(seed, known)) -- negatives drawn by the step's first launch -- equals ops.sample_negatives followed by the same step."""
+    from snag_amd import ops
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    n_ent, B, K = 700, 96, 16
+    g = torch.Generator().manual_seed(3)
+    feats = [torch.rand(n_ent, 96, generator=g), torch.randn(n_ent, 64, generator=g)]
+    hrt = [torch.randint(0, hi, (B,), generator=g, dtype=torch.int32).cuda() for hi in (n_ent, 11, n_ent)]
+    known = torch.unique((hrt[0].long() * 11 + hrt[1].long()) * n_ent + hrt[2].long())
+    res = []
+    for fused in (False, True):
+        cfg = MKGCConfig(n_ent=n_ent, n_rel=11, dim=64, feat_dims=[96, 64], num_proj=2, margin=6.0, neg_num=K, dropout=0.1, add_noise=1, seed=9, lr=1e-3)
+        eng = MKGCHotPath(cfg, feats, device="cuda")
+        eng.update_noise()
+        neg = torch.full((B, K), -1, device="cuda", dtype=torch.int32)
+        for _ in range(2):                  # two steps: the tick-dependent streams advance the same way
+            if fused:
+                loss = eng.train_step(*hrt, neg, sample=(77, known))
+            else:
+                ops.sample_negatives(*hrt, K, n_ent, 11, 77, known_sorted=known, tick=eng.tick, out=neg)
+                loss = eng.train_step(*hrt, neg)
+        torch.cuda.synchronize()
+        res.append((neg.cpu(), float(loss), eng.flat.cpu(), eng.keep_all.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and int(res[0][0].min()) >= 0
+    assert torch.equal(res[0][3], res[1][3])
+    assert res[0][1] == res[1][1] and torch.equal(res[0][2], res[1][2])
