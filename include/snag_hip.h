@@ -178,7 +178,13 @@ SNAG_API int snag_rank_full_table(const float* scores, int64_t batch, int64_t n_
 SNAG_API int snag_reduce_sum(const float* x, int64_t n, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Dense fp32 contraction on the exact-f32 matrix cores (v_mfma_f32_32x32x2_f32).
+ * Dense fp32 contraction on the matrix cores.  fp32 in, fp32 out, fp32 accumulation; the multiplies run as split-bf16 MFMA:
+ * every operand value is split EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits, a = h + m + l) in registers and a
+ * product a*b is the sum of the six bf16 x bf16 products of weight >= 2^-16 (v_mfma_f32_32x32x16_bf16; the three dropped ones are
+ * below 2^-23 |a*b|, the size of fp32's own product rounding).  On gfx950 the bf16 matrix rate is 16x the f32 one
+ * (v_mfma_f32_32x32x2_f32), so six products cost 3/8 of the f32-MFMA time; the measured error against an fp64 product is the
+ * f32-MFMA chain's or smaller (tools/probe_gemm_accuracy.py, DESIGN.md par. 5).  Build with -DSNAG_GEMM_BF16X=0 for the f32 MFMA
+ * form, =9 for all nine products.
  * Replaces the aten addmm/mm calls of the path: per-modality projections nn.Linear(F_m, D)
  * (model/SNAG_tools.py:92-96,134-150), ProjectionHead (model/layers.py:135-148), the Mformer
  * linears (model/SNAG_tools.py:183-186,219,251,263) and their autograd.

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(GemmOperands p, float al
     while (by > 0 && by * T - by * (by - 1) / 2 > k) --by;
     while (by + 1 < T && (by + 1) * T - (by + 1) * by / 2 <= k) ++by;
     const int bx = by + (k - (by * T - by * (by - 1) / 2));
-    using Core = GemmCore<128, 128, 64, 64, true, true, false>;
+    using Core = GemmCore<128, 128, 64, 64, true, true, false, true>;      // SYM: S[i][j] == S[j][i] inside the diagonal tiles too
     constexpr int kSmem = Core::SMEM_FLOATS > Core::kTransposeStageFloats ? Core::SMEM_FLOATS : Core::kTransposeStageFloats;
     __shared__ __attribute__((aligned(16))) float smem[kSmem];
     const int m0 = by * 128, n0 = bx * 128;

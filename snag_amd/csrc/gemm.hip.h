@@ -54,6 +54,18 @@ __host__ __device__ constexpr int swz(int row) { return kBK == 16 ? ((row >> 2) 
 #ifndef SNAG_GEMM_DMA
 #define SNAG_GEMM_DMA 1
 #endif
+//   SNAG_GEMM_BF16X 0: v_mfma_f32_32x32x2_f32 on the f32 operands (157 TF peak)
+//                   6: every operand value is split EXACTLY into three bf16 pieces a = h + m + l (round-to-nearest each time, the
+//                      two remainders are exact in f32) in registers, and a product a*b becomes the six bf16 MFMA products with weight
+//                      >= 2^-16: h*h, h*m, m*h, m*m, h*l, l*h (v_mfma_f32_32x32x16_bf16, f32 accumulation; the three dropped
+//                      products m*l, l*m, l*l are below 2^-23 of a*b -- the size of f32's own product rounding).  The bf16 matrix
+//                      rate is 16x the f32 one, so six products still cost 3/8 of the f32 MFMA time.
+//                   9: all nine products
+#ifndef SNAG_GEMM_BF16X
+#define SNAG_GEMM_BF16X 6
+#endif
+constexpr int kBf16x = SNAG_GEMM_BF16X;
+static_assert(kBf16x == 0 || kBf16x == 6 || kBf16x == 9, "SNAG_GEMM_BF16X");
 constexpr bool kDma = (SNAG_GEMM_DMA != 0) && (SNAG_GEMM_SWZ != 0);
 constexpr bool kSwz = SNAG_GEMM_SWZ != 0;
 constexpr bool kPipe = SNAG_GEMM_PIPE != 0;
@@ -259,9 +271,36 @@ __device__ __forceinline__ void load_fragments(const lds_float* tile, int row0, 
     }
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+#else
+struct bf16x8 { unsigned short v[8]; };
+#endif
+// a = h + m + l exactly (8 + 8 + 8 significand bits); f[j] is the lane's value for element j of the 32x32x16 operand
+struct Split3 {
+    bf16x8 h, m, l;
+    __device__ __forceinline__ void from(const float (&f)[8]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const __bf16 hj = (__bf16)f[j];
+            const float r1 = f[j] - (float)hj;
+            const __bf16 mj = (__bf16)r1;
+            const float r2 = r1 - (float)mj;
+            h[j] = hj;
+            m[j] = mj;
+            l[j] = (__bf16)r2;
+        }
+#endif
+    }
+};
+
 // Main loop.  acc[mi][ni] is the 32x32 tile (mi, ni) of this wave's WM x WN patch:
 //   row = wm0 + 32*mi + (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5),  col = wn0 + 32*ni + (lane & 31).
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC>
+// SYM (split-bf16 builds): C(a, b) == C(b, a) bit for bit.  The six products are not symmetric one by one (h*m <-> m*h, h*l <-> l*h
+// under an exchange of the operands) and f32 addition is not associative, so the two mirrored families accumulate in two extra
+// accumulator sets that exchange roles with the operands, and meet in one commutative addition at the end.
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, bool SYM = false>
 struct GemmCore {
     static constexpr int TM = WM / 32, TN = WN / 32;
     static constexpr int A_BUF = TileLd<BM, A_KC>::floats, B_BUF = TileLd<BN, B_KC>::floats, B_BASE = 2 * A_BUF;
@@ -272,8 +311,94 @@ struct GemmCore {
     static_assert((BM / WM) * (BN / WN) == 4, "four waves per block");
 
     f32x16 acc[TM][TN];
+    static constexpr bool kSym = SYM && kBf16x != 0;
+    f32x16 accx[kSym ? TM : 1][kSym ? TN : 1], accy[kSym ? TM : 1][kSym ? TN : 1];      // (a small, b large) / (a large, b small)
+
+    // one k-tile's worth of matrix work: av[s][i] / bv[s][j] are this lane's operand values of k-step s
+    __device__ __forceinline__ void mfma_chain(const float (&av)[kBK / 2][TM], const float (&bv)[kBK / 2][TN]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (kBf16x == 0) {
+#pragma unroll
+            for (int s = 0; s < kBK / 2; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int g = 0; g < kBK / 16; ++g) {
+                Split3 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = av[8 * g + e][i];
+                    a[i].from(f);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = bv[8 * g + e][j];
+                    b[j].from(f);
+                }
+                // smallest products first; one pass over the accumulators per product keeps dependent MFMAs apart
+#define SNAG_MFMA_TERM(ACC, X, Y)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                     \
+        ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].X, b[j].Y, ACC[i][j], 0, 0, 0);
+                if constexpr (kSym) {
+                    if constexpr (kBf16x == 9) {
+                        SNAG_MFMA_TERM(acc, l, l)
+                        SNAG_MFMA_TERM(accx, l, m)
+                        SNAG_MFMA_TERM(accy, m, l)
+                    }
+                    SNAG_MFMA_TERM(accx, l, h)
+                    SNAG_MFMA_TERM(accy, h, l)
+                    SNAG_MFMA_TERM(acc, m, m)
+                    SNAG_MFMA_TERM(accx, m, h)
+                    SNAG_MFMA_TERM(accy, h, m)
+                    SNAG_MFMA_TERM(acc, h, h)
+                } else {
+                    if constexpr (kBf16x == 9) {
+                        SNAG_MFMA_TERM(acc, l, l)
+                        SNAG_MFMA_TERM(acc, l, m)
+                        SNAG_MFMA_TERM(acc, m, l)
+                    }
+                    SNAG_MFMA_TERM(acc, l, h)
+                    SNAG_MFMA_TERM(acc, h, l)
+                    SNAG_MFMA_TERM(acc, m, m)
+                    SNAG_MFMA_TERM(acc, m, h)
+                    SNAG_MFMA_TERM(acc, h, m)
+                    SNAG_MFMA_TERM(acc, h, h)
+                }
+#undef SNAG_MFMA_TERM
+            }
+        }
+#endif
+    }
 
     __device__ __forceinline__ void run(const GemmOperands& p, float* __restrict__ smem, int m0, int n0, int kbeg, int kend) {
+        if constexpr (kSym) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) accx[i][j][e] = accy[i][j][e] = 0.f;
+        }
+        run_loop(p, smem, m0, n0, kbeg, kend);
+        if constexpr (kSym) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] += accx[i][j][e] + accy[i][j][e];
+        }
+    }
+
+    __device__ __forceinline__ void run_loop(const GemmOperands& p, float* __restrict__ smem, int m0, int n0, int kbeg, int kend) {
         const int tid = threadIdx.x;
         const int lane = tid & 63;
         const int wave = wave_id_uniform();
@@ -338,13 +463,7 @@ struct GemmCore {
                 if (more) via_regs = bring(kt + 1, cur ^ 1);
                 load_fragments<BM, A_KC, TM>(sm + cur * A_BUF, wm0, li, lh, av);
                 load_fragments<BN, B_KC, TN>(sm + B_BASE + cur * B_BUF, wn0, li, lh, bv);
-#pragma unroll
-                for (int s = 0; s < kBK / 2; ++s)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[i][j], 0, 0, 0);
+                mfma_chain(av, bv);
                 if (via_regs) stage(cur ^ 1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (p.dbg != 2) __syncthreads();       // dbg 2: ablation without the per-k-tile barrier (results are wrong)
@@ -361,13 +480,7 @@ struct GemmCore {
                 if (more) fetch(kt + 1);
                 load_fragments<BM, A_KC, TM>(sm + cur * A_BUF, wm0, li, lh, av);
                 load_fragments<BN, B_KC, TN>(sm + B_BASE + cur * B_BUF, wn0, li, lh, bv);
-#pragma unroll
-                for (int s = 0; s < kBK / 2; ++s)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[i][j], 0, 0, 0);
+                mfma_chain(av, bv);
                 if (more) stage(cur ^ 1);
                 __syncthreads();
             }
@@ -396,13 +509,7 @@ struct GemmCore {
                 load_fragments<BM, A_KC, TM>(sm + nxt * A_BUF, wm0, li, lh, an);
                 load_fragments<BN, B_KC, TN>(sm + B_BASE + nxt * B_BUF, wn0, li, lh, bn);
             }
-#pragma unroll
-            for (int s = 0; s < kBK / 2; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[i][j], 0, 0, 0);
+            mfma_chain(av, bv);
             if (more2) stage(kt & 1);
             __syncthreads();
             if (kt + 1 < nk) {

@@ -63,9 +63,18 @@ def test_config4_shape_properties():
     rl, rr = res["rank_l2r"].cpu(), res["rank_r2l"].cpu()
     assert int(rl.min()) >= 0 and int(rl.max()) < n and int(rr.min()) >= 0 and int(rr.max()) < n
     assert 0.2 < res["hits_l2r"][0] < 1.0 and res["hits_l2r"][0] <= res["hits_l2r"][1] <= res["hits_l2r"][2]
-    # transposing the problem swaps the two directions exactly (integer ranks)
+    # transposing the problem swaps the two directions: the same products, but a.b and b.a sum their split-bf16 product families in
+    # mirrored order, so the two distance matrices agree to f32 rounding and a rank may move only across a proven near-tie
     res_t = E.rank_metrics(xr, xl, csls_k=3)
-    assert torch.equal(res_t["rank_l2r"].cpu(), rr) and torch.equal(res_t["rank_r2l"].cpu(), rl)
+    d_t = (1 - O.csls_sim(1 - res_t["dist"].cpu(), 3)).t()
+    d_0 = 1 - O.csls_sim(1 - res["dist"].cpu(), 3)
+    tie = 2e-6
+    assert 2 * float((d_t - d_0).abs().max()) <= tie
+    for got, ref, dim in ((res_t["rank_l2r"].cpu(), rr, 0), (res_t["rank_r2l"].cpu(), rl, 1)):
+        diff = (got.long() - ref.long()).abs()
+        for i in diff.nonzero().flatten().tolist():
+            line = d_0[i] if dim == 1 else d_0[:, i]
+            assert int(diff[i]) <= int(((line - d_0[i, i]).abs() <= tie).sum()) - 1, (i, int(diff[i]))
     # a simultaneous permutation of the pairs permutes the ranks
     perm = torch.randperm(n, generator=g)
     res_p = E.rank_metrics(xl[perm.to(DEV)].contiguous(), xr[perm.to(DEV)].contiguous(), csls_k=3)

@@ -101,7 +101,9 @@ def test_gemm_splitk_long_k_deterministic():
 
 @pytest.mark.parametrize("n,k,pad", [(7, 3, 0), (129, 16, 0), (300, 37, 3), (301, 300, 0), (1000, 300, 4), (64, 0, 0)])
 def test_gram_is_symmetric_and_matches_gemm(n, k, pad):
-    """snag_gram_f32: upper-triangle tiles + transposed stores.  S == S^T bit for bit; equals the plain GEMM's values."""
+    """snag_gram_f32: upper-triangle tiles + transposed stores.  S == S^T bit for bit (inside the diagonal tiles too: the split-bf16
+    product families that mirror each other under an exchange of the operands accumulate separately and meet in one commutative
+    add); the same products as the plain GEMM, summed in that different order."""
     from snag_amd import ops
     g = torch.Generator().manual_seed(n * 31 + k)
     zfull = torch.randn(n, k + pad, generator=g).to(DEV)
@@ -111,7 +113,8 @@ def test_gram_is_symmetric_and_matches_gemm(n, k, pad):
     if k:
         assert_close(s, 0.25 * (z.double().cpu() @ z.double().cpu().t()), atol=1e-5 * max(1.0, k ** 0.5))
         full = ops.gemm(z, z, alpha=0.25)
-        assert torch.equal(torch.triu(s), torch.triu(full))
+        scale = 0.25 * (z.abs() @ z.abs().t())                      # sum of the products' magnitudes: the scale of f32 accumulation error
+        assert float(((s - full).abs() / scale.clamp_min(1e-30)).max()) <= 2e-6
     else:
         assert float(s.abs().max()) == 0.0
 
@@ -168,3 +171,27 @@ def test_gemm_pair_equals_two_single_launches(shape, a_kc, b_kc, split):
     call("snag_gemm_f32_pair", ctypes.byref(_desc(A[1], B[1], o2, a_kc, b_kc)), ctypes.byref(_desc(a3, b3, o3, True, True)), stream())
     assert_close(o2, ra, atol=2e-6 * K + 1e-5, rtol=2e-5)
     assert_close(o3, a3.double() @ b3.double().t(), atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K,dist", [(1500, 128, 4096, "randn"), (1500, 128, 4096, "uniform"), (1024, 256, 128, "randn"), (300, 128, 15000, "randn"),
+                                        (1500, 128, 4096, "wide")])
+def test_gemm_error_against_fp64_is_f32_grade(M, N, K, dist):
+    """The split-bf16 product form (six bf16 MFMA products of exactly split operands) against an fp64 product: the error, relative to
+    sum_k |a_k b_k| (the scale f32 accumulation itself errs on), stays at what an f32 fmaf chain of that length gives, and the
+    rounding of the result alone (2^-24) bounds it from below.  'wide': operand magnitudes spread over 12 decades."""
+    from snag_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    if dist == "randn":
+        a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    elif dist == "uniform":
+        a, b = torch.rand(M, K, generator=g), torch.rand(N, K, generator=g)
+    else:
+        a = torch.randn(M, K, generator=g) * torch.pow(10.0, torch.rand(M, K, generator=g) * 12 - 6)
+        b = torch.randn(N, K, generator=g) * torch.pow(10.0, torch.rand(N, K, generator=g) * 12 - 6)
+    c = ops.gemm(a.to(DEV), b.to(DEV)).double().cpu()
+    c64 = a.double() @ b.double().t()
+    scale = a.double().abs() @ b.double().abs().t()
+    err = (c - c64).abs() / scale
+    assert float(err.max()) <= 1e-6 and float(err.pow(2).mean().sqrt()) <= 1.5e-7
+    # and never worse than a sequential f32 accumulation of the same products would be allowed to be: K * 2^-24
+    assert float(err.max()) <= K * 2.0 ** -24
