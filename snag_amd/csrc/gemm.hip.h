@@ -14,6 +14,7 @@
 // 256 threads = 4 waves in a 2x2 grid, double-buffered LDS, global loads for tile t+1 in flight
 // while tile t feeds the matrix pipe.
 #pragma once
+#include <type_traits>
 #include "common.hip.h"
 
 namespace snag {
@@ -63,6 +64,9 @@ __host__ __device__ constexpr int swz(int row) { return kBK == 16 ? ((row >> 2) 
 //                   9: all nine products
 #ifndef SNAG_GEMM_BF16X
 #define SNAG_GEMM_BF16X 6
+#endif
+#ifndef SNAG_GEMM_PRESPLIT_KC
+#define SNAG_GEMM_PRESPLIT_KC 1          // A/B: 0 keeps the in-fragment split for kernels with a K-contiguous operand
 #endif
 constexpr int kBf16x = SNAG_GEMM_BF16X;
 static_assert(kBf16x == 0 || kBf16x == 6 || kBf16x == 9, "SNAG_GEMM_BF16X");
@@ -295,6 +299,149 @@ struct Split3 {
     }
 };
 
+// ---- pre-split staging (split-bf16 builds, both operands row-contiguous) -------------------------------------------------------
+// The in-fragment split above costs ~5.5 VALU instructions per operand value PER WAVE that consumes it; with 2 x 2 waves every value
+// is split twice, and at 11 VALU instructions per MFMA the loop is VALU-bound (compute-only ablation: 128 us for the visual
+// projection against 38 us of bf16 MFMA time).  Here every value is split ONCE per workgroup on its way from global memory to the
+// LDS, which then holds the three bf16 planes in MFMA operand order:
+//     image[plane p][k-half q][row r] = 16 bytes = the 8 bf16 pieces p of row r for k = 8q .. 8q+7 of the 16-deep k-tile
+// so a lane's 32x32x16 operand is ONE conflict-free ds_read_b128 per plane (16 consecutive rows = 256 contiguous bytes).
+// Thread t owns row t % BR and the KPT = 16 BR / 256 consecutive k starting at KPT (t / BR): KPT dword loads per k-tile, each
+// wave-instruction covering 64 consecutive rows of one k (256 contiguous bytes; the k index is wave-uniform, so its bound check is too
+// and ragged K needs no second loader), two register sets so that every load has two k-tiles of matrix work to land.
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+#endif
+    return r;
+}
+// two values -> their packed h, m, l pieces (11 VALU instructions)
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(s0, s1);
+}
+
+template <int BR, bool KC>
+struct SplitStager {
+    static constexpr int KPT = 16 * BR / 256;            // values per thread and k-tile (4: BR = 64, 8: BR = 128)
+    static_assert(KPT == 4 || KPT == 8, "pre-split staging: 64 or 128 rows per operand tile");
+    static constexpr int IMAGE_BYTES = 6 * BR * 16;
+    // The unit of work is a CHUNK: 4 consecutive k (4c .. 4c+3, c = 0..3) of one row = 16 bytes of f32 = 8 bytes per bf16 plane.
+    // Chunk c lives in k-half c & 1 of the image, in bytes 8 (c >> 1) .. of the row's 16-byte slot: a lane's MFMA operand (one
+    // ds_read_b128) is chunks {h, h + 2} of its row, for both operands alike -- a fixed permutation of k inside the k-tile.
+    //   row-contiguous, BR = 64 : thread = (row t % 64, chunk t / 64)                    4 dword loads (k = 4c + j)
+    //   row-contiguous, BR = 128: thread = (row t % 128, chunks h and h + 2, h = t / 128) 8 dword loads
+    //   K-contiguous,   BR = 64 : thread = (row t / 4, chunk t % 4)                      1 dwordx4 load
+    //   K-contiguous,   BR = 128: thread = (rows t / 4 and t / 4 + 64, chunk t % 4)      2 dwordx4 loads
+    // (row-contiguous: a wave-instruction covers 64 consecutive rows of one k, 256 contiguous bytes; K-contiguous: 4 adjacent
+    // lanes cover the 64 contiguous bytes a row has in this k-tile.)
+    float r[2][KPT];                 // two register sets: tiles t+1 and t+2 in flight
+    const char* ubase;               // wave-uniform.  row-contiguous: element (k = kbeg, row 0); K-contiguous: element (row0, k = kbeg)
+    int64_t ldb;                     // pitch in bytes
+    uint32_t voff, voff2;            // the lane's part of the address, bytes (rows past the edge clamped: their products are never stored)
+    int c;                           // first chunk of this thread (wave-uniform when row-contiguous)
+    int wr_off;                      // byte offset of this thread's (first) slot in plane 0 of the image
+    int vec;                         // K-contiguous: 16-byte loads legal
+
+    __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, int vec_ok, int row0, int nrows, int kbeg, int tid) {
+        ldb = ld * 4;
+        vec = vec_ok;
+        int row;
+        if constexpr (KC) {
+            row = tid >> 2, c = tid & 3;
+            ubase = reinterpret_cast<const char*>(P) + (int64_t)row0 * ldb + (int64_t)kbeg * 4;
+            voff = (uint32_t)(min(row0 + row, nrows - 1) - row0) * (uint32_t)ldb + (uint32_t)c * 16u;
+            voff2 = (uint32_t)(min(row0 + row + 64, nrows - 1) - row0) * (uint32_t)ldb + (uint32_t)c * 16u;
+            wr_off = ((c & 1) * BR + row) * 16 + (c >> 1) * 8;
+        } else {
+            row = tid % BR, c = __builtin_amdgcn_readfirstlane(tid / BR);
+            ubase = reinterpret_cast<const char*>(P) + (int64_t)kbeg * ldb;
+            voff = voff2 = (uint32_t)min(row0 + row, nrows - 1) * 4u;
+            wr_off = KPT == 8 ? (c * BR + row) * 16 : ((c & 1) * BR + row) * 16 + (c >> 1) * 8;
+        }
+    }
+    // k (inside the k-tile) of value j of this thread
+    __device__ __forceinline__ int k_of(int j) const { return KC ? 4 * c + (j & 3) : (KPT == 8 ? 4 * c + (j & 3) + 8 * (j >> 2) : 4 * c + j); }
+    // address of value j of k-tile kt
+    __device__ __forceinline__ const char* addr_of(int kt, int j) const {
+        if constexpr (KC) return ubase + (j < 4 ? voff : voff2) + (int64_t)kt * 64 + (j & 3) * 4;
+        else return ubase + (int64_t)(kt * 16 + k_of(j)) * ldb + voff;
+    }
+    // FULL k-tile kt (relative to kbeg) -> register set s, by buffer loads: scalar descriptor + scalar offset + the lane's 32-bit
+    // offset, no per-lane address arithmetic.  A tile at or past kleft / 16 reads zeros through an empty descriptor (the hardware's
+    // range check covers the vector offset only, not the scalar one: it cannot cut a ragged tile; that is load_tail()'s).
+    __device__ __forceinline__ void load(int s, int kt, int kleft /* kend - kbeg */) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int range = __builtin_amdgcn_readfirstlane(kt * 16 + 16 <= kleft ? (int)0xffffffffu : 0);
+        if constexpr (KC) {
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, range, 0x00020000);
+            const uint32_t so = (uint32_t)kt * 64u;
+            if (vec) {
+#pragma unroll
+                for (int i = 0; i < KPT / 4; ++i) {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, i ? voff2 : voff, so, 0);
+                    r[s][4 * i + 0] = __uint_as_float(v[0]);
+                    r[s][4 * i + 1] = __uint_as_float(v[1]);
+                    r[s][4 * i + 2] = __uint_as_float(v[2]);
+                    r[s][4 * i + 3] = __uint_as_float(v[3]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < KPT; ++j) r[s][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (j < 4 ? voff : voff2) + 4 * (j & 3), so, 0));
+            }
+        } else {
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase + (int64_t)kt * 16 * ldb), 0, range, 0x00020000);
+            const uint32_t l = (uint32_t)ldb;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) r[s][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (uint32_t)k_of(j) * l, 0));
+        }
+#endif
+    }
+    // the ragged last k-tile (kt = kleft / 16): element by element, k >= kend reads as zero
+    __device__ __forceinline__ void load_tail(int s, int kt, int kleft) {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) r[s][j] = kt * 16 + k_of(j) < kleft ? *reinterpret_cast<const float*>(addr_of(kt, j)) : 0.f;
+    }
+    __device__ __forceinline__ void split_store(int s, unsigned char* image) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        using lds_u4 = __attribute__((address_space(3))) uint4;
+        using lds_u2 = __attribute__((address_space(3))) uint2;
+        uint32_t h[KPT / 2], m[KPT / 2], l[KPT / 2];
+#pragma unroll
+        for (int j = 0; j < KPT / 2; ++j) split_pair(r[s][2 * j], r[s][2 * j + 1], h[j], m[j], l[j]);
+        auto* im = (__attribute__((address_space(3))) unsigned char*)image + wr_off;
+        if constexpr (KPT == 8 && !KC) {          // chunks c and c + 2 of one row: the whole 16-byte slot
+            *(lds_u4*)(im) = make_uint4(h[0], h[1], h[2], h[3]);
+            *(lds_u4*)(im + 2 * BR * 16) = make_uint4(m[0], m[1], m[2], m[3]);
+            *(lds_u4*)(im + 4 * BR * 16) = make_uint4(l[0], l[1], l[2], l[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPT / 4; ++i) {   // K-contiguous, BR = 128: the same chunk of rows row and row + 64
+                *(lds_u2*)(im + i * 64 * 16) = make_uint2(h[2 * i], h[2 * i + 1]);
+                *(lds_u2*)(im + i * 64 * 16 + 2 * BR * 16) = make_uint2(m[2 * i], m[2 * i + 1]);
+                *(lds_u2*)(im + i * 64 * 16 + 4 * BR * 16) = make_uint2(l[2 * i], l[2 * i + 1]);
+            }
+        }
+#endif
+    }
+};
+
+// a lane's three operand pieces of one 32-row fragment: rows row0 .. row0+31 of an image with BR rows
+template <int BR>
+__device__ __forceinline__ void load_split_fragment(const unsigned char* image, int row, int lh, Split3& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using lds_b8 = __attribute__((address_space(3))) bf16x8;
+    const auto* im = (const __attribute__((address_space(3))) unsigned char*)image + (lh * BR + row) * 16;
+    f.h = *(const lds_b8*)(im);
+    f.m = *(const lds_b8*)(im + 2 * BR * 16);
+    f.l = *(const lds_b8*)(im + 4 * BR * 16);
+#endif
+}
+
 // Main loop.  acc[mi][ni] is the 32x32 tile (mi, ni) of this wave's WM x WN patch:
 //   row = wm0 + 32*mi + (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5),  col = wn0 + 32*ni + (lane & 31).
 // SYM (split-bf16 builds): C(a, b) == C(b, a) bit for bit.  The six products are not symmetric one by one (h*m <-> m*h, h*l <-> l*h
@@ -307,7 +454,13 @@ struct GemmCore {
     static constexpr int TILE_FLOATS = 2 * (A_BUF + B_BUF);
     static constexpr int CW = (WN % 64 == 0) ? 64 : 32;   // epilogue staging chunk: 32 rows x CW columns per wave at a time
     static constexpr int STAGE_FLOATS = 4 * 32 * CW;
-    static constexpr int SMEM_FLOATS = TILE_FLOATS > STAGE_FLOATS ? TILE_FLOATS : STAGE_FLOATS;
+    // pre-split staging loop: split-bf16 builds, 64 / 128-row operand tiles (the 128 x 160 tile keeps the in-fragment split)
+    static constexpr bool kPresplit = kBf16x != 0 && (BM == 64 || BM == 128) && (BN == 64 || BN == 128) && kBK == 16 &&
+                                      (SNAG_GEMM_PRESPLIT_KC != 0 || (!A_KC && !B_KC));
+    static constexpr int PS_STAGE_FLOATS = 6 * (BM + BN) * 16 / 4;          // one stage: both images
+    static constexpr int PS_FLOATS = kPresplit ? 2 * PS_STAGE_FLOATS : 0;
+    static constexpr int SMEM_FLOATS_ = TILE_FLOATS > STAGE_FLOATS ? TILE_FLOATS : STAGE_FLOATS;
+    static constexpr int SMEM_FLOATS = kPresplit ? (PS_FLOATS > STAGE_FLOATS ? PS_FLOATS : STAGE_FLOATS) : SMEM_FLOATS_;
     static_assert((BM / WM) * (BN / WN) == 4, "four waves per block");
 
     f32x16 acc[TM][TN];
@@ -378,7 +531,131 @@ struct GemmCore {
 #endif
     }
 
+    // the six (nine) products of one k-tile on pre-split fragments
+    __device__ __forceinline__ void mfma_split(const Split3 (&a)[TM], const Split3 (&b)[TN]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SNAG_MFMA_TERM(ACC, X, Y)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                     \
+        ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].X, b[j].Y, ACC[i][j], 0, 0, 0);
+        if constexpr (kSym) {
+            if constexpr (kBf16x == 9) {
+                SNAG_MFMA_TERM(acc, l, l)
+                SNAG_MFMA_TERM(accx, l, m)
+                SNAG_MFMA_TERM(accy, m, l)
+            }
+            SNAG_MFMA_TERM(accx, l, h)
+            SNAG_MFMA_TERM(accy, h, l)
+            SNAG_MFMA_TERM(acc, m, m)
+            SNAG_MFMA_TERM(accx, m, h)
+            SNAG_MFMA_TERM(accy, h, m)
+            SNAG_MFMA_TERM(acc, h, h)
+        } else {
+            if constexpr (kBf16x == 9) {
+                SNAG_MFMA_TERM(acc, l, l)
+                SNAG_MFMA_TERM(acc, l, m)
+                SNAG_MFMA_TERM(acc, m, l)
+            }
+            SNAG_MFMA_TERM(acc, l, h)
+            SNAG_MFMA_TERM(acc, h, l)
+            SNAG_MFMA_TERM(acc, m, m)
+            SNAG_MFMA_TERM(acc, m, h)
+            SNAG_MFMA_TERM(acc, h, m)
+            SNAG_MFMA_TERM(acc, h, h)
+        }
+#undef SNAG_MFMA_TERM
+#endif
+    }
+
+    __device__ __forceinline__ void run_presplit(const GemmOperands& p, float* __restrict__ smem, int m0, int n0, int kbeg, int kend) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = wave_id_uniform();
+        const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
+        const int li = lane & 31, lh = lane >> 5;
+        unsigned char* const sm = reinterpret_cast<unsigned char*>(smem);
+        constexpr int STAGE = PS_STAGE_FLOATS * 4, A_IMG = SplitStager<BM, A_KC>::IMAGE_BYTES;
+        const int kleft = kend - kbeg;
+        const int nk = kleft / 16;            // full k-tiles; a ragged last one is the tail's
+        SplitStager<BM, A_KC> sa;
+        SplitStager<BN, B_KC> sb;
+        sa.init(p.A, p.lda, p.a_vec, m0, p.M, kbeg, tid);
+        sb.init(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, tid);
+        auto fetch = [&](int s, int kt) {
+            sa.load(s, kt, kleft);
+            sb.load(s, kt, kleft);
+        };
+        auto stage = [&](int s, int buf) {
+            sa.split_store(s, sm + buf * STAGE);
+            sb.split_store(s, sm + buf * STAGE + A_IMG);
+        };
+        auto multiply = [&](int buf) {
+            Split3 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) load_split_fragment<BM>(sm + buf * STAGE, wm0 + 32 * i + li, lh, a[i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + buf * STAGE + A_IMG, wn0 + 32 * j + li, lh, b[j]);
+            mfma_split(a, b);
+        };
+        // one k-tile: fragments of tile kt out of buffer kt & 1; tile kt+1 (register set S) split into the other buffer; tile kt+3 fetched
+        // into set S; the matrix work of tile kt; barrier.  Set S ^ 1 holds tile kt+2, in flight across the whole iteration.
+        // Staging and fetching are unconditional (a tile past the end reads as zeros and lands in the buffer nobody reads again): a
+        // fetch the compiler cannot count on forces its vmcnt waits down to 0, i.e. to wait for the NEWER set as well.
+        auto iteration = [&](int kt, auto S) {
+            constexpr int set = decltype(S)::value;
+            const int cur = kt & 1;
+            Split3 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) load_split_fragment<BM>(sm + cur * STAGE, wm0 + 32 * i + li, lh, a[i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + cur * STAGE + A_IMG, wn0 + 32 * j + li, lh, b[j]);
+            stage(set, cur ^ 1);
+            fetch(set, kt + 3);
+            mfma_split(a, b);
+            __syncthreads();
+        };
+        if (nk > 0) {
+            fetch(0, 0);
+            fetch(1, 1);
+            stage(0, 0);
+            fetch(0, 2);
+            __syncthreads();
+            // tile kt+1 sits in set (kt+1) & 1.  Always whole pairs: with an odd count the second iteration of the last pair multiplies
+            // a tile of zeros (at most one k-tile in 59+ per stream-K segment), which keeps the loop a single straight-line body.
+            for (int kt = 0; kt < nk; kt += 2) {
+                iteration(kt, std::integral_constant<int, 1>{});
+                iteration(kt + 1, std::integral_constant<int, 0>{});
+            }
+        }
+        if (kleft % 16 != 0) {
+            sa.load_tail(0, nk, kleft);
+            sb.load_tail(0, nk, kleft);
+            stage(0, 0);
+            __syncthreads();
+            multiply(0);
+            __syncthreads();
+        }
+    }
+
     __device__ __forceinline__ void run(const GemmOperands& p, float* __restrict__ smem, int m0, int n0, int kbeg, int kend) {
+        if constexpr (kPresplit) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        acc[i][j][e] = 0.f;
+                        if constexpr (kSym) accx[i][j][e] = accy[i][j][e] = 0.f;
+                    }
+            if (kend > kbeg) run_presplit(p, smem, m0, n0, kbeg, kend);
+            if constexpr (kSym) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] += accx[i][j][e] + accy[i][j][e];
+            }
+            return;
+        }
         if constexpr (kSym) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)

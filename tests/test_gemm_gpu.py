@@ -195,3 +195,25 @@ def test_gemm_error_against_fp64_is_f32_grade(M, N, K, dist):
     assert float(err.max()) <= 1e-6 and float(err.pow(2).mean().sqrt()) <= 1.5e-7
     # and never worse than a sequential f32 accumulation of the same products would be allowed to be: K * 2^-24
     assert float(err.max()) <= K * 2.0 ** -24
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 128, 1000), (4096, 128, 1500), (64, 64, 8), (130, 70, 41), (512, 128, 15000)])
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+def test_gemm_never_reads_past_its_operands(M, N, K, a_kc, b_kc):
+    """K not a multiple of the 16-deep k-tile, operands embedded in larger buffers whose surroundings are poisoned (1e30, alternating
+    signs): any read past row K / column K of an operand -- the staged loaders over-read by design and must discard it -- shows up
+    as a huge error.  Split-K shapes (small output, long K) included: the last split's range ends ragged."""
+    from snag_amd import ops
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + 2 * a_kc + b_kc)
+
+    def embedded(rows, cols):           # a [rows, cols] view with a 5-row / 4-column poisoned margin on every side
+        big = torch.full((rows + 10, cols + 8), 1e30)
+        big[::2] *= -1
+        big[5:5 + rows, 4:4 + cols] = torch.randn(rows, cols, generator=g)
+        big = big.to(DEV)
+        return big, big[5:5 + rows, 4:4 + cols]
+    _, a = embedded(*((M, K) if a_kc else (K, M)))
+    _, b = embedded(*((N, K) if b_kc else (K, N)))
+    c = ops.gemm(a, b, a_kcontig=a_kc, b_kcontig=b_kc)
+    ref = _ref(a.cpu(), b.cpu(), a_kc, b_kc)
+    assert_close(c, ref, atol=2e-6 * K + 1e-5, rtol=2e-5, what=f"gemm {M}x{N}x{K} inside poisoned buffers")

@@ -10,7 +10,7 @@ import sys
 def main():
     d = sys.argv[1]
     out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
-    marker = sys.argv[3] if len(sys.argv) > 3 else "sample_negatives_kernel"
+    marker = sys.argv[3] if len(sys.argv) > 3 else "step_prologue_kernel"
     rows = []
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         with open(f) as fh:
