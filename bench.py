@@ -88,9 +88,7 @@ def score_bytes(cfg, n_triples):
 def roofline_dominant(cfg, timer, rows=None):
     """The launch that takes the largest share of the step: the visual projection l1 GEMM over this rank's entity rows.
 
-    fp32 in / fp32 accumulate; the multiplies run as six bf16 MFMA products of exactly split operands (include/snag_hip.h, snag_gemm_f32).
-    ``frac`` stays priced against the f32 matrix peak (157.3 TF) the f32-MFMA form of the kernel is bound by: the conservative
-    denominator while the kernel is below it; ``peak_split_bf16`` is the bf16 dense peak / 6 products, the bound of the split form."""
+    fp32 in / fp32 accumulate; the multiplies run as six bf16 MFMA products of exactly split operands (include/snag_hip.h, snag_gemm_f32)."""
     us, n = timer.mean_us()
     rows = cfg.n_ent if rows is None else rows
     flops = 2.0 * rows * cfg.feat_dims[0] * cfg.dim
@@ -105,8 +103,14 @@ def roofline_dominant(cfg, timer, rows=None):
     except (OSError, KeyError, ValueError):
         pass
     return {"kernel": f"gemm_streamk_kernel<64,128,..> + streamk_fixup_kernel (visual projection: [{rows},{cfg.feat_dims[0]}]x[{cfg.feat_dims[0]},{cfg.dim}], fp32 via 6 split-bf16 MFMA products)",
-            "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
-            "peak_split_bf16": BF16_MFMA_PEAK_TFLOPS / 6, "frac_split_bf16": ach / (BF16_MFMA_PEAK_TFLOPS / 6),
+            # the bound of the kernel AS BUILT: six bf16 MFMA products per f32 multiply-add -> bf16 dense peak / 6 (37.5 us for this
+            # launch; its HBM floor, 255.5 MB at 8 TB/s, is 32 us).  frac is therefore the share of the matrix pipe's time the
+            # launch (kernel + fix-up) uses; against the f32 MFMA peak (157.3 TF), which bounded the previous form of this kernel
+            # (0.66 in round 1), the same time reads as frac_of_f32_mfma_peak.
+            "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS / 6, "unit": "TFLOP/s (f32 multiply-adds)", "frac": ach / (BF16_MFMA_PEAK_TFLOPS / 6),
+            "peak_basis": "bf16 dense MFMA peak 2516.6 TF / 6 products per f32 multiply-add",
+            "frac_of_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS,
+            "hbm_frac": (4 * (rows * cfg.feat_dims[0] + cfg.feat_dims[0] * cfg.dim + rows * cfg.dim)) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us else 0.0,
             "traffic": traffic, "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC)", "traffic_source": src,
             "algorithmic_bytes_per_launch": 4 * (rows * cfg.feat_dims[0] + cfg.feat_dims[0] * cfg.dim + rows * cfg.dim),
             "avg_us": us, "launches_timed": n, "algorithmic_flops_per_launch": flops}

@@ -225,7 +225,7 @@ SNAG_API int64_t snag_gemm_workspace_floats(int M, int N, int K);
  * one after the other.  Results are those of two snag_gemm_f32 calls, bit for bit.  Split-K workspaces must be distinct. */
 SNAG_API int snag_gemm_f32_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, void* stream);
 
-/* Gram matrix S [n, n] = alpha * Z Z^T for Z [n, k] (row stride ldz), exact-f32 MFMA.  Only the tiles on or above the diagonal are
+/* Gram matrix S [n, n] = alpha * Z Z^T for Z [n, k] (row stride ldz), fp32 via split-bf16 MFMA.  Only the tiles on or above the diagonal are
  * computed; each is also stored transposed, so S is symmetric bit for bit.  Used for the stacked InfoNCE logits
  * (icl_loss, model/SNAG_loss.py:99-110: the four z_a z_b^T blocks are one Gram matrix of [z1; z2]).  k == 0 gives zeros. */
 SNAG_API int snag_gram_f32(const float* Z, int64_t ldz, int n, int k, float alpha, float* S, int64_t lds, void* stream);
@@ -388,7 +388,7 @@ SNAG_API int snag_tick(uint64_t* tick, void* stream);
  * snag_row_sqnorm:    out[i] = |x_i|^2                               (src/utils.py:210-212)
  * snag_pairwise_dist: out[i,j] = max(xn[i] + yn[j] - 2 x_i.y_j, 0)   (pairwise_distances, src/utils.py:202-218);
  *                     as_similarity != 0 stores 1 - that (main.py:392).  The x.y^T product is the path's one
- *                     dense entity x entity GEMM and runs on the exact-f32 matrix cores.
+ *                     dense entity x entity GEMM and runs on the matrix cores (fp32 in, fp32 accumulate, split-bf16 products).
  * snag_csls_neighbourhood: r1[i] = mean of the k largest S[i,:], r2[j] = mean of the k largest S[:,j]
  *                     (csls_sim, src/utils.py:431-432), S = mat or 1 - mat (from_dist).  k <= 16.
  *                     work: snag_eval_work_floats(n, m) floats.

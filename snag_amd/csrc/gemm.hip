@@ -350,6 +350,7 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     // Split-bf16 builds: the pre-split staging loop (gemm.hip.h) runs the 64 x 128 tile fastest on every shape of the path
     // (forced 64 x 128 vs the choice above, one device: DB15K step 0.715 -> 0.704 ms, MKG-W 0.799 -> 0.788, MMEA step 22.5 -> 21.4 ms,
     // 10,500^2 x 1,200 similarity eval 7.8 -> 7.2 ms); the larger tiles stay reachable through SNAG_GEMM_TILE for A/B runs.
+    // (128 x 128 for the long-K shapes only, K >= 512 or 2048: step 0.708 / 0.711 vs 0.697 ms -- no.)
     if (kBf16x != 0) big = wide = false;
     if (force_tile() != 0) { big = force_tile() == 2; wide = force_tile() == 3; }
     if (kBK != 16) wide = false;        // the 128x160 tiles of a 32-deep k-tile do not fit the 64 KB static LDS limit

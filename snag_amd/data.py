@@ -260,7 +260,7 @@ def get_topk_indices(M, K=1000):
 def visual_pivot_induction(args, left_ents, right_ents, img_features, ills, logger):
     """Unsupervised seed alignment (src/data.py:367-404): walk the unsup_k * 100 most similar (left, right) pairs best first and keep a
     pair when neither entity is taken yet, until unsup_k pairs are found.  The similarity product runs wherever ``img_features`` lives
-    (on the GPU it is one exact-f32 MFMA GEMM through snag_amd.ops.gemm)."""
+    (on the GPU it is one split-bf16 MFMA GEMM (fp32 in, fp32 accumulate) through snag_amd.ops.gemm)."""
     l_img, r_img = img_features[left_ents], img_features[right_ents]
     if l_img.is_cuda:
         from . import ops

@@ -135,7 +135,7 @@ def link_prediction(ent, rel, h, r, t, filter_mask=None, top_k=(1, 10), method="
 
     ``method="exact"`` scores every candidate with the training scorer's difference form sum_k (q_k - t_k)^2 (bit-identical to the
     scores the model was trained on; 29 G scores/s).  ``method="gemm"`` expands it to |q|^2 + |t|^2 - 2 q.t and runs the B x N x D
-    product on the exact-f32 matrix cores through the similarity-eval GEMM (about 8x faster at 16k queries x 15k entities); the
+    product on the matrix cores (fp32 in, fp32 accumulate, split-bf16 products) through the similarity-eval GEMM (about 8x faster at 16k queries x 15k entities); the
     scores differ from the exact ones by fp32 cancellation error (~1e-6), so ranks can move by one place on near-ties.
     ``known_sorted`` (the sampler's sorted key table, ``ops.triple_keys``) builds the filtered protocol's mask on the device when no
     ``filter_mask`` is given.

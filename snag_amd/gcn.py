@@ -2,7 +2,7 @@
 
 Drop-in for ``GCN(nfeat, nhid, nout, dropout)`` (model/Tool_model.py:98-110) and ``GraphConvolution`` (model/layers.py:102-130): same
 constructors, same initialisers, same state_dict keys (``gc1.weight [in, out]``, ``gc1.bias``, ``gc2.*``), same ``forward(x, adj)`` with
-``adj`` a torch sparse COO tensor whose values ARE used (torch.spmm).  X W is an exact-f32 MFMA GEMM, A (X W) a CSR gather kernel
+``adj`` a torch sparse COO tensor whose values ARE used (torch.spmm).  X W is an split-bf16 MFMA GEMM (fp32 in, fp32 accumulate), A (X W) a CSR gather kernel
 (snag_spmm_csr); the backward runs the same kernel on the destination-grouped edge list, so nothing is scattered with atomics.
 Only dropout = 0 is built (run_snag.sh leaves --dropout at 0.0).
 """

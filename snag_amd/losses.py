@@ -2,7 +2,7 @@
 
 ``icl_loss`` keeps the reference's constructor and call signature (model/SNAG_loss.py:31-41,58): bidirectional in-batch
 InfoNCE over aligned pairs with an optional per-entity weight.  Gather + normalise, the masked row log-sum-exp and the
-logits-to-gradient transform are HIP kernels; the 2B x 2B x d products (one forward, one backward) are exact-f32 MFMA GEMMs.
+logits-to-gradient transform are HIP kernels; the 2B x 2B x d products (one forward, one backward) are split-bf16 MFMA GEMMs (fp32 in, fp32 accumulate).
 ``CustomMultiLossLayer`` (:12-29) is six scalars and stays plain torch.
 """
 import torch

@@ -4,7 +4,7 @@ Mirrors ``MultiModalEncoder`` (model/SNAG_tools.py:53-156) and ``SNAG`` (model/S
 same duck-typed driver interface (``model(batch) -> (loss, {"loss_dic", "emb"})``, ``joint_emb_generat``, ``update_noise``,
 ``Iter_new_links``, ``data_refresh``; main.py:58-75,246-289,359-455), same state_dict keys, so ``Runner`` can swap
 ``from model import SNAG`` for ``from snag_amd.mmea import SNAG`` and load existing checkpoints.  Every tensor operation of the
-forward/backward runs in libsnag_hip.so (projections and Mformer linears on the exact-f32 matrix cores, sparse GAT, noise blend,
+forward/backward runs in libsnag_hip.so (projections and Mformer linears on the matrix cores (fp32 in, fp32 accumulate, split-bf16 products), sparse GAT, noise blend,
 InfoNCE); torch is used for parameter containers, index bookkeeping and six-scalar loss weighting.
 
 Not built (never exercised by run_snag.sh): GCN structural encoder, ``use_project_head``, ``ial_loss`` (constructed but unused in

@@ -210,7 +210,7 @@ def gram(z, alpha=1.0, out=None):
 
 def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, alpha=1.0, act=None, want_pre_act=False,
          keep_mask=None, keep_p=0.0, add1=None, add2=None, out=None, accumulate=False, splitk=True, aux=None):
-    """C = add1 + add2 + keep * act(alpha * A.B + bias)   (C ABI: snag_gemm_f32; exact-f32 MFMA).
+    """C = add1 + add2 + keep * act(alpha * A.B + bias)   (C ABI: snag_gemm_f32; fp32 via split-bf16 MFMA).
 
     a: [M,K] if a_kcontig else [K,M];  b: [N,K] if b_kcontig else [K,N]  (2-D, last dim contiguous,
     row stride free).  Returns C [M,N] (and the pre-activation when want_pre_act).

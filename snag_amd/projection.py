@@ -1,4 +1,4 @@
-"""Per-modality projections on the exact-f32 matrix cores.
+"""Per-modality projections on the matrix cores (fp32 in, fp32 accumulate, split-bf16 products).
 
 Reference: ``img_fc / rel_fc / att_fc / name_fc / char_fc = nn.Linear(F_m, D)`` (model/SNAG_tools.py:92-96, used at
 :133-152) -- README ``num_proj = 1`` -- and ``ProjectionHead`` (model/layers.py:135-148: Linear(no bias) -> ReLU ->

@@ -1,4 +1,4 @@
-"""GPU numerics: snag_gemm_f32 (exact-f32 MFMA) vs a plain PyTorch fp32/fp64 reference of the same op."""
+"""GPU numerics: snag_gemm_f32 (fp32 via split-bf16 MFMA) vs a plain PyTorch fp32/fp64 reference of the same op."""
 import math
 
 import pytest

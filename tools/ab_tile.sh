@@ -1,9 +1,8 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
 p() { python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$1', round(d['ms_per_step'],4), round(d['value']))"; }
-export SNAG_GEMM_TILE=1
 for i in 1 2; do
-  for e in "X=1" "SNAG_GEMM_SK_BLOCKS=768" "SNAG_GEMM_SK_BLOCKS=1024" "SNAG_GEMM_SK=1" "SNAG_GEMM_SK=1 SNAG_GEMM_TARGET=768"; do
+  for e in "X=1" "SNAG_GEMM_SK=1" "SNAG_GEMM_SK=1 SNAG_GEMM_TARGET=768" "SNAG_GEMM_SK=1 SNAG_GEMM_TARGET=1280" "SNAG_GEMM_SK=1 SNAG_GEMM_TARGET=1536" "SNAG_GEMM_SK=1 SNAG_GEMM_TARGET=2048"; do
   env $e python3 bench.py --no-extras --cpu-seconds 0 --steps 100 2>/dev/null | p "[$e]"
   done
 done
