@@ -352,6 +352,11 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     // 10,500^2 x 1,200 similarity eval 7.8 -> 7.2 ms); the larger tiles stay reachable through SNAG_GEMM_TILE for A/B runs.
     // (128 x 128 for the long-K shapes only, K >= 512 or 2048: step 0.708 / 0.711 vs 0.697 ms -- no.)
     if (kBf16x != 0) big = wide = false;
+    // Long K (the projections and their weight gradients): 128 x 128 "row-private" tiles -- four waves stacked along M, each wave's
+    // 32 rows of A go straight to its registers, only B goes through the LDS (44 % less LDS traffic per multiply-add, half the
+    // re-reads of B per launch).  For K = 128 / 256 the 64 x 128 tile stays (twice the workgroups for the same output).
+    static const int tallk = env_int("SNAG_GEMM_TALLK");        // tuning: threshold (default 512); -1 = never
+    if (kBf16x != 0 && tallk >= 0 && p.K >= (tallk > 0 ? tallk : 512)) big = true;
     if (force_tile() != 0) { big = force_tile() == 2; wide = force_tile() == 3; }
     if (kBK != 16) wide = false;        // the 128x160 tiles of a 32-deep k-tile do not fit the 64 KB static LDS limit
     if (wide) big = false;
@@ -360,6 +365,10 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     int splits = 1;
     if (d->workspace != nullptr) {
         splits = force_splits() > 0 ? force_splits() : pick_splits(tiles, p.K, d->a_kcontig && d->b_kcontig);
+        // row-private tiles run two workgroups per CU: at most one resident wave of 512 (measured: 590 workgroups 0.7135 ms per step,
+        // 472-512 0.702, against 0.720 with 64 x 128 tiles)
+        if (kBf16x != 0 && big && force_splits() <= 0 && env_int("SNAG_GEMM_TARGET") <= 0)
+            splits = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(1, p.K / (kMinKTiles * 16)), 512 / std::max<int64_t>(1, tiles)));
         const int64_t cap = d->workspace_floats / ((int64_t)p.M * p.N);
         if (splits > cap) splits = (int)cap;
         if (splits < 1) splits = 1;
@@ -408,7 +417,7 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     if (pl.wide) launch_cfg<128, 160, 32, 160>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else
 #endif
-    if (pl.big) launch_cfg<128, 128, 64, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
+    if (pl.big) launch_cfg<128, 128, 32, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else launch_cfg<64, 128, 32, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     int rc = check_launch("snag_gemm_f32");
     if (rc) return rc;
@@ -441,7 +450,7 @@ int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipSt
     if (log_shapes())
         fprintf(stderr, "snag_gemm PAIR M=%d N=%d K=%d a_kc=%d b_kc=%d tile=%s splits=%d\n", a.p.M, a.p.N, a.p.K, (int)d0->a_kcontig, (int)d0->b_kcontig,
                 a.big ? "128x128" : "64x128", splits);
-    if (a.big) launch_cfg_pair<128, 128, 64, 64>(a.p, a.e, s0, b.p, b.e, s1, splits, d0->a_kcontig, d0->b_kcontig, vec, st);
+    if (a.big) launch_cfg_pair<128, 128, 32, 128>(a.p, a.e, s0, b.p, b.e, s1, splits, d0->a_kcontig, d0->b_kcontig, vec, st);
     else launch_cfg_pair<64, 128, 32, 64>(a.p, a.e, s0, b.p, b.e, s1, splits, d0->a_kcontig, d0->b_kcontig, vec, st);
     int rc = check_launch("snag_gemm_f32_pair");
     if (rc) return rc;

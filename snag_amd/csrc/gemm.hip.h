@@ -65,6 +65,15 @@ __host__ __device__ constexpr int swz(int row) { return kBK == 16 ? ((row >> 2) 
 #ifndef SNAG_GEMM_BF16X
 #define SNAG_GEMM_BF16X 6
 #endif
+#ifndef SNAG_GEMM_ABLATE
+#define SNAG_GEMM_ABLATE 0
+#endif
+#ifndef SNAG_GEMM_PIN_READS
+#define SNAG_GEMM_PIN_READS 0
+#endif
+#ifndef SNAG_GEMM_SK_WAVES
+#define SNAG_GEMM_SK_WAVES 2             // A/B: waves per SIMD the stream-K kernel is compiled for (4: at most 128 registers)
+#endif
 #ifndef SNAG_GEMM_PRESPLIT_KC
 #define SNAG_GEMM_PRESPLIT_KC 1          // A/B: 0 keeps the in-fragment split for kernels with a K-contiguous operand
 #endif
@@ -346,6 +355,7 @@ struct SplitStager {
     int c;                           // first chunk of this thread (wave-uniform when row-contiguous)
     int wr_off;                      // byte offset of this thread's (first) slot in plane 0 of the image
     int vec;                         // K-contiguous: 16-byte loads legal
+    int ablate;                      // tuning only (SNAG_GEMM_DBG): k-tiles >= 2 read through an empty descriptor (no memory traffic, zeros)
 
     __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, int vec_ok, int row0, int nrows, int kbeg, int tid) {
         ldb = ld * 4;
@@ -376,7 +386,7 @@ struct SplitStager {
     // range check covers the vector offset only, not the scalar one: it cannot cut a ragged tile; that is load_tail()'s).
     __device__ __forceinline__ void load(int s, int kt, int kleft /* kend - kbeg */) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const int range = __builtin_amdgcn_readfirstlane(kt * 16 + 16 <= kleft ? (int)0xffffffffu : 0);
+        const int range = __builtin_amdgcn_readfirstlane(kt * 16 + 16 <= kleft && !(ablate && kt >= 2) ? (int)0xffffffffu : 0);
         if constexpr (KC) {
             const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, range, 0x00020000);
             const uint32_t so = (uint32_t)kt * 64u;
@@ -430,6 +440,82 @@ struct SplitStager {
     }
 };
 
+// An operand whose fragment belongs to ONE wave (waves stacked along M: the wave's 32 rows are nobody else's) skips the LDS: the lane
+// loads its own 8 values of the k-tile -- chunks {h, h + 2} of its row, the same permutation of k as the images -- straight into
+// registers and splits them there (no redundancy: no other wave needs them).
+//   row-contiguous: 8 dword loads; a wave-instruction covers 32 rows of two k = two contiguous 128-byte runs
+//   K-contiguous:   2 dwordx4 loads (bytes 16 h and 32 + 16 h of the row's 64 bytes in this k-tile)
+template <bool KC>
+struct FragLoader {
+    float r[2][8];
+    const char* ubase;
+    int64_t ldb;
+    uint32_t voff;
+    int lh, vec, ablate;
+
+    __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, int vec_ok, int row0 /* of the wave */, int nrows, int kbeg, int lane) {
+        ldb = ld * 4;
+        vec = vec_ok;
+        lh = lane >> 5;
+        const int li = lane & 31;
+        if constexpr (KC) {
+            const int base = min(row0, nrows - 1);          // a wave wholly past the edge of the last tile reads the last row
+            ubase = reinterpret_cast<const char*>(P) + (int64_t)base * ldb + (int64_t)kbeg * 4;
+            voff = (uint32_t)(min(row0 + li, nrows - 1) - base) * (uint32_t)ldb + (uint32_t)lh * 16u;
+        } else {
+            ubase = reinterpret_cast<const char*>(P) + (int64_t)kbeg * ldb;
+            voff = (uint32_t)min(row0 + li, nrows - 1) * 4u + (uint32_t)(4 * lh) * (uint32_t)ldb;
+        }
+    }
+    __device__ __forceinline__ int k_of(int j) const { return 4 * lh + (j & 3) + 8 * (j >> 2); }
+    __device__ __forceinline__ void load(int s, int kt, int kleft) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int range = __builtin_amdgcn_readfirstlane(kt * 16 + 16 <= kleft && !(ablate && kt >= 2) ? (int)0xffffffffu : 0);
+        if constexpr (KC) {
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, range, 0x00020000);
+            const uint32_t so = (uint32_t)kt * 64u;
+            if (vec) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, so + 32u * i, 0);
+                    r[s][4 * i + 0] = __uint_as_float(v[0]);
+                    r[s][4 * i + 1] = __uint_as_float(v[1]);
+                    r[s][4 * i + 2] = __uint_as_float(v[2]);
+                    r[s][4 * i + 3] = __uint_as_float(v[3]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[s][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, so + 4u * (j & 3) + 32u * (j >> 2), 0));
+            }
+        } else {
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase + (int64_t)kt * 16 * ldb), 0, range, 0x00020000);
+            const uint32_t l = (uint32_t)ldb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[s][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (uint32_t)((j & 3) + 8 * (j >> 2)) * l, 0));
+        }
+#endif
+    }
+    __device__ __forceinline__ void load_tail(int s, int kt, int kleft) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kt * 16 + k_of(j);
+            const char* g = KC ? ubase + voff + (int64_t)kt * 64 + 4 * (j & 3) + 32 * (j >> 2) : ubase + voff + (int64_t)(kt * 16 + (j & 3) + 8 * (j >> 2)) * ldb;
+            r[s][j] = k < kleft ? *reinterpret_cast<const float*>(g) : 0.f;
+        }
+    }
+    __device__ __forceinline__ void split(int s, Split3& f) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t h[4], m[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_pair(r[s][2 * j], r[s][2 * j + 1], h[j], m[j], l[j]);
+        using u4 = __attribute__((ext_vector_type(4))) uint32_t;
+        f.h = __builtin_bit_cast(bf16x8, (u4){h[0], h[1], h[2], h[3]});
+        f.m = __builtin_bit_cast(bf16x8, (u4){m[0], m[1], m[2], m[3]});
+        f.l = __builtin_bit_cast(bf16x8, (u4){l[0], l[1], l[2], l[3]});
+#endif
+    }
+};
+
 // a lane's three operand pieces of one 32-row fragment: rows row0 .. row0+31 of an image with BR rows
 template <int BR>
 __device__ __forceinline__ void load_split_fragment(const unsigned char* image, int row, int lh, Split3& f) {
@@ -457,7 +543,9 @@ struct GemmCore {
     // pre-split staging loop: split-bf16 builds, 64 / 128-row operand tiles (the 128 x 160 tile keeps the in-fragment split)
     static constexpr bool kPresplit = kBf16x != 0 && (BM == 64 || BM == 128) && (BN == 64 || BN == 128) && kBK == 16 &&
                                       (SNAG_GEMM_PRESPLIT_KC != 0 || (!A_KC && !B_KC));
-    static constexpr int PS_STAGE_FLOATS = 6 * (BM + BN) * 16 / 4;          // one stage: both images
+    // waves stacked along M (each wave's 32 rows are its own): the A operand never goes through the LDS (FragLoader)
+    static constexpr bool kRowPrivate = kPresplit && WN == BN && WM == 32;
+    static constexpr int PS_STAGE_FLOATS = 6 * ((kRowPrivate ? 0 : BM) + BN) * 16 / 4;          // one stage: both images (B's only when row-private)
     static constexpr int PS_FLOATS = kPresplit ? 2 * PS_STAGE_FLOATS : 0;
     static constexpr int SMEM_FLOATS_ = TILE_FLOATS > STAGE_FLOATS ? TILE_FLOATS : STAGE_FLOATS;
     static constexpr int SMEM_FLOATS = kPresplit ? (PS_FLOATS > STAGE_FLOATS ? PS_FLOATS : STAGE_FLOATS) : SMEM_FLOATS_;
@@ -571,13 +659,82 @@ struct GemmCore {
         const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
         const int li = lane & 31, lh = lane >> 5;
         unsigned char* const sm = reinterpret_cast<unsigned char*>(smem);
-        constexpr int STAGE = PS_STAGE_FLOATS * 4, A_IMG = SplitStager<BM, A_KC>::IMAGE_BYTES;
+        constexpr int STAGE = PS_STAGE_FLOATS * 4, A_IMG = kRowPrivate ? 0 : SplitStager<BM, A_KC>::IMAGE_BYTES;
         const int kleft = kend - kbeg;
         const int nk = kleft / 16;            // full k-tiles; a ragged last one is the tail's
+        if constexpr (kRowPrivate) {
+            // A: registers only.  Iteration kt multiplies tile kt (A pieces split during iteration kt-1, B fragments out of buffer
+            // kt & 1), splits A of tile kt+1 and stages B of tile kt+1 (register sets (kt+1) & 1), fetches tile kt+3 into those sets.
+            static_assert(TM == 1, "row-private: one 32-row fragment per wave");
+            FragLoader<A_KC> fa;
+            SplitStager<BN, B_KC> sb;
+            fa.init(p.A, p.lda, p.a_vec, m0 + wm0, p.M, kbeg, lane);
+            sb.init(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, tid);
+            fa.ablate = p.dbg & 1;
+            sb.ablate = p.dbg & 2;
+            Split3 a_cur[1], a_nxt[1];
+            auto iteration = [&](int kt, auto S) {
+                constexpr int set = decltype(S)::value;
+                const int cur = kt & 1;
+                Split3 b[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + cur * STAGE, wn0 + 32 * j + li, lh, b[j]);
+#if defined(__HIP_DEVICE_COMPILE__) && SNAG_GEMM_PIN_READS
+                __builtin_amdgcn_sched_barrier(0);      // all fragment reads issue before anything else of the iteration (left alone, the
+#endif                                                  // compiler re-reads fragment by fragment right in front of each MFMA: exposed LDS latency)
+#if SNAG_GEMM_ABLATE
+                if (!(p.dbg & 16)) fa.split(set, a_nxt[0]);
+                if (!(p.dbg & 32)) fa.load(set, kt + 3, kleft);
+                if (!(p.dbg & 16)) sb.split_store(set, sm + (cur ^ 1) * STAGE);
+                if (!(p.dbg & 32)) sb.load(set, kt + 3, kleft);
+                if (!(p.dbg & 8)) mfma_split(a_cur, b);
+                a_cur[0] = a_nxt[0];
+                if (!(p.dbg & 4)) __syncthreads();
+#else
+                fa.split(set, a_nxt[0]);
+                fa.load(set, kt + 3, kleft);
+                sb.split_store(set, sm + (cur ^ 1) * STAGE);
+                sb.load(set, kt + 3, kleft);
+                mfma_split(a_cur, b);
+                a_cur[0] = a_nxt[0];
+                __syncthreads();
+#endif
+            };
+            if (nk > 0) {
+                fa.load(0, 0, kleft);
+                sb.load(0, 0, kleft);
+                fa.load(1, 1, kleft);
+                sb.load(1, 1, kleft);
+                fa.split(0, a_cur[0]);
+                sb.split_store(0, sm);
+                fa.load(0, 2, kleft);
+                sb.load(0, 2, kleft);
+                __syncthreads();
+                for (int kt = 0; kt < nk; kt += 2) {
+                    iteration(kt, std::integral_constant<int, 1>{});
+                    iteration(kt + 1, std::integral_constant<int, 0>{});
+                }
+            }
+            if (kleft % 16 != 0) {
+                fa.load_tail(0, nk, kleft);
+                sb.load_tail(0, nk, kleft);
+                fa.split(0, a_cur[0]);
+                sb.split_store(0, sm);
+                __syncthreads();
+                Split3 b[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm, wn0 + 32 * j + li, lh, b[j]);
+                mfma_split(a_cur, b);
+                __syncthreads();
+            }
+            return;
+        }
         SplitStager<BM, A_KC> sa;
         SplitStager<BN, B_KC> sb;
         sa.init(p.A, p.lda, p.a_vec, m0, p.M, kbeg, tid);
         sb.init(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, tid);
+        sa.ablate = p.dbg & 1;            // SNAG_GEMM_DBG: 1 = no A fetch, 2 = no B fetch, 3 = neither (results are wrong)
+        sb.ablate = p.dbg & 2;
         auto fetch = [&](int s, int kt) {
             sa.load(s, kt, kleft);
             sb.load(s, kt, kleft);
@@ -606,10 +763,20 @@ struct GemmCore {
             for (int i = 0; i < TM; ++i) load_split_fragment<BM>(sm + cur * STAGE, wm0 + 32 * i + li, lh, a[i]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + cur * STAGE + A_IMG, wn0 + 32 * j + li, lh, b[j]);
+#if defined(__HIP_DEVICE_COMPILE__) && SNAG_GEMM_PIN_READS
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#if SNAG_GEMM_ABLATE       // -DSNAG_GEMM_ABLATE=1 builds only: SNAG_GEMM_DBG & 4 / 8 / 16 / 32 drop the barrier / MFMAs / staging / fetch
+            if (!(p.dbg & 16)) stage(set, cur ^ 1);
+            if (!(p.dbg & 32)) fetch(set, kt + 3);
+            if (!(p.dbg & 8)) mfma_split(a, b);
+            if (!(p.dbg & 4)) __syncthreads();
+#else                       // (a conditional fetch in the production loop would degrade its counted vmcnt waits to vmcnt(0))
             stage(set, cur ^ 1);
             fetch(set, kt + 3);
             mfma_split(a, b);
             __syncthreads();
+#endif
         };
         if (nk > 0) {
             fetch(0, 0);
@@ -942,7 +1109,7 @@ struct StreamKPlan {
 };
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
-__global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmOperands p, Epi epi, float* __restrict__ slab, StreamKPlan plan) {
+__global__ __launch_bounds__(256, SNAG_GEMM_SK_WAVES) void gemm_streamk_kernel(GemmOperands p, Epi epi, float* __restrict__ slab, StreamKPlan plan) {
     using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
     __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
     const int64_t G = gridDim.x, b = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;   // virtual block id: slab slots and the fix-up use it too
