@@ -112,43 +112,98 @@ struct Epilogue {
     }
 };
 
-// sums the split-K slabs in slab order (deterministic) and applies the epilogue
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, Epilogue epi) {
+// sums the split-K slabs in slab order (deterministic) and applies the epilogue.  QUAD: N % 4 == 0 -- a thread owns four consecutive
+// columns: dwordx4 slab reads (the slabs are the whole traffic: 4 x 7.7 MB for the visual projection) and the epilogue's dwordx4 path.
+template <bool QUAD>
+__device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ slab, int splits, const Epilogue& epi, int64_t first, int64_t stride) {
     const int64_t total = (int64_t)epi.M * epi.N;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        float v = 0.f;
-        int z = 0;
-        for (; z + 8 <= splits; z += 8) {           // eight independent loads in flight, summed in slab order
-            float t[8];
+    if constexpr (QUAD) {
+        const int64_t quads = total / 4;
+        for (int64_t q = first; q < quads; q += stride) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int z = 0;
+            for (; z + 4 <= splits; z += 4) {           // four independent 16-byte loads in flight, summed in slab order
+                float4 t[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = slab[(int64_t)(z + u) * total + i];
+                for (int u = 0; u < 4; ++u) t[u] = reinterpret_cast<const float4*>(slab + (int64_t)(z + u) * total)[q];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v += t[u];
+                for (int u = 0; u < 4; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+            }
+            for (; z < splits; ++z) {
+                const float4 t = reinterpret_cast<const float4*>(slab + (int64_t)z * total)[q];
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            const int64_t i = q * 4;
+            epi((int)(i / epi.N), (int)(i % epi.N), v);
         }
-        for (; z < splits; ++z) v += slab[(int64_t)z * total + i];
-        epi((int)(i / epi.N), (int)(i % epi.N), v);
+    } else {
+        for (int64_t i = first; i < total; i += stride) {
+            float v = 0.f;
+            int z = 0;
+            for (; z + 8 <= splits; z += 8) {           // eight independent loads in flight, summed in slab order
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = slab[(int64_t)(z + u) * total + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += t[u];
+            }
+            for (; z < splits; ++z) v += slab[(int64_t)z * total + i];
+            epi((int)(i / epi.N), (int)(i % epi.N), v);
+        }
     }
 }
 
-// the same for the two problems of gemm_tile_pair_kernel (blockIdx.y = problem)
-__global__ __launch_bounds__(256) void splitk_reduce_pair_kernel(const float* __restrict__ slab0, Epilogue e0, const float* __restrict__ slab1, Epilogue e1,
-                                                                 int splits) {
-    const float* slab = blockIdx.y ? slab1 : slab0;
-    const Epilogue& epi = blockIdx.y ? e1 : e0;
-    const int64_t total = (int64_t)epi.M * epi.N;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        float v = 0.f;
-        int z = 0;
-        for (; z + 8 <= splits; z += 8) {
-            float t[8];
+// Small outputs with many slabs (the D x D and F x D weight gradients: 16-128 K floats, 56-166 slabs): one workgroup = 64 quads,
+// its four waves take every fourth slab each (ascending), the four partial sums meet in LDS in wave order -- a fixed order, four
+// times the loads in flight.
+__device__ __forceinline__ void splitk_reduce_small_body(const float* __restrict__ slab, int splits, const Epilogue& epi, int64_t block) {
+    __shared__ float4 part[3][64];
+    const int64_t total = (int64_t)epi.M * epi.N, quads = total / 4;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t q = block * 64 + lane;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < quads) {
+        int z = g;
+        for (; z + 12 < splits; z += 16) {
+            float4 t[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = slab[(int64_t)(z + u) * total + i];
+            for (int u = 0; u < 4; ++u) t[u] = reinterpret_cast<const float4*>(slab + (int64_t)(z + 4 * u) * total)[q];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v += t[u];
+            for (int u = 0; u < 4; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
         }
-        for (; z < splits; ++z) v += slab[(int64_t)z * total + i];
+        for (; z < splits; z += 4) {
+            const float4 t = reinterpret_cast<const float4*>(slab + (int64_t)z * total)[q];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+    }
+    if (g > 0) part[g - 1][lane] = v;
+    __syncthreads();
+    if (g == 0 && q < quads) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { const float4 t = part[u][lane]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        const int64_t i = q * 4;
         epi((int)(i / epi.N), (int)(i % epi.N), v);
     }
+}
+__global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const float* __restrict__ slab, int splits, Epilogue epi) {
+    splitk_reduce_small_body(slab, splits, epi, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void splitk_reduce_small_pair_kernel(const float* __restrict__ slab0, Epilogue e0, const float* __restrict__ slab1, Epilogue e1,
+                                                                       int splits) {
+    splitk_reduce_small_body(blockIdx.y ? slab1 : slab0, splits, blockIdx.y ? e1 : e0, blockIdx.x);
+}
+static bool reduce_small(int64_t total, int splits) { return total <= (1 << 18) && splits >= 8; }
+
+template <bool QUAD>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, Epilogue epi) {
+    splitk_reduce_body<QUAD>(slab, splits, epi, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+}
+
+// the same for the two problems of gemm_tile_pair_kernel (blockIdx.y = problem)
+template <bool QUAD>
+__global__ __launch_bounds__(256) void splitk_reduce_pair_kernel(const float* __restrict__ slab0, Epilogue e0, const float* __restrict__ slab1, Epilogue e1,
+                                                                 int splits) {
+    splitk_reduce_body<QUAD>(blockIdx.y ? slab1 : slab0, splits, blockIdx.y ? e1 : e0, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
 }
 
 // S = alpha * Z Z^T (Z [n, k], K-contiguous).  Only tiles on or above the diagonal run the main loop; each also writes its
@@ -355,8 +410,11 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     // Long K (the projections and their weight gradients): 128 x 128 "row-private" tiles -- four waves stacked along M, each wave's
     // 32 rows of A go straight to its registers, only B goes through the LDS (44 % less LDS traffic per multiply-add, half the
     // re-reads of B per launch).  For K = 128 / 256 the 64 x 128 tile stays (twice the workgroups for the same output).
-    static const int tallk = env_int("SNAG_GEMM_TALLK");        // tuning: threshold (default 512); -1 = never
-    if (kBf16x != 0 && tallk >= 0 && p.K >= (tallk > 0 ? tallk : 512)) big = true;
+    // (per shape, in the step: [15000,128,4096] 110 -> 92 us, [4096,128,15000] 94 -> 87; but [15000,128,768] 29.7 + 8.1 -> 28.6 + 11.4
+    // with its reduce, [128,128,15000] x 2 16.4 -> 20.6, [256,128,45000] 30.5 -> 31.6: long K AND many rows only.)
+    static const int tallk = env_int("SNAG_GEMM_TALLK");        // tuning: K threshold (default 1024); -1 = never
+    static const int tallm = env_int("SNAG_GEMM_TALLM");        // tuning: M threshold (default 1024)
+    if (kBf16x != 0 && tallk >= 0 && p.K >= (tallk > 0 ? tallk : 1024) && p.M >= (tallm > 0 ? tallm : 1024)) big = true;
     if (force_tile() != 0) { big = force_tile() == 2; wide = force_tile() == 3; }
     if (kBK != 16) wide = false;        // the 128x160 tiles of a 32-deep k-tile do not fit the 64 KB static LDS limit
     if (wide) big = false;
@@ -423,8 +481,12 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     if (rc) return rc;
     if (splits > 1) {
         const int64_t total = (int64_t)p.M * p.N;
-        const int blocks = (int)std::min<int64_t>(2048, (total + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, splits, e);
+        const bool quad = p.N % 4 == 0 && ((uintptr_t)slab & 15) == 0;         // (slab z starts z M N floats in: a multiple of 16 bytes)
+        const int blocks = (int)std::min<int64_t>(2048, (total / (quad ? 4 : 1) + 255) / 256);
+        if (quad && reduce_small(total, splits))
+            hipLaunchKernelGGL(splitk_reduce_small_kernel, dim3((unsigned)((total / 4 + 63) / 64)), dim3(256), 0, st, slab, splits, e);
+        else if (quad) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, slab, splits, e);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, slab, splits, e);
         rc = check_launch("snag_gemm_f32(split-K reduce)");
     }
     return rc;
@@ -456,8 +518,13 @@ int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipSt
     if (rc) return rc;
     if (splits > 1) {
         const int64_t total = (int64_t)a.p.M * a.p.N;
-        const int blocks = (int)std::min<int64_t>(1024, (total + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_pair_kernel, dim3(blocks, 2), dim3(256), 0, st, (const float*)s0, a.e, (const float*)s1, b.e, splits);
+        const bool quad = a.p.N % 4 == 0 && ((uintptr_t)s0 & 15) == 0 && ((uintptr_t)s1 & 15) == 0;
+        const int blocks = (int)std::min<int64_t>(1024, (total / (quad ? 4 : 1) + 255) / 256);
+        if (quad && reduce_small(total, splits))
+            hipLaunchKernelGGL(splitk_reduce_small_pair_kernel, dim3((unsigned)((total / 4 + 63) / 64), 2), dim3(256), 0, st, (const float*)s0, a.e,
+                               (const float*)s1, b.e, splits);
+        else if (quad) hipLaunchKernelGGL(splitk_reduce_pair_kernel<true>, dim3(blocks, 2), dim3(256), 0, st, (const float*)s0, a.e, (const float*)s1, b.e, splits);
+        else hipLaunchKernelGGL(splitk_reduce_pair_kernel<false>, dim3(blocks, 2), dim3(256), 0, st, (const float*)s0, a.e, (const float*)s1, b.e, splits);
         rc = check_launch("snag_gemm_f32_pair(split-K reduce)");
     }
     return rc;
