@@ -410,11 +410,11 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     // Long K (the projections and their weight gradients): 128 x 128 "row-private" tiles -- four waves stacked along M, each wave's
     // 32 rows of A go straight to its registers, only B goes through the LDS (44 % less LDS traffic per multiply-add, half the
     // re-reads of B per launch).  For K = 128 / 256 the 64 x 128 tile stays (twice the workgroups for the same output).
-    // (per shape, in the step: [15000,128,4096] 110 -> 92 us, [4096,128,15000] 94 -> 87; but [15000,128,768] 29.7 + 8.1 -> 28.6 + 11.4
-    // with its reduce, [128,128,15000] x 2 16.4 -> 20.6, [256,128,45000] 30.5 -> 31.6: long K AND many rows only.)
-    static const int tallk = env_int("SNAG_GEMM_TALLK");        // tuning: K threshold (default 1024); -1 = never
+    // (per shape, in the step: [15000,128,4096] 110 -> 92 us, [4096,128,15000] 94 -> 87, [15000,128,768] 29.7 -> 28.6; but
+    // [128,128,15000] x 2 16.4 -> 20.6, [256,128,45000] 30.5 -> 31.6: long K AND many rows only.)
+    static const int tallk = env_int("SNAG_GEMM_TALLK");        // tuning: K threshold (default 512); -1 = never
     static const int tallm = env_int("SNAG_GEMM_TALLM");        // tuning: M threshold (default 1024)
-    if (kBf16x != 0 && tallk >= 0 && p.K >= (tallk > 0 ? tallk : 1024) && p.M >= (tallm > 0 ? tallm : 1024)) big = true;
+    if (kBf16x != 0 && tallk >= 0 && p.K >= (tallk > 0 ? tallk : 512) && p.M >= (tallm > 0 ? tallm : 1024)) big = true;
     if (force_tile() != 0) { big = force_tile() == 2; wide = force_tile() == 3; }
     if (kBK != 16) wide = false;        // the 128x160 tiles of a 32-deep k-tile do not fit the 64 KB static LDS limit
     if (wide) big = false;
