@@ -98,11 +98,11 @@ def roofline_dominant(cfg, timer, rows=None):
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_dominant.json")) as f:
             pmc = json.load(f)
         if (pmc["n_ent"], pmc["feat0"], pmc["dim"]) == (rows, cfg.feat_dims[0], cfg.dim):
-            # the timed call is the stream-K kernel AND its fix-up launch: both kernels' HBM bytes
+            # the timed call is the GEMM kernel AND its split-K reduce launch: both kernels' HBM bytes
             traffic, src = pmc["fetch_bytes"] + pmc["write_bytes"] + pmc.get("fixup_fetch_bytes", 0) + pmc.get("fixup_write_bytes", 0), pmc["source"]
     except (OSError, KeyError, ValueError):
         pass
-    return {"kernel": f"gemm_streamk_kernel<64,128,..> + streamk_fixup_kernel (visual projection: [{rows},{cfg.feat_dims[0]}]x[{cfg.feat_dims[0]},{cfg.dim}], fp32 via 6 split-bf16 MFMA products)",
+    return {"kernel": f"gemm_tile_kernel<128,128,32,128,..> + splitk_reduce_kernel (visual projection: [{rows},{cfg.feat_dims[0]}]x[{cfg.feat_dims[0]},{cfg.dim}], fp32 via 6 split-bf16 MFMA products, 4 K-splits)",
             # the bound of the kernel AS BUILT: six bf16 MFMA products per f32 multiply-add -> bf16 dense peak / 6 (37.5 us for this
             # launch; its HBM floor, 255.5 MB at 8 TB/s, is 32 us).  frac is therefore the share of the matrix pipe's time the
             # launch (kernel + fix-up) uses; against the f32 MFMA peak (157.3 TF), which bounded the previous form of this kernel
