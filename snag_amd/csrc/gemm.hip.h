@@ -1,18 +1,19 @@
-// Exact-fp32 MFMA GEMM core (v_mfma_f32_32x32x2_f32: bitwise a k-ordered fmaf chain, 157 TFLOP/s peak).
+// fp32 GEMM core on the gfx950 matrix pipe.
 //
-//   C[m,n] = epilogue( sum_k A(m,k) * B(n,k) )
+//   C[m,n] = epilogue( sum_k A(m,k) * B(n,k) )          fp32 in, fp32 accumulate, fp32 out
 //
-// Each operand is either "K-contiguous" (element (r,k) at ptr[r*ld + k]: activations [rows,K],
-// nn.Linear weights W[out,in]) or "row-contiguous" (element (r,k) at ptr[k*ld + r]: the transposed
-// uses in the backward GEMMs).  A float4 fetched from global memory goes to LDS as ONE ds_write_b128:
-//   * K-contiguous: the tile keeps its row-major shape, [row][16 k] = four 16-byte chunks per row, with the chunk
-//     index XOR-swizzled by (row >> 2) & 3.  A lane fetches its MFMA operands as ds_read_b128: lane half h reads
-//     chunk 2cp + h of its row and feeds four consecutive MFMA k-steps from it, i.e. within a k-tile the sum runs
-//     over k in the order 8cp + 4h + j -- a permutation of k, applied identically to both operands (the swizzle
-//     makes every 16-lane ds_read_b128 group hit 16 distinct 16-byte slots: conflict-free);
-//   * row-contiguous: the tile is [k][row]; operands are conflict-free ds_read_b32 at the same permuted k.
-// 256 threads = 4 waves in a 2x2 grid, double-buffered LDS, global loads for tile t+1 in flight
-// while tile t feeds the matrix pipe.
+// Each operand is either "K-contiguous" (element (r,k) at ptr[r*ld + k]: activations [rows,K], nn.Linear weights W[out,in]) or
+// "row-contiguous" (element (r,k) at ptr[k*ld + r]: the transposed uses in the projections and the backward GEMMs).
+//
+// Three main loops live in GemmCore, chosen at compile time (DESIGN.md par. 4):
+//   * run_presplit, row-private (kRowPrivate: 128 x 128 tile, four waves stacked along M; long K): the default build multiplies f32
+//     values as six bf16 MFMA products of exactly split operands (SNAG_GEMM_BF16X = 6).  A wave's 32 rows of A go from global memory
+//     to its registers and are split there; B is split once per workgroup into an LDS image in MFMA operand order.
+//   * run_presplit, 64 x 128 tile (2 x 2 waves; short K, small outputs): both operands are split once per workgroup into LDS images.
+//   * run_loop: the f32-MFMA form (v_mfma_f32_32x32x2_f32; -DSNAG_GEMM_BF16X=0) and the in-fragment split (the 128 x 160 tile,
+//     reachable through SNAG_GEMM_TILE=3 only): f32 tiles in LDS -- K-contiguous tiles row-major with XOR-swizzled 16-byte chunks,
+//     row-contiguous tiles [k][row] -- filled by LDS-DMA or through registers, double-buffered.
+// Within a k-tile the sum runs over a fixed permutation of k, the same for both operands.  256 threads = 4 waves.
 #pragma once
 #include <type_traits>
 #include "common.hip.h"
