@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_pair_kernel(const float* __
 }
 
 // S = alpha * Z Z^T (Z [n, k], K-contiguous).  Only tiles on or above the diagonal run the main loop; each also writes its
-// transpose (staged through LDS so that both copies leave in full 128-byte lines), so S is symmetric bit for bit and the MFMA
-// work is (almost) halved.
+// transpose (staged through LDS so that both copies leave in full 128-byte lines) -- a diagonal tile the transpose of its own
+// upper triangle -- so S is symmetric bit for bit and the MFMA work is (almost) halved.
 __global__ __launch_bounds__(256) void gram_tile_kernel(GemmOperands p, float alpha, float* __restrict__ C, int64_t ldc, int T) {
     // 1-D grid over the T (T + 1) / 2 tiles on or above the diagonal, row-major; the XCD remap hands each L2 a contiguous run
     const int k = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(GemmOperands p, float al
     while (by > 0 && by * T - by * (by - 1) / 2 > k) --by;
     while (by + 1 < T && (by + 1) * T - (by + 1) * by / 2 <= k) ++by;
     const int bx = by + (k - (by * T - by * (by - 1) / 2));
-    using Core = GemmCore<128, 128, 64, 64, true, true, false, true>;      // SYM: S[i][j] == S[j][i] inside the diagonal tiles too
+    using Core = GemmCore<128, 128, 64, 64, true, true, false>;
     constexpr int kSmem = Core::SMEM_FLOATS > Core::kTransposeStageFloats ? Core::SMEM_FLOATS : Core::kTransposeStageFloats;
     __shared__ __attribute__((aligned(16))) float smem[kSmem];
     const int m0 = by * 128, n0 = bx * 128;
@@ -225,10 +225,19 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(GemmOperands p, float al
     core.run(p, smem, m0, n0, 0, p.K);
     const int n = p.M;
     const bool vec = (ldc % 4 == 0) && ((((uintptr_t)C) & 15) == 0);
+    // A diagonal tile holds S[i][j] and S[j][i] as two separately accumulated values (with split-bf16 products a.b and b.a differ in
+    // their last bits): only its elements on or above the diagonal are stored, the transposed pass below mirrors them.
+    const bool diag = bx == by;
     core.for_each(smem, m0, n0, [=](int r, int c, float4 v) {
         if (r >= n || c >= n) return;
         float* o = C + (int64_t)r * ldc + c;
         v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+        if (diag && c < r) {            // the quad starts left of the diagonal: element-wise, upper part only
+            if (c + 1 >= r && c + 1 < n) o[1] = v.y;
+            if (c + 2 >= r && c + 2 < n) o[2] = v.z;
+            if (c + 3 >= r && c + 3 < n) o[3] = v.w;
+            return;
+        }
         if (vec && c + 3 < n) {
             *reinterpret_cast<float4*>(o) = v;
         } else {
@@ -238,10 +247,10 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(GemmOperands p, float al
             if (c + 3 < n) o[3] = v.w;
         }
     });
-    if (bx != by)      // the mirror tile: C[col, row], 128-byte runs along the transposed rows
-        core.for_each_transposed(smem, m0, n0, [=](int c, int r, float v) {
-            if (r < n && c < n) C[(int64_t)c * ldc + r] = alpha * v;
-        });
+    // the mirror: C[col, row], 128-byte runs along the transposed rows (a diagonal tile mirrors its strict upper part)
+    core.for_each_transposed(smem, m0, n0, [=](int c, int r, float v) {
+        if (r < n && c < n && (!diag || c > r)) C[(int64_t)c * ldc + r] = alpha * v;
+    });
 }
 
 // VEC: every fetch is an unpredicated dwordx4 (all shapes of the hot path); otherwise the checked loader

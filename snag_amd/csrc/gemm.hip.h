@@ -531,10 +531,10 @@ __device__ __forceinline__ void load_split_fragment(const unsigned char* image, 
 
 // Main loop.  acc[mi][ni] is the 32x32 tile (mi, ni) of this wave's WM x WN patch:
 //   row = wm0 + 32*mi + (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5),  col = wn0 + 32*ni + (lane & 31).
-// SYM (split-bf16 builds): C(a, b) == C(b, a) bit for bit.  The six products are not symmetric one by one (h*m <-> m*h, h*l <-> l*h
-// under an exchange of the operands) and f32 addition is not associative, so the two mirrored families accumulate in two extra
-// accumulator sets that exchange roles with the operands, and meet in one commutative addition at the end.
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, bool SYM = false>
+// (With split-bf16 products C(a, b) and C(b, a) differ in their last bits: h*m <-> m*h, h*l <-> l*h under an exchange of the operands,
+// and f32 addition is not associative.  snag_gram_f32 therefore mirrors the upper triangle of its diagonal tiles instead of trusting
+// both halves.)
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC>
 struct GemmCore {
     static constexpr int TM = WM / 32, TN = WN / 32;
     static constexpr int A_BUF = TileLd<BM, A_KC>::floats, B_BUF = TileLd<BN, B_KC>::floats, B_BASE = 2 * A_BUF;
@@ -553,8 +553,6 @@ struct GemmCore {
     static_assert((BM / WM) * (BN / WN) == 4, "four waves per block");
 
     f32x16 acc[TM][TN];
-    static constexpr bool kSym = SYM && kBf16x != 0;
-    f32x16 accx[kSym ? TM : 1][kSym ? TN : 1], accy[kSym ? TM : 1][kSym ? TN : 1];      // (a small, b large) / (a large, b small)
 
     // one k-tile's worth of matrix work: av[s][i] / bv[s][j] are this lane's operand values of k-step s
     __device__ __forceinline__ void mfma_chain(const float (&av)[kBK / 2][TM], const float (&bv)[kBK / 2][TN]) {
@@ -589,31 +587,17 @@ struct GemmCore {
 #define SNAG_MFMA_TERM(ACC, X, Y)                                                                                     \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                     \
         ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].X, b[j].Y, ACC[i][j], 0, 0, 0);
-                if constexpr (kSym) {
-                    if constexpr (kBf16x == 9) {
-                        SNAG_MFMA_TERM(acc, l, l)
-                        SNAG_MFMA_TERM(accx, l, m)
-                        SNAG_MFMA_TERM(accy, m, l)
-                    }
-                    SNAG_MFMA_TERM(accx, l, h)
-                    SNAG_MFMA_TERM(accy, h, l)
-                    SNAG_MFMA_TERM(acc, m, m)
-                    SNAG_MFMA_TERM(accx, m, h)
-                    SNAG_MFMA_TERM(accy, h, m)
-                    SNAG_MFMA_TERM(acc, h, h)
-                } else {
-                    if constexpr (kBf16x == 9) {
-                        SNAG_MFMA_TERM(acc, l, l)
-                        SNAG_MFMA_TERM(acc, l, m)
-                        SNAG_MFMA_TERM(acc, m, l)
-                    }
-                    SNAG_MFMA_TERM(acc, l, h)
-                    SNAG_MFMA_TERM(acc, h, l)
-                    SNAG_MFMA_TERM(acc, m, m)
-                    SNAG_MFMA_TERM(acc, m, h)
-                    SNAG_MFMA_TERM(acc, h, m)
-                    SNAG_MFMA_TERM(acc, h, h)
+                if constexpr (kBf16x == 9) {
+                    SNAG_MFMA_TERM(acc, l, l)
+                    SNAG_MFMA_TERM(acc, l, m)
+                    SNAG_MFMA_TERM(acc, m, l)
                 }
+                SNAG_MFMA_TERM(acc, l, h)
+                SNAG_MFMA_TERM(acc, h, l)
+                SNAG_MFMA_TERM(acc, m, m)
+                SNAG_MFMA_TERM(acc, m, h)
+                SNAG_MFMA_TERM(acc, h, m)
+                SNAG_MFMA_TERM(acc, h, h)
 #undef SNAG_MFMA_TERM
             }
         }
@@ -626,31 +610,17 @@ struct GemmCore {
 #define SNAG_MFMA_TERM(ACC, X, Y)                                                                                     \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                     \
         ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].X, b[j].Y, ACC[i][j], 0, 0, 0);
-        if constexpr (kSym) {
-            if constexpr (kBf16x == 9) {
-                SNAG_MFMA_TERM(acc, l, l)
-                SNAG_MFMA_TERM(accx, l, m)
-                SNAG_MFMA_TERM(accy, m, l)
-            }
-            SNAG_MFMA_TERM(accx, l, h)
-            SNAG_MFMA_TERM(accy, h, l)
-            SNAG_MFMA_TERM(acc, m, m)
-            SNAG_MFMA_TERM(accx, m, h)
-            SNAG_MFMA_TERM(accy, h, m)
-            SNAG_MFMA_TERM(acc, h, h)
-        } else {
-            if constexpr (kBf16x == 9) {
-                SNAG_MFMA_TERM(acc, l, l)
-                SNAG_MFMA_TERM(acc, l, m)
-                SNAG_MFMA_TERM(acc, m, l)
-            }
-            SNAG_MFMA_TERM(acc, l, h)
-            SNAG_MFMA_TERM(acc, h, l)
-            SNAG_MFMA_TERM(acc, m, m)
-            SNAG_MFMA_TERM(acc, m, h)
-            SNAG_MFMA_TERM(acc, h, m)
-            SNAG_MFMA_TERM(acc, h, h)
+        if constexpr (kBf16x == 9) {
+            SNAG_MFMA_TERM(acc, l, l)
+            SNAG_MFMA_TERM(acc, l, m)
+            SNAG_MFMA_TERM(acc, m, l)
         }
+        SNAG_MFMA_TERM(acc, l, h)
+        SNAG_MFMA_TERM(acc, h, l)
+        SNAG_MFMA_TERM(acc, m, m)
+        SNAG_MFMA_TERM(acc, m, h)
+        SNAG_MFMA_TERM(acc, h, m)
+        SNAG_MFMA_TERM(acc, h, h)
 #undef SNAG_MFMA_TERM
 #endif
     }
@@ -809,38 +779,11 @@ struct GemmCore {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        acc[i][j][e] = 0.f;
-                        if constexpr (kSym) accx[i][j][e] = accy[i][j][e] = 0.f;
-                    }
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
             if (kend > kbeg) run_presplit(p, smem, m0, n0, kbeg, kend);
-            if constexpr (kSym) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[i][j][e] += accx[i][j][e] + accy[i][j][e];
-            }
             return;
         }
-        if constexpr (kSym) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) accx[i][j][e] = accy[i][j][e] = 0.f;
-        }
         run_loop(p, smem, m0, n0, kbeg, kend);
-        if constexpr (kSym) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] += accx[i][j][e] + accy[i][j][e];
-        }
     }
 
     __device__ __forceinline__ void run_loop(const GemmOperands& p, float* __restrict__ smem, int m0, int n0, int kbeg, int kend) {

@@ -101,9 +101,9 @@ def test_gemm_splitk_long_k_deterministic():
 
 @pytest.mark.parametrize("n,k,pad", [(7, 3, 0), (129, 16, 0), (300, 37, 3), (301, 300, 0), (1000, 300, 4), (64, 0, 0)])
 def test_gram_is_symmetric_and_matches_gemm(n, k, pad):
-    """snag_gram_f32: upper-triangle tiles + transposed stores.  S == S^T bit for bit (inside the diagonal tiles too: the split-bf16
-    product families that mirror each other under an exchange of the operands accumulate separately and meet in one commutative
-    add); the same products as the plain GEMM, summed in that different order."""
+    """snag_gram_f32: upper-triangle tiles + transposed stores.  S == S^T bit for bit (inside the diagonal tiles too: only their upper
+    triangle is stored, and mirrored -- with split-bf16 products a.b and b.a differ in their last bits); the plain GEMM's values up to
+    f32 summation order."""
     from snag_amd import ops
     g = torch.Generator().manual_seed(n * 31 + k)
     zfull = torch.randn(n, k + pad, generator=g).to(DEV)
