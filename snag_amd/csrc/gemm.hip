@@ -548,6 +548,9 @@ int gemm_check(const snag_gemm_desc* d) {
     SNAG_REQUIRE(d->ldc >= d->N, SNAG_ERR_ARG, "gemm: ldc=%ld < N=%d", (long)d->ldc, d->N);
     SNAG_REQUIRE(d->lda >= (d->a_kcontig ? d->K : d->M), SNAG_ERR_ARG, "gemm: lda=%ld too small", (long)d->lda);
     SNAG_REQUIRE(d->ldb >= (d->b_kcontig ? d->K : d->N), SNAG_ERR_ARG, "gemm: ldb=%ld too small", (long)d->ldb);
+    // the staged loaders address one operand tile with 32-bit byte offsets from a 64-bit base: 128 rows (or 16 k rows) x pitch < 4 GB
+    SNAG_REQUIRE(d->lda < (1 << 22) && d->ldb < (1 << 22), SNAG_ERR_UNSUPPORTED, "gemm: operand pitch lda=%ld / ldb=%ld above 4M elements", (long)d->lda,
+                 (long)d->ldb);
     SNAG_REQUIRE(d->act >= 0 && d->act <= 4, SNAG_ERR_ARG, "gemm: act=%d unknown", d->act);
     SNAG_REQUIRE(d->act < 3 || (d->aux && d->ldaux >= d->N), SNAG_ERR_ARG, "gemm: act=%d needs aux [M,N]", d->act);
     SNAG_REQUIRE(!d->add1 || d->ld1 >= d->N, SNAG_ERR_ARG, "gemm: ld1 too small");

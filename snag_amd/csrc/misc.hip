@@ -28,6 +28,13 @@ __device__ __forceinline__ void bernoulli_keep_body(int64_t vblock, uint64_t see
     if (tick != nullptr) seed += tick[0] * 0x9E3779B97F4A7C15ull;    // a fresh stream per training step inside a replayed graph
     const Philox4 r = philox4x32_10(seed, (uint64_t)q);
     const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+    if (q * 4 + 3 < n && (((uintptr_t)out) & 3) == 0) {          // one 4-byte store per draw
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w |= (u01(rr[e]) >= p ? 1u : 0u) << (8 * e);
+        reinterpret_cast<uint32_t*>(out)[q] = w;
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
         if (q * 4 + e < n) out[q * 4 + e] = u01(rr[e]) >= p ? 1 : 0;
@@ -218,6 +225,20 @@ __device__ __forceinline__ void entity_token_fwd_body(int64_t vblock, int64_t vg
                                                       const float* __restrict__ noise, const uint8_t* __restrict__ nmask,
                                                       float a, float* __restrict__ out, int64_t ld) {
     const int64_t total = N * (int64_t)D;
+    const bool quad = D % 4 == 0 && ld % 4 == 0 && ((((uintptr_t)table) | ((uintptr_t)out) | ((uintptr_t)noise)) & 15) == 0;
+    if (quad) {                 // four columns per thread: dwordx4 in, dwordx4 out
+        for (int64_t q = vblock * 256 + threadIdx.x; q * 4 < total; q += vgrid * 256) {
+            const int64_t i = q * 4, n = i / D;
+            const int c = (int)(i % D);
+            float4 v = *reinterpret_cast<const float4*>(table + i);
+            if (nmask != nullptr && nmask[n]) {
+                const float4 z = *reinterpret_cast<const float4*>(noise + i);
+                v.x = (1.0f - a) * v.x + a * z.x; v.y = (1.0f - a) * v.y + a * z.y; v.z = (1.0f - a) * v.z + a * z.z; v.w = (1.0f - a) * v.w + a * z.w;
+            }
+            *reinterpret_cast<float4*>(out + n * ld + c) = v;
+        }
+        return;
+    }
     for (int64_t i = vblock * 256 + threadIdx.x; i < total; i += vgrid * 256) {
         const int64_t n = i / D;
         const int c = (int)(i % D);
@@ -538,7 +559,7 @@ extern "C" SNAG_API int snag_step_prologue(uint64_t sample_seed, const uint64_t*
     a.table = table; a.N = n_rows; a.D = dim; a.noise = noise; a.nmask = noise_mask; a.a = half_mask_ratio; a.tok = tok; a.tok_ld = tok_ld;
     a.d_seed = drop_seed; a.d_n = drop_n; a.d_p = drop_p; a.d_out = drop_out;
     a.nb_s = (int)((batch * n_neg + 255) / 256);
-    a.nb_e = n_rows > 0 ? grid_for(n_rows * (int64_t)dim) : 0;
+    a.nb_e = n_rows > 0 ? grid_for((n_rows * (int64_t)dim + 3) / 4) : 0;          // (the dwordx4 form covers four elements per thread; the scalar form strides)
     const int nb_d = (int)((drop_n + 1023) / 1024);
     const int total = a.nb_s + a.nb_e + nb_d;
     if (total == 0) return SNAG_OK;

@@ -24,7 +24,9 @@ def _dev(h, r, t):
 
 @pytest.mark.parametrize("N,R,B,K,mode,filt,tick", [
     (15000, 558, 1024, 32, 0, True, 7), (60, 4, 50, 32, 0, True, None), (60, 4, 50, 5, 1, True, 3), (300, 7, 33, 130, 1, False, 0),
-    (40, 3, 9, 1, 0, True, 1), ((1 << 20) + 3, 11, 17, 64, 0, True, 123456789)])
+    (40, 3, 9, 1, 0, True, 1), ((1 << 20) + 3, 11, 17, 64, 0, True, 123456789),
+    # >= 8,192 known triples: the workgroup's coarse key index in LDS narrows the search (dense key space: many rejections)
+    (15000, 558, 4096, 32, 0, True, 5), (200, 5, 3000, 8, 1, True, 2), (120, 3, 4000, 16, 0, True, None)])
 def test_with_replacement_sampler_equals_oracle(N, R, B, K, mode, filt, tick):
     from snag_amd import ops
     h, r, t, known = _kg(N + K, B, N, R)
