@@ -122,11 +122,10 @@ static int fusion_fwd_readout(const snag_fusion_desc* f, const snag_fusion_layer
     // K,V of every token: columns D..3D of the stacked projection
     snag_gemm_desc gd = gemm_desc((int)NM, 2 * D, D, xin, D, true, P.wqkv + (int64_t)D * D, D, true, S.qkv + D, 3 * D);
     gd.bias = P.bqkv + D;
-    if ((rc = gemm_dispatch(&gd, st))) return rc;
-    // Q of token g only: rows n*M + g of x (stride M*D) -> the q part of the same rows of qkv
-    gd = gemm_desc(N, D, D, xin + (int64_t)g * D, MD, true, P.wqkv, D, true, S.qkv + (int64_t)g * 3 * D, 3 * MD);
-    gd.bias = P.bqkv;
-    if ((rc = gemm_dispatch(&gd, st))) return rc;
+    // Q of token g only: rows n*M + g of x (stride M*D) -> the q part of the same rows of qkv.  Disjoint outputs: one grouped launch.
+    snag_gemm_desc gq = gemm_desc(N, D, D, xin + (int64_t)g * D, MD, true, P.wqkv, D, true, S.qkv + (int64_t)g * 3 * D, 3 * MD);
+    gq.bias = P.bqkv;
+    if ((rc = gemm_dispatch_pair(&gd, &gq, st))) return rc;
     SNAG_MNU(attn_ro_fwd_kernel, M, D, egrid, st, (const float*)S.qkv, N, D, H, g, 1.0f / sqrtf((float)(D / H)), P.keep_probs, kscale, S.probs, S.ctx);
     if ((rc = check_launch("fusion attention (read-out)"))) return rc;
     gd = gemm_desc(N, D, D, S.ctx, D, true, P.wo, D, true, S.t1, D);

@@ -510,6 +510,31 @@ int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipSt
                       d0->K == d1->K && d0->a_kcontig == d1->a_kcontig && d0->b_kcontig == d1->b_kcontig && a.p.k_per_split == b.p.k_per_split &&
                       use_vec(a.p, d0->a_kcontig, d0->b_kcontig) == use_vec(b.p, d1->a_kcontig, d1->b_kcontig) &&
                       (a.splits == 1 || (d0->workspace != d1->workspace));
+    // different shapes, same layouts, 64 x 128 tiles, no K split on either side: one grouped launch
+    const bool group = !off && !same && !a.streamk && !b.streamk && !a.wide && !b.wide && !a.big && !b.big && a.splits == 1 && b.splits == 1 &&
+                       d0->K > 0 && d1->K > 0 && d0->a_kcontig == d1->a_kcontig && d0->b_kcontig == d1->b_kcontig &&
+                       use_vec(a.p, d0->a_kcontig, d0->b_kcontig) == use_vec(b.p, d1->a_kcontig, d1->b_kcontig);
+    if (group) {
+        const int tn0 = ceil_div(a.p.N, 128), tn1 = ceil_div(b.p.N, 128);
+        const int t0 = tn0 * ceil_div(a.p.M, 64), t1 = tn1 * ceil_div(b.p.M, 64);
+        const bool vec = use_vec(a.p, d0->a_kcontig, d0->b_kcontig);
+        if (log_shapes())
+            fprintf(stderr, "snag_gemm GROUP M=%d N=%d K=%d + M=%d N=%d K=%d a_kc=%d b_kc=%d tile=64x128\n", a.p.M, a.p.N, a.p.K, b.p.M, b.p.N, b.p.K,
+                    (int)d0->a_kcontig, (int)d0->b_kcontig);
+        GemmOperands pa = a.p, pb = b.p;
+        pa.k_per_split = pa.K; pb.k_per_split = pb.K;
+#define SNAG_GROUP(AK, BK_)                                                                                                                   \
+    do {                                                                                                                                      \
+        if (vec) hipLaunchKernelGGL((gemm_tile_group2_kernel<64, 128, 32, 64, AK, BK_, true, Epilogue>), dim3(t0 + t1), dim3(256), 0, st, pa, a.e, pb, b.e, t0, tn0, tn1);   \
+        else hipLaunchKernelGGL((gemm_tile_group2_kernel<64, 128, 32, 64, AK, BK_, false, Epilogue>), dim3(t0 + t1), dim3(256), 0, st, pa, a.e, pb, b.e, t0, tn0, tn1);     \
+    } while (0)
+        if (d0->a_kcontig && d0->b_kcontig) SNAG_GROUP(true, true);
+        else if (d0->a_kcontig && !d0->b_kcontig) SNAG_GROUP(true, false);
+        else if (!d0->a_kcontig && d0->b_kcontig) SNAG_GROUP(false, true);
+        else SNAG_GROUP(false, false);
+#undef SNAG_GROUP
+        return check_launch("snag_gemm_f32_pair(grouped)");
+    }
     if (!same) {
         int rc = gemm_dispatch(d0, st);
         return rc ? rc : gemm_dispatch(d1, st);

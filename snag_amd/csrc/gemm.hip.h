@@ -1019,6 +1019,25 @@ __device__ __forceinline__ void gemm_tile_body(const GemmOperands& p, const Epi&
     }
 }
 
+// Two problems of DIFFERENT shape (same layouts, no K split) in one launch: a linear tile index, problem 0's tiles first.  The
+// query projection of the read-out token (235 tiles) fills the drain of the key / value projection (1,408 tiles) instead of paying
+// its own launch, first-load latency and drain.
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
+__global__ __launch_bounds__(256) void gemm_tile_group2_kernel(GemmOperands p0, Epi e0, GemmOperands p1, Epi e1, int tiles0, int tiles_n0, int tiles_n1) {
+    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
+    __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
+    int b = blockIdx.x;
+    const bool first = b < tiles0;
+    if (!first) b -= tiles0;
+    const GemmOperands& p = first ? p0 : p1;
+    const int tn = first ? tiles_n0 : tiles_n1;
+    const int m0 = (b / tn) * BM, n0 = (b % tn) * BN;
+    Core core;
+    core.run(p, smem, m0, n0, 0, p.K);
+    if (first) core.for_each(smem, m0, n0, e0);
+    else core.for_each(smem, m0, n0, e1);
+}
+
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmOperands p, Epi epi, float* __restrict__ slab) {
     using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
