@@ -138,7 +138,7 @@ def _desc(a, b, out, a_kc, b_kc, ws=None, **kw):
                                                    ((128, 128, 15000), False, False, True), ((333, 100, 77), True, True, False)])
 def test_gemm_pair_equals_two_single_launches(shape, a_kc, b_kc, split):
     """snag_gemm_f32_pair: two same-shaped problems in one launch give the bits of two snag_gemm_f32 calls (with and without
-    split-K, with different epilogues per problem); different shapes fall back to two launches."""
+    split-K, with different epilogues per problem); different shapes: see test_gemm_pair_of_different_shapes_is_one_grouped_launch."""
     import ctypes
     from snag_amd import _lib
     from snag_amd._lib import call, ptr, stream
@@ -165,12 +165,42 @@ def test_gemm_pair_equals_two_single_launches(shape, a_kc, b_kc, split):
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
     ra = (A[1].double() if a_kc else A[1].double().t()) @ (B[1].double().t() if b_kc else B[1].double())
     assert_close(got[1], ra, atol=2e-6 * K + 1e-5, rtol=2e-5)
-    # different shapes: still correct (two launches)
+    # different shapes: still correct (grouped launch, or two launches when one side splits K)
     o2, o3 = torch.zeros(M, N, device=DEV), torch.zeros(64, 128, device=DEV)
     a3, b3 = mk(64, 32), mk(128, 32)
     call("snag_gemm_f32_pair", ctypes.byref(_desc(A[1], B[1], o2, a_kc, b_kc)), ctypes.byref(_desc(a3, b3, o3, True, True)), stream())
     assert_close(o2, ra, atol=2e-6 * K + 1e-5, rtol=2e-5)
     assert_close(o3, a3.double() @ b3.double().t(), atol=1e-4)
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("s0,s1", [((4500, 256, 128), (1500, 128, 128)), ((257, 130, 100), (64, 3, 37)), ((70, 300, 41), (900, 128, 256))])
+def test_gemm_pair_of_different_shapes_is_one_grouped_launch(s0, s1, a_kc, b_kc):
+    """snag_gemm_f32_pair with two DIFFERENT shapes of the same layouts and no K split: one grouped launch over a linear tile index
+    (the key/value + query projections of the read-out layer).  Bits equal to two snag_gemm_f32 calls, epilogues per problem, ragged
+    sizes and K on both sides."""
+    import ctypes
+    from snag_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(sum(s0) + 7 * sum(s1))
+    mk = lambda r, c: torch.randn(r, c, generator=g).to(DEV)
+    ops_ = []
+    for (M, N, K) in (s0, s1):
+        ops_.append((mk(*((M, K) if a_kc else (K, M))), mk(*((N, K) if b_kc else (K, N))), mk(1, N).reshape(N), mk(M, N)))
+    res = []
+    for single in (True, False):
+        outs = [torch.zeros(s[0], s[1], device=DEV) for s in (s0, s1)]
+        d0 = _desc(ops_[0][0], ops_[0][1], outs[0], a_kc, b_kc, bias=ptr(ops_[0][2]), act=1)
+        d1 = _desc(ops_[1][0], ops_[1][1], outs[1], a_kc, b_kc, add1=ptr(ops_[1][3]), ld1=ops_[1][3].stride(0))
+        if single:
+            call("snag_gemm_f32", ctypes.byref(d0), stream())
+            call("snag_gemm_f32", ctypes.byref(d1), stream())
+        else:
+            call("snag_gemm_f32_pair", ctypes.byref(d0), ctypes.byref(d1), stream())
+        res.append(outs)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    a, b, _, r1 = ops_[1]
+    ref = (a.double() if a_kc else a.double().t()) @ (b.double().t() if b_kc else b.double()) + r1.double()
+    assert_close(res[1][1], ref, atol=2e-6 * s1[2] + 1e-5, rtol=2e-5)
 
 
 @pytest.mark.parametrize("M,N,K,dist", [(1500, 128, 4096, "randn"), (1500, 128, 4096, "uniform"), (1024, 256, 128, "randn"), (300, 128, 15000, "randn"),
