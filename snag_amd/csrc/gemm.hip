@@ -265,7 +265,7 @@ static bool use_vec(const GemmOperands& p, bool a_kc, bool b_kc) {
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg_pair(const GemmOperands& p0, const Epilogue& e0, float* slab0, const GemmOperands& p1, const Epilogue& e1, float* slab1,
                             int splits, bool a_kc, bool b_kc, bool vec, hipStream_t st) {
-    dim3 grid(ceil_div(p0.N, BN), ceil_div(p0.M, BM), 2 * splits), block(256);
+    dim3 grid(ceil_div(p0.N, BN), ceil_div(p0.M, BM), 2 * splits), block(64 * (BM / WM) * (BN / WN));
 #define SNAG_GEMM2(AK, BK_)                                                                                        \
     do {                                                                                                           \
         if (vec) hipLaunchKernelGGL((gemm_tile_pair_kernel<BM, BN, WM, WN, AK, BK_, true, Epilogue>), grid, block, 0, st, p0, e0, slab0, p1, e1, slab1, splits);  \
@@ -280,7 +280,7 @@ static void launch_cfg_pair(const GemmOperands& p0, const Epilogue& e0, float* s
 
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(const GemmOperands& p, const Epilogue& e, float* slab, int splits, bool a_kc, bool b_kc, hipStream_t st) {
-    dim3 grid(ceil_div(p.N, BN), ceil_div(p.M, BM), splits), block(256);
+    dim3 grid(ceil_div(p.N, BN), ceil_div(p.M, BM), splits), block(64 * (BM / WM) * (BN / WN));
     const bool vec = use_vec(p, a_kc, b_kc);
 #define SNAG_GEMM(AK, BK_)                                                                                        \
     do {                                                                                                          \
@@ -373,7 +373,7 @@ int64_t gemm_workspace_floats(int M, int N, int K) {
 struct GemmPlan {
     GemmOperands p;
     Epilogue e;
-    bool big, wide, streamk;
+    bool big, wide, streamk, pp;
     int splits;
     StreamKChoice sk;
 };
@@ -427,15 +427,22 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     if (force_tile() != 0) { big = force_tile() == 2; wide = force_tile() == 3; }
     if (kBK != 16) wide = false;        // the 128x160 tiles of a 32-deep k-tile do not fit the 64 KB static LDS limit
     if (wide) big = false;
-    const int64_t tiles = wide ? wide_tiles : big ? big_tiles : (pm64 / 64) * (pn128 / 128);
+    // the eight-wave ping-pong form of the row-private tile (256 rows, one workgroup per CU) where the output is one tile wide, i.e.
+    // A is read exactly once (the projections): DB15K step 0.651 vs 0.657 ms, MKG-W 0.727 vs 0.737; with several column tiles
+    // (MMEA: N = 300 / 1,200) the four-wave form is faster (MMEA step 20.6 vs 21.8 ms)
+    static const int pp_off = env_int("SNAG_GEMM_PP_OFF");
+    const bool pp = big && kBf16x != 0 && !pp_off && p.N <= 128;
+    const int64_t tall_tiles = (int64_t)ceil_div(p.M, pp ? 256 : 128) * (pn128 / 128);
+    const int64_t tiles = wide ? wide_tiles : big ? (kBf16x != 0 ? tall_tiles : big_tiles) : (pm64 / 64) * (pn128 / 128);
     // split K when the output alone cannot fill 256 CUs (the dW = dY^T X shapes: tiny output, long K)
     int splits = 1;
     if (d->workspace != nullptr) {
         splits = force_splits() > 0 ? force_splits() : pick_splits(tiles, p.K, d->a_kcontig && d->b_kcontig);
-        // row-private tiles run two workgroups per CU: at most one resident wave of 512 (measured: 590 workgroups 0.7135 ms per step,
-        // 472-512 0.702, against 0.720 with 64 x 128 tiles)
+        // row-private tiles: at most ONE resident wave of workgroups -- 512 four-wave ones (two per CU), 256 eight-wave ones (measured
+        // with four waves: 590 workgroups 0.7135 ms per step, 472-512 0.702, against 0.720 with 64 x 128 tiles)
         if (kBf16x != 0 && big && force_splits() <= 0 && env_int("SNAG_GEMM_TARGET") <= 0)
-            splits = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(1, p.K / (kMinKTiles * 16)), 512 / std::max<int64_t>(1, tiles)));
+            splits = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(1, p.K / (kMinKTiles * 16)),
+                                                                (pp ? 256 : 512) / std::max<int64_t>(1, tiles)));
         const int64_t cap = d->workspace_floats / ((int64_t)p.M * p.N);
         if (splits > cap) splits = (int)cap;
         if (splits < 1) splits = 1;
@@ -443,7 +450,7 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     // K == 0 is legal (C = epilogue(0): bias / add1 / accumulate still apply): one split with an empty k-range; the split
     // arithmetic below would otherwise divide by zero
     if (p.K == 0) splits = 1;
-    pl.big = big; pl.wide = wide; pl.streamk = false;
+    pl.big = big; pl.wide = wide; pl.streamk = false; pl.pp = pp;
     if (splits > 1 && !big && !wide && streamk_mode() != 1) {
         // blocks per CU of the split grid vs what the slowest CU gets
         const double per_cu = (double)tiles * splits / 256.0;
@@ -479,12 +486,13 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     float* slab = splits > 1 ? d->workspace : nullptr;
     if (log_shapes())
         fprintf(stderr, "snag_gemm M=%d N=%d K=%d a_kc=%d b_kc=%d tile=%s splits=%d fast=%d acc=%d\n", p.M, p.N, p.K, (int)d->a_kcontig,
-                (int)d->b_kcontig, pl.wide ? "128x160" : pl.big ? "128x128" : "64x128", splits, (int)e.fast, (int)d->accumulate);
+                (int)d->b_kcontig, pl.wide ? "128x160" : pl.pp ? "256x128" : pl.big ? "128x128" : "64x128", splits, (int)e.fast, (int)d->accumulate);
 #if SNAG_GEMM_BK == 16
     if (pl.wide) launch_cfg<128, 160, 32, 160>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else
 #endif
-    if (pl.big) launch_cfg<128, 128, 32, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
+    if (pl.big && pl.pp) launch_cfg<256, 128, 32, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
+    else if (pl.big) launch_cfg<128, 128, 32, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else launch_cfg<64, 128, 32, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     int rc = check_launch("snag_gemm_f32");
     if (rc) return rc;
@@ -506,7 +514,7 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
 int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStream_t st) {
     static const int off = env_int("SNAG_GEMM_PAIR_OFF");      // tuning / A-B
     const GemmPlan a = plan_gemm(d0), b = plan_gemm(d1);
-    const bool same = !off && !a.streamk && !b.streamk && !a.wide && !b.wide && a.big == b.big && a.splits == b.splits && d0->M == d1->M && d0->N == d1->N &&
+    const bool same = !off && !a.streamk && !b.streamk && !a.wide && !b.wide && a.big == b.big && !a.pp && !b.pp && a.splits == b.splits && d0->M == d1->M && d0->N == d1->N &&
                       d0->K == d1->K && d0->a_kcontig == d1->a_kcontig && d0->b_kcontig == d1->b_kcontig && a.p.k_per_split == b.p.k_per_split &&
                       use_vec(a.p, d0->a_kcontig, d0->b_kcontig) == use_vec(b.p, d1->a_kcontig, d1->b_kcontig) &&
                       (a.splits == 1 || (d0->workspace != d1->workspace));

@@ -335,9 +335,9 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint
     l = cvt_pk_bf16(s0, s1);
 }
 
-template <int BR, bool KC>
+template <int BR, bool KC, int NT = 256>
 struct SplitStager {
-    static constexpr int KPT = 16 * BR / 256;            // values per thread and k-tile (4: BR = 64, 8: BR = 128)
+    static constexpr int KPT = 16 * BR / NT;             // values per thread and k-tile (4: BR = 64, or 128 rows over 512 threads; 8: BR = 128)
     static_assert(KPT == 4 || KPT == 8, "pre-split staging: 64 or 128 rows per operand tile");
     static constexpr int IMAGE_BYTES = 6 * BR * 16;
     // The unit of work is a CHUNK: 4 consecutive k (4c .. 4c+3, c = 0..3) of one row = 16 bytes of f32 = 8 bytes per bf16 plane.
@@ -349,7 +349,7 @@ struct SplitStager {
     //   K-contiguous,   BR = 128: thread = (rows t / 4 and t / 4 + 64, chunk t % 4)      2 dwordx4 loads
     // (row-contiguous: a wave-instruction covers 64 consecutive rows of one k, 256 contiguous bytes; K-contiguous: 4 adjacent
     // lanes cover the 64 contiguous bytes a row has in this k-tile.)
-    float r[2][KPT];                 // two register sets: tiles t+1 and t+2 in flight
+    float r[4][KPT];                 // register sets: two in flight (tiles t+1, t+2) in the four-wave loops, four in the ping-pong loop
     const char* ubase;               // wave-uniform.  row-contiguous: element (k = kbeg, row 0); K-contiguous: element (row0, k = kbeg)
     int64_t ldb;                     // pitch in bytes
     uint32_t voff, voff2;            // the lane's part of the address, bytes (rows past the edge clamped: their products are never stored)
@@ -448,7 +448,7 @@ struct SplitStager {
 //   K-contiguous:   2 dwordx4 loads (bytes 16 h and 32 + 16 h of the row's 64 bytes in this k-tile)
 template <bool KC>
 struct FragLoader {
-    float r[2][8];
+    float r[4][8];
     const char* ubase;
     int64_t ldb;
     uint32_t voff;
@@ -540,9 +540,10 @@ struct GemmCore {
     static constexpr int A_BUF = TileLd<BM, A_KC>::floats, B_BUF = TileLd<BN, B_KC>::floats, B_BASE = 2 * A_BUF;
     static constexpr int TILE_FLOATS = 2 * (A_BUF + B_BUF);
     static constexpr int CW = (WN % 64 == 0) ? 64 : 32;   // epilogue staging chunk: 32 rows x CW columns per wave at a time
-    static constexpr int STAGE_FLOATS = 4 * 32 * CW;
+    static constexpr int NW = (BM / WM) * (BN / WN), NT = 64 * NW;       // waves / threads per workgroup
+    static constexpr int STAGE_FLOATS = NW * 32 * CW;
     // pre-split staging loop: split-bf16 builds, 64 / 128-row operand tiles (the 128 x 160 tile keeps the in-fragment split)
-    static constexpr bool kPresplit = kBf16x != 0 && (BM == 64 || BM == 128) && (BN == 64 || BN == 128) && kBK == 16 &&
+    static constexpr bool kPresplit = kBf16x != 0 && (BM == 64 || BM == 128 || (BM == 256 && WM == 32 && WN == BN)) && (BN == 64 || BN == 128) && kBK == 16 &&
                                       (SNAG_GEMM_PRESPLIT_KC != 0 || (!A_KC && !B_KC));
     // waves stacked along M (each wave's 32 rows are its own): the A operand never goes through the LDS (FragLoader)
     static constexpr bool kRowPrivate = kPresplit && WN == BN && WM == 32;
@@ -550,7 +551,10 @@ struct GemmCore {
     static constexpr int PS_FLOATS = kPresplit ? 2 * PS_STAGE_FLOATS : 0;
     static constexpr int SMEM_FLOATS_ = TILE_FLOATS > STAGE_FLOATS ? TILE_FLOATS : STAGE_FLOATS;
     static constexpr int SMEM_FLOATS = kPresplit ? (PS_FLOATS > STAGE_FLOATS ? PS_FLOATS : STAGE_FLOATS) : SMEM_FLOATS_;
-    static_assert((BM / WM) * (BN / WN) == 4, "four waves per block");
+    static_assert(NW == 4 || NW == 8, "four or eight waves per block");
+    // eight waves stacked along M: two groups of four run the k-loop half an iteration apart (ping-pong, run_presplit)
+    static constexpr bool kPingPong = kRowPrivate && NW == 8;
+    static_assert(NW == 4 || kPingPong, "eight waves: the row-private ping-pong loop only");
 
     f32x16 acc[TM][TN];
 
@@ -630,7 +634,7 @@ struct GemmCore {
         const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
         const int li = lane & 31, lh = lane >> 5;
         unsigned char* const sm = reinterpret_cast<unsigned char*>(smem);
-        constexpr int STAGE = PS_STAGE_FLOATS * 4, A_IMG = kRowPrivate ? 0 : SplitStager<BM, A_KC>::IMAGE_BYTES;
+        constexpr int STAGE = PS_STAGE_FLOATS * 4, A_IMG = kRowPrivate ? 0 : 6 * BM * 16;
         const int kleft = kend - kbeg;
         const int nk = kleft / 16;            // full k-tiles; a ragged last one is the tail's
         if constexpr (kRowPrivate) {
@@ -638,7 +642,7 @@ struct GemmCore {
             // kt & 1), splits A of tile kt+1 and stages B of tile kt+1 (register sets (kt+1) & 1), fetches tile kt+3 into those sets.
             static_assert(TM == 1, "row-private: one 32-row fragment per wave");
             FragLoader<A_KC> fa;
-            SplitStager<BN, B_KC> sb;
+            SplitStager<BN, B_KC, NT> sb;
             fa.init(p.A, p.lda, p.a_vec, m0 + wm0, p.M, kbeg, lane);
             sb.init(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, tid);
             fa.ablate = p.dbg & 1;
@@ -671,19 +675,70 @@ struct GemmCore {
                 __syncthreads();
 #endif
             };
+            // Eight waves: PING-PONG.  The two groups of four waves (one wave of each group per SIMD) run the same loop half an
+            // iteration apart, and an iteration is cut by a barrier into its memory half (fragment reads, the A split, the group's
+            // share of the next B image, the loads) and its matrix half (24 MFMAs): while one group multiplies, the other one
+            // feeds -- the matrix pipe of a SIMD always has exactly one wave on it.  Group 1 starts one barrier late and group 0
+            // leaves one barrier late, so both pass the same number of barriers.  Four register sets (tiles kt+1 .. kt+4 in flight: twice
+            // the bytes in flight per CU of the four-wave loops).  B image of tile kt+1: group 0's half is written
+            // in interval 2 kt, group 1's in interval 2 kt + 1, both before anyone reads it (group 0 in interval 2 kt + 2); the
+            // buffer it replaces was last read in intervals 2 kt - 2 / 2 kt - 1.
+            auto pp_iteration = [&](int kt, auto S) {
+                constexpr int set = decltype(S)::value;
+                const int cur = kt & 1;
+                Split3 b[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + cur * STAGE, wn0 + 32 * j + li, lh, b[j]);
+                fa.split(set, a_nxt[0]);
+                fa.load(set, kt + 5, kleft);
+                sb.split_store(set, sm + (cur ^ 1) * STAGE);
+                sb.load(set, kt + 5, kleft);
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_split(a_cur, b);
+                a_cur[0] = a_nxt[0];
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            };
             if (nk > 0) {
                 fa.load(0, 0, kleft);
                 sb.load(0, 0, kleft);
                 fa.load(1, 1, kleft);
                 sb.load(1, 1, kleft);
+                if constexpr (kPingPong) {          // four register sets: tiles kt+1 .. kt+4 in flight (tile t in set t & 3)
+                    fa.load(2, 2, kleft);
+                    sb.load(2, 2, kleft);
+                    fa.load(3, 3, kleft);
+                    sb.load(3, 3, kleft);
+                }
                 fa.split(0, a_cur[0]);
                 sb.split_store(0, sm);
-                fa.load(0, 2, kleft);
-                sb.load(0, 2, kleft);
+                fa.load(0, kPingPong ? 4 : 2, kleft);
+                sb.load(0, kPingPong ? 4 : 2, kleft);
                 __syncthreads();
-                for (int kt = 0; kt < nk; kt += 2) {
-                    iteration(kt, std::integral_constant<int, 1>{});
-                    iteration(kt + 1, std::integral_constant<int, 0>{});
+                if constexpr (kPingPong) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    const bool late = wave >= 4;
+                    if (late) __builtin_amdgcn_s_barrier();
+                    for (int kt = 0; kt < nk; kt += 4) {
+                        pp_iteration(kt, std::integral_constant<int, 1>{});
+                        pp_iteration(kt + 1, std::integral_constant<int, 2>{});
+                        pp_iteration(kt + 2, std::integral_constant<int, 3>{});
+                        pp_iteration(kt + 3, std::integral_constant<int, 0>{});
+                    }
+                    if (!late) __builtin_amdgcn_s_barrier();
+                    __syncthreads();
+#endif
+                } else {
+                    for (int kt = 0; kt < nk; kt += 2) {
+                        iteration(kt, std::integral_constant<int, 1>{});
+                        iteration(kt + 1, std::integral_constant<int, 0>{});
+                    }
                 }
             }
             if (kleft % 16 != 0) {
@@ -699,7 +754,7 @@ struct GemmCore {
                 __syncthreads();
             }
             return;
-        }
+        } else {
         SplitStager<BM, A_KC> sa;
         SplitStager<BN, B_KC> sb;
         sa.init(p.A, p.lda, p.a_vec, m0, p.M, kbeg, tid);
@@ -769,6 +824,7 @@ struct GemmCore {
             __syncthreads();
             multiply(0);
             __syncthreads();
+        }
         }
     }
 
@@ -1039,7 +1095,7 @@ __global__ __launch_bounds__(256) void gemm_tile_group2_kernel(GemmOperands p0, 
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
-__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmOperands p, Epi epi, float* __restrict__ slab) {
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_kernel(GemmOperands p, Epi epi, float* __restrict__ slab) {
     using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
     __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
     gemm_tile_body<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi>(p, epi, slab, blockIdx.z, smem);
@@ -1050,7 +1106,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmOperands p, Epi epi,
 // the two modalities' second projections, their backward, the two D x D weight gradients of the read-out token --
 // fills the chip once instead of twice.
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
-__global__ __launch_bounds__(256) void gemm_tile_pair_kernel(GemmOperands p0, Epi e0, float* __restrict__ slab0, GemmOperands p1, Epi e1,
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_pair_kernel(GemmOperands p0, Epi e0, float* __restrict__ slab0, GemmOperands p1, Epi e1,
                                                              float* __restrict__ slab1, int splits) {
     using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
     __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
