@@ -648,7 +648,7 @@ struct GemmCore {
             fa.ablate = p.dbg & 1;
             sb.ablate = p.dbg & 2;
             Split3 a_cur[1], a_nxt[1];
-            auto iteration = [&](int kt, auto S) {
+            [[maybe_unused]] auto iteration = [&](int kt, auto S) {
                 constexpr int set = decltype(S)::value;
                 const int cur = kt & 1;
                 Split3 b[TN];
@@ -683,7 +683,7 @@ struct GemmCore {
             // the bytes in flight per CU of the four-wave loops).  B image of tile kt+1: group 0's half is written
             // in interval 2 kt, group 1's in interval 2 kt + 1, both before anyone reads it (group 0 in interval 2 kt + 2); the
             // buffer it replaces was last read in intervals 2 kt - 2 / 2 kt - 1.
-            auto pp_iteration = [&](int kt, auto S) {
+            [[maybe_unused]] auto pp_iteration = [&](int kt, auto S) {
                 constexpr int set = decltype(S)::value;
                 const int cur = kt & 1;
                 Split3 b[TN];
