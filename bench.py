@@ -352,15 +352,30 @@ def run_stress(args, world, rank, device, backend, real_stdout):
     B, K, N, R, D = args.batch, cfg.neg_num, cfg.n_ent, cfg.n_rel, cfg.dim
     gi = torch.Generator().manual_seed(cfg.seed + 1 + rank)
     n_batches = 16
-    idx = [[torch.randint(0, hi, (B,), generator=gi, dtype=torch.int32).to(device) for hi in (N, R, N)] for _ in range(n_batches)]
+    zipf = args.index_dist == "zipf"
+    if zipf:        # SURVEY par. 8d, config 5's "realistic" variant: entity popularity ~ 1 / rank (Zipf, exponent 1.0) for heads, tails AND negatives
+        cdf = torch.cumsum(1.0 / torch.arange(1, N + 1, dtype=torch.float64), 0)
+        cdf /= cdf[-1].clone()
+        perm = torch.randperm(N, generator=gi)                      # popular entities scattered over the table, not its first rows
+
+        def draw(shape):
+            u = torch.rand(shape, generator=gi, dtype=torch.float64)
+            return perm[torch.searchsorted(cdf, u).clamp_(max=N - 1)].to(torch.int32)
+        idx = [[draw((B,)).to(device), torch.randint(0, R, (B,), generator=gi, dtype=torch.int32).to(device), draw((B,)).to(device)] for _ in range(n_batches)]
+        negs = [draw((B, K)).to(device) for _ in range(n_batches)]
+    else:
+        idx = [[torch.randint(0, hi, (B,), generator=gi, dtype=torch.int32).to(device) for hi in (N, R, N)] for _ in range(n_batches)]
     neg = torch.empty(B, K, device=device, dtype=torch.int32)
     seed = cfg.seed * 7919 + rank
     timers = {}
 
     def one_step(i, tm=None):
         h, r, t = idx[i % n_batches]
-        ops.sample_negatives(h, r, t, K, N, R, seed, tick=eng.tick, out=neg)
-        eng.train_step(h, r, t, neg, timers=tm)
+        if zipf:
+            eng.train_step(h, r, t, negs[i % n_batches], timers=tm)          # popularity-weighted negatives, drawn ahead (the on-device sampler is uniform)
+        else:
+            ops.sample_negatives(h, r, t, K, N, R, seed, tick=eng.tick, out=neg)
+            eng.train_step(h, r, t, neg, timers=tm)
 
     for i in range(args.warmup):
         one_step(i)
@@ -398,7 +413,8 @@ def run_stress(args, world, rank, device, backend, real_stdout):
         "value": B * world * args.steps / elapsed, "unit": "triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 tables, f32 arithmetic",
         "data": "synthetic",
-        "config": {"workload": "configs[4]: stress, |E|=1M x 256 bf16 entity table (512 MB, replicated), 128 negative tails, uniform indices, "
+        "config": {"workload": "configs[4]: stress, |E|=1M x 256 bf16 entity table (512 MB, replicated), 128 negative tails, "
+                               + ("Zipf(1.0) entity popularity (heads, tails, negatives), " if zipf else "uniform indices, ") +
                                "fp32 master rows + Adam moments owned 1/N per rank", "n_ent": N, "n_rel": R, "dim": D, "neg": K, "batch_per_gpu": B,
                    "global_batch": B * world, "parallelism": f"dp{world} + row-owned optimiser state", "final_loss": float(eng.loss)},
         "phases_us": {"score_fwd_bwd (+ zeroing the relation gradient)": score_us, "reduce_scatter(table grad) + all_reduce(rel grad)": rs_us,
@@ -465,6 +481,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="positives per GPU per step (NUM_BATCH)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU-baseline leg (0 = skip)")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--index-dist", default="uniform", choices=["uniform", "zipf"],
+                    help="--config stress: entity indices uniform (worst-case locality) or Zipf(1.0) popularity (SURVEY par. 8d)")
     ap.add_argument("--config", default="db15k", choices=["db15k", "mkgw", "stress"],
                     help="db15k = BASELINE configs[1] (Mformer_hd_graph, num_proj=2, 558 relations); mkgw = configs[2] (Mformer_hd_mean, num_proj=1, 338 relations); "
                          "stress = configs[4] (|E|=1M, dim 256, 128 negatives, bf16 tables: scorer + row-owned AdamW, comm and compute reported separately)")

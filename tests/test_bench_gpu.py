@@ -64,6 +64,12 @@ def test_bench_stress_config_single_and_two_rank_dry_run():
     o = _json_line(p.stdout)
     assert o["n_gpus"] == 1 and o["config"]["n_ent"] == 1_000_000 and o["roofline"]["bound"] == "hbm" and 0 < o["roofline"]["frac"] < 1
     assert o["phases_us"]["compute_us"] > 0 and o["phases_us"]["comm_bytes_per_rank"]["all_gather_bf16"] == 0
+    # SURVEY par. 8d's second index distribution: Zipf(1.0) entity popularity (hot rows: contended gradient rows)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "stress", "--index-dist", "zipf", "--steps", "3", "--warmup", "1",
+                        "--cpu-seconds", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    z = _json_line(p.stdout)
+    assert "Zipf" in z["config"]["workload"] and z["config"]["final_loss"] > 0 and 0 < z["roofline"]["frac"] < 1
     env["BENCH_BACKEND"] = "gloo"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
            str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "stress", "--steps", "3", "--warmup", "1", "--batch", "256",
