@@ -418,9 +418,23 @@ constexpr int kNormBlocks = 1024;
 __global__ __launch_bounds__(256) void sumsq_part_kernel(const float* __restrict__ g, int64_t n, float pre_scale, float* __restrict__ part) {
     __shared__ float red[4];
     float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float v = g[i] * pre_scale;
-        s = fmaf(v, v, s);
+    if ((((uintptr_t)g) & 15) == 0) {          // dwordx4 body (fixed order per thread: x, y, z, w of its quads), scalar tail
+        const int64_t quads = n / 4;
+        for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (int64_t)gridDim.x * 256) {
+            const float4 v4 = reinterpret_cast<const float4*>(g)[q];
+            const float v[4] = {v4.x * pre_scale, v4.y * pre_scale, v4.z * pre_scale, v4.w * pre_scale};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = fmaf(v[e], v[e], s);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < n - quads * 4) {
+            const float v = g[quads * 4 + threadIdx.x] * pre_scale;
+            s = fmaf(v, v, s);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+            const float v = g[i] * pre_scale;
+            s = fmaf(v, v, s);
+        }
     }
     s = sum64(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
