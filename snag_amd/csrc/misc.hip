@@ -141,6 +141,18 @@ __global__ __launch_bounds__(256) void scaled_rows_kernel(const float* __restric
                                                           const uint8_t* __restrict__ nmask, float a, float* __restrict__ d_table,
                                                           int accumulate) {
     const int64_t total = N * (int64_t)D;
+    if (D % 4 == 0 && ld % 4 == 0 && ((((uintptr_t)d_tok) | ((uintptr_t)d_table)) & 15) == 0) {       // four columns per thread
+        for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q * 4 < total; q += (int64_t)gridDim.x * 256) {
+            const int64_t i = q * 4, n = i / D;
+            const int c = (int)(i % D);
+            float4 v = *reinterpret_cast<const float4*>(d_tok + n * ld + c);
+            if (nmask != nullptr && nmask[n]) { v.x *= (1.0f - a); v.y *= (1.0f - a); v.z *= (1.0f - a); v.w *= (1.0f - a); }
+            float4* o = reinterpret_cast<float4*>(d_table + i);
+            if (accumulate) { const float4 t = *o; v.x = t.x + v.x; v.y = t.y + v.y; v.z = t.z + v.z; v.w = t.w + v.w; }
+            *o = v;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t n = i / D;
         const int c = (int)(i % D);
@@ -406,7 +418,7 @@ extern "C" SNAG_API int snag_entity_token_bwd(const float* d_tok, int64_t ld, in
                                               float half_mask_ratio, float* d_table, int accumulate, void* stream) {
     SNAG_REQUIRE(d_tok && d_table && N >= 0 && D >= 1 && ld >= D, SNAG_ERR_ARG, "entity_token_bwd: bad arguments");
     if (N == 0) return SNAG_OK;
-    hipLaunchKernelGGL(scaled_rows_kernel, dim3(grid_for(N * (int64_t)D)), dim3(256), 0, (hipStream_t)stream, d_tok, ld, N, D, noise_mask,
+    hipLaunchKernelGGL(scaled_rows_kernel, dim3(grid_for((N * (int64_t)D + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_tok, ld, N, D, noise_mask,
                        half_mask_ratio, d_table, accumulate);
     return check_launch("snag_entity_token_bwd");
 }
