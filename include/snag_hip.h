@@ -404,6 +404,21 @@ SNAG_API int snag_tick(uint64_t* tick, void* stream);
 SNAG_API int snag_row_sqnorm(const float* x, int64_t n, int d, int64_t ld, float* out, void* stream);
 SNAG_API int snag_pairwise_dist(const float* x, int64_t ldx, int n, const float* y, int64_t ldy, int m, int d,
                                 const float* xn, const float* yn, float* out, int64_t ld_out, int as_similarity, void* stream);
+/* Row-sharded similarity evaluation across ranks (SURVEY.md par. 8e, BASELINE configs[3] on several GPUs): a rank holds rows
+ * [row0, row0 + n) of the n_total x m distance matrix (all m columns).  Per rank:
+ *   snag_csls_neighbourhood on its block      -> r1 of its rows (complete) and a LOCAL r2 that is not used;
+ *   snag_col_topk                             -> out[k, m]: the k largest similarities per column among its rows (descending);
+ *   all-gather of those candidates [G, k, m], snag_col_topk_mean -> r2[m], bit-equal to the single-rank value;
+ *   snag_rank_rows_block                      -> rank_l2r of its rows and the adjusted diagonal values diag[i] = D'[row0+i, row0+i];
+ *   all-gather of diag [m], snag_rank_cols_block -> count[j] = #{its rows i : D'[i,j] < diag[j]}; all-reduce(sum) = rank_r2l.
+ * The ranks equal those of snag_rank_diagonal on the whole matrix exactly (integers; same float expressions). */
+SNAG_API int snag_col_topk(const float* mat, int64_t ld, int n, int m, int k, int from_dist, float* out, float* work, void* stream);
+SNAG_API int snag_col_topk_mean(const float* cand, int chunks, int m, int k, float* out, void* stream);
+SNAG_API int snag_rank_rows_block(const float* dist, int64_t ld, int n, int m, int row0, const float* r1, const float* r2, int32_t* rank,
+                                  float* diag, void* stream);
+SNAG_API int snag_rank_cols_block(const float* dist, int64_t ld, int n, int m, const float* r1, const float* r2, const float* diag,
+                                  int32_t* count, void* stream);
+
 /* --distance 1 of Runner._test (main.py:388-391: scipy cdist(..., metric="cityblock") on the CPU): out[i,j] = sum_k |x[i,k] - y[j,k]|. */
 SNAG_API int snag_cityblock_dist(const float* x, int64_t ldx, int n, const float* y, int64_t ldy, int m, int d, float* out, int64_t ld_out,
                                  void* stream);

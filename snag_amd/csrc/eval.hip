@@ -213,6 +213,53 @@ __global__ __launch_bounds__(256) void rank_cols_kernel(const float* __restrict_
     atomicAdd(rank + col, cnt);
 }
 
+// the k largest values per column (descending) instead of their mean: what a rank contributes to the global column neighbourhoods
+template <int KK>
+__global__ __launch_bounds__(256) void col_topk_values_kernel(const float* __restrict__ part, int chunks, int m, int k, float* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= m) return;
+    TopK<KK> t;
+    t.init();
+    for (int c = 0; c < chunks; ++c)
+        for (int i = 0; i < k; ++i) t.push(part[((int64_t)c * k + i) * m + col]);
+#pragma unroll
+    for (int i = 0; i < KK; ++i)
+        if (i < k) out[(int64_t)i * m + col] = t.v[i];
+}
+
+// Row-sharded evaluation (SURVEY par. 8e, config 4): a rank holds rows [row0, row0 + n) of the distance matrix, all m columns.
+// rank_l2r of its rows and the CSLS-adjusted diagonal values D'[row0+i, row0+i] ...
+__global__ __launch_bounds__(256) void rank_rows_block_kernel(const float* __restrict__ dist, int64_t ld, int n, int m, int row0,
+                                                              const float* __restrict__ r1, const float* __restrict__ r2, int csls,
+                                                              int* __restrict__ rank, float* __restrict__ diag) {
+    __shared__ int red[4];
+    const int row = blockIdx.x, dcol = row0 + row;
+    const float a = csls ? r1[row] : 0.f;
+    const float ref = eval_dist(dist[(int64_t)row * ld + dcol], a, csls ? r2[dcol] : 0.f, csls);
+    int cnt = 0;
+    for (int c = threadIdx.x; c < m; c += 256) cnt += eval_dist(dist[(int64_t)row * ld + c], a, csls ? r2[c] : 0.f, csls) < ref ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        rank[row] = red[0] + red[1] + red[2] + red[3];
+        diag[row] = ref;
+    }
+}
+// ... and this rank's share of rank_r2l: count[j] += #{local i : D'[i,j] < diag[j]} with the gathered diagonal (integer, exact)
+__global__ __launch_bounds__(256) void rank_cols_block_kernel(const float* __restrict__ dist, int64_t ld, int n, int m, const float* __restrict__ r1,
+                                                              const float* __restrict__ r2, int csls, const float* __restrict__ diag,
+                                                              int rows_per_chunk, int* __restrict__ count) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= m) return;
+    const float b = csls ? r2[col] : 0.f, ref = diag[col];
+    const int r0 = blockIdx.y * rows_per_chunk, r1e = min(n, r0 + rows_per_chunk);
+    int cnt = 0;
+    for (int r = r0; r < r1e; ++r) cnt += eval_dist(dist[(int64_t)r * ld + col], csls ? r1[r] : 0.f, b, csls) < ref ? 1 : 0;
+    atomicAdd(count + col, cnt);
+}
+
 // Hits@k counts, sum(rank+1), sum(1/(rank+1)) in double, fixed order  (main.py:400-407,430-436)
 __global__ __launch_bounds__(256) void rank_summary_kernel(const int* __restrict__ rank, int n, const int* __restrict__ topk, int ntop,
                                                            double* __restrict__ out) {
@@ -441,6 +488,64 @@ extern "C" SNAG_API int snag_rank_diagonal(const float* dist, int64_t ld, int n,
         hipLaunchKernelGGL(rank_cols_kernel, dim3(ceil_div(m, 256), ceil_div(n, rpc)), dim3(256), 0, st, dist, ld, n, m, r1, r2, csls, rpc, rank_r2l);
     }
     return check_launch("snag_rank_diagonal");
+}
+
+extern "C" SNAG_API int snag_col_topk(const float* mat, int64_t ld, int n, int m, int k, int from_dist, float* out, float* work, void* stream) {
+    SNAG_REQUIRE(n >= 1 && m >= 1 && ld >= m, SNAG_ERR_ARG, "col_topk: bad sizes");
+    SNAG_REQUIRE(k >= 1 && k <= kMaxK, SNAG_ERR_UNSUPPORTED, "col_topk: k=%d outside [1, %d]", k, kMaxK);
+    SNAG_REQUIRE(mat && out && work, SNAG_ERR_ARG, "col_topk: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = std::min(kColChunks, n);
+    const int rpc = ceil_div(n, chunks);
+    const int nch = ceil_div(n, rpc);
+#define SNAG_TOPK(KK)                                                                                                                       \
+    do {                                                                                                                                    \
+        hipLaunchKernelGGL((col_topk_part_kernel<KK>), dim3(ceil_div(m, 256), nch), dim3(256), 0, st, mat, ld, n, m, k, from_dist, rpc, work); \
+        hipLaunchKernelGGL((col_topk_values_kernel<KK>), dim3(ceil_div(m, 256)), dim3(256), 0, st, (const float*)work, nch, m, k, out);       \
+    } while (0)
+    if (k <= 3) SNAG_TOPK(3);
+    else if (k <= 5) SNAG_TOPK(5);
+    else if (k <= 10) SNAG_TOPK(10);
+    else SNAG_TOPK(16);
+#undef SNAG_TOPK
+    return check_launch("snag_col_topk");
+}
+
+extern "C" SNAG_API int snag_col_topk_mean(const float* cand, int chunks, int m, int k, float* out, void* stream) {
+    SNAG_REQUIRE(cand && out && chunks >= 1 && m >= 1, SNAG_ERR_ARG, "col_topk_mean: bad arguments");
+    SNAG_REQUIRE(k >= 1 && k <= kMaxK, SNAG_ERR_UNSUPPORTED, "col_topk_mean: k=%d outside [1, %d]", k, kMaxK);
+    hipStream_t st = (hipStream_t)stream;
+#define SNAG_TOPK(KK) hipLaunchKernelGGL((col_topk_merge_kernel<KK>), dim3(ceil_div(m, 256)), dim3(256), 0, st, cand, chunks, m, k, out)
+    if (k <= 3) SNAG_TOPK(3);
+    else if (k <= 5) SNAG_TOPK(5);
+    else if (k <= 10) SNAG_TOPK(10);
+    else SNAG_TOPK(16);
+#undef SNAG_TOPK
+    return check_launch("snag_col_topk_mean");
+}
+
+extern "C" SNAG_API int snag_rank_rows_block(const float* dist, int64_t ld, int n, int m, int row0, const float* r1, const float* r2, int32_t* rank,
+                                             float* diag, void* stream) {
+    SNAG_REQUIRE(n >= 1 && m >= 1 && ld >= m && row0 >= 0 && row0 + n <= m, SNAG_ERR_ARG, "rank_rows_block: rows [%d, %d) outside the %d columns", row0,
+                 row0 + n, m);
+    SNAG_REQUIRE(dist && rank && diag, SNAG_ERR_ARG, "rank_rows_block: null pointer");
+    SNAG_REQUIRE((r1 == nullptr) == (r2 == nullptr), SNAG_ERR_ARG, "rank_rows_block: r1 and r2 go together");
+    hipLaunchKernelGGL(rank_rows_block_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, dist, ld, n, m, row0, r1, r2, r1 != nullptr, rank, diag);
+    return check_launch("snag_rank_rows_block");
+}
+
+extern "C" SNAG_API int snag_rank_cols_block(const float* dist, int64_t ld, int n, int m, const float* r1, const float* r2, const float* diag,
+                                             int32_t* count, void* stream) {
+    SNAG_REQUIRE(n >= 1 && m >= 1 && ld >= m, SNAG_ERR_ARG, "rank_cols_block: bad sizes");
+    SNAG_REQUIRE(dist && diag && count, SNAG_ERR_ARG, "rank_cols_block: null pointer");
+    SNAG_REQUIRE((r1 == nullptr) == (r2 == nullptr), SNAG_ERR_ARG, "rank_cols_block: r1 and r2 go together");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(count, 0, sizeof(int32_t) * m, st) != hipSuccess) return fail(SNAG_ERR_LAUNCH, "rank_cols_block: memset failed");
+    const int chunks = std::min(kColChunks, n);
+    const int rpc = ceil_div(n, chunks);
+    hipLaunchKernelGGL(rank_cols_block_kernel, dim3(ceil_div(m, 256), ceil_div(n, rpc)), dim3(256), 0, st, dist, ld, n, m, r1, r2, r1 != nullptr, diag, rpc,
+                       count);
+    return check_launch("snag_rank_cols_block");
 }
 
 extern "C" SNAG_API int snag_rank_summary(const int32_t* rank, int n, const int32_t* topk, int ntop, double* out, void* stream) {

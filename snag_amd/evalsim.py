@@ -105,6 +105,76 @@ def rank_metrics(emb_left, emb_right, csls_k=0, top_k=(1, 10, 50), distance=2):
     return out
 
 
+def rank_metrics_sharded(emb_left, emb_right, csls_k=0, top_k=(1, 10, 50), rank=None, world=None, group=None):
+    """``rank_metrics`` with the rows of the left side sharded over the ranks of a process group (SURVEY.md par. 8e, config 4): every
+    rank holds both embedding tables (they are the model's output), computes the distance block of ITS n/G left rows against all right
+    rows -- 1/G of the similarity GEMM -- and three small exchanges finish the job: an all-gather of the per-column top-k candidates
+    ([G, k, m] floats) for the CSLS column neighbourhoods, an all-gather of the adjusted diagonal (m floats) and an all-reduce of the
+    per-column counts (m integers).  Ranks and summaries equal ``rank_metrics`` on one rank exactly.  Squared-Euclidean distance only.
+
+    Returns the same dict on every rank (without ``dist``: no rank holds the whole matrix)."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group) if rank is None else rank
+    world = dist.get_world_size(group) if world is None else world
+    n, m = emb_left.shape[0], emb_right.shape[0]
+    if n != m:
+        raise ValueError("rank_metrics_sharded: left and right must hold the same number of aligned rows")
+    dev = emb_left.device
+    per = -(-n // world)
+    lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
+    host = dist.get_backend(group) == "gloo"
+
+    def gather(t):                  # [per, ...] on every rank -> [world * per, ...]
+        t = t.contiguous()
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device="cpu" if host else dev)
+        dist.all_gather_into_tensor(out, t.cpu() if host else t, group=group)
+        return out.to(dev)
+
+    nl = hi - lo
+    k = int(csls_k) if csls_k and csls_k > 0 else 0
+    r1 = r2 = None
+    rl_loc = torch.zeros(per, device=dev, dtype=torch.int32)
+    diag_loc = torch.zeros(per, device=dev, dtype=f32)
+    cand = torch.full((max(k, 1), m), float("-inf"), device=dev, dtype=f32)
+    block = None
+    if nl > 0:
+        block = pairwise_distances(emb_left[lo:hi].contiguous(), emb_right, _padded=True)
+        if k:
+            if nl < k:
+                raise ValueError("rank_metrics_sharded: every non-empty shard needs at least csls_k rows")
+            r1, _ = _neighbourhood(block, k, True)              # row neighbourhoods: complete (a row sees every column); the local r2 is not used
+            work = torch.empty(_lib.load().snag_eval_work_floats(nl, m), device=dev, dtype=f32)
+            call("snag_col_topk", ptr(block), block.stride(0), nl, m, k, 1, ptr(cand), ptr(work), stream())
+    if k:
+        allc = gather(cand)                                     # [world * k, m]: world chunks of k descending candidates
+        r2 = torch.empty(m, device=dev, dtype=f32)
+        call("snag_col_topk_mean", ptr(allc), world, m, k, ptr(r2), stream())
+    if nl > 0:
+        call("snag_rank_rows_block", ptr(block), block.stride(0), nl, m, lo, ptr(r1), ptr(r2), ptr(rl_loc), ptr(diag_loc), stream())
+    diag = gather(diag_loc)[:n].contiguous()
+    cnt = torch.zeros(m, device=dev, dtype=torch.int32)
+    if nl > 0:
+        call("snag_rank_cols_block", ptr(block), block.stride(0), nl, m, ptr(r1), ptr(r2), ptr(diag), ptr(cnt), stream())
+    if host:
+        c = cnt.cpu()
+        dist.all_reduce(c, group=group)
+        rr = c.to(dev)
+    else:
+        dist.all_reduce(cnt, group=group)
+        rr = cnt
+    rl = gather(rl_loc)[:n].contiguous()
+    tk = torch.tensor(list(top_k), device=dev, dtype=torch.int32)
+    out = {"rank_l2r": rl, "rank_r2l": rr}
+    for name, rk in (("l2r", rl), ("r2l", rr)):
+        summ = torch.empty(len(top_k) + 2, device=dev, dtype=torch.float64)
+        call("snag_rank_summary", ptr(rk), n, ptr(tk), len(top_k), ptr(summ), stream())
+        sv = summ.cpu().tolist()
+        out[f"hits_{name}"] = [round(c / n, 4) for c in sv[:len(top_k)]]
+        out[f"mr_{name}"] = sv[len(top_k)] / n
+        out[f"mrr_{name}"] = sv[len(top_k) + 1] / n
+    return out
+
+
 def mutual_nearest(final_emb, left, right, chunk=None):
     """Row / column arg-min of the left x right distance matrix and the mutual pairs (model/SNAG.py:195-204).
 
