@@ -252,10 +252,11 @@ static int colsum(const float* x, int64_t R, int C, float* part, float* out, int
 // LayerNorm backward + the bias gradient of the dense layer in front of it (colsum of what flows into that dense)
 static int ln_bwd(const float* dy, const float* t, const float* stats, const float* g, int64_t R, int D, const uint8_t* keep,
                   float kscale, float* dt, float* dtm, float* part, float* dgamma, float* dbeta, float* dbias, int accumulate,
-                  hipStream_t st, int64_t keep_ld = 0, bool zero_dy = false) {
+                  hipStream_t st, int64_t keep_ld = 0, bool zero_dy = false, bool defer_reduce = false) {
     const int blocks = (int)std::min<int64_t>(kRedBlocks, (R + 3) / 4);
     SNAG_NU(ln_bwd_kernel, D, dim3(blocks), st, dy, t, stats, g, R, D, keep, keep_ld > 0 ? keep_ld : (int64_t)D, kscale, dt, dtm, part,
             zero_dy ? const_cast<float*>(dy) : (float*)nullptr);
+    if (defer_reduce) return check_launch("fusion LayerNorm backward");       // the caller reduces this slab together with another one
     // part is [blocks][3][D]: one launch reduces the three rows as 3*D "columns" of stride 3*D, each into its own destination
     hipLaunchKernelGGL(slab_colsum3_kernel, dim3(ceil_div(3 * D, 64)), dim3(1024), 0, st, (const float*)part, blocks, D, dgamma, dbeta, dbias, accumulate);
     return check_launch("fusion LayerNorm backward");
@@ -334,8 +335,11 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
                 dout = W.dC;
             }
             float* dtm = P.keep_attn_out ? W.dB : nullptr;
+            // (its slab [blocks][3][D] stays in W.part; the attention backward's goes behind it and ONE launch reduces both)
             if ((rc = ln_bwd(dout, S.t1, S.st1, P.ln1_g, N, D, P.keep_attn_out ? P.keep_attn_out + (int64_t)ro * D : nullptr, kscale, W.dA, dtm, W.part,
-                             G.ln1_g, G.ln1_b, G.bo, acc, st, MD, zero_up))) return rc;
+                             G.ln1_g, G.ln1_b, G.bo, acc, st, MD, zero_up, true))) return rc;
+            const int lnblocks = (int)std::min<int64_t>(kRedBlocks, (N + 3) / 4);
+            float* partq = W.part + (int64_t)kRedBlocks * 3 * D;
             const float* dz = dtm ? dtm : W.dA;
             // (dWo = dz^T ctx_g is launched further down, paired with dWq)
             // dctx_g = dz Wo -> dC
@@ -346,8 +350,9 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             float* dq_g = W.dqkv + NM * 2 * D;
             const int ablocks = (int)std::min<int64_t>(kRedBlocks, (N + 3) / 4);
             SNAG_MNU(attn_ro_bwd_kernel, M, D, dim3(ablocks), st, (const float*)S.qkv, (const float*)W.dC, N, D, H, ro, 1.0f / sqrtf((float)(D / H)),
-                     P.keep_probs, kscale, dq_g, dkv, W.part);
-            hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(3 * D, 64)), dim3(1024), 0, st, (const float*)W.part, ablocks, (int64_t)3 * D, 3 * D, G.bqkv, acc);
+                     P.keep_probs, kscale, dq_g, dkv, partq);
+            hipLaunchKernelGGL(slab_colsum_ro_kernel, dim3(ceil_div(3 * D, 64), 2), dim3(1024), 0, st, (const float*)W.part, lnblocks, D, G.ln1_g, G.ln1_b, G.bo,
+                               (const float*)partq, ablocks, G.bqkv, acc);
             if ((rc = check_launch("fusion attention backward (read-out)"))) return rc;
             // dWo = dz^T ctx_g and dWq = dq_g^T x_g (rows 0..D of wqkv): two D x D outputs over N rows -> ONE launch (+ one reduce)
             {
