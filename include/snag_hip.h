@@ -216,6 +216,8 @@ typedef struct snag_gemm_desc {
     float* workspace; int64_t workspace_floats;
     const float* aux; int64_t ldaux;
     int64_t ldmask;
+    int32_t defer_reduce;   /* 1: when the K split of this problem produces slabs, leave them in the workspace (C is not touched);
+                             * snag_gemm_reduce_pair finishes the job.  Ignored when the problem runs without a slab split. */
 } snag_gemm_desc;
 
 SNAG_API int snag_gemm_f32(const snag_gemm_desc* desc, void* stream);
@@ -224,6 +226,11 @@ SNAG_API int64_t snag_gemm_workspace_floats(int M, int N, int K);
  * [rows x D x D]-sized GEMMs are grids of fewer workgroups than the chip has CUs: a pair fills it once instead of twice), otherwise
  * one after the other.  Results are those of two snag_gemm_f32 calls, bit for bit.  Split-K workspaces must be distinct. */
 SNAG_API int snag_gemm_f32_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, void* stream);
+/* Finishes two problems launched with defer_reduce = 1 (same descriptors, distinct workspaces): ONE launch sums both problems' K-split
+ * slabs in slab order and applies their epilogues -- the two modalities' first projections, or their weight gradients, pay one
+ * reduce launch instead of two.  A problem whose launch made no slabs (no split, stream-K) was finished by snag_gemm_f32 already and
+ * is skipped.  Results are those of two plain snag_gemm_f32 calls, bit for bit. */
+SNAG_API int snag_gemm_reduce_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, void* stream);
 
 /* Gram matrix S [n, n] = alpha * Z Z^T for Z [n, k] (row stride ldz), fp32 via split-bf16 MFMA.  Only the tiles on or above the diagonal are
  * computed; each is also stored transposed, so S is symmetric bit for bit.  Used for the stacked InfoNCE logits

@@ -29,7 +29,7 @@ class GemmDesc(_c.Structure):
                 ("keep_mask", _P), ("keep_scale", _F),
                 ("add1", _P), ("ld1", _L), ("add2", _P), ("ld2", _L),
                 ("accumulate", _c.c_int32), ("workspace", _P), ("workspace_floats", _L),
-                ("aux", _P), ("ldaux", _L), ("ldmask", _L)]
+                ("aux", _P), ("ldaux", _L), ("ldmask", _L), ("defer_reduce", _c.c_int32)]
 
 
 class FusionLayer(_c.Structure):
@@ -75,6 +75,7 @@ SIGNATURES = {
     "snag_reduce_sum": [_P, _L, _P, _P],
     "snag_rank_full_table": [_P, _L, _L, _P, _I, _P, _P, _P],
     "snag_gemm_f32": [_c.POINTER(GemmDesc), _P],
+    "snag_gemm_reduce_pair": [_P, _P, _P],
     "snag_gemm_f32_pair": [_c.POINTER(GemmDesc), _c.POINTER(GemmDesc), _P],
     "snag_fusion_fwd": [_c.POINTER(FusionDesc), _P],
     "snag_fusion_bwd": [_c.POINTER(FusionBwdDesc), _P],

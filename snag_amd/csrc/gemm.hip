@@ -194,6 +194,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_small_pair_kernel(const flo
 }
 static bool reduce_small(int64_t total, int splits) { return total <= (1 << 18) && splits >= 8; }
 
+// two problems of different shape and split count (snag_gemm_reduce_pair): blockIdx.y = problem
+template <bool QUAD>
+__global__ __launch_bounds__(256) void splitk_reduce_two_kernel(const float* __restrict__ slab0, int splits0, Epilogue e0, const float* __restrict__ slab1,
+                                                                int splits1, Epilogue e1) {
+    if (blockIdx.y == 0) splitk_reduce_body<QUAD>(slab0, splits0, e0, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+    else splitk_reduce_body<QUAD>(slab1, splits1, e1, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+}
+
 template <bool QUAD>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, Epilogue epi) {
     splitk_reduce_body<QUAD>(slab, splits, epi, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
@@ -496,7 +504,7 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     else launch_cfg<64, 128, 32, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     int rc = check_launch("snag_gemm_f32");
     if (rc) return rc;
-    if (splits > 1) {
+    if (splits > 1 && !d->defer_reduce) {
         const int64_t total = (int64_t)p.M * p.N;
         const bool quad = p.N % 4 == 0 && ((uintptr_t)slab & 15) == 0;         // (slab z starts z M N floats in: a multiple of 16 bytes)
         const int blocks = (int)std::min<int64_t>(2048, (total / (quad ? 4 : 1) + 255) / 256);
@@ -572,6 +580,39 @@ int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipSt
     return rc;
 }
 
+// the reduce launch of one problem (what gemm_dispatch appends to a K split)
+static int launch_reduce(const GemmPlan& pl, float* slab, hipStream_t st) {
+    const GemmOperands& p = pl.p;
+    const int64_t total = (int64_t)p.M * p.N;
+    const bool quad = p.N % 4 == 0 && ((uintptr_t)slab & 15) == 0;
+    const int blocks = (int)std::min<int64_t>(2048, (total / (quad ? 4 : 1) + 255) / 256);
+    if (quad && reduce_small(total, pl.splits))
+        hipLaunchKernelGGL(splitk_reduce_small_kernel, dim3((unsigned)((total / 4 + 63) / 64)), dim3(256), 0, st, (const float*)slab, pl.splits, pl.e);
+    else if (quad) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, (const float*)slab, pl.splits, pl.e);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, (const float*)slab, pl.splits, pl.e);
+    return check_launch("snag_gemm_f32(split-K reduce)");
+}
+
+int gemm_reduce_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStream_t st) {
+    const GemmPlan a = plan_gemm(d0), b = plan_gemm(d1);
+    const bool ha = d0->defer_reduce && !a.streamk && a.splits > 1 && d0->M > 0 && d0->N > 0;      // slabs waiting in d0's workspace
+    const bool hb = d1->defer_reduce && !b.streamk && b.splits > 1 && d1->M > 0 && d1->N > 0;
+    if (ha && hb) {
+        SNAG_REQUIRE(d0->workspace != d1->workspace, SNAG_ERR_ARG, "gemm_reduce_pair: the two problems share a workspace");
+        const bool quad = a.p.N % 4 == 0 && b.p.N % 4 == 0 && (((uintptr_t)d0->workspace | (uintptr_t)d1->workspace) & 15) == 0;
+        const int64_t t0 = (int64_t)a.p.M * a.p.N, t1 = (int64_t)b.p.M * b.p.N;
+        const int blocks = (int)std::min<int64_t>(2048, (std::max(t0, t1) / (quad ? 4 : 1) + 255) / 256);
+        if (quad) hipLaunchKernelGGL(splitk_reduce_two_kernel<true>, dim3(blocks, 2), dim3(256), 0, st, (const float*)d0->workspace, a.splits, a.e,
+                                     (const float*)d1->workspace, b.splits, b.e);
+        else hipLaunchKernelGGL(splitk_reduce_two_kernel<false>, dim3(blocks, 2), dim3(256), 0, st, (const float*)d0->workspace, a.splits, a.e,
+                                (const float*)d1->workspace, b.splits, b.e);
+        return check_launch("snag_gemm_reduce_pair");
+    }
+    if (ha) return launch_reduce(a, d0->workspace, st);
+    if (hb) return launch_reduce(b, d1->workspace, st);
+    return SNAG_OK;
+}
+
 int gemm_check(const snag_gemm_desc* d) {
     SNAG_REQUIRE(d != nullptr, SNAG_ERR_ARG, "gemm: null descriptor");
     SNAG_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, SNAG_ERR_ARG, "gemm: negative size M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -614,6 +655,13 @@ extern "C" SNAG_API int snag_gemm_f32_pair(const snag_gemm_desc* d0, const snag_
         return SNAG_OK;
     }
     return gemm_dispatch_pair(d0, d1, (hipStream_t)stream);
+}
+
+extern "C" SNAG_API int snag_gemm_reduce_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, void* stream) {
+    int rc = gemm_check(d0);
+    if (rc) return rc;
+    if ((rc = gemm_check(d1))) return rc;
+    return gemm_reduce_pair(d0, d1, (hipStream_t)stream);
 }
 
 extern "C" SNAG_API int snag_gram_f32(const float* Z, int64_t ldz, int n, int k, float alpha, float* S, int64_t lds, void* stream) {

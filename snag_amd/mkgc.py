@@ -229,7 +229,8 @@ class MKGCHotPath:
         self.save = torch.empty(lib.snag_fusion_save_floats(Nl, M, D, cfg.num_heads, I, L, int(ffn)), device=dev)
         ws = lib.snag_fusion_work_floats(Nl, M, D, cfg.num_heads, I, L, int(ffn))
         for fd in cfg.feat_dims:
-            ws = max(ws, lib.snag_gemm_workspace_floats(fd, D, Nl) + 64, lib.snag_gemm_workspace_floats(Nl, D, fd) + 64, 256 * max(D, fd))
+            # (the first projections and their weight gradients run two modalities at a time, each in its own half of the scratch)
+            ws = max(ws, 2 * (lib.snag_gemm_workspace_floats(fd, D, Nl) + 64), 2 * (lib.snag_gemm_workspace_floats(Nl, D, fd) + 64), 256 * max(D, fd))
         ws = max(ws, 2 * (lib.snag_gemm_workspace_floats(D, D, Nl) + 64), lib.snag_gemm_workspace_floats(Nl, D, D) + 64)
         self.work = torch.empty(ws, device=dev)
         H = cfg.num_heads
@@ -364,6 +365,21 @@ class MKGCHotPath:
         workgroups than the chip has CUs.  Split-K workspaces: the two halves of the engine's scratch."""
         call("snag_gemm_f32_pair", ctypes.byref(d0), ctypes.byref(d1), self._st)
 
+    def _gemm_deferred_pairs(self, descs, tags=None):
+        """Independent split-K GEMMs of DIFFERENT shape, two at a time (descs[i] uses workspace half i % 2): both kernels run with
+        their K-split slabs left in place, then ONE launch reduces both (snag_gemm_reduce_pair) -- one reduce launch per pair
+        instead of one per problem.  ``tags``: per-problem probe names for bench.py's launch timers (the pair's reduce is timed as
+        tags[i] + "_reduce")."""
+        st = self._st
+        for i in range(0, len(descs), 2):
+            pair = descs[i:i + 2]
+            for j, d in enumerate(pair):
+                d.defer_reduce = 1 if len(pair) == 2 else 0
+                tag = tags[i + j] if tags else ""
+                self._probed(tag, call, "snag_gemm_f32", ctypes.byref(d), st)
+            if len(pair) == 2:
+                self._probed((tags[i] + "_reduce") if tags and tags[i] else "", call, "snag_gemm_reduce_pair", ctypes.byref(pair[0]), ctypes.byref(pair[1]), st)
+
     def _gemm_desc(self, M, N, K, A, lda, akc, B, ldb, bkc, C, ldc, *, bias=None, act=0, pre=None, add1=None, ld1=0,
                    aux=None, ldaux=0, splitk=True, keep=None, keep_scale=1.0, half=None):
         d = _lib.GemmDesc()
@@ -476,17 +492,18 @@ class MKGCHotPath:
         call("snag_step_prologue", *s_args, self.p["ent"].data_ptr() + 4 * lo * D, Nl, D, (self.ent_noise.data_ptr() + 4 * lo * D) if noisy else None,
              (self.ent_noise_mask.data_ptr() + lo) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD,
              cfg.seed + 1 + 7919 * self.shard.rank, self.keep_all.numel() if drop else 0, cfg.dropout if drop else 0.0, ptr(self.keep_all) if drop else None, st)
+        l1 = []
         for i, fd in enumerate(cfg.feat_dims):
             feat_t = self.noisy_t[i] if noisy else self.feats_t[i]          # [fd, Nl]
             slot = x0p + 4 * i * D
-            tag = "proj_l1_fwd" if i == 0 else ""
             if cfg.num_proj == 1:
-                self._probed(tag, self._gemm, Nl, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.weight"]), D, 0, slot, MD,
-                             bias=ptr(self.p[f"proj{i}.bias"]))
+                l1.append(self._gemm_desc(Nl, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.weight"]), D, 0, slot, MD,
+                                          bias=ptr(self.p[f"proj{i}.bias"]), half=i % 2))
             else:   # ProjectionHead: Linear(no bias) -> ReLU -> dropout -> Linear(no bias)   (model/layers.py:135-148)
-                pk = self._proj_keep(i)
-                self._probed(tag, self._gemm, Nl, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.l1"]), D, 0, ptr(self.mid[i]), D, act=1,
-                             keep=pk, keep_scale=1.0 / (1.0 - cfg.proj_dropout))
+                l1.append(self._gemm_desc(Nl, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.l1"]), D, 0, ptr(self.mid[i]), D, act=1,
+                                          keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout), half=i % 2))
+        # the modalities' first projections: K-split GEMMs of different K -- two kernels, ONE reduce launch per pair
+        self._gemm_deferred_pairs(l1, ["proj_l1_fwd"] + [""] * (len(l1) - 1))
         if cfg.num_proj == 2:       # the second projections, two modalities per launch
             l2 = [self._gemm_desc(Nl, D, D, ptr(self.mid[i]), D, 1, ptr(self.p[f"proj{i}.l2"]), D, 1, x0p + 4 * i * D, MD) for i in range(len(cfg.feat_dims))]
             for i in range(0, len(l2) - 1, 2):
@@ -634,15 +651,23 @@ class MKGCHotPath:
                     self._gemm_pair(group[i], group[i + 1])
                 if nmod % 2:
                     call("snag_gemm_f32", ctypes.byref(group[-1]), st)
+        dl1 = []
         for i, fd in enumerate(cfg.feat_dims):
             feat = self.noisy[i] if noisy else self.feats[i]
             dslot = dx0 + 4 * i * D
             if cfg.num_proj == 1:
                 # dW^T [fd, D] = feat^T dTok ; db = colsum(dTok)
-                self._gemm(fd, D, Nl, ptr(feat), fd, 0, dslot, MD, 0, ptr(self.g[f"proj{i}.weight"]), D, splitk=True)
-                call("snag_colsum", dslot, Nl, D, MD, ptr(self.g[f"proj{i}.bias"]), 0, wk, st)
+                dl1.append(self._gemm_desc(fd, D, Nl, ptr(feat), fd, 0, dslot, MD, 0, ptr(self.g[f"proj{i}.weight"]), D, splitk=True, half=i % 2))
             else:
-                self._gemm(fd, D, Nl, ptr(feat), fd, 0, ptr(self.d_mid[i]), D, 0, ptr(self.g[f"proj{i}.l1"]), D, splitk=True)   # dl1^T [fd, D]
+                dl1.append(self._gemm_desc(fd, D, Nl, ptr(feat), fd, 0, ptr(self.d_mid[i]), D, 0, ptr(self.g[f"proj{i}.l1"]), D, splitk=True,
+                                           half=i % 2))   # dl1^T [fd, D]
+        if reducer is None:         # weight gradients of the first projections: two kernels, ONE reduce launch per pair of modalities
+            self._gemm_deferred_pairs(dl1)
+        for i, fd in enumerate(cfg.feat_dims):
+            if reducer is not None:         # data parallel: each modality's bucket goes out as soon as its gradient is final
+                call("snag_gemm_f32", ctypes.byref(dl1[i]), st)
+            if cfg.num_proj == 1:
+                call("snag_colsum", dx0 + 4 * i * D, Nl, D, MD, ptr(self.g[f"proj{i}.bias"]), 0, wk, st)
             if reducer is not None:
                 reducer.start(buckets[2 + i])
 
