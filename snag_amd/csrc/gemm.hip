@@ -194,12 +194,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_small_pair_kernel(const flo
 }
 static bool reduce_small(int64_t total, int splits) { return total <= (1 << 18) && splits >= 8; }
 
-// two problems of different shape and split count (snag_gemm_reduce_pair): blockIdx.y = problem
-template <bool QUAD>
-__global__ __launch_bounds__(256) void splitk_reduce_two_kernel(const float* __restrict__ slab0, int splits0, Epilogue e0, const float* __restrict__ slab1,
-                                                                int splits1, Epilogue e1) {
-    if (blockIdx.y == 0) splitk_reduce_body<QUAD>(slab0, splits0, e0, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
-    else splitk_reduce_body<QUAD>(slab1, splits1, e1, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+// two problems of different shape and split count (snag_gemm_reduce_pair): blockIdx.y = problem, each reduced by the body -- and in
+// the summation order -- its own snag_gemm_f32 call would have used (small: the four-wave slab-parallel one), over its own block count
+// mode: 0 = one column per thread, 1 = four columns per thread, 2 = the small-output slab-parallel form
+__global__ __launch_bounds__(256) void splitk_reduce_two_kernel(const float* __restrict__ slab0, int splits0, Epilogue e0, int mode0, int nblk0,
+                                                                const float* __restrict__ slab1, int splits1, Epilogue e1, int mode1, int nblk1) {
+    const bool first = blockIdx.y == 0;
+    const float* slab = first ? slab0 : slab1;
+    const int splits = first ? splits0 : splits1, mode = first ? mode0 : mode1, nblk = first ? nblk0 : nblk1;
+    const Epilogue& e = first ? e0 : e1;
+    if ((int)blockIdx.x >= nblk) return;
+    if (mode == 2) splitk_reduce_small_body(slab, splits, e, blockIdx.x);
+    else if (mode == 1) splitk_reduce_body<true>(slab, splits, e, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)nblk * 256);
+    else splitk_reduce_body<false>(slab, splits, e, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)nblk * 256);
 }
 
 template <bool QUAD>
@@ -599,13 +606,17 @@ int gemm_reduce_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStre
     const bool hb = d1->defer_reduce && !b.streamk && b.splits > 1 && d1->M > 0 && d1->N > 0;
     if (ha && hb) {
         SNAG_REQUIRE(d0->workspace != d1->workspace, SNAG_ERR_ARG, "gemm_reduce_pair: the two problems share a workspace");
-        const bool quad = a.p.N % 4 == 0 && b.p.N % 4 == 0 && (((uintptr_t)d0->workspace | (uintptr_t)d1->workspace) & 15) == 0;
-        const int64_t t0 = (int64_t)a.p.M * a.p.N, t1 = (int64_t)b.p.M * b.p.N;
-        const int blocks = (int)std::min<int64_t>(2048, (std::max(t0, t1) / (quad ? 4 : 1) + 255) / 256);
-        if (quad) hipLaunchKernelGGL(splitk_reduce_two_kernel<true>, dim3(blocks, 2), dim3(256), 0, st, (const float*)d0->workspace, a.splits, a.e,
-                                     (const float*)d1->workspace, b.splits, b.e);
-        else hipLaunchKernelGGL(splitk_reduce_two_kernel<false>, dim3(blocks, 2), dim3(256), 0, st, (const float*)d0->workspace, a.splits, a.e,
-                                (const float*)d1->workspace, b.splits, b.e);
+        // per problem: the form (and block count) its own snag_gemm_f32 call would have launched
+        auto plan_of = [&](const GemmPlan& pl, const float* slab, int& mode) {
+            const int64_t total = (int64_t)pl.p.M * pl.p.N;
+            const bool quad = pl.p.N % 4 == 0 && ((uintptr_t)slab & 15) == 0;
+            mode = quad ? (reduce_small(total, pl.splits) ? 2 : 1) : 0;
+            return mode == 2 ? (int)((total / 4 + 63) / 64) : (int)std::min<int64_t>(2048, (total / (quad ? 4 : 1) + 255) / 256);
+        };
+        int m0 = 0, m1 = 0;
+        const int nb0 = plan_of(a, d0->workspace, m0), nb1 = plan_of(b, d1->workspace, m1);
+        hipLaunchKernelGGL(splitk_reduce_two_kernel, dim3(std::max(nb0, nb1), 2), dim3(256), 0, st, (const float*)d0->workspace, a.splits, a.e, m0, nb0,
+                           (const float*)d1->workspace, b.splits, b.e, m1, nb1);
         return check_launch("snag_gemm_reduce_pair");
     }
     if (ha) return launch_reduce(a, d0->workspace, st);

@@ -203,6 +203,36 @@ def test_gemm_pair_of_different_shapes_is_one_grouped_launch(s0, s1, a_kc, b_kc)
     assert_close(res[1][1], ref, atol=2e-6 * s1[2] + 1e-5, rtol=2e-5)
 
 
+@pytest.mark.parametrize("s0,s1", [((15000, 128, 4096), (15000, 128, 768)), ((4096, 128, 15000), (768, 128, 15000)), ((300, 128, 5000), (64, 64, 16)),
+                                   ((130, 70, 4000), (257, 100, 3000))])
+def test_gemm_deferred_reduce_pair(s0, s1):
+    """defer_reduce + snag_gemm_reduce_pair: two K-split problems of different shape leave their slabs in (distinct) workspaces and ONE
+    launch reduces both and applies their epilogues -- the bits of two plain snag_gemm_f32 calls.  (64, 64, 16): no split on one
+    side -- finished by its own call, skipped by the pair reduce; N = 70 / 100: the scalar (non-quad) reduce path."""
+    import ctypes
+    from snag_amd import _lib
+    from snag_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(sum(s0) + 3 * sum(s1))
+    mk = lambda r, c: torch.randn(r, c, generator=g).to(DEV)
+    probs = []
+    for (M, N, K) in (s0, s1):
+        probs.append((mk(K, M), mk(K, N), mk(1, N).reshape(N)))          # both operands row-contiguous (the projection layouts)
+    res = []
+    for deferred in (False, True):
+        outs = [torch.zeros(s[0], s[1], device=DEV) for s in (s0, s1)]
+        ws = [torch.empty(max(_lib.load().snag_gemm_workspace_floats(*s), 1) + 64, device=DEV) for s in (s0, s1)]
+        d = [_desc(probs[i][0], probs[i][1], outs[i], False, False, ws[i], bias=ptr(probs[i][2]), act=1 if i == 0 else 0) for i in range(2)]
+        for x in d:
+            x.defer_reduce = int(deferred)
+            call("snag_gemm_f32", ctypes.byref(x), stream())
+        if deferred:
+            call("snag_gemm_reduce_pair", ctypes.byref(d[0]), ctypes.byref(d[1]), stream())
+        res.append(outs)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    a, b, bias = probs[1]
+    assert_close(res[1][1], a.double().t() @ b.double() + bias.double(), atol=2e-6 * s1[2] + 1e-5, rtol=2e-5)
+
+
 @pytest.mark.parametrize("M,N,K,dist", [(1500, 128, 4096, "randn"), (1500, 128, 4096, "uniform"), (1024, 256, 128, "randn"), (300, 128, 15000, "randn"),
                                         (1500, 128, 4096, "wide")])
 def test_gemm_error_against_fp64_is_f32_grade(M, N, K, dist):
