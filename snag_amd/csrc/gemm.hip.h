@@ -6,14 +6,15 @@
 // "row-contiguous" (element (r,k) at ptr[k*ld + r]: the transposed uses in the projections and the backward GEMMs).
 //
 // Three main loops live in GemmCore, chosen at compile time (DESIGN.md par. 4):
-//   * run_presplit, row-private (kRowPrivate: 128 x 128 tile, four waves stacked along M; long K): the default build multiplies f32
-//     values as six bf16 MFMA products of exactly split operands (SNAG_GEMM_BF16X = 6).  A wave's 32 rows of A go from global memory
-//     to its registers and are split there; B is split once per workgroup into an LDS image in MFMA operand order.
+//   * run_presplit, row-private (kRowPrivate: waves stacked along M; long K): the default build multiplies f32 values as six bf16
+//     MFMA products of exactly split operands (SNAG_GEMM_BF16X = 6).  A wave's 32 rows of A go from global memory to its registers
+//     and are split there; B is split once per workgroup into an LDS image in MFMA operand order.  Two forms: 128 x 128, four
+//     waves; 256 x 128, eight waves in two groups running half an iteration apart (kPingPong: outputs one column tile wide).
 //   * run_presplit, 64 x 128 tile (2 x 2 waves; short K, small outputs): both operands are split once per workgroup into LDS images.
 //   * run_loop: the f32-MFMA form (v_mfma_f32_32x32x2_f32; -DSNAG_GEMM_BF16X=0) and the in-fragment split (the 128 x 160 tile,
 //     reachable through SNAG_GEMM_TILE=3 only): f32 tiles in LDS -- K-contiguous tiles row-major with XOR-swizzled 16-byte chunks,
 //     row-contiguous tiles [k][row] -- filled by LDS-DMA or through registers, double-buffered.
-// Within a k-tile the sum runs over a fixed permutation of k, the same for both operands.  256 threads = 4 waves.
+// Within a k-tile the sum runs over a fixed permutation of k, the same for both operands.  256 threads = 4 waves (512 = 8 in the ping-pong form).
 #pragma once
 #include <type_traits>
 #include "common.hip.h"
