@@ -277,3 +277,18 @@ def test_gemm_never_reads_past_its_operands(M, N, K, a_kc, b_kc):
     c = ops.gemm(a, b, a_kcontig=a_kc, b_kcontig=b_kc)
     ref = _ref(a.cpu(), b.cpu(), a_kc, b_kc)
     assert_close(c, ref, atol=2e-6 * K + 1e-5, rtol=2e-5, what=f"gemm {M}x{N}x{K} inside poisoned buffers")
+
+
+@pytest.mark.parametrize("sa,sb,a_kc,b_kc", [((4096, 6000), (4096, 128), False, False),      # eight-wave ping-pong tile (N <= 128, long K)
+                                             ((3000, 2000), (3000, 300), True, False),       # four-wave row-private tile (several column tiles)
+                                             ((9000, 128), (256, 128), True, True),          # 64 x 128 pre-split tile
+                                             ((1501, 4099), (1501, 130), False, False)])     # ragged everything, K split
+def test_gemm_repeated_launches_are_bit_identical(sa, sb, a_kc, b_kc):
+    """Race screen for the staged k-loops (LDS images written and read across barriers, two groups of waves half an iteration apart in
+    the ping-pong form): 40 launches of one problem give 40 bit-identical results (tools/stress_gemm_determinism.py runs the long form)."""
+    from snag_amd import ops
+    g = torch.Generator().manual_seed(sa[0] + sb[1])
+    a, b = torch.randn(*sa, generator=g).to(DEV), torch.randn(*sb, generator=g).to(DEV)
+    ref = ops.gemm(a, b, a_kcontig=a_kc, b_kcontig=b_kc).clone()
+    for _ in range(40):
+        assert torch.equal(ops.gemm(a, b, a_kcontig=a_kc, b_kcontig=b_kc), ref)
