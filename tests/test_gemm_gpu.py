@@ -280,7 +280,7 @@ def test_gemm_never_reads_past_its_operands(M, N, K, a_kc, b_kc):
 
 
 @pytest.mark.parametrize("sa,sb,a_kc,b_kc", [((4096, 6000), (4096, 128), False, False),      # eight-wave ping-pong tile (N <= 128, long K)
-                                             ((3000, 2000), (3000, 300), True, False),       # four-wave row-private tile (several column tiles)
+                                             ((3000, 2000), (2000, 300), True, False),       # four-wave row-private tile (several column tiles)
                                              ((9000, 128), (256, 128), True, True),          # 64 x 128 pre-split tile
                                              ((1501, 4099), (1501, 130), False, False)])     # ragged everything, K split
 def test_gemm_repeated_launches_are_bit_identical(sa, sb, a_kc, b_kc):
