@@ -385,6 +385,15 @@ SNAG_API int snag_adamw_step_groups(float* param, const float* grad, float* exp_
 SNAG_API int snag_clip_grad_norm(const float* grad, int64_t n, float grad_scale, float max_norm, float* out2, float* work,
                                 uint64_t* advance_tick, void* stream);
 
+/* snag_clip_grad_norm + snag_adamw_step_groups + the step counter's increment as TWO launches instead of three: the sum-of-squares
+ * partials (work: 1024 floats) are turned into the clip coefficient by every AdamW workgroup itself, in one fixed order; the partial-
+ * sum launch advances *tick.  out2 (optional): {coefficient, gradient norm}.  The update is that of
+ * clip_grad_norm_(max_norm) followed by AdamW at step *tick + 1 (bias correction from the device counter). */
+SNAG_API int snag_clip_adamw_step_groups(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                                         float beta2, float eps, const int64_t* seg_end, const float* seg_weight_decay,
+                                         const float* seg_lr_scale, int n_seg, uint64_t* tick, float grad_scale, float max_norm, float* out2,
+                                         float* work, void* stream);
+
 /* Device-resident step counter: tick[0] += 1.  When `tick` is given to snag_adamw_step the bias
  * correction uses t = tick[0] + 1 instead of the host `step`, which lets a captured hipGraph of a
  * whole training step be replayed without re-recording. */

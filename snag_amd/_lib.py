@@ -90,6 +90,7 @@ SIGNATURES = {
     "snag_entity_token_bwd": [_P, _L, _L, _I, _P, _F, _P, _I, _P],
     "snag_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _P, _F, _P],
     "snag_adamw_step_groups": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P, _P, _I, _L, _P, _F, _P, _I, _P],
+    "snag_clip_adamw_step_groups": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P, _P, _I, _P, _F, _F, _P, _P, _P],
     "snag_clip_grad_norm": [_P, _L, _F, _F, _P, _P, _P, _P],
     "snag_tick": [_P, _P],
     "snag_gat_layer_fwd": [_P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],

@@ -168,8 +168,24 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float wd, float bc1, float bc2, float gscale,
                                                     const uint64_t* __restrict__ tick, const int64_t* __restrict__ seg_end,
                                                     const float* __restrict__ seg_wd, const float* __restrict__ seg_lr, int n_seg,
-                                                    const float* __restrict__ gscale_dev, int tick_advanced, int vec) {
+                                                    const float* __restrict__ gscale_dev, int tick_advanced, int vec,
+                                                    const float* __restrict__ norm_parts = nullptr, int n_parts = 0, float max_norm = 0.f,
+                                                    float* __restrict__ clip_out = nullptr) {
     if (gscale_dev != nullptr) gscale *= gscale_dev[0];      // e.g. the clip coefficient of snag_clip_grad_norm
+    if (norm_parts != nullptr) {
+        // clip_grad_norm_'s coefficient from the sum-of-squares partials, computed by EVERY workgroup in the same fixed order (4 KB of
+        // L2-resident partials): the single-block launch that used to turn them into the coefficient is gone
+        __shared__ float red[4];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n_parts; i += 256) s += norm_parts[i];
+        s = sum64(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        const float norm = sqrtf(((red[0] + red[1]) + red[2]) + red[3]);
+        const float coef = fminf(1.0f, max_norm / (norm + 1e-6f));
+        gscale *= coef;
+        if (clip_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { clip_out[0] = coef; clip_out[1] = norm; }
+    }
     if (tick != nullptr) {          // step number lives on the device (graph replay): t = tick + 1 (tick itself when already advanced)
         const float t = (float)(tick[0] + (tick_advanced ? 0 : 1));
         bc1 = 1.0f - powf(b1, t);
@@ -427,7 +443,9 @@ namespace snag {
 // torch.nn.utils.clip_grad_norm_ without leaving the device: fixed-order sum of squares in two levels, then
 // out[0] = min(1, max_norm / (total_norm + 1e-6)), out[1] = total_norm.
 constexpr int kNormBlocks = 1024;
-__global__ __launch_bounds__(256) void sumsq_part_kernel(const float* __restrict__ g, int64_t n, float pre_scale, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void sumsq_part_kernel(const float* __restrict__ g, int64_t n, float pre_scale, float* __restrict__ part,
+                                                         uint64_t* __restrict__ advance = nullptr) {
+    if (advance != nullptr && blockIdx.x == 0 && threadIdx.x == 0) advance[0] += 1;        // (nothing in this launch reads the counter)
     __shared__ float red[4];
     float s = 0.f;
     if ((((uintptr_t)g) & 15) == 0) {          // dwordx4 body (fixed order per thread: x, y, z, w of its quads), scalar tail
@@ -512,6 +530,23 @@ extern "C" SNAG_API int snag_adamw_step_groups(float* param, const float* grad, 
                        eps, 0.0f, bc1, bc2, grad_scale, tick, seg_end, seg_weight_decay, seg_lr_scale, n_seg, grad_scale_dev, tick_advanced,
                        adamw_vec_ok(param, grad, exp_avg, exp_avg_sq));
     return check_launch("snag_adamw_step_groups");
+}
+
+extern "C" SNAG_API int snag_clip_adamw_step_groups(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                                                    float beta2, float eps, const int64_t* seg_end, const float* seg_weight_decay,
+                                                    const float* seg_lr_scale, int n_seg, uint64_t* tick, float grad_scale, float max_norm,
+                                                    float* out2, float* work, void* stream) {
+    SNAG_REQUIRE(n >= 0 && tick != nullptr && max_norm > 0.f && work != nullptr, SNAG_ERR_ARG, "clip_adamw_step_groups: bad arguments");
+    SNAG_REQUIRE(n_seg >= 1 && seg_end && seg_weight_decay && seg_lr_scale, SNAG_ERR_ARG, "clip_adamw_step_groups: segment table missing");
+    if (n == 0) return snag_tick(tick, stream);
+    SNAG_REQUIRE(param && grad && exp_avg && exp_avg_sq, SNAG_ERR_ARG, "clip_adamw_step_groups: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kNormBlocks, (n + 255) / 256));
+    hipLaunchKernelGGL(sumsq_part_kernel, dim3(nb), dim3(256), 0, st, grad, n, grad_scale, work, tick);          // also advances the step counter
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, 0.0f, 1.0f, 1.0f,
+                       grad_scale, (const uint64_t*)tick, seg_end, seg_weight_decay, seg_lr_scale, n_seg, (const float*)nullptr, 1,
+                       adamw_vec_ok(param, grad, exp_avg, exp_avg_sq), (const float*)work, nb, max_norm, out2);
+    return check_launch("snag_clip_adamw_step_groups");
 }
 
 extern "C" SNAG_API int snag_tick(uint64_t* tick, void* stream) {

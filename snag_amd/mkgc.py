@@ -674,10 +674,13 @@ class MKGCHotPath:
     def optimizer_step(self, grad_scale=1.0):
         cfg = self.cfg
         coef, advanced = None, 0
-        if cfg.clip > 0:                      # global-norm clipping, coefficient stays on the device; its single-block tail also advances tick
-            call("snag_clip_grad_norm", ptr(self.gflat), self.n_params, float(grad_scale), float(cfg.clip), ptr(self._clip), ptr(self._clip_work),
-                 ptr(self.tick), self._st)
-            coef, advanced = ptr(self._clip), 1
+        if cfg.clip > 0:
+            # global-norm clipping + AdamW + the step counter in two launches: the coefficient never leaves the device (every AdamW
+            # workgroup derives it from the sum-of-squares partials), self._clip receives {coefficient, norm}
+            call("snag_clip_adamw_step_groups", ptr(self.flat), ptr(self.gflat), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n_params,
+                 float(cfg.lr), 0.9, 0.999, 1e-8, ptr(self._seg_end), ptr(self._seg_wd), ptr(self._seg_lr), len(self.param_groups),
+                 ptr(self.tick), float(grad_scale), float(cfg.clip), ptr(self._clip), ptr(self._clip_work), self._st)
+            return
         call("snag_adamw_step_groups", ptr(self.flat), ptr(self.gflat), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n_params,
              float(cfg.lr), 0.9, 0.999, 1e-8, ptr(self._seg_end), ptr(self._seg_wd), ptr(self._seg_lr), len(self.param_groups), 0,
              ptr(self.tick), float(grad_scale), coef, advanced, self._st)
