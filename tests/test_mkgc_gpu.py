@@ -259,8 +259,8 @@ def test_grad_buckets_partition_the_flat_buffer(num_proj):
 
 @pytest.mark.parametrize("clip", [0.0, 1.0, 25.0])
 def test_optimizer_matches_torch_adamw_with_reference_param_groups(clip):
-    """clip_grad_norm_ + AdamW as the reference's train loop runs them (main.py:266-270): snag_clip_grad_norm + snag_adamw_step_groups over
-    the flat buffer == torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW with the reference's groups (set_optim, src/utils.py:47-55:
+    """clip_grad_norm_ + AdamW as the reference's train loop runs them (main.py:266-270): snag_clip_adamw_step_groups (clip > 0) /
+    snag_adamw_step_groups over the flat buffer == torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW with the reference's groups (set_optim, src/utils.py:47-55:
     names containing 'bias' / 'weight_raw' are not decayed), over several steps with the device-side step counter."""
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
     cfg = MKGCConfig(n_ent=200, n_rel=5, dim=64, feat_dims=[24, 16], num_proj=1, use_intermediate=1, intermediate_size=32, lr=3e-3, weight_decay=0.05,
@@ -294,6 +294,35 @@ def test_optimizer_matches_torch_adamw_with_reference_param_groups(clip):
     for k in names:
         o, shp = eng.slices[k]
         assert_close(got[o:o + ref[k].numel()].view(shp), ref[k].detach(), atol=2e-6, rtol=2e-6, what=k)
+
+
+def test_three_launch_clip_path_equals_the_two_launch_one():
+    """snag_clip_grad_norm + snag_adamw_step_groups (coefficient from a single-block launch; kept in the C ABI) against
+    snag_clip_adamw_step_groups (every AdamW workgroup derives it): same norm to rounding, same update."""
+    from snag_amd._lib import call, ptr, stream
+    n = 300_001
+    g = torch.Generator().manual_seed(2)
+    p0, grad = torch.randn(n, generator=g).to(DEV), (torch.randn(n, generator=g) * 3).to(DEV)
+    seg_end = torch.tensor([100_000, n], dtype=torch.int64, device=DEV)
+    seg_wd, seg_lr = torch.tensor([0.05, 0.0], device=DEV), torch.tensor([1.0, 0.5], device=DEV)
+    res = []
+    for fused in (False, True):
+        p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        tick = torch.zeros(1, dtype=torch.int64, device=DEV)
+        out2, work = torch.zeros(2, device=DEV), torch.empty(1024, device=DEV)
+        for _ in range(3):
+            if fused:
+                call("snag_clip_adamw_step_groups", ptr(p), ptr(grad), ptr(m), ptr(v), n, 1e-2, 0.9, 0.999, 1e-8, ptr(seg_end), ptr(seg_wd), ptr(seg_lr), 2,
+                     ptr(tick), 1.0, 2.5, ptr(out2), ptr(work), stream())
+            else:
+                call("snag_clip_grad_norm", ptr(grad), n, 1.0, 2.5, ptr(out2), ptr(work), ptr(tick), stream())
+                call("snag_adamw_step_groups", ptr(p), ptr(grad), ptr(m), ptr(v), n, 1e-2, 0.9, 0.999, 1e-8, ptr(seg_end), ptr(seg_wd), ptr(seg_lr), 2, 0,
+                     ptr(tick), 1.0, ptr(out2), 1, stream())
+        res.append((p.cpu(), out2.cpu(), int(tick)))
+    assert res[0][2] == res[1][2] == 3
+    assert abs(float(res[0][1][1]) - float(res[1][1][1])) <= 1e-5 * float(res[0][1][1]) and float(res[0][1][0]) < 1.0
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-6
+    assert abs(float(res[0][1][1]) - float(grad.double().norm())) <= 1e-5 * float(grad.double().norm())
 
 
 def test_graph_replay_equals_eager_steps():
