@@ -218,6 +218,10 @@ typedef struct snag_gemm_desc {
     int64_t ldmask;
     int32_t defer_reduce;   /* 1: when the K split of this problem produces slabs, leave them in the workspace (C is not touched);
                              * snag_gemm_reduce_pair finishes the job.  Ignored when the problem runs without a slab split. */
+    /* optional second copy of the FINAL C values (after accumulate): mirror[m*ldmirror + n] = C[m,n] * (mirror_rowmask && mirror_rowmask[m]
+     * ? mirror_scale : 1).  The entity table's gradient (the structural token's rows of d_x0 through the noise blend) leaves the
+     * Mformer backward's last GEMM this way instead of through a copy launch. */
+    float* mirror; int64_t ldmirror; const uint8_t* mirror_rowmask; float mirror_scale;
 } snag_gemm_desc;
 
 SNAG_API int snag_gemm_f32(const snag_gemm_desc* desc, void* stream);
@@ -302,6 +306,10 @@ typedef struct snag_fusion_bwd_desc {
     int32_t accumulate;
     int32_t zero_d_hidden;                /* 1: d_hidden is overwritten with zeros once it has been read (a scatter-add target is
                                              clean for the next step without a fill launch); d_hidden is [N, D] in read-out mode */
+    /* read-out mode with L = 1 only (SNAG_ERR_UNSUPPORTED otherwise): the rows of token readout_slot_p1 - 1 of d_x0 are ALSO written
+     * to d_slot_out [N, d_slot_ld], scaled by d_slot_scale where d_slot_rowmask[n] != 0 -- what snag_entity_token_bwd would compute
+     * from d_x0 in a launch of its own (the entity-table gradient through the noise blend). */
+    float* d_slot_out; int64_t d_slot_ld; const uint8_t* d_slot_rowmask; float d_slot_scale;
 } snag_fusion_bwd_desc;
 
 SNAG_API int snag_fusion_bwd(const snag_fusion_bwd_desc* desc, void* stream);

@@ -29,7 +29,8 @@ class GemmDesc(_c.Structure):
                 ("keep_mask", _P), ("keep_scale", _F),
                 ("add1", _P), ("ld1", _L), ("add2", _P), ("ld2", _L),
                 ("accumulate", _c.c_int32), ("workspace", _P), ("workspace_floats", _L),
-                ("aux", _P), ("ldaux", _L), ("ldmask", _L), ("defer_reduce", _c.c_int32)]
+                ("aux", _P), ("ldaux", _L), ("ldmask", _L), ("defer_reduce", _c.c_int32),
+                ("mirror", _P), ("ldmirror", _L), ("mirror_rowmask", _P), ("mirror_scale", _F)]
 
 
 class FusionLayer(_c.Structure):
@@ -56,7 +57,7 @@ class FusionBwdDesc(_c.Structure):
     """struct snag_fusion_bwd_desc."""
     _fields_ = [("f", FusionDesc), ("d_joint", _P), ("d_joint_fz", _P), ("d_hidden", _P), ("d_weight_norm", _P),
                 ("d_x0", _P), ("grads", _c.POINTER(FusionLayerGrad)), ("d_weight_raw", _P), ("accumulate", _c.c_int32),
-                ("zero_d_hidden", _c.c_int32)]
+                ("zero_d_hidden", _c.c_int32), ("d_slot_out", _P), ("d_slot_ld", _L), ("d_slot_rowmask", _P), ("d_slot_scale", _F)]
 
 
 # name -> argtypes; every entry returns int (0 = enqueued) except the two listed in _SPECIAL

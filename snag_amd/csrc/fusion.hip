@@ -373,6 +373,9 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             if ((rc = gemm_dispatch(&g, st))) return rc;
             g = gemm_desc(N, D, D, dq_g, D, true, P.wqkv, D, false, dxin + (int64_t)ro * D, MD);
             g.add1 = W.dA; g.ld1 = D; g.accumulate = 1;
+            if (b->d_slot_out != nullptr && l == 0) {          // this launch writes the final token-ro rows of d_x0: mirror them (entity-table gradient)
+                g.mirror = b->d_slot_out; g.ldmirror = b->d_slot_ld; g.mirror_rowmask = b->d_slot_rowmask; g.mirror_scale = b->d_slot_scale;
+            }
             if ((rc = gemm_dispatch(&g, st))) return rc;
             dout = W.dC;
             continue;
@@ -464,6 +467,8 @@ extern "C" SNAG_API int snag_fusion_bwd(const snag_fusion_bwd_desc* b, void* str
     SNAG_REQUIRE(b->d_x0 && b->grads && b->f.work, SNAG_ERR_ARG, "fusion_bwd: null d_x0 / grads / work");
     SNAG_REQUIRE(b->f.readout_slot_p1 == 0 || !(b->d_joint || b->d_joint_fz || b->d_weight_norm), SNAG_ERR_UNSUPPORTED,
                  "fusion_bwd: read-out-only mode takes d_hidden [N, D] alone");
+    SNAG_REQUIRE(b->d_slot_out == nullptr || (b->f.readout_slot_p1 != 0 && b->f.L == 1 && b->d_slot_ld >= b->f.D), SNAG_ERR_UNSUPPORTED,
+                 "fusion_bwd: d_slot_out needs read-out mode with one layer (and d_slot_ld >= D)");
     const int64_t need = snag_fusion_work_floats(b->f.N, b->f.M, b->f.D, b->f.H, b->f.I, b->f.L, b->f.use_intermediate);
     SNAG_REQUIRE(b->f.work_floats >= need, SNAG_ERR_ARG, "fusion_bwd: work buffer holds %ld floats, need %ld", (long)b->f.work_floats, (long)need);
     for (int l = 0; l < b->f.L; ++l) {

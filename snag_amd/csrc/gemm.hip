@@ -28,6 +28,10 @@ struct Epilogue {
     int accumulate;         // C += result instead of C = result
     int M, N;
     int fast;               // host-decided: the dwordx4 path of operator()(m, n, float4) is legal
+    float* mirror;          // optional second copy of the final values, rows scaled where mirror_mask[m] != 0
+    int64_t ldmirror;
+    const uint8_t* mirror_mask;
+    float mirror_scale;
 
     __device__ __forceinline__ float one(int m, int n, float v) const {
         v *= alpha;
@@ -52,7 +56,9 @@ struct Epilogue {
         if (m >= M || n >= N) return;
         v = one(m, n, v);
         float* c = C + (int64_t)m * ldc + n;
-        *c = accumulate ? *c + v : v;
+        v = accumulate ? *c + v : v;
+        *c = v;
+        if (mirror) mirror[(int64_t)m * ldmirror + n] = (mirror_mask && mirror_mask[m]) ? v * mirror_scale : v;
     }
 
     // four consecutive columns n..n+3 of row m
@@ -103,6 +109,10 @@ struct Epilogue {
                 x[0] = o.x + x[0]; x[1] = o.y + x[1]; x[2] = o.z + x[2]; x[3] = o.w + x[3];
             }
             *c = make_float4(x[0], x[1], x[2], x[3]);
+            if (mirror) {
+                const float ms = (mirror_mask && mirror_mask[m]) ? mirror_scale : 1.0f;
+                *reinterpret_cast<float4*>(mirror + (int64_t)m * ldmirror + n) = make_float4(x[0] * ms, x[1] * ms, x[2] * ms, x[3] * ms);
+            }
             return;
         }
         (*this)(m, n + 0, v.x);
@@ -406,10 +416,12 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     e.C = d->C; e.ldc = d->ldc; e.bias = d->bias; e.alpha = d->alpha; e.act = d->act; e.pre = d->pre_act;
     e.mask = d->keep_mask; e.ldm = d->ldmask > 0 ? d->ldmask : d->N; e.mscale = d->keep_scale; e.add1 = d->add1; e.ld1 = d->ld1; e.add2 = d->add2; e.ld2 = d->ld2;
     e.accumulate = d->accumulate; e.M = d->M; e.N = d->N; e.aux = d->aux; e.ldaux = d->ldaux;
+    e.mirror = d->mirror; e.ldmirror = d->ldmirror; e.mirror_mask = d->mirror_rowmask; e.mirror_scale = d->mirror_scale;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     e.fast = (d->ldc % 4 == 0) && al16(d->C) && (!d->bias || al16(d->bias)) && (!d->pre_act || al16(d->pre_act)) &&
              (!d->add1 || (al16(d->add1) && d->ld1 % 4 == 0)) && (!d->add2 || (al16(d->add2) && d->ld2 % 4 == 0)) &&
-             (d->act < 3 || (al16(d->aux) && d->ldaux % 4 == 0)) && (!d->keep_mask || (e.ldm % 4 == 0 && ((uintptr_t)d->keep_mask & 3) == 0));
+             (d->act < 3 || (al16(d->aux) && d->ldaux % 4 == 0)) && (!d->keep_mask || (e.ldm % 4 == 0 && ((uintptr_t)d->keep_mask & 3) == 0)) &&
+             (!d->mirror || (al16(d->mirror) && d->ldmirror % 4 == 0));
 
     // Tile choice by padded work x a measured per-configuration factor (tools/tune_gemm.py, tools/tune_gemm_mmea.py, one device):
     //   128x128  when its tiles alone fill the chip; the best loop when both operands are K-contiguous;
@@ -641,6 +653,7 @@ int gemm_check(const snag_gemm_desc* d) {
     SNAG_REQUIRE(!d->add1 || d->ld1 >= d->N, SNAG_ERR_ARG, "gemm: ld1 too small");
     SNAG_REQUIRE(!d->add2 || d->ld2 >= d->N, SNAG_ERR_ARG, "gemm: ld2 too small");
     SNAG_REQUIRE(d->ldmask == 0 || d->ldmask >= d->N, SNAG_ERR_ARG, "gemm: ldmask=%ld < N=%d", (long)d->ldmask, d->N);
+    SNAG_REQUIRE(!d->mirror || d->ldmirror >= d->N, SNAG_ERR_ARG, "gemm: ldmirror=%ld < N=%d", (long)d->ldmirror, d->N);
     return SNAG_OK;
 }
 

@@ -17,6 +17,7 @@ import math
 from dataclasses import dataclass, field
 from typing import List, Optional
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -624,13 +625,22 @@ class MKGCHotPath:
             self.shard.reduce_scatter(self.d_repr, self.d_repr_full)
         if cfg.joint_way == "Mformer_hd_mean":
             call("snag_token_mean_bwd", ptr(self.d_repr), Nl, M, D, ptr(self.d_hidden), 0 if cfg.scorer == "segmented" else 1, st)
-        call("snag_fusion_bwd", ctypes.byref(self._bdesc), st)
+        # the entity table's gradient (this rank's rows only; the others stay zero from construction) = the structural token's rows of
+        # d_x0 through the noise blend: in read-out mode with one layer the Mformer backward's last GEMM writes it as a second copy of
+        # its output, otherwise a launch of its own derives it from d_x0
+        mirror = self.ro and cfg.num_layers == 1
+        bd = self._bdesc
+        bd.d_slot_out = (self.g["ent"].data_ptr() + 4 * lo * D) if mirror else None
+        bd.d_slot_ld = D
+        bd.d_slot_scale = float(np.float32(1.0) - np.float32(float(cfg.mask_ratio) * 0.5))       # 1.0f - a in float, as snag_entity_token_bwd forms it
+        bd.d_slot_rowmask = (self.ent_noise_mask.data_ptr() + lo) if (mirror and noisy) else None
+        call("snag_fusion_bwd", ctypes.byref(bd), st)
         self._d_repr_clean = cfg.scorer != "segmented"     # (atomic scorer: its reader cleared it behind itself)
         dx0 = self.d_x0.data_ptr()
         wk = ptr(self.work)
-        # the entity table's gradient: this rank's rows only (the others stay zero from construction)
-        call("snag_entity_token_bwd", dx0 + 4 * self.g_slot * D, MD, Nl, D, (self.ent_noise_mask.data_ptr() + lo) if noisy else None,
-             float(cfg.mask_ratio) * 0.5, self.g["ent"].data_ptr() + 4 * lo * D, 0, st)
+        if not mirror:
+            call("snag_entity_token_bwd", dx0 + 4 * self.g_slot * D, MD, Nl, D, (self.ent_noise_mask.data_ptr() + lo) if noisy else None,
+                 float(cfg.mask_ratio) * 0.5, self.g["ent"].data_ptr() + 4 * lo * D, 0, st)
         buckets = self.grad_buckets() if reducer is not None else None
         if reducer is not None:
             if self.shard.sharded:       # entity rows: each rank holds its own slice -> all-gather; relations: summed

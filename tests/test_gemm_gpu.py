@@ -292,3 +292,26 @@ def test_gemm_repeated_launches_are_bit_identical(sa, sb, a_kc, b_kc):
     ref = ops.gemm(a, b, a_kcontig=a_kc, b_kcontig=b_kc).clone()
     for _ in range(40):
         assert torch.equal(ops.gemm(a, b, a_kcontig=a_kc, b_kcontig=b_kc), ref)
+
+
+@pytest.mark.parametrize("M,N,K,split", [(1500, 128, 128, False), (333, 100, 77, False), (200, 128, 5000, True), (64, 70, 900, True)])
+def test_gemm_mirror_output(M, N, K, split):
+    """desc.mirror: a second copy of the FINAL C values (after accumulate), rows scaled where mirror_rowmask[m] != 0 -- the way the
+    entity-table gradient leaves the Mformer backward's last GEMM.  Through the plain epilogue and through the split-K reduce,
+    dwordx4 and scalar (N = 70 / 100) paths."""
+    import ctypes
+    from snag_amd import _lib
+    from snag_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b = torch.randn(M, K, generator=g).to(DEV), torch.randn(N, K, generator=g).to(DEV)
+    c0 = torch.randn(M, N, generator=g).to(DEV)
+    rowmask = (torch.rand(M, generator=g) < 0.4).to(torch.uint8).to(DEV)
+    out, mirror = c0.clone(), torch.full((M, N + 4), 7.0, device=DEV)
+    ws = torch.empty(max(_lib.load().snag_gemm_workspace_floats(M, N, K), 1) + 64, device=DEV) if split else None
+    d = _desc(a, b, out, True, True, ws, accumulate=1, mirror=ptr(mirror), ldmirror=mirror.stride(0), mirror_rowmask=ptr(rowmask), mirror_scale=0.65)
+    call("snag_gemm_f32", ctypes.byref(d), stream())
+    ref = torch.zeros(M, N, device=DEV)
+    call("snag_gemm_f32", ctypes.byref(_desc(a, b, ref, True, True, ws)), stream())
+    assert torch.equal(out, c0 + ref)
+    scale = torch.where(rowmask.bool(), torch.tensor(0.65, device=DEV), torch.tensor(1.0, device=DEV)).view(-1, 1)
+    assert torch.equal(mirror[:, :N], out * scale) and float((mirror[:, N:] - 7.0).abs().max()) == 0.0
