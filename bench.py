@@ -104,7 +104,7 @@ def roofline_dominant(cfg, timer, rows=None, reduce_timer=None):
             traffic, src = pmc["fetch_bytes"] + pmc["write_bytes"] + pmc.get("fixup_fetch_bytes", 0) + pmc.get("fixup_write_bytes", 0), pmc["source"]
     except (OSError, KeyError, ValueError):
         pass
-    return {"kernel": f"gemm_tile_kernel<256,128,32,128,..> (8-wave ping-pong) + splitk_reduce_two_kernel (shared with the text projection, counted in full) (visual projection: [{rows},{cfg.feat_dims[0]}]x[{cfg.feat_dims[0]},{cfg.dim}], fp32 via 6 split-bf16 MFMA products, 4 K-splits)",
+    return {"kernel": f"gemm_tile_kernel<256,128,32,128,..> (8-wave ping-pong) + splitk_reduce_multi_kernel (shared with the text projection, counted in full) (visual projection: [{rows},{cfg.feat_dims[0]}]x[{cfg.feat_dims[0]},{cfg.dim}], fp32 via 6 split-bf16 MFMA products, 4 K-splits)",
             # the bound of the kernel AS BUILT: six bf16 MFMA products per f32 multiply-add -> bf16 dense peak / 6 (37.5 us for this
             # launch; its HBM floor, 255.5 MB at 8 TB/s, is 32 us).  frac is therefore the share of the matrix pipe's time the
             # launch (kernel + fix-up) uses; against the f32 MFMA peak (157.3 TF), which bounded the previous form of this kernel

@@ -217,7 +217,8 @@ typedef struct snag_gemm_desc {
     const float* aux; int64_t ldaux;
     int64_t ldmask;
     int32_t defer_reduce;   /* 1: when the K split of this problem produces slabs, leave them in the workspace (C is not touched);
-                             * snag_gemm_reduce_pair finishes the job.  Ignored when the problem runs without a slab split. */
+                             * snag_gemm_reduce_pair / snag_gemm_reduce_group finishes the job.  Ignored when the problem runs without a slab split;
+                             * snag_gemm_f32_pair honours it when both members set it. */
     /* optional second copy of the FINAL C values (after accumulate): mirror[m*ldmirror + n] = C[m,n] * (mirror_rowmask && mirror_rowmask[m]
      * ? mirror_scale : 1).  The entity table's gradient (the structural token's rows of d_x0 through the noise blend) leaves the
      * Mformer backward's last GEMM this way instead of through a copy launch. */
@@ -235,6 +236,9 @@ SNAG_API int snag_gemm_f32_pair(const snag_gemm_desc* d0, const snag_gemm_desc* 
  * reduce launch instead of two.  A problem whose launch made no slabs (no split, stream-K) was finished by snag_gemm_f32 already and
  * is skipped.  Results are those of two plain snag_gemm_f32 calls, bit for bit. */
 SNAG_API int snag_gemm_reduce_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, void* stream);
+/* The same for up to four problems (n <= 4): the slab splits of f32_pair launches count too when BOTH members carried defer_reduce.
+ * Problems that ran without slabs are skipped; every slab workspace must be distinct. */
+SNAG_API int snag_gemm_reduce_group(const snag_gemm_desc* const* descs, int n, void* stream);
 
 /* Gram matrix S [n, n] = alpha * Z Z^T for Z [n, k] (row stride ldz), fp32 via split-bf16 MFMA.  Only the tiles on or above the diagonal are
  * computed; each is also stored transposed, so S is symmetric bit for bit.  Used for the stacked InfoNCE logits

@@ -209,7 +209,8 @@ struct Work {
 
 static int64_t bwd_gemm_ws(int N, int M, int D, int I, bool ffn) {
     const int NM = N * M;
-    int64_t w = std::max(gemm_workspace_floats(3 * D, D, NM), 2 * (gemm_workspace_floats(D, D, NM) + 64));
+    // (a sum, not a max: in read-out mode the slabs of dWo, dWq and dWkv wait side by side for ONE reduce launch)
+    int64_t w = gemm_workspace_floats(3 * D, D, NM) + 64 + 2 * (gemm_workspace_floats(D, D, NM) + 64);
     if (ffn) w = std::max({w, gemm_workspace_floats(D, I, NM), gemm_workspace_floats(I, D, NM)});
     return w;
 }
@@ -358,15 +359,18 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             {
                 snag_gemm_desc g0 = gemm_desc(D, D, N, dz, D, false, S.ctx, D, false, G.wo, D);
                 snag_gemm_desc g1 = gemm_desc(D, D, N, dq_g, D, false, xin + (int64_t)ro * D, MD, false, G.wqkv, D);
-                const int64_t halfws = W.gemm_ws_floats / 2 / 64 * 64;
-                g0.accumulate = acc; g0.workspace = W.gemm_ws; g0.workspace_floats = halfws;
-                g1.accumulate = acc; g1.workspace = W.gemm_ws + halfws; g1.workspace_floats = halfws;
+                // dWkv = dkv^T x (rows D..3D).  All three K splits leave their slabs in their own parts of the scratch; one launch reduces them
+                snag_gemm_desc gk = gemm_desc(2 * D, D, (int)NM, dkv, 2 * D, false, xin, D, false, G.wqkv + (int64_t)D * D, D);
+                const int64_t pw = (gemm_workspace_floats(D, D, (int)NM) + 64) / 64 * 64;
+                g0.accumulate = acc; g0.workspace = W.gemm_ws; g0.workspace_floats = pw;
+                g1.accumulate = acc; g1.workspace = W.gemm_ws + pw; g1.workspace_floats = pw;
+                gk.accumulate = acc; gk.workspace = W.gemm_ws + 2 * pw; gk.workspace_floats = W.gemm_ws_floats - 2 * pw;
+                g0.defer_reduce = g1.defer_reduce = gk.defer_reduce = 1;
                 if ((rc = gemm_dispatch_pair(&g0, &g1, st))) return rc;
+                if ((rc = gemm_dispatch(&gk, st))) return rc;
+                const snag_gemm_desc* three[3] = {&g0, &g1, &gk};
+                if ((rc = gemm_reduce_multi(three, 3, st))) return rc;
             }
-            // dWkv = dkv^T x (rows D..3D)
-            g = gemm_desc(2 * D, D, (int)NM, dkv, 2 * D, false, xin, D, false, G.wqkv + (int64_t)D * D, D);
-            g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
-            if ((rc = gemm_dispatch(&g, st))) return rc;
             // d(layer input) = dkv Wkv for every token, + dq_g Wq + dT1 into the rows of token ro
             float* dxin = (l == 0) ? b->d_x0 : W.dC;
             g = gemm_desc((int)NM, D, 2 * D, dkv, 2 * D, true, P.wqkv + (int64_t)D * D, D, false, dxin, D);

@@ -204,19 +204,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_small_pair_kernel(const flo
 }
 static bool reduce_small(int64_t total, int splits) { return total <= (1 << 18) && splits >= 8; }
 
-// two problems of different shape and split count (snag_gemm_reduce_pair): blockIdx.y = problem, each reduced by the body -- and in
-// the summation order -- its own snag_gemm_f32 call would have used (small: the four-wave slab-parallel one), over its own block count
-// mode: 0 = one column per thread, 1 = four columns per thread, 2 = the small-output slab-parallel form
-__global__ __launch_bounds__(256) void splitk_reduce_two_kernel(const float* __restrict__ slab0, int splits0, Epilogue e0, int mode0, int nblk0,
-                                                                const float* __restrict__ slab1, int splits1, Epilogue e1, int mode1, int nblk1) {
-    const bool first = blockIdx.y == 0;
-    const float* slab = first ? slab0 : slab1;
-    const int splits = first ? splits0 : splits1, mode = first ? mode0 : mode1, nblk = first ? nblk0 : nblk1;
-    const Epilogue& e = first ? e0 : e1;
-    if ((int)blockIdx.x >= nblk) return;
-    if (mode == 2) splitk_reduce_small_body(slab, splits, e, blockIdx.x);
-    else if (mode == 1) splitk_reduce_body<true>(slab, splits, e, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)nblk * 256);
-    else splitk_reduce_body<false>(slab, splits, e, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)nblk * 256);
+// Up to four problems of different shape and split count in one reduce launch (snag_gemm_reduce_pair / _group, the Mformer backward's weight
+// gradients): blockIdx.y = problem, each reduced by the body -- and in the summation order -- its own snag_gemm_f32 call would have
+// used, over its own block count.  mode: 0 = one column per thread, 1 = four columns per thread, 2 = the small-output slab-parallel form
+struct ReduceSet {
+    const float* slab[4];
+    int splits[4], mode[4], nblk[4];
+    Epilogue e[4];
+};
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceSet rs) {
+    const int q = blockIdx.y;
+    if ((int)blockIdx.x >= rs.nblk[q]) return;
+    if (rs.mode[q] == 2) splitk_reduce_small_body(rs.slab[q], rs.splits[q], rs.e[q], blockIdx.x);
+    else if (rs.mode[q] == 1) splitk_reduce_body<true>(rs.slab[q], rs.splits[q], rs.e[q], (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)rs.nblk[q] * 256);
+    else splitk_reduce_body<false>(rs.slab[q], rs.splits[q], rs.e[q], (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)rs.nblk[q] * 256);
 }
 
 template <bool QUAD>
@@ -585,7 +586,7 @@ int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipSt
     else launch_cfg_pair<64, 128, 32, 64>(a.p, a.e, s0, b.p, b.e, s1, splits, d0->a_kcontig, d0->b_kcontig, vec, st);
     int rc = check_launch("snag_gemm_f32_pair");
     if (rc) return rc;
-    if (splits > 1) {
+    if (splits > 1 && !(d0->defer_reduce && d1->defer_reduce)) {
         const int64_t total = (int64_t)a.p.M * a.p.N;
         const bool quad = a.p.N % 4 == 0 && ((uintptr_t)s0 & 15) == 0 && ((uintptr_t)s1 & 15) == 0;
         const int blocks = (int)std::min<int64_t>(1024, (total / (quad ? 4 : 1) + 255) / 256);
@@ -612,28 +613,37 @@ static int launch_reduce(const GemmPlan& pl, float* slab, hipStream_t st) {
     return check_launch("snag_gemm_f32(split-K reduce)");
 }
 
-int gemm_reduce_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStream_t st) {
-    const GemmPlan a = plan_gemm(d0), b = plan_gemm(d1);
-    const bool ha = d0->defer_reduce && !a.streamk && a.splits > 1 && d0->M > 0 && d0->N > 0;      // slabs waiting in d0's workspace
-    const bool hb = d1->defer_reduce && !b.streamk && b.splits > 1 && d1->M > 0 && d1->N > 0;
-    if (ha && hb) {
-        SNAG_REQUIRE(d0->workspace != d1->workspace, SNAG_ERR_ARG, "gemm_reduce_pair: the two problems share a workspace");
-        // per problem: the form (and block count) its own snag_gemm_f32 call would have launched
-        auto plan_of = [&](const GemmPlan& pl, const float* slab, int& mode) {
-            const int64_t total = (int64_t)pl.p.M * pl.p.N;
-            const bool quad = pl.p.N % 4 == 0 && ((uintptr_t)slab & 15) == 0;
-            mode = quad ? (reduce_small(total, pl.splits) ? 2 : 1) : 0;
-            return mode == 2 ? (int)((total / 4 + 63) / 64) : (int)std::min<int64_t>(2048, (total / (quad ? 4 : 1) + 255) / 256);
-        };
-        int m0 = 0, m1 = 0;
-        const int nb0 = plan_of(a, d0->workspace, m0), nb1 = plan_of(b, d1->workspace, m1);
-        hipLaunchKernelGGL(splitk_reduce_two_kernel, dim3(std::max(nb0, nb1), 2), dim3(256), 0, st, (const float*)d0->workspace, a.splits, a.e, m0, nb0,
-                           (const float*)d1->workspace, b.splits, b.e, m1, nb1);
-        return check_launch("snag_gemm_reduce_pair");
+// finishes up to four problems launched with defer_reduce (distinct workspaces): ONE launch for all that left slabs behind
+int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st) {
+    ReduceSet rs{};
+    int cnt = 0, maxblk = 0;
+    GemmPlan last{};
+    float* last_slab = nullptr;
+    for (int i = 0; i < n && i < 4; ++i) {
+        const snag_gemm_desc* d = ds[i];
+        const GemmPlan pl = plan_gemm(d);
+        if (!(d->defer_reduce && !pl.streamk && pl.splits > 1 && d->M > 0 && d->N > 0)) continue;      // finished by its own launch
+        for (int j = 0; j < cnt; ++j) SNAG_REQUIRE(rs.slab[j] != d->workspace, SNAG_ERR_ARG, "gemm_reduce: two problems share a workspace");
+        const int64_t total = (int64_t)pl.p.M * pl.p.N;
+        const bool quad = pl.p.N % 4 == 0 && ((uintptr_t)d->workspace & 15) == 0;
+        rs.slab[cnt] = d->workspace;
+        rs.splits[cnt] = pl.splits;
+        rs.mode[cnt] = quad ? (reduce_small(total, pl.splits) ? 2 : 1) : 0;
+        rs.nblk[cnt] = rs.mode[cnt] == 2 ? (int)((total / 4 + 63) / 64) : (int)std::min<int64_t>(2048, (total / (quad ? 4 : 1) + 255) / 256);
+        rs.e[cnt] = pl.e;
+        maxblk = std::max(maxblk, rs.nblk[cnt]);
+        last = pl; last_slab = d->workspace;
+        ++cnt;
     }
-    if (ha) return launch_reduce(a, d0->workspace, st);
-    if (hb) return launch_reduce(b, d1->workspace, st);
-    return SNAG_OK;
+    if (cnt == 0) return SNAG_OK;
+    if (cnt == 1) return launch_reduce(last, last_slab, st);
+    hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(maxblk, cnt), dim3(256), 0, st, rs);
+    return check_launch("snag_gemm_reduce_pair");
+}
+
+int gemm_reduce_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStream_t st) {
+    const snag_gemm_desc* ds[2] = {d0, d1};
+    return gemm_reduce_multi(ds, 2, st);
 }
 
 int gemm_check(const snag_gemm_desc* d) {
@@ -686,6 +696,16 @@ extern "C" SNAG_API int snag_gemm_reduce_pair(const snag_gemm_desc* d0, const sn
     if (rc) return rc;
     if ((rc = gemm_check(d1))) return rc;
     return gemm_reduce_pair(d0, d1, (hipStream_t)stream);
+}
+
+extern "C" SNAG_API int snag_gemm_reduce_group(const snag_gemm_desc* const* descs, int n, void* stream) {
+    SNAG_REQUIRE(n >= 0 && n <= 4 && (n == 0 || descs), SNAG_ERR_ARG, "gemm_reduce_group: n=%d (0..4 problems per launch)", n);
+    for (int i = 0; i < n; ++i) {
+        SNAG_REQUIRE(descs[i], SNAG_ERR_ARG, "gemm_reduce_group: null descriptor %d", i);
+        int rc = gemm_check(descs[i]);
+        if (rc) return rc;
+    }
+    return gemm_reduce_multi(descs, n, (hipStream_t)stream);
 }
 
 extern "C" SNAG_API int snag_gram_f32(const float* Z, int64_t ldz, int n, int k, float alpha, float* S, int64_t lds, void* stream) {

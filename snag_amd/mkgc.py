@@ -234,6 +234,8 @@ class MKGCHotPath:
             ws = max(ws, 2 * (lib.snag_gemm_workspace_floats(fd, D, Nl) + 64), 2 * (lib.snag_gemm_workspace_floats(Nl, D, fd) + 64), 256 * max(D, fd))
         ws = max(ws, 2 * (lib.snag_gemm_workspace_floats(D, D, Nl) + 64), lib.snag_gemm_workspace_floats(Nl, D, D) + 64)
         self.work = torch.empty(ws, device=dev)
+        # the second projections' weight gradients keep their K-split slabs here until the first projections' reduce launch takes them along
+        self.work_l2 = torch.empty(2 * (lib.snag_gemm_workspace_floats(D, D, Nl) + 64), device=dev) if cfg.num_proj == 2 else None
         H = cfg.num_heads
         # all dropout keep-masks of the step live in ONE byte buffer (views below), so one Philox launch draws them all
         n_probs, n_tok = _align(Nl * H * M * M), _align(Nl * M * D)
@@ -382,7 +384,7 @@ class MKGCHotPath:
                 self._probed((tags[i] + "_reduce") if tags and tags[i] else "", call, "snag_gemm_reduce_pair", ctypes.byref(pair[0]), ctypes.byref(pair[1]), st)
 
     def _gemm_desc(self, M, N, K, A, lda, akc, B, ldb, bkc, C, ldc, *, bias=None, act=0, pre=None, add1=None, ld1=0,
-                   aux=None, ldaux=0, splitk=True, keep=None, keep_scale=1.0, half=None):
+                   aux=None, ldaux=0, splitk=True, keep=None, keep_scale=1.0, half=None, scratch=None):
         d = _lib.GemmDesc()
         d.M, d.N, d.K = M, N, K
         d.a_kcontig, d.b_kcontig = int(akc), int(bkc)
@@ -393,11 +395,12 @@ class MKGCHotPath:
         if keep is not None:
             d.keep_mask, d.keep_scale = keep, keep_scale
         if splitk:
+            work = self.work if scratch is None else scratch
             if half is None:
-                d.workspace, d.workspace_floats = ptr(self.work), self.work.numel()
+                d.workspace, d.workspace_floats = ptr(work), work.numel()
             else:                         # member `half` (0 / 1) of a pair: its own half of the scratch
-                n = self.work.numel() // 2 // 64 * 64
-                d.workspace, d.workspace_floats = self.work.data_ptr() + 4 * n * half, n
+                n = work.numel() // 2 // 64 * 64
+                d.workspace, d.workspace_floats = work.data_ptr() + 4 * n * half, n
         return d
 
     def _proj_keep(self, i):
@@ -650,10 +653,15 @@ class MKGCHotPath:
                 reducer.start(buckets[0])
             reducer.start(buckets[1])
         nmod = len(cfg.feat_dims)
+        # two modalities, one rank: the four projection weight gradients (dl2 pair, dl1 x 2) leave their K-split slabs in place and
+        # ONE launch at the end reduces all four
+        one_reduce = reducer is None and cfg.num_proj == 2 and nmod == 2
         if cfg.num_proj == 2:
             # dl2 = dTok^T mid and d mid = (dTok l2) * [mid > 0] (* keep): same shapes for every modality -> two per launch
-            dl2 = [self._gemm_desc(D, D, Nl, dx0 + 4 * i * D, MD, 0, ptr(self.mid[i]), D, 0, ptr(self.g[f"proj{i}.l2"]), D, splitk=True, half=i % 2)
-                   for i in range(nmod)]
+            dl2 = [self._gemm_desc(D, D, Nl, dx0 + 4 * i * D, MD, 0, ptr(self.mid[i]), D, 0, ptr(self.g[f"proj{i}.l2"]), D, splitk=True, half=i % 2,
+                                   scratch=self.work_l2 if one_reduce else None) for i in range(nmod)]
+            for d in dl2:
+                d.defer_reduce = int(one_reduce)
             dmid = [self._gemm_desc(Nl, D, D, dx0 + 4 * i * D, MD, 1, ptr(self.p[f"proj{i}.l2"]), D, 0, ptr(self.d_mid[i]), D, act=4, aux=ptr(self.mid[i]),
                                     ldaux=D, keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout), splitk=False) for i in range(nmod)]
             for group in (dl2, dmid):
@@ -671,7 +679,15 @@ class MKGCHotPath:
             else:
                 dl1.append(self._gemm_desc(fd, D, Nl, ptr(feat), fd, 0, ptr(self.d_mid[i]), D, 0, ptr(self.g[f"proj{i}.l1"]), D, splitk=True,
                                            half=i % 2))   # dl1^T [fd, D]
-        if reducer is None:         # weight gradients of the first projections: two kernels, ONE reduce launch per pair of modalities
+        if one_reduce:
+            group = (ctypes.POINTER(_lib.GemmDesc) * 4)()
+            for j, d in enumerate(dl2 + dl1):
+                d.defer_reduce = 1
+                group[j] = ctypes.pointer(d)
+            call("snag_gemm_f32", ctypes.byref(dl1[0]), st)
+            call("snag_gemm_f32", ctypes.byref(dl1[1]), st)
+            call("snag_gemm_reduce_group", group, 4, st)
+        elif reducer is None:       # weight gradients of the first projections: two kernels, ONE reduce launch per pair of modalities
             self._gemm_deferred_pairs(dl1)
         for i, fd in enumerate(cfg.feat_dims):
             if reducer is not None:         # data parallel: each modality's bucket goes out as soon as its gradient is final

@@ -233,6 +233,41 @@ def test_gemm_deferred_reduce_pair(s0, s1):
     assert_close(res[1][1], a.double().t() @ b.double() + bias.double(), atol=2e-6 * s1[2] + 1e-5, rtol=2e-5)
 
 
+@pytest.mark.parametrize("pair_shape,s2,s3", [((128, 128, 15000), (4096, 128, 15000), (768, 128, 15000)), ((128, 128, 15000), (64, 64, 16), (130, 70, 4000)),
+                                              ((100, 60, 3000), (300, 128, 5000), (257, 100, 3000))])
+def test_gemm_deferred_reduce_group(pair_shape, s2, s3):
+    """snag_gemm_reduce_group: a same-shaped snag_gemm_f32_pair (both members deferred) and two more deferred problems leave four sets of
+    slabs behind, ONE launch finishes them all -- the bits of the plain calls, accumulate and epilogues per problem (the step's four
+    projection weight gradients; the Mformer backward's dWo / dWq / dWkv use the same launch inside the library)."""
+    import ctypes
+    from snag_amd import _lib
+    from snag_amd._lib import call, ptr, stream
+    shapes = [pair_shape, pair_shape, s2, s3]
+    g = torch.Generator().manual_seed(sum(pair_shape) + 3 * sum(s2) + 5 * sum(s3))
+    mk = lambda r, c: torch.randn(r, c, generator=g).to(DEV)
+    probs = [(mk(K, M), mk(K, N), mk(1, N).reshape(N), mk(M, N)) for (M, N, K) in shapes]
+    res = []
+    for deferred in (False, True):
+        outs = [probs[i][3].clone() for i in range(4)]          # accumulate = 1 on problem 1 and 3: C += the product
+        ws = [torch.empty(max(_lib.load().snag_gemm_workspace_floats(*s), 1) + 64, device=DEV) for s in shapes]
+        d = [_desc(probs[i][0], probs[i][1], outs[i], False, False, ws[i], bias=ptr(probs[i][2]) if i % 2 == 0 else None, act=1 if i == 2 else 0,
+                   accumulate=i % 2, defer_reduce=int(deferred)) for i in range(4)]
+        call("snag_gemm_f32_pair", ctypes.byref(d[0]), ctypes.byref(d[1]), stream())
+        call("snag_gemm_f32", ctypes.byref(d[2]), stream())
+        call("snag_gemm_f32", ctypes.byref(d[3]), stream())
+        if deferred:
+            group = (ctypes.POINTER(_lib.GemmDesc) * 4)(*[ctypes.pointer(x) for x in d])
+            call("snag_gemm_reduce_group", group, 4, stream())
+        res.append(outs)
+    for i in range(4):
+        assert torch.equal(res[0][i], res[1][i]), i
+    a, b, _, c0 = probs[3]
+    assert_close(res[1][3], a.double().t() @ b.double() + c0.double(), atol=2e-6 * s3[2] + 1e-5, rtol=2e-5)
+    # more than four problems / a shared workspace are refused
+    with pytest.raises(Exception):
+        call("snag_gemm_reduce_group", group, 5, stream())
+
+
 @pytest.mark.parametrize("M,N,K,dist", [(1500, 128, 4096, "randn"), (1500, 128, 4096, "uniform"), (1024, 256, 128, "randn"), (300, 128, 15000, "randn"),
                                         (1500, 128, 4096, "wide")])
 def test_gemm_error_against_fp64_is_f32_grade(M, N, K, dist):
