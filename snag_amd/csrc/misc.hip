@@ -391,7 +391,7 @@ extern "C" SNAG_API int snag_colstats(const float* x, int64_t R, int C, const ui
 }
 
 extern "C" SNAG_API int snag_colsum(const float* x, int64_t R, int C, int64_t ld, float* out, int accumulate, float* work, void* stream) {
-    SNAG_REQUIRE(x && out && work && R >= 0 && C >= 1 && ld >= C, SNAG_ERR_ARG, "colsum: bad arguments");
+    SNAG_REQUIRE((x || R == 0) && out && work && R >= 0 && C >= 1 && ld >= C, SNAG_ERR_ARG, "colsum: bad arguments");     // (no rows: zeros)
     hipStream_t st = (hipStream_t)stream;
     const int by = (int)std::max<int64_t>(1, std::min<int64_t>(256, (R + 3) / 4));
     hipLaunchKernelGGL(colsum_part_kernel, dim3(ceil_div(C, 64), by), dim3(256), 0, st, x, R, C, ld, work);

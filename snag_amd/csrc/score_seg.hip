@@ -431,7 +431,8 @@ extern "C" SNAG_API int snag_score_margin_fwd_bwd_seg(const float* ent, int64_t 
                                                       int64_t batch, int n_neg, float margin, float grad_scale, float* pos, float* neg,
                                                       float* loss_part, float* loss, uint32_t* ticket, float* d_ent, int64_t d_ent_ld,
                                                       float* d_rel, int write_untouched, void* work, int64_t work_bytes, void* stream) {
-    SNAG_REQUIRE(ent && rel && d_ent && d_rel && work && ticket && loss_part, SNAG_ERR_ARG, "score_fwd_bwd_seg: null table / gradient / workspace / ticket / loss_part");
+    SNAG_REQUIRE(ent && rel && d_ent && d_rel && work && (batch == 0 || (ticket && loss_part)), SNAG_ERR_ARG,
+                 "score_fwd_bwd_seg: null table / gradient / workspace / ticket / loss_part");
     SNAG_REQUIRE(n_ent > 0 && n_rel > 0 && dim > 0 && batch >= 0 && n_neg >= 0, SNAG_ERR_ARG, "score_fwd_bwd_seg: bad sizes");
     SNAG_REQUIRE(idx_bytes == 4 || idx_bytes == 8, SNAG_ERR_ARG, "score_fwd_bwd_seg: idx_bytes=%d (want 4 or 8)", idx_bytes);
     SNAG_REQUIRE(dim <= 512 && dim % 4 == 0 && ent_ld % 4 == 0 && d_ent_ld % 4 == 0 && ent_ld >= dim && d_ent_ld >= dim, SNAG_ERR_UNSUPPORTED,

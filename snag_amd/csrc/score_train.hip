@@ -226,10 +226,10 @@ extern "C" SNAG_API int snag_score_margin_fwd_bwd(const float* ent, int64_t ent_
                                                   int64_t batch, int n_neg, float margin, float grad_scale, float* pos, float* neg,
                                                   float* loss_part, float* loss, uint32_t* ticket, float* d_ent, int64_t d_ent_ld,
                                                   float* d_rel, void* stream) {
-    SNAG_REQUIRE((loss == nullptr) || (loss_part != nullptr && ticket != nullptr), SNAG_ERR_ARG,
-                 "score_fwd_bwd: the summed loss needs loss_part and a ticket word");
     hipStream_t st = (hipStream_t)stream;
-    if (batch == 0) {
+    SNAG_REQUIRE(batch == 0 || (loss == nullptr) || (loss_part != nullptr && ticket != nullptr), SNAG_ERR_ARG,
+                 "score_fwd_bwd: the summed loss needs loss_part and a ticket word");
+    if (batch == 0) {           // nothing to score: the summed loss is zero, the gradients are untouched
         if (loss != nullptr) return hipMemsetAsync(loss, 0, sizeof(float), st) == hipSuccess ? SNAG_OK : fail(SNAG_ERR_LAUNCH, "score_fwd_bwd: memset failed");
         return SNAG_OK;
     }
@@ -249,10 +249,10 @@ extern "C" SNAG_API int snag_score_margin_fwd_bwd_bf16(const uint16_t* ent, int6
                                                        int64_t batch, int n_neg, float margin, float grad_scale, float* pos, float* neg,
                                                        float* loss_part, float* loss, uint32_t* ticket, float* d_ent, int64_t d_ent_ld,
                                                        float* d_rel, void* stream) {
-    SNAG_REQUIRE((loss == nullptr) || (loss_part != nullptr && ticket != nullptr), SNAG_ERR_ARG,
-                 "score_fwd_bwd_bf16: the summed loss needs loss_part and a ticket buffer");
     hipStream_t st = (hipStream_t)stream;
-    if (batch == 0) {
+    SNAG_REQUIRE(batch == 0 || (loss == nullptr) || (loss_part != nullptr && ticket != nullptr), SNAG_ERR_ARG,
+                 "score_fwd_bwd_bf16: the summed loss needs loss_part and a ticket buffer");
+    if (batch == 0) {           // nothing to score: the summed loss is zero, the gradients are untouched
         if (loss != nullptr) return hipMemsetAsync(loss, 0, sizeof(float), st) == hipSuccess ? SNAG_OK : fail(SNAG_ERR_LAUNCH, "score_fwd_bwd_bf16: memset failed");
         return SNAG_OK;
     }

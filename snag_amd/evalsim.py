@@ -86,6 +86,8 @@ def rank_metrics(emb_left, emb_right, csls_k=0, top_k=(1, 10, 50), distance=2):
     n, m = dist.shape
     if n != m:
         raise ValueError("rank_metrics: left and right must hold the same number of aligned rows")
+    if n == 0:          # (the reference divides by len(test_left), main.py:435: Hits over nothing are undefined)
+        raise ValueError("rank_metrics: no aligned test pairs")
     dev = dist.device
     r1 = r2 = None
     if csls_k and csls_k > 0:
@@ -212,6 +214,8 @@ def link_prediction(ent, rel, h, r, t, filter_mask=None, top_k=(1, 10), method="
     """
     ops._rows(ent, "ent"), ops._chk(rel, "rel", ndim=2)
     B, N, dev = h.shape[0], ent.shape[0], ent.device
+    if B == 0:
+        raise ValueError("link_prediction: no query triples")
     ib = 4 if h.dtype == torch.int32 else 8
     if method == "exact":
         pos = torch.empty(B, device=dev, dtype=f32)

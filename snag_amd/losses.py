@@ -74,6 +74,8 @@ class icl_loss(nn.Module):
         links = torch.as_tensor(train_links, device=emb.device)
         if links.dtype not in (torch.int32, torch.int64):
             links = links.long()
+        if links.dim() != 2 or links.shape[0] == 0 or links.shape[1] < 2:
+            raise ValueError("icl_loss: train_links must be [B >= 1, 2] (the reference's mean over an empty batch is NaN)")
         left, right = links[:, 0].contiguous(), links[:, 1].contiguous()
         w = None
         if weight_norm is not None:                                    # :66-70 min over the pair, differentiable

@@ -56,6 +56,10 @@ def oracle_params(eng):
     # ragged everything: entity count, feature widths and hidden size that are not multiples of 4 / 64 (checked GEMM loaders, padded rows)
     (2, "Mformer_hd_graph", 0, True, torch.int32, (701, 5, 100, 33, 5, 37, 10)),
     (1, "Mformer_hd_mean", 1, False, torch.int64, (333, 3, 36, 17, 3, 13, 9)),
+    # degenerate sizes: one triple, one negative tail, one relation, a handful of entities, one-column features
+    (2, "Mformer_hd_graph", 0, True, torch.int32, (5, 1, 128, 1, 1, 9, 4)),
+    (1, "Mformer_hd_mean", 1, False, torch.int64, (3, 1, 8, 2, 1, 1, 1)),
+    (2, "Mformer_weight", 0, True, torch.int32, (2, 1, 4, 1, 1, 1, 2)),
     # BASELINE configs[1] at its full size: 15,000 entities, 4096/768-wide features, 1,024 triples x 32 negative tails
     (2, "Mformer_hd_graph", 0, True, torch.int32, (15000, 558, 128, 1024, 32, 4096, 768)),
     # two Mformer layers (num_hidden_layers = 2), with and without the FFN: shape tuple carries an 8th entry = layer count
