@@ -727,6 +727,21 @@ class MKGCHotPath:
         self.optimizer_step()
         return self.loss
 
+    def _check_triples(self, h, r, t):
+        """The kernels trust their indices (as a device-side embedding gather does); the training set is checked ONCE here -- one host
+        sync per distinct (buffer, length), not per step -- and refused the way an out-of-range index into nn.Embedding is."""
+        key = (h.data_ptr(), r.data_ptr(), t.data_ptr(), h.shape[0])
+        if getattr(self, "_checked_triples", None) == key or h.shape[0] == 0:
+            return
+        if not (h.shape == r.shape == t.shape and h.dim() == 1):
+            raise ValueError(f"train_epoch: h, r, t must be 1-D of equal length, got {tuple(h.shape)}, {tuple(r.shape)}, {tuple(t.shape)}")
+        ends = torch.stack([h.min(), h.max(), t.min(), t.max(), r.min(), r.max()]).tolist()
+        if ends[0] < 0 or ends[2] < 0 or max(ends[1], ends[3]) >= self.cfg.n_ent:
+            raise IndexError(f"train_epoch: entity index out of range [0, {self.cfg.n_ent}): heads {ends[0]}..{ends[1]}, tails {ends[2]}..{ends[3]}")
+        if ends[4] < 0 or ends[5] >= self.cfg.n_rel:
+            raise IndexError(f"train_epoch: relation index out of range [0, {self.cfg.n_rel}): {ends[4]}..{ends[5]}")
+        self._checked_triples = key
+
     def train_epoch(self, h, r, t, batch_size, known_sorted=None, allreduce=None, seed=None, rank=None, world=None):
         """One epoch in the order the README's MKGC loop implies (noise refresh once per epoch -- "noise-level: epoch" --, then every
         batch: NEG_NUM negative tails drawn on the device, forward, backward, exchange, clip, AdamW).  ``h, r, t``: this rank's int32
@@ -739,6 +754,7 @@ class MKGCHotPath:
         from . import ops
         from .parallel import common_step_count, step_bounds
         n = h.shape[0]
+        self._check_triples(h, r, t)
         dp = allreduce is not None and dist.is_available() and dist.is_initialized()
         if rank is None:
             rank = dist.get_rank() if dp else 0

@@ -389,6 +389,24 @@ def test_deterministic_mode_is_bit_reproducible_and_matches_the_default(joint_wa
     assert all(abs(x - y) <= 1e-5 * max(1.0, abs(y)) for x, y in zip(a[2], c[2]))
 
 
+def test_train_epoch_refuses_out_of_range_triples():
+    """The kernels trust their indices; train_epoch checks the training set once and raises IndexError, as nn.Embedding would."""
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    N, R = 50, 3
+    g = torch.Generator().manual_seed(2)
+    eng = MKGCHotPath(MKGCConfig(n_ent=N, n_rel=R, dim=64, feat_dims=[8, 8], neg_num=4, add_noise=0), [torch.rand(N, 8, generator=g), torch.rand(N, 8, generator=g)],
+                      device=DEV)
+    ok = lambda hi, n=20: torch.randint(0, hi, (n,), generator=g, dtype=torch.int32).to(DEV)
+    h, r, t = ok(N), ok(R), ok(N)
+    bad_t = t.clone(); bad_t[7] = N
+    bad_h = h.clone(); bad_h[0] = -1
+    bad_r = r.clone(); bad_r[3] = R
+    for args in ((h, r, bad_t), (bad_h, r, t), (h, bad_r, t)):
+        with pytest.raises(IndexError):
+            eng.train_epoch(*args, 8)
+    assert torch.isfinite(eng.train_epoch(h, r, t, 8))
+
+
 def test_train_epoch_learns_a_planted_graph():
     """train_epoch (noise refresh, on-device negative sampling with the known-triple filter, steps) + filtered link prediction:
     on triples whose tail is a function of (head, relation) the loss falls and the filtered mean rank of the training triples improves."""
