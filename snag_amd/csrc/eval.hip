@@ -344,7 +344,16 @@ static void launch_dist_gemm(const GemmOperands& p, const DistEpilogue& e, hipSt
     const int64_t big_tiles = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128);
     const bool vec = p.a_vec && p.b_vec;
     const dim3 gbig(ceil_div(p.N, 128), ceil_div(p.M, 128), 1), gsmall(ceil_div(p.N, 128), ceil_div(p.M, 64), 1);
-    if (big_tiles >= 512) {
+    // Large problems: the eight-wave row-private 256 x 128 tile (A straight to registers, B through the LDS, two wave groups half an
+    // iteration apart).  The kernel is bound by what the CUs pull in per tile ((BM + BN) K floats): 1.77 -> 1.52 ms against the
+    // 2 x 2-wave 128 x 128 tile at 10,500 x 10,500 x 1,200.  SNAG_DIST_TILE (tuning / A-B): 1 = that 128 x 128 tile, 2 = row-private 128 x 128
+    static const int tile_mode = env_int("SNAG_DIST_TILE");
+    if (tile_mode == 2 && big_tiles >= 512) {
+        hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 32, 128, true, true, true, DistEpilogue>), gbig, dim3(256), 0, st, p, e, (float*)nullptr);
+    } else if (tile_mode == 0 && big_tiles >= 1024) {
+        hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, true, true, true, DistEpilogue>), dim3(ceil_div(p.N, 128), ceil_div(p.M, 256), 1), dim3(512), 0, st, p, e,
+                           (float*)nullptr);
+    } else if (big_tiles >= 512) {
         if (vec) hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 64, 64, true, true, true, DistEpilogue>), gbig, dim3(256), 0, st, p, e, (float*)nullptr);
         else hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 64, 64, true, true, false, DistEpilogue>), gbig, dim3(256), 0, st, p, e, (float*)nullptr);
     } else {
