@@ -351,7 +351,10 @@ static void launch_dist_gemm(const GemmOperands& p, const DistEpilogue& e, hipSt
     if (tile_mode == 2 && big_tiles >= 512) {
         hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 32, 128, true, true, true, DistEpilogue>), gbig, dim3(256), 0, st, p, e, (float*)nullptr);
     } else if (tile_mode == 0 && big_tiles >= 1024) {
-        hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, true, true, true, DistEpilogue>), dim3(ceil_div(p.N, 128), ceil_div(p.M, 256), 1), dim3(512), 0, st, p, e,
+        static const int group_env = env_int("SNAG_DIST_GROUP");       // tuning: row tiles per group (default 4; -1 = row-major order)
+        GemmOperands pg = p;
+        pg.xcd = 1 | ((group_env < 0 ? 0 : group_env == 0 ? 4 : group_env) << 4);
+        hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, true, true, true, DistEpilogue>), dim3(ceil_div(p.N, 128), ceil_div(p.M, 256), 1), dim3(512), 0, st, pg, e,
                            (float*)nullptr);
     } else if (big_tiles >= 512) {
         if (vec) hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 64, 64, true, true, true, DistEpilogue>), gbig, dim3(256), 0, st, p, e, (float*)nullptr);

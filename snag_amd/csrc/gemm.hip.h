@@ -102,7 +102,7 @@ struct GemmOperands {
     // the VEC kernel variant additionally needs: row-contiguous operands with a row count that is a multiple of 4
     int k_per_split;     // K range handled by one blockIdx.z (multiple of kBK); == K rounded up when no split
     int dbg;             // tuning only: nonzero = stop fetching after the first two k-tiles (compute-only ceiling)
-    int xcd;             // 1: XCD-aware workgroup -> tile mapping (xcd_swizzle)
+    int xcd;             // bit 0: XCD-aware workgroup -> tile mapping (xcd_swizzle); bits 4..: row tiles per group of the grouped order (0 = row-major)
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (observed, never relied on for correctness): ids b and b + 8 share an L2.
@@ -1047,8 +1047,18 @@ __device__ __forceinline__ void gemm_tile_body(const GemmOperands& p, const Epi&
     int bx = blockIdx.x, by = blockIdx.y;
     if (p.xcd) {
         const int id = xcd_swizzle(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
-        bx = id % gridDim.x;
-        by = id / gridDim.x;
+        const int gm = p.xcd >> 4;
+        if (gm > 0) {
+            // grouped order inside the XCD's range: gm row tiles deep, rows fastest -- the ~32 workgroups an XCD runs side by side
+            // cover gm x (32 / gm) tiles instead of 1 x 32, and (moving through K in step) share every A and B k-slab through the L2
+            const int per = gm * (int)gridDim.x, g = id / per, first = g * gm;
+            const int gsz = min((int)gridDim.y - first, gm), in = id - g * per;
+            by = first + in % gsz;
+            bx = in / gsz;
+        } else {
+            bx = id % gridDim.x;
+            by = id / gridDim.x;
+        }
     }
     const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = z * p.k_per_split;
