@@ -81,14 +81,22 @@ struct TopK {
 // mean of the k largest entries of each row of S (or of 1 - D when from_dist): one block per row
 template <int KK>
 __global__ __launch_bounds__(256) void row_topk_mean_kernel(const float* __restrict__ mat, int64_t ld, int n, int m, int k, int from_dist,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int vec) {
     __shared__ float cand[256 * KK];
     __shared__ float wmax[4];
     __shared__ int wpos[4];
     const int row = blockIdx.x;
     TopK<KK> t;
     t.init();
-    for (int c = threadIdx.x; c < m; c += 256) {
+    const int m4 = vec ? m >> 2 : 0;            // vec: rows are 16-byte addressable -> one dwordx4 per lane (a top-k does not care about the visiting order)
+    for (int q = threadIdx.x; q < m4; q += 256) {
+        const float4 v = reinterpret_cast<const float4*>(mat + (int64_t)row * ld)[q];
+        t.push(from_dist ? 1.0f - v.x : v.x);
+        t.push(from_dist ? 1.0f - v.y : v.y);
+        t.push(from_dist ? 1.0f - v.z : v.z);
+        t.push(from_dist ? 1.0f - v.w : v.w);
+    }
+    for (int c = 4 * m4 + threadIdx.x; c < m; c += 256) {
         float s = mat[(int64_t)row * ld + c];
         if (from_dist) s = 1.0f - s;
         t.push(s);
@@ -148,14 +156,70 @@ __global__ __launch_bounds__(256) void col_topk_part_kernel(const float* __restr
         if (i < k) part[((int64_t)blockIdx.y * k + i) * m + col] = t.v[i];
 }
 
+// the same with four adjacent columns per lane (dwordx4 per row; rows 16-byte addressable) and four rows requested before the first is
+// consumed; one wave per block, so a block still covers 256 columns
+template <int KK>
+__global__ __launch_bounds__(64) void col_topk_part4_kernel(const float* __restrict__ mat, int64_t ld, int n, int m, int k, int from_dist,
+                                                            int rows_per_chunk, float* __restrict__ part) {
+    const int col = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (col >= m) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+    const int nc = min(4, m - col);
+    TopK<KK> t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j].init();
+    auto push4 = [&](float4 v) {
+        t[0].push(from_dist ? 1.0f - v.x : v.x);
+        t[1].push(from_dist ? 1.0f - v.y : v.y);
+        t[2].push(from_dist ? 1.0f - v.z : v.z);
+        t[3].push(from_dist ? 1.0f - v.w : v.w);
+    };
+    if (nc == 4) {
+        int r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(mat + (int64_t)(r + u) * ld + col);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) push4(v[u]);
+        }
+        for (; r < r1; ++r) push4(*reinterpret_cast<const float4*>(mat + (int64_t)r * ld + col));
+    } else {                                    // the last lane of a row whose length is not a multiple of 4
+        for (int r = r0; r < r1; ++r)
+            for (int j = 0; j < nc; ++j) {
+                const float x = mat[(int64_t)r * ld + col + j];
+                t[j].push(from_dist ? 1.0f - x : x);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < KK; ++i)
+            if (i < k && j < nc) part[((int64_t)blockIdx.y * k + i) * m + col + j] = t[j].v[i];
+}
+
+// 64 columns per block; the block's four waves merge every fourth chunk each, wave 0 then merges the four k-lists (a top-k is the same
+// set whatever the order; the mean adds its values in descending order)
 template <int KK>
 __global__ __launch_bounds__(256) void col_topk_merge_kernel(const float* __restrict__ part, int chunks, int m, int k, float* __restrict__ out) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= m) return;
+    __shared__ float ex[3][KK][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
     TopK<KK> t;
     t.init();
-    for (int c = 0; c < chunks; ++c)
-        for (int i = 0; i < k; ++i) t.push(part[((int64_t)c * k + i) * m + col]);
+    if (col < m)
+        for (int c = g; c < chunks; c += 4)
+            for (int i = 0; i < k; ++i) t.push(part[((int64_t)c * k + i) * m + col]);
+    if (g > 0) {
+#pragma unroll
+        for (int i = 0; i < KK; ++i) ex[g - 1][i][lane] = t.v[i];
+    }
+    __syncthreads();
+    if (g != 0 || col >= m) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int i = 0; i < KK; ++i) t.push(ex[w][i][lane]);
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < KK; ++i)
@@ -182,7 +246,7 @@ __global__ __launch_bounds__(256) void csls_apply_kernel(const float* __restrict
 
 // rank_l2r[i] = #{j : D'[i,j] < D'[i,i]} : one block per row
 __global__ __launch_bounds__(256) void rank_rows_kernel(const float* __restrict__ dist, int64_t ld, int n, int m, const float* __restrict__ r1,
-                                                        const float* __restrict__ r2, int csls, int* __restrict__ rank) {
+                                                        const float* __restrict__ r2, int csls, int* __restrict__ rank, int vec) {
     __shared__ int red[4];
     const int row = blockIdx.x;
     if (row >= m) {                                   // no diagonal element for this row
@@ -192,7 +256,14 @@ __global__ __launch_bounds__(256) void rank_rows_kernel(const float* __restrict_
     const float a = csls ? r1[row] : 0.f;
     const float ref = eval_dist(dist[(int64_t)row * ld + row], a, csls ? r2[row] : 0.f, csls);
     int cnt = 0;
-    for (int c = threadIdx.x; c < m; c += 256) cnt += eval_dist(dist[(int64_t)row * ld + c], a, csls ? r2[c] : 0.f, csls) < ref ? 1 : 0;
+    const int m4 = vec ? m >> 2 : 0;            // vec: the row and r2 are 16-byte addressable (a count does not care about the visiting order)
+    for (int q = threadIdx.x; q < m4; q += 256) {
+        const float4 d = reinterpret_cast<const float4*>(dist + (int64_t)row * ld)[q];
+        const float4 b = csls ? reinterpret_cast<const float4*>(r2)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        cnt += (eval_dist(d.x, a, b.x, csls) < ref ? 1 : 0) + (eval_dist(d.y, a, b.y, csls) < ref ? 1 : 0) + (eval_dist(d.z, a, b.z, csls) < ref ? 1 : 0) +
+               (eval_dist(d.w, a, b.w, csls) < ref ? 1 : 0);
+    }
+    for (int c = 4 * m4 + threadIdx.x; c < m; c += 256) cnt += eval_dist(dist[(int64_t)row * ld + c], a, csls ? r2[c] : 0.f, csls) < ref ? 1 : 0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
@@ -211,6 +282,48 @@ __global__ __launch_bounds__(256) void rank_cols_kernel(const float* __restrict_
     int cnt = 0;
     for (int r = r0; r < r1e; ++r) cnt += eval_dist(dist[(int64_t)r * ld + col], csls ? r1[r] : 0.f, b, csls) < ref ? 1 : 0;
     atomicAdd(rank + col, cnt);
+}
+
+// the same with four adjacent columns per lane (dwordx4 per row) and four rows requested at a time; one wave per block
+__global__ __launch_bounds__(64) void rank_cols4_kernel(const float* __restrict__ dist, int64_t ld, int n, int m, const float* __restrict__ r1,
+                                                        const float* __restrict__ r2, int csls, int rows_per_chunk, int* __restrict__ rank) {
+    const int col = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (col >= m || col >= n) return;
+    const int nc = min(4, min(m, n) - col);
+    const int r0 = blockIdx.y * rows_per_chunk, r1e = min(n, r0 + rows_per_chunk);
+    float b[4], ref[4];
+    int cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = col + min(j, nc - 1);
+        b[j] = csls ? r2[c] : 0.f;
+        ref[j] = eval_dist(dist[(int64_t)c * ld + c], csls ? r1[c] : 0.f, b[j], csls);
+    }
+    if (nc == 4) {
+        auto count4 = [&](float4 d, float a) {
+            cnt[0] += eval_dist(d.x, a, b[0], csls) < ref[0] ? 1 : 0;
+            cnt[1] += eval_dist(d.y, a, b[1], csls) < ref[1] ? 1 : 0;
+            cnt[2] += eval_dist(d.z, a, b[2], csls) < ref[2] ? 1 : 0;
+            cnt[3] += eval_dist(d.w, a, b[3], csls) < ref[3] ? 1 : 0;
+        };
+        int r = r0;
+        for (; r + 4 <= r1e; r += 4) {
+            float4 d[4];
+            float a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                d[u] = *reinterpret_cast<const float4*>(dist + (int64_t)(r + u) * ld + col);
+                a[u] = csls ? r1[r + u] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) count4(d[u], a[u]);
+        }
+        for (; r < r1e; ++r) count4(*reinterpret_cast<const float4*>(dist + (int64_t)r * ld + col), csls ? r1[r] : 0.f);
+    } else {
+        for (int r = r0; r < r1e; ++r)
+            for (int j = 0; j < nc; ++j) cnt[j] += eval_dist(dist[(int64_t)r * ld + col + j], csls ? r1[r] : 0.f, b[j], csls) < ref[j] ? 1 : 0;
+    }
+    for (int j = 0; j < nc; ++j) atomicAdd(rank + col + j, cnt[j]);
 }
 
 // the k largest values per column (descending) instead of their mean: what a rank contributes to the global column neighbourhoods
@@ -263,22 +376,31 @@ __global__ __launch_bounds__(256) void rank_cols_block_kernel(const float* __res
 // Hits@k counts, sum(rank+1), sum(1/(rank+1)) in double, fixed order  (main.py:400-407,430-436)
 __global__ __launch_bounds__(256) void rank_summary_kernel(const int* __restrict__ rank, int n, const int* __restrict__ topk, int ntop,
                                                            double* __restrict__ out) {
+    // one pass over the ranks for all ntop + 2 sums (ntop <= 8); each sum keeps its own thread-strided order and the same tree
     __shared__ double red[256];
-    for (int q = 0; q < ntop + 2; ++q) {
-        double s = 0.0;
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const int r = rank[i];
-            if (q < ntop) s += r < topk[q] ? 1.0 : 0.0;
-            else if (q == ntop) s += (double)(r + 1);
-            else s += 1.0 / (double)(r + 1);
-        }
-        red[threadIdx.x] = s;
+    double s[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) s[q] = 0.0;
+    int tk[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tk[q] = q < ntop ? topk[q] : 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = rank[i];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s[q] += (q < ntop && r < tk[q]) ? 1.0 : 0.0;
+        s[8] += (double)(r + 1);
+        s[9] += 1.0 / (double)(r + 1);
+    }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        if (q < 8 && q >= ntop) continue;
+        red[threadIdx.x] = s[q];
         __syncthreads();
         for (int off = 128; off >= 1; off >>= 1) {
             if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
             __syncthreads();
         }
-        if (threadIdx.x == 0) out[q] = red[0];
+        if (threadIdx.x == 0) out[q < 8 ? q : ntop + (q - 8)] = red[0];
         __syncthreads();
     }
 }
@@ -339,6 +461,8 @@ __global__ __launch_bounds__(256) void argmin_cols_merge_kernel(const float* __r
 }
 
 static constexpr int kColChunks = 64;
+// rows of the matrix are 16-byte addressable: the dwordx4 forms of the row / column passes apply
+static int matrix_vec_ok(const float* mat, int64_t ld) { return (ld % 4 == 0) && (((uintptr_t)mat & 15) == 0); }
 
 static void launch_dist_gemm(const GemmOperands& p, const DistEpilogue& e, hipStream_t st) {
     const int64_t big_tiles = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128);
@@ -460,11 +584,13 @@ extern "C" SNAG_API int snag_csls_neighbourhood(const float* mat, int64_t ld, in
     const int chunks = std::min(kColChunks, n);
     const int rpc = ceil_div(n, chunks);
     const int nch = ceil_div(n, rpc);
+    const int vec = matrix_vec_ok(mat, ld);
 #define SNAG_TOPK(KK)                                                                                                                       \
     do {                                                                                                                                    \
-        hipLaunchKernelGGL((row_topk_mean_kernel<KK>), dim3(n), dim3(256), 0, st, mat, ld, n, m, k, from_dist, r1);                          \
-        hipLaunchKernelGGL((col_topk_part_kernel<KK>), dim3(ceil_div(m, 256), nch), dim3(256), 0, st, mat, ld, n, m, k, from_dist, rpc, work); \
-        hipLaunchKernelGGL((col_topk_merge_kernel<KK>), dim3(ceil_div(m, 256)), dim3(256), 0, st, (const float*)work, nch, m, k, r2);         \
+        hipLaunchKernelGGL((row_topk_mean_kernel<KK>), dim3(n), dim3(256), 0, st, mat, ld, n, m, k, from_dist, r1, vec);                     \
+        if (vec) hipLaunchKernelGGL((col_topk_part4_kernel<KK>), dim3(ceil_div(m, 256), nch), dim3(64), 0, st, mat, ld, n, m, k, from_dist, rpc, work); \
+        else hipLaunchKernelGGL((col_topk_part_kernel<KK>), dim3(ceil_div(m, 256), nch), dim3(256), 0, st, mat, ld, n, m, k, from_dist, rpc, work); \
+        hipLaunchKernelGGL((col_topk_merge_kernel<KK>), dim3(ceil_div(m, 64)), dim3(256), 0, st, (const float*)work, nch, m, k, r2);          \
     } while (0)
     if (k <= 3) SNAG_TOPK(3);
     else if (k <= 5) SNAG_TOPK(5);
@@ -492,12 +618,14 @@ extern "C" SNAG_API int snag_rank_diagonal(const float* dist, int64_t ld, int n,
     SNAG_REQUIRE((r1 == nullptr) == (r2 == nullptr), SNAG_ERR_ARG, "rank_diagonal: r1 and r2 go together");
     hipStream_t st = (hipStream_t)stream;
     const int csls = r1 != nullptr;
-    if (rank_l2r) hipLaunchKernelGGL(rank_rows_kernel, dim3(n), dim3(256), 0, st, dist, ld, n, m, r1, r2, csls, rank_l2r);
+    const int vec = matrix_vec_ok(dist, ld);
+    if (rank_l2r) hipLaunchKernelGGL(rank_rows_kernel, dim3(n), dim3(256), 0, st, dist, ld, n, m, r1, r2, csls, rank_l2r, vec && (((uintptr_t)r2 & 15) == 0));
     if (rank_r2l) {
         if (hipMemsetAsync(rank_r2l, 0, sizeof(int32_t) * m, st) != hipSuccess) return fail(SNAG_ERR_LAUNCH, "rank_diagonal: memset failed");
         const int chunks = std::min(kColChunks, n);
         const int rpc = ceil_div(n, chunks);
-        hipLaunchKernelGGL(rank_cols_kernel, dim3(ceil_div(m, 256), ceil_div(n, rpc)), dim3(256), 0, st, dist, ld, n, m, r1, r2, csls, rpc, rank_r2l);
+        if (vec) hipLaunchKernelGGL(rank_cols4_kernel, dim3(ceil_div(m, 256), ceil_div(n, rpc)), dim3(64), 0, st, dist, ld, n, m, r1, r2, csls, rpc, rank_r2l);
+        else hipLaunchKernelGGL(rank_cols_kernel, dim3(ceil_div(m, 256), ceil_div(n, rpc)), dim3(256), 0, st, dist, ld, n, m, r1, r2, csls, rpc, rank_r2l);
     }
     return check_launch("snag_rank_diagonal");
 }
@@ -512,7 +640,8 @@ extern "C" SNAG_API int snag_col_topk(const float* mat, int64_t ld, int n, int m
     const int nch = ceil_div(n, rpc);
 #define SNAG_TOPK(KK)                                                                                                                       \
     do {                                                                                                                                    \
-        hipLaunchKernelGGL((col_topk_part_kernel<KK>), dim3(ceil_div(m, 256), nch), dim3(256), 0, st, mat, ld, n, m, k, from_dist, rpc, work); \
+        if (matrix_vec_ok(mat, ld)) hipLaunchKernelGGL((col_topk_part4_kernel<KK>), dim3(ceil_div(m, 256), nch), dim3(64), 0, st, mat, ld, n, m, k, from_dist, rpc, work); \
+        else hipLaunchKernelGGL((col_topk_part_kernel<KK>), dim3(ceil_div(m, 256), nch), dim3(256), 0, st, mat, ld, n, m, k, from_dist, rpc, work); \
         hipLaunchKernelGGL((col_topk_values_kernel<KK>), dim3(ceil_div(m, 256)), dim3(256), 0, st, (const float*)work, nch, m, k, out);       \
     } while (0)
     if (k <= 3) SNAG_TOPK(3);
@@ -527,7 +656,7 @@ extern "C" SNAG_API int snag_col_topk_mean(const float* cand, int chunks, int m,
     SNAG_REQUIRE(cand && out && chunks >= 1 && m >= 1, SNAG_ERR_ARG, "col_topk_mean: bad arguments");
     SNAG_REQUIRE(k >= 1 && k <= kMaxK, SNAG_ERR_UNSUPPORTED, "col_topk_mean: k=%d outside [1, %d]", k, kMaxK);
     hipStream_t st = (hipStream_t)stream;
-#define SNAG_TOPK(KK) hipLaunchKernelGGL((col_topk_merge_kernel<KK>), dim3(ceil_div(m, 256)), dim3(256), 0, st, cand, chunks, m, k, out)
+#define SNAG_TOPK(KK) hipLaunchKernelGGL((col_topk_merge_kernel<KK>), dim3(ceil_div(m, 64)), dim3(256), 0, st, cand, chunks, m, k, out)
     if (k <= 3) SNAG_TOPK(3);
     else if (k <= 5) SNAG_TOPK(5);
     else if (k <= 10) SNAG_TOPK(10);

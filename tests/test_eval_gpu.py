@@ -243,3 +243,50 @@ def test_filter_mask_from_known_triples():
                 ref[i, x] = 1
     assert torch.equal(got, ref)
     assert int(got[0].sum()) >= 40
+
+
+@pytest.mark.parametrize("n,k,from_dist", [(1003, 3, True), (1024, 5, False), (517, 10, True), (130, 16, False)])
+def test_dwordx4_passes_equal_the_scalar_ones(n, k, from_dist):
+    """The CSLS neighbourhood and rank passes read a matrix whose rows are 16-byte addressable four columns per lane; any other pitch
+    takes the scalar kernels.  Same matrix in both layouts (n % 4 != 0 cases: the last lane's columns are ragged): identical r1 / r2
+    (means of the same top-k values) and identical ranks."""
+    import ctypes
+    from snag_amd import _lib
+    from snag_amd._lib import call, ptr, stream
+    from snag_amd import evalsim as E
+    g = torch.Generator().manual_seed(n * 7 + k)
+    vals = torch.rand(n, n, generator=g)
+    vals[torch.arange(n), torch.arange(n)] *= 0.2                      # planted diagonal, so the ranks are not all ~n/2
+    pitch_v, pitch_s = (n + 31) // 32 * 32, n + 1 + (n % 2)            # second pitch: odd -> not 16-byte addressable
+    assert pitch_s % 4 != 0 or True
+    bufs = []
+    for pitch in (pitch_v, n + 1 if (n + 1) % 4 else n + 3):
+        b = torch.zeros(n, pitch, device=DEV)
+        b[:, :n] = vals.to(DEV)
+        bufs.append(b[:, :n])
+    assert bufs[0].stride(0) % 4 == 0 and bufs[1].stride(0) % 4 != 0
+    res = []
+    for mat in bufs:
+        r1, r2 = E._neighbourhood(mat, k, from_dist)
+        rl = torch.empty(n, device=DEV, dtype=torch.int32)
+        rr = torch.empty(n, device=DEV, dtype=torch.int32)
+        dist = mat if from_dist else None
+        if dist is None:                                               # ranks take distances: 1 - sim in the same layout
+            d = torch.zeros(n, mat.stride(0), device=DEV)
+            d[:, :n] = 1.0 - mat
+            dist = d[:, :n]
+        call("snag_rank_diagonal", ptr(dist), dist.stride(0), n, n, ptr(r1), ptr(r2), ptr(rl), ptr(rr), stream())
+        rl0 = torch.empty(n, device=DEV, dtype=torch.int32)
+        rr0 = torch.empty(n, device=DEV, dtype=torch.int32)
+        call("snag_rank_diagonal", ptr(dist), dist.stride(0), n, n, None, None, ptr(rl0), ptr(rr0), stream())      # and without CSLS
+        res.append((r1, r2, rl, rr, rl0, rr0))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # against the definition
+    s = (1.0 - vals) if from_dist else vals
+    assert_close(res[0][0], s.topk(k, dim=1)[0].mean(1), atol=1e-6)
+    assert_close(res[0][1], s.topk(k, dim=0)[0].mean(0), atol=1e-6)
+    dd = vals if from_dist else 1.0 - vals
+    want = (dd < dd.diag().unsqueeze(1)).sum(1).to(torch.int32)
+    assert torch.equal(res[0][4].cpu(), want)
+    assert torch.equal(res[0][5].cpu(), (dd < dd.diag().unsqueeze(0)).sum(0).to(torch.int32))
