@@ -268,7 +268,15 @@ __global__ __launch_bounds__(256) void rank_full_kernel(const float* __restrict_
     const float* row = scores + b * n_ent;
     const float ref = row[(int64_t)t[b]];
     int cnt = 0;
-    for (int64_t n = threadIdx.x; n < n_ent; n += 256) {
+    // rows that are 16-byte addressable: one dwordx4 of scores (and one dword of filter bytes) per lane
+    const bool vec = (n_ent & 3) == 0 && (((uintptr_t)scores) & 15) == 0 && (filter == nullptr || (((uintptr_t)filter) & 3) == 0);
+    const int64_t n4 = vec ? n_ent >> 2 : 0;
+    for (int64_t q = threadIdx.x; q < n4; q += 256) {
+        const float4 v = reinterpret_cast<const float4*>(row)[q];
+        const uchar4 f = filter != nullptr ? reinterpret_cast<const uchar4*>(filter + b * n_ent)[q] : make_uchar4(0, 0, 0, 0);
+        cnt += ((!f.x && v.x < ref) ? 1 : 0) + ((!f.y && v.y < ref) ? 1 : 0) + ((!f.z && v.z < ref) ? 1 : 0) + ((!f.w && v.w < ref) ? 1 : 0);
+    }
+    for (int64_t n = 4 * n4 + threadIdx.x; n < n_ent; n += 256) {
         const bool skip = filter != nullptr && filter[b * n_ent + n] != 0;
         cnt += (!skip && row[n] < ref) ? 1 : 0;
     }
