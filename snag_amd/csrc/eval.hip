@@ -244,6 +244,20 @@ __global__ __launch_bounds__(256) void csls_apply_kernel(const float* __restrict
     }
 }
 
+// this thread's share of #{c : D'[row, c] < ref}; vec: the row and r2 are 16-byte addressable (a count does not care about the visiting order)
+__device__ __forceinline__ int row_count_less(const float* __restrict__ row, int m, float a, const float* __restrict__ r2, int csls, float ref, int vec) {
+    int cnt = 0;
+    const int m4 = vec ? m >> 2 : 0;
+    for (int q = threadIdx.x; q < m4; q += 256) {
+        const float4 d = reinterpret_cast<const float4*>(row)[q];
+        const float4 b = csls ? reinterpret_cast<const float4*>(r2)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        cnt += (eval_dist(d.x, a, b.x, csls) < ref ? 1 : 0) + (eval_dist(d.y, a, b.y, csls) < ref ? 1 : 0) + (eval_dist(d.z, a, b.z, csls) < ref ? 1 : 0) +
+               (eval_dist(d.w, a, b.w, csls) < ref ? 1 : 0);
+    }
+    for (int c = 4 * m4 + threadIdx.x; c < m; c += 256) cnt += eval_dist(row[c], a, csls ? r2[c] : 0.f, csls) < ref ? 1 : 0;
+    return cnt;
+}
+
 // rank_l2r[i] = #{j : D'[i,j] < D'[i,i]} : one block per row
 __global__ __launch_bounds__(256) void rank_rows_kernel(const float* __restrict__ dist, int64_t ld, int n, int m, const float* __restrict__ r1,
                                                         const float* __restrict__ r2, int csls, int* __restrict__ rank, int vec) {
@@ -255,15 +269,7 @@ __global__ __launch_bounds__(256) void rank_rows_kernel(const float* __restrict_
     }
     const float a = csls ? r1[row] : 0.f;
     const float ref = eval_dist(dist[(int64_t)row * ld + row], a, csls ? r2[row] : 0.f, csls);
-    int cnt = 0;
-    const int m4 = vec ? m >> 2 : 0;            // vec: the row and r2 are 16-byte addressable (a count does not care about the visiting order)
-    for (int q = threadIdx.x; q < m4; q += 256) {
-        const float4 d = reinterpret_cast<const float4*>(dist + (int64_t)row * ld)[q];
-        const float4 b = csls ? reinterpret_cast<const float4*>(r2)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        cnt += (eval_dist(d.x, a, b.x, csls) < ref ? 1 : 0) + (eval_dist(d.y, a, b.y, csls) < ref ? 1 : 0) + (eval_dist(d.z, a, b.z, csls) < ref ? 1 : 0) +
-               (eval_dist(d.w, a, b.w, csls) < ref ? 1 : 0);
-    }
-    for (int c = 4 * m4 + threadIdx.x; c < m; c += 256) cnt += eval_dist(dist[(int64_t)row * ld + c], a, csls ? r2[c] : 0.f, csls) < ref ? 1 : 0;
+    int cnt = row_count_less(dist + (int64_t)row * ld, m, a, r2, csls, ref, vec);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
@@ -285,11 +291,15 @@ __global__ __launch_bounds__(256) void rank_cols_kernel(const float* __restrict_
 }
 
 // the same with four adjacent columns per lane (dwordx4 per row) and four rows requested at a time; one wave per block
+// (DIAG: the reference values come gathered in diag[] -- the row-sharded evaluation, where the diagonal element of a column lives on another rank)
+template <bool DIAG>
 __global__ __launch_bounds__(64) void rank_cols4_kernel(const float* __restrict__ dist, int64_t ld, int n, int m, const float* __restrict__ r1,
-                                                        const float* __restrict__ r2, int csls, int rows_per_chunk, int* __restrict__ rank) {
+                                                        const float* __restrict__ r2, int csls, const float* __restrict__ diag, int rows_per_chunk,
+                                                        int* __restrict__ rank) {
     const int col = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (col >= m || col >= n) return;
-    const int nc = min(4, min(m, n) - col);
+    const int ncols = DIAG ? m : min(m, n);
+    if (col >= ncols) return;
+    const int nc = min(4, ncols - col);
     const int r0 = blockIdx.y * rows_per_chunk, r1e = min(n, r0 + rows_per_chunk);
     float b[4], ref[4];
     int cnt[4] = {0, 0, 0, 0};
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(64) void rank_cols4_kernel(const float* __restrict_
     for (int j = 0; j < 4; ++j) {
         const int c = col + min(j, nc - 1);
         b[j] = csls ? r2[c] : 0.f;
-        ref[j] = eval_dist(dist[(int64_t)c * ld + c], csls ? r1[c] : 0.f, b[j], csls);
+        ref[j] = DIAG ? diag[c] : eval_dist(dist[(int64_t)c * ld + c], csls ? r1[c] : 0.f, b[j], csls);
     }
     if (nc == 4) {
         auto count4 = [&](float4 d, float a) {
@@ -344,13 +354,12 @@ __global__ __launch_bounds__(256) void col_topk_values_kernel(const float* __res
 // rank_l2r of its rows and the CSLS-adjusted diagonal values D'[row0+i, row0+i] ...
 __global__ __launch_bounds__(256) void rank_rows_block_kernel(const float* __restrict__ dist, int64_t ld, int n, int m, int row0,
                                                               const float* __restrict__ r1, const float* __restrict__ r2, int csls,
-                                                              int* __restrict__ rank, float* __restrict__ diag) {
+                                                              int* __restrict__ rank, float* __restrict__ diag, int vec) {
     __shared__ int red[4];
     const int row = blockIdx.x, dcol = row0 + row;
     const float a = csls ? r1[row] : 0.f;
     const float ref = eval_dist(dist[(int64_t)row * ld + dcol], a, csls ? r2[dcol] : 0.f, csls);
-    int cnt = 0;
-    for (int c = threadIdx.x; c < m; c += 256) cnt += eval_dist(dist[(int64_t)row * ld + c], a, csls ? r2[c] : 0.f, csls) < ref ? 1 : 0;
+    int cnt = row_count_less(dist + (int64_t)row * ld, m, a, r2, csls, ref, vec);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
@@ -624,7 +633,7 @@ extern "C" SNAG_API int snag_rank_diagonal(const float* dist, int64_t ld, int n,
         if (hipMemsetAsync(rank_r2l, 0, sizeof(int32_t) * m, st) != hipSuccess) return fail(SNAG_ERR_LAUNCH, "rank_diagonal: memset failed");
         const int chunks = std::min(kColChunks, n);
         const int rpc = ceil_div(n, chunks);
-        if (vec) hipLaunchKernelGGL(rank_cols4_kernel, dim3(ceil_div(m, 256), ceil_div(n, rpc)), dim3(64), 0, st, dist, ld, n, m, r1, r2, csls, rpc, rank_r2l);
+        if (vec) hipLaunchKernelGGL(rank_cols4_kernel<false>, dim3(ceil_div(m, 256), ceil_div(n, rpc)), dim3(64), 0, st, dist, ld, n, m, r1, r2, csls, (const float*)nullptr, rpc, rank_r2l);
         else hipLaunchKernelGGL(rank_cols_kernel, dim3(ceil_div(m, 256), ceil_div(n, rpc)), dim3(256), 0, st, dist, ld, n, m, r1, r2, csls, rpc, rank_r2l);
     }
     return check_launch("snag_rank_diagonal");
@@ -671,7 +680,8 @@ extern "C" SNAG_API int snag_rank_rows_block(const float* dist, int64_t ld, int 
                  row0 + n, m);
     SNAG_REQUIRE(dist && rank && diag, SNAG_ERR_ARG, "rank_rows_block: null pointer");
     SNAG_REQUIRE((r1 == nullptr) == (r2 == nullptr), SNAG_ERR_ARG, "rank_rows_block: r1 and r2 go together");
-    hipLaunchKernelGGL(rank_rows_block_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, dist, ld, n, m, row0, r1, r2, r1 != nullptr, rank, diag);
+    hipLaunchKernelGGL(rank_rows_block_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, dist, ld, n, m, row0, r1, r2, r1 != nullptr, rank, diag,
+                       matrix_vec_ok(dist, ld) && (((uintptr_t)r2 & 15) == 0));
     return check_launch("snag_rank_rows_block");
 }
 
@@ -684,8 +694,11 @@ extern "C" SNAG_API int snag_rank_cols_block(const float* dist, int64_t ld, int 
     if (hipMemsetAsync(count, 0, sizeof(int32_t) * m, st) != hipSuccess) return fail(SNAG_ERR_LAUNCH, "rank_cols_block: memset failed");
     const int chunks = std::min(kColChunks, n);
     const int rpc = ceil_div(n, chunks);
-    hipLaunchKernelGGL(rank_cols_block_kernel, dim3(ceil_div(m, 256), ceil_div(n, rpc)), dim3(256), 0, st, dist, ld, n, m, r1, r2, r1 != nullptr, diag, rpc,
-                       count);
+    if (matrix_vec_ok(dist, ld))
+        hipLaunchKernelGGL(rank_cols4_kernel<true>, dim3(ceil_div(m, 256), ceil_div(n, rpc)), dim3(64), 0, st, dist, ld, n, m, r1, r2, r1 != nullptr, diag, rpc, count);
+    else
+        hipLaunchKernelGGL(rank_cols_block_kernel, dim3(ceil_div(m, 256), ceil_div(n, rpc)), dim3(256), 0, st, dist, ld, n, m, r1, r2, r1 != nullptr, diag, rpc,
+                           count);
     return check_launch("snag_rank_cols_block");
 }
 

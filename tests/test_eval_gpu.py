@@ -257,10 +257,8 @@ def test_dwordx4_passes_equal_the_scalar_ones(n, k, from_dist):
     g = torch.Generator().manual_seed(n * 7 + k)
     vals = torch.rand(n, n, generator=g)
     vals[torch.arange(n), torch.arange(n)] *= 0.2                      # planted diagonal, so the ranks are not all ~n/2
-    pitch_v, pitch_s = (n + 31) // 32 * 32, n + 1 + (n % 2)            # second pitch: odd -> not 16-byte addressable
-    assert pitch_s % 4 != 0 or True
     bufs = []
-    for pitch in (pitch_v, n + 1 if (n + 1) % 4 else n + 3):
+    for pitch in ((n + 31) // 32 * 32, n + 1 if (n + 1) % 4 else n + 3):     # second pitch: rows not 16-byte addressable
         b = torch.zeros(n, pitch, device=DEV)
         b[:, :n] = vals.to(DEV)
         bufs.append(b[:, :n])
@@ -279,6 +277,13 @@ def test_dwordx4_passes_equal_the_scalar_ones(n, k, from_dist):
         rl0 = torch.empty(n, device=DEV, dtype=torch.int32)
         rr0 = torch.empty(n, device=DEV, dtype=torch.int32)
         call("snag_rank_diagonal", ptr(dist), dist.stride(0), n, n, None, None, ptr(rl0), ptr(rr0), stream())      # and without CSLS
+        # the row-sharded entries on the whole matrix as one shard: the same ranks
+        rb = torch.empty(n, device=DEV, dtype=torch.int32)
+        diag = torch.empty(n, device=DEV)
+        cb = torch.empty(n, device=DEV, dtype=torch.int32)
+        call("snag_rank_rows_block", ptr(dist), dist.stride(0), n, n, 0, ptr(r1), ptr(r2), ptr(rb), ptr(diag), stream())
+        call("snag_rank_cols_block", ptr(dist), dist.stride(0), n, n, ptr(r1), ptr(r2), ptr(diag), ptr(cb), stream())
+        assert torch.equal(rb, rl) and torch.equal(cb, rr)
         res.append((r1, r2, rl, rr, rl0, rr0))
     for a, b in zip(*res):
         assert torch.equal(a, b)
