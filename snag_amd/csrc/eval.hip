@@ -415,15 +415,23 @@ __global__ __launch_bounds__(256) void rank_summary_kernel(const int* __restrict
 }
 
 // ---- arg-min per row / per column (Iter_new_links, model/SNAG.py:200-201); ties -> smallest index ----
-__global__ __launch_bounds__(256) void argmin_rows_kernel(const float* __restrict__ dist, int64_t ld, int n, int m, int* __restrict__ out) {
+__global__ __launch_bounds__(256) void argmin_rows_kernel(const float* __restrict__ dist, int64_t ld, int n, int m, int* __restrict__ out, int vec) {
     __shared__ float bv[4];
     __shared__ int bi[4];
     const int row = blockIdx.x;
     float best = INFINITY;
     int pos = 0x7fffffff;
-    for (int c = threadIdx.x; c < m; c += 256) {
+    const int m4 = vec ? m >> 2 : 0;            // vec: 16-byte addressable rows; a thread still meets its columns in ascending order
+    for (int q = threadIdx.x; q < m4; q += 256) {
+        const float4 v = reinterpret_cast<const float4*>(dist + (int64_t)row * ld)[q];
+        if (v.x < best) { best = v.x; pos = 4 * q; }
+        if (v.y < best) { best = v.y; pos = 4 * q + 1; }
+        if (v.z < best) { best = v.z; pos = 4 * q + 2; }
+        if (v.w < best) { best = v.w; pos = 4 * q + 3; }
+    }
+    for (int c = 4 * m4 + threadIdx.x; c < m; c += 256) {
         const float v = dist[(int64_t)row * ld + c];
-        if (v < best) { best = v; pos = c; }
+        if (v < best || (v == best && c < pos)) { best = v; pos = c; }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -453,6 +461,44 @@ __global__ __launch_bounds__(256) void argmin_cols_part_kernel(const float* __re
     }
     pv[(int64_t)blockIdx.y * m + col] = best;
     pi[(int64_t)blockIdx.y * m + col] = pos;
+}
+
+// four adjacent columns per lane (dwordx4 per row, four rows requested at a time); one wave per block; rows ascending, so the first of equals stays
+__global__ __launch_bounds__(64) void argmin_cols_part4_kernel(const float* __restrict__ dist, int64_t ld, int n, int m, int rows_per_chunk,
+                                                               float* __restrict__ pv, int* __restrict__ pi) {
+    const int col = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (col >= m) return;
+    const int nc = min(4, m - col);
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+    float best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int pos[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    if (nc == 4) {
+        auto take = [&](float4 v, int r) {
+            if (v.x < best[0]) { best[0] = v.x; pos[0] = r; }
+            if (v.y < best[1]) { best[1] = v.y; pos[1] = r; }
+            if (v.z < best[2]) { best[2] = v.z; pos[2] = r; }
+            if (v.w < best[3]) { best[3] = v.w; pos[3] = r; }
+        };
+        int r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(dist + (int64_t)(r + u) * ld + col);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) take(v[u], r + u);
+        }
+        for (; r < r1; ++r) take(*reinterpret_cast<const float4*>(dist + (int64_t)r * ld + col), r);
+    } else {
+        for (int r = r0; r < r1; ++r)
+            for (int j = 0; j < nc; ++j) {
+                const float v = dist[(int64_t)r * ld + col + j];
+                if (v < best[j]) { best[j] = v; pos[j] = r; }
+            }
+    }
+    for (int j = 0; j < nc; ++j) {
+        pv[(int64_t)blockIdx.y * m + col + j] = best[j];
+        pi[(int64_t)blockIdx.y * m + col + j] = pos[j];
+    }
 }
 
 __global__ __launch_bounds__(256) void argmin_cols_merge_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int chunks, int m,
@@ -712,7 +758,8 @@ extern "C" SNAG_API int snag_argmin_rows_cols(const float* dist, int64_t ld, int
                                               void* stream) {
     SNAG_REQUIRE(n >= 1 && m >= 1 && ld >= m && dist, SNAG_ERR_ARG, "argmin: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (row_argmin) hipLaunchKernelGGL(argmin_rows_kernel, dim3(n), dim3(256), 0, st, dist, ld, n, m, row_argmin);
+    const int vec = matrix_vec_ok(dist, ld);
+    if (row_argmin) hipLaunchKernelGGL(argmin_rows_kernel, dim3(n), dim3(256), 0, st, dist, ld, n, m, row_argmin, vec);
     if (col_argmin) {
         SNAG_REQUIRE(work != nullptr, SNAG_ERR_ARG, "argmin: column arg-min needs the work buffer");
         const int chunks = std::min(kColChunks, n);
@@ -720,7 +767,8 @@ extern "C" SNAG_API int snag_argmin_rows_cols(const float* dist, int64_t ld, int
         const int nch = ceil_div(n, rpc);
         float* pv = work;
         int* pi = reinterpret_cast<int*>(work + (int64_t)kColChunks * m);
-        hipLaunchKernelGGL(argmin_cols_part_kernel, dim3(ceil_div(m, 256), nch), dim3(256), 0, st, dist, ld, n, m, rpc, pv, pi);
+        if (vec) hipLaunchKernelGGL(argmin_cols_part4_kernel, dim3(ceil_div(m, 256), nch), dim3(64), 0, st, dist, ld, n, m, rpc, pv, pi);
+        else hipLaunchKernelGGL(argmin_cols_part_kernel, dim3(ceil_div(m, 256), nch), dim3(256), 0, st, dist, ld, n, m, rpc, pv, pi);
         hipLaunchKernelGGL(argmin_cols_merge_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, st, (const float*)pv, (const int*)pi, nch, m, col_argmin);
     }
     return check_launch("snag_argmin_rows_cols");

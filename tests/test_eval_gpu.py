@@ -295,3 +295,26 @@ def test_dwordx4_passes_equal_the_scalar_ones(n, k, from_dist):
     want = (dd < dd.diag().unsqueeze(1)).sum(1).to(torch.int32)
     assert torch.equal(res[0][4].cpu(), want)
     assert torch.equal(res[0][5].cpu(), (dd < dd.diag().unsqueeze(0)).sum(0).to(torch.int32))
+
+
+@pytest.mark.parametrize("n,m", [(1003, 517), (512, 1024), (130, 131)])
+def test_argmin_passes_in_both_layouts_with_ties(n, m):
+    """snag_argmin_rows_cols on 16-byte addressable rows (dwordx4 kernels) and on an odd pitch (scalar kernels): the same arg-mins, and
+    among equal minima the smallest index (numpy's first occurrence) -- values quantised to 1/64 so that ties are everywhere."""
+    from snag_amd import _lib
+    from snag_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(n + 3 * m)
+    vals = torch.floor(torch.rand(n, m, generator=g) * 64) / 64
+    outs = []
+    for pitch in ((m + 31) // 32 * 32, m + 1 if (m + 1) % 4 else m + 3):
+        b = torch.zeros(n, pitch, device=DEV)
+        b[:, :m] = vals.to(DEV)
+        mat = b[:, :m]
+        pl = torch.empty(n, device=DEV, dtype=torch.int32)
+        pr = torch.empty(m, device=DEV, dtype=torch.int32)
+        work = torch.empty(_lib.load().snag_eval_work_floats(n, m), device=DEV)
+        call("snag_argmin_rows_cols", ptr(mat), mat.stride(0), n, m, ptr(pl), ptr(pr), ptr(work), stream())
+        outs.append((pl.cpu().numpy(), pr.cpu().numpy()))
+    v = vals.numpy()
+    for pl, pr in outs:
+        assert np.array_equal(pl, v.argmin(1)) and np.array_equal(pr, v.argmin(0))
