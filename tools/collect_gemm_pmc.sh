@@ -1,13 +1,16 @@
 #!/bin/bash
-# PMC evidence for the dominant GEMM launch (separate passes, kernel-trace free as the pool requires): MFMA busy cycles vs active
-# cycles, LDS bank conflicts.  Writes gpurun_out/gemm_pmc.txt.
+# PMC evidence for a GEMM launch (separate passes, kernel-trace free as the pool requires): MFMA busy cycles vs active cycles, LDS
+# bank conflicts, VALU / LDS / wait counters.  Writes gpurun_out/gemm_pmc.txt.
+#   tools/collect_gemm_pmc.sh                     the dominant projection GEMM ([15000,4096] x [4096,128], tools/one_shape.py)
+#   tools/collect_gemm_pmc.sh tools/probe_eval.py the similarity GEMM of configs[3] (10,500 x 10,500 x 1,200)
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/gemm_pmc
 rm -rf $O && mkdir -p $O
+if [ $# -ge 1 ]; then CMD="$*"; else CMD="tools/one_shape.py 4096 15000 128"; fi
 for c in ${PMC_LIST:-SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INST_CYCLES_VMEM}; do
-  rocprofv3 --pmc $c --output-format csv -d $O/$c -- python3 tools/one_shape.py 4096 15000 128 > $O/$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/$c -- python3 $CMD > $O/$c.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections, os
