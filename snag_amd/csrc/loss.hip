@@ -103,7 +103,27 @@ __global__ __launch_bounds__(256) void infonce_grad_kernel(float* __restrict__ S
     float* row = S + (int64_t)r * ld;
     const float cr = (r < B ? ca : cb) * (w ? w[r < B ? r : r - B] : 1.0f), lr = lse[r];
     const int tgt = r < B ? r + B : r - B;
-    for (int j = threadIdx.x; j < n; j += 256) {
+    // rows and lse 16-byte addressable, B a multiple of 4 (a quad never straddles the two halves): one dwordx4 per lane
+    const bool vec = (ld & 3) == 0 && (B & 3) == 0 && ((((uintptr_t)S) | ((uintptr_t)lse) | ((uintptr_t)w)) & 15) == 0;
+    const int n4 = vec ? n >> 2 : 0;
+    for (int q = threadIdx.x; q < n4; q += 256) {
+        const int j0 = 4 * q;
+        const float4 x4 = reinterpret_cast<const float4*>(row)[q], l4 = reinterpret_cast<const float4*>(lse)[q];
+        const float4 w4 = w ? reinterpret_cast<const float4*>(w)[(j0 < B ? j0 : j0 - B) >> 2] : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float cside = j0 < B ? ca : cb;
+        const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ls[4] = {l4.x, l4.y, l4.z, l4.w}, ws[4] = {w4.x, w4.y, w4.z, w4.w};
+        float gs[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = j0 + e;
+            const float cj = cside * ws[e];
+            float g = cr * __expf(xs[e] - lr) + cj * __expf(xs[e] - ls[e]);
+            if (j == tgt) g -= cr + cj;
+            gs[e] = (j == r) ? 0.f : g;
+        }
+        reinterpret_cast<float4*>(row)[q] = make_float4(gs[0], gs[1], gs[2], gs[3]);
+    }
+    for (int j = 4 * n4 + threadIdx.x; j < n; j += 256) {
         const float cj = (j < B ? ca : cb) * (w ? w[j < B ? j : j - B] : 1.0f);
         const float x = row[j];
         float g = cr * __expf(x - lr) + cj * __expf(x - lse[j]);

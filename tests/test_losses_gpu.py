@@ -60,3 +60,24 @@ def test_multi_loss_layer_matches_golden():
     assert_close(tot, z["ml.total"], atol=1e-6)
     tot.backward()
     assert_close(ml.log_vars.grad, z["ml.g.log_vars"], atol=1e-6)
+
+
+@pytest.mark.parametrize("B,weighted", [(8, True), (64, False), (132, True)])
+def test_infonce_grad_dwordx4_rows_equal_scalar_rows(B, weighted):
+    """snag_infonce_grad transforms the logits in place one dwordx4 per lane when rows, lse and weights are 16-byte addressable and B is
+    a multiple of 4; any other layout goes element by element.  Same numbers in both layouts -> identical output."""
+    from snag_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(B)
+    n = 2 * B
+    logits = torch.randn(n, n, generator=g) * 3
+    lse = torch.logsumexp(logits, dim=1).to("cuda")
+    w = torch.rand(B, generator=g).to("cuda") if weighted else None
+    outs = []
+    for pitch in (n + 32 - n % 32, n + 1):
+        buf = torch.zeros(n, pitch, device="cuda")
+        buf[:, :n] = logits.to("cuda")
+        S = buf[:, :n]
+        call("snag_infonce_grad", ptr(S), S.stride(0), B, ptr(lse), ptr(w), 0.3 / B, 0.7 / B, None, stream())
+        outs.append(S.clone())
+    assert outs[0].stride(0) == n and torch.equal(outs[0], outs[1])
+    assert float(outs[0].diagonal().abs().max()) == 0.0
