@@ -363,6 +363,10 @@ SNAG_API int snag_gaussian_fill(uint64_t seed, int64_t N, int F, const float* me
  *   snag_entity_token_fwd is the forward blend written straight into a token slot (row stride out_ld). */
 SNAG_API int snag_colsum(const float* x, int64_t R, int C, int64_t ld, float* out, int accumulate,
                          float* work, void* stream);
+/* Two column-sum problems of one shape in one pair of launches (the two modalities' projection bias gradients); bit-equal to two
+ * snag_colsum calls.  work: 2 x 256 x C floats. */
+SNAG_API int snag_colsum_pair(const float* x0, const float* x1, int64_t R, int C, int64_t ld, float* out0, float* out1, int accumulate,
+                              float* work, void* stream);
 /* dst [cols, rows] (row stride ld_dst) = transpose of src [rows, cols] (row stride ld_src).  The MKGC engine keeps each raw feature
  * table in both layouts so that the first projection X W^T (a5, model/SNAG_tools.py:134-150) and its weight gradient both stream
  * row-contiguous operands; the transposed copy is refreshed once per noise epoch (model/SNAG.py:86-98). */

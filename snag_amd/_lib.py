@@ -88,6 +88,7 @@ SIGNATURES = {
     "snag_dropout_keep_mask": [_U64, _P, _L, _F, _P, _P],
     "snag_gaussian_fill": [_U64, _L, _I, _P, _P, _P, _P],
     "snag_colsum": [_P, _L, _I, _L, _P, _I, _P, _P],
+    "snag_colsum_pair": [_P, _P, _L, _I, _L, _P, _P, _I, _P, _P],
     "snag_token_mean_bwd": [_P, _L, _I, _I, _P, _I, _P],
     "snag_entity_token_bwd": [_P, _L, _L, _I, _P, _F, _P, _I, _P],
     "snag_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _P, _F, _P],

@@ -419,6 +419,52 @@ extern "C" SNAG_API int snag_colsum(const float* x, int64_t R, int C, int64_t ld
 }
 
 namespace snag {
+// two column-sum problems of one shape in one pair of launches (the two modalities' projection bias gradients): blockIdx.z = problem
+__global__ __launch_bounds__(256) void colsum_part_pair_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int64_t R, int C, int64_t ld,
+                                                               float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const float* x = blockIdx.z ? x1 : x0;
+    const int lane = threadIdx.x & 63, wave = wave_id_uniform();
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < C)
+        for (int64_t r = (int64_t)blockIdx.y * 4 + wave; r < R; r += (int64_t)gridDim.y * 4) s += x[r * ld + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < C)
+        part[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+__global__ __launch_bounds__(1024) void slab_colsum_pair_kernel(const float* __restrict__ part, int nblocks, int ncol, float* __restrict__ out0,
+                                                                float* __restrict__ out1, int accumulate) {
+    __shared__ float red[16][64];
+    part += (int64_t)blockIdx.y * nblocks * ncol;
+    float* out = blockIdx.y ? out1 : out0;
+    const int lane = threadIdx.x & 63, wave = wave_id_uniform();
+    const int c = blockIdx.x * 64 + lane;
+    const int per = (nblocks + 15) / 16;
+    const int b0 = wave * per, b1 = min(nblocks, b0 + per);
+    float s = 0.f;
+    if (c < ncol) {              // the order of slab_colsum_kernel: sixteen runs of consecutive blocks, then the runs in wave order
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = part[(int64_t)(b + u) * ncol + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; b < b1; ++b) s += part[(int64_t)b * ncol + c];
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < ncol) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w][lane];
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+
 // dst[c, r] = src[r, c]: 64 x 64 tiles through LDS (pitch 65: conflict-free both ways), 256-byte runs on both sides.
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int64_t ld_src, int64_t R, int64_t C,
                                                         float* __restrict__ dst, int64_t ld_dst) {
@@ -432,6 +478,17 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
         if (c0 + i < C && r0 + tx < R) dst[(c0 + i) * ld_dst + r0 + tx] = tile[tx][i];
 }
 }  // namespace snag
+
+// two problems of one shape (R, C, ld) in one pair of launches; results bit-equal to two snag_colsum calls.  work: 2 x 256 x C floats
+extern "C" SNAG_API int snag_colsum_pair(const float* x0, const float* x1, int64_t R, int C, int64_t ld, float* out0, float* out1, int accumulate, float* work,
+                                         void* stream) {
+    SNAG_REQUIRE(((x0 && x1) || R == 0) && out0 && out1 && work && R >= 0 && C >= 1 && ld >= C, SNAG_ERR_ARG, "colsum_pair: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int by = (int)std::max<int64_t>(1, std::min<int64_t>(256, (R + 3) / 4));
+    hipLaunchKernelGGL(colsum_part_pair_kernel, dim3(ceil_div(C, 64), by, 2), dim3(256), 0, st, x0, x1, R, C, ld, work);
+    hipLaunchKernelGGL(slab_colsum_pair_kernel, dim3(ceil_div(C, 64), 2), dim3(1024), 0, st, (const float*)work, by, C, out0, out1, accumulate);
+    return check_launch("snag_colsum_pair");
+}
 
 extern "C" SNAG_API int snag_transpose_f32(const float* src, int64_t ld_src, int64_t rows, int64_t cols, float* dst, int64_t ld_dst, void* stream) {
     SNAG_REQUIRE(rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= rows, SNAG_ERR_ARG, "transpose: bad sizes");

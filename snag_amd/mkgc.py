@@ -231,7 +231,7 @@ class MKGCHotPath:
         ws = lib.snag_fusion_work_floats(Nl, M, D, cfg.num_heads, I, L, int(ffn))
         for fd in cfg.feat_dims:
             # (the first projections and their weight gradients run two modalities at a time, each in its own half of the scratch)
-            ws = max(ws, 2 * (lib.snag_gemm_workspace_floats(fd, D, Nl) + 64), 2 * (lib.snag_gemm_workspace_floats(Nl, D, fd) + 64), 256 * max(D, fd))
+            ws = max(ws, 2 * (lib.snag_gemm_workspace_floats(fd, D, Nl) + 64), 2 * (lib.snag_gemm_workspace_floats(Nl, D, fd) + 64), 256 * max(2 * D, fd))
         ws = max(ws, 2 * (lib.snag_gemm_workspace_floats(D, D, Nl) + 64), lib.snag_gemm_workspace_floats(Nl, D, D) + 64)
         self.work = torch.empty(ws, device=dev)
         # the second projections' weight gradients keep their K-split slabs here until the first projections' reduce launch takes them along
@@ -689,10 +689,13 @@ class MKGCHotPath:
             call("snag_gemm_reduce_group", group, 4, st)
         elif reducer is None:       # weight gradients of the first projections: two kernels, ONE reduce launch per pair of modalities
             self._gemm_deferred_pairs(dl1)
+        bias_pair = cfg.num_proj == 1 and reducer is None and nmod == 2
+        if bias_pair:       # db = colsum(dTok) of both modalities in one pair of launches
+            call("snag_colsum_pair", dx0, dx0 + 4 * D, Nl, D, MD, ptr(self.g["proj0.bias"]), ptr(self.g["proj1.bias"]), 0, wk, st)
         for i, fd in enumerate(cfg.feat_dims):
             if reducer is not None:         # data parallel: each modality's bucket goes out as soon as its gradient is final
                 call("snag_gemm_f32", ctypes.byref(dl1[i]), st)
-            if cfg.num_proj == 1:
+            if cfg.num_proj == 1 and not bias_pair:
                 call("snag_colsum", dx0 + 4 * i * D, Nl, D, MD, ptr(self.g[f"proj{i}.bias"]), 0, wk, st)
             if reducer is not None:
                 reducer.start(buckets[2 + i])
