@@ -122,3 +122,28 @@ def test_transpose_kernel(R, C, pad):
     call("snag_transpose_f32", ptr(src), src.stride(0), R, C, ptr(dst), dst.stride(0), stream())
     assert torch.equal(dst[:, :R], src.t())
     assert float((dst[:, R:] + 7.0).abs().sum()) == 0.0          # padding untouched
+
+
+@pytest.mark.parametrize("R,C,pad", [(15000, 128, 256), (1, 5, 0), (333, 300, 3), (4096, 64, 0)])
+def test_colsum_and_its_pair_form(R, C, pad):
+    """snag_colsum (nn.Linear bias gradient: column sums of a row-strided matrix, fixed-order partial sums) against an fp64 sum, with
+    accumulate; snag_colsum_pair = two such problems in one pair of launches, bit-equal to two single calls."""
+    from snag_amd import ops
+    from snag_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(R + C)
+    bufs = [torch.randn(R, C + pad, generator=g).to(DEV) for _ in range(2)]
+    xs = [b[:, :C] for b in bufs]                                     # row stride C + pad
+    work = torch.empty(2 * 256 * C, device=DEV)
+    singles = []
+    for x in xs:
+        out = torch.full((C,), 3.0, device=DEV)
+        call("snag_colsum", ptr(x), R, C, x.stride(0), ptr(out), 1, ptr(work), stream())          # accumulate onto 3
+        ref = x.double().sum(0) + 3.0
+        assert float((out.double() - ref).abs().max()) <= 1e-5 * max(1.0, R ** 0.5)
+        out0 = torch.empty(C, device=DEV)
+        call("snag_colsum", ptr(x), R, C, x.stride(0), ptr(out0), 0, ptr(work), stream())
+        singles.append(out0)
+    o0, o1 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    call("snag_colsum_pair", ptr(xs[0]), ptr(xs[1]), R, C, xs[0].stride(0), ptr(o0), ptr(o1), 0, ptr(work), stream())
+    assert torch.equal(o0, singles[0]) and torch.equal(o1, singles[1])
+    assert torch.equal(ops.colsum(xs[0].contiguous()), singles[0])
