@@ -457,9 +457,13 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     if (wide) big = false;
     // the eight-wave ping-pong form of the row-private tile (256 rows, one workgroup per CU) where the output is one tile wide, i.e.
     // A is read exactly once (the projections): DB15K step 0.651 vs 0.657 ms, MKG-W 0.727 vs 0.737; with several column tiles
-    // (MMEA: N = 300 / 1,200) the four-wave form is faster (MMEA step 20.6 vs 21.8 ms)
+    // (MMEA: N = 300 / 1,200) the four-wave form is faster (MMEA step 20.6 vs 21.8 ms; only for shapes with >= 256 / >= 1,024 tiles
+    // of 256 rows, in grouped order: 21.3 / 20.6-20.7 vs 20.2-20.6 -- SNAG_GEMM_PP_WIDE); the 10,500^2 similarity GEMM, 83 column
+    // tiles wide, does gain (eval.hip picks the tile itself)
     static const int pp_off = env_int("SNAG_GEMM_PP_OFF");
-    const bool pp = big && kBf16x != 0 && !pp_off && p.N <= 128;
+    static const int pp_wide = env_int("SNAG_GEMM_PP_WIDE");     // tuning: 256-row tiles needed for the eight-wave form when N > 128 (0 = never)
+    const int64_t tiles256 = (int64_t)ceil_div(p.M, 256) * (pn128 / 128);
+    const bool pp = big && kBf16x != 0 && !pp_off && (p.N <= 128 || (pp_wide > 0 && tiles256 >= pp_wide));
     const int64_t tall_tiles = (int64_t)ceil_div(p.M, pp ? 256 : 128) * (pn128 / 128);
     const int64_t tiles = wide ? wide_tiles : big ? (kBf16x != 0 ? tall_tiles : big_tiles) : (pm64 / 64) * (pn128 / 128);
     // split K when the output alone cannot fill 256 CUs (the dW = dY^T X shapes: tiny output, long K)
@@ -479,6 +483,7 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     // arithmetic below would otherwise divide by zero
     if (p.K == 0) splits = 1;
     pl.big = big; pl.wide = wide; pl.streamk = false; pl.pp = pp;
+    if (pp && p.N > 128 && p.xcd) p.xcd |= 4 << 4;           // several column tiles: grouped tile order (4 row tiles deep per XCD, gemm_tile_body)
     if (splits > 1 && !big && !wide && streamk_mode() != 1) {
         // blocks per CU of the split grid vs what the slowest CU gets
         const double per_cu = (double)tiles * splits / 256.0;
