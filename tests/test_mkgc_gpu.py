@@ -62,6 +62,8 @@ def oracle_params(eng):
     (2, "Mformer_weight", 0, True, torch.int32, (2, 1, 4, 1, 1, 1, 2)),
     # BASELINE configs[1] at its full size: 15,000 entities, 4096/768-wide features, 1,024 triples x 32 negative tails
     (2, "Mformer_hd_graph", 0, True, torch.int32, (15000, 558, 128, 1024, 32, 4096, 768)),
+    # BASELINE configs[2] at its full size on one GPU: MKG-W-shaped (338 relations), Mformer_hd_mean over all three tokens, one projection layer
+    (1, "Mformer_hd_mean", 0, True, torch.int32, (15000, 338, 128, 1024, 32, 4096, 768)),
     # two Mformer layers (num_hidden_layers = 2), with and without the FFN: shape tuple carries an 8th entry = layer count
     (2, "Mformer_hd_graph", 1, True, torch.int32, (400, 7, 64, 48, 8, 40, 24, 2)),
     (1, "Mformer_hd_mean", 0, False, torch.int32, (400, 7, 64, 48, 8, 40, 24, 2)),
