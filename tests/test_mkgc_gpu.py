@@ -498,3 +498,77 @@ def test_step_prologue_draws_the_sampler_stream():
     assert torch.equal(res[0][0], res[1][0]) and int(res[0][0].min()) >= 0
     assert torch.equal(res[0][3], res[1][3])
     assert res[0][1] == res[1][1] and torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("num_proj,joint_way,ffn", [(2, "Mformer_hd_graph", 0), (1, "Mformer_hd_mean", 1)])
+def test_training_trajectory_equals_oracle_autograd_plus_torch_adamw(num_proj, joint_way, ffn):
+    """Whole steps, composed: four train_step()s (forward, hinge scorer, backward, clip_grad_norm_, AdamW with the reference's parameter
+    groups) against the oracle's forward under torch autograd + torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW on the same
+    parameters, triples and negative tails (dropout off, no noise): the loss of every step and every parameter after the last one."""
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    N, R, D, B, K = 300, 7, 64, 48, 8
+    cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[40, 24], num_proj=num_proj, joint_way=joint_way, use_intermediate=ffn, intermediate_size=96,
+                     margin=6.0, neg_num=K, dropout=0.0, proj_dropout=0.0, add_noise=0, seed=5, lr=2e-3, weight_decay=0.05, clip=1.0)
+    g = torch.Generator().manual_seed(21)
+    feats = [torch.rand(N, 40, generator=g), torch.randn(N, 24, generator=g)]
+    eng = MKGCHotPath(cfg, feats, device=DEV)
+    eng.p["ent"].copy_(torch.randn(N, D, generator=g).to(DEV))
+    p, proj, fp = oracle_params(eng)                                   # leaves sharing storage with proj / fp views
+    names = [k for k, _, _ in eng.param_groups]
+    decay = [p[k] for k, _, w in eng.param_groups if w > 0]
+    plain = [p[k] for k, _, w in eng.param_groups if w == 0]
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": cfg.weight_decay}, {"params": plain, "weight_decay": 0.0}], lr=cfg.lr, eps=1e-8)
+    for step in range(4):
+        h = torch.randint(0, N, (B,), generator=g, dtype=torch.int32)
+        r = torch.randint(0, R, (B,), generator=g, dtype=torch.int32)
+        t = torch.randint(0, N, (B,), generator=g, dtype=torch.int32)
+        neg = torch.randint(0, N, (B, K), generator=g, dtype=torch.int32)
+        loss = eng.train_step(h.to(DEV), r.to(DEV), t.to(DEV), neg.to(DEV))
+        # the oracle reads the CURRENT reference parameters: rebuild its views from the leaves
+        _, proj, fp = _views(cfg, p)
+        opt.zero_grad()
+        oloss, _, _, _ = O.mkgc_forward([f for f in feats], proj, p["ent"], fp, p["rel"], h, r, t, neg, num_heads=cfg.num_heads, margin=cfg.margin,
+                                        joint_way=joint_way, use_intermediate=bool(ffn), num_layers=cfg.num_layers, loss_kind="hinge")
+        oloss.backward()
+        torch.nn.utils.clip_grad_norm_([p[k] for k in names], cfg.clip)
+        opt.step()
+        assert_close(loss, oloss.detach(), atol=1e-3, rtol=2e-5, what=f"loss of step {step}")
+    got = eng.named_parameters()
+    for k in names:
+        scale = max(1.0, float(p[k].detach().abs().max()))
+        a, b = got[k], p[k].detach()
+        if k.endswith(".bqkv"):
+            # the KEY bias has no gradient in exact arithmetic (a constant added to every key's score cancels in the softmax): both
+            # sides feed Adam rounding noise of ~1e-9, which it normalises into steps of up to lr each -- bounded, not comparable
+            D = cfg.dim
+            assert float((a[D:2 * D].cpu() - b[D:2 * D]).abs().max()) <= 4 * cfg.lr
+            keep = torch.cat([torch.arange(0, D), torch.arange(2 * D, 3 * D)])
+            a, b = a.cpu()[keep], b[keep]
+        assert_close(a, b, atol=5e-5 * scale, rtol=1e-4, what=f"parameter {k} after 4 steps")
+
+
+def _views(cfg, p):
+    """the oracle's (proj, fusion) dicts as views of the leaf parameters p (so that autograd reaches the leaves)"""
+    D = cfg.dim
+    proj = []
+    for i in range(len(cfg.feat_dims)):
+        proj.append({"weight": p[f"proj{i}.weight"], "bias": p[f"proj{i}.bias"]} if cfg.num_proj == 1 else {"l1": p[f"proj{i}.l1"], "l2": p[f"proj{i}.l2"]})
+    fp = {"weight_raw": p["weight_raw"]}
+    for l in range(cfg.num_layers):
+        pre = f"fusion_layer.{l}."
+        wqkv, bqkv = p[f"layer{l}.wqkv"], p[f"layer{l}.bqkv"]
+        for j, nm in enumerate(("query", "key", "value")):
+            fp[pre + f"attention.self.{nm}.weight"] = wqkv[j * D:(j + 1) * D]
+            fp[pre + f"attention.self.{nm}.bias"] = bqkv[j * D:(j + 1) * D]
+        fp[pre + "attention.output.dense.weight"] = p[f"layer{l}.wo"]
+        fp[pre + "attention.output.dense.bias"] = p[f"layer{l}.bo"]
+        fp[pre + "attention.output.LayerNorm.weight"] = p[f"layer{l}.ln1_g"]
+        fp[pre + "attention.output.LayerNorm.bias"] = p[f"layer{l}.ln1_b"]
+        if cfg.use_intermediate:
+            fp[pre + "intermediate.dense.weight"] = p[f"layer{l}.w1"]
+            fp[pre + "intermediate.dense.bias"] = p[f"layer{l}.b1"]
+            fp[pre + "output.dense.weight"] = p[f"layer{l}.w2"]
+            fp[pre + "output.dense.bias"] = p[f"layer{l}.b2"]
+            fp[pre + "output.LayerNorm.weight"] = p[f"layer{l}.ln2_g"]
+            fp[pre + "output.LayerNorm.bias"] = p[f"layer{l}.ln2_b"]
+    return p, proj, fp
