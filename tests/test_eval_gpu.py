@@ -318,3 +318,25 @@ def test_argmin_passes_in_both_layouts_with_ties(n, m):
     v = vals.numpy()
     for pl, pr in outs:
         assert np.array_equal(pl, v.argmin(1)) and np.array_equal(pr, v.argmin(0))
+
+
+def test_csls_neighbourhood_fuzz_rectangular_shapes_and_pitches():
+    """snag_csls_neighbourhood on random rectangular shapes, both layouts (16-byte addressable rows or not), k up to 16, similarities and
+    distances: r1 / r2 are the means of the k largest entries of every row / column (torch.topk), whichever kernels the layout picks."""
+    from snag_amd import evalsim as E
+    g = torch.Generator().manual_seed(77)
+    for case in range(24):
+        n = int(torch.randint(1, 700, (1,), generator=g))
+        m = int(torch.randint(1, 700, (1,), generator=g))
+        k = int(torch.randint(1, min(16, n, m) + 1, (1,), generator=g))
+        from_dist = bool(case % 2)
+        pitch = m + int(torch.randint(0, 9, (1,), generator=g))
+        vals = torch.rand(n, m, generator=g)
+        if case % 3 == 0:
+            vals = torch.floor(vals * 16) / 16                          # ties
+        buf = torch.zeros(n, pitch, device=DEV)
+        buf[:, :m] = vals.to(DEV)
+        r1, r2 = E._neighbourhood(buf[:, :m], k, from_dist)
+        s = (1.0 - vals) if from_dist else vals
+        assert_close(r1, s.topk(k, dim=1)[0].mean(1), atol=2e-6, what=f"rows, case {case}: {n}x{m} k={k} pitch={pitch}")
+        assert_close(r2, s.topk(k, dim=0)[0].mean(0), atol=2e-6, what=f"columns, case {case}: {n}x{m} k={k} pitch={pitch}")
