@@ -340,3 +340,33 @@ def test_csls_neighbourhood_fuzz_rectangular_shapes_and_pitches():
         s = (1.0 - vals) if from_dist else vals
         assert_close(r1, s.topk(k, dim=1)[0].mean(1), atol=2e-6, what=f"rows, case {case}: {n}x{m} k={k} pitch={pitch}")
         assert_close(r2, s.topk(k, dim=0)[0].mean(0), atol=2e-6, what=f"columns, case {case}: {n}x{m} k={k} pitch={pitch}")
+
+
+def test_rank_diagonal_fuzz_against_the_float32_definition():
+    """snag_rank_diagonal with and without CSLS on random square matrices and pitches (ties included): the counts
+    #{j : D'[i,j] < D'[i,i]} / #{i : D'[i,j] < D'[j,j]} with D' = 1 - ((2 (1 - D) - r1) - r2) evaluated in float32 in the kernels' operation
+    order (main.py:392, utils.py:433-434) -- exact integers."""
+    from snag_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(123)
+    for case in range(16):
+        n = int(torch.randint(1, 600, (1,), generator=g))
+        pitch = n + int(torch.randint(0, 9, (1,), generator=g))
+        d = torch.rand(n, n, generator=g)
+        if case % 2:
+            d = torch.floor(d * 32) / 32
+        r1, r2 = torch.rand(n, generator=g), torch.rand(n, generator=g)
+        buf = torch.zeros(n, pitch, device=DEV)
+        buf[:, :n] = d.to(DEV)
+        mat = buf[:, :n]
+        for csls in (False, True):
+            rl = torch.empty(n, device=DEV, dtype=torch.int32)
+            rr = torch.empty(n, device=DEV, dtype=torch.int32)
+            a, b = (r1.to(DEV), r2.to(DEV)) if csls else (None, None)
+            call("snag_rank_diagonal", ptr(mat), mat.stride(0), n, n, ptr(a), ptr(b), ptr(rl), ptr(rr), stream())
+            dd = d
+            if csls:
+                s = 1.0 - d
+                dd = 1.0 - ((2.0 * s - r1[:, None]) - r2[None, :])
+            want_l = (dd < dd.diag()[:, None]).sum(1).to(torch.int32)
+            want_r = (dd < dd.diag()[None, :]).sum(0).to(torch.int32)
+            assert torch.equal(rl.cpu(), want_l) and torch.equal(rr.cpu(), want_r), f"case {case}: n={n} pitch={pitch} csls={csls}"
