@@ -370,3 +370,29 @@ def test_rank_diagonal_fuzz_against_the_float32_definition():
             want_l = (dd < dd.diag()[:, None]).sum(1).to(torch.int32)
             want_r = (dd < dd.diag()[None, :]).sum(0).to(torch.int32)
             assert torch.equal(rl.cpu(), want_l) and torch.equal(rr.cpu(), want_r), f"case {case}: n={n} pitch={pitch} csls={csls}"
+
+
+def test_rank_full_table_fuzz_with_filters():
+    """snag_rank_full_table: rank[b] = #{n not filtered : score[b, n] < score[b, t_b]} on random sizes (entity counts that are and are not
+    multiples of 4: dwordx4 rows / scalar rows), with and without a filter mask, ties included -- exact counts."""
+    from snag_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(9)
+    for case in range(16):
+        B = int(torch.randint(1, 70, (1,), generator=g))
+        N = int(torch.randint(1, 2000, (1,), generator=g))
+        if case % 2 == 0:
+            N = (N + 3) // 4 * 4
+        sc = torch.rand(B, N, generator=g)
+        if case % 3 == 0:
+            sc = torch.floor(sc * 64) / 64
+        t = torch.randint(0, N, (B,), generator=g, dtype=torch.int32)
+        filt = (torch.rand(B, N, generator=g) < 0.05).to(torch.uint8) if case % 4 else None
+        rank = torch.empty(B, device=DEV, dtype=torch.int32)
+        scd, td = sc.to(DEV), t.to(DEV)
+        fd = filt.to(DEV) if filt is not None else None
+        call("snag_rank_full_table", ptr(scd), B, N, ptr(td), 4, ptr(fd), ptr(rank), stream())
+        ref = sc[torch.arange(B), t.long()][:, None]
+        less = sc < ref
+        if filt is not None:
+            less &= filt == 0
+        assert torch.equal(rank.cpu(), less.sum(1).to(torch.int32)), f"case {case}: B={B} N={N} filter={filt is not None}"
