@@ -147,3 +147,39 @@ def test_colsum_and_its_pair_form(R, C, pad):
     call("snag_colsum_pair", ptr(xs[0]), ptr(xs[1]), R, C, xs[0].stride(0), ptr(o0), ptr(o1), 0, ptr(work), stream())
     assert torch.equal(o0, singles[0]) and torch.equal(o1, singles[1])
     assert torch.equal(ops.colsum(xs[0].contiguous()), singles[0])
+
+
+@pytest.mark.parametrize("with_z", [False, True])
+def test_noise_apply_quad_path_equals_the_element_path(with_z):
+    """snag_noise_apply handles a quad of columns per thread (one dwordx4 per operand, ONE Philox draw for the quad) when the rows are
+    whole quads and every pointer is 16-byte aligned, and goes element by element otherwise (drawing the quad's normals for each of
+    its elements and keeping one).  Same inputs behind aligned and behind misaligned pointers: identical outputs."""
+    from snag_amd._lib import call, ptr, stream
+    N, F = 333, 40
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(N, F, generator=g)
+    mean, std = torch.randn(F, generator=g), torch.rand(F, generator=g) + 0.1
+    mask = (torch.rand(N, generator=g) < 0.4).to(torch.uint8).to(DEV)
+    nsel = int(mask.sum())
+    sel = (torch.cumsum(mask.cpu().to(torch.int32), 0) - 1).to(torch.int32).to(DEV)
+    z = torch.randn(max(nsel, 1), F, generator=g)
+    outs = []
+    for off in (0, 1):                      # 1: every float buffer starts 4 bytes past a 16-byte boundary
+        def put(t):
+            b = torch.zeros(t.numel() + 4, device=DEV)
+            v = b[off:off + t.numel()].view(t.shape)
+            v.copy_(t.to(DEV))
+            return v
+        xd, md, sd, zd = put(x), put(mean), put(std), put(z)
+        od = put(torch.zeros(N, F))
+        call("snag_noise_apply", ptr(xd), N, F, ptr(md), ptr(sd), ptr(mask), ptr(sel) if with_z else None, ptr(zd) if with_z else None, 12345, 0.7,
+             ptr(od), stream())
+        outs.append(od.clone())
+    assert torch.equal(outs[0], outs[1])
+    untouched = mask.cpu() == 0
+    assert torch.equal(outs[0].cpu()[untouched], x[untouched])
+    if with_z:
+        want = x.clone()
+        rows = (~untouched).nonzero().flatten()
+        want[rows] = (1.0 - 0.7) * x[rows] + 0.7 * (mean + std * z[sel.cpu()[rows].long()])
+        torch.testing.assert_close(outs[0].cpu(), want, atol=1e-6, rtol=1e-6)
