@@ -461,6 +461,9 @@ SNAG_API int snag_csls_apply(const float* sim, int64_t ld, int n, int m, const f
 SNAG_API int snag_rank_diagonal(const float* dist, int64_t ld, int n, int m, const float* r1, const float* r2,
                                 int32_t* rank_l2r, int32_t* rank_r2l, void* stream);
 SNAG_API int snag_rank_summary(const int32_t* rank, int n, const int32_t* topk, int ntop, double* out, void* stream);
+/* Both directions of one evaluation in one launch: out[0 .. ntop+2) summarises rank_a, out[ntop+2 .. 2(ntop+2)) rank_b (same n, same
+ * thresholds); the numbers of two snag_rank_summary calls. */
+SNAG_API int snag_rank_summary_pair(const int32_t* rank_a, const int32_t* rank_b, int n, const int32_t* topk, int ntop, double* out, void* stream);
 SNAG_API int snag_argmin_rows_cols(const float* dist, int64_t ld, int n, int m, int32_t* row_argmin, int32_t* col_argmin,
                                    float* work, void* stream);
 

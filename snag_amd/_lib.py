@@ -123,6 +123,7 @@ SIGNATURES = {
     "snag_rank_rows_block": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P],
     "snag_rank_cols_block": [_P, _L, _I, _I, _P, _P, _P, _P, _P],
     "snag_rank_summary": [_P, _I, _P, _I, _P, _P],
+    "snag_rank_summary_pair": [_P, _P, _I, _P, _I, _P, _P],
     "snag_argmin_rows_cols": [_P, _L, _I, _I, _P, _P, _P, _P],
     "snag_entity_token_fwd": [_P, _L, _I, _P, _P, _F, _P, _L, _P],
 }

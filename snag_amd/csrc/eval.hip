@@ -384,7 +384,11 @@ __global__ __launch_bounds__(256) void rank_cols_block_kernel(const float* __res
 
 // Hits@k counts, sum(rank+1), sum(1/(rank+1)) in double, fixed order  (main.py:400-407,430-436)
 __global__ __launch_bounds__(256) void rank_summary_kernel(const int* __restrict__ rank, int n, const int* __restrict__ topk, int ntop,
-                                                           double* __restrict__ out) {
+                                                           double* __restrict__ out, const int* __restrict__ rank_b) {
+    if (blockIdx.x == 1) {                        // second direction of the same evaluation (snag_rank_summary_pair): block 1, out + ntop + 2
+        rank = rank_b;
+        out += ntop + 2;
+    }
     // one pass over the ranks for all ntop + 2 sums (ntop <= 8); each sum keeps its own thread-strided order and the same tree
     __shared__ double red[256];
     double s[10];
@@ -750,8 +754,14 @@ extern "C" SNAG_API int snag_rank_cols_block(const float* dist, int64_t ld, int 
 
 extern "C" SNAG_API int snag_rank_summary(const int32_t* rank, int n, const int32_t* topk, int ntop, double* out, void* stream) {
     SNAG_REQUIRE(rank && topk && out && n >= 1 && ntop >= 0 && ntop <= 8, SNAG_ERR_ARG, "rank_summary: bad arguments");
-    hipLaunchKernelGGL(rank_summary_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rank, n, topk, ntop, out);
+    hipLaunchKernelGGL(rank_summary_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rank, n, topk, ntop, out, (const int32_t*)nullptr);
     return check_launch("snag_rank_summary");
+}
+
+extern "C" SNAG_API int snag_rank_summary_pair(const int32_t* rank_a, const int32_t* rank_b, int n, const int32_t* topk, int ntop, double* out, void* stream) {
+    SNAG_REQUIRE(rank_a && rank_b && topk && out && n >= 1 && ntop >= 0 && ntop <= 8, SNAG_ERR_ARG, "rank_summary_pair: bad arguments");
+    hipLaunchKernelGGL(rank_summary_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, rank_a, n, topk, ntop, out, rank_b);
+    return check_launch("snag_rank_summary_pair");
 }
 
 extern "C" SNAG_API int snag_argmin_rows_cols(const float* dist, int64_t ld, int n, int m, int32_t* row_argmin, int32_t* col_argmin, float* work,

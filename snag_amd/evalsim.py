@@ -97,10 +97,12 @@ def rank_metrics(emb_left, emb_right, csls_k=0, top_k=(1, 10, 50), distance=2):
     call("snag_rank_diagonal", ptr(dist), dist.stride(0), n, m, ptr(r1), ptr(r2), ptr(rl), ptr(rr), stream())
     tk = torch.tensor(list(top_k), device=dev, dtype=torch.int32)
     out = {"rank_l2r": rl, "rank_r2l": rr, "dist": dist}
-    for name, rk in (("l2r", rl), ("r2l", rr)):
-        summ = torch.empty(len(top_k) + 2, device=dev, dtype=torch.float64)
-        call("snag_rank_summary", ptr(rk), n, ptr(tk), len(top_k), ptr(summ), stream())
-        s = summ.cpu().tolist()
+    nt = len(top_k) + 2
+    summ = torch.empty(2 * nt, device=dev, dtype=torch.float64)              # both directions: one launch, one copy to the host
+    call("snag_rank_summary_pair", ptr(rl), ptr(rr), n, ptr(tk), len(top_k), ptr(summ), stream())
+    both = summ.cpu().tolist()
+    for d, name in enumerate(("l2r", "r2l")):
+        s = both[d * nt:(d + 1) * nt]
         out[f"hits_{name}"] = [round(c / n, 4) for c in s[:len(top_k)]]          # main.py:435-436
         out[f"mr_{name}"] = s[len(top_k)] / n
         out[f"mrr_{name}"] = s[len(top_k) + 1] / n
