@@ -15,6 +15,7 @@ epoch") runs inside the timed region every 78th step.  All inputs are resident i
 timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -385,6 +386,8 @@ def run_stress(args, world, rank, device, backend, real_stdout):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()                         # (see main(): no full collection inside the timed loop)
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i, timers)
@@ -393,6 +396,7 @@ def run_stress(args, world, rank, device, backend, real_stdout):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -605,6 +609,10 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # the host enqueues a step in ~140 us of Python; a full garbage collection in the middle of the loop (tens of ms with torch's heap)
+    # would drain the launch queue and show up as device time -- collect now, keep the collector off while the K steps are timed
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for k in range(args.steps):
         # the per-launch HIP events sit INSIDE the timed region, on every TIMER_EVERY-th step only: an event pair around a launch
@@ -618,6 +626,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
