@@ -195,6 +195,46 @@ def untimed_extras(eng, batches, args, device):
     return out
 
 
+def noise_refresh_us(eng, reps=8):
+    """One noise refresh (README 'noise-level'; model/SNAG.py:86-98: three row masks, both feature tables' blend incl. their transposed
+    copies, the entity table's column statistics and noise rows), HIP events around ``update_noise`` on the launch stream, mean of
+    ``reps`` back-to-back refreshes after two untimed ones.  State (noise epoch, masks, noisy tables) moves on as in training."""
+    for _ in range(2):
+        eng.update_noise()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        eng.update_noise()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def phases_summary(phase_marks, world, row_sharded, cfg, eng):
+    """Mean duration of every phase of the step between consecutive HIP events on the compute stream (rank 0).  The compute stream
+    WAITS for each collective, so "all_gather" / "reduce_scatter" / "allreduce_wait" are the time the stream could not compute: a
+    collective's exposed cost, not its wire time."""
+    acc = {}
+    for marks in phase_marks:
+        for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
+            acc.setdefault(name, []).append(a.elapsed_time(b) * 1e3)
+    out = {k: sum(v) / len(v) for k, v in acc.items()}
+    comm = sum(out.get(k, 0.0) for k in ("all_gather", "reduce_scatter", "allreduce_wait"))
+    total = sum(out.values())
+    D, W = cfg.dim, eng.sdim
+    ns = eng.shard.n_shard
+    out["comm_exposed_us"] = comm
+    out["compute_us"] = total - comm
+    out["steps_sampled"] = len(phase_marks)
+    out["order"] = [n for n, _ in phase_marks[0][1:]]
+    if world > 1:
+        out["comm_bytes_per_rank"] = ({"all_gather_readout_recv": (world - 1) * ns * W * 4, "reduce_scatter_readout_grad_recv": (world - 1) * ns * W * 4,
+                                       "all_gather_entity_grad_recv": (world - 1) * ns * D * 4,
+                                       "all_reduce_dense_grads": 4 * (eng.n_params - eng.slices["rel"][0])} if row_sharded
+                                      else {"all_reduce_flat_grads": 4 * eng.n_params})
+    return out
+
+
 def device_copy_ceiling(device, reps=5):
     """Device-to-device copy rate of this GPU (1 GiB src -> 1 GiB dst), reported next to the nominal 8 TB/s."""
     src = torch.empty(1 << 28, device=device)
@@ -498,6 +538,8 @@ def main():
                     help="weak: --batch positives PER GPU (default); strong: --batch is the GLOBAL batch, split over the GPUs")
     ap.add_argument("--replicate-fusion", action="store_true",
                     help="N > 1: every rank projects and fuses ALL entities (round-1 behaviour) instead of owning 1/N of the rows")
+    ap.add_argument("--noise-level", default="epoch", choices=["epoch", "step"],
+                    help="README 'noise-level': refresh the feature / entity noise once per epoch (every 78th step; run_snag.sh) or in EVERY step")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (forward-only rate, copy ceiling, HBM-resident score probe)")
     args = ap.parse_args()
 
@@ -570,9 +612,15 @@ def main():
         timers["proj_l1_fwd_reduce"] = KernelTimer()     # the ONE reduce launch the visual and the text projection share
         eng.probe = timers
 
+    noise_every = 1 if args.noise_level == "step" else STEPS_PER_EPOCH
+    phase_marks = []                    # per timed step with phase events: [(name, event), ...] from "start" to "clip_adamw"
+
     def one_step(i):
-        if cfg.add_noise and i % STEPS_PER_EPOCH == 0:
+        if eng.marks is not None:
+            eng._mark("start")
+        if cfg.add_noise and i % noise_every == 0:
             eng.update_noise()
+            eng._mark("noise_refresh")
         h, r, t = batches[i % len(batches)]
         # negatives are drawn by the step's first launch (snag_step_prologue); the scorer runs fwd+bwd as one launch
         if SPLIT_PROLOGUE:      # A/B: the sampler as its own launch
@@ -581,7 +629,9 @@ def main():
         eng.backward(gscale, reducer=reducer)         # buckets go out as they become final (overlaps the projection backward)
         if reducer is not None:
             reducer.finish()
+            eng._mark("allreduce_wait")
         eng.optimizer_step()
+        eng._mark("clip_adamw")
 
     if args.graph:
         if world > 1:
@@ -593,12 +643,14 @@ def main():
         eng.capture_step(args.batch, cfg.neg_num, sample=(rank_seed, known))
 
         def one_step(i):                                  # noqa: F811  (graph replay variant)
-            if cfg.add_noise and i % STEPS_PER_EPOCH == 0 and i > 0:
+            if cfg.add_noise and i % noise_every == 0 and i > 0:
                 eng.update_noise()
             eng.replay_step(*batches[i % len(batches)])
 
     copy_gbs = device_copy_ceiling(device)
     extras = untimed_extras(eng, batches, args, device) if not args.no_extras else {}
+    if cfg.add_noise:
+        extras["noise_refresh_us"] = noise_refresh_us(eng)
     step_no = 0
     for _ in range(args.warmup):
         one_step(step_no)
@@ -606,6 +658,7 @@ def main():
     for tm in timers.values():
         tm.pairs.clear()
     torch.cuda.synchronize()
+    want_phases = (world > 1 or bool(os.environ.get("BENCH_PHASES"))) and not args.graph
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -619,7 +672,12 @@ def main():
         # costs the step 5-10 us of stream bubbles (measured: 0.786-0.792 ms with events on every step vs 0.763 ms without)
         if timers:
             eng.probe = timers if k % TIMER_EVERY == TIMER_EVERY - 1 else None
+        # phase events (N > 1, or BENCH_PHASES=1): on the timed steps that carry no per-launch timers, every TIMER_EVERY-th too
+        if want_phases and k % TIMER_EVERY == 1:
+            eng.marks = []
+            phase_marks.append(eng.marks)
         one_step(step_no)
+        eng.marks = None
         step_no += 1
     torch.cuda.synchronize()
     if world > 1:
@@ -652,6 +710,9 @@ def main():
                                  "reduce-scatter of their gradient)" if row_sharded else "replicated on every rank"),
                        "replicated_fraction": None if world == 1 else (REPLICATED_FRACTION_SHARDED if row_sharded else REPLICATED_FRACTION_REPLICATED)},
         }
+        if phase_marks:
+            out["phases_us"] = phases_summary(phase_marks, world, row_sharded, cfg, eng)
+        out["config"]["noise_level"] = args.noise_level
         out["measured_copy_GBs"] = copy_gbs
         out.update(extras)
         if timers:

@@ -350,6 +350,31 @@ SNAG_API int snag_noise_apply(const float* x, int64_t N, int F, const float* mea
                               const uint8_t* row_mask, const int32_t* sel_index, const float* z,
                               uint64_t seed, float mask_ratio, float* out, void* stream);
 SNAG_API int snag_dropout_keep_mask(uint64_t seed, const uint64_t* tick, int64_t n, float p, uint8_t* out, void* stream);
+/* Bernoulli byte masks as REGIONS of global streams: region i covers the elements [offset, offset + n) of the stream Philox(seed [+ tick]):
+ * element g is word g % 4 of philox4x32_10(seed, g / 4), whichever region asks for it, and out[j] = (u(offset + j) >= p) != invert.
+ * A rank that owns the entity rows [lo, hi) of a [N, W] mask therefore draws, with offset = lo * W, exactly the bytes the single rank
+ * draws for those rows (SURVEY.md par. 8e: the G-rank step equals the 1-rank step with dropout and noise ON).  invert = 0: the keep mask
+ * of nn.Dropout(p); invert = 1: the "rand < p" row mask of the noise injection (model/SNAG.py:68).  snag_dropout_keep_mask is the one
+ * region (seed, 0, n, p, 0).  Up to SNAG_MAX_MASK_REGIONS regions per launch; the table is read on the host. */
+#define SNAG_MAX_MASK_REGIONS 8
+typedef struct snag_mask_region {
+    uint64_t seed;
+    int64_t offset;
+    int64_t n;
+    float p;
+    int32_t invert;
+    uint8_t* out;
+} snag_mask_region;
+SNAG_API int snag_bernoulli_regions(const snag_mask_region* regions, int n_regions, const uint64_t* tick, void* stream);
+/* snag_noise_apply for a table that is refreshed once per epoch (model/SNAG.py:86-92), incremental and keyed on GLOBAL rows:
+ *   rows with new_mask[n] != 0:            noisy[n,:] = (1 - mask_ratio) x[n,:] + mask_ratio (mean + std * z), z = Philox(seed, ((row0 + n) F + c) / 4)
+ *   rows with only old_mask[n] != 0:       noisy[n,:] = x[n,:]      (last epoch's noise taken back)
+ *   rows in neither mask:                  not touched (they equal x already; old_mask == NULL: every row is written)
+ * x holds the rows [row0, row0 + N) of the whole table: a row-owning rank draws the noise the single rank draws for its rows.
+ * noisy_t (optional): the transposed copy [F, ld_t] (ld_t >= N), rewritten whole; noisy may then be NULL. */
+SNAG_API int snag_noise_refresh(const float* x, int64_t N, int F, const float* mean, const float* std_, const uint8_t* new_mask,
+                                const uint8_t* old_mask, uint64_t seed, int64_t row0, float mask_ratio, float* noisy, float* noisy_t,
+                                int64_t ld_t, void* stream);
 SNAG_API int snag_gaussian_fill(uint64_t seed, int64_t N, int F, const float* mean, const float* std_,
                                 float* out, void* stream);
 
@@ -501,12 +526,13 @@ SNAG_API int snag_sample_negatives(uint64_t seed, const uint64_t* tick, const in
 
 /* ONE launch for the three independent, small launches that open an MKGC training step: snag_sample_negatives (mode 0: negative
  * tails; same Philox stream, same results), snag_entity_token_fwd (the structural token with the noise blend) and
- * snag_dropout_keep_mask (the step's Bert dropout masks).  Workgroup ranges of the one grid run the three bodies side by side; any
- * part is skipped when its size is zero (batch * n_neg, n_rows, drop_n). */
+ * snag_bernoulli_regions (the step's Bert dropout masks, one region per mask tensor, each keyed on the global row of its first
+ * element).  Workgroup ranges of the one grid run the three bodies side by side; any part is skipped when its size is zero
+ * (batch * n_neg, n_rows, n_mask_regions). */
 SNAG_API int snag_step_prologue(uint64_t sample_seed, const uint64_t* tick, const int32_t* h, const int32_t* r, const int32_t* t, int64_t batch,
                                 int n_neg, int n_ent, int n_rel, const int64_t* known_sorted, int64_t n_known, int32_t* neg_t,
                                 const float* table, int64_t n_rows, int dim, const float* noise, const uint8_t* noise_mask, float half_mask_ratio,
-                                float* tok, int64_t tok_ld, uint64_t drop_seed, int64_t drop_n, float drop_p, uint8_t* drop_out, void* stream);
+                                float* tok, int64_t tok_ld, const snag_mask_region* mask_regions, int n_mask_regions, void* stream);
 
 /* The same sampler with the two in-tree properties snag_sample_negatives gives up: candidates are drawn from the KG's OWN entity
  * list ent_list [n_list] (int32 ids; NULL = 0..n_ent-1; model/MSNEA_tools.py:64-65) and the n_neg negatives of one positive are

@@ -17,6 +17,7 @@ _L = _c.c_int64
 _F = _c.c_float
 _U64 = _c.c_uint64
 SCORE_TICKET_WORDS = 1056      # SNAG_SCORE_TICKET_WORDS (include/snag_hip.h)
+MAX_MASK_REGIONS = 8           # SNAG_MAX_MASK_REGIONS
 
 
 
@@ -31,6 +32,11 @@ class GemmDesc(_c.Structure):
                 ("accumulate", _c.c_int32), ("workspace", _P), ("workspace_floats", _L),
                 ("aux", _P), ("ldaux", _L), ("ldmask", _L), ("defer_reduce", _c.c_int32),
                 ("mirror", _P), ("ldmirror", _L), ("mirror_rowmask", _P), ("mirror_scale", _F)]
+
+
+class MaskRegion(_c.Structure):
+    """struct snag_mask_region."""
+    _fields_ = [("seed", _U64), ("offset", _L), ("n", _L), ("p", _F), ("invert", _c.c_int32), ("out", _P)]
 
 
 class FusionLayer(_c.Structure):
@@ -100,7 +106,9 @@ SIGNATURES = {
     "snag_gat_layer_bwd": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P],
     "snag_build_filter_mask": [_P, _P, _P, _L, _I, _I, _P, _L, _P, _P],
     "snag_sample_negatives": [_U64, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P, _P, _P],
-    "snag_step_prologue": [_U64, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P, _P, _F, _P, _L, _U64, _L, _F, _P, _P],
+    "snag_step_prologue": [_U64, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P, _P, _F, _P, _L, _P, _I, _P],
+    "snag_bernoulli_regions": [_P, _I, _P, _P],
+    "snag_noise_refresh": [_P, _L, _I, _P, _P, _P, _P, _U64, _L, _F, _P, _P, _L, _P],
     "snag_sample_negatives_distinct": [_U64, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P, _I, _P, _P, _P],
     "snag_gather_normalize_fwd": [_P, _L, _L, _I, _P, _I, _L, _I, _P, _P, _P],
     "snag_gather_normalize_bwd": [_P, _P, _P, _I, _P, _I, _L, _I, _P, _L, _P],

@@ -20,29 +20,79 @@ __device__ __forceinline__ float4 normal4(uint64_t seed, uint64_t ctr) {
     return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
 }
 
-// keep[i] = (u >= p): the inverted-dropout keep mask of nn.Dropout(p)
-__device__ __forceinline__ void bernoulli_keep_body(int64_t vblock, uint64_t seed, const uint64_t* __restrict__ tick, int64_t n, float p,
-                                                    uint8_t* __restrict__ out) {
-    const int64_t q = vblock * 256 + threadIdx.x;       // one Philox draw = 4 elements
-    if (q * 4 >= n) return;
+// Bernoulli byte mask of the elements [offset, offset + n) of ONE global stream: element g comes from Philox(seed, g / 4), word g % 4 --
+// whatever part of the stream a caller asks for (a rank that owns rows [lo, hi) of a table draws exactly what the single rank draws for
+// those rows).  out[i] = (u(offset + i) >= p) != invert: invert = 0 is the inverted-dropout keep mask of nn.Dropout(p), invert = 1 the
+// "rand < p" row mask of the noise injection (model/SNAG.py:68).
+__device__ __forceinline__ void bernoulli_region_body(int64_t vblock, uint64_t seed, const uint64_t* __restrict__ tick, int64_t offset, int64_t n, float p,
+                                                      int invert, uint8_t* __restrict__ out) {
+    const int64_t q = (offset >> 2) + vblock * 256 + threadIdx.x;       // one Philox draw = 4 elements of the global stream
+    if (q * 4 >= offset + n) return;
     if (tick != nullptr) seed += tick[0] * 0x9E3779B97F4A7C15ull;    // a fresh stream per training step inside a replayed graph
     const Philox4 r = philox4x32_10(seed, (uint64_t)q);
     const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
-    if (q * 4 + 3 < n && (((uintptr_t)out) & 3) == 0) {          // one 4-byte store per draw
+    const uint32_t inv = invert ? 1u : 0u;
+    const int64_t i0 = q * 4 - offset;                  // local index of the draw's first element
+    if (i0 >= 0 && i0 + 3 < n && (((uintptr_t)(out + i0)) & 3) == 0) {          // one 4-byte store per draw
         uint32_t w = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w |= (u01(rr[e]) >= p ? 1u : 0u) << (8 * e);
-        reinterpret_cast<uint32_t*>(out)[q] = w;
+        for (int e = 0; e < 4; ++e) w |= ((u01(rr[e]) >= p ? 1u : 0u) ^ inv) << (8 * e);
+        *reinterpret_cast<uint32_t*>(out + i0) = w;
         return;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-        if (q * 4 + e < n) out[q * 4 + e] = u01(rr[e]) >= p ? 1 : 0;
+        if (i0 + e >= 0 && i0 + e < n) out[i0 + e] = (uint8_t)((u01(rr[e]) >= p ? 1u : 0u) ^ inv);
+}
+
+__device__ __forceinline__ void bernoulli_keep_body(int64_t vblock, uint64_t seed, const uint64_t* __restrict__ tick, int64_t n, float p,
+                                                    uint8_t* __restrict__ out) {
+    bernoulli_region_body(vblock, seed, tick, 0, n, p, 0, out);
 }
 
 __global__ __launch_bounds__(256) void bernoulli_keep_kernel(uint64_t seed, const uint64_t* __restrict__ tick, int64_t n, float p,
                                                              uint8_t* __restrict__ out) {
     bernoulli_keep_body(blockIdx.x, seed, tick, n, p, out);
+}
+
+// up to SNAG_MAX_MASK_REGIONS regions in one launch: blocks [cum[i-1], cum[i]) draw region i
+struct RegionArgs {
+    snag_mask_region r[SNAG_MAX_MASK_REGIONS];
+    int cum[SNAG_MAX_MASK_REGIONS];
+    int n;
+};
+__device__ __forceinline__ void bernoulli_regions_body(int vblock, const RegionArgs& a, const uint64_t* __restrict__ tick) {
+    int i = 0;
+    while (i + 1 < a.n && vblock >= a.cum[i]) ++i;
+    const int first = i ? a.cum[i - 1] : 0;
+    bernoulli_region_body(vblock - first, a.r[i].seed, tick, a.r[i].offset, a.r[i].n, a.r[i].p, a.r[i].invert, a.r[i].out);
+}
+__global__ __launch_bounds__(256) void bernoulli_regions_kernel(RegionArgs a, const uint64_t* __restrict__ tick) {
+    bernoulli_regions_body(blockIdx.x, a, tick);
+}
+static int region_blocks(const snag_mask_region& r) {
+    if (r.n <= 0) return 0;
+    const int64_t q0 = r.offset >> 2, q1 = (r.offset + r.n + 3) >> 2;
+    return (int)((q1 - q0 + 255) / 256);
+}
+// validates and lays out a region table; returns the total block count or a negative error
+static int fill_regions(const snag_mask_region* regions, int n_regions, RegionArgs& a, const char* who) {
+    if (n_regions < 0 || n_regions > SNAG_MAX_MASK_REGIONS || (n_regions > 0 && regions == nullptr))
+        return fail(SNAG_ERR_ARG, "%s: %d mask regions (at most %d)", who, n_regions, SNAG_MAX_MASK_REGIONS);
+    a.n = 0;
+    int total = 0;
+    for (int i = 0; i < n_regions; ++i) {
+        const snag_mask_region& r = regions[i];
+        if (r.n < 0 || r.offset < 0 || (r.n > 0 && r.out == nullptr) || !(r.p >= 0.f && r.p < 1.f))
+            return fail(SNAG_ERR_ARG, "%s: bad mask region %d (n=%ld offset=%ld p=%g)", who, i, (long)r.n, (long)r.offset, r.p);
+        const int nb = region_blocks(r);
+        if (nb == 0) continue;
+        total += nb;
+        a.r[a.n] = r;
+        a.cum[a.n] = total;
+        ++a.n;
+    }
+    return total;
 }
 
 // out[n, c] = mean[c] + std[c] * z    (model/SNAG.py:96)
@@ -131,14 +181,113 @@ __global__ __launch_bounds__(256) void colstat_part_kernel(const float* __restri
     if (wave == 0 && c < C) part[(int64_t)blockIdx.y * C + c] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
-// mode 0: out = sum / n ; mode 1: out = sqrt(sum / (n - 1))
-__global__ __launch_bounds__(256) void colstat_finish_kernel(const float* __restrict__ part, int nblocks, int C, float n, int mode,
-                                                             float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+// mode 0: out = sum / n ; mode 1: out = sqrt(sum / (n - 1)).  One workgroup per 64 columns: sixteen waves sum runs of consecutive
+// partial blocks (eight loads in flight), the runs are added in wave order -- a fixed order, 16 x shorter than one thread's serial walk
+// over all blocks (59 us for a 128-column table as a single 128-thread block).
+__global__ __launch_bounds__(1024) void colstat_finish_kernel(const float* __restrict__ part, int nblocks, int C, float n, int mode,
+                                                              float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wave = wave_id_uniform();
+    const int c = blockIdx.x * 64 + lane;
+    const int per = (nblocks + 15) / 16;
+    const int b0 = wave * per, b1 = min(nblocks, b0 + per);
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * C + c];
-    out[c] = mode == 0 ? s / n : sqrtf(s / (n - 1.0f));
+    if (c < C) {
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = part[(int64_t)(b + u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; b < b1; ++b) s += part[(int64_t)b * C + c];
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w][lane];
+        out[c] = mode == 0 ? t / n : sqrtf(t / (n - 1.0f));
+    }
+}
+
+// Refresh of one modality's noisy feature table, incremental (model/SNAG.py:66-75 once per epoch, :86-92):
+//   row in new_mask          : noisy = (1 - eps) x + eps (mean + std * z),  z = Philox(seed, ((row0 + n) F + c) / 4): keyed on the GLOBAL row
+//   row in old_mask only     : noisy = x   (the previous epoch's noise is taken back)
+//   row in neither           : untouched -- it already equals x
+// One workgroup walks rows blockIdx.x, + gridDim.x, ...; the masks are wave-uniform, so an untouched row costs two byte loads.
+__global__ __launch_bounds__(256) void noise_refresh_rows_kernel(const float* __restrict__ x, int64_t N, int F, const float* __restrict__ mean,
+                                                                 const float* __restrict__ std_, const uint8_t* __restrict__ new_mask,
+                                                                 const uint8_t* __restrict__ old_mask, uint64_t seed, int64_t row0, float eps,
+                                                                 float* __restrict__ out) {
+    const bool quad = (F & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)mean) | ((uintptr_t)std_)) & 15) == 0;
+    for (int64_t n = blockIdx.x; n < N; n += gridDim.x) {
+        const int nm = new_mask[n], om = old_mask != nullptr ? old_mask[n] : 1;
+        if (!(nm | om)) continue;
+        const float* xr = x + n * F;
+        float* o = out + n * F;
+        const int64_t g0 = (row0 + n) * (int64_t)F;                 // global element index of the row's first column
+        if (quad) {
+            for (int c = threadIdx.x * 4; c < F; c += 1024) {
+                float4 v = *reinterpret_cast<const float4*>(xr + c);
+                if (nm) {
+                    const float4 g = normal4(seed, (uint64_t)((g0 + c) >> 2));
+                    const float4 mu = *reinterpret_cast<const float4*>(mean + c), sd = *reinterpret_cast<const float4*>(std_ + c);
+                    v.x = (1.0f - eps) * v.x + eps * (mu.x + sd.x * g.x);
+                    v.y = (1.0f - eps) * v.y + eps * (mu.y + sd.y * g.y);
+                    v.z = (1.0f - eps) * v.z + eps * (mu.z + sd.z * g.z);
+                    v.w = (1.0f - eps) * v.w + eps * (mu.w + sd.w * g.w);
+                }
+                *reinterpret_cast<float4*>(o + c) = v;
+            }
+        } else {
+            for (int c = threadIdx.x; c < F; c += 256) {
+                float v = xr[c];
+                if (nm) {
+                    const int64_t gi = g0 + c;
+                    const float4 g = normal4(seed, (uint64_t)(gi >> 2));
+                    const int e = (int)(gi & 3);
+                    const float zv = e == 0 ? g.x : (e == 1 ? g.y : (e == 2 ? g.z : g.w));
+                    v = (1.0f - eps) * v + eps * (mean[c] + std_[c] * zv);
+                }
+                o[c] = v;
+            }
+        }
+    }
+}
+
+// The same refresh for engines that also keep the table TRANSPOSED ([F, ld_t], rows of the table along the contiguous axis): 64 x 64
+// tiles through LDS (pitch 65), every element of the transposed copy rewritten, the row-major copy only where a mask touches it.
+__global__ __launch_bounds__(256) void noise_refresh_tiles_kernel(const float* __restrict__ x, int64_t N, int F, const float* __restrict__ mean,
+                                                                  const float* __restrict__ std_, const uint8_t* __restrict__ new_mask,
+                                                                  const uint8_t* __restrict__ old_mask, uint64_t seed, int64_t row0, float eps,
+                                                                  float* __restrict__ out, float* __restrict__ out_t, int64_t ld_t) {
+    __shared__ float tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.y * 64;
+    const int c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = c0 + tx;
+    const float mu = c < F ? mean[c] : 0.f, sd = c < F ? std_[c] : 0.f;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t n = r0 + i;
+        if (n >= N || c >= F) continue;
+        float v = x[n * F + c];
+        const int nm = new_mask[n], om = old_mask != nullptr ? old_mask[n] : 1;
+        if (nm) {
+            const int64_t gi = (row0 + n) * (int64_t)F + c;
+            const float4 g = normal4(seed, (uint64_t)(gi >> 2));
+            const int e = (int)(gi & 3);
+            const float zv = e == 0 ? g.x : (e == 1 ? g.y : (e == 2 ? g.z : g.w));
+            v = (1.0f - eps) * v + eps * (mu + sd * zv);
+        }
+        if (out != nullptr && (nm | om)) out[n * F + c] = v;
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4)
+        if (c0 + i < F && r0 + tx < N) out_t[(int64_t)(c0 + i) * ld_t + r0 + tx] = tile[tx][i];
 }
 
 // d hidden[n, m, :] = d_out[n, :] / M ; zero_src: d_out is overwritten with zeros once read (it is the scorer's scatter-add target)
@@ -346,8 +495,8 @@ struct PrologueArgs {
     int32_t *neg_h, *neg_t;
     // structural token (blocks [nb_s, nb_s + nb_e))
     const float* table; int64_t N; int D; const float* noise; const uint8_t* nmask; float a; float* tok; int64_t tok_ld;
-    // dropout masks (the rest)
-    uint64_t d_seed; int64_t d_n; float d_p; uint8_t* d_out;
+    // Bernoulli mask regions (the rest): the Bert dropout masks, one region per mask tensor
+    RegionArgs masks;
     int nb_s, nb_e;
 };
 
@@ -355,7 +504,7 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(PrologueArgs a) {
     const int b = blockIdx.x;
     if (b < a.nb_s) sample_negatives_body(b, a.s_seed, a.tick, a.h, a.r, a.t, a.B, a.K, a.n_ent, a.n_rel, a.mode, a.known, a.n_known, a.neg_h, a.neg_t);
     else if (b < a.nb_s + a.nb_e) entity_token_fwd_body(b - a.nb_s, a.nb_e, a.table, a.N, a.D, a.noise, a.nmask, a.a, a.tok, a.tok_ld);
-    else bernoulli_keep_body(b - a.nb_s - a.nb_e, a.d_seed, a.tick, a.d_n, a.d_p, a.d_out);
+    else bernoulli_regions_body(b - a.nb_s - a.nb_e, a.masks, a.tick);
 }
 
 static int grid_for(int64_t n) { return (int)std::min<int64_t>(4096, (n + 255) / 256); }
@@ -369,6 +518,15 @@ extern "C" SNAG_API int snag_dropout_keep_mask(uint64_t seed, const uint64_t* ti
     if (n == 0) return SNAG_OK;
     hipLaunchKernelGGL(bernoulli_keep_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, seed, tick, n, p, out);
     return check_launch("snag_dropout_keep_mask");
+}
+
+extern "C" SNAG_API int snag_bernoulli_regions(const snag_mask_region* regions, int n_regions, const uint64_t* tick, void* stream) {
+    RegionArgs a{};
+    const int total = fill_regions(regions, n_regions, a, "bernoulli_regions");
+    if (total < 0) return total;
+    if (total == 0) return SNAG_OK;
+    hipLaunchKernelGGL(bernoulli_regions_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a, tick);
+    return check_launch("snag_bernoulli_regions");
 }
 
 extern "C" SNAG_API int snag_gaussian_fill(uint64_t seed, int64_t N, int F, const float* mean, const float* std_, float* out, void* stream) {
@@ -391,6 +549,25 @@ extern "C" SNAG_API int snag_noise_apply(const float* x, int64_t N, int F, const
     return check_launch("snag_noise_apply");
 }
 
+extern "C" SNAG_API int snag_noise_refresh(const float* x, int64_t N, int F, const float* mean, const float* std_, const uint8_t* new_mask,
+                                           const uint8_t* old_mask, uint64_t seed, int64_t row0, float mask_ratio, float* noisy, float* noisy_t,
+                                           int64_t ld_t, void* stream) {
+    SNAG_REQUIRE(N >= 0 && F >= 1 && row0 >= 0, SNAG_ERR_ARG, "noise_refresh: bad sizes");
+    if (N == 0) return SNAG_OK;
+    SNAG_REQUIRE(x && mean && std_ && new_mask && (noisy || noisy_t), SNAG_ERR_ARG, "noise_refresh: null pointer");
+    SNAG_REQUIRE(noisy_t == nullptr || ld_t >= N, SNAG_ERR_ARG, "noise_refresh: transposed pitch %ld < %ld rows", (long)ld_t, (long)N);
+    hipStream_t st = (hipStream_t)stream;
+    if (noisy_t != nullptr) {
+        SNAG_REQUIRE(ceil_div(N, 64) <= 65535, SNAG_ERR_UNSUPPORTED, "noise_refresh: more than 4M rows with a transposed copy");
+        hipLaunchKernelGGL(noise_refresh_tiles_kernel, dim3(ceil_div(F, 64), ceil_div(N, 64)), dim3(256), 0, st, x, N, F, mean, std_, new_mask, old_mask,
+                           seed, row0, mask_ratio, noisy, noisy_t, ld_t);
+    } else {
+        hipLaunchKernelGGL(noise_refresh_rows_kernel, dim3((unsigned)std::min<int64_t>(N, 8192)), dim3(256), 0, st, x, N, F, mean, std_, new_mask, old_mask,
+                           seed, row0, mask_ratio, noisy);
+    }
+    return check_launch("snag_noise_refresh");
+}
+
 extern "C" SNAG_API int64_t snag_colstats_work_floats(int C) { return (int64_t)256 * C; }
 
 extern "C" SNAG_API int snag_colstats(const float* x, int64_t R, int C, const uint8_t* exclude, int64_t n_valid, float* mean, float* std_,
@@ -399,12 +576,12 @@ extern "C" SNAG_API int snag_colstats(const float* x, int64_t R, int C, const ui
     SNAG_REQUIRE(n_valid >= 1 && n_valid <= R, SNAG_ERR_ARG, "colstats: n_valid=%ld outside [1, %ld]", (long)n_valid, (long)R);
     hipStream_t st = (hipStream_t)stream;
     const int by = (int)std::min<int64_t>(256, (R + 3) / 4);
-    const dim3 grid(ceil_div(C, 64), by), fgrid(ceil_div(C, 256));
+    const dim3 grid(ceil_div(C, 64), by), fgrid(ceil_div(C, 64));
     hipLaunchKernelGGL(colstat_part_kernel, grid, dim3(256), 0, st, x, R, C, exclude, (const float*)nullptr, work);
-    hipLaunchKernelGGL(colstat_finish_kernel, fgrid, dim3(256), 0, st, (const float*)work, by, C, (float)n_valid, 0, mean);
+    hipLaunchKernelGGL(colstat_finish_kernel, fgrid, dim3(1024), 0, st, (const float*)work, by, C, (float)n_valid, 0, mean);
     if (std_ != nullptr) {
         hipLaunchKernelGGL(colstat_part_kernel, grid, dim3(256), 0, st, x, R, C, exclude, (const float*)mean, work);
-        hipLaunchKernelGGL(colstat_finish_kernel, fgrid, dim3(256), 0, st, (const float*)work, by, C, (float)n_valid, 1, std_);
+        hipLaunchKernelGGL(colstat_finish_kernel, fgrid, dim3(1024), 0, st, (const float*)work, by, C, (float)n_valid, 1, std_);
     }
     return check_launch("snag_colstats");
 }
@@ -682,22 +859,21 @@ extern "C" SNAG_API int snag_build_filter_mask(const int32_t* h, const int32_t* 
 extern "C" SNAG_API int snag_step_prologue(uint64_t sample_seed, const uint64_t* tick, const int32_t* h, const int32_t* r, const int32_t* t, int64_t batch,
                                            int n_neg, int n_ent, int n_rel, const int64_t* known_sorted, int64_t n_known, int32_t* neg_t,
                                            const float* table, int64_t n_rows, int dim, const float* noise, const uint8_t* noise_mask, float half_mask_ratio,
-                                           float* tok, int64_t tok_ld, uint64_t drop_seed, int64_t drop_n, float drop_p, uint8_t* drop_out, void* stream) {
-    SNAG_REQUIRE(batch >= 0 && n_neg >= 0 && n_ent >= 1 && n_rel >= 1 && n_rows >= 0 && dim >= 1 && drop_n >= 0, SNAG_ERR_ARG, "step_prologue: bad sizes");
+                                           float* tok, int64_t tok_ld, const snag_mask_region* mask_regions, int n_mask_regions, void* stream) {
+    SNAG_REQUIRE(batch >= 0 && n_neg >= 0 && n_ent >= 1 && n_rel >= 1 && n_rows >= 0 && dim >= 1, SNAG_ERR_ARG, "step_prologue: bad sizes");
     SNAG_REQUIRE(batch * n_neg == 0 || (h && r && t && neg_t), SNAG_ERR_ARG, "step_prologue: null sampler pointer");
     SNAG_REQUIRE((known_sorted != nullptr) == (n_known > 0), SNAG_ERR_ARG, "step_prologue: known_sorted and n_known go together");
     SNAG_REQUIRE(n_rows == 0 || (table && tok && tok_ld >= dim), SNAG_ERR_ARG, "step_prologue: null structural-token pointer");
     SNAG_REQUIRE((noise == nullptr) == (noise_mask == nullptr), SNAG_ERR_ARG, "step_prologue: noise and noise_mask go together");
-    SNAG_REQUIRE(drop_n == 0 || (drop_out && drop_p >= 0.f && drop_p < 1.f), SNAG_ERR_ARG, "step_prologue: bad dropout arguments");
     SNAG_REQUIRE((int64_t)n_ent * n_rel < (1LL << 62) / n_ent, SNAG_ERR_UNSUPPORTED, "step_prologue: triple key overflows int64");
     PrologueArgs a{};
     a.s_seed = sample_seed; a.tick = tick; a.h = h; a.r = r; a.t = t; a.B = batch; a.K = n_neg; a.n_ent = n_ent; a.n_rel = n_rel; a.mode = 0;
     a.known = known_sorted; a.n_known = n_known; a.neg_h = nullptr; a.neg_t = neg_t;
     a.table = table; a.N = n_rows; a.D = dim; a.noise = noise; a.nmask = noise_mask; a.a = half_mask_ratio; a.tok = tok; a.tok_ld = tok_ld;
-    a.d_seed = drop_seed; a.d_n = drop_n; a.d_p = drop_p; a.d_out = drop_out;
+    const int nb_d = fill_regions(mask_regions, n_mask_regions, a.masks, "step_prologue");
+    if (nb_d < 0) return nb_d;
     a.nb_s = (int)((batch * n_neg + 255) / 256);
     a.nb_e = n_rows > 0 ? grid_for((n_rows * (int64_t)dim + 3) / 4) : 0;          // (the dwordx4 form covers four elements per thread; the scalar form strides)
-    const int nb_d = (int)((drop_n + 1023) / 1024);
     const int total = a.nb_s + a.nb_e + nb_d;
     if (total == 0) return SNAG_OK;
     hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);

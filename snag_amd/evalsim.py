@@ -136,6 +136,13 @@ def rank_metrics_sharded(emb_left, emb_right, csls_k=0, top_k=(1, 10, 50), rank=
 
     nl = hi - lo
     k = int(csls_k) if csls_k and csls_k > 0 else 0
+    if k:
+        # decided from (n, world, k), which every rank knows: all ranks raise together, before any collective (a rank that raised
+        # alone would leave the others waiting in the all-gather)
+        short = [g for g in range(world) if 0 < min(n, (g + 1) * per) - min(n, g * per) < k]
+        if short:
+            raise ValueError(f"rank_metrics_sharded: every non-empty shard needs at least csls_k = {k} rows; with n = {n} over {world} ranks "
+                             f"rank(s) {short} would hold fewer")
     r1 = r2 = None
     rl_loc = torch.zeros(per, device=dev, dtype=torch.int32)
     diag_loc = torch.zeros(per, device=dev, dtype=f32)
@@ -144,8 +151,6 @@ def rank_metrics_sharded(emb_left, emb_right, csls_k=0, top_k=(1, 10, 50), rank=
     if nl > 0:
         block = pairwise_distances(emb_left[lo:hi].contiguous(), emb_right, _padded=True)
         if k:
-            if nl < k:
-                raise ValueError("rank_metrics_sharded: every non-empty shard needs at least csls_k rows")
             r1, _ = _neighbourhood(block, k, True)              # row neighbourhoods: complete (a row sees every column); the local r2 is not used
             work = torch.empty(_lib.load().snag_eval_work_floats(nl, m), device=dev, dtype=f32)
             call("snag_col_topk", ptr(block), block.stride(0), nl, m, k, 1, ptr(cand), ptr(work), stream())

@@ -152,13 +152,15 @@ class MKGCHotPath:
         self.slices = {}
         off = 0
 
-        def add(name, *shape):
+        def add(name, *shape, reserve=0):
             nonlocal off
             n = int(math.prod(shape))
             self.slices[name] = (off, tuple(shape))
-            off = _align(off + n)
+            off = _align(off + max(n, reserve))
 
-        add("ent", N, D)
+        # row-sharded: the entity table's region is padded to whole shards (n_pad rows; the pad rows hold zero parameters and zero
+        # gradients for ever), so that the in-place all-gather of the owners' gradient rows applies whatever N and the rank count are
+        add("ent", N, D, reserve=self.shard.n_pad * D if self.shard.sharded else 0)
         add("rel", R, self.sdim)
         for i, fd in enumerate(cfg.feat_dims):
             if cfg.num_proj == 1:
@@ -191,6 +193,7 @@ class MKGCHotPath:
         self.exp_avg_sq = torch.zeros(off, device=self.dev, dtype=f32)
         self.p = {k: self.flat[o:o + math.prod(s)].view(s) for k, (o, s) in self.slices.items()}
         self.g = {k: self.gflat[o:o + math.prod(s)].view(s) for k, (o, s) in self.slices.items()}
+        self.g_ent_pad = self.gflat[:self.shard.n_pad * D].view(self.shard.n_pad, D) if self.shard.sharded else self.g["ent"]
         self._init_params()
         self._seg_end = torch.tensor([e for _, e, _ in self.param_groups], device=self.dev, dtype=torch.int64)
         self._seg_wd = torch.tensor([w for _, _, w in self.param_groups], device=self.dev, dtype=f32)
@@ -248,17 +251,34 @@ class MKGCHotPath:
         # ProjectionHead dropout masks (num_proj=2, proj_dropout > 0): one [rows, D] keep mask per modality, drawn per step
         self.keep_proj = (torch.ones(len(cfg.feat_dims), max(Nl, 1), D, device=dev, dtype=torch.uint8)
                           if (cfg.num_proj == 2 and cfg.proj_dropout > 0) else None)
+        # Every mask that covers entity rows is a REGION of a global Philox stream, keyed on the global index of its first element
+        # (snag_bernoulli_regions): a rank that owns rows [lo, lo + Nl) draws exactly the bytes the single rank draws for them, so the
+        # G-rank step equals the 1-rank step with dropout and noise on (SURVEY.md par. 8e)
+        regs = []
+        for l in range(L):
+            regs.append((cfg.seed * 131 + 17 * l + 1, lo * H * M * M, Nl * H * M * M, cfg.dropout, self.keep_probs[l]))
+            regs.append((cfg.seed * 131 + 17 * l + 2, lo * M * D, Nl * M * D, cfg.dropout, self.keep_attn[l]))
+            if ffn:
+                regs.append((cfg.seed * 131 + 17 * l + 3, lo * M * D, Nl * M * D, cfg.dropout, self.keep_ffn[l]))
+        if len(regs) > _lib.MAX_MASK_REGIONS:
+            raise NotImplementedError(f"{len(regs)} dropout masks per step: the step prologue draws at most {_lib.MAX_MASK_REGIONS} (num_layers <= "
+                                      f"{_lib.MAX_MASK_REGIONS // (3 if ffn else 2)})")
+        self._drop_regions = self._regions(regs)
+        self._proj_regions = (self._regions([(cfg.seed * 131 + 7 + i, lo * D, Nl * D, cfg.proj_dropout, self.keep_proj[i]) for i in range(len(cfg.feat_dims))])
+                              if self.keep_proj is not None else None)
         self.tick = torch.zeros(1, device=dev, dtype=torch.int64)      # device-side step counter
         # noise state (model/SNAG.py:86-98)
         self.noisy = [f.clone() for f in self.feats]
         self.noisy_t = [self._transposed(f) for f in self.feats]
         self.ent_noise = torch.zeros(N, D, device=dev)                 # whole table on every rank (same seed): a rank reads its rows
         self.ent_noise_mask = torch.zeros(N, device=dev, dtype=torch.uint8)
-        self.row_mask = torch.zeros(max(Nl, 1), device=dev, dtype=torch.uint8)
+        # row masks of the feature-noise refresh, two generations per modality (the refresh rewrites only rows in the new or the old mask)
+        self.row_mask = [[torch.zeros(max(Nl, 1), device=dev, dtype=torch.uint8) for _ in range(2)] for _ in cfg.feat_dims]
         self.noise_active = False
         self.noise_epoch = 0
         self.training = True
         self.probe = None                # optional {tag: timer with .wrap(fn)}: bench.py's per-kernel HIP-event timers
+        self.marks = None                # optional list: (phase name, HIP event on the launch stream) appended at the step's phase boundaries
         self._loss_part = None
         self._score_bwd_scale = None
         self._ticket = torch.zeros(_lib.SCORE_TICKET_WORDS, device=dev, dtype=torch.int32)      # last-block ticket of the fused scorer (self-resetting)
@@ -409,33 +429,60 @@ class MKGCHotPath:
             return None
         return self.keep_proj[i].data_ptr()
 
+    def _mark(self, name):
+        """Phase boundary on the launch stream (bench.py's phases_us: fusion forward, all-gather wait, scorer, reduce-scatter wait,
+        backward, exposed all-reduce wait, clip + AdamW).  The compute stream waits for every collective, so an event behind one
+        includes the time the stream sat waiting for it."""
+        if self.marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.marks.append((name, e))
+
     def _probed(self, tag, fn, *a, **k):
         tm = self.probe.get(tag) if self.probe else None
         return tm.wrap(fn)(*a, **k) if tm is not None else fn(*a, **k)
 
+    @staticmethod
+    def _regions(rows):
+        """(seed, offset, n, p, tensor) rows -> a host array of snag_mask_region."""
+        arr = (_lib.MaskRegion * len(rows))()
+        for a, (seed, off, n, p, out) in zip(arr, rows):
+            a.seed, a.offset, a.n, a.p, a.invert, a.out = int(seed) & (2 ** 64 - 1), int(off), int(n), float(p), 0, out.data_ptr()
+        return arr
+
     def update_noise(self, seed: Optional[int] = None):
-        """Once per epoch (README "noise-level: epoch", main.py:253-254 -> SNAG.update_noise model/SNAG.py:86-98)."""
+        """Once per epoch (README "noise-level: epoch", main.py:253-254 -> SNAG.update_noise model/SNAG.py:86-98) -- or per step
+        ("noise-level: step").  Launches: ONE for the three row masks (rand < ratio, drawn inverted: no xor pass), one refresh per
+        modality that rewrites only the rows in the new or the previous mask (and the transposed copy in the same pass), the entity
+        table's column statistics and its noise rows.  Every stream is keyed on global rows: all ranks draw one experiment."""
         cfg = self.cfg
         st = stream()
         from . import ops
         if self.feat_stats is None:            # clean-table statistics are constants (get_mean_std, :77-84)
             self.feat_stats = [ops.colstats(f) for f in self.feats]
+            self._stat_work = torch.empty(self.lib.snag_colstats_work_floats(cfg.dim), device=self.dev)
+            self._ent_stats = (torch.empty(cfg.dim, device=self.dev), torch.empty(cfg.dim, device=self.dev))
+        elif getattr(self, "_stat_work", None) is None:
+            self._stat_work = torch.empty(self.lib.snag_colstats_work_floats(cfg.dim), device=self.dev)
+            self._ent_stats = (torch.empty(cfg.dim, device=self.dev), torch.empty(cfg.dim, device=self.dev))
         self.noise_epoch += 1
         base = (cfg.seed if seed is None else seed) * 1000003 + self.noise_epoch * 7919
-        N, D, Nl = cfg.n_ent, cfg.dim, self.shard.n_loc
-        fbase = base + 104723 * self.shard.rank               # feature rows are this rank's own: its own stream
+        N, D, Nl, lo = cfg.n_ent, cfg.dim, self.shard.n_loc, self.shard.lo
+        gen = self.noise_epoch & 1
+        rows = [(base + 11 * i + 1, lo, Nl, float(cfg.noise_ratio), self.row_mask[i][gen]) for i in range(len(self.feats))]
+        rows.append((base + 102, 0, N, float(cfg.noise_ratio) * 0.5, self.ent_noise_mask))
+        regs = self._regions(rows)
+        for a in regs:
+            a.invert = 1                       # row mask = rand < ratio (model/SNAG.py:68, :97)
+        call("snag_bernoulli_regions", regs, len(regs), None, st)
         for i, f in enumerate(self.feats):
-            # row mask = rand(N) < noise_ratio  ==  NOT keep with keep = (u >= noise_ratio)
-            call("snag_dropout_keep_mask", fbase + 11 * i + 1, None, Nl, float(cfg.noise_ratio), ptr(self.row_mask), st)
-            self.row_mask.bitwise_xor_(1)
             mean, std = self.feat_stats[i]
-            call("snag_noise_apply", ptr(f), Nl, f.shape[1], ptr(mean), ptr(std), ptr(self.row_mask), None, None,
-                 fbase + 11 * i + 2, float(cfg.mask_ratio), ptr(self.noisy[i]), st)
-            self._transposed(self.noisy[i], self.noisy_t[i])     # once per epoch
-        mean, std = ops.colstats(self.p["ent"])
+            call("snag_noise_refresh", ptr(f), Nl, f.shape[1], ptr(mean), ptr(std), ptr(self.row_mask[i][gen]),
+                 ptr(self.row_mask[i][gen ^ 1]) if self.noise_active else None, base + 11 * i + 2, lo, float(cfg.mask_ratio),
+                 ptr(self.noisy[i]), ptr(self.noisy_t[i]), self.ld_t, st)
+        mean, std = self._ent_stats
+        call("snag_colstats", ptr(self.p["ent"]), N, D, None, N, ptr(mean), ptr(std), ptr(self._stat_work), st)
         call("snag_gaussian_fill", base + 101, N, D, ptr(mean), ptr(std), ptr(self.ent_noise), st)
-        call("snag_dropout_keep_mask", base + 102, None, N, float(cfg.noise_ratio) * 0.5, ptr(self.ent_noise_mask), st)
-        self.ent_noise_mask.bitwise_xor_(1)
         self.noise_active = True
 
     # ------------------------------------------------------------------------------------------
@@ -481,7 +528,7 @@ class MKGCHotPath:
         st = self._st = stream()
         noisy = self.training and cfg.add_noise and self.noise_active
         if self.keep_proj is not None and self.training:
-            call("snag_dropout_keep_mask", cfg.seed + 3 + 7919 * self.shard.rank, ptr(self.tick), self.keep_proj.numel(), cfg.proj_dropout, ptr(self.keep_proj), st)
+            call("snag_bernoulli_regions", self._proj_regions, len(self._proj_regions), ptr(self.tick), st)
         MD = M * D
         x0p = self.x0.data_ptr()
         # one launch: (negative tails,) structural token, Bert dropout masks -- three independent, under-filled grids side by side
@@ -495,7 +542,7 @@ class MKGCHotPath:
             s_args = (0, ptr(self.tick), None, None, None, 0, 0, N, cfg.n_rel, None, 0, None)
         call("snag_step_prologue", *s_args, self.p["ent"].data_ptr() + 4 * lo * D, Nl, D, (self.ent_noise.data_ptr() + 4 * lo * D) if noisy else None,
              (self.ent_noise_mask.data_ptr() + lo) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD,
-             cfg.seed + 1 + 7919 * self.shard.rank, self.keep_all.numel() if drop else 0, cfg.dropout if drop else 0.0, ptr(self.keep_all) if drop else None, st)
+             self._drop_regions if drop else None, len(self._drop_regions) if drop else 0, st)
         l1 = []
         for i, fd in enumerate(cfg.feat_dims):
             feat_t = self.noisy_t[i] if noisy else self.feats_t[i]          # [fd, Nl]
@@ -525,13 +572,15 @@ class MKGCHotPath:
         else:
             self._repr, self._repr_ld = self.hidden.data_ptr() + 4 * self.g_slot * D, MD
         D = self.sdim                                          # from here on: the width the scorer works at
+        self._mark("fusion_fwd")
         if self.shard.sharded:
             # every rank's compact read-outs -> the one [N, D] table all ranks score against (the only data-path collective of the
             # forward; stream-ordered: the compute stream waits for it, the host does not)
             self.shard.all_gather(self.repr_full, self.repr_mean if cfg.joint_way == "Mformer_hd_mean" else (self.joint if self.concat else self.hidden))
             self._repr, self._repr_ld = self.repr_full.data_ptr(), D
+            self._mark("all_gather")
         B, K = neg_t.shape
-        if self._loss_part is None or self._loss_part.shape[0] != B:
+        if self._loss_part is None or self._loss_part.shape[0] != B or self._neg.shape[1] != K:       # keyed on (B, K): eval scores one dummy negative
             self._loss_part = torch.empty(B, device=self.dev)
             self._pos = torch.empty(B, device=self.dev)
             self._neg = torch.empty(B, K, device=self.dev)
@@ -551,6 +600,7 @@ class MKGCHotPath:
                          ptr(self._loss_part), ptr(self.loss), ptr(self._ticket), tgt, tld, ptr(self.g["rel"]), 1, ptr(work), work.numel(), st)
             self._score_bwd_scale = float(grad_scale)
             self._d_repr_clean = False
+            self._mark("score")
             if want_scores:
                 return self.loss, self._pos, self._neg
             return self.loss
@@ -561,6 +611,7 @@ class MKGCHotPath:
                          ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K, float(cfg.margin), float(grad_scale), ptr(self._pos), ptr(self._neg),
                          ptr(self._loss_part), ptr(self.loss), ptr(self._ticket), d_repr, d_ld, ptr(self.g["rel"]), st)
             self._score_bwd_scale = float(grad_scale)
+            self._mark("score")
             if want_scores:
                 return self.loss, self._pos, self._neg
             return self.loss
@@ -626,6 +677,7 @@ class MKGCHotPath:
         if self.shard.sharded:
             # every rank scattered its triples' gradients over ALL entity rows: the owners get the sums of their rows
             self.shard.reduce_scatter(self.d_repr, self.d_repr_full)
+            self._mark("reduce_scatter")
         if cfg.joint_way == "Mformer_hd_mean":
             call("snag_token_mean_bwd", ptr(self.d_repr), Nl, M, D, ptr(self.d_hidden), 0 if cfg.scorer == "segmented" else 1, st)
         # the entity table's gradient (this rank's rows only; the others stay zero from construction) = the structural token's rows of
@@ -647,7 +699,7 @@ class MKGCHotPath:
         buckets = self.grad_buckets() if reducer is not None else None
         if reducer is not None:
             if self.shard.sharded:       # entity rows: each rank holds its own slice -> all-gather; relations: summed
-                reducer.start_gather(self.g["ent"], self.shard)
+                reducer.start_gather(self.g_ent_pad, self.shard)
                 reducer.start(self.g["rel"].reshape(-1))
             else:
                 reducer.start(buckets[0])
@@ -699,6 +751,7 @@ class MKGCHotPath:
                 call("snag_colsum", dx0 + 4 * i * D, Nl, D, MD, ptr(self.g[f"proj{i}.bias"]), 0, wk, st)
             if reducer is not None:
                 reducer.start(buckets[2 + i])
+        self._mark("backward")
 
     def optimizer_step(self, grad_scale=1.0):
         cfg = self.cfg
@@ -726,6 +779,12 @@ class MKGCHotPath:
         else:
             self.backward()
             if allreduce is not None:
+                if self.shard.sharded:
+                    # this rank wrote ITS rows of the entity-table gradient only; the others still hold what the previous exchange
+                    # left there, and a summed exchange would add them in once per rank
+                    lo, hi = self.shard.lo, self.shard.lo + self.shard.n_loc
+                    self.g_ent_pad[:lo].zero_()
+                    self.g_ent_pad[hi:].zero_()
                 allreduce(self.gflat)
         self.optimizer_step()
         return self.loss
@@ -759,17 +818,18 @@ class MKGCHotPath:
         n = h.shape[0]
         self._check_triples(h, r, t)
         dp = allreduce is not None and dist.is_available() and dist.is_initialized()
+        group = getattr(allreduce, "group", None)          # a sub-group reducer: counts and ranks are those of ITS group
         if rank is None:
-            rank = dist.get_rank() if dp else 0
+            rank = dist.get_rank(group) if dp else 0
         if world is None:
-            world = dist.get_world_size() if dp else 1
+            world = dist.get_world_size(group) if dp else 1
         epoch_seed = self.cfg.seed * 104729 + self.noise_epoch if seed is None else seed
         sample_seed = epoch_seed * world + rank
         if self.cfg.add_noise:
             self.update_noise()
         # the permutation is per rank too: every rank shuffles its OWN shard
         perm = torch.randperm(n, device=self.dev, generator=torch.Generator(device=self.dev).manual_seed(sample_seed))
-        steps = common_step_count(n, batch_size) if dp else -(-n // batch_size)
+        steps = common_step_count(n, batch_size, group=group) if dp else -(-n // batch_size)
         total = torch.zeros((), device=self.dev, dtype=f32)
         for lo, hi in (step_bounds(n, steps) if dp else [(lo, min(n, lo + batch_size)) for lo in range(0, n, batch_size)]):
             idx = perm[lo:hi]
@@ -914,7 +974,8 @@ class MKGCHotPath:
             moments[name] = {k: v.clone() for k, v in self._logical(views).items()}
         return {"cfg": asdict(self.cfg), "params": {k: v.clone() for k, v in self.named_parameters().items()}, **moments,
                 "tick": self.tick.clone(), "noise_epoch": self.noise_epoch, "noise_active": self.noise_active,
-                "noisy": [x.clone() for x in self.noisy], "ent_noise": self.ent_noise.clone(), "ent_noise_mask": self.ent_noise_mask.clone()}
+                "noisy": [x.clone() for x in self.noisy], "ent_noise": self.ent_noise.clone(), "ent_noise_mask": self.ent_noise_mask.clone(),
+                "row_mask": [[m.clone() for m in pair] for pair in self.row_mask]}
 
     def load_state_dict(self, sd):
         with torch.no_grad():
@@ -931,6 +992,9 @@ class MKGCHotPath:
                 self._transposed(self.noisy[i], self.noisy_t[i])
             self.ent_noise.copy_(sd["ent_noise"])
             self.ent_noise_mask.copy_(sd["ent_noise_mask"])
+            for pair, saved in zip(self.row_mask, sd["row_mask"]):        # the next refresh takes back the rows of the CURRENT mask
+                for m, x in zip(pair, saved):
+                    m.copy_(x)
 
     def save_checkpoint(self, path):
         """``torch.save`` of ``state_dict()`` (the reference's checkpoints are ``torch.save(model.state_dict())`` too, main.py:482-500)."""

@@ -117,7 +117,7 @@ _TICKETS = {}
 
 def _ticket(device):
     """SNAG_SCORE_TICKET_WORDS zeroed uint32 per device for the fused scorer's last-block reduction (the kernel leaves it zero again)."""
-    key = (device.type, device.index)
+    key = (device.type, device.index, stream())          # per stream: two streams' launches must not share the ticket words
     if key not in _TICKETS:
         _TICKETS[key] = torch.zeros(_lib.SCORE_TICKET_WORDS, device=device, dtype=torch.int32)
     return _TICKETS[key]
@@ -149,7 +149,8 @@ def score_margin_fwd_bwd(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, d_ent
     return loss, pos, neg, loss_part, d_ent, d_rel
 
 
-_SEG_WORK = {}
+_SEG_WORK = {}           # at most _SEG_WORK_MAX workspaces, least recently used dropped (ragged batch sizes would otherwise keep one each)
+_SEG_WORK_MAX = 4
 
 
 def score_margin_fwd_bwd_seg(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, d_ent=None, d_rel=None, write_untouched=True):
@@ -170,10 +171,14 @@ def score_margin_fwd_bwd_seg(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, d
         raise ValueError("gradient buffers must match the table shapes")
     N, R, D = ent.shape[0], rel.shape[0], ent.shape[1]
     nbytes = _lib.load().snag_score_seg_work_bytes(N, R, B, K, D)
-    key = (ent.device.type, ent.device.index, N, R, B, K, D)
+    # The workspace and the ticket words belong to ONE stream at a time (the launches hand their header phase and counters to each
+    # other in stream order): they are keyed by the stream as well, so two streams never share them.
+    key = (ent.device.type, ent.device.index, stream(), N, R, B, K, D)
     if key not in _SEG_WORK:                     # zeroed ONCE; every launch leaves it ready for the next
+        while len(_SEG_WORK) >= _SEG_WORK_MAX:
+            _SEG_WORK.pop(next(iter(_SEG_WORK)))
         _SEG_WORK[key] = torch.zeros((nbytes + 255) // 256 * 256, device=ent.device, dtype=torch.uint8)
-    work = _SEG_WORK[key]
+    work = _SEG_WORK[key] = _SEG_WORK.pop(key)   # (re-inserted: most recently used last)
     pos = torch.empty(B, device=ent.device, dtype=f32)
     neg = torch.empty(B, K, device=ent.device, dtype=f32)
     loss_part = torch.empty(B, device=ent.device, dtype=f32)

@@ -126,11 +126,17 @@ class GradAllReduce:
 
     def start_gather(self, full: torch.Tensor, shard: RowShard):
         """A gradient region in which every rank wrote ONLY the rows it owns (the entity table under row-sharded fusion): an
-        in-place all-gather moves 1/world of what the summed all-reduce of the same region would.  Needs equal unpadded shards
-        (n_rows divisible by world); otherwise the region goes through the all-reduce (the foreign rows are zeros)."""
+        in-place all-gather moves 1/world of what the summed all-reduce of the same region would.  ``full`` is the region padded
+        to whole shards, [shard.n_pad, D] (the engine reserves the pad rows inside its flat buffer).  A region WITHOUT the pad rows
+        (n_rows not divisible by world) cannot be gathered in place: its foreign rows are cleared first -- they hold what the
+        previous exchange left there -- and it goes through the summed all-reduce."""
         if self.world <= 1 and not self.force:
             return
-        if shard.n_pad != shard.n_rows or full.shape[0] != shard.n_rows:
+        if full.shape[0] != shard.n_pad:
+            if full.shape[0] != shard.n_rows:
+                raise ValueError(f"start_gather: region of {full.shape[0]} rows, shards cover {shard.n_rows} (padded {shard.n_pad})")
+            full[:shard.lo].zero_()
+            full[shard.lo + shard.n_loc:].zero_()
             return self.start(full.reshape(-1))
         if not hasattr(self, "_pending"):
             self._pending = []
@@ -149,7 +155,7 @@ class GradAllReduce:
         self._pending = []
 
     def __call__(self, flat: torch.Tensor):
-        if self.world <= 1:
+        if self.world <= 1 and not self.force:
             return flat
         n = flat.numel()
         if n <= self.bucket_elems:

@@ -115,7 +115,7 @@ def _structs():
                 elif base.replace("const", "").strip().startswith("snag_"):
                     kind = "struct"
                 else:
-                    kind = {"int32_t": "i32", "int": "i32", "int64_t": "i64", "float": "f32"}[base.replace("const", "").strip()]
+                    kind = {"int32_t": "i32", "int": "i32", "int64_t": "i64", "uint64_t": "u64", "float": "f32"}[base.replace("const", "").strip()]
                 fields.append((nm, kind))
         out[m.group(1)] = fields
     return out
@@ -124,7 +124,7 @@ def _structs():
 def test_ctypes_structures_match_the_header_structs():
     from snag_amd import _lib
     pairs = {"snag_gemm_desc": _lib.GemmDesc, "snag_fusion_layer": _lib.FusionLayer, "snag_fusion_layer_grad": _lib.FusionLayerGrad,
-             "snag_fusion_desc": _lib.FusionDesc, "snag_fusion_bwd_desc": _lib.FusionBwdDesc}
+             "snag_fusion_desc": _lib.FusionDesc, "snag_fusion_bwd_desc": _lib.FusionBwdDesc, "snag_mask_region": _lib.MaskRegion}
     structs = _structs()
     assert set(structs) == set(pairs)
 
@@ -133,7 +133,7 @@ def test_ctypes_structures_match_the_header_structs():
             return "struct"
         if c in (ctypes.c_void_p,) or hasattr(c, "contents") or (hasattr(c, "_type_") and not isinstance(c._type_, str)):
             return "ptr"
-        return {ctypes.c_int32: "i32", ctypes.c_int: "i32", ctypes.c_int64: "i64", ctypes.c_float: "f32"}[c]
+        return {ctypes.c_int32: "i32", ctypes.c_int: "i32", ctypes.c_int64: "i64", ctypes.c_uint64: "u64", ctypes.c_float: "f32"}[c]
 
     for name, cls in pairs.items():
         got = [(n, kind(t)) for n, t in cls._fields_]

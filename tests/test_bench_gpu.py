@@ -40,6 +40,16 @@ def test_bench_single_gpu_line():
         assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1.5 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
 
 
+def test_bench_noise_level_step_refreshes_the_noise_in_every_timed_step():
+    """README "noise-level: step": --noise-level step puts a refresh into every timed step; the line also carries the measured cost of one refresh."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3", "--cpu-seconds", "0", "--no-kernel-timers",
+                        "--noise-level", "step"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, BENCH_PHASES="1"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    o = _json_line(p.stdout)
+    assert o["config"]["noise_level"] == "step" and 0 < o["noise_refresh_us"] < 2000
+    assert o["phases_us"]["noise_refresh"] > 0 and "noise_refresh" in o["phases_us"]["order"]
+
+
 @pytest.mark.parametrize("extra,scaling,per_gpu", [([], "weak", 256), (["--scaling", "strong"], "strong", 128), (["--replicate-fusion"], "weak", 256)])
 def test_bench_two_rank_dry_run(extra, scaling, per_gpu):
     env = dict(os.environ, BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -52,6 +62,13 @@ def test_bench_two_rank_dry_run(extra, scaling, per_gpu):
     assert o["n_gpus"] == 2 and o["scaling"] == scaling and o["config"]["batch_per_gpu"] == per_gpu and o["config"]["global_batch"] == 2 * per_gpu
     assert ("row-sharded" in o["config"]["fusion"]) == ("--replicate-fusion" not in extra)
     assert o["value"] == pytest.approx(2 * per_gpu * 4 / (o["ms_per_step"] * 4e-3), rel=1e-6) and o["config"]["final_loss"] > 0
+    # the N > 1 line splits the step into phases (HIP events on the compute stream): what a first real 8-GPU run is diagnosed with
+    ph = o["phases_us"]
+    want = ["fusion_fwd", "score", "backward", "allreduce_wait", "clip_adamw"] + (["all_gather", "reduce_scatter"] if "--replicate-fusion" not in extra else [])
+    for k in want:
+        assert ph[k] > 0, (k, ph)
+    assert ph["comm_exposed_us"] > 0 and ph["compute_us"] > 0 and ph["steps_sampled"] >= 1
+    assert abs(ph["comm_exposed_us"] + ph["compute_us"] - sum(ph[k] for k in ph["order"])) < 1e-6 * (ph["compute_us"] + ph["comm_exposed_us"]) + 1e-3
 
 
 def test_bench_stress_config_single_and_two_rank_dry_run():
