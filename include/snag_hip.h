@@ -108,7 +108,8 @@ SNAG_API int snag_score_margin_fwd_bwd(const float* ent, int64_t ent_ld, int64_t
  * with 0 only the rows of the batch's own heads, tails and negative tails are written (a large, otherwise clean buffer: config 5).
  * |grad_scale * 2 * n_neg * (occurrences of one entity in the batch)| must stay below 2^29 (fixed point with 32 fractional bits).
  * work: snag_score_seg_work_bytes(...) bytes, 256-byte aligned, zeroed ONCE by the caller (every launch leaves it ready for the
- * next); dim % 4 == 0, 16-byte aligned rows; launches sharing a workspace must be stream-ordered. */
+ * next); dim % 4 == 0, 16-byte aligned rows; launches sharing a workspace must be stream-ordered.  The summed loss is formed by one
+ * extra workgroup of pass B (fixed order); `ticket` is unused since round 3 and may be NULL. */
 SNAG_API int64_t snag_score_seg_work_bytes(int64_t n_ent, int64_t n_rel, int64_t batch, int n_neg, int dim);
 SNAG_API int snag_score_margin_fwd_bwd_seg(const float* ent, int64_t ent_ld, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
                           const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
@@ -116,6 +117,26 @@ SNAG_API int snag_score_margin_fwd_bwd_seg(const float* ent, int64_t ent_ld, int
                           float* pos, float* neg, float* loss_part, float* loss, uint32_t* ticket,
                           float* d_ent, int64_t d_ent_ld, float* d_rel, int write_untouched,
                           void* work, int64_t work_bytes, void* stream);
+
+/* The segmented form for tables far LARGER than a batch's footprint (BASELINE configs[4]: 1M entities, 134k entries per batch): pass A
+ * additionally appends every destination to a compact list when it receives its FIRST entry (the slot atomic returns 0), and pass B
+ * walks that list -- at most batch * (n_neg + 3) destinations -- instead of all n_ent + n_rel counters.  Only touched rows of d_ent /
+ * d_rel are written (overwritten, not accumulated into): the caller keeps the rest of the buffers zero.  Hot rows of skewed index
+ * distributions: entries beyond a destination's 16 inline slots go to an open-addressed hash of 64-entry chunks keyed (dest, chunk)
+ * (wait-free insertion, one home per entry) and are summed in 64-bit fixed point -- bit-reproducible whatever the arrival order.
+ * Same scores / losses / gradients as snag_score_margin_fwd_bwd_seg.  _bf16: tables of raw bfloat16 bit patterns (8-byte aligned rows),
+ * fp32 arithmetic and gradients.  work: snag_score_touched_work_bytes(...) bytes, 256-byte aligned, zeroed ONCE by the caller. */
+SNAG_API int64_t snag_score_touched_work_bytes(int64_t n_ent, int64_t n_rel, int64_t batch, int n_neg, int dim);
+SNAG_API int snag_score_margin_fwd_bwd_touched(const float* ent, int64_t ent_ld, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+                          const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                          int64_t batch, int n_neg, float margin, float grad_scale,
+                          float* pos, float* neg, float* loss_part, float* loss,
+                          float* d_ent, int64_t d_ent_ld, float* d_rel, void* work, int64_t work_bytes, void* stream);
+SNAG_API int snag_score_margin_fwd_bwd_touched_bf16(const uint16_t* ent, int64_t ent_ld, int64_t n_ent, const uint16_t* rel, int64_t n_rel, int dim,
+                          const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                          int64_t batch, int n_neg, float margin, float grad_scale,
+                          float* pos, float* neg, float* loss_part, float* loss,
+                          float* d_ent, int64_t d_ent_ld, float* d_rel, void* work, int64_t work_bytes, void* stream);
 
 /* The same three training entries over bf16 TABLES (raw bfloat16 bit patterns; BASELINE config 5: |E| = 1M, dim 256, 128 negatives):
  * fp32 arithmetic, fp32 scores, fp32 gradient accumulation -- only the gathered rows are 2-byte.  d_ent / d_rel stay fp32. */
@@ -223,10 +244,25 @@ typedef struct snag_gemm_desc {
      * ? mirror_scale : 1).  The entity table's gradient (the structural token's rows of d_x0 through the noise blend) leaves the
      * Mformer backward's last GEMM this way instead of through a copy launch. */
     float* mirror; int64_t ldmirror; const uint8_t* mirror_rowmask; float mirror_scale;
+    /* 1: A points at the TILED copy of the [M, K] operand made by snag_tile_a_f32 (lda and a_kcontig are ignored).  Long-K products
+     * with N <= 128 only (the first projections X W^T and their weight gradients X^T dY: the eight-wave row-private tile): a lane's
+     * eight values of a k-tile are two 16-byte loads of one contiguous KiB per wave-instruction instead of eight 4-byte loads. */
+    int32_t a_tiled;
+    /* 1: C is stored transposed -- value (m, n) goes to C[n * ldc + m], ldc >= M (accumulate, bias, act, masks, add1 / add2 still index
+     * their [M, N] operands by (m, n)); no pre_act, no mirror.  The weight gradient dW^T = X^T dY lands in the nn.Linear layout
+     * [out, in] this way, and an activation gradient in the K-contiguous layout its consumer streams fastest. */
+    int32_t c_transposed;
 } snag_gemm_desc;
 
 SNAG_API int snag_gemm_f32(const snag_gemm_desc* desc, void* stream);
 SNAG_API int64_t snag_gemm_workspace_floats(int M, int N, int K);
+/* The tiled copy of an operand A [M, K] for snag_gemm_desc.a_tiled (src: K-contiguous [M, ld >= K] or row-contiguous [K, ld >= M]):
+ * blocks of 32 rows x 16 k, block (mb, kt) at ((mb * ceil(K / 16)) + kt) * 512 floats, inside it [c (2)][lh (2)][li (32)][j (4)] =
+ * A(32 mb + li, 16 kt + 8 c + 4 lh + j), zero-padded to whole blocks.  snag_tile_a_floats(M, K) floats, 16-byte aligned.  Made once
+ * per epoch for the raw feature tables (the first projection's operand, model/SNAG_tools.py:134-150, is constant between noise
+ * refreshes, model/SNAG.py:86-92). */
+SNAG_API int64_t snag_tile_a_floats(int64_t M, int64_t K);
+SNAG_API int snag_tile_a_f32(const float* src, int64_t ld, int64_t M, int64_t K, int kcontig, float* dst, void* stream);
 /* Two independent problems; when they have the same shape, layouts and split decision they run as ONE launch (the step's many
  * [rows x D x D]-sized GEMMs are grids of fewer workgroups than the chip has CUs: a pair fills it once instead of twice), otherwise
  * one after the other.  Results are those of two snag_gemm_f32 calls, bit for bit.  Split-K workspaces must be distinct. */

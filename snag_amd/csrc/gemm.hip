@@ -27,6 +27,7 @@ struct Epilogue {
     int64_t ld2;
     int accumulate;         // C += result instead of C = result
     int M, N;
+    int ct;                 // C is stored TRANSPOSED: value (m, n) goes to C[n * ldc + m] (element stores; no pre / mirror)
     int fast;               // host-decided: the dwordx4 path of operator()(m, n, float4) is legal
     float* mirror;          // optional second copy of the final values, rows scaled where mirror_mask[m] != 0
     int64_t ldmirror;
@@ -36,7 +37,7 @@ struct Epilogue {
     __device__ __forceinline__ float one(int m, int n, float v) const {
         v *= alpha;
         if (bias) v += bias[n];
-        if (pre) pre[(int64_t)m * ldc + n] = v;
+        if (pre && !ct) pre[(int64_t)m * ldc + n] = v;
         if (act == 1) v = fmaxf(v, 0.f);
         else if (act == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
         else if (act == 3) {
@@ -55,7 +56,7 @@ struct Epilogue {
     __device__ __forceinline__ void operator()(int m, int n, float v) const {
         if (m >= M || n >= N) return;
         v = one(m, n, v);
-        float* c = C + (int64_t)m * ldc + n;
+        float* c = ct ? C + (int64_t)n * ldc + m : C + (int64_t)m * ldc + n;
         v = accumulate ? *c + v : v;
         *c = v;
         if (mirror) mirror[(int64_t)m * ldmirror + n] = (mirror_mask && mirror_mask[m]) ? v * mirror_scale : v;
@@ -416,13 +417,14 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     p.xcd = xcd_mode();
     e.C = d->C; e.ldc = d->ldc; e.bias = d->bias; e.alpha = d->alpha; e.act = d->act; e.pre = d->pre_act;
     e.mask = d->keep_mask; e.ldm = d->ldmask > 0 ? d->ldmask : d->N; e.mscale = d->keep_scale; e.add1 = d->add1; e.ld1 = d->ld1; e.add2 = d->add2; e.ld2 = d->ld2;
-    e.accumulate = d->accumulate; e.M = d->M; e.N = d->N; e.aux = d->aux; e.ldaux = d->ldaux;
+    e.accumulate = d->accumulate; e.M = d->M; e.N = d->N; e.aux = d->aux; e.ldaux = d->ldaux; e.ct = d->c_transposed;
+    p.a_nkt = d->a_tiled ? ceil_div(d->K, 16) : 0;
     e.mirror = d->mirror; e.ldmirror = d->ldmirror; e.mirror_mask = d->mirror_rowmask; e.mirror_scale = d->mirror_scale;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     e.fast = (d->ldc % 4 == 0) && al16(d->C) && (!d->bias || al16(d->bias)) && (!d->pre_act || al16(d->pre_act)) &&
              (!d->add1 || (al16(d->add1) && d->ld1 % 4 == 0)) && (!d->add2 || (al16(d->add2) && d->ld2 % 4 == 0)) &&
              (d->act < 3 || (al16(d->aux) && d->ldaux % 4 == 0)) && (!d->keep_mask || (e.ldm % 4 == 0 && ((uintptr_t)d->keep_mask & 3) == 0)) &&
-             (!d->mirror || (al16(d->mirror) && d->ldmirror % 4 == 0));
+             (!d->mirror || (al16(d->mirror) && d->ldmirror % 4 == 0)) && !d->c_transposed;
 
     // Tile choice by padded work x a measured per-configuration factor (tools/tune_gemm.py, tools/tune_gemm_mmea.py, one device):
     //   128x128  when its tiles alone fill the chip; the best loop when both operands are K-contiguous;
@@ -463,7 +465,8 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     static const int pp_off = env_int("SNAG_GEMM_PP_OFF");
     static const int pp_wide = env_int("SNAG_GEMM_PP_WIDE");     // tuning: 256-row tiles needed for the eight-wave form when N > 128 (0 = never)
     const int64_t tiles256 = (int64_t)ceil_div(p.M, 256) * (pn128 / 128);
-    const bool pp = big && kBf16x != 0 && !pp_off && (p.N <= 128 || (pp_wide > 0 && tiles256 >= pp_wide));
+    if (d->a_tiled) { big = true; wide = false; }            // the tiled A layout exists for the eight-wave row-private tile only (gemm_check)
+    const bool pp = (big && kBf16x != 0 && !pp_off && (p.N <= 128 || (pp_wide > 0 && tiles256 >= pp_wide))) || d->a_tiled;
     const int64_t tall_tiles = (int64_t)ceil_div(p.M, pp ? 256 : 128) * (pn128 / 128);
     const int64_t tiles = wide ? wide_tiles : big ? (kBf16x != 0 ? tall_tiles : big_tiles) : (pm64 / 64) * (pn128 / 128);
     // split K when the output alone cannot fill 256 CUs (the dW = dY^T X shapes: tiny output, long K)
@@ -524,7 +527,11 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     if (pl.wide) launch_cfg<128, 160, 32, 160>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else
 #endif
-    if (pl.big && pl.pp) launch_cfg<256, 128, 32, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
+    if (d->a_tiled) {
+        dim3 grid(ceil_div(p.N, 128), ceil_div(p.M, 256), splits), block(512);
+        if (d->b_kcontig) hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, false, true, true, Epilogue, true>), grid, block, 0, st, p, e, slab);
+        else hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, false, false, true, Epilogue, true>), grid, block, 0, st, p, e, slab);
+    } else if (pl.big && pl.pp) launch_cfg<256, 128, 32, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else if (pl.big) launch_cfg<128, 128, 32, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else launch_cfg<64, 128, 32, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     int rc = check_launch("snag_gemm_f32");
@@ -651,17 +658,37 @@ int gemm_reduce_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStre
     return gemm_reduce_multi(ds, 2, st);
 }
 
+// one thread = one 16-byte piece of the tiled copy: (block mb, k-tile kt, c, lh, li) <- A(32 mb + li, 16 kt + 8 c + 4 lh + 0..3)
+__global__ __launch_bounds__(256) void tile_a_kernel(const float* __restrict__ src, int64_t ld, int64_t M, int64_t K, int kcontig, float* __restrict__ dst,
+                                                     int64_t nkt, int64_t pieces) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < pieces; t += (int64_t)gridDim.x * 256) {
+        const int li = (int)(t & 31), lh = (int)((t >> 5) & 1), c = (int)((t >> 6) & 1);
+        const int64_t blk = t >> 7, kt = blk % nkt, mb = blk / nkt;
+        const int64_t m = mb * 32 + li, k0 = kt * 16 + 8 * c + 4 * lh;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m < M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < K) v[j] = kcontig ? src[m * ld + k0 + j] : src[(k0 + j) * ld + m];
+        }
+        reinterpret_cast<float4*>(dst)[t] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 int gemm_check(const snag_gemm_desc* d) {
     SNAG_REQUIRE(d != nullptr, SNAG_ERR_ARG, "gemm: null descriptor");
     SNAG_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, SNAG_ERR_ARG, "gemm: negative size M=%d N=%d K=%d", d->M, d->N, d->K);
     if (d->M == 0 || d->N == 0) return SNAG_OK;
     SNAG_REQUIRE(d->C != nullptr, SNAG_ERR_ARG, "gemm: null C");
     SNAG_REQUIRE(d->K == 0 || (d->A && d->B), SNAG_ERR_ARG, "gemm: null A or B");
-    SNAG_REQUIRE(d->ldc >= d->N, SNAG_ERR_ARG, "gemm: ldc=%ld < N=%d", (long)d->ldc, d->N);
-    SNAG_REQUIRE(d->lda >= (d->a_kcontig ? d->K : d->M), SNAG_ERR_ARG, "gemm: lda=%ld too small", (long)d->lda);
+    SNAG_REQUIRE(d->ldc >= (d->c_transposed ? d->M : d->N), SNAG_ERR_ARG, "gemm: ldc=%ld < %s=%d", (long)d->ldc, d->c_transposed ? "M" : "N", d->c_transposed ? d->M : d->N);
+    SNAG_REQUIRE(!d->c_transposed || (!d->pre_act && !d->mirror), SNAG_ERR_UNSUPPORTED, "gemm: a transposed C takes no pre_act / mirror copy");
+    SNAG_REQUIRE(!d->a_tiled || (kBf16x != 0 && kBK == 16 && d->N <= 128 && ((uintptr_t)d->A & 15) == 0), SNAG_ERR_UNSUPPORTED,
+                 "gemm: the tiled A layout feeds the 256 x 128 row-private tile only (N <= 128, 16-byte aligned A)");
+    SNAG_REQUIRE(d->a_tiled || d->lda >= (d->a_kcontig ? d->K : d->M), SNAG_ERR_ARG, "gemm: lda=%ld too small", (long)d->lda);
     SNAG_REQUIRE(d->ldb >= (d->b_kcontig ? d->K : d->N), SNAG_ERR_ARG, "gemm: ldb=%ld too small", (long)d->ldb);
     // the staged loaders address one operand tile with 32-bit byte offsets from a 64-bit base: 128 rows (or 16 k rows) x pitch < 4 GB
-    SNAG_REQUIRE(d->lda < (1 << 22) && d->ldb < (1 << 22), SNAG_ERR_UNSUPPORTED, "gemm: operand pitch lda=%ld / ldb=%ld above 4M elements", (long)d->lda,
+    SNAG_REQUIRE((d->a_tiled || d->lda < (1 << 22)) && d->ldb < (1 << 22), SNAG_ERR_UNSUPPORTED, "gemm: operand pitch lda=%ld / ldb=%ld above 4M elements", (long)d->lda,
                  (long)d->ldb);
     SNAG_REQUIRE(d->act >= 0 && d->act <= 4, SNAG_ERR_ARG, "gemm: act=%d unknown", d->act);
     SNAG_REQUIRE(d->act < 3 || (d->aux && d->ldaux >= d->N), SNAG_ERR_ARG, "gemm: act=%d needs aux [M,N]", d->act);
@@ -681,6 +708,21 @@ extern "C" SNAG_API int snag_gemm_f32(const snag_gemm_desc* d, void* stream) {
     if (rc) return rc;
     if (d->M == 0 || d->N == 0) return SNAG_OK;
     return gemm_dispatch(d, (hipStream_t)stream);
+}
+
+extern "C" SNAG_API int64_t snag_tile_a_floats(int64_t M, int64_t K) {
+    if (M < 0 || K < 0) return 0;
+    return ((M + 31) / 32) * ((K + 15) / 16) * 512;
+}
+
+extern "C" SNAG_API int snag_tile_a_f32(const float* src, int64_t ld, int64_t M, int64_t K, int kcontig, float* dst, void* stream) {
+    SNAG_REQUIRE(M >= 0 && K >= 0 && ld >= (kcontig ? K : M), SNAG_ERR_ARG, "tile_a: bad sizes (M=%ld K=%ld ld=%ld)", (long)M, (long)K, (long)ld);
+    if (M == 0 || K == 0) return SNAG_OK;
+    SNAG_REQUIRE(src && dst && ((uintptr_t)dst & 15) == 0, SNAG_ERR_ARG, "tile_a: null pointer or unaligned destination");
+    const int64_t nkt = (K + 15) / 16, pieces = ((M + 31) / 32) * nkt * 128;
+    hipLaunchKernelGGL(tile_a_kernel, dim3((unsigned)std::min<int64_t>(65536, (pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld, M, K, kcontig, dst,
+                       nkt, pieces);
+    return check_launch("snag_tile_a_f32");
 }
 
 extern "C" SNAG_API int snag_gemm_f32_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, void* stream) {
@@ -729,3 +771,10 @@ extern "C" SNAG_API int snag_gram_f32(const float* Z, int64_t ldz, int n, int k,
 }
 
 extern "C" SNAG_API int64_t snag_gemm_workspace_floats(int M, int N, int K) { return gemm_workspace_floats(M, N, K); }
+
+#if SNAG_GEMM_STAMP
+// diagnostic builds only (not part of the ABI): the s_memtime stamps of the last ping-pong GEMM launch
+extern "C" __attribute__((visibility("default"))) int snag_debug_read_gemm_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(snag::g_gemm_stamps), sizeof(unsigned long long) * 72, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -73,6 +73,21 @@ __host__ __device__ constexpr int swz(int row) { return kBK == 16 ? ((row >> 2) 
 #ifndef SNAG_GEMM_PIN_READS
 #define SNAG_GEMM_PIN_READS 0
 #endif
+#ifndef SNAG_GEMM_STAMP
+#define SNAG_GEMM_STAMP 0                // diagnostic builds only: s_memtime stamps around the halves of four ping-pong iterations (tools/stamp_gemm.py)
+#endif
+#if SNAG_GEMM_STAMP
+__device__ unsigned long long g_gemm_stamps[2 * 4 * 9];
+#define SNAG_STAMP(I, P) do { __builtin_amdgcn_sched_barrier(0); if ((kt >> 2) == 6) stamp[I][P] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SNAG_STAMP(I, P) do { } while (0)
+#endif
+#ifndef SNAG_GEMM_PP_LATE_READS
+#define SNAG_GEMM_PP_LATE_READS 1        // ping-pong loop: B fragments are read in the MATRIX half (in the MFMAs' shadow), three B images
+#endif
+#ifndef SNAG_GEMM_PP_PRIO
+#define SNAG_GEMM_PP_PRIO 0
+#endif
 #ifndef SNAG_GEMM_SK_WAVES
 #define SNAG_GEMM_SK_WAVES 2             // A/B: waves per SIMD the stream-K kernel is compiled for (4: at most 128 registers)
 #endif
@@ -103,6 +118,7 @@ struct GemmOperands {
     int k_per_split;     // K range handled by one blockIdx.z (multiple of kBK); == K rounded up when no split
     int dbg;             // tuning only: nonzero = stop fetching after the first two k-tiles (compute-only ceiling)
     int xcd;             // bit 0: XCD-aware workgroup -> tile mapping (xcd_swizzle); bits 4..: row tiles per group of the grouped order (0 = row-major)
+    int a_nkt;           // A in the tiled layout (snag_tile_a_f32; kernels compiled with A_TILED): k-tiles per 32-row block = ceil(K / 16)
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (observed, never relied on for correctness): ids b and b + 8 share an L2.
@@ -518,6 +534,54 @@ struct FragLoader {
     }
 };
 
+// A in the TILED layout (snag_tile_a_f32): the matrix is cut into blocks of 32 rows x 16 k, block (mb, kt) = 512 floats at
+// ((mb * nkt) + kt) * 512, inside it [c (2)][lh (2)][li (32)][j (4)] holds A(mb * 32 + li, kt * 16 + 8 c + 4 lh + j) -- the order in which
+// the lanes of a wave consume them: the lane's eight values of a k-tile are TWO dwordx4 loads, and each of the two wave-instructions
+// reads one contiguous KiB.  (In-kernel stamps: every vector-memory instruction costs the issuing wave ~45 cycles of its memory half
+// whatever it moves -- 8 dword loads per k-tile for a row-contiguous A, 2 here.)  The buffer is zero-padded to whole blocks.
+struct FragLoaderTiled {
+    float r[4][8];
+    const char* ubase;
+    uint32_t voff;
+    int lh, ablate;
+
+    __device__ __forceinline__ void init(const float* __restrict__ P, int nkt, int row0 /* of the wave */, int nrows, int kbeg, int lane) {
+        lh = lane >> 5;
+        const int nblk = (nrows + 31) >> 5;
+        const int mb = min(row0 >> 5, nblk - 1);               // a wave wholly past the edge reads the last block (its products are never stored)
+        ubase = reinterpret_cast<const char*>(P) + ((int64_t)mb * nkt + (kbeg >> 4)) * 2048;
+        voff = (uint32_t)lane * 16u;
+    }
+    __device__ __forceinline__ int k_of(int j) const { return 4 * lh + (j & 3) + 8 * (j >> 2); }
+    __device__ __forceinline__ void load(int s, int kt, int kleft) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int range = __builtin_amdgcn_readfirstlane(kt * 16 < kleft && !(ablate && kt >= 2) ? (int)0xffffffffu : 0);      // (whole tiles: the padding is zeros)
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, range, 0x00020000);
+        const uint32_t so = (uint32_t)kt * 2048u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, so + 1024u * i, 0);
+            r[s][4 * i + 0] = __uint_as_float(v[0]);
+            r[s][4 * i + 1] = __uint_as_float(v[1]);
+            r[s][4 * i + 2] = __uint_as_float(v[2]);
+            r[s][4 * i + 3] = __uint_as_float(v[3]);
+        }
+#endif
+    }
+    __device__ __forceinline__ void load_tail(int s, int kt, int kleft) { load(s, kt, kleft); }       // the ragged tile is zero-padded in the buffer
+    __device__ __forceinline__ void split(int s, Split3& f) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t h[4], m[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_pair(r[s][2 * j], r[s][2 * j + 1], h[j], m[j], l[j]);
+        using u4 = __attribute__((ext_vector_type(4))) uint32_t;
+        f.h = __builtin_bit_cast(bf16x8, (u4){h[0], h[1], h[2], h[3]});
+        f.m = __builtin_bit_cast(bf16x8, (u4){m[0], m[1], m[2], m[3]});
+        f.l = __builtin_bit_cast(bf16x8, (u4){l[0], l[1], l[2], l[3]});
+#endif
+    }
+};
+
 // a lane's three operand pieces of one 32-row fragment: rows row0 .. row0+31 of an image with BR rows
 template <int BR>
 __device__ __forceinline__ void load_split_fragment(const unsigned char* image, int row, int lh, Split3& f) {
@@ -535,7 +599,7 @@ __device__ __forceinline__ void load_split_fragment(const unsigned char* image, 
 // (With split-bf16 products C(a, b) and C(b, a) differ in their last bits: h*m <-> m*h, h*l <-> l*h under an exchange of the operands,
 // and f32 addition is not associative.  snag_gram_f32 therefore mirrors the upper triangle of its diagonal tiles instead of trusting
 // both halves.)
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, bool A_TILED = false>
 struct GemmCore {
     static constexpr int TM = WM / 32, TN = WN / 32;
     static constexpr int A_BUF = TileLd<BM, A_KC>::floats, B_BUF = TileLd<BN, B_KC>::floats, B_BASE = 2 * A_BUF;
@@ -549,7 +613,9 @@ struct GemmCore {
     // waves stacked along M (each wave's 32 rows are its own): the A operand never goes through the LDS (FragLoader)
     static constexpr bool kRowPrivate = kPresplit && WN == BN && WM == 32;
     static constexpr int PS_STAGE_FLOATS = 6 * ((kRowPrivate ? 0 : BM) + BN) * 16 / 4;          // one stage: both images (B's only when row-private)
-    static constexpr int PS_FLOATS = kPresplit ? 2 * PS_STAGE_FLOATS : 0;
+    // (the eight-wave ping-pong loop keeps THREE B images: a group reads the fragments of tile kt inside its matrix half, while the other
+    // group is already writing tile kt+2 -- SNAG_GEMM_PP_LATE_READS)
+    static constexpr int PS_FLOATS = kPresplit ? ((kRowPrivate && (BM / WM) * (BN / WN) == 8 && SNAG_GEMM_PP_LATE_READS) ? 3 : 2) * PS_STAGE_FLOATS : 0;
     static constexpr int SMEM_FLOATS_ = TILE_FLOATS > STAGE_FLOATS ? TILE_FLOATS : STAGE_FLOATS;
     static constexpr int SMEM_FLOATS = kPresplit ? (PS_FLOATS > STAGE_FLOATS ? PS_FLOATS : STAGE_FLOATS) : SMEM_FLOATS_;
     static_assert(NW == 4 || NW == 8, "four or eight waves per block");
@@ -636,15 +702,17 @@ struct GemmCore {
         const int li = lane & 31, lh = lane >> 5;
         unsigned char* const sm = reinterpret_cast<unsigned char*>(smem);
         constexpr int STAGE = PS_STAGE_FLOATS * 4, A_IMG = kRowPrivate ? 0 : 6 * BM * 16;
+        [[maybe_unused]] constexpr int kPPImages = PS_FLOATS / PS_STAGE_FLOATS;          // B images of the ping-pong loop (3 with late reads)
         const int kleft = kend - kbeg;
         const int nk = kleft / 16;            // full k-tiles; a ragged last one is the tail's
         if constexpr (kRowPrivate) {
             // A: registers only.  Iteration kt multiplies tile kt (A pieces split during iteration kt-1, B fragments out of buffer
             // kt & 1), splits A of tile kt+1 and stages B of tile kt+1 (register sets (kt+1) & 1), fetches tile kt+3 into those sets.
             static_assert(TM == 1, "row-private: one 32-row fragment per wave");
-            FragLoader<A_KC> fa;
+            std::conditional_t<A_TILED, FragLoaderTiled, FragLoader<A_KC>> fa;
             SplitStager<BN, B_KC, NT> sb;
-            fa.init(p.A, p.lda, p.a_vec, m0 + wm0, p.M, kbeg, lane);
+            if constexpr (A_TILED) fa.init(p.A, p.a_nkt, m0 + wm0, p.M, kbeg, lane);
+            else fa.init(p.A, p.lda, p.a_vec, m0 + wm0, p.M, kbeg, lane);
             sb.init(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, tid);
             fa.ablate = p.dbg & 1;
             sb.ablate = p.dbg & 2;
@@ -684,27 +752,67 @@ struct GemmCore {
             // the bytes in flight per CU of the four-wave loops).  B image of tile kt+1: group 0's half is written
             // in interval 2 kt, group 1's in interval 2 kt + 1, both before anyone reads it (group 0 in interval 2 kt + 2); the
             // buffer it replaces was last read in intervals 2 kt - 2 / 2 kt - 1.
+#if SNAG_GEMM_STAMP
+            unsigned long long stamp[4][9] = {};
+#endif
+            // In-kernel stamps (tools/stamp_gemm.py) of the first form of this loop -- fragment reads at the END of the memory half,
+            // behind the split's VALU block -- showed the memory half (780-1,100 cycles with every load landed) longer than the matrix
+            // half (~860): the intervals ran at the pace of the feeding group.  The fragment reads therefore moved INTO the matrix half
+            // (SNAG_GEMM_PP_LATE_READS): twelve ds_read_b128 in the shadow of 24 MFMAs cost next to nothing there (2 per MFMA gap are
+            // free, MI355X_MICROARCH.md "LDS"), the memory half is the split and the loads alone.  A group then reads tile kt one
+            // interval later than before -- while the other group writes tile kt+2 -- hence three B images instead of two.
+            [[maybe_unused]] int rd_off = 0, wr_off = STAGE;               // byte offsets of the image being read (tile kt) / written (tile kt+1)
             [[maybe_unused]] auto pp_iteration = [&](int kt, auto S) {
                 constexpr int set = decltype(S)::value;
-                const int cur = kt & 1;
-                Split3 b[TN];
+                [[maybe_unused]] Split3 b[TN];
+                SNAG_STAMP(set, 0);
+#if !SNAG_GEMM_PP_LATE_READS
 #pragma unroll
-                for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + cur * STAGE, wn0 + 32 * j + li, lh, b[j]);
+                for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + rd_off, wn0 + 32 * j + li, lh, b[j]);
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && SNAG_GEMM_PIN_READS
+                __builtin_amdgcn_sched_barrier(0);      // the fragment reads issue first: their latency runs under the A split
+#endif
+#if SNAG_GEMM_ABLATE       // -DSNAG_GEMM_ABLATE=1 builds only (results are wrong): SNAG_GEMM_DBG & 16 / 64 / 32 / 8 drop the A split / the B split + image write / the loads / the MFMAs
+                if (!(p.dbg & 16)) fa.split(set, a_nxt[0]);
+                if (!(p.dbg & 32)) fa.load(set, kt + 5, kleft);
+                if (!(p.dbg & 64)) sb.split_store(set, sm + wr_off);
+                if (!(p.dbg & 32)) sb.load(set, kt + 5, kleft);
+#else
                 fa.split(set, a_nxt[0]);
+                SNAG_STAMP(set, 5);
                 fa.load(set, kt + 5, kleft);
-                sb.split_store(set, sm + (cur ^ 1) * STAGE);
+                SNAG_STAMP(set, 6);
+                sb.split_store(set, sm + wr_off);
+                SNAG_STAMP(set, 7);
                 sb.load(set, kt + 5, kleft);
+                SNAG_STAMP(set, 8);
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                SNAG_STAMP(set, 1);
                 __builtin_amdgcn_s_barrier();
+                SNAG_STAMP(set, 2);
                 __builtin_amdgcn_sched_barrier(0);
+#if SNAG_GEMM_PP_LATE_READS
+#pragma unroll
+                for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + rd_off, wn0 + 32 * j + li, lh, b[j]);
+#endif
+#if SNAG_GEMM_ABLATE
+                if (!(p.dbg & 8)) mfma_split(a_cur, b);
+#else
                 mfma_split(a_cur, b);
+#endif
                 a_cur[0] = a_nxt[0];
                 __builtin_amdgcn_sched_barrier(0);
+                SNAG_STAMP(set, 3);
                 __builtin_amdgcn_s_barrier();
+                SNAG_STAMP(set, 4);
                 __builtin_amdgcn_sched_barrier(0);
 #endif
+                rd_off = wr_off;
+                wr_off = wr_off + STAGE == kPPImages * STAGE ? 0 : wr_off + STAGE;
             };
             if (nk > 0) {
                 fa.load(0, 0, kleft);
@@ -725,6 +833,9 @@ struct GemmCore {
                 if constexpr (kPingPong) {
 #if defined(__HIP_DEVICE_COMPILE__)
                     const bool late = wave >= 4;
+#if SNAG_GEMM_PP_PRIO
+                    if (late) __builtin_amdgcn_s_setprio(1);      // the second-dispatched half loses every issue arbitration otherwise (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#endif
                     if (late) __builtin_amdgcn_s_barrier();
                     for (int kt = 0; kt < nk; kt += 4) {
                         pp_iteration(kt, std::integral_constant<int, 1>{});
@@ -734,6 +845,11 @@ struct GemmCore {
                     }
                     if (!late) __builtin_amdgcn_s_barrier();
                     __syncthreads();
+#if SNAG_GEMM_STAMP
+                    if (blockIdx.x == 0 && blockIdx.y == 17 && blockIdx.z == 1 && lane == 0 && (wave == 0 || wave == 4))
+                        for (int i = 0; i < 4; ++i)
+                            for (int q = 0; q < 9; ++q) g_gemm_stamps[((wave >> 2) * 4 + i) * 9 + q] = stamp[i][q];
+#endif
 #endif
                 } else {
                     for (int kt = 0; kt < nk; kt += 2) {
@@ -1041,9 +1157,9 @@ struct GemmCore {
 
 // One block = one BM x BN output tile (x one K split): main loop, then either the epilogue functor
 // epi(row, col, float4) or, for split-K, a raw store into this split's slab (split index z).
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi, bool A_TILED = false>
 __device__ __forceinline__ void gemm_tile_body(const GemmOperands& p, const Epi& epi, float* __restrict__ slab, int z, float* smem) {
-    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
+    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC, A_TILED>;
     int bx = blockIdx.x, by = blockIdx.y;
     if (p.xcd) {
         const int id = xcd_swizzle(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
@@ -1105,11 +1221,11 @@ __global__ __launch_bounds__(256) void gemm_tile_group2_kernel(GemmOperands p0, 
     else core.for_each(smem, m0, n0, e1);
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi, bool A_TILED = false>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_kernel(GemmOperands p, Epi epi, float* __restrict__ slab) {
-    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
+    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC, A_TILED>;
     __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
-    gemm_tile_body<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi>(p, epi, slab, blockIdx.z, smem);
+    gemm_tile_body<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi, A_TILED>(p, epi, slab, blockIdx.z, smem);
 }
 
 // TWO problems of the same shape and layout in one launch (blockIdx.z = problem * splits + split): the step's many

@@ -24,6 +24,8 @@ from . import _lib
 from ._lib import call, ptr, stream
 
 f32 = torch.float32
+import os as _os
+_L1_KC = bool(int(_os.environ.get("SNAG_L1_KC", "0")))
 
 
 @dataclass
@@ -136,7 +138,7 @@ class MKGCHotPath:
         # stores that weight transposed.  The weight gradient dW^T = X^T-shaped product needs no extra copy.
         # Rows of the transposed copies are padded to a multiple of 32 floats: with N = 15000 a row is 60,000 B, not a multiple of
         # the 128-B line, so every 256-B tile segment would straddle three lines instead of two (PMC: 1.7x the algorithmic fetch).
-        self.ld_t = _align(max(Nl, 1), 32)
+        self.ld_t = _align(max(Nl, 1), 32) + int(_os.environ.get("SNAG_LDT_EXTRA", "0"))        # (SNAG_LDT_EXTRA: tuning -- extra floats of pitch, multiple of 32)
 
         def transposed(f, out=None):
             if out is None:
@@ -546,12 +548,16 @@ class MKGCHotPath:
         l1 = []
         for i, fd in enumerate(cfg.feat_dims):
             feat_t = self.noisy_t[i] if noisy else self.feats_t[i]          # [fd, Nl]
+            fa, fld, fkc = ptr(feat_t), self.ld_t, 0
+            if _L1_KC:                   # A/B: the row-major table as a K-contiguous operand (no transposed copy needed)
+                feat = self.noisy[i] if noisy else self.feats[i]
+                fa, fld, fkc = ptr(feat), fd, 1
             slot = x0p + 4 * i * D
             if cfg.num_proj == 1:
-                l1.append(self._gemm_desc(Nl, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.weight"]), D, 0, slot, MD,
+                l1.append(self._gemm_desc(Nl, D, fd, fa, fld, fkc, ptr(self.p[f"proj{i}.weight"]), D, 0, slot, MD,
                                           bias=ptr(self.p[f"proj{i}.bias"]), half=i % 2))
             else:   # ProjectionHead: Linear(no bias) -> ReLU -> dropout -> Linear(no bias)   (model/layers.py:135-148)
-                l1.append(self._gemm_desc(Nl, D, fd, ptr(feat_t), self.ld_t, 0, ptr(self.p[f"proj{i}.l1"]), D, 0, ptr(self.mid[i]), D, act=1,
+                l1.append(self._gemm_desc(Nl, D, fd, fa, fld, fkc, ptr(self.p[f"proj{i}.l1"]), D, 0, ptr(self.mid[i]), D, act=1,
                                           keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout), half=i % 2))
         # the modalities' first projections: K-split GEMMs of different K -- two kernels, ONE reduce launch per pair
         self._gemm_deferred_pairs(l1, ["proj_l1_fwd"] + [""] * (len(l1) - 1))

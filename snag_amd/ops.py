@@ -189,6 +189,47 @@ def score_margin_fwd_bwd_seg(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, d
     return loss, pos, neg, loss_part, d_ent, d_rel
 
 
+_TOUCHED_WORK = {}
+
+
+def score_margin_fwd_bwd_touched(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, d_ent=None, d_rel=None):
+    """The segmented hinge scorer for tables far larger than a batch's footprint: pass B walks the compact list of destinations that
+    received an entry instead of every counter; only touched rows of d_ent / d_rel are written (allocated zeroed when None).  fp32 or
+    bfloat16 tables.  -> (loss, pos, neg, loss_part, d_ent, d_rel).  C ABI: snag_score_margin_fwd_bwd_touched(_bf16)."""
+    bf16 = ent.dtype == torch.bfloat16
+    for x, nm in ((ent, "ent"), (rel, "rel")):
+        if not (torch.is_tensor(x) and x.is_cuda and x.dtype == (torch.bfloat16 if bf16 else f32) and x.dim() == 2 and x.stride(1) == 1):
+            raise ValueError(f"{nm}: expected a 2-D {'bfloat16' if bf16 else 'fp32'} CUDA tensor with unit inner stride")
+    if not rel.is_contiguous() or ent.shape[1] != rel.shape[1]:
+        raise ValueError("rel must be contiguous and as wide as ent")
+    if neg_t is None:
+        raise ValueError("score_margin_fwd_bwd_touched needs explicit negative tails")
+    B, K, ib = _idx_group(h, r, t, neg_t)
+    N, R, D = ent.shape[0], rel.shape[0], ent.shape[1]
+    if d_ent is None:
+        d_ent = torch.zeros(N, D, device=ent.device, dtype=f32)
+    if d_rel is None:
+        d_rel = torch.zeros(R, D, device=ent.device, dtype=f32)
+    _rows(d_ent, "d_ent"), _chk(d_rel, "d_rel", ndim=2)
+    if tuple(d_ent.shape) != (N, D) or tuple(d_rel.shape) != (R, D):
+        raise ValueError("gradient buffers must match the table shapes")
+    nbytes = _lib.load().snag_score_touched_work_bytes(N, R, B, K, D)
+    key = (ent.device.type, ent.device.index, stream(), N, R, B, K, D)
+    if key not in _TOUCHED_WORK:                 # zeroed ONCE; every launch leaves it ready for the next
+        while len(_TOUCHED_WORK) >= _SEG_WORK_MAX:
+            _TOUCHED_WORK.pop(next(iter(_TOUCHED_WORK)))
+        _TOUCHED_WORK[key] = torch.zeros((nbytes + 255) // 256 * 256, device=ent.device, dtype=torch.uint8)
+    work = _TOUCHED_WORK[key] = _TOUCHED_WORK.pop(key)
+    pos = torch.empty(B, device=ent.device, dtype=f32)
+    neg = torch.empty(B, K, device=ent.device, dtype=f32)
+    loss_part = torch.empty(B, device=ent.device, dtype=f32)
+    loss = torch.empty((), device=ent.device, dtype=f32)
+    call("snag_score_margin_fwd_bwd_touched_bf16" if bf16 else "snag_score_margin_fwd_bwd_touched", ptr(ent), ent.stride(0), N, ptr(rel), R, D, ptr(h), ptr(r),
+         ptr(t), ptr(neg_t), ib, B, K, float(margin), float(grad_scale), ptr(pos), ptr(neg), ptr(loss_part), ptr(loss), ptr(d_ent), d_ent.stride(0),
+         ptr(d_rel), ptr(work), work.numel(), stream())
+    return loss, pos, neg, loss_part, d_ent, d_rel
+
+
 def reduce_sum(x):
     """Deterministic sum of a float tensor -> 0-dim tensor.  C ABI: snag_reduce_sum."""
     _chk(x, "x")
@@ -213,28 +254,42 @@ def gram(z, alpha=1.0, out=None):
     return out
 
 
+def tile_a(a, kcontig=True):
+    """The tiled copy of an operand A (a: [M, K] when kcontig else [K, M]) for ``gemm(..., a_tiled=(M, K))``.  C ABI: snag_tile_a_f32."""
+    if not (torch.is_tensor(a) and a.is_cuda and a.dtype == f32 and a.dim() == 2 and a.stride(1) == 1):
+        raise ValueError("tile_a: a must be a 2-D fp32 CUDA tensor with unit inner stride")
+    M, K = a.shape if kcontig else (a.shape[1], a.shape[0])
+    out = torch.empty(_lib.load().snag_tile_a_floats(M, K), device=a.device, dtype=f32)
+    call("snag_tile_a_f32", ptr(a), a.stride(0), M, K, int(kcontig), ptr(out), stream())
+    return out
+
+
 def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, alpha=1.0, act=None, want_pre_act=False,
-         keep_mask=None, keep_p=0.0, add1=None, add2=None, out=None, accumulate=False, splitk=True, aux=None):
+         keep_mask=None, keep_p=0.0, add1=None, add2=None, out=None, accumulate=False, splitk=True, aux=None, a_tiled=None, c_transposed=False):
     """C = add1 + add2 + keep * act(alpha * A.B + bias)   (C ABI: snag_gemm_f32; fp32 via split-bf16 MFMA).
 
     a: [M,K] if a_kcontig else [K,M];  b: [N,K] if b_kcontig else [K,N]  (2-D, last dim contiguous,
     row stride free).  Returns C [M,N] (and the pre-activation when want_pre_act).
     """
     for t, nm in ((a, "a"), (b, "b")):
+        if nm == "a" and a_tiled is not None:
+            continue
         if not (torch.is_tensor(t) and t.is_cuda and t.dtype == f32 and t.dim() == 2 and t.stride(1) == 1):
             raise ValueError(f"gemm: {nm} must be a 2-D fp32 CUDA tensor with unit inner stride")
-    M, K = (a.shape if a_kcontig else (a.shape[1], a.shape[0]))
+    M, K = a_tiled if a_tiled is not None else (a.shape if a_kcontig else (a.shape[1], a.shape[0]))
     N, Kb = (b.shape if b_kcontig else (b.shape[1], b.shape[0]))
     if K != Kb:
         raise ValueError(f"gemm: inner sizes differ ({K} vs {Kb})")
+    oshape = (N, M) if c_transposed else (M, N)
     if out is None:
-        out = torch.empty(M, N, device=a.device, dtype=f32)
-    if tuple(out.shape) != (M, N) or out.stride(1) != 1:
+        out = torch.empty(oshape, device=a.device, dtype=f32)
+    if tuple(out.shape) != oshape or out.stride(1) != 1:
         raise ValueError("gemm: out has the wrong shape")
     d = _lib.GemmDesc()
     d.M, d.N, d.K = M, N, K
     d.a_kcontig, d.b_kcontig = int(a_kcontig), int(b_kcontig)
-    d.A, d.lda = ptr(a), a.stride(0)
+    d.a_tiled, d.c_transposed = int(a_tiled is not None), int(c_transposed)
+    d.A, d.lda = ptr(a), (0 if a_tiled is not None else a.stride(0))
     d.B, d.ldb = ptr(b), b.stride(0)
     d.C, d.ldc = ptr(out), out.stride(0)
     d.bias = ptr(_chk(bias, "bias", ndim=1)) if bias is not None else None

@@ -34,7 +34,9 @@ class StressConfig:
     lr: float = 1e-4
     weight_decay: float = 1e-4
     init_scale: float = 0.05            # tables ~ N(0,1) * 0.05 (SURVEY.md par. 8d "Config 5")
-    deterministic: bool = False         # fixed-point scatter (bit-reproducible), two launches instead of the fused one
+    scorer: str = "touched"             # "touched": segmented form over the batch's touched destinations (no float atomics, bit-reproducible,
+                                        # snag_score_margin_fwd_bwd_touched_bf16); "atomic": one launch scatter-adding with fp32 atomics
+    deterministic: bool = False         # with scorer="atomic": fixed-point scatter (bit-reproducible), two launches instead of the fused one
     seed: int = 1234
 
 
@@ -78,6 +80,9 @@ class StressHotPath:
         self._ticket = torch.zeros(_lib.SCORE_TICKET_WORDS, device=dev, dtype=torch.int32)
         self.loss = torch.zeros((), device=dev)
         self._bufs = None
+        self._touched_work = None
+        if cfg.scorer not in ("touched", "atomic"):
+            raise ValueError(f"scorer must be 'touched' or 'atomic', got {cfg.scorer!r}")
 
     def _outputs(self, B, K):
         if self._bufs is None or self._bufs[0].shape[0] != B or self._bufs[1].shape[1] != K:
@@ -124,6 +129,14 @@ class StressHotPath:
                  float(cfg.margin), 1.0, None, None, ptr(self._acc_ent), ptr(self._acc_rel), st)
             call("snag_fixed_to_float", ptr(self._acc_ent), N, D, ptr(self.d_ent_full), D, 0, st)
             call("snag_fixed_to_float", ptr(self._acc_rel), R, D, ptr(self.d_rel), D, 0, st)
+        elif cfg.scorer == "touched":
+            # scores, loss and every touched gradient row WRITTEN (the rest of d_ent_full / d_rel is zero: cleared row by row below)
+            if self._touched_work is None or self._touched_work[0] != (B, K):
+                nb = _lib.load().snag_score_touched_work_bytes(sh.n_pad, R, B, K, D)
+                self._touched_work = ((B, K), torch.zeros((nb + 255) // 256 * 256, device=self.dev, dtype=torch.uint8))
+            work = self._touched_work[1]
+            call("snag_score_margin_fwd_bwd_touched_bf16", ptr(self.ent16), D, sh.n_pad, ptr(self.rel16), R, D, ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K,
+                 float(cfg.margin), 1.0, ptr(pos), ptr(neg), ptr(part), ptr(self.loss), ptr(self.d_ent_full), D, ptr(self.d_rel), ptr(work), work.numel(), st)
         else:
             call("snag_score_margin_fwd_bwd_bf16", ptr(self.ent16), D, N, ptr(self.rel16), R, D, ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K,
                  float(cfg.margin), 1.0, ptr(pos), ptr(neg), ptr(part), ptr(self.loss), ptr(self._ticket), ptr(self.d_ent_full), D, ptr(self.d_rel), st)

@@ -135,6 +135,50 @@ def test_score_segmented_entry_vs_oracle(D, K, B, idt, margin):
     assert torch.equal(de3[touched.to(DEV)], de[touched.to(DEV)]) and float((de3[~touched.to(DEV)] - 9.0).abs().max() if (~touched).any() else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("D,K,B,idt", [(128, 32, 100, torch.int32), (256, 128, 48, torch.int64), (64, 3, 50, torch.int32), (8, 2, 9, torch.int32),
+                                        (512, 9, 12, torch.int32), (104, 5, 21, torch.int32), (128, 32, 700, torch.int32)])
+@pytest.mark.parametrize("tab", ["f32", "bf16"])
+def test_score_touched_form_vs_oracle_and_the_segmented_form(D, K, B, idt, tab):
+    """snag_score_margin_fwd_bwd_touched(_bf16): the segmented scorer whose second pass walks the touched destinations only.  Against the
+    oracle (bf16 tables: fp32 arithmetic on the bf16-rounded values); for fp32 tables bit-equal to the all-destinations form; hot rows
+    (one entity drawn by hundreds of entries: inline bucket + several hash chunks) included; three launches in a row on one
+    workspace give identical bits (the counters, the touched list and the overflow hash are handed over clean)."""
+    from snag_amd import ops
+    N, R, margin = 2001, 13, 6.0
+    ent, rel, h, r, t, neg = _mk(N, R, D, B, K, seed=D * 77 + K, idt=idt)
+    ent[7].zero_()
+    h[0] = 7
+    if B > 40:
+        t[3:3 + B // 2] = 5                              # a hub tail ...
+        neg[B // 3:, 0] = 11                             # ... and a hot negative: > 16 + 64 entries at B = 700 (two hash chunks)
+        neg[2, :] = 3
+    if tab == "bf16":
+        ent, rel = ent.bfloat16(), rel.bfloat16()
+    e_ = ent.float().clone().requires_grad_(True)
+    r_ = rel.float().clone().requires_grad_(True)
+    loss, pos, ng = O.score_margin(e_, r_, h, r, t, neg, margin)
+    (0.5 * loss).backward()
+    d = [x.to(DEV) for x in (ent, rel, h, r, t, neg)]
+    outs = []
+    for _ in range(3):
+        outs.append(ops.score_margin_fwd_bwd_touched(*d, margin, grad_scale=0.5))
+    lg, pos_g, neg_g, lp, de, dr = outs[0]
+    assert_close(pos_g, pos, atol=1e-5, what="pos")
+    assert_close(neg_g, ng, atol=1e-5, what="neg")
+    assert_close(lg, loss, atol=1e-4, rtol=1e-5, what="loss")
+    assert_close(de, e_.grad, atol=2e-4, rtol=1e-4, what="d_ent")
+    assert_close(dr, r_.grad, atol=2e-4, rtol=1e-4, what="d_rel")
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+    if tab == "f32":
+        ref = ops.score_margin_fwd_bwd_seg(*d, margin, grad_scale=0.5)
+        assert torch.equal(ref[0], lg) and torch.equal(ref[1], pos_g) and torch.equal(ref[2], neg_g)
+        touched = torch.zeros(N, dtype=torch.bool)
+        touched[torch.cat([h, t, neg.flatten()]).long()] = True
+        assert torch.equal(ref[4][touched.to(DEV)], de[touched.to(DEV)]) and float(de[~touched.to(DEV)].abs().sum()) == 0.0
+        assert torch.equal(ref[5][torch.unique(r.long()).to(DEV)], dr[torch.unique(r.long()).to(DEV)])
+
+
 def test_score_fused_accumulates_into_strided_rows_and_resets_its_ticket():
     """The engine's use: the table is the slot hidden[:, g, :] of a stacked [N, M, D] tensor (row stride M*D) and the gradient is
     scatter-added into the same slot of d_hidden; two launches in a row accumulate; the ticket word is zero again after each."""
