@@ -389,7 +389,7 @@ def run_stress(args, world, rank, device, backend, real_stdout):
     from snag_amd import ops
     from snag_amd.parallel import RowShard
     from snag_amd.stress import StressConfig, StressHotPath
-    cfg = StressConfig()
+    cfg = StressConfig(scorer=os.environ.get("BENCH_STRESS_SCORER", "touched"))
     shard = RowShard(cfg.n_ent, rank, world) if world > 1 else None
     eng = StressHotPath(cfg, device=device, shard=shard)
     B, K, N, R, D = args.batch, cfg.neg_num, cfg.n_ent, cfg.n_rel, cfg.dim
@@ -467,10 +467,12 @@ def run_stress(args, world, rank, device, backend, real_stdout):
                       "adamw(owned rows) + bf16 copy + clear touched rows": adam_us, "all_gather(updated bf16 rows)": ag_us,
                       "compute_us": score_us + adam_us, "comm_us": rs_us + ag_us,
                       "comm_bytes_per_rank": {"reduce_scatter_fp32": (world - 1) * shard_rows * D * 4, "all_gather_bf16": (world - 1) * shard_rows * D * 2}},
-        "roofline": {"kernel": "score_fused_kernel<bf16 tables> (snag_score_margin_fwd_bwd_bf16), HBM-resident 512 MB table", "bound": "hbm",
+        "roofline": {"kernel": "touched_a_kernel + touched_b_kernel + touched_hub_kernel <bf16 tables> (snag_score_margin_fwd_bwd_touched_bf16: segmented form over the "
+                               "batch's entries, no float atomics, bit-reproducible), HBM-resident 512 MB table" if cfg.scorer == "touched" else
+                               "score_fused_kernel<bf16 tables> (snag_score_margin_fwd_bwd_bf16, fp32 atomics), HBM-resident 512 MB table", "bound": "hbm",
                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_us": score_us,
                      "algorithmic_bytes_per_launch": alg_bytes, "atomic_bytes_per_launch": rows * D * 4, "atomic_floor_us": rows * D * 4 / 1.3e12 * 1e6,
-                     "timed": "HIP events around the launch (+ a 1 MB fill), inside the timed region"},
+                     "timed": "HIP events (torch events on the launch stream) around the entry's three launches + the 1 MB relation-gradient fill, inside the timed region"},
     }
     if world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline_stress(cfg, B, min(args.cpu_seconds, 30.0))

@@ -139,10 +139,11 @@ def test_score_segmented_entry_vs_oracle(D, K, B, idt, margin):
                                         (512, 9, 12, torch.int32), (104, 5, 21, torch.int32), (128, 32, 700, torch.int32)])
 @pytest.mark.parametrize("tab", ["f32", "bf16"])
 def test_score_touched_form_vs_oracle_and_the_segmented_form(D, K, B, idt, tab):
-    """snag_score_margin_fwd_bwd_touched(_bf16): the segmented scorer whose second pass walks the touched destinations only.  Against the
-    oracle (bf16 tables: fp32 arithmetic on the bf16-rounded values); for fp32 tables bit-equal to the all-destinations form; hot rows
-    (one entity drawn by hundreds of entries: inline bucket + several hash chunks) included; three launches in a row on one
-    workspace give identical bits (the counters, the touched list and the overflow hash are handed over clean)."""
+    """snag_score_margin_fwd_bwd_touched(_bf16): the segmented scorer whose second pass walks the batch's entries instead of every
+    destination.  Against the oracle (bf16 tables: fp32 arithmetic on the bf16-rounded values); for fp32 tables scores and losses
+    bit-equal to the all-destinations form and, while a triple is one part (K < 48), the gradients too; hot rows (one entity drawn by
+    hundreds of entries: inline bucket + several hash chunks + the hot-row pass) included; three launches in a row on one workspace give
+    identical bits (counters, hash keys and hot-row list are handed over clean)."""
     from snag_amd import ops
     N, R, margin = 2001, 13, 6.0
     ent, rel, h, r, t, neg = _mk(N, R, D, B, K, seed=D * 77 + K, idt=idt)
@@ -172,11 +173,16 @@ def test_score_touched_form_vs_oracle_and_the_segmented_form(D, K, B, idt, tab):
         assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
     if tab == "f32":
         ref = ops.score_margin_fwd_bwd_seg(*d, margin, grad_scale=0.5)
-        assert torch.equal(ref[0], lg) and torch.equal(ref[1], pos_g) and torch.equal(ref[2], neg_g)
+        assert torch.equal(ref[1], pos_g) and torch.equal(ref[2], neg_g)
         touched = torch.zeros(N, dtype=torch.bool)
         touched[torch.cat([h, t, neg.flatten()]).long()] = True
-        assert torch.equal(ref[4][touched.to(DEV)], de[touched.to(DEV)]) and float(de[~touched.to(DEV)].abs().sum()) == 0.0
-        assert torch.equal(ref[5][torch.unique(r.long()).to(DEV)], dr[torch.unique(r.long()).to(DEV)])
+        assert float(de[~touched.to(DEV)].abs().sum()) == 0.0
+        rels = torch.unique(r.long()).to(DEV)
+        if K < 48:                                       # one wave per triple on both sides: the same sums in the same order
+            assert torch.equal(ref[0], lg) and torch.equal(ref[4][touched.to(DEV)], de[touched.to(DEV)]) and torch.equal(ref[5][rels], dr[rels])
+        else:                                            # the query gradient is dealt to several parts: equal to fp32 rounding
+            assert_close(lg, ref[0], atol=1e-4, rtol=1e-6)
+            assert_close(de, torch.where(touched.to(DEV)[:, None], ref[4], torch.zeros_like(ref[4])), atol=1e-5, rtol=1e-5)
 
 
 def test_score_fused_accumulates_into_strided_rows_and_resets_its_ticket():
