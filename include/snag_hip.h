@@ -252,6 +252,10 @@ typedef struct snag_gemm_desc {
      * their [M, N] operands by (m, n)); no pre_act, no mirror.  The weight gradient dW^T = X^T dY lands in the nn.Linear layout
      * [out, in] this way, and an activation gradient in the K-contiguous layout its consumer streams fastest. */
     int32_t c_transposed;
+    /* optional: B as the pre-split bf16 image made by snag_presplit_b from the SAME [N, K] operand (B / ldb / b_kcontig must still
+     * describe it: shapes that do not run the eight-wave row-private tile ignore the image).  The projection weights are split once
+     * per step instead of once per workgroup and k-tile, and reach the LDS by DMA: no registers, no VALU.  Bit-identical results. */
+    const void* b_image;
 } snag_gemm_desc;
 
 SNAG_API int snag_gemm_f32(const snag_gemm_desc* desc, void* stream);
@@ -261,6 +265,12 @@ SNAG_API int64_t snag_gemm_workspace_floats(int M, int N, int K);
  * A(32 mb + li, 16 kt + 8 c + 4 lh + j), zero-padded to whole blocks.  snag_tile_a_floats(M, K) floats, 16-byte aligned.  Made once
  * per epoch for the raw feature tables (the first projection's operand, model/SNAG_tools.py:134-150, is constant between noise
  * refreshes, model/SNAG.py:86-92). */
+/* The pre-split image of an operand B [N, K] (K-contiguous [N, ldb >= K] or row-contiguous [K, ldb >= N]) for snag_gemm_desc.b_image:
+ * per (column tile of 128, k-tile of 16) one 16 KiB block [plane h / m / l][k-half][row (128)][8 bf16] (+ 4 KiB padding), the three
+ * planes being the exact split b = h + m + l of snag_gemm_f32; zero-padded to whole tiles.  snag_presplit_b_bytes(N, K) bytes, 16-byte
+ * aligned. */
+SNAG_API int64_t snag_presplit_b_bytes(int64_t N, int64_t K);
+SNAG_API int snag_presplit_b(const float* B, int64_t ldb, int b_kcontig, int64_t N, int64_t K, void* image, void* stream);
 SNAG_API int64_t snag_tile_a_floats(int64_t M, int64_t K);
 SNAG_API int snag_tile_a_f32(const float* src, int64_t ld, int64_t M, int64_t K, int kcontig, float* dst, void* stream);
 /* Two independent problems; when they have the same shape, layouts and split decision they run as ONE launch (the step's many

@@ -419,6 +419,7 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     e.mask = d->keep_mask; e.ldm = d->ldmask > 0 ? d->ldmask : d->N; e.mscale = d->keep_scale; e.add1 = d->add1; e.ld1 = d->ld1; e.add2 = d->add2; e.ld2 = d->ld2;
     e.accumulate = d->accumulate; e.M = d->M; e.N = d->N; e.aux = d->aux; e.ldaux = d->ldaux; e.ct = d->c_transposed;
     p.a_nkt = d->a_tiled ? ceil_div(d->K, 16) : 0;
+    p.b_image = d->b_image;
     e.mirror = d->mirror; e.ldmirror = d->ldmirror; e.mirror_mask = d->mirror_rowmask; e.mirror_scale = d->mirror_scale;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     e.fast = (d->ldc % 4 == 0) && al16(d->C) && (!d->bias || al16(d->bias)) && (!d->pre_act || al16(d->pre_act)) &&
@@ -523,11 +524,18 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     if (log_shapes())
         fprintf(stderr, "snag_gemm M=%d N=%d K=%d a_kc=%d b_kc=%d tile=%s splits=%d fast=%d acc=%d\n", p.M, p.N, p.K, (int)d->a_kcontig,
                 (int)d->b_kcontig, pl.wide ? "128x160" : pl.pp ? "256x128" : pl.big ? "128x128" : "64x128", splits, (int)e.fast, (int)d->accumulate);
+    const bool img = d->b_image != nullptr && !pl.wide && pl.big && pl.pp && kBf16x != 0;      // (other tiles split B themselves: the image is ignored)
 #if SNAG_GEMM_BK == 16
     if (pl.wide) launch_cfg<128, 160, 32, 160>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else
 #endif
-    if (d->a_tiled) {
+    if (img) {
+        // B from its pre-split image (LDS-DMA): A tiled, K-contiguous (16-byte loads) or row-contiguous
+        dim3 grid(ceil_div(p.N, 128), ceil_div(p.M, 256), splits), block(512);
+        if (d->a_tiled) hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, false, false, true, Epilogue, true, true>), grid, block, 0, st, p, e, slab);
+        else if (d->a_kcontig) hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, true, false, true, Epilogue, false, true>), grid, block, 0, st, p, e, slab);
+        else hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, false, false, true, Epilogue, false, true>), grid, block, 0, st, p, e, slab);
+    } else if (d->a_tiled) {
         dim3 grid(ceil_div(p.N, 128), ceil_div(p.M, 256), splits), block(512);
         if (d->b_kcontig) hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, false, true, true, Epilogue, true>), grid, block, 0, st, p, e, slab);
         else hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, false, false, true, Epilogue, true>), grid, block, 0, st, p, e, slab);
@@ -658,6 +666,30 @@ int gemm_reduce_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStre
     return gemm_reduce_multi(ds, 2, st);
 }
 
+// one thread = one 16-byte slot of the image of one plane triple: (column tile, k-tile, k-half q, row n) <- the exact split of
+// B(n, 16 kt + 4 q + 0..3) and B(n, 16 kt + 8 + 4 q + 0..3) -- the same split_pair the kernels apply to a staged value
+__global__ __launch_bounds__(256) void presplit_b_kernel(const float* __restrict__ src, int64_t ld, int64_t N, int64_t K, int kcontig, unsigned char* __restrict__ img,
+                                                         int64_t nkt, int64_t slots) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < slots; t += (int64_t)gridDim.x * 256) {
+        const int nl = (int)(t & 127), q = (int)((t >> 7) & 1);
+        const int64_t blk = t >> 8, kt = blk % nkt, nt = blk / nkt;
+        const int64_t n = nt * 128 + nl, k0 = kt * 16 + 4 * q;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t k = k0 + (j & 3) + 8 * (j >> 2);
+            v[j] = (n < N && k < K) ? (kcontig ? src[n * ld + k] : src[k * ld + n]) : 0.f;
+        }
+        uint32_t h[4], m[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
+        unsigned char* base = img + blk * ImageStager::kBlock + ((int64_t)q * 128 + nl) * 16;
+        *reinterpret_cast<uint4*>(base) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4*>(base + 2 * 128 * 16) = make_uint4(m[0], m[1], m[2], m[3]);
+        *reinterpret_cast<uint4*>(base + 4 * 128 * 16) = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+}
+
 // one thread = one 16-byte piece of the tiled copy: (block mb, k-tile kt, c, lh, li) <- A(32 mb + li, 16 kt + 8 c + 4 lh + 0..3)
 __global__ __launch_bounds__(256) void tile_a_kernel(const float* __restrict__ src, int64_t ld, int64_t M, int64_t K, int kcontig, float* __restrict__ dst,
                                                      int64_t nkt, int64_t pieces) {
@@ -708,6 +740,22 @@ extern "C" SNAG_API int snag_gemm_f32(const snag_gemm_desc* d, void* stream) {
     if (rc) return rc;
     if (d->M == 0 || d->N == 0) return SNAG_OK;
     return gemm_dispatch(d, (hipStream_t)stream);
+}
+
+extern "C" SNAG_API int64_t snag_presplit_b_bytes(int64_t N, int64_t K) {
+    if (N < 0 || K < 0) return 0;
+    return ((N + 127) / 128) * ((K + 15) / 16) * (int64_t)ImageStager::kBlock;
+}
+
+extern "C" SNAG_API int snag_presplit_b(const float* B, int64_t ldb, int b_kcontig, int64_t N, int64_t K, void* image, void* stream) {
+    SNAG_REQUIRE(N >= 0 && K >= 0 && ldb >= (b_kcontig ? K : N), SNAG_ERR_ARG, "presplit_b: bad sizes (N=%ld K=%ld ldb=%ld)", (long)N, (long)K, (long)ldb);
+    if (N == 0 || K == 0) return SNAG_OK;
+    SNAG_REQUIRE(B && image && ((uintptr_t)image & 15) == 0, SNAG_ERR_ARG, "presplit_b: null pointer or unaligned image");
+    SNAG_REQUIRE(kBf16x != 0, SNAG_ERR_UNSUPPORTED, "presplit_b: this build multiplies on the f32 matrix pipe (no split operands)");
+    const int64_t nkt = (K + 15) / 16, slots = ((N + 127) / 128) * nkt * 256;
+    hipLaunchKernelGGL(presplit_b_kernel, dim3((unsigned)std::min<int64_t>(65536, (slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, ldb, N, K, b_kcontig,
+                       (unsigned char*)image, nkt, slots);
+    return check_launch("snag_presplit_b");
 }
 
 extern "C" SNAG_API int64_t snag_tile_a_floats(int64_t M, int64_t K) {

@@ -119,6 +119,7 @@ struct GemmOperands {
     int dbg;             // tuning only: nonzero = stop fetching after the first two k-tiles (compute-only ceiling)
     int xcd;             // bit 0: XCD-aware workgroup -> tile mapping (xcd_swizzle); bits 4..: row tiles per group of the grouped order (0 = row-major)
     int a_nkt;           // A in the tiled layout (snag_tile_a_f32; kernels compiled with A_TILED): k-tiles per 32-row block = ceil(K / 16)
+    const void* b_image; // B as pre-split bf16 planes in LDS-image order (snag_presplit_b; kernels compiled with B_IMG), ceil(K / 16) blocks of 16 KiB per column tile
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (observed, never relied on for correctness): ids b and b + 8 share an L2.
@@ -465,6 +466,7 @@ struct SplitStager {
 //   K-contiguous:   2 dwordx4 loads (bytes 16 h and 32 + 16 h of the row's 64 bytes in this k-tile)
 template <bool KC>
 struct FragLoader {
+    static constexpr int kLoads = KC ? 2 : 8;  // vector-memory instructions per k-tile (K-contiguous: the 16-byte form; the checked 4-byte form is not used with B images)
     float r[4][8];
     const char* ubase;
     int64_t ldb;
@@ -534,12 +536,41 @@ struct FragLoader {
     }
 };
 
+// B as a PRE-SPLIT IMAGE (snag_presplit_b): per (column tile of 128, k-tile) one 16 KiB block holding the three bf16 planes in the very
+// order the LDS image has -- [plane][k-half][row][8 values] (12 KiB) + 4 KiB of padding, so that each of the eight waves moves exactly two
+// KiB pieces.  Staging a k-tile is then an LDS-DMA copy: no registers, no VALU (the weight of a projection is split ONCE per step by
+// snag_presplit_b instead of once per workgroup and k-tile: 236 times for the visual projection), no ds_write.
+struct ImageStager {
+    static constexpr int kBlock = 16384;
+    const char* ubase;               // block of (column tile, k-tile kbeg / 16)
+    int tiles_left;                  // blocks from there to the end of the column tile's run (the DMA of a tile past it re-reads the last one)
+    int wave, lane;
+
+    __device__ __forceinline__ void init(const void* img, int nkt, int n0, int kbeg, int tid) {
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        lane = tid & 63;
+        ubase = reinterpret_cast<const char*>(img) + ((int64_t)(n0 >> 7) * nkt + (kbeg >> 4)) * kBlock;
+        tiles_left = nkt - (kbeg >> 4);
+    }
+    // k-tile kt (relative to kbeg) -> the LDS image at dst: two 1 KiB pieces per wave, counted in vmcnt like any load
+    __device__ __forceinline__ void dma(int kt, unsigned char* dst) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const char* src = ubase + (int64_t)min(kt, tiles_left - 1) * kBlock + (wave * 2) * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + (wave * 2 + i) * 1024), 16, 0, 0);
+#endif
+    }
+};
+
 // A in the TILED layout (snag_tile_a_f32): the matrix is cut into blocks of 32 rows x 16 k, block (mb, kt) = 512 floats at
 // ((mb * nkt) + kt) * 512, inside it [c (2)][lh (2)][li (32)][j (4)] holds A(mb * 32 + li, kt * 16 + 8 c + 4 lh + j) -- the order in which
 // the lanes of a wave consume them: the lane's eight values of a k-tile are TWO dwordx4 loads, and each of the two wave-instructions
 // reads one contiguous KiB.  (In-kernel stamps: every vector-memory instruction costs the issuing wave ~45 cycles of its memory half
 // whatever it moves -- 8 dword loads per k-tile for a row-contiguous A, 2 here.)  The buffer is zero-padded to whole blocks.
 struct FragLoaderTiled {
+    static constexpr int kLoads = 2;           // vector-memory instructions per k-tile
     float r[4][8];
     const char* ubase;
     uint32_t voff;
@@ -553,9 +584,12 @@ struct FragLoaderTiled {
         voff = (uint32_t)lane * 16u;
     }
     __device__ __forceinline__ int k_of(int j) const { return 4 * lh + (j & 3) + 8 * (j >> 2); }
-    __device__ __forceinline__ void load(int s, int kt, int kleft) {
+    // FULL k-tiles only, like FragLoader::load (a tile at or past kleft / 16 reads zeros through an empty descriptor: the k-loop runs whole
+    // quadruples of tiles); the ragged last tile -- whole in the buffer, zero-padded -- is load_tail()'s
+    __device__ __forceinline__ void load(int s, int kt, int kleft) { fetch(s, kt, kt * 16 + 16 <= kleft && !(ablate && kt >= 2)); }
+    __device__ __forceinline__ void fetch(int s, int kt, bool in_range) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const int range = __builtin_amdgcn_readfirstlane(kt * 16 < kleft && !(ablate && kt >= 2) ? (int)0xffffffffu : 0);      // (whole tiles: the padding is zeros)
+        const int range = __builtin_amdgcn_readfirstlane(in_range ? (int)0xffffffffu : 0);
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, range, 0x00020000);
         const uint32_t so = (uint32_t)kt * 2048u;
 #pragma unroll
@@ -568,7 +602,7 @@ struct FragLoaderTiled {
         }
 #endif
     }
-    __device__ __forceinline__ void load_tail(int s, int kt, int kleft) { load(s, kt, kleft); }       // the ragged tile is zero-padded in the buffer
+    __device__ __forceinline__ void load_tail(int s, int kt, int) { fetch(s, kt, true); }
     __device__ __forceinline__ void split(int s, Split3& f) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         uint32_t h[4], m[4], l[4];
@@ -599,7 +633,7 @@ __device__ __forceinline__ void load_split_fragment(const unsigned char* image, 
 // (With split-bf16 products C(a, b) and C(b, a) differ in their last bits: h*m <-> m*h, h*l <-> l*h under an exchange of the operands,
 // and f32 addition is not associative.  snag_gram_f32 therefore mirrors the upper triangle of its diagonal tiles instead of trusting
 // both halves.)
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, bool A_TILED = false>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, bool A_TILED = false, bool B_IMG = false>
 struct GemmCore {
     static constexpr int TM = WM / 32, TN = WN / 32;
     static constexpr int A_BUF = TileLd<BM, A_KC>::floats, B_BUF = TileLd<BN, B_KC>::floats, B_BASE = 2 * A_BUF;
@@ -612,10 +646,12 @@ struct GemmCore {
                                       (SNAG_GEMM_PRESPLIT_KC != 0 || (!A_KC && !B_KC));
     // waves stacked along M (each wave's 32 rows are its own): the A operand never goes through the LDS (FragLoader)
     static constexpr bool kRowPrivate = kPresplit && WN == BN && WM == 32;
-    static constexpr int PS_STAGE_FLOATS = 6 * ((kRowPrivate ? 0 : BM) + BN) * 16 / 4;          // one stage: both images (B's only when row-private)
+    static_assert(!B_IMG || (BM == 256 && BN == 128 && WM == 32 && WN == 128), "pre-split B images feed the eight-wave row-private tile");
+    static constexpr int PS_STAGE_FLOATS = B_IMG ? ImageStager::kBlock / 4 : 6 * ((kRowPrivate ? 0 : BM) + BN) * 16 / 4;          // one stage: both images (B's only when row-private)
     // (the eight-wave ping-pong loop keeps THREE B images: a group reads the fragments of tile kt inside its matrix half, while the other
     // group is already writing tile kt+2 -- SNAG_GEMM_PP_LATE_READS)
-    static constexpr int PS_FLOATS = kPresplit ? ((kRowPrivate && (BM / WM) * (BN / WN) == 8 && SNAG_GEMM_PP_LATE_READS) ? 3 : 2) * PS_STAGE_FLOATS : 0;
+    // (B images by DMA: four of them -- the copy of tile kt+2 is issued while tile kt multiplies and has a whole iteration to land)
+    static constexpr int PS_FLOATS = kPresplit ? (B_IMG ? 4 : (kRowPrivate && (BM / WM) * (BN / WN) == 8 && SNAG_GEMM_PP_LATE_READS) ? 3 : 2) * PS_STAGE_FLOATS : 0;
     static constexpr int SMEM_FLOATS_ = TILE_FLOATS > STAGE_FLOATS ? TILE_FLOATS : STAGE_FLOATS;
     static constexpr int SMEM_FLOATS = kPresplit ? (PS_FLOATS > STAGE_FLOATS ? PS_FLOATS : STAGE_FLOATS) : SMEM_FLOATS_;
     static_assert(NW == 4 || NW == 8, "four or eight waves per block");
@@ -713,7 +749,9 @@ struct GemmCore {
             SplitStager<BN, B_KC, NT> sb;
             if constexpr (A_TILED) fa.init(p.A, p.a_nkt, m0 + wm0, p.M, kbeg, lane);
             else fa.init(p.A, p.lda, p.a_vec, m0 + wm0, p.M, kbeg, lane);
-            sb.init(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, tid);
+            [[maybe_unused]] ImageStager ib;
+            if constexpr (B_IMG) ib.init(p.b_image, (p.K + 15) >> 4, n0, kbeg, tid);
+            else sb.init(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, tid);
             fa.ablate = p.dbg & 1;
             sb.ablate = p.dbg & 2;
             Split3 a_cur[1], a_nxt[1];
@@ -779,13 +817,26 @@ struct GemmCore {
                 if (!(p.dbg & 64)) sb.split_store(set, sm + wr_off);
                 if (!(p.dbg & 32)) sb.load(set, kt + 5, kleft);
 #else
+                if constexpr (B_IMG) {
+                    // the B image of tile kt+2: an LDS-DMA copy, issued FIRST in the iteration (the wait at the end of the NEXT iteration's
+                    // matrix half then leaves exactly one iteration's DMA pieces and two iterations' A loads outstanding).  Issued -> landed is
+                    // ~1 us under load (MI355X_MICROARCH.md, ldsdma-fill): with the copy of tile kt+1 issued here and waited for at the
+                    // end of this iteration the step ran SLOWER than with the in-kernel split (114 vs 106 us).
+                    const int dma_off = rd_off + 2 * STAGE >= kPPImages * STAGE ? rd_off + 2 * STAGE - kPPImages * STAGE : rd_off + 2 * STAGE;
+                    ib.dma(kt + 2, sm + dma_off);
+#if defined(__HIP_DEVICE_COMPILE__)
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
                 fa.split(set, a_nxt[0]);
                 SNAG_STAMP(set, 5);
                 fa.load(set, kt + 5, kleft);
                 SNAG_STAMP(set, 6);
-                sb.split_store(set, sm + wr_off);
-                SNAG_STAMP(set, 7);
-                sb.load(set, kt + 5, kleft);
+                if constexpr (!B_IMG) {
+                    sb.split_store(set, sm + wr_off);
+                    SNAG_STAMP(set, 7);
+                    sb.load(set, kt + 5, kleft);
+                }
                 SNAG_STAMP(set, 8);
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -806,6 +857,12 @@ struct GemmCore {
 #endif
                 a_cur[0] = a_nxt[0];
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (B_IMG) {
+                    // this wave's pieces of tile kt+1's image (issued one iteration ago) have landed before the barrier behind which the first
+                    // group reads them; everything issued after them: last iteration's A loads, this iteration's DMA pieces and A loads
+                    if constexpr (decltype(fa)::kLoads == 8) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                }
                 SNAG_STAMP(set, 3);
                 __builtin_amdgcn_s_barrier();
                 SNAG_STAMP(set, 4);
@@ -815,20 +872,27 @@ struct GemmCore {
                 wr_off = wr_off + STAGE == kPPImages * STAGE ? 0 : wr_off + STAGE;
             };
             if (nk > 0) {
+                if constexpr (B_IMG) {
+                    ib.dma(0, sm);                  // the first two images: waited for right here (once per workgroup), before the A loads queue up behind them
+                    ib.dma(1, sm + STAGE);
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                }
                 fa.load(0, 0, kleft);
-                sb.load(0, 0, kleft);
+                if constexpr (!B_IMG) sb.load(0, 0, kleft);
                 fa.load(1, 1, kleft);
-                sb.load(1, 1, kleft);
+                if constexpr (!B_IMG) sb.load(1, 1, kleft);
                 if constexpr (kPingPong) {          // four register sets: tiles kt+1 .. kt+4 in flight (tile t in set t & 3)
                     fa.load(2, 2, kleft);
-                    sb.load(2, 2, kleft);
+                    if constexpr (!B_IMG) sb.load(2, 2, kleft);
                     fa.load(3, 3, kleft);
-                    sb.load(3, 3, kleft);
+                    if constexpr (!B_IMG) sb.load(3, 3, kleft);
                 }
                 fa.split(0, a_cur[0]);
-                sb.split_store(0, sm);
+                if constexpr (!B_IMG) sb.split_store(0, sm);
                 fa.load(0, kPingPong ? 4 : 2, kleft);
-                sb.load(0, kPingPong ? 4 : 2, kleft);
+                if constexpr (!B_IMG) sb.load(0, kPingPong ? 4 : 2, kleft);
                 __syncthreads();
                 if constexpr (kPingPong) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -860,9 +924,16 @@ struct GemmCore {
             }
             if (kleft % 16 != 0) {
                 fa.load_tail(0, nk, kleft);
-                sb.load_tail(0, nk, kleft);
+                if constexpr (B_IMG) {
+                    ib.dma(nk, sm);                 // (the image is zero-padded to whole k-tiles)
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                } else {
+                    sb.load_tail(0, nk, kleft);
+                }
                 fa.split(0, a_cur[0]);
-                sb.split_store(0, sm);
+                if constexpr (!B_IMG) sb.split_store(0, sm);
                 __syncthreads();
                 Split3 b[TN];
 #pragma unroll
@@ -1157,9 +1228,9 @@ struct GemmCore {
 
 // One block = one BM x BN output tile (x one K split): main loop, then either the epilogue functor
 // epi(row, col, float4) or, for split-K, a raw store into this split's slab (split index z).
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi, bool A_TILED = false>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi, bool A_TILED = false, bool B_IMG = false>
 __device__ __forceinline__ void gemm_tile_body(const GemmOperands& p, const Epi& epi, float* __restrict__ slab, int z, float* smem) {
-    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC, A_TILED>;
+    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC, A_TILED, B_IMG>;
     int bx = blockIdx.x, by = blockIdx.y;
     if (p.xcd) {
         const int id = xcd_swizzle(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
@@ -1221,11 +1292,11 @@ __global__ __launch_bounds__(256) void gemm_tile_group2_kernel(GemmOperands p0, 
     else core.for_each(smem, m0, n0, e1);
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi, bool A_TILED = false>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi, bool A_TILED = false, bool B_IMG = false>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_kernel(GemmOperands p, Epi epi, float* __restrict__ slab) {
-    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC, A_TILED>;
+    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC, A_TILED, B_IMG>;
     __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
-    gemm_tile_body<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi, A_TILED>(p, epi, slab, blockIdx.z, smem);
+    gemm_tile_body<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi, A_TILED, B_IMG>(p, epi, slab, blockIdx.z, smem);
 }
 
 // TWO problems of the same shape and layout in one launch (blockIdx.z = problem * splits + split): the step's many

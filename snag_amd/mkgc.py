@@ -25,7 +25,10 @@ from ._lib import call, ptr, stream
 
 f32 = torch.float32
 import os as _os
-_L1_KC = bool(int(_os.environ.get("SNAG_L1_KC", "0")))
+# A/B switches of the first projections (tools/ab_r03c.sh; all measured slower or equal inside the step, DESIGN.md par. 8):
+_L1_KC = bool(int(_os.environ.get("SNAG_L1_KC", "0")))            # the row-major table as a K-contiguous operand
+_L1_TILED = bool(int(_os.environ.get("SNAG_L1_TILED", "0")))      # the feature table in the tiled layout (snag_tile_a_f32)
+_L1_IMG = bool(int(_os.environ.get("SNAG_L1_IMG", "0")))          # the weight as a pre-split image (snag_presplit_b)
 
 
 @dataclass
@@ -269,6 +272,9 @@ class MKGCHotPath:
         self._proj_regions = (self._regions([(cfg.seed * 131 + 7 + i, lo * D, Nl * D, cfg.proj_dropout, self.keep_proj[i]) for i in range(len(cfg.feat_dims))])
                               if self.keep_proj is not None else None)
         self.tick = torch.zeros(1, device=dev, dtype=torch.int64)      # device-side step counter
+        # the first projections' weights as pre-split bf16 images, remade once per step (snag_presplit_b): the GEMM copies them into the
+        # LDS by DMA instead of splitting the same 2 MB weight in every workgroup and k-tile
+        self.w_img = [torch.empty(lib.snag_presplit_b_bytes(D, fd), device=dev, dtype=torch.uint8) for fd in cfg.feat_dims] if _L1_IMG else None
         # noise state (model/SNAG.py:86-98)
         self.noisy = [f.clone() for f in self.feats]
         self.noisy_t = [self._transposed(f) for f in self.feats]
@@ -546,9 +552,21 @@ class MKGCHotPath:
              (self.ent_noise_mask.data_ptr() + lo) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD,
              self._drop_regions if drop else None, len(self._drop_regions) if drop else 0, st)
         l1 = []
+        if self.w_img is not None:
+            for i, fd in enumerate(cfg.feat_dims):
+                call("snag_presplit_b", ptr(self.p[f"proj{i}.weight" if cfg.num_proj == 1 else f"proj{i}.l1"]), D, 0, D, fd, ptr(self.w_img[i]), st)
         for i, fd in enumerate(cfg.feat_dims):
             feat_t = self.noisy_t[i] if noisy else self.feats_t[i]          # [fd, Nl]
             fa, fld, fkc = ptr(feat_t), self.ld_t, 0
+            if _L1_TILED:
+                from . import ops as _ops
+                key = ("tf", i, bool(noisy), self.noise_epoch)
+                if getattr(self, "_tf_key", {}).get(i) != key:
+                    self._tf = getattr(self, "_tf", {})
+                    self._tf[i] = _ops.tile_a(self.noisy[i] if noisy else self.feats[i], kcontig=True)
+                    self._tf_key = getattr(self, "_tf_key", {})
+                    self._tf_key[i] = key
+                fa, fld, fkc = ptr(self._tf[i]), 0, 0
             if _L1_KC:                   # A/B: the row-major table as a K-contiguous operand (no transposed copy needed)
                 feat = self.noisy[i] if noisy else self.feats[i]
                 fa, fld, fkc = ptr(feat), fd, 1
@@ -559,6 +577,12 @@ class MKGCHotPath:
             else:   # ProjectionHead: Linear(no bias) -> ReLU -> dropout -> Linear(no bias)   (model/layers.py:135-148)
                 l1.append(self._gemm_desc(Nl, D, fd, fa, fld, fkc, ptr(self.p[f"proj{i}.l1"]), D, 0, ptr(self.mid[i]), D, act=1,
                                           keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout), half=i % 2))
+        if self.w_img is not None:
+            for i, d_ in enumerate(l1):
+                d_.b_image = ptr(self.w_img[i])
+        if _L1_TILED:
+            for d_ in l1:
+                d_.a_tiled = 1
         # the modalities' first projections: K-split GEMMs of different K -- two kernels, ONE reduce launch per pair
         self._gemm_deferred_pairs(l1, ["proj_l1_fwd"] + [""] * (len(l1) - 1))
         if cfg.num_proj == 2:       # the second projections, two modalities per launch

@@ -264,8 +264,20 @@ def tile_a(a, kcontig=True):
     return out
 
 
+def presplit_b(b, kcontig=True, out=None):
+    """The pre-split bf16 image of an operand B (b: [N, K] when kcontig else [K, N]) for ``gemm(..., b_image=...)``.  C ABI: snag_presplit_b."""
+    if not (torch.is_tensor(b) and b.is_cuda and b.dtype == f32 and b.dim() == 2 and b.stride(1) == 1):
+        raise ValueError("presplit_b: b must be a 2-D fp32 CUDA tensor with unit inner stride")
+    N, K = b.shape if kcontig else (b.shape[1], b.shape[0])
+    nbytes = _lib.load().snag_presplit_b_bytes(N, K)
+    if out is None:
+        out = torch.empty(nbytes, device=b.device, dtype=torch.uint8)
+    call("snag_presplit_b", ptr(b), b.stride(0), int(kcontig), N, K, ptr(out), stream())
+    return out
+
+
 def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, alpha=1.0, act=None, want_pre_act=False,
-         keep_mask=None, keep_p=0.0, add1=None, add2=None, out=None, accumulate=False, splitk=True, aux=None, a_tiled=None, c_transposed=False):
+         keep_mask=None, keep_p=0.0, add1=None, add2=None, out=None, accumulate=False, splitk=True, aux=None, a_tiled=None, c_transposed=False, b_image=None):
     """C = add1 + add2 + keep * act(alpha * A.B + bias)   (C ABI: snag_gemm_f32; fp32 via split-bf16 MFMA).
 
     a: [M,K] if a_kcontig else [K,M];  b: [N,K] if b_kcontig else [K,N]  (2-D, last dim contiguous,
@@ -289,6 +301,7 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, alpha=1.0, act=None
     d.M, d.N, d.K = M, N, K
     d.a_kcontig, d.b_kcontig = int(a_kcontig), int(b_kcontig)
     d.a_tiled, d.c_transposed = int(a_tiled is not None), int(c_transposed)
+    d.b_image = ptr(b_image)
     d.A, d.lda = ptr(a), (0 if a_tiled is not None else a.stride(0))
     d.B, d.ldb = ptr(b), b.stride(0)
     d.C, d.ldc = ptr(out), out.stride(0)

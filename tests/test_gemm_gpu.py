@@ -388,3 +388,29 @@ def test_gemm_transposed_output(M, N, K, split):
     acc = torch.ones(N, M, device=DEV)
     ops.gemm(a, b, a_kcontig=False, b_kcontig=False, splitk=split, c_transposed=True, out=acc, accumulate=True)
     assert_close(acc.t(), 1.0 + ops.gemm(a, b, a_kcontig=False, b_kcontig=False, splitk=split), atol=1e-5, rtol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(15000, 128, 4096), (15000, 128, 768), (4096, 128, 15000), (1100, 100, 777), (1024, 128, 512)])
+@pytest.mark.parametrize("a_mode,b_kc", [("rowc", False), ("rowc", True), ("kc", False), ("tiled", True)])
+def test_gemm_presplit_b_image_equals_the_plain_call_bit_for_bit(M, N, K, a_mode, b_kc):
+    """snag_presplit_b + snag_gemm_desc.b_image: the weight's three bf16 planes made ONCE (not per workgroup and k-tile) and copied into
+    the LDS by DMA give the bits of the call that splits B itself (same split, same order of products and k-tiles); ragged N / K are
+    zero-padded inside the image; epilogue (bias, ReLU) as usual."""
+    from snag_amd import ops
+    g = torch.Generator().manual_seed(M + 7 * N + 11 * K)
+    a = torch.randn((M, K) if a_mode != "rowc" else (K, M), generator=g).to(DEV)
+    b = torch.randn((N, K) if b_kc else (K, N), generator=g).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    img = ops.presplit_b(b, kcontig=b_kc)
+    assert img.numel() == ((N + 127) // 128) * ((K + 15) // 16) * 16384
+    kw = dict(b_kcontig=b_kc, bias=bias, act="relu")
+    if a_mode == "tiled":
+        at = ops.tile_a(a, kcontig=True)
+        plain = ops.gemm(at, b, a_tiled=(M, K), **kw)
+        got = ops.gemm(at, b, a_tiled=(M, K), b_image=img, **kw)
+    else:
+        plain = ops.gemm(a, b, a_kcontig=(a_mode == "kc"), **kw)
+        got = ops.gemm(a, b, a_kcontig=(a_mode == "kc"), b_image=img, **kw)
+    assert torch.equal(got, plain)
+    ref = torch.relu(_ref(a.cpu(), b.cpu(), a_mode != "rowc", b_kc) + bias.cpu().double())
+    assert_close(got, ref, atol=2e-6 * K + 1e-5, rtol=2e-5)

@@ -44,3 +44,10 @@ for fd in (4096, 768):
     res["bwd tiled A, B kc, C^T"] = timed(lambda: ops.gemm(x_tb, dmid_t, a_tiled=(fd, N), b_kcontig=True, out=dw_n, c_transposed=True))
     for k, v in res.items():
         print(f"fd={fd}: {k:32s} {v:7.1f} us  ({2.0 * N * fd * D / v / 1e6:6.1f} TF)", flush=True)
+    w_img = ops.presplit_b(w_t, kcontig=False)
+    w_img_kc = ops.presplit_b(w, kcontig=True)
+    print(f"fd={fd}: presplit_b                       {timed(lambda: ops.presplit_b(w_t, kcontig=False, out=w_img)):7.1f} us", flush=True)
+    for k, fn in (("fwd plain A, B image", lambda: ops.gemm(xt, w_t, a_kcontig=False, b_kcontig=False, out=mid, act="relu", b_image=w_img)),
+                  ("fwd tiled A, B image", lambda: ops.gemm(x_tf, w_t, a_tiled=(N, fd), b_kcontig=False, out=mid, act="relu", b_image=w_img))):
+        v = timed(fn)
+        print(f"fd={fd}: {k:32s} {v:7.1f} us  ({2.0 * N * fd * D / v / 1e6:6.1f} TF)", flush=True)
