@@ -105,18 +105,20 @@ def roofline_dominant(cfg, timer, rows=None, reduce_timer=None):
             traffic, src = pmc["fetch_bytes"] + pmc["write_bytes"] + pmc.get("fixup_fetch_bytes", 0) + pmc.get("fixup_write_bytes", 0), pmc["source"]
     except (OSError, KeyError, ValueError):
         pass
-    return {"kernel": f"gemm_tile_kernel<256,128,32,128,..> (8-wave ping-pong) + splitk_reduce_multi_kernel (shared with the text projection, counted in full) (visual projection: [{rows},{cfg.feat_dims[0]}]x[{cfg.feat_dims[0]},{cfg.dim}], fp32 via 6 split-bf16 MFMA products, 4 K-splits)",
+    return {"kernel": f"gemm_tile_kernel<256,128,32,128,A K-contiguous,B K-contiguous> (8-wave ping-pong) + splitk_reduce_multi_kernel (shared with the text projection, counted in full) (visual projection: [{rows},{cfg.feat_dims[0]}]x[{cfg.dim},{cfg.feat_dims[0]}]^T, fp32 via 6 split-bf16 MFMA products, 4 K-splits)",
             # the bound of the kernel AS BUILT: six bf16 MFMA products per f32 multiply-add -> bf16 dense peak / 6 (37.5 us for this
             # launch; its HBM floor, 255.5 MB at 8 TB/s, is 32 us).  frac is therefore the share of the matrix pipe's time the
             # launch (kernel + fix-up) uses; against the f32 MFMA peak (157.3 TF), which bounded the previous form of this kernel
             # (0.66 in round 1), the same time reads as frac_of_f32_mfma_peak.
             "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS / 6, "unit": "TFLOP/s (f32 multiply-adds)", "frac": ach / (BF16_MFMA_PEAK_TFLOPS / 6),
             "peak_basis": "bf16 dense MFMA peak 2516.6 TF / 6 products per f32 multiply-add",
-            "frac_of_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS,
+            "time_vs_round1_f32_mfma_bound": ach / F32_MFMA_PEAK_TFLOPS,      # (the kernel issues no f32 MFMAs: how this launch compares with the bound of the round-1 kernel)
             "hbm_frac": (4 * (rows * cfg.feat_dims[0] + cfg.feat_dims[0] * cfg.dim + rows * cfg.dim)) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us else 0.0,
             "traffic": traffic, "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC)", "traffic_source": src,
             "algorithmic_bytes_per_launch": 4 * (rows * cfg.feat_dims[0] + cfg.feat_dims[0] * cfg.dim + rows * cfg.dim),
-            "avg_us": us, "launches_timed": n, "algorithmic_flops_per_launch": flops}
+            "avg_us": us, "avg_us_source": "HIP events (torch events on the launch stream) around the GEMM launch + the whole shared reduce launch, inside the timed "
+                                           "region; an event pair adds ~5-10 us of stream bubbles: the rocprofv3 per-kernel durations under profiles/ are the tighter figure",
+            "launches_timed": n, "algorithmic_flops_per_launch": flops}
 
 
 def score_train_bytes(cfg, n_triples):

@@ -24,12 +24,6 @@ from . import _lib
 from ._lib import call, ptr, stream
 
 f32 = torch.float32
-import os as _os
-# A/B switches of the first projections (tools/ab_r03c.sh; all measured slower or equal inside the step, DESIGN.md par. 8):
-_L1_KC = bool(int(_os.environ.get("SNAG_L1_KC", "0")))            # the row-major table as a K-contiguous operand
-_L1_TILED = bool(int(_os.environ.get("SNAG_L1_TILED", "0")))      # the feature table in the tiled layout (snag_tile_a_f32)
-_L1_IMG = bool(int(_os.environ.get("SNAG_L1_IMG", "0")))          # the weight as a pre-split image (snag_presplit_b)
-
 
 @dataclass
 class MKGCConfig:
@@ -135,21 +129,11 @@ class MKGCHotPath:
             if tuple(f.shape) == (N, fd) and Nl != N:
                 f = f[lo:lo + Nl]
             self.feats.append(f.to(self.dev).contiguous())
-        # The first projection of every modality is X W^T with X [N, F] and F in the thousands.  As a GEMM with both
-        # operands K-contiguous it measures 81 TF; with both row-contiguous (X^T [F, N], W^T [F, D]) the LDS-DMA loop
-        # reaches 93 TF, so the engine keeps a transposed copy of each (static / once-per-epoch) feature table and
-        # stores that weight transposed.  The weight gradient dW^T = X^T-shaped product needs no extra copy.
-        # Rows of the transposed copies are padded to a multiple of 32 floats: with N = 15000 a row is 60,000 B, not a multiple of
-        # the 128-B line, so every 256-B tile segment would straddle three lines instead of two (PMC: 1.7x the algorithmic fetch).
-        self.ld_t = _align(max(Nl, 1), 32) + int(_os.environ.get("SNAG_LDT_EXTRA", "0"))        # (SNAG_LDT_EXTRA: tuning -- extra floats of pitch, multiple of 32)
-
-        def transposed(f, out=None):
-            if out is None:
-                out = torch.zeros(f.shape[1], self.ld_t, device=self.dev, dtype=f32)[:, :Nl]
-            call("snag_transpose_f32", ptr(f), f.stride(0), Nl, f.shape[1], ptr(out), out.stride(0), stream())
-            return out
-        self._transposed = transposed
-        self.feats_t = [transposed(f) for f in self.feats]
+        # The first projection of every modality is X W^T with X [N, F] and F in the thousands: both operands are streamed in the layout
+        # they are stored in -- the row-major table (K-contiguous A) and the nn.Linear weight [D, F] (K-contiguous B).  Rounds 1-2 kept a
+        # transposed copy of every feature table for this GEMM (row-contiguous operands measured 3 % faster inside the step: 101.6 vs
+        # 105.0 us for the visual projection + its reduce); it cost 290 MB, a full rewrite at every noise refresh (the refresh now touches
+        # only the rows in the new or the previous mask) and a second layout for the weights.
         self.g_slot = M - 1                                   # structural token last
         I, L, ffn = cfg.intermediate_size, cfg.num_layers, bool(cfg.use_intermediate)
 
@@ -169,10 +153,10 @@ class MKGCHotPath:
         add("rel", R, self.sdim)
         for i, fd in enumerate(cfg.feat_dims):
             if cfg.num_proj == 1:
-                add(f"proj{i}.weight", fd, D)      # stored TRANSPOSED ([in, out]): see _first_proj
+                add(f"proj{i}.weight", D, fd)      # nn.Linear layout [out, in]
                 add(f"proj{i}.bias", D)
             else:
-                add(f"proj{i}.l1", fd, D)          # stored TRANSPOSED
+                add(f"proj{i}.l1", D, fd)
                 add(f"proj{i}.l2", D, D)
         add("weight_raw", 6)
         for l in range(L):
@@ -272,12 +256,8 @@ class MKGCHotPath:
         self._proj_regions = (self._regions([(cfg.seed * 131 + 7 + i, lo * D, Nl * D, cfg.proj_dropout, self.keep_proj[i]) for i in range(len(cfg.feat_dims))])
                               if self.keep_proj is not None else None)
         self.tick = torch.zeros(1, device=dev, dtype=torch.int64)      # device-side step counter
-        # the first projections' weights as pre-split bf16 images, remade once per step (snag_presplit_b): the GEMM copies them into the
-        # LDS by DMA instead of splitting the same 2 MB weight in every workgroup and k-tile
-        self.w_img = [torch.empty(lib.snag_presplit_b_bytes(D, fd), device=dev, dtype=torch.uint8) for fd in cfg.feat_dims] if _L1_IMG else None
         # noise state (model/SNAG.py:86-98)
         self.noisy = [f.clone() for f in self.feats]
-        self.noisy_t = [self._transposed(f) for f in self.feats]
         self.ent_noise = torch.zeros(N, D, device=dev)                 # whole table on every rank (same seed): a rank reads its rows
         self.ent_noise_mask = torch.zeros(N, device=dev, dtype=torch.uint8)
         # row masks of the feature-noise refresh, two generations per modality (the refresh rewrites only rows in the new or the old mask)
@@ -311,10 +291,10 @@ class MKGCHotPath:
         self.p["rel"].copy_(torch.randn(cfg.n_rel, self.sdim, generator=g) * math.sqrt(2.0 / (cfg.n_rel + self.sdim)))   # xavier normal
         for i, fd in enumerate(cfg.feat_dims):
             if cfg.num_proj == 1:
-                self.p[f"proj{i}.weight"].copy_(lin((D, fd)).t())
+                self.p[f"proj{i}.weight"].copy_(lin((D, fd)))
                 self.p[f"proj{i}.bias"].copy_(bias(D, fd))
             else:
-                self.p[f"proj{i}.l1"].copy_(lin((D, fd)).t())
+                self.p[f"proj{i}.l1"].copy_(lin((D, fd)))
                 self.p[f"proj{i}.l2"].copy_(lin((D, D)))
         self.p["weight_raw"].fill_(1.0)
         I = cfg.intermediate_size
@@ -461,8 +441,8 @@ class MKGCHotPath:
     def update_noise(self, seed: Optional[int] = None):
         """Once per epoch (README "noise-level: epoch", main.py:253-254 -> SNAG.update_noise model/SNAG.py:86-98) -- or per step
         ("noise-level: step").  Launches: ONE for the three row masks (rand < ratio, drawn inverted: no xor pass), one refresh per
-        modality that rewrites only the rows in the new or the previous mask (and the transposed copy in the same pass), the entity
-        table's column statistics and its noise rows.  Every stream is keyed on global rows: all ranks draw one experiment."""
+        modality that rewrites only the rows in the new or the previous mask, the entity table's column statistics and its noise
+        rows.  Every stream is keyed on global rows: all ranks draw one experiment."""
         cfg = self.cfg
         st = stream()
         from . import ops
@@ -487,7 +467,7 @@ class MKGCHotPath:
             mean, std = self.feat_stats[i]
             call("snag_noise_refresh", ptr(f), Nl, f.shape[1], ptr(mean), ptr(std), ptr(self.row_mask[i][gen]),
                  ptr(self.row_mask[i][gen ^ 1]) if self.noise_active else None, base + 11 * i + 2, lo, float(cfg.mask_ratio),
-                 ptr(self.noisy[i]), ptr(self.noisy_t[i]), self.ld_t, st)
+                 ptr(self.noisy[i]), None, 0, st)
         mean, std = self._ent_stats
         call("snag_colstats", ptr(self.p["ent"]), N, D, None, N, ptr(mean), ptr(std), ptr(self._stat_work), st)
         call("snag_gaussian_fill", base + 101, N, D, ptr(mean), ptr(std), ptr(self.ent_noise), st)
@@ -552,37 +532,17 @@ class MKGCHotPath:
              (self.ent_noise_mask.data_ptr() + lo) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD,
              self._drop_regions if drop else None, len(self._drop_regions) if drop else 0, st)
         l1 = []
-        if self.w_img is not None:
-            for i, fd in enumerate(cfg.feat_dims):
-                call("snag_presplit_b", ptr(self.p[f"proj{i}.weight" if cfg.num_proj == 1 else f"proj{i}.l1"]), D, 0, D, fd, ptr(self.w_img[i]), st)
         for i, fd in enumerate(cfg.feat_dims):
-            feat_t = self.noisy_t[i] if noisy else self.feats_t[i]          # [fd, Nl]
-            fa, fld, fkc = ptr(feat_t), self.ld_t, 0
-            if _L1_TILED:
-                from . import ops as _ops
-                key = ("tf", i, bool(noisy), self.noise_epoch)
-                if getattr(self, "_tf_key", {}).get(i) != key:
-                    self._tf = getattr(self, "_tf", {})
-                    self._tf[i] = _ops.tile_a(self.noisy[i] if noisy else self.feats[i], kcontig=True)
-                    self._tf_key = getattr(self, "_tf_key", {})
-                    self._tf_key[i] = key
-                fa, fld, fkc = ptr(self._tf[i]), 0, 0
-            if _L1_KC:                   # A/B: the row-major table as a K-contiguous operand (no transposed copy needed)
-                feat = self.noisy[i] if noisy else self.feats[i]
-                fa, fld, fkc = ptr(feat), fd, 1
+            feat = self.noisy[i] if noisy else self.feats[i]                 # [Nl, fd] row-major: a K-contiguous operand
+            fa, fld, fkc = ptr(feat), fd, 1
             slot = x0p + 4 * i * D
             if cfg.num_proj == 1:
-                l1.append(self._gemm_desc(Nl, D, fd, fa, fld, fkc, ptr(self.p[f"proj{i}.weight"]), D, 0, slot, MD,
+                l1.append(self._gemm_desc(Nl, D, fd, fa, fld, fkc, ptr(self.p[f"proj{i}.weight"]), fd, 1, slot, MD,
                                           bias=ptr(self.p[f"proj{i}.bias"]), half=i % 2))
             else:   # ProjectionHead: Linear(no bias) -> ReLU -> dropout -> Linear(no bias)   (model/layers.py:135-148)
-                l1.append(self._gemm_desc(Nl, D, fd, fa, fld, fkc, ptr(self.p[f"proj{i}.l1"]), D, 0, ptr(self.mid[i]), D, act=1,
+                wb, wld, wkc = ptr(self.p[f"proj{i}.l1"]), fd, 1
+                l1.append(self._gemm_desc(Nl, D, fd, fa, fld, fkc, wb, wld, wkc, ptr(self.mid[i]), D, act=1,
                                           keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout), half=i % 2))
-        if self.w_img is not None:
-            for i, d_ in enumerate(l1):
-                d_.b_image = ptr(self.w_img[i])
-        if _L1_TILED:
-            for d_ in l1:
-                d_.a_tiled = 1
         # the modalities' first projections: K-split GEMMs of different K -- two kernels, ONE reduce launch per pair
         self._gemm_deferred_pairs(l1, ["proj_l1_fwd"] + [""] * (len(l1) - 1))
         if cfg.num_proj == 2:       # the second projections, two modalities per launch
@@ -756,11 +716,13 @@ class MKGCHotPath:
             feat = self.noisy[i] if noisy else self.feats[i]
             dslot = dx0 + 4 * i * D
             if cfg.num_proj == 1:
-                # dW^T [fd, D] = feat^T dTok ; db = colsum(dTok)
-                dl1.append(self._gemm_desc(fd, D, Nl, ptr(feat), fd, 0, dslot, MD, 0, ptr(self.g[f"proj{i}.weight"]), D, splitk=True, half=i % 2))
+                # dW^T [fd, D] = feat^T dTok, stored transposed: straight into the [D, fd] gradient ; db = colsum(dTok)
+                dl1.append(self._gemm_desc(fd, D, Nl, ptr(feat), fd, 0, dslot, MD, 0, ptr(self.g[f"proj{i}.weight"]), fd, splitk=True, half=i % 2))
             else:
-                dl1.append(self._gemm_desc(fd, D, Nl, ptr(feat), fd, 0, ptr(self.d_mid[i]), D, 0, ptr(self.g[f"proj{i}.l1"]), D, splitk=True,
-                                           half=i % 2))   # dl1^T [fd, D]
+                dl1.append(self._gemm_desc(fd, D, Nl, ptr(feat), fd, 0, ptr(self.d_mid[i]), D, 0, ptr(self.g[f"proj{i}.l1"]), fd, splitk=True,
+                                           half=i % 2))   # dl1^T [fd, D], stored transposed
+        for d in dl1:
+            d.c_transposed = 1
         if one_reduce:
             group = (ctypes.POINTER(_lib.GemmDesc) * 4)()
             for j, d in enumerate(dl2 + dl1):
@@ -941,13 +903,9 @@ class MKGCHotPath:
         self.train(was)
         return out
 
-    # parameters as a name -> tensor dict in the LOGICAL nn.Linear layout [out, in] (for tests / checkpoints);
-    # the transposed-storage projection weights come back as transposed views of the flat buffer
+    # parameters as a name -> tensor dict (every weight in the nn.Linear layout [out, in], as stored)
     def _logical(self, d):
-        out = {}
-        for k, v in d.items():
-            out[k] = v.t() if (k.startswith("proj") and (k.endswith(".l1") or k.endswith(".weight"))) else v
-        return out
+        return dict(d)
 
     def named_parameters(self):
         return self._logical(self.p)
@@ -1019,7 +977,6 @@ class MKGCHotPath:
             self.noise_epoch, self.noise_active = int(sd["noise_epoch"]), bool(sd["noise_active"])
             for i, x in enumerate(sd["noisy"]):
                 self.noisy[i].copy_(x)
-                self._transposed(self.noisy[i], self.noisy_t[i])
             self.ent_noise.copy_(sd["ent_noise"])
             self.ent_noise_mask.copy_(sd["ent_noise_mask"])
             for pair, saved in zip(self.row_mask, sd["row_mask"]):        # the next refresh takes back the rows of the CURRENT mask

@@ -8,7 +8,7 @@ d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
 print('$label', 'ms/step', round(d['ms_per_step'],4), 'l1fwd+reduce us', round(d['roofline']['avg_us'],1), 'score us', round(d['roofline_score']['avg_us'],1), 'loss', round(d['config'].get('final_loss',0),2))" || tail -5 gpurun_out/err.log
 }
 for rep in 1 2 3; do
-run base SNAG_L1_IMG=0 SNAG_L1_TILED=0
-run tiled SNAG_L1_TILED=1
-run tiled_img SNAG_L1_TILED=1 SNAG_L1_IMG=1
+run natural X=1
+
+
 done
