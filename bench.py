@@ -132,7 +132,9 @@ def roofline_score(cfg, batch, timer):
     row gathered ONCE; scores, losses, q / dq rows, one 8-byte entry per touched destination) and a per-destination pass (gathers the
     L2-resident q / dq rows, applies the normalisation backward once, WRITES each gradient row: no float atomics, no zero-fill,
     bit-reproducible), vs the 8 TB/s HBM figure.  The 7.7 MB table is cache-resident at this size: `achieved` is ALGORITHMIC bytes
-    (SURVEY par. 8d: rows read once + read-modify-write of the K+3 gradient rows per triple) / time of the two launches together."""
+    (SURVEY par. 8d: rows read once + read-modify-write of the K+3 gradient rows per triple) / time of the two launches together.
+    ``hbm_resident`` (added by main) holds the forward kernel AND the training form (``train_bf16_B*``) on the 1M x 256 table that no
+    cache holds; ``batch_8192`` the same two launches with eight times the work."""
     us, n = timer.mean_us()
     by = score_train_bytes(cfg, batch)
     ach = by / (us * 1e-6) / 1e9 if us else 0.0
@@ -278,6 +280,26 @@ def score_hbm_resident(device):
             us = e0.elapsed_time(e1) * 1e3 / 20
             by = B * ((K + 3) * D * esz + (K + 3) * 4 + (K + 1) * 4)
             out[f"{dt}_B{B}"] = {"avg_us": us, "achieved": by / us / 1e3, "unit": "GB/s", "frac": by / us / 1e3 / HBM_PEAK_GBS, "triples_per_s": B / us * 1e6}
+    # the TRAINING form on the same table (bf16 rows, fp32 gradient rows): forward bytes + read-modify-write of the (K + 3) gradient rows per
+    # triple (SURVEY par. 8d) over the time of the entry's launches (segmented form over the batch's entries: no float atomics)
+    from snag_amd import ops
+    e16, r16 = tables["bf16"][0], tables["bf16"][1]
+    d_ent, d_rel = torch.zeros(N, D, device=device), torch.zeros(R, D, device=device)
+    for B in (1024, 8192):
+        idx = [torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(device) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (N, (B, K)))]
+        run = lambda: ops.score_margin_fwd_bwd_touched(e16, r16, *idx, 12.0, d_ent=d_ent, d_rel=d_rel)
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 10
+        by = B * ((K + 3) * D * 2 + (K + 3) * 4 + (K + 1) * 4) + B * (K + 3) * D * 4 * 2
+        out[f"train_bf16_B{B}"] = {"entry": "snag_score_margin_fwd_bwd_touched_bf16", "avg_us": us, "achieved": by / us / 1e3, "unit": "GB/s",
+                                   "frac": by / us / 1e3 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": by, "triples_per_s": B / us * 1e6}
     return out
 
 

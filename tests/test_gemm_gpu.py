@@ -414,3 +414,36 @@ def test_gemm_presplit_b_image_equals_the_plain_call_bit_for_bit(M, N, K, a_mode
     assert torch.equal(got, plain)
     ref = torch.relu(_ref(a.cpu(), b.cpu(), a_mode != "rowc", b_kc) + bias.cpu().double())
     assert_close(got, ref, atol=2e-6 * K + 1e-5, rtol=2e-5)
+
+
+def test_gemm_non_finite_and_extreme_operands_are_documented_behaviour():
+    """The split-bf16 form (a = h + m + l, six products) vs an fp32 addmm on operands at the edges of fp32 (include/snag_hip.h, snag_gemm_f32):
+    * finite values up to ~3e38 and down to the smallest normals multiply like fp32 (the split is exact, accumulation is fp32);
+    * an infinite operand: the split gives (inf, NaN, NaN) -- a - bf16(a) is inf - inf --, so the affected outputs are NaN where fp32 gives
+      +-inf: DOCUMENTED divergence (feature tables and weights are finite; a non-finite input still poisons its outputs visibly);
+    * a NaN operand stays NaN in its row / column, as in fp32;
+    * denormal operands: their lower planes flush, the product is exact to the top 8 bits of the denormal (absolute error < 2^-133 |b|)."""
+    from snag_amd import ops
+    M, N, K = 64, 128, 64
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)
+    a[0, 0] = 3.0e38                                    # near FLT_MAX, times values below one: representable, no overflow in the split
+    b[:, 0] = b[:, 0].clamp(-0.9, 0.9)
+    a[1, :] = 0.0
+    a[1, 3], b[5, 3] = 1.1754944e-38, 1.0               # the smallest normal
+    a[2, 7] = float("inf")
+    a[3, 9] = float("nan")
+    a[4, :] = 0.0
+    a[4, 2], b[9, 2] = 1.0e-40, 1.0                     # a denormal
+    c = ops.gemm(a.to(DEV), b.to(DEV)).cpu()
+    ref = a.double() @ b.double().t()
+    fin = torch.ones(M, dtype=torch.bool)
+    fin[[0, 2, 3]] = False                              # (row 0 carries the 3e38 value, rows 2 / 3 the inf / NaN)
+    assert_close(c[fin], ref[fin], atol=1e-5, rtol=2e-5)
+    assert torch.isfinite(c[0]).all() and torch.allclose(c[0].double(), ref[0], rtol=1e-5, atol=1e31)      # huge but finite, as in fp32
+    assert c[1, 5] == 1.1754944e-38                                      # smallest normal: exact
+    assert torch.isnan(c[2]).all() or torch.isinf(c[2]).any()            # inf operand: NaN (documented), never a silently finite value
+    assert not torch.isfinite(c[2]).any()
+    assert torch.isnan(c[3]).all()                                       # NaN operand: NaN, as in fp32
+    assert abs(float(c[4, 9]) - 1.0e-40) < 1e-42                          # denormal: top bits survive
