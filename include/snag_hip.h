@@ -221,7 +221,7 @@ SNAG_API int snag_reduce_sum(const float* x, int64_t n, float* out, void* stream
  * long-K shapes; snag_gemm_workspace_floats(M,N,K) is the size that never limits the split.
  * Non-finite / extreme operands: every finite fp32 value (normals up to FLT_MAX, down to the smallest normal) multiplies as in fp32.  An
  * INFINITE operand splits to (inf, NaN, NaN) -- a - bf16(a) is inf - inf --, so outputs that fp32 would make +-inf come out NaN; a NaN
- * operand gives NaN as in fp32; a denormal operand keeps its top 8 significant bits (its lower planes flush).  The tables this path
+ * operand gives NaN as in fp32; a denormal operand keeps what bf16's denormal range holds (absolute error < 2^-133 per unit of the other operand).  The tables this path
  * multiplies (features, weights, activations) are finite; a non-finite input still shows in its outputs, as NaN
  * (tests/test_gemm_gpu.py::test_gemm_non_finite_and_extreme_operands_are_documented_behaviour). */
 typedef struct snag_gemm_desc {
