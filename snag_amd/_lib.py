@@ -86,7 +86,7 @@ SIGNATURES = {
     "snag_rank_full_table": [_P, _L, _L, _P, _I, _P, _P, _P],
     "snag_gemm_f32": [_c.POINTER(GemmDesc), _P],
     "snag_gemm_reduce_pair": [_P, _P, _P],
-    "snag_tile_a_f32": [_P, _L, _L, _L, _I, _P, _P],
+    "snag_tile_a_f32": [_P, _L, _L, _L, _I, _I, _P, _P],
     "snag_presplit_b": [_P, _L, _I, _L, _L, _P, _P],
     "snag_gemm_reduce_group": [_P, _c.c_int, _P],
     "snag_gemm_f32_pair": [_c.POINTER(GemmDesc), _c.POINTER(GemmDesc), _P],

@@ -419,6 +419,7 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     e.mask = d->keep_mask; e.ldm = d->ldmask > 0 ? d->ldmask : d->N; e.mscale = d->keep_scale; e.add1 = d->add1; e.ld1 = d->ld1; e.add2 = d->add2; e.ld2 = d->ld2;
     e.accumulate = d->accumulate; e.M = d->M; e.N = d->N; e.aux = d->aux; e.ldaux = d->ldaux; e.ct = d->c_transposed;
     p.a_nkt = d->a_tiled ? ceil_div(d->K, 16) : 0;
+    p.a_layout = d->a_tiled;
     p.b_image = d->b_image;
     e.mirror = d->mirror; e.ldmirror = d->ldmirror; e.mirror_mask = d->mirror_rowmask; e.mirror_scale = d->mirror_scale;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(256) void presplit_b_kernel(const float* __restrict
 
 // one thread = one 16-byte piece of the tiled copy: (block mb, k-tile kt, c, lh, li) <- A(32 mb + li, 16 kt + 8 c + 4 lh + 0..3)
 __global__ __launch_bounds__(256) void tile_a_kernel(const float* __restrict__ src, int64_t ld, int64_t M, int64_t K, int kcontig, float* __restrict__ dst,
-                                                     int64_t nkt, int64_t pieces) {
+                                                     int64_t nkt, int64_t pieces, int layout) {
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < pieces; t += (int64_t)gridDim.x * 256) {
         const int li = (int)(t & 31), lh = (int)((t >> 5) & 1), c = (int)((t >> 6) & 1);
         const int64_t blk = t >> 7, kt = blk % nkt, mb = blk / nkt;
@@ -703,7 +704,9 @@ __global__ __launch_bounds__(256) void tile_a_kernel(const float* __restrict__ s
             for (int j = 0; j < 4; ++j)
                 if (k0 + j < K) v[j] = kcontig ? src[m * ld + k0 + j] : src[(k0 + j) * ld + m];
         }
-        reinterpret_cast<float4*>(dst)[t] = make_float4(v[0], v[1], v[2], v[3]);
+        // layout 1: the piece index IS the lane order; layout 2: row li's 64 bytes hold its pieces (c, lh) in k order
+        const int64_t at = layout == 2 ? (blk * 128 + (int64_t)li * 4 + c * 2 + lh) : t;
+        reinterpret_cast<float4*>(dst)[at] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -715,6 +718,7 @@ int gemm_check(const snag_gemm_desc* d) {
     SNAG_REQUIRE(d->K == 0 || (d->A && d->B), SNAG_ERR_ARG, "gemm: null A or B");
     SNAG_REQUIRE(d->ldc >= (d->c_transposed ? d->M : d->N), SNAG_ERR_ARG, "gemm: ldc=%ld < %s=%d", (long)d->ldc, d->c_transposed ? "M" : "N", d->c_transposed ? d->M : d->N);
     SNAG_REQUIRE(!d->c_transposed || (!d->pre_act && !d->mirror), SNAG_ERR_UNSUPPORTED, "gemm: a transposed C takes no pre_act / mirror copy");
+    SNAG_REQUIRE(d->a_tiled >= 0 && d->a_tiled <= 2, SNAG_ERR_ARG, "gemm: a_tiled=%d (0 plain, 1 lane order, 2 row order)", d->a_tiled);
     SNAG_REQUIRE(!d->a_tiled || (kBf16x != 0 && kBK == 16 && d->N <= 128 && ((uintptr_t)d->A & 15) == 0), SNAG_ERR_UNSUPPORTED,
                  "gemm: the tiled A layout feeds the 256 x 128 row-private tile only (N <= 128, 16-byte aligned A)");
     SNAG_REQUIRE(d->a_tiled || d->lda >= (d->a_kcontig ? d->K : d->M), SNAG_ERR_ARG, "gemm: lda=%ld too small", (long)d->lda);
@@ -763,13 +767,14 @@ extern "C" SNAG_API int64_t snag_tile_a_floats(int64_t M, int64_t K) {
     return ((M + 31) / 32) * ((K + 15) / 16) * 512;
 }
 
-extern "C" SNAG_API int snag_tile_a_f32(const float* src, int64_t ld, int64_t M, int64_t K, int kcontig, float* dst, void* stream) {
-    SNAG_REQUIRE(M >= 0 && K >= 0 && ld >= (kcontig ? K : M), SNAG_ERR_ARG, "tile_a: bad sizes (M=%ld K=%ld ld=%ld)", (long)M, (long)K, (long)ld);
+extern "C" SNAG_API int snag_tile_a_f32(const float* src, int64_t ld, int64_t M, int64_t K, int kcontig, int layout, float* dst, void* stream) {
+    SNAG_REQUIRE(M >= 0 && K >= 0 && ld >= (kcontig ? K : M) && (layout == 1 || layout == 2), SNAG_ERR_ARG, "tile_a: bad sizes / layout (M=%ld K=%ld ld=%ld layout=%d)",
+                 (long)M, (long)K, (long)ld, layout);
     if (M == 0 || K == 0) return SNAG_OK;
     SNAG_REQUIRE(src && dst && ((uintptr_t)dst & 15) == 0, SNAG_ERR_ARG, "tile_a: null pointer or unaligned destination");
     const int64_t nkt = (K + 15) / 16, pieces = ((M + 31) / 32) * nkt * 128;
     hipLaunchKernelGGL(tile_a_kernel, dim3((unsigned)std::min<int64_t>(65536, (pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld, M, K, kcontig, dst,
-                       nkt, pieces);
+                       nkt, pieces, layout);
     return check_launch("snag_tile_a_f32");
 }
 

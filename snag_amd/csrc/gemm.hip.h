@@ -119,6 +119,7 @@ struct GemmOperands {
     int dbg;             // tuning only: nonzero = stop fetching after the first two k-tiles (compute-only ceiling)
     int xcd;             // bit 0: XCD-aware workgroup -> tile mapping (xcd_swizzle); bits 4..: row tiles per group of the grouped order (0 = row-major)
     int a_nkt;           // A in the tiled layout (snag_tile_a_f32; kernels compiled with A_TILED): k-tiles per 32-row block = ceil(K / 16)
+    int a_layout;        // 1: lane order inside a block ([c][lh][li][4]); 2: row order ([li][c][lh][4]: a row's 16 values of the k-tile are 64 contiguous bytes)
     const void* b_image; // B as pre-split bf16 planes in LDS-image order (snag_presplit_b; kernels compiled with B_IMG), ceil(K / 16) blocks of 16 KiB per column tile
 };
 
@@ -573,15 +574,21 @@ struct FragLoaderTiled {
     static constexpr int kLoads = 2;           // vector-memory instructions per k-tile
     float r[4][8];
     const char* ubase;
-    uint32_t voff;
+    uint32_t voff, istep;            // the lane's byte offset inside a block; distance of its second 16-byte piece
     int lh, ablate;
 
-    __device__ __forceinline__ void init(const float* __restrict__ P, int nkt, int row0 /* of the wave */, int nrows, int kbeg, int lane) {
+    __device__ __forceinline__ void init(const float* __restrict__ P, int nkt, int row0 /* of the wave */, int nrows, int kbeg, int lane, int layout) {
         lh = lane >> 5;
         const int nblk = (nrows + 31) >> 5;
         const int mb = min(row0 >> 5, nblk - 1);               // a wave wholly past the edge reads the last block (its products are never stored)
         ubase = reinterpret_cast<const char*>(P) + ((int64_t)mb * nkt + (kbeg >> 4)) * 2048;
-        voff = (uint32_t)lane * 16u;
+        if (layout == 2) {           // row order: row li's 64 bytes, pieces c * 32 + lh * 16
+            voff = (uint32_t)(lane & 31) * 64u + (uint32_t)lh * 16u;
+            istep = 32u;
+        } else {                     // lane order: piece (c * 2 + lh) * 512 + li * 16
+            voff = (uint32_t)lane * 16u;
+            istep = 1024u;
+        }
     }
     __device__ __forceinline__ int k_of(int j) const { return 4 * lh + (j & 3) + 8 * (j >> 2); }
     // FULL k-tiles only, like FragLoader::load (a tile at or past kleft / 16 reads zeros through an empty descriptor: the k-loop runs whole
@@ -594,7 +601,7 @@ struct FragLoaderTiled {
         const uint32_t so = (uint32_t)kt * 2048u;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, so + 1024u * i, 0);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, so + istep * i, 0);
             r[s][4 * i + 0] = __uint_as_float(v[0]);
             r[s][4 * i + 1] = __uint_as_float(v[1]);
             r[s][4 * i + 2] = __uint_as_float(v[2]);
@@ -747,7 +754,7 @@ struct GemmCore {
             static_assert(TM == 1, "row-private: one 32-row fragment per wave");
             std::conditional_t<A_TILED, FragLoaderTiled, FragLoader<A_KC>> fa;
             SplitStager<BN, B_KC, NT> sb;
-            if constexpr (A_TILED) fa.init(p.A, p.a_nkt, m0 + wm0, p.M, kbeg, lane);
+            if constexpr (A_TILED) fa.init(p.A, p.a_nkt, m0 + wm0, p.M, kbeg, lane, p.a_layout);
             else fa.init(p.A, p.lda, p.a_vec, m0 + wm0, p.M, kbeg, lane);
             [[maybe_unused]] ImageStager ib;
             if constexpr (B_IMG) ib.init(p.b_image, (p.K + 15) >> 4, n0, kbeg, tid);

@@ -254,13 +254,15 @@ def gram(z, alpha=1.0, out=None):
     return out
 
 
-def tile_a(a, kcontig=True):
-    """The tiled copy of an operand A (a: [M, K] when kcontig else [K, M]) for ``gemm(..., a_tiled=(M, K))``.  C ABI: snag_tile_a_f32."""
+def tile_a(a, kcontig=True, layout=1, out=None):
+    """The tiled copy of an operand A (a: [M, K] when kcontig else [K, M]) for ``gemm(..., a_tiled=(M, K), a_layout=layout)``.
+    C ABI: snag_tile_a_f32."""
     if not (torch.is_tensor(a) and a.is_cuda and a.dtype == f32 and a.dim() == 2 and a.stride(1) == 1):
         raise ValueError("tile_a: a must be a 2-D fp32 CUDA tensor with unit inner stride")
     M, K = a.shape if kcontig else (a.shape[1], a.shape[0])
-    out = torch.empty(_lib.load().snag_tile_a_floats(M, K), device=a.device, dtype=f32)
-    call("snag_tile_a_f32", ptr(a), a.stride(0), M, K, int(kcontig), ptr(out), stream())
+    if out is None:
+        out = torch.empty(_lib.load().snag_tile_a_floats(M, K), device=a.device, dtype=f32)
+    call("snag_tile_a_f32", ptr(a), a.stride(0), M, K, int(kcontig), int(layout), ptr(out), stream())
     return out
 
 
@@ -277,7 +279,7 @@ def presplit_b(b, kcontig=True, out=None):
 
 
 def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, alpha=1.0, act=None, want_pre_act=False,
-         keep_mask=None, keep_p=0.0, add1=None, add2=None, out=None, accumulate=False, splitk=True, aux=None, a_tiled=None, c_transposed=False, b_image=None):
+         keep_mask=None, keep_p=0.0, add1=None, add2=None, out=None, accumulate=False, splitk=True, aux=None, a_tiled=None, c_transposed=False, b_image=None, a_layout=1):
     """C = add1 + add2 + keep * act(alpha * A.B + bias)   (C ABI: snag_gemm_f32; fp32 via split-bf16 MFMA).
 
     a: [M,K] if a_kcontig else [K,M];  b: [N,K] if b_kcontig else [K,N]  (2-D, last dim contiguous,
@@ -300,7 +302,7 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, alpha=1.0, act=None
     d = _lib.GemmDesc()
     d.M, d.N, d.K = M, N, K
     d.a_kcontig, d.b_kcontig = int(a_kcontig), int(b_kcontig)
-    d.a_tiled, d.c_transposed = int(a_tiled is not None), int(c_transposed)
+    d.a_tiled, d.c_transposed = (int(a_layout) if a_tiled is not None else 0), int(c_transposed)
     d.b_image = ptr(b_image)
     d.A, d.lda = ptr(a), (0 if a_tiled is not None else a.stride(0))
     d.B, d.ldb = ptr(b), b.stride(0)

@@ -354,7 +354,8 @@ def test_gemm_mirror_output(M, N, K, split):
 
 @pytest.mark.parametrize("M,N,K", [(1000, 128, 4096), (15000, 128, 768), (4096, 128, 15000), (257, 100, 333), (31, 5, 17), (700, 128, 16), (512, 64, 2048)])
 @pytest.mark.parametrize("src_kc,b_kc", [(True, True), (False, False), (False, True), (True, False)])
-def test_gemm_tiled_a_equals_the_plain_layout_bit_for_bit(M, N, K, src_kc, b_kc):
+@pytest.mark.parametrize("layout", [1, 2])
+def test_gemm_tiled_a_equals_the_plain_layout_bit_for_bit(M, N, K, src_kc, b_kc, layout):
     """snag_tile_a_f32 + snag_gemm_desc.a_tiled: the same eight-wave row-private kernel fed from the tiled copy of A (two 16-byte loads
     per lane and k-tile instead of eight 4-byte ones) gives the BITS of the plain-layout call when both run that tile (N <= 128, long K,
     many rows), and fp64-close results everywhere; ragged M and K are zero-padded inside the tiled copy."""
@@ -362,15 +363,15 @@ def test_gemm_tiled_a_equals_the_plain_layout_bit_for_bit(M, N, K, src_kc, b_kc)
     g = torch.Generator().manual_seed(M + 3 * N + 5 * K)
     a = torch.randn((M, K) if src_kc else (K, M), generator=g).to(DEV)
     b = torch.randn((N, K) if b_kc else (K, N), generator=g).to(DEV)
-    at = ops.tile_a(a, kcontig=src_kc)
+    at = ops.tile_a(a, kcontig=src_kc, layout=layout)
     assert at.numel() == ((M + 31) // 32) * ((K + 15) // 16) * 512
-    c = ops.gemm(at, b, a_tiled=(M, K), b_kcontig=b_kc)
+    c = ops.gemm(at, b, a_tiled=(M, K), a_layout=layout, b_kcontig=b_kc)
     ref = _ref(a.cpu(), b.cpu(), src_kc, b_kc)
     assert_close(c, ref, atol=2e-6 * K + 1e-5, rtol=2e-5, what=f"tiled gemm {M}x{N}x{K}")
     if K >= 512 and M >= 1024:                       # the plain call picks the same tile and K split: same summation order
         plain = ops.gemm(a, b, a_kcontig=src_kc, b_kcontig=b_kc)
         assert torch.equal(c, plain)
-    c2 = ops.gemm(at, b, a_tiled=(M, K), b_kcontig=b_kc)
+    c2 = ops.gemm(at, b, a_tiled=(M, K), a_layout=layout, b_kcontig=b_kc)
     assert torch.equal(c, c2)
 
 
