@@ -342,11 +342,34 @@ typedef struct snag_fusion_desc {
      * projection, LayerNorm (and FFN) for token g alone -- same values, (2M+2)/(4M) of the GEMM work -- and `hidden` is [N, D].
      * joint / joint_fz / weight_norm must be NULL in that mode. */
     int32_t readout_slot_p1;
+    /* read-out mode with L = 1 only.  1: the caller SUPPLIES the keys / values of every token but the read-out one, and takes their
+     * gradient back (projection folding: a token that is x_m = mid_m l2_m^T enters the layer through K, V alone, so
+     * KV_m = mid_m (Wkv l2_m)^T + b needs neither x_m nor its own GEMM pass over l2).  Forward: before the call the caller has written
+     * KV_m into rows n * M + m, columns D..3D of the layer's q/k/v activation (snag_fusion_readout_offsets: `qkv` floats into `save`,
+     * row pitch 3 D); only the read-out token's K, V, Q are projected here.  Backward: d_x0 receives the read-out token's rows only, the
+     * key / value weight gradient its contribution only, and the caller reads dKV_m from rows n * M + m of the [N * M, 2 D] block at
+     * `dkv` floats into `work` (it owes d mid_m = dKV_m (Wkv l2_m), d(Wkv l2_m) = dKV_m^T mid_m and the chain rule onto Wkv and l2_m). */
+    int32_t fold_others;
 } snag_fusion_desc;
 
 SNAG_API int64_t snag_fusion_save_floats(int N, int M, int D, int H, int I, int L, int use_intermediate);
 SNAG_API int64_t snag_fusion_work_floats(int N, int M, int D, int H, int I, int L, int use_intermediate);
 SNAG_API int snag_fusion_fwd(const snag_fusion_desc* desc, void* stream);
+/* where the read-out layer keeps its stacked q/k/v activation ([N * M, 3 D], floats into `save`) and the gradient of its keys / values
+ * ([N * M, 2 D], floats into `work`): see fold_others */
+SNAG_API int snag_fusion_readout_offsets(const snag_fusion_desc* desc, int64_t* qkv_save_offset, int64_t* dkv_work_offset);
+/* Up to four small dense products in ONE launch, plain fp32 fused multiply-adds in k order (an f32 fmaf chain per output):
+ *   C[m * ldc + n] (=|+=) sum_k A(m, k) B(k, n),  A(m, k) = A[m * sam + k * sak],  B(k, n) = B[k * sbk + n * sbn]
+ * (the problems of one launch must write disjoint outputs)
+ * for the parameter-sized products of projection folding (Wkv l2_m and the chain rule back onto Wkv / l2_m: 128..256-sized). */
+typedef struct snag_small_mm {
+    int32_t M, N, K, accumulate;
+    const float* A; int64_t sam, sak;
+    const float* B; int64_t sbk, sbn;
+    float* C; int64_t ldc;
+    const float* A2; const float* B2;     /* optional second term with the same sizes and strides: C (=|+=) A B + A2 B2 (NULL: none) */
+} snag_small_mm;
+SNAG_API int snag_small_matmul(const snag_small_mm* problems, int n_problems, void* stream);
 
 /* Backward.  `f` is the forward's descriptor (same save buffer, still holding the forward's
  * activations; f.hidden etc. are not read).  Upstream gradients d_* may each be NULL (= zero).

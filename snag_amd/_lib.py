@@ -57,7 +57,14 @@ class FusionDesc(_c.Structure):
                 ("L", _c.c_int32), ("use_intermediate", _c.c_int32), ("drop_p", _F),
                 ("layers", _c.POINTER(FusionLayer)), ("weight_raw", _P), ("x0", _P),
                 ("joint", _P), ("joint_fz", _P), ("hidden", _P), ("weight_norm", _P),
-                ("save", _P), ("save_floats", _L), ("work", _P), ("work_floats", _L), ("readout_slot_p1", _c.c_int32)]
+                ("save", _P), ("save_floats", _L), ("work", _P), ("work_floats", _L), ("readout_slot_p1", _c.c_int32),
+                ("fold_others", _c.c_int32)]
+
+
+class SmallMM(_c.Structure):
+    """struct snag_small_mm."""
+    _fields_ = [("M", _c.c_int32), ("N", _c.c_int32), ("K", _c.c_int32), ("accumulate", _c.c_int32), ("A", _P), ("sam", _L), ("sak", _L),
+                ("B", _P), ("sbk", _L), ("sbn", _L), ("C", _P), ("ldc", _L), ("A2", _P), ("B2", _P)]
 
 
 class FusionBwdDesc(_c.Structure):
@@ -92,6 +99,8 @@ SIGNATURES = {
     "snag_gemm_f32_pair": [_c.POINTER(GemmDesc), _c.POINTER(GemmDesc), _P],
     "snag_fusion_fwd": [_c.POINTER(FusionDesc), _P],
     "snag_fusion_bwd": [_c.POINTER(FusionBwdDesc), _P],
+    "snag_fusion_readout_offsets": [_c.POINTER(FusionDesc), _P, _P],
+    "snag_small_matmul": [_P, _I, _P],
     "snag_pack_tokens": [_c.POINTER(_P), _I, _L, _I, _I, _P, _P, _F, _P, _P],
     "snag_token_mean": [_P, _L, _I, _I, _P, _P],
     "snag_colstats": [_P, _L, _I, _P, _L, _P, _P, _P, _P],

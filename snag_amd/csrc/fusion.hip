@@ -96,6 +96,7 @@ static int check_fusion(const snag_fusion_desc* f) {
     SNAG_REQUIRE(f->readout_slot_p1 >= 0 && f->readout_slot_p1 <= f->M, SNAG_ERR_ARG, "fusion: readout_slot_p1=%d outside [0, M=%d]", f->readout_slot_p1, f->M);
     SNAG_REQUIRE(f->readout_slot_p1 == 0 || !(f->joint || f->joint_fz || f->weight_norm), SNAG_ERR_UNSUPPORTED,
                  "fusion: the read-out-only last layer computes attention for one token only; joint / joint_fz / weight_norm need all of it");
+    SNAG_REQUIRE(!f->fold_others || (f->readout_slot_p1 > 0 && f->L == 1), SNAG_ERR_UNSUPPORTED, "fusion: fold_others needs the read-out mode with one layer");
     if (f->N == 0) return SNAG_OK;
     SNAG_REQUIRE(f->layers && f->weight_raw && f->x0 && f->save, SNAG_ERR_ARG, "fusion: null layers / weight_raw / x0 / save");
     const int64_t need = snag_fusion_save_floats(f->N, f->M, f->D, f->H, f->I, f->L, f->use_intermediate);
@@ -119,8 +120,10 @@ static int fusion_fwd_readout(const snag_fusion_desc* f, const snag_fusion_layer
     const float kscale = 1.0f / (1.0f - f->drop_p);
     const dim3 egrid((unsigned)ceil_div(N, 4));
     int rc;
-    // K,V of every token: columns D..3D of the stacked projection
-    snag_gemm_desc gd = gemm_desc((int)NM, 2 * D, D, xin, D, true, P.wqkv + (int64_t)D * D, D, true, S.qkv + D, 3 * D);
+    // K,V of every token: columns D..3D of the stacked projection (fold_others: of the read-out token only -- the caller has written
+    // the other tokens' keys / values, computed from what their tokens are projected from)
+    snag_gemm_desc gd = f->fold_others ? gemm_desc(N, 2 * D, D, xin + (int64_t)g * D, MD, true, P.wqkv + (int64_t)D * D, D, true, S.qkv + (int64_t)g * 3 * D + D, 3 * MD)
+                                       : gemm_desc((int)NM, 2 * D, D, xin, D, true, P.wqkv + (int64_t)D * D, D, true, S.qkv + D, 3 * D);
     gd.bias = P.bqkv + D;
     // Q of token g only: rows n*M + g of x (stride M*D) -> the q part of the same rows of qkv.  Disjoint outputs: one grouped launch.
     snag_gemm_desc gq = gemm_desc(N, D, D, xin + (int64_t)g * D, MD, true, P.wqkv, D, true, S.qkv + (int64_t)g * 3 * D, 3 * MD);
@@ -360,7 +363,9 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
                 snag_gemm_desc g0 = gemm_desc(D, D, N, dz, D, false, S.ctx, D, false, G.wo, D);
                 snag_gemm_desc g1 = gemm_desc(D, D, N, dq_g, D, false, xin + (int64_t)ro * D, MD, false, G.wqkv, D);
                 // dWkv = dkv^T x (rows D..3D).  All three K splits leave their slabs in their own parts of the scratch; one launch reduces them
-                snag_gemm_desc gk = gemm_desc(2 * D, D, (int)NM, dkv, 2 * D, false, xin, D, false, G.wqkv + (int64_t)D * D, D);
+                snag_gemm_desc gk = f->fold_others     // (the read-out token's rows only: the caller owns the other tokens' share)
+                                        ? gemm_desc(2 * D, D, N, dkv + (int64_t)ro * 2 * D, 2 * MD, false, xin + (int64_t)ro * D, MD, false, G.wqkv + (int64_t)D * D, D)
+                                        : gemm_desc(2 * D, D, (int)NM, dkv, 2 * D, false, xin, D, false, G.wqkv + (int64_t)D * D, D);
                 const int64_t pw = (gemm_workspace_floats(D, D, (int)NM) + 64) / 64 * 64;
                 g0.accumulate = acc; g0.workspace = W.gemm_ws; g0.workspace_floats = pw;
                 g1.accumulate = acc; g1.workspace = W.gemm_ws + pw; g1.workspace_floats = pw;
@@ -373,7 +378,8 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             }
             // d(layer input) = dkv Wkv for every token, + dq_g Wq + dT1 into the rows of token ro
             float* dxin = (l == 0) ? b->d_x0 : W.dC;
-            g = gemm_desc((int)NM, D, 2 * D, dkv, 2 * D, true, P.wqkv + (int64_t)D * D, D, false, dxin, D);
+            g = f->fold_others ? gemm_desc(N, D, 2 * D, dkv + (int64_t)ro * 2 * D, 2 * MD, true, P.wqkv + (int64_t)D * D, D, false, dxin + (int64_t)ro * D, MD)
+                               : gemm_desc((int)NM, D, 2 * D, dkv, 2 * D, true, P.wqkv + (int64_t)D * D, D, false, dxin, D);
             if ((rc = gemm_dispatch(&g, st))) return rc;
             g = gemm_desc(N, D, D, dq_g, D, true, P.wqkv, D, false, dxin + (int64_t)ro * D, MD);
             g.add1 = W.dA; g.ld1 = D; g.accumulate = 1;
@@ -454,6 +460,91 @@ extern "C" SNAG_API int64_t snag_fusion_save_floats(int N, int M, int D, int H, 
 extern "C" SNAG_API int64_t snag_fusion_work_floats(int N, int M, int D, int H, int I, int L, int use_intermediate) {
     if (N < 0 || M < 1 || D < 1 || H < 1 || L < 1) return 0;
     return work_floats(N, M, D, H, I, use_intermediate != 0);
+}
+
+extern "C" SNAG_API int snag_fusion_readout_offsets(const snag_fusion_desc* f, int64_t* qkv_save_offset, int64_t* dkv_work_offset) {
+    SNAG_REQUIRE(f != nullptr && qkv_save_offset && dkv_work_offset, SNAG_ERR_ARG, "fusion_readout_offsets: null argument");
+    SNAG_REQUIRE(f->readout_slot_p1 > 0 && f->L >= 1, SNAG_ERR_UNSUPPORTED, "fusion_readout_offsets: read-out mode only");
+    const bool ffn = f->use_intermediate != 0;
+    const SaveLayout lay(f->N, f->M, f->D, f->H, f->I, ffn);
+    *qkv_save_offset = lay.per_layer * (f->L - 1);                       // LayerSave::qkv is the first region of a layer
+    *dkv_work_offset = 3 * (int64_t)f->N * f->M * f->D;                  // Work: dA, dB, dC, then dqkv (dkv first)
+    return SNAG_OK;
+}
+
+namespace snag {
+struct SmallMMSet {
+    snag_small_mm p[4];
+    int first[5];                     // block ranges
+};
+// One 16x16 output tile per workgroup, one output per thread; the operands go through LDS in 64-deep k slices, read from memory along
+// whichever of their two strides is 1 (a weight and its transpose are both operands here: the one-thread-per-output form with direct
+// strided reads took 43 / 87 us per launch of these parameter-sized products).  Sums run in k order: one result whatever the grid.
+__global__ __launch_bounds__(256) void small_matmul_kernel(SmallMMSet s, int n) {
+    __shared__ float As[64][17], Bs[64][17];
+    int q = 0;
+    while (q + 1 < n && (int)blockIdx.x >= s.first[q + 1]) ++q;
+    const snag_small_mm& P = s.p[q];
+    const int tiles_n = (P.N + 15) / 16;
+    const int tile = (int)blockIdx.x - s.first[q];
+    const int m0 = tile / tiles_n * 16, n0 = tile % tiles_n * 16;
+    const int t = threadIdx.x, tm = t >> 4, tn = t & 15;
+    float acc = 0.f;
+    auto term = [&](const float* __restrict__ A, const float* __restrict__ B) {
+        for (int k0 = 0; k0 < P.K; k0 += 64) {
+            // unconditional loads at clamped indices, then a select: loads inside a bounds branch are issued one at a time
+            float av[4], bv[4];
+            int sa[4], sb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = t + 256 * e;
+                int mm, ka, nn, kb;
+                if (P.sak == 1) { ka = idx & 63; mm = idx >> 6; } else { mm = idx & 15; ka = idx >> 4; }
+                if (P.sbk == 1) { kb = idx & 63; nn = idx >> 6; } else { nn = idx & 15; kb = idx >> 4; }
+                const bool ina = m0 + mm < P.M && k0 + ka < P.K, inb = n0 + nn < P.N && k0 + kb < P.K;
+                av[e] = A[(int64_t)min(m0 + mm, P.M - 1) * P.sam + (int64_t)min(k0 + ka, P.K - 1) * P.sak];
+                bv[e] = B[(int64_t)min(k0 + kb, P.K - 1) * P.sbk + (int64_t)min(n0 + nn, P.N - 1) * P.sbn];
+                if (!ina) av[e] = 0.f;
+                if (!inb) bv[e] = 0.f;
+                sa[e] = ka * 17 + mm;
+                sb[e] = kb * 17 + nn;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { (&As[0][0])[sa[e]] = av[e]; (&Bs[0][0])[sb[e]] = bv[e]; }
+            __syncthreads();
+            // rows past K hold zeros: a full slice adds the same sum
+#pragma unroll 16
+            for (int kk = 0; kk < 64; ++kk) acc = fmaf(As[kk][tm], Bs[kk][tn], acc);
+            __syncthreads();
+        }
+    };
+    term(P.A, P.B);
+    if (P.A2 != nullptr) term(P.A2, P.B2);
+    if (m0 + tm < P.M && n0 + tn < P.N) {
+        float* out = P.C + (int64_t)(m0 + tm) * P.ldc + n0 + tn;
+        *out = P.accumulate ? *out + acc : acc;
+    }
+}
+}  // namespace snag
+
+extern "C" SNAG_API int snag_small_matmul(const snag_small_mm* problems, int n_problems, void* stream) {
+    SNAG_REQUIRE(problems != nullptr && n_problems >= 1 && n_problems <= 4, SNAG_ERR_ARG, "small_matmul: 1..4 problems");
+    SmallMMSet s{};
+    int blocks = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        const snag_small_mm& P = problems[i];
+        SNAG_REQUIRE(P.M >= 0 && P.N >= 0 && P.K >= 0 && (P.M == 0 || P.N == 0 || (P.C && P.ldc >= P.N && (P.K == 0 || (P.A && P.B)))), SNAG_ERR_ARG,
+                     "small_matmul: bad problem %d", i);
+        SNAG_REQUIRE((P.A2 == nullptr) == (P.B2 == nullptr), SNAG_ERR_ARG, "small_matmul: problem %d has half a second term", i);
+        SNAG_REQUIRE((int64_t)P.M * P.N <= (1 << 22), SNAG_ERR_UNSUPPORTED, "small_matmul: problem %d has more than 4M outputs (use snag_gemm_f32)", i);
+        s.p[i] = P;
+        s.first[i] = blocks;
+        blocks += ceil_div(P.M, 16) * ceil_div(P.N, 16);
+    }
+    s.first[n_problems] = blocks;
+    if (blocks == 0) return SNAG_OK;
+    hipLaunchKernelGGL(small_matmul_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, s, n_problems);
+    return check_launch("snag_small_matmul");
 }
 
 extern "C" SNAG_API int snag_fusion_fwd(const snag_fusion_desc* f, void* stream) {

@@ -51,6 +51,10 @@ class MKGCConfig:
     weight_decay: float = 1e-4
     readout_only: bool = True           # Mformer_hd_graph consumes hidden[:, g, :] alone: the last layer computes the query / attention row /
                                         # output projection / LayerNorm (/ FFN) for the structural token only (same values, 2/3 of the GEMM work)
+    fold_proj: bool = True              # read-out-only, one layer, num_proj = 2: the projected tokens enter the layer through their keys /
+                                        # values alone, so KV_m = mid_m (Wkv l2_m)^T + b is computed straight from the first projection's
+                                        # output -- the second projection's GEMM (and its share of the backward) is folded into the
+                                        # key / value projection (fp32 re-association of (mid l2^T) Wkv^T: equal to rounding, not bit-equal)
     scorer: str = "segmented"           # training form of the hinge scorer: "segmented" = per-triple pass + per-destination pass, no float atomics,
                                         # bit-reproducible, gradient rows written (snag_score_margin_fwd_bwd_seg); "atomic" = one launch that
                                         # scatter-adds with fp32 atomics (snag_score_margin_fwd_bwd)
@@ -227,7 +231,11 @@ class MKGCHotPath:
         ws = max(ws, 2 * (lib.snag_gemm_workspace_floats(D, D, Nl) + 64), lib.snag_gemm_workspace_floats(Nl, D, D) + 64)
         self.work = torch.empty(ws, device=dev)
         # the second projections' weight gradients keep their K-split slabs here until the first projections' reduce launch takes them along
-        self.work_l2 = torch.empty(2 * (lib.snag_gemm_workspace_floats(D, D, Nl) + 64), device=dev) if cfg.num_proj == 2 else None
+        self.fold = bool(cfg.fold_proj) and self.ro and L == 1 and cfg.num_proj == 2 and len(cfg.feat_dims) == M - 1
+        self.work_l2 = torch.empty(2 * (lib.snag_gemm_workspace_floats(2 * D if self.fold else D, D, Nl) + 64), device=dev) if cfg.num_proj == 2 else None
+        # projection folding: Wf_m = Wkv l2_m [2D, D] (remade every step) and its gradient
+        self.wf = [torch.empty(2 * D, D, device=dev) for _ in cfg.feat_dims] if self.fold else None
+        self.d_wf = [torch.empty(2 * D, D, device=dev) for _ in cfg.feat_dims] if self.fold else None
         H = cfg.num_heads
         # all dropout keep-masks of the step live in ONE byte buffer (views below), so one Philox launch draws them all
         n_probs, n_tok = _align(Nl * H * M * M), _align(Nl * M * D)
@@ -333,8 +341,14 @@ class MKGCHotPath:
         elif cfg.joint_way == "learnable_weight":
             d.joint_fz = ptr(self.joint)
         d.readout_slot_p1 = self.g_slot + 1 if self.ro else 0
+        d.fold_others = int(self.fold)
         d.save, d.save_floats = ptr(self.save), self.save.numel()
         d.work, d.work_floats = ptr(self.work), self.work.numel()
+        if self.fold:
+            q_off, k_off = ctypes.c_int64(), ctypes.c_int64()
+            call("snag_fusion_readout_offsets", ctypes.byref(d), ctypes.byref(q_off), ctypes.byref(k_off))
+            self._qkv_ptr = self.save.data_ptr() + 4 * q_off.value            # [rows * M, 3 D] q/k/v activation of the read-out layer
+            self._dkv_ptr = self.work.data_ptr() + 4 * k_off.value            # [rows * M, 2 D] gradient of its keys / values
         self._fdesc = d
         b = _lib.FusionBwdDesc()
         b.d_hidden = ptr(self.d_repr) if self.ro else ptr(self.d_hidden)      # None for the concatenation read-outs
@@ -545,7 +559,27 @@ class MKGCHotPath:
                                           keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout), half=i % 2))
         # the modalities' first projections: K-split GEMMs of different K -- two kernels, ONE reduce launch per pair
         self._gemm_deferred_pairs(l1, ["proj_l1_fwd"] + [""] * (len(l1) - 1))
-        if cfg.num_proj == 2:       # the second projections, two modalities per launch
+        if self.fold:
+            # folded second projections: Wf_m = Wkv l2_m (parameter-sized: one small launch), then the projected tokens' keys / values
+            # straight from mid_m into the layer's q/k/v activation; the tokens themselves are never formed
+            nmod = len(cfg.feat_dims)
+            wkv = self.p["layer0.wqkv"].data_ptr() + 4 * D * D
+            for i0 in range(0, nmod, 4):
+                probs = (_lib.SmallMM * min(4, nmod - i0))()
+                for j, pm in enumerate(probs):
+                    i = i0 + j
+                    pm.M, pm.N, pm.K, pm.accumulate = 2 * D, D, D, 0
+                    pm.A, pm.sam, pm.sak = wkv, D, 1
+                    pm.B, pm.sbk, pm.sbn = ptr(self.p[f"proj{i}.l2"]), D, 1
+                    pm.C, pm.ldc = ptr(self.wf[i]), D
+                call("snag_small_matmul", probs, len(probs), st)
+            kv = [self._gemm_desc(Nl, 2 * D, D, ptr(self.mid[i]), D, 1, ptr(self.wf[i]), D, 1, self._qkv_ptr + 4 * (i * 3 * D + D), 3 * MD,
+                                  bias=self.p["layer0.bqkv"].data_ptr() + 4 * D, splitk=False) for i in range(nmod)]
+            for i in range(0, nmod - 1, 2):
+                self._gemm_pair(kv[i], kv[i + 1])
+            if nmod % 2:
+                call("snag_gemm_f32", ctypes.byref(kv[-1]), st)
+        elif cfg.num_proj == 2:       # the second projections, two modalities per launch
             l2 = [self._gemm_desc(Nl, D, D, ptr(self.mid[i]), D, 1, ptr(self.p[f"proj{i}.l2"]), D, 1, x0p + 4 * i * D, MD) for i in range(len(cfg.feat_dims))]
             for i in range(0, len(l2) - 1, 2):
                 self._gemm_pair(l2[i], l2[i + 1])
@@ -693,12 +727,30 @@ class MKGCHotPath:
                 reducer.start(self.g["rel"].reshape(-1))
             else:
                 reducer.start(buckets[0])
-            reducer.start(buckets[1])
+            if not self.fold:            # (folded second projections: the key / value weight gradient is completed further down)
+                reducer.start(buckets[1])
         nmod = len(cfg.feat_dims)
         # two modalities, one rank: the four projection weight gradients (dl2 pair, dl1 x 2) leave their K-split slabs in place and
         # ONE launch at the end reduces all four
         one_reduce = reducer is None and cfg.num_proj == 2 and nmod == 2
-        if cfg.num_proj == 2:
+        if self.fold:
+            # folded second projections: from the gradient of the projected tokens' keys / values (left in the Mformer backward's scratch)
+            #   d mid_m = (dKV_m Wf_m) * [mid_m > 0] (* keep)        [rows, D]   <- K = 2 D
+            #   d Wf_m  = dKV_m^T mid_m                               [2 D, D]   <- K = rows (split, slabs in work_l2: the scratch holds dKV)
+            # and, once d Wf_m is final, the chain rule onto the two factors of Wf_m = Wkv l2_m (parameter-sized, one small launch)
+            dkv = self._dkv_ptr
+            dl2 = [self._gemm_desc(2 * D, D, Nl, dkv + 4 * i * 2 * D, 2 * MD, 0, ptr(self.mid[i]), D, 0, ptr(self.d_wf[i]), D, splitk=True, half=i % 2,
+                                   scratch=self.work_l2) for i in range(nmod)]
+            for d in dl2:
+                d.defer_reduce = int(one_reduce)
+            dmid = [self._gemm_desc(Nl, D, 2 * D, dkv + 4 * i * 2 * D, 2 * MD, 1, ptr(self.wf[i]), D, 0, ptr(self.d_mid[i]), D, act=4, aux=ptr(self.mid[i]),
+                                    ldaux=D, keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout), splitk=False) for i in range(nmod)]
+            for group in (dmid, dl2):
+                for i in range(0, nmod - 1, 2):
+                    self._gemm_pair(group[i], group[i + 1])
+                if nmod % 2:
+                    call("snag_gemm_f32", ctypes.byref(group[-1]), st)
+        elif cfg.num_proj == 2:
             # dl2 = dTok^T mid and d mid = (dTok l2) * [mid > 0] (* keep): same shapes for every modality -> two per launch
             dl2 = [self._gemm_desc(D, D, Nl, dx0 + 4 * i * D, MD, 0, ptr(self.mid[i]), D, 0, ptr(self.g[f"proj{i}.l2"]), D, splitk=True, half=i % 2,
                                    scratch=self.work_l2 if one_reduce else None) for i in range(nmod)]
@@ -733,6 +785,30 @@ class MKGCHotPath:
             call("snag_gemm_reduce_group", group, 4, st)
         elif reducer is None:       # weight gradients of the first projections: two kernels, ONE reduce launch per pair of modalities
             self._gemm_deferred_pairs(dl1)
+        if self.fold:
+            # d l2_m = Wkv^T d Wf_m ; d Wkv += d Wf_m l2_m^T   (the read-out token's own contribution to d Wkv is already there)
+            wkv = self.p["layer0.wqkv"].data_ptr() + 4 * D * D
+            gkv = self.g["layer0.wqkv"].data_ptr() + 4 * D * D
+            for i0 in range(0, nmod, 2):           # two modalities per launch: their d l2 (disjoint outputs) and ONE two-term problem for d Wkv
+                n_here = min(2, nmod - i0)
+                probs = (_lib.SmallMM * (n_here + 1))()
+                for j in range(n_here):
+                    i = i0 + j
+                    a = probs[j]
+                    a.M, a.N, a.K, a.accumulate = D, D, 2 * D, 0
+                    a.A, a.sam, a.sak = wkv, 1, D
+                    a.B, a.sbk, a.sbn = ptr(self.d_wf[i]), D, 1
+                    a.C, a.ldc = ptr(self.g[f"proj{i}.l2"]), D
+                b2 = probs[n_here]
+                b2.M, b2.N, b2.K, b2.accumulate = 2 * D, D, D, 1
+                b2.A, b2.sam, b2.sak = ptr(self.d_wf[i0]), D, 1
+                b2.B, b2.sbk, b2.sbn = ptr(self.p[f"proj{i0}.l2"]), 1, D
+                if n_here == 2:
+                    b2.A2, b2.B2 = ptr(self.d_wf[i0 + 1]), ptr(self.p[f"proj{i0 + 1}.l2"])
+                b2.C, b2.ldc = gkv, D
+                call("snag_small_matmul", probs, len(probs), st)
+            if reducer is not None:
+                reducer.start(buckets[1])
         bias_pair = cfg.num_proj == 1 and reducer is None and nmod == 2
         if bias_pair:       # db = colsum(dTok) of both modalities in one pair of launches
             call("snag_colsum_pair", dx0, dx0 + 4 * D, Nl, D, MD, ptr(self.g["proj0.bias"]), ptr(self.g["proj1.bias"]), 0, wk, st)
