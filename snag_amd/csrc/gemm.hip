@@ -285,6 +285,11 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(GemmOperands p, float al
 // row-contiguous, but loses 5-20 % when both are K-contiguous, so those keep the checked loader.
 static bool use_vec(const GemmOperands& p, bool a_kc, bool b_kc) {
     static const int vec_mode = env_int("SNAG_GEMM_VEC");      // tuning: 1 = never, 2 = whenever legal
+    // split-bf16 builds (every tile runs the pre-split loops, which look at VEC for K-contiguous operands only): 16-byte loads as a
+    // compile-time choice whenever they are legal -- the loop's waits are then counted (vmcnt(9) in the ping-pong loop) instead of one
+    // vmcnt(0) every fourth iteration; same box, in the step: 0.6206 / 0.6251 / 0.6268 vs 0.6280 / 0.6303 / 0.6297 ms.  SNAG_GEMM_VEC=1: the
+    // loaders decide at run time (A/B)
+    if (kBf16x != 0) return vec_mode != 1 && (!a_kc || p.a_vec) && (!b_kc || p.b_vec);
     const bool legal = p.a_vec && p.b_vec && (a_kc || p.M % 4 == 0) && (b_kc || p.N % 4 == 0) && p.M >= 4 && p.N >= 4;
     return legal && vec_mode != 1 && (vec_mode == 2 || !(a_kc && b_kc));
 }
@@ -347,8 +352,7 @@ static StreamKChoice plan_streamk(int M, int N, int K, int BM, int BN) {
 
 template <int BM, int BN, int WM, int WN>
 static int launch_streamk(const GemmOperands& p, const Epilogue& e, float* slab, const StreamKChoice& c, bool a_kc, bool b_kc, hipStream_t st) {
-    const bool legal = p.a_vec && p.b_vec && (a_kc || p.M % 4 == 0) && (b_kc || p.N % 4 == 0) && p.M >= 4 && p.N >= 4;
-    const bool vec = legal && !(a_kc && b_kc);
+    const bool vec = use_vec(p, a_kc, b_kc);
     dim3 grid(c.G), block(256);
 #define SNAG_SK(AK, BK_)                                                                                                           \
     do {                                                                                                                           \

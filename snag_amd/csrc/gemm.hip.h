@@ -82,6 +82,9 @@ __device__ unsigned long long g_gemm_stamps[2 * 4 * 9];
 #else
 #define SNAG_STAMP(I, P) do { } while (0)
 #endif
+#ifndef SNAG_GEMM_SKIP_ASPLIT
+#define SNAG_GEMM_SKIP_ASPLIT 0
+#endif
 #ifndef SNAG_GEMM_PP_LATE_READS
 #define SNAG_GEMM_PP_LATE_READS 1        // ping-pong loop: B fragments are read in the MATRIX half (in the MFMAs' shadow), three B images
 #endif
@@ -354,7 +357,10 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint
     l = cvt_pk_bf16(s0, s1);
 }
 
-template <int BR, bool KC, int NT = 256>
+// VK: a K-contiguous operand is fetched by 16-byte loads as a COMPILE-TIME choice; otherwise the choice is the run-time `vec`.  With the
+// run-time branch around the loads the compiler cannot count them and the waits of the ping-pong loop degrade to one vmcnt(0) every
+// fourth iteration (all register sets landed) instead of vmcnt(9) in each: use_vec() in gemm.hip picks VK whenever it is legal.
+template <int BR, bool KC, int NT = 256, bool VK = true>
 struct SplitStager {
     static constexpr int KPT = 16 * BR / NT;             // values per thread and k-tile (4: BR = 64, or 128 rows over 512 threads; 8: BR = 128)
     static_assert(KPT == 4 || KPT == 8, "pre-split staging: 64 or 128 rows per operand tile");
@@ -410,7 +416,7 @@ struct SplitStager {
         if constexpr (KC) {
             const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, range, 0x00020000);
             const uint32_t so = (uint32_t)kt * 64u;
-            if (vec) {
+            if (VK || vec) {
 #pragma unroll
                 for (int i = 0; i < KPT / 4; ++i) {
                     const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, i ? voff2 : voff, so, 0);
@@ -465,9 +471,9 @@ struct SplitStager {
 // registers and splits them there (no redundancy: no other wave needs them).
 //   row-contiguous: 8 dword loads; a wave-instruction covers 32 rows of two k = two contiguous 128-byte runs
 //   K-contiguous:   2 dwordx4 loads (bytes 16 h and 32 + 16 h of the row's 64 bytes in this k-tile)
-template <bool KC>
+template <bool KC, bool VK = true>
 struct FragLoader {
-    static constexpr int kLoads = KC ? 2 : 8;  // vector-memory instructions per k-tile (K-contiguous: the 16-byte form; the checked 4-byte form is not used with B images)
+    static constexpr int kLoads = KC ? 2 : 8;    // vector-memory instructions per k-tile (K-contiguous: the 16-byte form; the checked 4-byte form is not used with B images)
     float r[4][8];
     const char* ubase;
     int64_t ldb;
@@ -495,7 +501,7 @@ struct FragLoader {
         if constexpr (KC) {
             const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, range, 0x00020000);
             const uint32_t so = (uint32_t)kt * 64u;
-            if (vec) {
+            if (VK || vec) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, so + 32u * i, 0);
@@ -527,8 +533,13 @@ struct FragLoader {
     __device__ __forceinline__ void split(int s, Split3& f) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         uint32_t h[4], m[4], l[4];
+#if SNAG_GEMM_SKIP_ASPLIT     // timing experiment only (wrong products): the loaded words taken as if they were split planes
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = __float_as_uint(r[s][j]); m[j] = __float_as_uint(r[s][4 + j]); l[j] = h[j] ^ m[j]; }
+#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) split_pair(r[s][2 * j], r[s][2 * j + 1], h[j], m[j], l[j]);
+#endif
         using u4 = __attribute__((ext_vector_type(4))) uint32_t;
         f.h = __builtin_bit_cast(bf16x8, (u4){h[0], h[1], h[2], h[3]});
         f.m = __builtin_bit_cast(bf16x8, (u4){m[0], m[1], m[2], m[3]});
@@ -613,8 +624,13 @@ struct FragLoaderTiled {
     __device__ __forceinline__ void split(int s, Split3& f) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         uint32_t h[4], m[4], l[4];
+#if SNAG_GEMM_SKIP_ASPLIT     // timing experiment only (wrong products): the loaded words taken as if they were split planes
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = __float_as_uint(r[s][j]); m[j] = __float_as_uint(r[s][4 + j]); l[j] = h[j] ^ m[j]; }
+#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) split_pair(r[s][2 * j], r[s][2 * j + 1], h[j], m[j], l[j]);
+#endif
         using u4 = __attribute__((ext_vector_type(4))) uint32_t;
         f.h = __builtin_bit_cast(bf16x8, (u4){h[0], h[1], h[2], h[3]});
         f.m = __builtin_bit_cast(bf16x8, (u4){m[0], m[1], m[2], m[3]});
@@ -752,8 +768,8 @@ struct GemmCore {
             // A: registers only.  Iteration kt multiplies tile kt (A pieces split during iteration kt-1, B fragments out of buffer
             // kt & 1), splits A of tile kt+1 and stages B of tile kt+1 (register sets (kt+1) & 1), fetches tile kt+3 into those sets.
             static_assert(TM == 1, "row-private: one 32-row fragment per wave");
-            std::conditional_t<A_TILED, FragLoaderTiled, FragLoader<A_KC>> fa;
-            SplitStager<BN, B_KC, NT> sb;
+            std::conditional_t<A_TILED, FragLoaderTiled, FragLoader<A_KC, VEC>> fa;
+            SplitStager<BN, B_KC, NT, VEC> sb;
             if constexpr (A_TILED) fa.init(p.A, p.a_nkt, m0 + wm0, p.M, kbeg, lane, p.a_layout);
             else fa.init(p.A, p.lda, p.a_vec, m0 + wm0, p.M, kbeg, lane);
             [[maybe_unused]] ImageStager ib;
@@ -950,8 +966,8 @@ struct GemmCore {
             }
             return;
         } else {
-        SplitStager<BM, A_KC> sa;
-        SplitStager<BN, B_KC> sb;
+        SplitStager<BM, A_KC, 256, VEC> sa;
+        SplitStager<BN, B_KC, 256, VEC> sb;
         sa.init(p.A, p.lda, p.a_vec, m0, p.M, kbeg, tid);
         sb.init(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, tid);
         sa.ablate = p.dbg & 1;            // SNAG_GEMM_DBG: 1 = no A fetch, 2 = no B fetch, 3 = neither (results are wrong)

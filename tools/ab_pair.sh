@@ -1,5 +1,5 @@
 #!/bin/bash
-# in-step A/B of environment switches on one box: tools/ab_env.sh "NAME=VALUE" ...   (each against the default, three rounds)
+# in-step A/B of the working-tree library against variants: tools/ab_pair.sh NAME [NAME...]   (variants under snag_amd/variants/)
 cd "$GRAFT_REPO_ROOT"
 run() {
   local label=$1; shift
@@ -9,6 +9,6 @@ d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
 print('$label', 'ms/step', round(d['ms_per_step'],4), 'l1fwd+reduce us', round(d['roofline']['avg_us'],1), 'score us', round(d['roofline_score']['avg_us'],1))"
 }
 for rep in 1 2 3; do
-run default X=1
-for v in "$@"; do run "$v" $v; done
+run tree X=1
+for v in "$@"; do run "var_$v" SNAG_HIP_LIB=$PWD/snag_amd/variants/libsnag_hip_$v.so; done
 done

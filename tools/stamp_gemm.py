@@ -15,8 +15,17 @@ ldt = (M + 31) // 32 * 32
 xt = torch.randn(K, ldt, device="cuda")[:, :M]
 w = torch.randn(K, N, device="cuda")
 out = torch.empty(M, N, device="cuda")
+KC = os.environ.get("STAMP_KC", "0") == "1"          # both operands K-contiguous (the engine's natural layout)
+x, wk = xt.t().contiguous(), w.t().contiguous()
+COLD = os.environ.get("STAMP_COLD", "0") == "1"      # a 1.2 GB sweep in front of every launch: A arrives from HBM, as inside the step
+big = torch.empty(300_000_000, device="cuda") if COLD else None
 for _ in range(30):
-    ops.gemm(xt, w, a_kcontig=False, b_kcontig=False, out=out, act="relu")
+    if COLD:
+        big.add_(1.0)
+    if KC:
+        ops.gemm(x, wk, a_kcontig=True, b_kcontig=True, out=out, act="relu")
+    else:
+        ops.gemm(xt, w, a_kcontig=False, b_kcontig=False, out=out, act="relu")
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = (ctypes.c_uint64 * 72)()
