@@ -262,6 +262,15 @@ typedef struct snag_gemm_desc {
     const void* b_image;
 } snag_gemm_desc;
 
+/* Up to SNAG_GEMM_GROUP_MAX independent problems of ANY shapes in one call -- one launch when each of them would run the 64 x 128 tile
+ * (plain or split K, no stream-K plan) on the same operand layouts (a_kcontig / b_kcontig equal across the group), one launch per problem
+ * otherwise.  Results are the same bits as separate snag_gemm_f32 calls: every problem keeps its own K split, workspace (distinct per
+ * split problem) and epilogue; defer_reduce is honoured per problem.  The outputs must not overlap.  (The six independent products behind
+ * the read-out layer's attention backward, reference ops: the nn.Linear backward of BertSelfAttention / ProjectionHead,
+ * model/SNAG_tools.py:32-51, 134-142.) */
+#define SNAG_GEMM_GROUP_MAX 6
+SNAG_API int snag_gemm_f32_group(const snag_gemm_desc* const* descs, int n, void* stream);
+
 SNAG_API int snag_gemm_f32(const snag_gemm_desc* desc, void* stream);
 SNAG_API int64_t snag_gemm_workspace_floats(int M, int N, int K);
 /* The tiled copy of an operand A [M, K] for snag_gemm_desc.a_tiled (src: K-contiguous [M, ld >= K] or row-contiguous [K, ld >= M]):
@@ -350,6 +359,12 @@ typedef struct snag_fusion_desc {
      * key / value weight gradient its contribution only, and the caller reads dKV_m from rows n * M + m of the [N * M, 2 D] block at
      * `dkv` floats into `work` (it owes d mid_m = dKV_m (Wkv l2_m), d(Wkv l2_m) = dKV_m^T mid_m and the chain rule onto Wkv and l2_m). */
     int32_t fold_others;
+    /* fold_others only.  The caller's own key / value products (A and B K-contiguous, no K split) that snag_fusion_fwd launches TOGETHER
+     * with the read-out token's q/k/v projection -- one grouped launch under the rules of snag_gemm_f32_group (each of these
+     * [rows x 2D x D] products alone is a grid of fewer workgroups than the chip has CUs).  They must be complete descriptors whose
+     * operands are ready when snag_fusion_fwd is called. */
+    const snag_gemm_desc* co_fwd[2];
+    int32_t n_co_fwd;
 } snag_fusion_desc;
 
 SNAG_API int64_t snag_fusion_save_floats(int N, int M, int D, int H, int I, int L, int use_intermediate);
@@ -389,6 +404,13 @@ typedef struct snag_fusion_bwd_desc {
      * to d_slot_out [N, d_slot_ld], scaled by d_slot_scale where d_slot_rowmask[n] != 0 -- what snag_entity_token_bwd would compute
      * from d_x0 in a launch of its own (the entity-table gradient through the noise blend). */
     float* d_slot_out; int64_t d_slot_ld; const uint8_t* d_slot_rowmask; float d_slot_scale;
+    /* fold_others only: the caller's products on the key / value gradient (see fold_others), launched together with this call's own
+     * products of the same operand layouts, in one grouped launch each (snag_gemm_f32_group rules):
+     *   co_dx: A K-contiguous, B row-contiguous, no K split (d mid_m = dKV_m Wf_m ...), with the read-out token's d x = dqkv Wqkv;
+     *   co_dw: A and B row-contiguous, K split over the rows with defer_reduce = 1 and a workspace of their own (d Wf_m = dKV_m^T mid_m),
+     *          with d Wo and the read-out token's d Wqkv; ONE reduce launch finishes all four. */
+    const snag_gemm_desc* co_dx[2]; int32_t n_co_dx;
+    const snag_gemm_desc* co_dw[2]; int32_t n_co_dw;
 } snag_fusion_bwd_desc;
 
 SNAG_API int snag_fusion_bwd(const snag_fusion_bwd_desc* desc, void* stream);

@@ -58,7 +58,7 @@ class FusionDesc(_c.Structure):
                 ("layers", _c.POINTER(FusionLayer)), ("weight_raw", _P), ("x0", _P),
                 ("joint", _P), ("joint_fz", _P), ("hidden", _P), ("weight_norm", _P),
                 ("save", _P), ("save_floats", _L), ("work", _P), ("work_floats", _L), ("readout_slot_p1", _c.c_int32),
-                ("fold_others", _c.c_int32)]
+                ("fold_others", _c.c_int32), ("co_fwd", _c.POINTER(GemmDesc) * 2), ("n_co_fwd", _c.c_int32)]
 
 
 class SmallMM(_c.Structure):
@@ -71,7 +71,8 @@ class FusionBwdDesc(_c.Structure):
     """struct snag_fusion_bwd_desc."""
     _fields_ = [("f", FusionDesc), ("d_joint", _P), ("d_joint_fz", _P), ("d_hidden", _P), ("d_weight_norm", _P),
                 ("d_x0", _P), ("grads", _c.POINTER(FusionLayerGrad)), ("d_weight_raw", _P), ("accumulate", _c.c_int32),
-                ("zero_d_hidden", _c.c_int32), ("d_slot_out", _P), ("d_slot_ld", _L), ("d_slot_rowmask", _P), ("d_slot_scale", _F)]
+                ("zero_d_hidden", _c.c_int32), ("d_slot_out", _P), ("d_slot_ld", _L), ("d_slot_rowmask", _P), ("d_slot_scale", _F),
+                ("co_dx", _c.POINTER(GemmDesc) * 2), ("n_co_dx", _c.c_int32), ("co_dw", _c.POINTER(GemmDesc) * 2), ("n_co_dw", _c.c_int32)]
 
 
 # name -> argtypes; every entry returns int (0 = enqueued) except the two listed in _SPECIAL
@@ -96,6 +97,7 @@ SIGNATURES = {
     "snag_tile_a_f32": [_P, _L, _L, _L, _I, _I, _P, _P],
     "snag_presplit_b": [_P, _L, _I, _L, _L, _P, _P],
     "snag_gemm_reduce_group": [_P, _c.c_int, _P],
+    "snag_gemm_f32_group": [_P, _c.c_int, _P],
     "snag_gemm_f32_pair": [_c.POINTER(GemmDesc), _c.POINTER(GemmDesc), _P],
     "snag_fusion_fwd": [_c.POINTER(FusionDesc), _P],
     "snag_fusion_bwd": [_c.POINTER(FusionBwdDesc), _P],

@@ -86,6 +86,7 @@ static inline int env_int(const char* name) {
 int gemm_check(const snag_gemm_desc* d);
 int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st);
 int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStream_t st);
+int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st);   // 2..6 problems, one launch when their plans allow
 int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st);   // finishes problems launched with defer_reduce
 int64_t gemm_workspace_floats(int M, int N, int K);
 

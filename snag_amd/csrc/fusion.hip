@@ -97,6 +97,12 @@ static int check_fusion(const snag_fusion_desc* f) {
     SNAG_REQUIRE(f->readout_slot_p1 == 0 || !(f->joint || f->joint_fz || f->weight_norm), SNAG_ERR_UNSUPPORTED,
                  "fusion: the read-out-only last layer computes attention for one token only; joint / joint_fz / weight_norm need all of it");
     SNAG_REQUIRE(!f->fold_others || (f->readout_slot_p1 > 0 && f->L == 1), SNAG_ERR_UNSUPPORTED, "fusion: fold_others needs the read-out mode with one layer");
+    SNAG_REQUIRE(f->n_co_fwd >= 0 && f->n_co_fwd <= 2 && (f->n_co_fwd == 0 || f->fold_others), SNAG_ERR_ARG, "fusion: n_co_fwd=%d (0..2, fold_others only)", f->n_co_fwd);
+    for (int i = 0; i < f->n_co_fwd; ++i) {
+        SNAG_REQUIRE(f->co_fwd[i] != nullptr, SNAG_ERR_ARG, "fusion: null co_fwd[%d]", i);
+        const int rc = gemm_check(f->co_fwd[i]);
+        if (rc) return rc;
+    }
     if (f->N == 0) return SNAG_OK;
     SNAG_REQUIRE(f->layers && f->weight_raw && f->x0 && f->save, SNAG_ERR_ARG, "fusion: null layers / weight_raw / x0 / save");
     const int64_t need = snag_fusion_save_floats(f->N, f->M, f->D, f->H, f->I, f->L, f->use_intermediate);
@@ -128,7 +134,15 @@ static int fusion_fwd_readout(const snag_fusion_desc* f, const snag_fusion_layer
     // Q of token g only: rows n*M + g of x (stride M*D) -> the q part of the same rows of qkv.  Disjoint outputs: one grouped launch.
     snag_gemm_desc gq = gemm_desc(N, D, D, xin + (int64_t)g * D, MD, true, P.wqkv, D, true, S.qkv + (int64_t)g * 3 * D, 3 * MD);
     gq.bias = P.bqkv;
-    if ((rc = gemm_dispatch_pair(&gd, &gq, st))) return rc;
+    if (f->fold_others) {
+        // the read-out token's q | k | v in ONE product (N x 3D: the rows' 3D columns are contiguous in the activation), grouped with the
+        // caller's key / value products of the other tokens
+        snag_gemm_desc gqkv = gemm_desc(N, 3 * D, D, xin + (int64_t)g * D, MD, true, P.wqkv, D, true, S.qkv + (int64_t)g * 3 * D, 3 * MD);
+        gqkv.bias = P.bqkv;
+        const snag_gemm_desc* grp[3] = {f->n_co_fwd > 0 ? f->co_fwd[0] : nullptr, f->n_co_fwd > 1 ? f->co_fwd[1] : nullptr, nullptr};
+        grp[f->n_co_fwd] = &gqkv;                                  // (the caller's products first: they are the larger ones)
+        if ((rc = f->n_co_fwd > 0 ? gemm_dispatch_group(grp, f->n_co_fwd + 1, st) : gemm_dispatch(&gqkv, st))) return rc;
+    } else if ((rc = gemm_dispatch_pair(&gd, &gq, st))) return rc;
     SNAG_MNU(attn_ro_fwd_kernel, M, D, egrid, st, (const float*)S.qkv, N, D, H, g, 1.0f / sqrtf((float)(D / H)), P.keep_probs, kscale, S.probs, S.ctx);
     if ((rc = check_launch("fusion attention (read-out)"))) return rc;
     gd = gemm_desc(N, D, D, S.ctx, D, true, P.wo, D, true, S.t1, D);
@@ -353,11 +367,41 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             float* dkv = W.dqkv;
             float* dq_g = W.dqkv + NM * 2 * D;
             const int ablocks = (int)std::min<int64_t>(kRedBlocks, (N + 3) / 4);
+            // fold_others with M >= 3: the read-out token's dq | dk | dv side by side in the [N, 3D] block where dq_g alone would go
+            float* ro3 = (f->fold_others && M >= 3) ? dq_g : nullptr;
             SNAG_MNU(attn_ro_bwd_kernel, M, D, dim3(ablocks), st, (const float*)S.qkv, (const float*)W.dC, N, D, H, ro, 1.0f / sqrtf((float)(D / H)),
-                     P.keep_probs, kscale, dq_g, dkv, partq);
+                     P.keep_probs, kscale, dq_g, dkv, partq, ro3);
             hipLaunchKernelGGL(slab_colsum_ro_kernel, dim3(ceil_div(3 * D, 64), 2), dim3(1024), 0, st, (const float*)W.part, lnblocks, D, G.ln1_g, G.ln1_b, G.bo,
                                (const float*)partq, ablocks, G.bqkv, acc);
             if ((rc = check_launch("fusion attention backward (read-out)"))) return rc;
+            float* dxin = (l == 0) ? b->d_x0 : W.dC;
+            if (ro3) {
+                // weight gradients: dWo = dz^T ctx_g [D, D] and dWqkv = [dq | dk | dv]^T x_g [3D, D] (all of wqkv: the caller adds the other
+                // tokens' share to the key / value rows afterwards), with the caller's co_dw problems -- one grouped launch, one reduce
+                snag_gemm_desc g0 = gemm_desc(D, D, N, dz, D, false, S.ctx, D, false, G.wo, D);
+                snag_gemm_desc g1 = gemm_desc(3 * D, D, N, ro3, 3 * D, false, xin + (int64_t)ro * D, MD, false, G.wqkv, D);
+                const int64_t pw = (gemm_workspace_floats(D, D, (int)NM) + 64) / 64 * 64;
+                g0.accumulate = acc; g0.workspace = W.gemm_ws; g0.workspace_floats = pw;
+                g1.accumulate = acc; g1.workspace = W.gemm_ws + pw; g1.workspace_floats = W.gemm_ws_floats - pw;
+                g0.defer_reduce = g1.defer_reduce = 1;
+                const snag_gemm_desc* grp[4] = {&g1, &g0, nullptr, nullptr};
+                int ng = 2;
+                for (int i = 0; i < b->n_co_dw; ++i) grp[ng++] = b->co_dw[i];
+                if ((rc = gemm_dispatch_group(grp, ng, st))) return rc;
+                if ((rc = gemm_reduce_multi(grp, ng, st))) return rc;
+                // d(layer input), rows of token ro: [dq | dk | dv] Wqkv + dT1 (K = 3D), with the caller's co_dx problems in the same launch
+                g = gemm_desc(N, D, 3 * D, ro3, 3 * D, true, P.wqkv, D, false, dxin + (int64_t)ro * D, MD);
+                g.add1 = W.dA; g.ld1 = D;
+                if (b->d_slot_out != nullptr && l == 0) {
+                    g.mirror = b->d_slot_out; g.ldmirror = b->d_slot_ld; g.mirror_rowmask = b->d_slot_rowmask; g.mirror_scale = b->d_slot_scale;
+                }
+                const snag_gemm_desc* gx[3] = {&g, nullptr, nullptr};
+                int nx = 1;
+                for (int i = 0; i < b->n_co_dx; ++i) gx[nx++] = b->co_dx[i];
+                if ((rc = nx > 1 ? gemm_dispatch_group(gx, nx, st) : gemm_dispatch(&g, st))) return rc;
+                dout = W.dC;
+                continue;
+            }
             // dWo = dz^T ctx_g and dWq = dq_g^T x_g (rows 0..D of wqkv): two D x D outputs over N rows -> ONE launch (+ one reduce)
             {
                 snag_gemm_desc g0 = gemm_desc(D, D, N, dz, D, false, S.ctx, D, false, G.wo, D);
@@ -377,7 +421,6 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
                 if ((rc = gemm_reduce_multi(three, 3, st))) return rc;
             }
             // d(layer input) = dkv Wkv for every token, + dq_g Wq + dT1 into the rows of token ro
-            float* dxin = (l == 0) ? b->d_x0 : W.dC;
             g = f->fold_others ? gemm_desc(N, D, 2 * D, dkv + (int64_t)ro * 2 * D, 2 * MD, true, P.wqkv + (int64_t)D * D, D, false, dxin + (int64_t)ro * D, MD)
                                : gemm_desc((int)NM, D, 2 * D, dkv, 2 * D, true, P.wqkv + (int64_t)D * D, D, false, dxin, D);
             if ((rc = gemm_dispatch(&g, st))) return rc;
@@ -387,6 +430,12 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
                 g.mirror = b->d_slot_out; g.ldmirror = b->d_slot_ld; g.mirror_rowmask = b->d_slot_rowmask; g.mirror_scale = b->d_slot_scale;
             }
             if ((rc = gemm_dispatch(&g, st))) return rc;
+            // (fold_others with fewer than three tokens: the caller's problems one by one)
+            for (int i = 0; i < b->n_co_dw; ++i)
+                if ((rc = gemm_dispatch(b->co_dw[i], st))) return rc;
+            if (b->n_co_dw > 0 && (rc = gemm_reduce_multi(b->co_dw, b->n_co_dw, st))) return rc;
+            for (int i = 0; i < b->n_co_dx; ++i)
+                if ((rc = gemm_dispatch(b->co_dx[i], st))) return rc;
             dout = W.dC;
             continue;
         }
@@ -564,6 +613,14 @@ extern "C" SNAG_API int snag_fusion_bwd(const snag_fusion_bwd_desc* b, void* str
                  "fusion_bwd: read-out-only mode takes d_hidden [N, D] alone");
     SNAG_REQUIRE(b->d_slot_out == nullptr || (b->f.readout_slot_p1 != 0 && b->f.L == 1 && b->d_slot_ld >= b->f.D), SNAG_ERR_UNSUPPORTED,
                  "fusion_bwd: d_slot_out needs read-out mode with one layer (and d_slot_ld >= D)");
+    SNAG_REQUIRE(b->n_co_dx >= 0 && b->n_co_dx <= 2 && b->n_co_dw >= 0 && b->n_co_dw <= 2 && ((b->n_co_dx == 0 && b->n_co_dw == 0) || b->f.fold_others), SNAG_ERR_ARG,
+                 "fusion_bwd: n_co_dx=%d n_co_dw=%d (0..2 each, fold_others only)", b->n_co_dx, b->n_co_dw);
+    for (int i = 0; i < b->n_co_dx + b->n_co_dw; ++i) {
+        const snag_gemm_desc* d = i < b->n_co_dx ? b->co_dx[i] : b->co_dw[i - b->n_co_dx];
+        SNAG_REQUIRE(d != nullptr, SNAG_ERR_ARG, "fusion_bwd: null co-launched descriptor %d", i);
+        if ((rc = gemm_check(d))) return rc;
+        SNAG_REQUIRE(i < b->n_co_dx || d->defer_reduce, SNAG_ERR_ARG, "fusion_bwd: co_dw[%d] must carry defer_reduce (this call finishes it)", i - b->n_co_dx);
+    }
     const int64_t need = snag_fusion_work_floats(b->f.N, b->f.M, b->f.D, b->f.H, b->f.I, b->f.L, b->f.use_intermediate);
     SNAG_REQUIRE(b->f.work_floats >= need, SNAG_ERR_ARG, "fusion_bwd: work buffer holds %ld floats, need %ld", (long)b->f.work_floats, (long)need);
     for (int l = 0; l < b->f.L; ++l) {

@@ -351,10 +351,12 @@ __global__ __launch_bounds__(256) void attn_ro_fwd_kernel(const float* __restric
 }
 
 //   dctx_g [N, D] -> dq_g [N, D] (compact) and dkv [N*M, 2D] (k then v); bias_part [block][3][D] = column sums of dq_g, dk, dv.
+//   (ro3: see below)
 template <int M, int NU>
 __global__ __launch_bounds__(256) void attn_ro_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx_g, int N, int D,
                                                           int H, int g, float inv_sqrt_d, const uint8_t* __restrict__ keep, float kscale,
-                                                          float* __restrict__ dq_g, float* __restrict__ dkv, float* __restrict__ bias_part) {
+                                                          float* __restrict__ dq_g, float* __restrict__ dkv, float* __restrict__ bias_part,
+                                                          float* __restrict__ ro3) {
     __shared__ float red[4][3][64 * NU];
     const int lane = threadIdx.x & 63;
     const int wave = wave_id_uniform();
@@ -419,12 +421,14 @@ __global__ __launch_bounds__(256) void attn_ro_bwd_kernel(const float* __restric
                 dq.v[u] += in ? aq : 0.f;
             }
         }
-        st_cols<NU>(dq_g + n * (int64_t)D, dq, D, lane);
+        // ro3 != nullptr: the read-out token's dq | dk | dv side by side in ro3 [N, 3D] (one K = 3D operand for d x and d Wqkv) instead of
+        // dq_g and the token's own rows of dkv
+        st_cols<NU>(ro3 ? ro3 + n * (int64_t)(3 * D) : dq_g + n * (int64_t)D, dq, D, lane);
 #pragma unroll
         for (int u = 0; u < NU; ++u) sq.v[u] += dq.v[u];
 #pragma unroll
         for (int i = 0; i < M; ++i) {
-            float* row = dkv + (n * M + i) * (int64_t)(2 * D);
+            float* row = (ro3 && i == g) ? ro3 + n * (int64_t)(3 * D) + D : dkv + (n * M + i) * (int64_t)(2 * D);
             st_cols<NU>(row, dk[i], D, lane);
             st_cols<NU>(row + D, dv[i], D, lane);
 #pragma unroll

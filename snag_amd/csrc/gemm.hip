@@ -625,6 +625,64 @@ int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipSt
     return rc;
 }
 
+static int launch_reduce(const GemmPlan& pl, float* slab, hipStream_t st);
+
+// Up to kGroupMax problems in ONE launch (gemm_tile_group_kernel) when every one of them would run the 64 x 128 tile with plain or split K
+// (no stream-K) on the same operand layouts; anything else: one after the other.  Each problem keeps the K split, slab and epilogue its
+// own dispatch would use, so the results are the same bits as one-by-one launches.
+int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) {
+    static const int off = env_int("SNAG_GEMM_GROUP_OFF");      // tuning / A-B
+    GemmPlan pl[kGroupMax];
+    bool ok = !off && n >= 2 && n <= kGroupMax;
+    for (int i = 0; ok && i < n; ++i) {
+        const snag_gemm_desc* d = ds[i];
+        pl[i] = plan_gemm(d);
+        ok = d->M > 0 && d->N > 0 && d->K > 0 && !pl[i].streamk && !pl[i].wide && !pl[i].big && !pl[i].pp && !d->a_tiled && !d->b_image &&
+             d->a_kcontig == ds[0]->a_kcontig && d->b_kcontig == ds[0]->b_kcontig &&
+             use_vec(pl[i].p, d->a_kcontig, d->b_kcontig) == use_vec(pl[0].p, ds[0]->a_kcontig, ds[0]->b_kcontig);
+        for (int j = 0; ok && j < i; ++j) ok = !(pl[i].splits > 1 && pl[j].splits > 1 && ds[i]->workspace == ds[j]->workspace);
+    }
+    if (!ok) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = gemm_dispatch(ds[i], st);
+            if (rc) return rc;
+        }
+        return SNAG_OK;
+    }
+    GemmGroup<Epilogue> g{};
+    g.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        g.p[i] = pl[i].p;
+        g.p[i].xcd = 0;
+        g.e[i] = pl[i].e;
+        g.slab[i] = pl[i].splits > 1 ? ds[i]->workspace : nullptr;
+        g.tiles_n[i] = ceil_div(pl[i].p.N, 128);
+        g.tiles[i] = g.tiles_n[i] * ceil_div(pl[i].p.M, 64);
+        g.first[i] = blocks;
+        blocks += g.tiles[i] * pl[i].splits;
+        if (log_shapes())
+            fprintf(stderr, "snag_gemm GROUP[%d/%d] M=%d N=%d K=%d a_kc=%d b_kc=%d tile=64x128 splits=%d\n", i, n, pl[i].p.M, pl[i].p.N, pl[i].p.K, (int)ds[i]->a_kcontig,
+                    (int)ds[i]->b_kcontig, pl[i].splits);
+    }
+    g.first[n] = blocks;
+    const bool vec = use_vec(pl[0].p, ds[0]->a_kcontig, ds[0]->b_kcontig);
+#define SNAG_GROUPN(AK, BK_)                                                                                                              \
+    do {                                                                                                                                  \
+        if (vec) hipLaunchKernelGGL((gemm_tile_group_kernel<64, 128, 32, 64, AK, BK_, true, Epilogue>), dim3(blocks), dim3(256), 0, st, g);     \
+        else hipLaunchKernelGGL((gemm_tile_group_kernel<64, 128, 32, 64, AK, BK_, false, Epilogue>), dim3(blocks), dim3(256), 0, st, g);       \
+    } while (0)
+    if (ds[0]->a_kcontig && ds[0]->b_kcontig) SNAG_GROUPN(true, true);
+    else if (ds[0]->a_kcontig && !ds[0]->b_kcontig) SNAG_GROUPN(true, false);
+    else if (!ds[0]->a_kcontig && ds[0]->b_kcontig) SNAG_GROUPN(false, true);
+    else SNAG_GROUPN(false, false);
+#undef SNAG_GROUPN
+    int rc = check_launch("snag_gemm_f32_group");
+    for (int i = 0; !rc && i < n; ++i)
+        if (pl[i].splits > 1 && !ds[i]->defer_reduce) rc = launch_reduce(pl[i], ds[i]->workspace, st);
+    return rc;
+}
+
 // the reduce launch of one problem (what gemm_dispatch appends to a K split)
 static int launch_reduce(const GemmPlan& pl, float* slab, hipStream_t st) {
     const GemmOperands& p = pl.p;
@@ -793,6 +851,21 @@ extern "C" SNAG_API int snag_gemm_f32_pair(const snag_gemm_desc* d0, const snag_
         return SNAG_OK;
     }
     return gemm_dispatch_pair(d0, d1, (hipStream_t)stream);
+}
+
+extern "C" SNAG_API int snag_gemm_f32_group(const snag_gemm_desc* const* descs, int n, void* stream) {
+    SNAG_REQUIRE(n >= 0 && n <= kGroupMax && (n == 0 || descs), SNAG_ERR_ARG, "gemm_f32_group: n=%d (0..%d problems per call)", n, kGroupMax);
+    const snag_gemm_desc* live[kGroupMax];
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        SNAG_REQUIRE(descs[i], SNAG_ERR_ARG, "gemm_f32_group: null descriptor %d", i);
+        int rc = gemm_check(descs[i]);
+        if (rc) return rc;
+        if (descs[i]->M > 0 && descs[i]->N > 0) live[m++] = descs[i];
+    }
+    if (m == 0) return SNAG_OK;
+    if (m == 1) return gemm_dispatch(live[0], (hipStream_t)stream);
+    return gemm_dispatch_group(live, m, (hipStream_t)stream);
 }
 
 extern "C" SNAG_API int snag_gemm_reduce_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, void* stream) {

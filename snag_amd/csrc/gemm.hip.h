@@ -1249,6 +1249,9 @@ struct GemmCore {
     }
 };
 
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi, bool A_TILED = false, bool B_IMG = false>
+__device__ __forceinline__ void gemm_tile_at(const GemmOperands& p, const Epi& epi, float* __restrict__ slab, int z, int m0, int n0, float* smem);
+
 // One block = one BM x BN output tile (x one K split): main loop, then either the epilogue functor
 // epi(row, col, float4) or, for split-K, a raw store into this split's slab (split index z).
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi, bool A_TILED = false, bool B_IMG = false>
@@ -1270,7 +1273,13 @@ __device__ __forceinline__ void gemm_tile_body(const GemmOperands& p, const Epi&
             by = id / gridDim.x;
         }
     }
-    const int m0 = by * BM, n0 = bx * BN;
+    gemm_tile_at<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi, A_TILED, B_IMG>(p, epi, slab, z, by * BM, bx * BN, smem);
+}
+
+// the tile at (m0, n0) of K split z
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi, bool A_TILED, bool B_IMG>
+__device__ __forceinline__ void gemm_tile_at(const GemmOperands& p, const Epi& epi, float* __restrict__ slab, int z, int m0, int n0, float* smem) {
+    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC, A_TILED, B_IMG>;
     const int kbeg = z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     Core core;
@@ -1334,6 +1343,31 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_pair_ker
     const int z = blockIdx.z % splits;
     if (blockIdx.z < splits) gemm_tile_body<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi>(p0, e0, slab0, z, smem);
     else gemm_tile_body<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi>(p1, e1, slab1, z, smem);
+}
+
+// UP TO SIX problems of any shapes (same layouts and loader) in one launch, each with its own K split and slab: a linear block index,
+// problem by problem, inside a problem split by split.  The backward of the read-out layer has six independent [15000 x 128 x 128..384]-
+// class products behind the attention backward; one by one each is a 235-workgroup grid that pays its own launch, first-load latency
+// and drain (16-27 us each for 1-3 us of matrix work).
+constexpr int kGroupMax = 6;
+template <class Epi>
+struct GemmGroup {
+    GemmOperands p[kGroupMax];
+    Epi e[kGroupMax];
+    float* slab[kGroupMax];          // nullptr: no K split
+    int first[kGroupMax + 1];        // block ranges
+    int tiles[kGroupMax], tiles_n[kGroupMax];
+    int n;
+};
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_group_kernel(GemmGroup<Epi> g) {
+    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
+    __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
+    int q = 0;
+    while (q + 1 < g.n && (int)blockIdx.x >= g.first[q + 1]) ++q;
+    const int b = (int)blockIdx.x - g.first[q];
+    const int z = b / g.tiles[q], t = b % g.tiles[q];
+    gemm_tile_at<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi>(g.p[q], g.e[q], g.slab[q], z, (t / g.tiles_n[q]) * BM, (t % g.tiles_n[q]) * BN, smem);
 }
 
 // Stream-K: G persistent blocks (512 = two per CU by default) share the (tile, k-tile) iteration space evenly, so every CU gets the same MFMA work whatever

@@ -372,6 +372,7 @@ class MKGCHotPath:
             self._layers[l].keep_attn_out = ptr(self.keep_attn[l]) if on else None
             self._layers[l].keep_ffn_out = ptr(self.keep_ffn[l]) if (on and self.keep_ffn) else None
         self._bdesc.f = self._fdesc
+        self._bdesc.f.n_co_fwd = 0           # (the forward's co-launched products are the forward call's alone)
 
     def train(self, mode=True):
         self.training = bool(mode)
@@ -384,6 +385,21 @@ class MKGCHotPath:
     # ------------------------------------------------------------------------------------------
     def _gemm(self, *a, **k):
         call("snag_gemm_f32", ctypes.byref(self._gemm_desc(*a, **k)), self._st)
+
+    def _fold_bwd_descs(self, defer):
+        """Folded second projections, backward: (d Wf_m = dKV_m^T mid_m, K split over the rows, slabs in work_l2), (d mid_m = (dKV_m Wf_m) *
+        [mid_m > 0] (* keep)) for every modality; dKV_m sits in the Mformer backward's scratch (rows n * M + m of its [rows * M, 2 D] block)."""
+        cfg = self.cfg
+        D, M, Nl = cfg.dim, cfg.n_tokens, self.shard.n_loc
+        MD, dkv = M * D, self._dkv_ptr
+        nmod = len(cfg.feat_dims)
+        dl2 = [self._gemm_desc(2 * D, D, Nl, dkv + 4 * i * 2 * D, 2 * MD, 0, ptr(self.mid[i]), D, 0, ptr(self.d_wf[i]), D, splitk=True, half=i % 2,
+                               scratch=self.work_l2) for i in range(nmod)]
+        for d in dl2:
+            d.defer_reduce = int(defer)
+        dmid = [self._gemm_desc(Nl, D, 2 * D, dkv + 4 * i * 2 * D, 2 * MD, 1, ptr(self.wf[i]), D, 0, ptr(self.d_mid[i]), D, act=4, aux=ptr(self.mid[i]),
+                                ldaux=D, keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout), splitk=False) for i in range(nmod)]
+        return dl2, dmid
 
     def _gemm_pair(self, d0, d1):
         """Two same-shaped GEMMs (the two modalities' second projections / their backward) as ONE launch: each is a grid of fewer
@@ -575,10 +591,16 @@ class MKGCHotPath:
                 call("snag_small_matmul", probs, len(probs), st)
             kv = [self._gemm_desc(Nl, 2 * D, D, ptr(self.mid[i]), D, 1, ptr(self.wf[i]), D, 1, self._qkv_ptr + 4 * (i * 3 * D + D), 3 * MD,
                                   bias=self.p["layer0.bqkv"].data_ptr() + 4 * D, splitk=False) for i in range(nmod)]
-            for i in range(0, nmod - 1, 2):
-                self._gemm_pair(kv[i], kv[i + 1])
-            if nmod % 2:
-                call("snag_gemm_f32", ctypes.byref(kv[-1]), st)
+            if nmod <= 2:             # launched by snag_fusion_fwd together with the read-out token's q/k/v projection (one grouped launch)
+                self._co_fwd = kv
+                for j, d in enumerate(kv):
+                    self._fdesc.co_fwd[j] = ctypes.pointer(d)
+                self._fdesc.n_co_fwd = nmod
+            else:
+                for i in range(0, nmod - 1, 2):
+                    self._gemm_pair(kv[i], kv[i + 1])
+                if nmod % 2:
+                    call("snag_gemm_f32", ctypes.byref(kv[-1]), st)
         elif cfg.num_proj == 2:       # the second projections, two modalities per launch
             l2 = [self._gemm_desc(Nl, D, D, ptr(self.mid[i]), D, 1, ptr(self.p[f"proj{i}.l2"]), D, 1, x0p + 4 * i * D, MD) for i in range(len(cfg.feat_dims))]
             for i in range(0, len(l2) - 1, 2):
@@ -713,6 +735,16 @@ class MKGCHotPath:
         bd.d_slot_ld = D
         bd.d_slot_scale = float(np.float32(1.0) - np.float32(float(cfg.mask_ratio) * 0.5))       # 1.0f - a in float, as snag_entity_token_bwd forms it
         bd.d_slot_rowmask = (self.ent_noise_mask.data_ptr() + lo) if (mirror and noisy) else None
+        nmod = len(cfg.feat_dims)
+        co = self.fold and nmod <= 2
+        if co:
+            # folded second projections (see below): with one or two modalities their products on the key / value gradient ride in the
+            # Mformer backward's own grouped launches (co_dx with d x of the read-out token, co_dw with d Wo / d Wqkv and ONE reduce)
+            dl2, dmid = self._fold_bwd_descs(True)
+            self._co_bwd = (dl2, dmid)
+            for j in range(nmod):
+                bd.co_dw[j], bd.co_dx[j] = ctypes.pointer(dl2[j]), ctypes.pointer(dmid[j])
+            bd.n_co_dw = bd.n_co_dx = nmod
         call("snag_fusion_bwd", ctypes.byref(bd), st)
         self._d_repr_clean = cfg.scorer != "segmented"     # (atomic scorer: its reader cleared it behind itself)
         dx0 = self.d_x0.data_ptr()
@@ -729,22 +761,17 @@ class MKGCHotPath:
                 reducer.start(buckets[0])
             if not self.fold:            # (folded second projections: the key / value weight gradient is completed further down)
                 reducer.start(buckets[1])
-        nmod = len(cfg.feat_dims)
         # two modalities, one rank: the four projection weight gradients (dl2 pair, dl1 x 2) leave their K-split slabs in place and
         # ONE launch at the end reduces all four
-        one_reduce = reducer is None and cfg.num_proj == 2 and nmod == 2
-        if self.fold:
+        one_reduce = reducer is None and cfg.num_proj == 2 and nmod == 2 and not co
+        if co:
+            pass
+        elif self.fold:
             # folded second projections: from the gradient of the projected tokens' keys / values (left in the Mformer backward's scratch)
             #   d mid_m = (dKV_m Wf_m) * [mid_m > 0] (* keep)        [rows, D]   <- K = 2 D
             #   d Wf_m  = dKV_m^T mid_m                               [2 D, D]   <- K = rows (split, slabs in work_l2: the scratch holds dKV)
             # and, once d Wf_m is final, the chain rule onto the two factors of Wf_m = Wkv l2_m (parameter-sized, one small launch)
-            dkv = self._dkv_ptr
-            dl2 = [self._gemm_desc(2 * D, D, Nl, dkv + 4 * i * 2 * D, 2 * MD, 0, ptr(self.mid[i]), D, 0, ptr(self.d_wf[i]), D, splitk=True, half=i % 2,
-                                   scratch=self.work_l2) for i in range(nmod)]
-            for d in dl2:
-                d.defer_reduce = int(one_reduce)
-            dmid = [self._gemm_desc(Nl, D, 2 * D, dkv + 4 * i * 2 * D, 2 * MD, 1, ptr(self.wf[i]), D, 0, ptr(self.d_mid[i]), D, act=4, aux=ptr(self.mid[i]),
-                                    ldaux=D, keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout), splitk=False) for i in range(nmod)]
+            dl2, dmid = self._fold_bwd_descs(one_reduce)
             for group in (dmid, dl2):
                 for i in range(0, nmod - 1, 2):
                     self._gemm_pair(group[i], group[i + 1])

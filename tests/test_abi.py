@@ -110,13 +110,16 @@ def _structs():
                 nm = nm.strip()
                 ptr = "*" in base or nm.startswith("*")
                 nm = nm.lstrip("* ")
+                arr = re.match(r"(\w+)\[(\d+)\]$", nm)           # a fixed-size array member: kind[n]
+                if arr:
+                    nm = arr.group(1)
                 if ptr:
                     kind = "ptr"
                 elif base.replace("const", "").strip().startswith("snag_"):
                     kind = "struct"
                 else:
                     kind = {"int32_t": "i32", "int": "i32", "int64_t": "i64", "uint64_t": "u64", "float": "f32"}[base.replace("const", "").strip()]
-                fields.append((nm, kind))
+                fields.append((nm, f"{kind}[{arr.group(2)}]" if arr else kind))
         out[m.group(1)] = fields
     return out
 
@@ -129,6 +132,8 @@ def test_ctypes_structures_match_the_header_structs():
     assert set(structs) == set(pairs)
 
     def kind(c):
+        if isinstance(c, type) and issubclass(c, ctypes.Array):
+            return f"{kind(c._type_)}[{c._length_}]"
         if isinstance(c, type) and issubclass(c, ctypes.Structure):
             return "struct"
         if c in (ctypes.c_void_p,) or hasattr(c, "contents") or (hasattr(c, "_type_") and not isinstance(c._type_, str)):

@@ -203,6 +203,48 @@ def test_gemm_pair_of_different_shapes_is_one_grouped_launch(s0, s1, a_kc, b_kc)
     assert_close(res[1][1], ref, atol=2e-6 * s1[2] + 1e-5, rtol=2e-5)
 
 
+@pytest.mark.parametrize("a_kc,b_kc,shapes", [
+    (True, False, [(15000, 128, 384), (15000, 128, 256), (15000, 128, 256)]),                        # dX of the read-out token + the two modalities' dmid
+    (False, False, [(128, 128, 15000), (384, 128, 15000), (256, 128, 15000), (256, 128, 15000)]),     # dWo, dWqkv, dWf x 2: K splits, deferred reduces
+    (True, True, [(15000, 256, 128), (15000, 256, 128), (15000, 256, 128), (15000, 128, 128)]),       # key/value of three tokens + query
+    (True, True, [(257, 130, 100), (64, 3, 37), (1, 1, 1), (900, 128, 256), (70, 300, 41), (33, 64, 17)]),
+    (False, True, [(300, 128, 5000), (64, 64, 16)]),
+])
+def test_gemm_group_equals_single_launches(a_kc, b_kc, shapes):
+    """snag_gemm_f32_group: up to six problems of different shapes (same layouts) in one launch, each with its own epilogue, K split and
+    workspace, give the bits of separate snag_gemm_f32 calls; deferred reduces are finished by snag_gemm_reduce_group."""
+    import ctypes
+    from snag_amd import _lib
+    from snag_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(sum(sum(x) for x in shapes))
+    mk = lambda r, c: torch.randn(r, c, generator=g).to(DEV)
+    ops_ = [(mk(*((M, K) if a_kc else (K, M))), mk(*((N, K) if b_kc else (K, N))), mk(1, N).reshape(N), mk(M, N)) for (M, N, K) in shapes]
+    lib = _lib.load()
+    res = []
+    for single in (True, False):
+        outs = [torch.zeros(M, N, device=DEV) for (M, N, K) in shapes]
+        ws = [torch.empty(max(1, lib.snag_gemm_workspace_floats(M, N, K)), device=DEV) for (M, N, K) in shapes]
+        descs = []
+        for i, (a, b, bias, r) in enumerate(ops_):
+            kw = [dict(bias=ptr(bias), act=1), dict(add1=ptr(r), ld1=r.stride(0)), dict(accumulate=1), dict()][i % 4]
+            if i % 4 == 2:
+                outs[i].copy_(r)
+            descs.append(_desc(a, b, outs[i], a_kc, b_kc, ws[i], defer_reduce=int(i < 4 and not single), **kw))
+        if single:
+            for d in descs:
+                call("snag_gemm_f32", ctypes.byref(d), stream())
+        else:
+            arr = (ctypes.c_void_p * len(descs))(*[ctypes.addressof(d) for d in descs])
+            call("snag_gemm_f32_group", arr, len(descs), stream())
+            call("snag_gemm_reduce_group", arr, min(4, len(descs)), stream())
+        res.append(outs)
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    a, b, _, r = ops_[1]
+    ref = (a.double() if a_kc else a.double().t()) @ (b.double().t() if b_kc else b.double()) + r.double()
+    assert_close(res[1][1], ref, atol=2e-6 * shapes[1][2] + 1e-5, rtol=2e-5)
+
+
 @pytest.mark.parametrize("s0,s1", [((15000, 128, 4096), (15000, 128, 768)), ((4096, 128, 15000), (768, 128, 15000)), ((300, 128, 5000), (64, 64, 16)),
                                    ((130, 70, 4000), (257, 100, 3000))])
 def test_gemm_deferred_reduce_pair(s0, s1):
