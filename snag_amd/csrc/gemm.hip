@@ -514,9 +514,6 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     return pl;
 }
 
-static bool stream_ok(const snag_gemm_desc* d, const GemmPlan& pl);
-static int launch_stream(const snag_gemm_desc* const* ds, const GemmPlan* pl, int n, hipStream_t st);
-
 int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     const GemmPlan pl = plan_gemm(d);
     const GemmOperands& p = pl.p;
@@ -527,8 +524,6 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
                     (int)d->b_kcontig, pl.sk.G, (int)e.fast, (int)d->accumulate);
         return launch_streamk<64, 128, 32, 64>(p, e, d->workspace, pl.sk, d->a_kcontig, d->b_kcontig, st);
     }
-    static const int stream_single = env_int("SNAG_GEMM_STREAM_SINGLE");      // tuning / A-B: one problem alone is a chain of latencies either way
-    if (stream_single == 1 && stream_ok(d, pl)) return launch_stream(&d, &pl, 1, st);
     const int splits = pl.splits;
     float* slab = splits > 1 ? d->workspace : nullptr;
     if (log_shapes())
@@ -632,98 +627,12 @@ int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipSt
 
 static int launch_reduce(const GemmPlan& pl, float* slab, hipStream_t st);
 
-// ---- the B-resident streaming form (gemm_stream_kernel) ----------------------------------------------------------------------------
-// columns per unit for this K: 128 while the images of all k-tiles fit the LDS next to nothing else (K <= 192), else 64 (K <= 416)
-static int stream_tn(int K) { return K <= 192 ? 4 : (K <= 416 ? 2 : 0); }
-// its epilogue addresses every [M, ld] operand by a 32-bit byte offset
-static bool stream_spans_ok(const snag_gemm_desc* d) {
-    const int64_t lim = (int64_t)1 << 30;       // elements of 4 bytes
-    auto ok = [&](const void* q, int64_t ld) { return q == nullptr || (int64_t)d->M * ld < lim; };
-    return ok(d->C, d->ldc) && ok(d->pre_act, d->ldc) && ok(d->aux, d->ldaux) && ok(d->keep_mask, d->ldmask / 4 + 1) && ok(d->add1, d->ld1) && ok(d->add2, d->ld2) &&
-           ok(d->mirror, d->ldmirror);
-}
-static bool stream_ok(const snag_gemm_desc* d, const GemmPlan& pl) {
-    // OFF by default: measured (round 3, in the step) the grouped forward projections take 41.0 us in this form against 40.8 in 64 x 128
-    // tiles, the grouped d x products 52.2 against 37.1 -- in-kernel stamps (tools/stamp_stream.py): 2,070 cycles per k-tile and wave for 768
-    // cycles of MFMA; the eight waves re-read every B fragment from the LDS once per 32 rows (12 ds_read_b128 per 24 MFMAs and wave, 96 KB per
-    // k-tile step and CU), which is as long as the matrix work itself.  SNAG_GEMM_STREAM=1 selects it (A/B).
-    static const int on = env_int("SNAG_GEMM_STREAM");
-    static const int min_rows = env_int("SNAG_GEMM_STREAM_ROWS");
-    const bool off = on != 1;
-    return !off && kBf16x == 6 && kBK == 16 && d->a_kcontig && !d->a_tiled && !d->b_image && !d->c_transposed && pl.splits == 1 && !pl.streamk && d->K % 128 == 0 &&
-           stream_tn(d->K) != 0 && pl.p.a_vec && (!d->b_kcontig || pl.p.b_vec) && d->M >= (min_rows > 0 ? min_rows : 2048) && d->N >= 1 &&
-           ceil_div(d->N, 32 * stream_tn(d->K)) <= 8 && stream_spans_ok(d);
-}
-// n problems that all passed stream_ok with the same K class (TN) and B layout
-static int launch_stream(const snag_gemm_desc* const* ds, const GemmPlan* pl, int n, hipStream_t st) {
-    const int TN = stream_tn(ds[0]->K), BN = 32 * TN;
-    StreamGroup<Epilogue> g{};
-    double work[kStreamMaxUnits];
-    int cap[kStreamMaxUnits];
-    double total = 0;
-    int maxK = 0, nu = 0;
-    for (int i = 0; i < n; ++i) {
-        g.p[i] = pl[i].p;
-        g.e[i] = pl[i].e;
-        maxK = std::max(maxK, pl[i].p.K);
-        for (int c = 0; c < ceil_div(pl[i].p.N, BN); ++c) {
-            g.prob[nu] = (unsigned char)i;
-            g.ctile[nu] = (unsigned char)c;
-            work[nu] = (double)ceil_div(pl[i].p.M, 32) * pl[i].p.K;
-            cap[nu] = ceil_div(ceil_div(pl[i].p.M, 32), 8);          // a workgroup per eight row blocks at most
-            total += work[nu];
-            ++nu;
-        }
-    }
-    g.n_units = nu;
-    // one workgroup per CU (the images take most of the LDS), shared out by work; every unit gets at least one
-    int blocks = 0;
-    for (int u = 0; u < nu; ++u) {
-        const int share = std::max(1, std::min(cap[u], (int)(256.0 * work[u] / total)));
-        g.first[u] = (short)blocks;
-        blocks += share;
-    }
-    g.first[nu] = (short)blocks;
-    const size_t lds = (size_t)(maxK / 16) * 6 * BN * 16;
-    if (log_shapes())
-        for (int i = 0; i < n; ++i)
-            fprintf(stderr, "snag_gemm STREAM[%d/%d] M=%d N=%d K=%d b_kc=%d columns=%d workgroups=%d lds=%zu\n", i, n, pl[i].p.M, pl[i].p.N, pl[i].p.K, (int)ds[i]->b_kcontig, BN,
-                    blocks, lds);
-#define SNAG_STREAM(TN_, BK_)                                                                                                          \
-    do {                                                                                                                               \
-        auto* k = gemm_stream_kernel<TN_, BK_, Epilogue>;                                                                              \
-        static bool attr = false;                                                                                                      \
-        if (!attr) {                                                                                                                   \
-            if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)             \
-                return fail(SNAG_ERR_LAUNCH, "snag_gemm_f32(stream): cannot raise the dynamic LDS limit");                            \
-            attr = true;                                                                                                               \
-        }                                                                                                                              \
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, st, g);                                                                    \
-    } while (0)
-    if (TN == 4 && ds[0]->b_kcontig) SNAG_STREAM(4, true);
-    else if (TN == 4) SNAG_STREAM(4, false);
-    else if (ds[0]->b_kcontig) SNAG_STREAM(2, true);
-    else SNAG_STREAM(2, false);
-#undef SNAG_STREAM
-    return check_launch("snag_gemm_f32(stream)");
-}
-
 // Up to kGroupMax problems in ONE launch (gemm_tile_group_kernel) when every one of them would run the 64 x 128 tile with plain or split K
 // (no stream-K) on the same operand layouts; anything else: one after the other.  Each problem keeps the K split, slab and epilogue its
 // own dispatch would use, so the results are the same bits as one-by-one launches.
 int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) {
     static const int off = env_int("SNAG_GEMM_GROUP_OFF");      // tuning / A-B
     GemmPlan pl[kGroupMax];
-    if (!off && n >= 2 && n <= kGroupMax) {
-        bool stream = true;
-        int units = 0;
-        for (int i = 0; stream && i < n; ++i) {
-            pl[i] = plan_gemm(ds[i]);
-            stream = stream_ok(ds[i], pl[i]) && stream_tn(ds[i]->K) == stream_tn(ds[0]->K) && ds[i]->b_kcontig == ds[0]->b_kcontig;
-            if (stream) units += ceil_div(ds[i]->N, 32 * stream_tn(ds[i]->K));
-        }
-        if (stream && units <= kStreamMaxUnits) return launch_stream(ds, pl, n, st);
-    }
     bool ok = !off && n >= 2 && n <= kGroupMax;
     for (int i = 0; ok && i < n; ++i) {
         const snag_gemm_desc* d = ds[i];
@@ -740,12 +649,6 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
         }
         return SNAG_OK;
     }
-    // tall tiles (128 x 128, each wave's 32 rows of A straight to its registers) when nothing splits K and every problem has rows to spare:
-    // half the re-reads of B per output row
-    static const int tall_env = env_int("SNAG_GEMM_GROUP_TALL");      // tuning / A-B: 1 = on
-    bool tall = tall_env == 1;
-    for (int i = 0; i < n; ++i) tall = tall && pl[i].splits == 1 && pl[i].p.M >= 2048;
-    const int BMg = tall ? 128 : 64;
     GemmGroup<Epilogue> g{};
     g.n = n;
     int blocks = 0;
@@ -755,7 +658,7 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
         g.e[i] = pl[i].e;
         g.slab[i] = pl[i].splits > 1 ? ds[i]->workspace : nullptr;
         g.tiles_n[i] = ceil_div(pl[i].p.N, 128);
-        g.tiles[i] = g.tiles_n[i] * ceil_div(pl[i].p.M, BMg);
+        g.tiles[i] = g.tiles_n[i] * ceil_div(pl[i].p.M, 64);
         g.first[i] = blocks;
         blocks += g.tiles[i] * pl[i].splits;
         if (log_shapes())
@@ -766,9 +669,7 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
     const bool vec = use_vec(pl[0].p, ds[0]->a_kcontig, ds[0]->b_kcontig);
 #define SNAG_GROUPN(AK, BK_)                                                                                                              \
     do {                                                                                                                                  \
-        if (tall && vec) hipLaunchKernelGGL((gemm_tile_group_kernel<128, 128, 32, 128, AK, BK_, true, Epilogue>), dim3(blocks), dim3(256), 0, st, g);       \
-        else if (tall) hipLaunchKernelGGL((gemm_tile_group_kernel<128, 128, 32, 128, AK, BK_, false, Epilogue>), dim3(blocks), dim3(256), 0, st, g);        \
-        else if (vec) hipLaunchKernelGGL((gemm_tile_group_kernel<64, 128, 32, 64, AK, BK_, true, Epilogue>), dim3(blocks), dim3(256), 0, st, g);     \
+        if (vec) hipLaunchKernelGGL((gemm_tile_group_kernel<64, 128, 32, 64, AK, BK_, true, Epilogue>), dim3(blocks), dim3(256), 0, st, g);     \
         else hipLaunchKernelGGL((gemm_tile_group_kernel<64, 128, 32, 64, AK, BK_, false, Epilogue>), dim3(blocks), dim3(256), 0, st, g);       \
     } while (0)
     if (ds[0]->a_kcontig && ds[0]->b_kcontig) SNAG_GROUPN(true, true);

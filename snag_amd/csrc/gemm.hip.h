@@ -83,9 +83,6 @@ __device__ unsigned long long g_gemm_stamps[2 * 4 * 9];
 #else
 #define SNAG_STAMP(I, P) do { } while (0)
 #endif
-#ifndef SNAG_GEMM_DEEP
-#define SNAG_GEMM_DEEP 0                 // four-wave pre-split loop (64 x 128 tiles): 1 = four register sets, tiles kt+2 .. kt+5 in flight
-#endif
 #ifndef SNAG_GEMM_SKIP_ASPLIT
 #define SNAG_GEMM_SKIP_ASPLIT 0
 #endif
@@ -1014,29 +1011,12 @@ struct GemmCore {
             if (!(p.dbg & 4)) __syncthreads();
 #else                       // (a conditional fetch in the production loop would degrade its counted vmcnt waits to vmcnt(0))
             stage(set, cur ^ 1);
-            fetch(set, kt + (SNAG_GEMM_DEEP ? 5 : 3));
+            fetch(set, kt + 3);
             mfma_split(a, b);
             __syncthreads();
 #endif
         };
         if (nk > 0) {
-#if SNAG_GEMM_DEEP
-            // FOUR register sets: tiles kt+2 .. kt+5 in flight (tile t in set t & 3) -- a K = 128 product has five of its eight k-tiles
-            // requested before the first one is used.  Whole quadruples of iterations (tiles past the end are zeros).
-            fetch(0, 0);
-            fetch(1, 1);
-            fetch(2, 2);
-            fetch(3, 3);
-            stage(0, 0);
-            fetch(0, 4);
-            __syncthreads();
-            for (int kt = 0; kt < nk; kt += 4) {
-                iteration(kt, std::integral_constant<int, 1>{});
-                iteration(kt + 1, std::integral_constant<int, 2>{});
-                iteration(kt + 2, std::integral_constant<int, 3>{});
-                iteration(kt + 3, std::integral_constant<int, 0>{});
-            }
-#else
             fetch(0, 0);
             fetch(1, 1);
             stage(0, 0);
@@ -1048,7 +1028,6 @@ struct GemmCore {
                 iteration(kt, std::integral_constant<int, 1>{});
                 iteration(kt + 1, std::integral_constant<int, 0>{});
             }
-#endif
         }
         if (kleft % 16 != 0) {
             sa.load_tail(0, nk, kleft);
@@ -1390,212 +1369,6 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_group_ke
     const int b = (int)blockIdx.x - g.first[q];
     const int z = b / g.tiles[q], t = b % g.tiles[q];
     gemm_tile_at<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi>(g.p[q], g.e[q], g.slab[q], z, (t / g.tiles_n[q]) * BM, (t % g.tiles_n[q]) * BN, smem);
-}
-
-// B-RESIDENT STREAMING form for short K (K = 128 / 256 / 384: every product around the Mformer layer).  The 64 x 128 tile loop spends
-// its time on what surrounds the matrix work -- per k-tile a barrier, the split of A and of B and their LDS images, per tile a launch-
-// to-first-load latency and a drain: 40 us for 3.4 GFLOP (the grouped forward projections), a fifth of what the MFMAs need.  Here a
-// workgroup splits its column tile of B (32 TN columns x K) ONCE into LDS images of all k-tiles (K / 16 x 6 x 32 TN x 16 bytes: 96 KB
-// for 128 columns x K = 128, 144 KB for 64 columns x K = 384), then its eight waves stream 32-row blocks of A through it WITHOUT any
-// further barrier: a wave loads its rows' K values straight into registers (sixteen dwordx4 per 128 k), splits them, and multiplies
-// against B fragments read from the resident images.  Same split, same products, same k order as the tile loops: the same bits.
-constexpr int kStreamMaxUnits = 40;
-template <class Epi>
-struct StreamGroup {
-    GemmOperands p[kGroupMax];
-    Epi e[kGroupMax];
-    int n_units;
-    unsigned char prob[kStreamMaxUnits];      // unit = (problem, column tile)
-    unsigned char ctile[kStreamMaxUnits];
-    short first[kStreamMaxUnits + 1];         // workgroup ranges of the units
-};
-
-// The epilogue of one 32 x (32 TN) block straight from the accumulators (lane: column col + 32 j, rows row + (e & 3) + 8 (e >> 2)), operand
-// by operand: ALL the loads of one side input first, then its arithmetic -- a handful of memory round trips per block.  (Element by
-// element, epi(m, n, v) costs one dependent round trip per element: 64 in a row, 90 us for a [15000 x 128 x 128] product.)  Per element
-// the operations and their order are Epilogue::one()'s and operator()'s: the same bits.  Needs the Epilogue of gemm.hip (not C-transposed).
-template <int J0, int TN, class Core, class Epi>      // accumulator tiles J0 .. J0 + TN - 1 (col: the lane's column in tile J0)
-__device__ __forceinline__ void stream_epilogue(const Core& core, const Epi& epi, int row, int col) {
-#define SNAG_JE _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int e = 0; e < 16; ++e)
-    // addresses: uniform base + a 32-bit byte offset per lane (the host checked that every operand spans < 4 GB)
-    auto ldf = [](const float* base, uint32_t off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off); };
-    auto stf = [](float* base, uint32_t off, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) = v; };
-    float x[TN][16];
-    uint32_t mc[16], nc[TN];          // rows / columns clamped into the matrix (out-of-range elements load a valid address, their stores are skipped)
-    bool mok[16], nok[TN];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int m = row + (e & 3) + 8 * (e >> 2);
-        mok[e] = m < epi.M;
-        mc[e] = (uint32_t)min(m, epi.M - 1);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        nok[j] = col + 32 * j < epi.N;
-        nc[j] = (uint32_t)min(col + 32 * j, epi.N - 1);
-    }
-    SNAG_JE x[j][e] = core.acc[0][J0 + j][e] * epi.alpha;
-    if (epi.bias) {
-        float b[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = epi.bias[nc[j]];
-        SNAG_JE x[j][e] += b[j];
-    }
-    const uint32_t ldc4 = (uint32_t)epi.ldc * 4u;
-    if (epi.pre) SNAG_JE if (mok[e] && nok[j]) stf(epi.pre, mc[e] * ldc4 + nc[j] * 4u, x[j][e]);
-    if (epi.act == 1) {
-        SNAG_JE x[j][e] = fmaxf(x[j][e], 0.f);
-    } else if (epi.act == 2) {
-        SNAG_JE x[j][e] = 0.5f * x[j][e] * (1.0f + erff(x[j][e] * 0.70710678118654752440f));
-    } else if (epi.act == 3 || epi.act == 4) {
-        float u[TN][16];
-        const uint32_t ld4 = (uint32_t)epi.ldaux * 4u;
-        SNAG_JE u[j][e] = ldf(epi.aux, mc[e] * ld4 + nc[j] * 4u);
-        if (epi.act == 3) SNAG_JE x[j][e] *= 0.5f * (1.0f + erff(u[j][e] * 0.70710678118654752440f)) + u[j][e] * expf(-0.5f * u[j][e] * u[j][e]) * 0.39894228040143267794f;
-        else SNAG_JE x[j][e] = u[j][e] > 0.f ? x[j][e] : 0.f;
-    }
-    if (epi.mask) {
-        uint8_t k[TN][16];
-        const uint32_t ldm = (uint32_t)epi.ldm;
-        SNAG_JE k[j][e] = *(epi.mask + (mc[e] * ldm + nc[j]));
-        SNAG_JE x[j][e] = k[j][e] ? x[j][e] * epi.mscale : 0.f;
-    }
-    if (epi.add1) {
-        float t[TN][16];
-        const uint32_t ld4 = (uint32_t)epi.ld1 * 4u;
-        SNAG_JE t[j][e] = ldf(epi.add1, mc[e] * ld4 + nc[j] * 4u);
-        SNAG_JE x[j][e] += t[j][e];
-    }
-    if (epi.add2) {
-        float t[TN][16];
-        const uint32_t ld4 = (uint32_t)epi.ld2 * 4u;
-        SNAG_JE t[j][e] = ldf(epi.add2, mc[e] * ld4 + nc[j] * 4u);
-        SNAG_JE x[j][e] += t[j][e];
-    }
-    if (epi.accumulate) {
-        float t[TN][16];
-        SNAG_JE t[j][e] = ldf(epi.C, mc[e] * ldc4 + nc[j] * 4u);
-        SNAG_JE x[j][e] = t[j][e] + x[j][e];
-    }
-    SNAG_JE if (mok[e] && nok[j]) stf(epi.C, mc[e] * ldc4 + nc[j] * 4u, x[j][e]);
-    if (epi.mirror) {
-        uint8_t k[16];
-        const uint32_t ld4 = (uint32_t)epi.ldmirror * 4u;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) k[e] = epi.mirror_mask ? epi.mirror_mask[mc[e]] : (uint8_t)0;
-        SNAG_JE if (mok[e] && nok[j]) stf(epi.mirror, mc[e] * ld4 + nc[j] * 4u, k[e] ? x[j][e] * epi.mirror_scale : x[j][e]);
-    }
-#undef SNAG_JE
-}
-
-template <int TN, bool B_KC, class Epi>
-__global__ __launch_bounds__(512) void gemm_stream_kernel(StreamGroup<Epi> g) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BN = 32 * TN;
-    constexpr int IMG = 6 * BN * 16;          // bytes of one k-tile's image: 3 planes x 2 k-halves x BN rows x 16
-    extern __shared__ __attribute__((aligned(16))) unsigned char stream_images[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id_uniform();
-    int u = 0;
-    while (u + 1 < g.n_units && (int)blockIdx.x >= g.first[u + 1]) ++u;
-    const GemmOperands& p = g.p[g.prob[u]];
-    const Epi& epi = g.e[g.prob[u]];
-    const int n0 = g.ctile[u] * BN;
-    const int nwg = g.first[u + 1] - g.first[u], w = (int)blockIdx.x - g.first[u];
-    const int nk = p.K >> 4;                  // K is a multiple of 128 (host)
-#if SNAG_GEMM_STAMP
-    unsigned long long sst[8] = {};
-    int sst_blocks = 0;
-#define SNAG_SST(I) do { __builtin_amdgcn_sched_barrier(0); if (sst_blocks == 0) sst[I] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define SNAG_SST(I) do { } while (0)
-#endif
-    SNAG_SST(0);
-    {   // 1. the images of this column tile, all k-tiles
-        constexpr int NTB = BN == 128 ? 512 : 256;
-        if (tid < NTB) {
-            SplitStager<BN, B_KC, NTB, true> sb;
-            sb.init(p.B, p.ldb, 1, n0, p.N, 0, tid);
-            sb.ablate = 0;
-            for (int kt = 0; kt < nk; kt += 4) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) sb.load(s, kt + s, p.K);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) sb.split_store(s, stream_images + (kt + s) * IMG);
-            }
-        }
-    }
-    SNAG_SST(1);
-    __syncthreads();
-    SNAG_SST(2);
-    // 2. 32-row blocks of A, wave by wave
-    using Core = GemmCore<256, BN, 32, BN, true, B_KC, true>;      // (its accumulators and mfma_split: TM = 1)
-    const int li = lane & 31, lh = lane >> 5;
-    const int nrb = (p.M + 31) >> 5;
-    // A in half-chunks of four k-tiles (eight dwordx4 per lane), double-buffered: while one half multiplies, the next one -- of this row
-    // block or of the wave's next one -- is in flight.  Straight-line code: every load is unconditional (the one past the wave's last half
-    // re-reads its first), so the waits stay counted.
-    auto row_ptr = [&](int rb) { return p.A + (int64_t)min(rb * 32 + li, p.M - 1) * p.lda + 4 * lh; };
-    auto load_half = [&](const float* src, float4 (&dst)[4][2]) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            dst[t][0] = *reinterpret_cast<const float4*>(src + t * 16);
-            dst[t][1] = *reinterpret_cast<const float4*>(src + t * 16 + 8);
-        }
-    };
-    Core core;
-    auto mul_half = [&](const float4 (&av)[4][2], int kt0) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            uint32_t h[4], m[4], l[4];
-            split_pair(av[t][0].x, av[t][0].y, h[0], m[0], l[0]);
-            split_pair(av[t][0].z, av[t][0].w, h[1], m[1], l[1]);
-            split_pair(av[t][1].x, av[t][1].y, h[2], m[2], l[2]);
-            split_pair(av[t][1].z, av[t][1].w, h[3], m[3], l[3]);
-            using u4 = __attribute__((ext_vector_type(4))) uint32_t;
-            Split3 a[1], b[TN];
-            a[0].h = __builtin_bit_cast(bf16x8, (u4){h[0], h[1], h[2], h[3]});
-            a[0].m = __builtin_bit_cast(bf16x8, (u4){m[0], m[1], m[2], m[3]});
-            a[0].l = __builtin_bit_cast(bf16x8, (u4){l[0], l[1], l[2], l[3]});
-#pragma unroll
-            for (int j = 0; j < TN; ++j) load_split_fragment<BN>(stream_images + (kt0 + t) * IMG, 32 * j + li, lh, b[j]);
-            core.mfma_split(a, b);
-        }
-    };
-    const int rb_first = w * 8 + wave, rb_step = nwg * 8;
-    float4 av0[4][2], av1[4][2];
-    if (rb_first < nrb) load_half(row_ptr(rb_first), av0);
-    for (int rb = rb_first; rb < nrb; rb += rb_step) {
-        const int row0 = rb * 32;
-        const float* arow = row_ptr(rb);
-        const float* anext = row_ptr(rb + rb_step < nrb ? rb + rb_step : rb_first);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) core.acc[0][j][e] = 0.f;
-        SNAG_SST(3);
-        for (int kc = 0; kc < nk; kc += 8) {
-            load_half(arow + (kc + 4) * 16, av1);
-            mul_half(av0, kc);
-            load_half(kc + 8 < nk ? arow + (kc + 8) * 16 : anext, av0);
-            mul_half(av1, kc + 4);
-        }
-        SNAG_SST(4);
-        // (two column halves at a time: 32 values per lane and their side inputs stay in registers)
-        stream_epilogue<0, 2>(core, epi, row0 + 4 * lh, n0 + li);
-        if constexpr (TN == 4) stream_epilogue<2, 2>(core, epi, row0 + 4 * lh, n0 + 64 + li);
-        SNAG_SST(5);
-#if SNAG_GEMM_STAMP
-        ++sst_blocks;
-#endif
-    }
-#if SNAG_GEMM_STAMP
-    sst_blocks = 0;
-    SNAG_SST(6);
-    if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 5)) {
-        for (int i = 0; i < 7; ++i) g_gemm_stamps[(wave ? 9 : 0) + i] = sst[i];
-    }
-#endif
-#endif
 }
 
 // Stream-K: G persistent blocks (512 = two per CU by default) share the (tile, k-tile) iteration space evenly, so every CU gets the same MFMA work whatever

@@ -492,17 +492,3 @@ def test_gemm_non_finite_and_extreme_operands_are_documented_behaviour():
     assert torch.isnan(c[3]).all()                                       # NaN operand: NaN, as in fp32
     assert abs(float(c[4, 9]) - 1.0e-40) < 9.2e-41                        # denormal: what bf16's own denormal range holds (absolute error < 2^-133 |b|)
 
-
-@pytest.mark.parametrize("shape,b_kc", [((4100, 384, 128), True), ((2500, 100, 256), False), ((3000, 128, 384), False)])
-def test_streaming_form_is_correct_when_selected(shape, b_kc):
-    """The B-resident streaming form of the short-K products (SNAG_GEMM_STREAM=1; off by default, see gemm.hip stream_ok) against fp64,
-    in a process of its own (the switch is read once)."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SNAG_GEMM_STREAM="1", SNAG_GEMM_STREAM_SINGLE="1", SNAG_GEMM_LOG="1")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg_stream.py"), *map(str, shape), "1" if b_kc else "0"], env=env, capture_output=True,
-                       text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert "bad 0 of" in r.stdout, r.stdout
-    assert "STREAM" in r.stderr, r.stderr[-500:]
