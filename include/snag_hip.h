@@ -260,11 +260,15 @@ typedef struct snag_gemm_desc {
      * describe it: shapes that do not run the eight-wave row-private tile ignore the image).  The projection weights are split once
      * per step instead of once per workgroup and k-tile, and reach the LDS by DMA: no registers, no VALU.  Bit-identical results. */
     const void* b_image;
+    /* 0: the library chooses the K split.  > 0: this many K splits are wanted (capped by K / 64 and by what the workspace holds; the
+     * reduce entries read the same field, so a deferred reduce agrees with its launch).  A caller that puts several long-K problems
+     * into one grouped launch balances the workgroups' k-ranges across them with it. */
+    int32_t splits;
 } snag_gemm_desc;
 
 /* Up to SNAG_GEMM_GROUP_MAX independent problems of ANY shapes in one call -- one launch when each of them would run the 64 x 128 tile
- * (plain or split K, no stream-K plan) on the same operand layouts (a_kcontig / b_kcontig equal across the group), one launch per problem
- * otherwise.  Results are the same bits as separate snag_gemm_f32 calls: every problem keeps its own K split, workspace (distinct per
+ * (plain or split K, no stream-K plan), or each of them the eight-wave 256 x 128 tile of the long-K shapes (M >= 1024, K >= 512,
+ * N <= 128), on the same operand layouts (a_kcontig / b_kcontig equal across the group), one launch per problem otherwise.  Results are the same bits as separate snag_gemm_f32 calls: every problem keeps its own K split, workspace (distinct per
  * split problem) and epilogue; defer_reduce is honoured per problem.  The outputs must not overlap.  (The six independent products behind
  * the read-out layer's attention backward, reference ops: the nn.Linear backward of BertSelfAttention / ProjectionHead,
  * model/SNAG_tools.py:32-51, 134-142.) */

@@ -32,7 +32,7 @@ class GemmDesc(_c.Structure):
                 ("accumulate", _c.c_int32), ("workspace", _P), ("workspace_floats", _L),
                 ("aux", _P), ("ldaux", _L), ("ldmask", _L), ("defer_reduce", _c.c_int32),
                 ("mirror", _P), ("ldmirror", _L), ("mirror_rowmask", _P), ("mirror_scale", _F),
-                ("a_tiled", _c.c_int32), ("c_transposed", _c.c_int32), ("b_image", _P)]
+                ("a_tiled", _c.c_int32), ("c_transposed", _c.c_int32), ("b_image", _P), ("splits", _c.c_int32)]
 
 
 class MaskRegion(_c.Structure):

@@ -481,7 +481,8 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
         splits = force_splits() > 0 ? force_splits() : pick_splits(tiles, p.K, d->a_kcontig && d->b_kcontig);
         // row-private tiles: at most ONE resident wave of workgroups -- 512 four-wave ones (two per CU), 256 eight-wave ones (measured
         // with four waves: 590 workgroups 0.7135 ms per step, 472-512 0.702, against 0.720 with 64 x 128 tiles)
-        if (kBf16x != 0 && big && force_splits() <= 0 && env_int("SNAG_GEMM_TARGET") <= 0)
+        if (d->splits > 0) splits = (int)std::min<int64_t>(d->splits, std::max<int64_t>(1, p.K / (kMinKTiles * 16)));
+        else if (kBf16x != 0 && big && force_splits() <= 0 && env_int("SNAG_GEMM_TARGET") <= 0)
             splits = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(1, p.K / (kMinKTiles * 16)),
                                                                 (pp ? 256 : 512) / std::max<int64_t>(1, tiles)));
         const int64_t cap = d->workspace_floats / ((int64_t)p.M * p.N);
@@ -493,7 +494,7 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     if (p.K == 0) splits = 1;
     pl.big = big; pl.wide = wide; pl.streamk = false; pl.pp = pp;
     if (pp && p.N > 128 && p.xcd) p.xcd |= 4 << 4;           // several column tiles: grouped tile order (4 row tiles deep per XCD, gemm_tile_body)
-    if (splits > 1 && !big && !wide && streamk_mode() != 1) {
+    if (splits > 1 && !big && !wide && streamk_mode() != 1 && d->splits <= 0) {      // (an explicit split request is a split-K request)
         // blocks per CU of the split grid vs what the slowest CU gets
         const double per_cu = (double)tiles * splits / 256.0;
         const double balance = per_cu / std::ceil(per_cu);
@@ -634,10 +635,15 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
     static const int off = env_int("SNAG_GEMM_GROUP_OFF");      // tuning / A-B
     GemmPlan pl[kGroupMax];
     bool ok = !off && n >= 2 && n <= kGroupMax;
+    bool pp = false;                  // every problem on the eight-wave 256 x 128 tile instead (512 threads per workgroup)
     for (int i = 0; ok && i < n; ++i) {
         const snag_gemm_desc* d = ds[i];
         pl[i] = plan_gemm(d);
-        ok = d->M > 0 && d->N > 0 && d->K > 0 && !pl[i].streamk && !pl[i].wide && !pl[i].big && !pl[i].pp && !d->a_tiled && !d->b_image &&
+        if (i == 0) pp = pl[0].big && pl[0].pp;
+        // (in a group of eight-wave tiles a problem with an explicit split request rides along even if, alone, its row count would pick
+        // the 64 x 128 tile: its K split and epilogue do not depend on the tile)
+        const bool pp_ok = (pl[i].big && pl[i].pp) || (d->splits > 0 && kBf16x != 0 && d->K >= 512 && d->N <= 128 && !pl[i].big);
+        ok = d->M > 0 && d->N > 0 && d->K > 0 && !pl[i].streamk && !pl[i].wide && (pp ? pp_ok : (!pl[i].big && !pl[i].pp)) && !d->a_tiled && !d->b_image &&
              d->a_kcontig == ds[0]->a_kcontig && d->b_kcontig == ds[0]->b_kcontig &&
              use_vec(pl[i].p, d->a_kcontig, d->b_kcontig) == use_vec(pl[0].p, ds[0]->a_kcontig, ds[0]->b_kcontig);
         for (int j = 0; ok && j < i; ++j) ok = !(pl[i].splits > 1 && pl[j].splits > 1 && ds[i]->workspace == ds[j]->workspace);
@@ -658,18 +664,20 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
         g.e[i] = pl[i].e;
         g.slab[i] = pl[i].splits > 1 ? ds[i]->workspace : nullptr;
         g.tiles_n[i] = ceil_div(pl[i].p.N, 128);
-        g.tiles[i] = g.tiles_n[i] * ceil_div(pl[i].p.M, 64);
+        g.tiles[i] = g.tiles_n[i] * ceil_div(pl[i].p.M, pp ? 256 : 64);
         g.first[i] = blocks;
         blocks += g.tiles[i] * pl[i].splits;
         if (log_shapes())
-            fprintf(stderr, "snag_gemm GROUP[%d/%d] M=%d N=%d K=%d a_kc=%d b_kc=%d tile=64x128 splits=%d\n", i, n, pl[i].p.M, pl[i].p.N, pl[i].p.K, (int)ds[i]->a_kcontig,
-                    (int)ds[i]->b_kcontig, pl[i].splits);
+            fprintf(stderr, "snag_gemm GROUP[%d/%d] M=%d N=%d K=%d a_kc=%d b_kc=%d tile=%s splits=%d\n", i, n, pl[i].p.M, pl[i].p.N, pl[i].p.K, (int)ds[i]->a_kcontig,
+                    (int)ds[i]->b_kcontig, pp ? "256x128" : "64x128", pl[i].splits);
     }
     g.first[n] = blocks;
     const bool vec = use_vec(pl[0].p, ds[0]->a_kcontig, ds[0]->b_kcontig);
 #define SNAG_GROUPN(AK, BK_)                                                                                                              \
     do {                                                                                                                                  \
-        if (vec) hipLaunchKernelGGL((gemm_tile_group_kernel<64, 128, 32, 64, AK, BK_, true, Epilogue>), dim3(blocks), dim3(256), 0, st, g);     \
+        if (pp && vec) hipLaunchKernelGGL((gemm_tile_group_kernel<256, 128, 32, 128, AK, BK_, true, Epilogue>), dim3(blocks), dim3(512), 0, st, g);     \
+        else if (pp) hipLaunchKernelGGL((gemm_tile_group_kernel<256, 128, 32, 128, AK, BK_, false, Epilogue>), dim3(blocks), dim3(512), 0, st, g);      \
+        else if (vec) hipLaunchKernelGGL((gemm_tile_group_kernel<64, 128, 32, 64, AK, BK_, true, Epilogue>), dim3(blocks), dim3(256), 0, st, g);     \
         else hipLaunchKernelGGL((gemm_tile_group_kernel<64, 128, 32, 64, AK, BK_, false, Epilogue>), dim3(blocks), dim3(256), 0, st, g);       \
     } while (0)
     if (ds[0]->a_kcontig && ds[0]->b_kcontig) SNAG_GROUPN(true, true);

@@ -810,6 +810,18 @@ class MKGCHotPath:
             call("snag_gemm_f32", ctypes.byref(dl1[0]), st)
             call("snag_gemm_f32", ctypes.byref(dl1[1]), st)
             call("snag_gemm_reduce_group", group, 4, st)
+        elif reducer is None and len(dl1) == 2 and all(fd >= 512 for fd in cfg.feat_dims):
+            # weight gradients of the two first projections in ONE launch of eight-wave tiles (snag_gemm_f32_group): alone, the visual one
+            # fills the chip exactly (16 row tiles x 16 K splits) and the text one then runs as a second, under-filled launch; together,
+            # with the K split chosen so that all row tiles x splits fit one round of workgroups, every CU walks the same k-range once.
+            tiles = sum((fd + 255) // 256 for fd in cfg.feat_dims)
+            splits = max(1, 256 // tiles)
+            group = (ctypes.POINTER(_lib.GemmDesc) * 2)()
+            for j, d in enumerate(dl1):
+                d.defer_reduce, d.splits = 1, splits
+                group[j] = ctypes.pointer(d)
+            call("snag_gemm_f32_group", group, 2, st)
+            call("snag_gemm_reduce_pair", ctypes.byref(dl1[0]), ctypes.byref(dl1[1]), st)
         elif reducer is None:       # weight gradients of the first projections: two kernels, ONE reduce launch per pair of modalities
             self._gemm_deferred_pairs(dl1)
         if self.fold:

@@ -492,3 +492,35 @@ def test_gemm_non_finite_and_extreme_operands_are_documented_behaviour():
     assert torch.isnan(c[3]).all()                                       # NaN operand: NaN, as in fp32
     assert abs(float(c[4, 9]) - 1.0e-40) < 9.2e-41                        # denormal: what bf16's own denormal range holds (absolute error < 2^-133 |b|)
 
+
+
+@pytest.mark.parametrize("shapes,splits", [([(4096, 128, 15000), (768, 128, 15000)], 13), ([(2048, 128, 3000), (1100, 100, 3000), (300, 64, 3000)], 5)])
+def test_gemm_group_of_long_k_problems_with_a_requested_split(shapes, splits):
+    """snag_gemm_f32_group on the eight-wave 256 x 128 tile: long-K weight-gradient shapes (A and B row-contiguous, C stored transposed)
+    with snag_gemm_desc.splits set by the caller -- one launch, deferred reduces -- give the bits of single launches with the same request,
+    and the problem whose row count alone would pick another tile rides along."""
+    import ctypes
+    from snag_amd import _lib
+    from snag_amd._lib import call, stream
+    g = torch.Generator().manual_seed(sum(sum(x) for x in shapes) + splits)
+    mk = lambda r, c: torch.randn(r, c, generator=g).to(DEV)
+    ops_ = [(mk(K, M), mk(K, N)) for (M, N, K) in shapes]
+    res = []
+    for single in (True, False):
+        outs = [torch.zeros(N, M, device=DEV) for (M, N, K) in shapes]           # transposed outputs
+        ws = [torch.empty(splits * M * N + 64, device=DEV) for (M, N, K) in shapes]
+        descs = [_desc(a, b, o, False, False, w, c_transposed=1, splits=splits, defer_reduce=int(not single)) for (a, b), o, w in zip(ops_, outs, ws)]
+        for d, (M, N, K) in zip(descs, shapes):
+            d.ldc = M
+        if single:
+            for d in descs:
+                call("snag_gemm_f32", ctypes.byref(d), stream())
+        else:
+            arr = (ctypes.c_void_p * len(descs))(*[ctypes.addressof(d) for d in descs])
+            call("snag_gemm_f32_group", arr, len(descs), stream())
+            call("snag_gemm_reduce_group", arr, len(descs), stream())
+        res.append(outs)
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    a, b = ops_[1]
+    assert_close(res[1][1], (a.double().t() @ b.double()).t(), atol=2e-6 * shapes[1][2] + 1e-5, rtol=2e-5)
