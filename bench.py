@@ -86,26 +86,35 @@ def score_bytes(cfg, n_triples):
     return n_triples * ((cfg.neg_num + 3) * cfg.dim * 4 + (cfg.neg_num + 3) * 4 + (cfg.neg_num + 1) * 4)
 
 
-def roofline_dominant(cfg, timer, rows=None, reduce_timer=None):
-    """The launch that takes the largest share of the step: the visual projection l1 GEMM over this rank's entity rows.
+def roofline_dominant(cfg, timer, rows=None, reduce_timer=None, grouped=False):
+    """The launch that takes the largest share of the step: the first projection over this rank's entity rows -- the visual one
+    alone, or (``grouped``: two modalities, snag_gemm_f32_group) the visual and the text one in ONE launch of eight-wave tiles with
+    balanced K splits; work and bytes are then those of both.
 
     fp32 in / fp32 accumulate; the multiplies run as six bf16 MFMA products of exactly split operands (include/snag_hip.h, snag_gemm_f32)."""
     us, n = timer.mean_us()
-    if reduce_timer is not None:        # + the whole reduce launch it shares with the text projection (conservative: all of it counted here)
+    if reduce_timer is not None:        # + the whole reduce launch (conservative: all of it counted here)
         us += reduce_timer.mean_us()[0]
     rows = cfg.n_ent if rows is None else rows
-    flops = 2.0 * rows * cfg.feat_dims[0] * cfg.dim
+    dims = list(cfg.feat_dims[:2]) if grouped else [cfg.feat_dims[0]]
+    flops = sum(2.0 * rows * fd * cfg.dim for fd in dims)
+    alg_bytes = sum(4 * (rows * fd + fd * cfg.dim + rows * cfg.dim) for fd in dims)
     ach = flops / (us * 1e-6) / 1e12 if us else 0.0
     traffic, src = None, None
     try:  # PMC passes cannot run inside this process; the committed per-launch figure is quoted when it is for this very shape
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_dominant.json")) as f:
             pmc = json.load(f)
-        if (pmc["n_ent"], pmc["feat0"], pmc["dim"]) == (rows, cfg.feat_dims[0], cfg.dim):
+        if (pmc["n_ent"], pmc["feat0"], pmc["dim"], bool(pmc.get("grouped", False))) == (rows, cfg.feat_dims[0], cfg.dim, bool(grouped)):
             # the timed call is the GEMM kernel AND its split-K reduce launch: both kernels' HBM bytes
             traffic, src = pmc["fetch_bytes"] + pmc["write_bytes"] + pmc.get("fixup_fetch_bytes", 0) + pmc.get("fixup_write_bytes", 0), pmc["source"]
     except (OSError, KeyError, ValueError):
         pass
-    return {"kernel": f"gemm_tile_kernel<256,128,32,128,A K-contiguous,B K-contiguous> (8-wave ping-pong) + splitk_reduce_multi_kernel (shared with the text projection, counted in full) (visual projection: [{rows},{cfg.feat_dims[0]}]x[{cfg.dim},{cfg.feat_dims[0]}]^T, fp32 via 6 split-bf16 MFMA products, 4 K-splits)",
+    shapes = " + ".join(f"[{rows},{fd}]x[{cfg.dim},{fd}]^T" for fd in dims)
+    kern = (f"gemm_tile_group_kernel<256,128,32,128,A K-contiguous,B K-contiguous> (8-wave ping-pong tiles; the visual and the text projection in ONE launch, K splits "
+            f"balanced across both) + the split-K reduce of the visual one ({shapes}, fp32 via 6 split-bf16 MFMA products)" if grouped else
+            f"gemm_tile_kernel<256,128,32,128,A K-contiguous,B K-contiguous> (8-wave ping-pong) + splitk_reduce_multi_kernel (shared with the text projection, "
+            f"counted in full) (visual projection: {shapes}, fp32 via 6 split-bf16 MFMA products, 4 K-splits)")
+    return {"kernel": kern,
             # the bound of the kernel AS BUILT: six bf16 MFMA products per f32 multiply-add -> bf16 dense peak / 6 (37.5 us for this
             # launch; its HBM floor, 255.5 MB at 8 TB/s, is 32 us).  frac is therefore the share of the matrix pipe's time the
             # launch (kernel + fix-up) uses; against the f32 MFMA peak (157.3 TF), which bounded the previous form of this kernel
@@ -113,9 +122,9 @@ def roofline_dominant(cfg, timer, rows=None, reduce_timer=None):
             "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS / 6, "unit": "TFLOP/s (f32 multiply-adds)", "frac": ach / (BF16_MFMA_PEAK_TFLOPS / 6),
             "peak_basis": "bf16 dense MFMA peak 2516.6 TF / 6 products per f32 multiply-add",
             "time_vs_round1_f32_mfma_bound": ach / F32_MFMA_PEAK_TFLOPS,      # (the kernel issues no f32 MFMAs: how this launch compares with the bound of the round-1 kernel)
-            "hbm_frac": (4 * (rows * cfg.feat_dims[0] + cfg.feat_dims[0] * cfg.dim + rows * cfg.dim)) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us else 0.0,
+            "hbm_frac": alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us else 0.0,
             "traffic": traffic, "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC)", "traffic_source": src,
-            "algorithmic_bytes_per_launch": 4 * (rows * cfg.feat_dims[0] + cfg.feat_dims[0] * cfg.dim + rows * cfg.dim),
+            "algorithmic_bytes_per_launch": alg_bytes,
             "avg_us": us, "avg_us_source": "HIP events (torch events on the launch stream) around the GEMM launch + the whole shared reduce launch, inside the timed "
                                            "region; an event pair adds ~5-10 us of stream bubbles: the rocprofv3 per-kernel durations under profiles/ are the tighter figure",
             "launches_timed": n, "algorithmic_flops_per_launch": flops}
@@ -742,7 +751,7 @@ def main():
         out["measured_copy_GBs"] = copy_gbs
         out.update(extras)
         if timers:
-            out["roofline"] = roofline_dominant(cfg, timers["proj_l1_fwd"], rows=eng.shard.n_loc, reduce_timer=timers["proj_l1_fwd_reduce"])
+            out["roofline"] = roofline_dominant(cfg, timers["proj_l1_fwd"], rows=eng.shard.n_loc, reduce_timer=timers["proj_l1_fwd_reduce"], grouped=eng.l1_grouped)
             out["roofline_score"] = roofline_score(cfg, args.batch, timers["score_fwd_bwd"])
             if not args.no_extras:
                 out["roofline_score"]["batch_8192"] = score_train_larger_batch(eng, cfg, device)

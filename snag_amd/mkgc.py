@@ -274,6 +274,7 @@ class MKGCHotPath:
         self.noise_epoch = 0
         self.training = True
         self.probe = None                # optional {tag: timer with .wrap(fn)}: bench.py's per-kernel HIP-event timers
+        self.l1_grouped = False          # the two first projections ran as one grouped launch (bench.py's roofline object describes it)
         self.marks = None                # optional list: (phase name, HIP event on the launch stream) appended at the step's phase boundaries
         self._loss_part = None
         self._score_bwd_scale = None
@@ -385,6 +386,37 @@ class MKGCHotPath:
     # ------------------------------------------------------------------------------------------
     def _gemm(self, *a, **k):
         call("snag_gemm_f32", ctypes.byref(self._gemm_desc(*a, **k)), self._st)
+
+    @staticmethod
+    def _balanced_splits(shapes):
+        """K splits for long-K problems [(M, K)] that share ONE launch of eight-wave 256-row tiles (snag_gemm_f32_group): every
+        workgroup should walk about the same number of k-tiles and all row tiles x splits should fit one round of 256 workgroups."""
+        tiles = [(m + 255) // 256 for m, _ in shapes]
+        nk = [(k + 15) // 16 for _, k in shapes]
+        per_wg = max(1.0, sum(t * k for t, k in zip(tiles, nk)) / 256.0)
+        cap = [max(1, k // 64) for _, k in shapes]
+        s = [max(1, min(c, int(k / per_wg))) for k, c in zip(nk, cap)]
+        while True:      # left-over workgroups go to the problem with the longest k-range per workgroup
+            i = max(range(len(s)), key=lambda j: nk[j] / s[j])
+            if s[i] >= cap[i] or sum(t * x for t, x in zip(tiles, s)) + tiles[i] > 256:
+                return s
+            s[i] += 1
+
+    def _grouped_long_k(self, descs, shapes, tags=None):
+        """Two long-K split-K GEMMs (the modalities' first projections, or their weight gradients) as ONE launch of eight-wave tiles with
+        balanced K splits + ONE reduce; False when the shapes do not qualify (the caller then launches them one by one)."""
+        if len(descs) != 2 or self.cfg.dim > 128 or any(k < 512 for _, k in shapes) or max(m for m, _ in shapes) < 1024:
+            return False
+        order = sorted(range(2), key=lambda j: -shapes[j][0])          # the problem that picks the eight-wave tile on its own goes first
+        splits = self._balanced_splits([shapes[j] for j in order])
+        group = (ctypes.POINTER(_lib.GemmDesc) * 2)()
+        for pos, j in enumerate(order):
+            descs[j].defer_reduce, descs[j].splits = 1, splits[pos]
+            group[pos] = ctypes.pointer(descs[j])
+        tag = tags[0] if tags else ""
+        self._probed(tag, call, "snag_gemm_f32_group", group, 2, self._st)
+        self._probed((tag + "_reduce") if tag else "", call, "snag_gemm_reduce_pair", ctypes.byref(descs[0]), ctypes.byref(descs[1]), self._st)
+        return True
 
     def _fold_bwd_descs(self, defer):
         """Folded second projections, backward: (d Wf_m = dKV_m^T mid_m, K split over the rows, slabs in work_l2), (d mid_m = (dKV_m Wf_m) *
@@ -573,8 +605,12 @@ class MKGCHotPath:
                 wb, wld, wkc = ptr(self.p[f"proj{i}.l1"]), fd, 1
                 l1.append(self._gemm_desc(Nl, D, fd, fa, fld, fkc, wb, wld, wkc, ptr(self.mid[i]), D, act=1,
                                           keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout), half=i % 2))
-        # the modalities' first projections: K-split GEMMs of different K -- two kernels, ONE reduce launch per pair
-        self._gemm_deferred_pairs(l1, ["proj_l1_fwd"] + [""] * (len(l1) - 1))
+        # the modalities' first projections: K-split GEMMs of different K.  Two modalities: ONE launch of eight-wave tiles with the K
+        # splits balanced across both (visual 3 + text 1 at the DB15K shape: 236 workgroups walking 86 / 48 k-tiles instead of a 236-
+        # and a 177-workgroup launch) + one reduce; otherwise two kernels and ONE reduce launch per pair
+        self.l1_grouped = self._grouped_long_k(l1, [(Nl, fd) for fd in cfg.feat_dims], ["proj_l1_fwd"])
+        if not self.l1_grouped:
+            self._gemm_deferred_pairs(l1, ["proj_l1_fwd"] + [""] * (len(l1) - 1))
         if self.fold:
             # folded second projections: Wf_m = Wkv l2_m (parameter-sized: one small launch), then the projected tokens' keys / values
             # straight from mid_m into the layer's q/k/v activation; the tokens themselves are never formed
@@ -810,18 +846,11 @@ class MKGCHotPath:
             call("snag_gemm_f32", ctypes.byref(dl1[0]), st)
             call("snag_gemm_f32", ctypes.byref(dl1[1]), st)
             call("snag_gemm_reduce_group", group, 4, st)
-        elif reducer is None and len(dl1) == 2 and all(fd >= 512 for fd in cfg.feat_dims):
-            # weight gradients of the two first projections in ONE launch of eight-wave tiles (snag_gemm_f32_group): alone, the visual one
-            # fills the chip exactly (16 row tiles x 16 K splits) and the text one then runs as a second, under-filled launch; together,
-            # with the K split chosen so that all row tiles x splits fit one round of workgroups, every CU walks the same k-range once.
-            tiles = sum((fd + 255) // 256 for fd in cfg.feat_dims)
-            splits = max(1, 256 // tiles)
-            group = (ctypes.POINTER(_lib.GemmDesc) * 2)()
-            for j, d in enumerate(dl1):
-                d.defer_reduce, d.splits = 1, splits
-                group[j] = ctypes.pointer(d)
-            call("snag_gemm_f32_group", group, 2, st)
-            call("snag_gemm_reduce_pair", ctypes.byref(dl1[0]), ctypes.byref(dl1[1]), st)
+        elif reducer is None and self._grouped_long_k(dl1, [(fd, Nl) for fd in cfg.feat_dims]):
+            # (both weight gradients in ONE launch of eight-wave tiles: alone, the visual one fills the chip exactly -- 16 row tiles x 16
+            # K splits -- and the text one then runs as a second, under-filled launch; together, 13 splits each, every CU walks the same
+            # k-range once: 78.5 + 30.4 -> 97.8 us)
+            pass
         elif reducer is None:       # weight gradients of the first projections: two kernels, ONE reduce launch per pair of modalities
             self._gemm_deferred_pairs(dl1)
         if self.fold:
