@@ -9,13 +9,14 @@ sys.path.insert(0, root)
 sys.path.insert(0, os.path.join(root, "tests"))
 import test_fusion_fuzz_gpu as ff  # noqa: E402
 import test_gemm_fuzz_gpu as gf  # noqa: E402
+import test_gemm_group_fuzz_gpu as gg  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 bad = 0
 for s in range(first, first + count):
     for name, fn in (("gemm small", lambda: gf.test_gemm_random_cases(s, False)), ("gemm big", lambda: gf.test_gemm_random_cases(s, True) if s % 6 == 0 else None),
-                     ("fusion", lambda: ff._run(s))):
+                     ("gemm group", lambda: gg._run(s)), ("fusion", lambda: ff._run(s))):
         try:
             fn()
         except Exception:
