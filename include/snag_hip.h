@@ -628,12 +628,14 @@ SNAG_API int snag_sample_negatives(uint64_t seed, const uint64_t* tick, const in
 /* ONE launch for the three independent, small launches that open an MKGC training step: snag_sample_negatives (mode 0: negative
  * tails; same Philox stream, same results), snag_entity_token_fwd (the structural token with the noise blend) and
  * snag_bernoulli_regions (the step's Bert dropout masks, one region per mask tensor, each keyed on the global row of its first
- * element).  Workgroup ranges of the one grid run the three bodies side by side; any part is skipped when its size is zero
- * (batch * n_neg, n_rows, n_mask_regions). */
+ * element), and up to four parameter-sized products (snag_small_matmul's problems: the folded-projection weights of the step, which
+ * depend on nothing but the parameters).  Workgroup ranges of the one grid run the bodies side by side; any part is skipped when its
+ * size is zero (batch * n_neg, n_rows, n_mask_regions, n_small_products). */
 SNAG_API int snag_step_prologue(uint64_t sample_seed, const uint64_t* tick, const int32_t* h, const int32_t* r, const int32_t* t, int64_t batch,
                                 int n_neg, int n_ent, int n_rel, const int64_t* known_sorted, int64_t n_known, int32_t* neg_t,
                                 const float* table, int64_t n_rows, int dim, const float* noise, const uint8_t* noise_mask, float half_mask_ratio,
-                                float* tok, int64_t tok_ld, const snag_mask_region* mask_regions, int n_mask_regions, void* stream);
+                                float* tok, int64_t tok_ld, const snag_mask_region* mask_regions, int n_mask_regions,
+                                const snag_small_mm* small_products, int n_small_products, void* stream);
 
 /* The same sampler with the two in-tree properties snag_sample_negatives gives up: candidates are drawn from the KG's OWN entity
  * list ent_list [n_list] (int32 ids; NULL = 0..n_ent-1; model/MSNEA_tools.py:64-65) and the n_neg negatives of one positive are

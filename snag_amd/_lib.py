@@ -122,7 +122,7 @@ SIGNATURES = {
     "snag_gat_layer_bwd": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P],
     "snag_build_filter_mask": [_P, _P, _P, _L, _I, _I, _P, _L, _P, _P],
     "snag_sample_negatives": [_U64, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P, _P, _P],
-    "snag_step_prologue": [_U64, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P, _P, _F, _P, _L, _P, _I, _P],
+    "snag_step_prologue": [_U64, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P, _P, _F, _P, _L, _P, _I, _P, _I, _P],
     "snag_bernoulli_regions": [_P, _I, _P, _P],
     "snag_noise_refresh": [_P, _L, _I, _P, _P, _P, _P, _U64, _L, _F, _P, _P, _L, _P],
     "snag_sample_negatives_distinct": [_U64, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P, _I, _P, _P, _P],

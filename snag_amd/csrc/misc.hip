@@ -497,14 +497,17 @@ struct PrologueArgs {
     const float* table; int64_t N; int D; const float* noise; const uint8_t* nmask; float a; float* tok; int64_t tok_ld;
     // Bernoulli mask regions (the rest): the Bert dropout masks, one region per mask tensor
     RegionArgs masks;
-    int nb_s, nb_e;
+    // parameter-sized products (the last blocks): the folded-projection weights Wf_m = Wkv l2_m of the step
+    SmallMMSet mm;
+    int nb_s, nb_e, nb_d;
 };
 
 __global__ __launch_bounds__(256) void step_prologue_kernel(PrologueArgs a) {
     const int b = blockIdx.x;
     if (b < a.nb_s) sample_negatives_body(b, a.s_seed, a.tick, a.h, a.r, a.t, a.B, a.K, a.n_ent, a.n_rel, a.mode, a.known, a.n_known, a.neg_h, a.neg_t);
     else if (b < a.nb_s + a.nb_e) entity_token_fwd_body(b - a.nb_s, a.nb_e, a.table, a.N, a.D, a.noise, a.nmask, a.a, a.tok, a.tok_ld);
-    else bernoulli_regions_body(b - a.nb_s - a.nb_e, a.masks, a.tick);
+    else if (b < a.nb_s + a.nb_e + a.nb_d) bernoulli_regions_body(b - a.nb_s - a.nb_e, a.masks, a.tick);
+    else small_matmul_body(a.mm, b - a.nb_s - a.nb_e - a.nb_d);
 }
 
 static int grid_for(int64_t n) { return (int)std::min<int64_t>(4096, (n + 255) / 256); }
@@ -859,7 +862,8 @@ extern "C" SNAG_API int snag_build_filter_mask(const int32_t* h, const int32_t* 
 extern "C" SNAG_API int snag_step_prologue(uint64_t sample_seed, const uint64_t* tick, const int32_t* h, const int32_t* r, const int32_t* t, int64_t batch,
                                            int n_neg, int n_ent, int n_rel, const int64_t* known_sorted, int64_t n_known, int32_t* neg_t,
                                            const float* table, int64_t n_rows, int dim, const float* noise, const uint8_t* noise_mask, float half_mask_ratio,
-                                           float* tok, int64_t tok_ld, const snag_mask_region* mask_regions, int n_mask_regions, void* stream) {
+                                           float* tok, int64_t tok_ld, const snag_mask_region* mask_regions, int n_mask_regions,
+                                           const snag_small_mm* small_products, int n_small_products, void* stream) {
     SNAG_REQUIRE(batch >= 0 && n_neg >= 0 && n_ent >= 1 && n_rel >= 1 && n_rows >= 0 && dim >= 1, SNAG_ERR_ARG, "step_prologue: bad sizes");
     SNAG_REQUIRE(batch * n_neg == 0 || (h && r && t && neg_t), SNAG_ERR_ARG, "step_prologue: null sampler pointer");
     SNAG_REQUIRE((known_sorted != nullptr) == (n_known > 0), SNAG_ERR_ARG, "step_prologue: known_sorted and n_known go together");
@@ -874,7 +878,10 @@ extern "C" SNAG_API int snag_step_prologue(uint64_t sample_seed, const uint64_t*
     if (nb_d < 0) return nb_d;
     a.nb_s = (int)((batch * n_neg + 255) / 256);
     a.nb_e = n_rows > 0 ? grid_for((n_rows * (int64_t)dim + 3) / 4) : 0;          // (the dwordx4 form covers four elements per thread; the scalar form strides)
-    const int total = a.nb_s + a.nb_e + nb_d;
+    a.nb_d = nb_d;
+    const int nb_m = fill_small_mm(small_products, n_small_products, a.mm, "step_prologue");
+    if (nb_m < 0) return nb_m;
+    const int total = a.nb_s + a.nb_e + nb_d + nb_m;
     if (total == 0) return SNAG_OK;
     hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("snag_step_prologue");

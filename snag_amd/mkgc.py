@@ -590,9 +590,21 @@ class MKGCHotPath:
             s_args = (int(s_seed), ptr(self.tick), ptr(h), ptr(r), ptr(t), B, cfg.neg_num, N, cfg.n_rel, ptr(known), 0 if known is None else known.numel(), ptr(neg_t))
         else:
             s_args = (0, ptr(self.tick), None, None, None, 0, 0, N, cfg.n_rel, None, 0, None)
+        # folded second projections: Wf_m = Wkv l2_m (parameter-sized, depends on nothing but the parameters) rides in the same launch
+        # (up to four modalities; more: the products get a launch of their own further down)
+        nmod = len(cfg.feat_dims)
+        wf_probs, n_wf = None, 0
+        if self.fold and nmod <= 4:
+            wkv = self.p["layer0.wqkv"].data_ptr() + 4 * D * D
+            wf_probs, n_wf = (_lib.SmallMM * nmod)(), nmod
+            for i, pm in enumerate(wf_probs):
+                pm.M, pm.N, pm.K, pm.accumulate = 2 * D, D, D, 0
+                pm.A, pm.sam, pm.sak = wkv, D, 1
+                pm.B, pm.sbk, pm.sbn = ptr(self.p[f"proj{i}.l2"]), D, 1
+                pm.C, pm.ldc = ptr(self.wf[i]), D
         call("snag_step_prologue", *s_args, self.p["ent"].data_ptr() + 4 * lo * D, Nl, D, (self.ent_noise.data_ptr() + 4 * lo * D) if noisy else None,
              (self.ent_noise_mask.data_ptr() + lo) if noisy else None, float(cfg.mask_ratio) * 0.5, x0p + 4 * self.g_slot * D, MD,
-             self._drop_regions if drop else None, len(self._drop_regions) if drop else 0, st)
+             self._drop_regions if drop else None, len(self._drop_regions) if drop else 0, wf_probs, n_wf, st)
         l1 = []
         for i, fd in enumerate(cfg.feat_dims):
             feat = self.noisy[i] if noisy else self.feats[i]                 # [Nl, fd] row-major: a K-contiguous operand
@@ -614,9 +626,8 @@ class MKGCHotPath:
         if self.fold:
             # folded second projections: Wf_m = Wkv l2_m (parameter-sized: one small launch), then the projected tokens' keys / values
             # straight from mid_m into the layer's q/k/v activation; the tokens themselves are never formed
-            nmod = len(cfg.feat_dims)
             wkv = self.p["layer0.wqkv"].data_ptr() + 4 * D * D
-            for i0 in range(0, nmod, 4):
+            for i0 in range(0, nmod if n_wf == 0 else 0, 4):
                 probs = (_lib.SmallMM * min(4, nmod - i0))()
                 for j, pm in enumerate(probs):
                     i = i0 + j
