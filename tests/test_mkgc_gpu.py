@@ -147,21 +147,24 @@ def test_readout_only_last_layer_equals_the_full_layer(ffn, layers, dropout):
         assert float((a[4][k] - b[4][k]).abs().max()) <= 2e-5 * scale, k
 
 
+@pytest.mark.parametrize("dims,D", [([96, 40], 128), ([64], 100), ([96, 40, 24], 64), ([600, 520], 128)])
 @pytest.mark.parametrize("dropout,proj_dropout", [(0.0, 0.0), (0.1, 0.2)])
-def test_folded_second_projection_equals_the_unfolded_step(dropout, proj_dropout):
+def test_folded_second_projection_equals_the_unfolded_step(dropout, proj_dropout, dims, D):
     """MKGCConfig.fold_proj (default in the read-out-only, one-layer, num_proj = 2 configuration): the projected tokens' keys / values
     come straight from the first projection's output, KV_m = mid_m (Wkv l2_m)^T + b, the second projection is never run, and the
     backward applies the chain rule onto Wkv and l2_m.  Same function, fp32 re-association only: read-out, scores, loss and EVERY
-    gradient equal the unfolded step's to rounding (same dropout masks, same noise)."""
+    gradient equal the unfolded step's to rounding (same dropout masks, same noise).  One modality (two tokens: the caller's products are
+    launched one by one), two (they ride in the layer's grouped launches), three (launched by the engine), and feature widths at which
+    both first projections share one launch of eight-wave tiles."""
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
-    N, R, D, B, K = 1500, 9, 128, 200, 16
+    N, R, B, K = 1500, 9, 200, 16
     g = torch.Generator().manual_seed(33)
-    feats = [torch.rand(N, 96, generator=g), torch.randn(N, 40, generator=g)]
+    feats = [torch.rand(N, fd, generator=g) if i % 2 == 0 else torch.randn(N, fd, generator=g) for i, fd in enumerate(dims)]
     idx = [torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(DEV) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (N, (B, K)))]
     ent0 = torch.randn(N, D, generator=g).to(DEV)
     out = {}
     for fold in (True, False):
-        cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[96, 40], num_proj=2, joint_way="Mformer_hd_graph", margin=6.0, neg_num=K, dropout=dropout,
+        cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=list(dims), num_proj=2, joint_way="Mformer_hd_graph", margin=6.0, neg_num=K, dropout=dropout,
                          proj_dropout=proj_dropout, add_noise=1, seed=7, fold_proj=fold)
         eng = MKGCHotPath(cfg, feats, device=DEV)
         assert eng.fold == fold
