@@ -100,3 +100,23 @@ def test_lr_schedules_match_transformers():
             assert abs(sch.get_last_lr()[0] - mine(step, 50, 7, 5e-4)) < 1e-12, (make.__name__, step)
             opt.step()
             sch.step()
+
+
+def test_balanced_splits_of_grouped_long_k_launches():
+    """MKGCHotPath._balanced_splits (host arithmetic only): the K splits the engine requests when two long-K products share one launch of
+    256-row tiles -- all row tiles x splits fit one round of 256 workgroups, no split is finer than 64 k, and the workgroups' k-ranges are as
+    even as the row-tile granularity allows."""
+    from snag_amd.mkgc import MKGCHotPath
+    bs = MKGCHotPath._balanced_splits
+    assert bs([(15000, 4096), (15000, 768)]) == [3, 1]               # both first projections at the DB15K shape: 177 + 59 workgroups
+    assert bs([(4096, 15000), (768, 15000)]) == [13, 13]             # their weight gradients: 208 + 39
+    for shapes in ([(15000, 4096), (15000, 768)], [(4096, 15000), (768, 15000)], [(1875, 4096), (1875, 768)], [(4096, 1875), (768, 1875)],
+                   [(3750, 2048), (3750, 2048)], [(1024, 512), (300, 640)], [(100000, 1024), (2048, 600)]):
+        s = bs(shapes)
+        tiles = [(m + 255) // 256 for m, _ in shapes]
+        assert all(1 <= x <= max(1, k // 64) for x, (_, k) in zip(s, shapes)), (shapes, s)
+        total = sum(t * x for t, x in zip(tiles, s))
+        assert total <= 256 or all(x == 1 for x in s), (shapes, s, total)          # (more row tiles than workgroups: nothing to split)
+        if total <= 256:     # no problem could take one more split without leaving the round
+            i = max(range(len(s)), key=lambda j: ((shapes[j][1] + 15) // 16) / s[j])
+            assert s[i] >= max(1, shapes[i][1] // 64) or total + tiles[i] > 256, (shapes, s)
