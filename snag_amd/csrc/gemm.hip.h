@@ -1257,7 +1257,6 @@ __device__ __forceinline__ void gemm_tile_at(const GemmOperands& p, const Epi& e
 // epi(row, col, float4) or, for split-K, a raw store into this split's slab (split index z).
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi, bool A_TILED = false, bool B_IMG = false>
 __device__ __forceinline__ void gemm_tile_body(const GemmOperands& p, const Epi& epi, float* __restrict__ slab, int z, float* smem) {
-    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC, A_TILED, B_IMG>;
     int bx = blockIdx.x, by = blockIdx.y;
     if (p.xcd) {
         const int id = xcd_swizzle(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
