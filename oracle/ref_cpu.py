@@ -436,26 +436,33 @@ def mkgc_forward(feats: Sequence[Tensor], proj: Sequence[Dict[str, Tensor]], ent
                  num_heads: int, margin: float, joint_way: str = "Mformer_hd_graph",
                  use_intermediate: bool = False, num_layers: int = 1,
                  ent_noise: Optional[Tensor] = None, ent_noise_mask: Optional[Tensor] = None,
-                 mask_ratio: float = 0.0, loss_kind: str = "hinge", adv_temp: float = 1.0):
+                 mask_ratio: float = 0.0, loss_kind: str = "hinge", adv_temp: float = 1.0,
+                 drop_masks: Optional[List[Dict[str, Tensor]]] = None, drop_p: float = 0.1,
+                 proj_keep: Optional[Sequence[Optional[Tensor]]] = None, proj_p: float = 0.0):
     """One MKGC hot-path step: projections -> tokens -> Mformer -> read-out -> margin score.
 
     Token order is [modality_0, ..., modality_{P-1}, structural]; the structural token is the
     (optionally noise-blended) entity-table row (model/SNAG_tools.py:122-152 with the GAT removed,
     which is how SURVEY par. 8 a5 scopes the MKGC structural token).  ``proj[i]`` holds either
     {"weight","bias"} (num_proj=1) or {"l1","l2"} (+ optional "weight","bias" applied first).
+
+    Training mode with explicit masks: ``drop_masks`` / ``drop_p`` are ``fusion_forward``'s (the Bert dropouts,
+    model/SNAG_tools.py:201,220,264); ``proj_keep[i]`` / ``proj_p`` the 0/1 keep mask [N, D] and rate of modality i's
+    ProjectionHead dropout (model/layers.py:142-147).
     """
     toks = []
-    for f, p in zip(feats, proj):
+    for i, (f, p) in enumerate(zip(feats, proj)):
         if "weight" in p:
             f = linear(f, p["weight"], p.get("bias"))
         if "l1" in p:
-            f = projection_head(f, p["l1"], p["l2"])
+            f = projection_head(f, p["l1"], p["l2"], keep_mask=proj_keep[i] if proj_keep is not None else None, p=proj_p)
         toks.append(f)
     e = ent_table
     if ent_noise is not None:
         e = entity_noise_blend(e, ent_noise, ent_noise_mask, mask_ratio)
     toks.append(e)
-    joint, joint_fz, hidden, w = fusion_forward(toks, fusion_params, num_heads, num_layers, use_intermediate)
+    joint, joint_fz, hidden, w = fusion_forward(toks, fusion_params, num_heads, num_layers, use_intermediate,
+                                                drop_masks=drop_masks, drop_p=drop_p)
     ent = readout(joint_way, joint, joint_fz, hidden, graph_index=len(toks) - 1)
     if loss_kind == "self_adversarial":
         loss, pos, neg = selfadv_loss(ent, rel_table, h, rel, t, neg_t, margin, adv_temp)

@@ -71,6 +71,23 @@ def test_bench_two_rank_dry_run(extra, scaling, per_gpu):
     assert abs(ph["comm_exposed_us"] + ph["compute_us"] - sum(ph[k] for k in ph["order"])) < 1e-6 * (ph["compute_us"] + ph["comm_exposed_us"]) + 1e-3
 
 
+def test_bench_gpus_n_without_the_launcher_starts_it_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver types for --gpus 1): bench.py starts
+    torch.distributed.run as a child process before touching the GPU and forwards the one JSON line and the return code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "256", "--cpu-seconds", "0",
+                        "--no-extras", "--no-kernel-timers"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    o = _json_line(p.stdout)
+    assert o["n_gpus"] == 2 and o["steps"] == 3 and o["config"]["global_batch"] == 512
+    assert o["config"]["dist"] == {"backend": "gloo", "world_size": 2} and o["phases_us"]["compute_us"] > 0
+    # a launcher that started the wrong number of ranks is refused, not silently benchmarked
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert p.returncode != 0 and "--nproc-per-node" in p.stderr
+
+
 def test_bench_stress_config_single_and_two_rank_dry_run():
     """bench.py --config stress (BASELINE configs[4]: 1M x 256 bf16 table, 128 negatives): one rank, and two ranks sharing the device over gloo
     (row-owned optimiser state, reduce-scatter / all-gather phases reported separately)."""

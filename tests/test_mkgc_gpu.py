@@ -115,6 +115,88 @@ def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape, loss_k
         assert_close(grads[k], gref, atol=2e-4 * scale, rtol=1e-4, what=f"grad {k}")
 
 
+def engine_masks(eng):
+    """The keep masks the engine drew for its last step, in the oracle's form: (fusion_forward's drop_masks, mkgc_forward's proj_keep).
+    The masks cover every token of every layer (the read-out-only layer consumes the read-out token's rows of them)."""
+    cfg = eng.cfg
+    N, M, D = eng.shard.n_loc, cfg.n_tokens, cfg.dim
+    masks = []
+    for l in range(cfg.num_layers):
+        m = {"probs": eng.keep_probs[l].cpu().float(), "attn_out": eng.keep_attn[l].cpu().float().view(N, M, D)}
+        if eng.keep_ffn:
+            m["ffn_out"] = eng.keep_ffn[l].cpu().float().view(N, M, D)
+        masks.append(m)
+    proj_keep = [eng.keep_proj[i][:N].cpu().float() for i in range(len(cfg.feat_dims))] if eng.keep_proj is not None else None
+    return masks, proj_keep
+
+
+@pytest.mark.parametrize("num_proj,joint_way,ffn,proj_dropout,fold,shape", [
+    # the engine's default (read-out-only last layer + folded second projection) -- the configuration bench.py times
+    (2, "Mformer_hd_graph", 0, 0.2, True, (700, 23, 128, 96, 32, 200, 72)),
+    (2, "Mformer_hd_graph", 0, 0.0, True, (700, 23, 128, 96, 32, 200, 72)),
+    (2, "Mformer_hd_graph", 0, 0.2, False, (700, 23, 128, 96, 32, 200, 72)),                 # read-out-only, second projection as its own GEMM
+    (2, "Mformer_hd_graph_full", 0, 0.2, False, (700, 23, 128, 96, 32, 200, 72)),            # the full layer
+    (2, "Mformer_hd_graph_full", 1, 0.2, False, (700, 23, 128, 96, 32, 200, 72)),
+    (2, "Mformer_hd_graph", 1, 0.2, True, (700, 23, 128, 96, 32, 200, 72)),                  # FFN behind the read-out token
+    (1, "Mformer_hd_mean", 0, 0.0, False, (700, 23, 128, 96, 32, 200, 72)),
+    (2, "Mformer_hd_mean", 1, 0.2, False, (700, 23, 128, 96, 32, 200, 72)),
+    (2, "Mformer_weight", 0, 0.2, False, (700, 23, 128, 96, 32, 200, 72)),                   # joint: weights from the DROPPED attention map (:41-45)
+    (1, "learnable_weight", 0, 0.0, False, (400, 7, 64, 48, 8, 40, 24)),
+    # ragged sizes
+    (2, "Mformer_hd_graph", 0, 0.2, True, (701, 5, 100, 33, 5, 37, 10)),
+    (1, "Mformer_hd_mean", 1, 0.0, False, (333, 3, 36, 17, 3, 13, 9)),
+    (2, "Mformer_hd_graph", 0, 0.2, True, (5, 1, 128, 1, 1, 9, 4)),
+    # two layers (the first one full, the last one read-out-only)
+    (2, "Mformer_hd_graph", 1, 0.2, False, (400, 7, 64, 48, 8, 40, 24, 2)),
+    (1, "Mformer_hd_mean", 0, 0.0, False, (400, 7, 64, 48, 8, 40, 24, 2)),
+    # BASELINE configs[1] at its full size, exactly as bench.py runs it; configs[2] likewise
+    (2, "Mformer_hd_graph", 0, 0.0, True, (15000, 558, 128, 1024, 32, 4096, 768)),
+    (2, "Mformer_hd_graph", 0, 0.2, True, (15000, 558, 128, 1024, 32, 4096, 768)),
+    (1, "Mformer_hd_mean", 0, 0.0, False, (15000, 338, 128, 1024, 32, 4096, 768)),
+])
+def test_mkgc_step_with_dropout_vs_oracle(num_proj, joint_way, ffn, proj_dropout, fold, shape):
+    """Training mode as the reference runs it (Bert dropout 0.1 on the attention map and the output projection, SNAG_tools.py:201,220 (,264);
+    ProjectionHead dropout, model/layers.py:142-147; noise on): the engine's step -- read-out-only + folded by default -- against the
+    oracle fed the very keep masks the engine drew (Philox regions) and the engine's noisy tables."""
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    N, R, D, B, K, F0, F1 = shape[:7]
+    full_layer, joint_way = joint_way.endswith("_full"), joint_way.replace("_full", "")
+    cfg = MKGCConfig(readout_only=not full_layer, fold_proj=fold, n_ent=N, n_rel=R, dim=D, feat_dims=[F0, F1], num_proj=num_proj, joint_way=joint_way,
+                     num_layers=shape[7] if len(shape) > 7 else 1, use_intermediate=ffn, intermediate_size=96, margin=6.0, neg_num=K,
+                     dropout=0.1, proj_dropout=proj_dropout if num_proj == 2 else 0.0, add_noise=1, seed=11)
+    g = torch.Generator().manual_seed(98)
+    feats = [torch.rand(N, F0, generator=g), torch.randn(N, F1, generator=g)]
+    eng = MKGCHotPath(cfg, feats, device=DEV)
+    assert eng.fold == (fold and num_proj == 2 and eng.ro and cfg.num_layers == 1)
+    eng.p["ent"].copy_(torch.randn(N, D, generator=g).to(DEV))
+    eng.p["weight_raw"].copy_(torch.randn(6, generator=g).to(DEV))
+    eng.update_noise()
+    h = torch.randint(0, N, (B,), generator=g, dtype=torch.int32)
+    r = torch.randint(0, R, (B,), generator=g, dtype=torch.int32)
+    t = torch.randint(0, N, (B,), generator=g, dtype=torch.int32)
+    neg = torch.randint(0, N, (B, K), generator=g, dtype=torch.int32)
+    loss, pos, ng = eng.forward(h.to(DEV), r.to(DEV), t.to(DEV), neg.to(DEV), want_scores=True, with_backward=True)
+    eng.backward()
+    torch.cuda.synchronize()
+    masks, proj_keep = engine_masks(eng)
+    if N >= 100:
+        assert 0.85 < float(masks[0]["attn_out"].mean()) < 0.95        # the masks are really drawn (p = 0.1)
+    p, proj, fp = oracle_params(eng)
+    oloss, opos, oneg, _ = O.mkgc_forward(
+        [f.cpu() for f in eng.noisy], proj, p["ent"], fp, p["rel"], h, r, t, neg, num_heads=cfg.num_heads, margin=cfg.margin, joint_way=joint_way,
+        use_intermediate=bool(ffn), num_layers=cfg.num_layers, ent_noise=eng.ent_noise.cpu(), ent_noise_mask=eng.ent_noise_mask.cpu().bool(),
+        mask_ratio=cfg.mask_ratio, drop_masks=masks, drop_p=cfg.dropout, proj_keep=proj_keep, proj_p=cfg.proj_dropout)
+    oloss.backward()
+    assert_close(pos, opos, atol=1e-4, what="pos")
+    assert_close(ng, oneg, atol=1e-4, what="neg")
+    assert_close(loss, oloss, atol=1e-4, rtol=2e-6, what="loss")
+    grads = eng.named_gradients()
+    for k, ref in p.items():
+        gref = ref.grad if ref.grad is not None else torch.zeros_like(ref)
+        scale = max(1.0, float(gref.abs().max()))
+        assert_close(grads[k], gref, atol=2e-4 * scale, rtol=1e-4, what=f"grad {k}")
+
+
 @pytest.mark.parametrize("ffn,layers,dropout", [(0, 1, 0.1), (1, 1, 0.1), (0, 2, 0.0), (1, 2, 0.1)])
 def test_readout_only_last_layer_equals_the_full_layer(ffn, layers, dropout):
     """joint_way Mformer_hd_graph consumes hidden[:, g, :] alone.  The engine's default computes the LAST layer's query, attention
@@ -540,15 +622,19 @@ def test_step_prologue_draws_the_sampler_stream():
     assert res[0][1] == res[1][1] and torch.equal(res[0][2], res[1][2])
 
 
-@pytest.mark.parametrize("num_proj,joint_way,ffn", [(2, "Mformer_hd_graph", 0), (1, "Mformer_hd_mean", 1)])
-def test_training_trajectory_equals_oracle_autograd_plus_torch_adamw(num_proj, joint_way, ffn):
+@pytest.mark.parametrize("num_proj,joint_way,ffn,dropout", [(2, "Mformer_hd_graph", 0, 0.0), (1, "Mformer_hd_mean", 1, 0.0),
+                                                            (2, "Mformer_hd_graph", 0, 0.1), (1, "Mformer_hd_mean", 1, 0.1)])
+def test_training_trajectory_equals_oracle_autograd_plus_torch_adamw(num_proj, joint_way, ffn, dropout):
     """Whole steps, composed: four train_step()s (forward, hinge scorer, backward, clip_grad_norm_, AdamW with the reference's parameter
     groups) against the oracle's forward under torch autograd + torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW on the same
-    parameters, triples and negative tails (dropout off, no noise): the loss of every step and every parameter after the last one."""
+    parameters, triples and negative tails: the loss of every step and every parameter after the last one.  With dropout on (Bert 0.1,
+    ProjectionHead 0.2) the oracle of step s is fed the keep masks the engine drew IN step s (they are redrawn per step from the device
+    tick)."""
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
     N, R, D, B, K = 300, 7, 64, 48, 8
     cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[40, 24], num_proj=num_proj, joint_way=joint_way, use_intermediate=ffn, intermediate_size=96,
-                     margin=6.0, neg_num=K, dropout=0.0, proj_dropout=0.0, add_noise=0, seed=5, lr=2e-3, weight_decay=0.05, clip=1.0)
+                     margin=6.0, neg_num=K, dropout=dropout, proj_dropout=0.2 if (dropout and num_proj == 2) else 0.0, add_noise=0, seed=5, lr=2e-3,
+                     weight_decay=0.05, clip=1.0)
     g = torch.Generator().manual_seed(21)
     feats = [torch.rand(N, 40, generator=g), torch.randn(N, 24, generator=g)]
     eng = MKGCHotPath(cfg, feats, device=DEV)
@@ -567,8 +653,10 @@ def test_training_trajectory_equals_oracle_autograd_plus_torch_adamw(num_proj, j
         # the oracle reads the CURRENT reference parameters: rebuild its views from the leaves
         _, proj, fp = _views(cfg, p)
         opt.zero_grad()
+        masks, proj_keep = engine_masks(eng) if dropout else (None, None)           # (synchronises: this step's masks)
         oloss, _, _, _ = O.mkgc_forward([f for f in feats], proj, p["ent"], fp, p["rel"], h, r, t, neg, num_heads=cfg.num_heads, margin=cfg.margin,
-                                        joint_way=joint_way, use_intermediate=bool(ffn), num_layers=cfg.num_layers, loss_kind="hinge")
+                                        joint_way=joint_way, use_intermediate=bool(ffn), num_layers=cfg.num_layers, loss_kind="hinge",
+                                        drop_masks=masks, drop_p=cfg.dropout, proj_keep=proj_keep, proj_p=cfg.proj_dropout)
         oloss.backward()
         torch.nn.utils.clip_grad_norm_([p[k] for k in names], cfg.clip)
         opt.step()
