@@ -313,6 +313,56 @@ def score_hbm_resident(device):
     return out
 
 
+def roofline_sim(device, reps=5):
+    """BASELINE configs[3] (DBP15K ja_en MMEA eval: 10,500 aligned test pairs x 1,200-wide joint embeddings, CSLS k = 3; SURVEY par. 8d):
+    the similarity GEMM with its distance epilogue (`snag_pairwise_dist`, src/utils.py:202-218) against the MFMA roofline of the six
+    split-bf16 products, and the whole `rank_metrics` (GEMM + CSLS neighbourhoods + ranks + summaries, main.py:376-436), HIP events on
+    the launch stream, mean of ``reps`` back-to-back calls after one warm-up.  Returns (record, left, right) -- the embeddings feed the
+    oracle check of the cpu_baseline leg."""
+    from snag_amd import evalsim
+    n, d, k = 10500, 1200, 3
+    g = torch.Generator().manual_seed(4321)
+    left = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1)
+    # planted signal (SURVEY par. 8d): right = normalise(left + noise); noise of norm ~8 puts the true pair ~4 sigma above a random one, so
+    # Hits@1 is neither 0 nor 1
+    right = torch.nn.functional.normalize(left + 8.0 * torch.randn(n, d, generator=g) / d ** 0.5, dim=1)
+    L, Rt = left.to(device), right.to(device)
+
+    def timed(fn):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps, out
+
+    gemm_us, _ = timed(lambda: evalsim.pairwise_distances(L, Rt, _padded=True))
+    eval_us, res = timed(lambda: evalsim.rank_metrics(L, Rt, csls_k=k, top_k=(1, 10, 50)))
+    flops = 2.0 * n * n * d
+    peak = BF16_MFMA_PEAK_TFLOPS / 6.0
+    rec = {"workload": f"configs[3]: {n} x {n} x {d} similarity GEMM + distance epilogue, CSLS k={k}, ranks both directions", "bound": "mfma",
+           "gemm_avg_us": gemm_us, "achieved": flops / gemm_us / 1e6, "peak": peak, "unit": "TFLOP/s", "frac": flops / gemm_us / 1e6 / peak,
+           "peak_is": "bf16 dense MFMA peak / 6 (f32 products as six split-bf16 MFMA products)", "flops_per_launch": flops,
+           "matrix_bytes": n * n * 4, "rank_metrics_ms": eval_us / 1e3, "hits_l2r": res["hits_l2r"], "hits_r2l": res["hits_r2l"],
+           "timed": f"{reps} back-to-back calls, HIP events, outside the timed region"}
+    return rec, left, right
+
+
+def cpu_baseline_sim_check(left, right, device, rows=512, k=3):
+    """Part of the cpu_baseline leg: Hits@1/10 and the rank arrays of a ``rows``-pair sub-block of the configs[3] workload, GPU path vs the
+    CPU oracle's restated Runner._test (oracle.rank_metrics) -- north_star: "Hits@1/10 equal to the CPU reference"."""
+    from oracle import ref_cpu as O
+    from snag_amd import evalsim
+    l, r = left[:rows].contiguous(), right[:rows].contiguous()
+    got = evalsim.rank_metrics(l.to(device), r.to(device), csls_k=k, top_k=(1, 10))
+    ref = O.rank_metrics(l, r, csls_k=k, top_k=(1, 10))
+    same = bool((got["rank_l2r"].cpu() == ref["rank_l2r"]).all()) and bool((got["rank_r2l"].cpu() == ref["rank_r2l"]).all())
+    return {"rows": rows, "hits_l2r_gpu": got["hits_l2r"], "hits_l2r_oracle": ref["hits_l2r"], "hits_r2l_gpu": got["hits_r2l"], "hits_r2l_oracle": ref["hits_r2l"],
+            "hits_equal": got["hits_l2r"] == ref["hits_l2r"] and got["hits_r2l"] == ref["hits_r2l"], "rank_arrays_equal": same}
+
+
 def cpu_baseline(cfg, feats, batch, budget_s, seed):
     """The CPU oracle (plain PyTorch restatement of the reference path) on this host's cores: same step definition."""
     from oracle import ref_cpu as O
@@ -707,6 +757,9 @@ def main():
 
     copy_gbs = device_copy_ceiling(device)
     extras = untimed_extras(eng, batches, args, device) if not args.no_extras else {}
+    sim_inputs = None
+    if world == 1 and not args.no_extras and args.config == "db15k":
+        extras["roofline_sim"], *sim_inputs = roofline_sim(device)
     if cfg.add_noise:
         extras["noise_refresh_us"] = noise_refresh_us(eng)
     step_no = 0
@@ -783,6 +836,8 @@ def main():
                 out["roofline_score"]["hbm_resident"] = score_hbm_resident(device)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, [f.cpu() for f in feats], args.batch, args.cpu_seconds, cfg.seed)
+            if sim_inputs is not None:
+                out["roofline_sim"]["oracle_check"] = cpu_baseline_sim_check(*sim_inputs, device)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

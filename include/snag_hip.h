@@ -248,18 +248,10 @@ typedef struct snag_gemm_desc {
      * ? mirror_scale : 1).  The entity table's gradient (the structural token's rows of d_x0 through the noise blend) leaves the
      * Mformer backward's last GEMM this way instead of through a copy launch. */
     float* mirror; int64_t ldmirror; const uint8_t* mirror_rowmask; float mirror_scale;
-    /* 1 / 2: A points at the TILED copy (layout 1 / 2) of the [M, K] operand made by snag_tile_a_f32 (lda and a_kcontig are ignored).  Long-K products
-     * with N <= 128 only (the first projections X W^T and their weight gradients X^T dY: the eight-wave row-private tile): a lane's
-     * eight values of a k-tile are two 16-byte loads of one contiguous KiB per wave-instruction instead of eight 4-byte loads. */
-    int32_t a_tiled;
     /* 1: C is stored transposed -- value (m, n) goes to C[n * ldc + m], ldc >= M (accumulate, bias, act, masks, add1 / add2 still index
      * their [M, N] operands by (m, n)); no pre_act, no mirror.  The weight gradient dW^T = X^T dY lands in the nn.Linear layout
      * [out, in] this way, and an activation gradient in the K-contiguous layout its consumer streams fastest. */
     int32_t c_transposed;
-    /* optional: B as the pre-split bf16 image made by snag_presplit_b from the SAME [N, K] operand (B / ldb / b_kcontig must still
-     * describe it: shapes that do not run the eight-wave row-private tile ignore the image).  The projection weights are split once
-     * per step instead of once per workgroup and k-tile, and reach the LDS by DMA: no registers, no VALU.  Bit-identical results. */
-    const void* b_image;
     /* 0: the library chooses the K split.  > 0: this many K splits are wanted (capped by K / 64 and by what the workspace holds; the
      * reduce entries read the same field, so a deferred reduce agrees with its launch).  A caller that puts several long-K problems
      * into one grouped launch balances the workgroups' k-ranges across them with it. */
@@ -277,21 +269,6 @@ SNAG_API int snag_gemm_f32_group(const snag_gemm_desc* const* descs, int n, void
 
 SNAG_API int snag_gemm_f32(const snag_gemm_desc* desc, void* stream);
 SNAG_API int64_t snag_gemm_workspace_floats(int M, int N, int K);
-/* The tiled copy of an operand A [M, K] for snag_gemm_desc.a_tiled (src: K-contiguous [M, ld >= K] or row-contiguous [K, ld >= M]):
- * blocks of 32 rows x 16 k, block (mb, kt) at ((mb * ceil(K / 16)) + kt) * 512 floats, zero-padded to whole blocks; inside a block
- * layout 1 (lane order): [c (2)][lh (2)][li (32)][j (4)] = A(32 mb + li, 16 kt + 8 c + 4 lh + j) -- each of the wave's two loads is one
- * contiguous KiB; layout 2 (row order): [li (32)][16 k] -- a row's 16 values of the k-tile are 64 contiguous bytes (a table that is
- * rewritten row by row keeps whole 64-byte pieces), each load covers 32-byte halves of them.  a_tiled carries the layout number.  snag_tile_a_floats(M, K) floats, 16-byte aligned.  Made once
- * per epoch for the raw feature tables (the first projection's operand, model/SNAG_tools.py:134-150, is constant between noise
- * refreshes, model/SNAG.py:86-92). */
-/* The pre-split image of an operand B [N, K] (K-contiguous [N, ldb >= K] or row-contiguous [K, ldb >= N]) for snag_gemm_desc.b_image:
- * per (column tile of 128, k-tile of 16) one 16 KiB block [plane h / m / l][k-half][row (128)][8 bf16] (+ 4 KiB padding), the three
- * planes being the exact split b = h + m + l of snag_gemm_f32; zero-padded to whole tiles.  snag_presplit_b_bytes(N, K) bytes, 16-byte
- * aligned. */
-SNAG_API int64_t snag_presplit_b_bytes(int64_t N, int64_t K);
-SNAG_API int snag_presplit_b(const float* B, int64_t ldb, int b_kcontig, int64_t N, int64_t K, void* image, void* stream);
-SNAG_API int64_t snag_tile_a_floats(int64_t M, int64_t K);
-SNAG_API int snag_tile_a_f32(const float* src, int64_t ld, int64_t M, int64_t K, int kcontig, int layout, float* dst, void* stream);
 /* Two independent problems; when they have the same shape, layouts and split decision they run as ONE launch (the step's many
  * [rows x D x D]-sized GEMMs are grids of fewer workgroups than the chip has CUs: a pair fills it once instead of twice), otherwise
  * one after the other.  Results are those of two snag_gemm_f32 calls, bit for bit.  Split-K workspaces must be distinct. */

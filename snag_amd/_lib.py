@@ -32,7 +32,7 @@ class GemmDesc(_c.Structure):
                 ("accumulate", _c.c_int32), ("workspace", _P), ("workspace_floats", _L),
                 ("aux", _P), ("ldaux", _L), ("ldmask", _L), ("defer_reduce", _c.c_int32),
                 ("mirror", _P), ("ldmirror", _L), ("mirror_rowmask", _P), ("mirror_scale", _F),
-                ("a_tiled", _c.c_int32), ("c_transposed", _c.c_int32), ("b_image", _P), ("splits", _c.c_int32)]
+                ("c_transposed", _c.c_int32), ("splits", _c.c_int32)]
 
 
 class MaskRegion(_c.Structure):
@@ -94,8 +94,6 @@ SIGNATURES = {
     "snag_rank_full_table": [_P, _L, _L, _P, _I, _P, _P, _P],
     "snag_gemm_f32": [_c.POINTER(GemmDesc), _P],
     "snag_gemm_reduce_pair": [_P, _P, _P],
-    "snag_tile_a_f32": [_P, _L, _L, _L, _I, _I, _P, _P],
-    "snag_presplit_b": [_P, _L, _I, _L, _L, _P, _P],
     "snag_gemm_reduce_group": [_P, _c.c_int, _P],
     "snag_gemm_f32_group": [_P, _c.c_int, _P],
     "snag_gemm_f32_pair": [_c.POINTER(GemmDesc), _c.POINTER(GemmDesc), _P],
@@ -152,7 +150,7 @@ SIGNATURES = {
     "snag_entity_token_fwd": [_P, _L, _I, _P, _P, _F, _P, _L, _P],
 }
 _SPECIAL = {"snag_version": ([], _I), "snag_last_error": ([], _c.c_char_p),
-            "snag_gemm_workspace_floats": ([_I, _I, _I], _L), "snag_tile_a_floats": ([_L, _L], _L), "snag_presplit_b_bytes": ([_L, _L], _L),
+            "snag_gemm_workspace_floats": ([_I, _I, _I], _L),
             "snag_fusion_save_floats": ([_I] * 7, _L), "snag_fusion_work_floats": ([_I] * 7, _L),
             "snag_colstats_work_floats": ([_I], _L), "snag_eval_work_floats": ([_I, _I], _L),
             "snag_gat_work_floats": ([_L, _I, _I], _L), "snag_score_seg_work_bytes": ([_L, _L, _L, _I, _I], _L),

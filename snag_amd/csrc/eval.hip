@@ -525,22 +525,16 @@ static int matrix_vec_ok(const float* mat, int64_t ld) { return (ld % 4 == 0) &&
 
 static void launch_dist_gemm(const GemmOperands& p, const DistEpilogue& e, hipStream_t st) {
     const int64_t big_tiles = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128);
-    // (VEC = false: the loaders pick 16-byte or 4-byte loads at run time from p.a_vec / p.b_vec; the counted-wait form is an A/B below)
-    const bool vec = p.a_vec && p.b_vec && env_int("SNAG_DIST_VEC") == 1;
     const dim3 gbig(ceil_div(p.N, 128), ceil_div(p.M, 128), 1), gsmall(ceil_div(p.N, 128), ceil_div(p.M, 64), 1);
     // Large problems: the eight-wave row-private 256 x 128 tile (A straight to registers, B through the LDS, two wave groups half an
     // iteration apart).  The kernel is bound by what the CUs pull in per tile ((BM + BN) K floats): 1.77 -> 1.52 ms against the
-    // 2 x 2-wave 128 x 128 tile at 10,500 x 10,500 x 1,200.  SNAG_DIST_TILE (tuning / A-B): 1 = that 128 x 128 tile, 2 = row-private 128 x 128
-    static const int tile_mode = env_int("SNAG_DIST_TILE");
-    if (tile_mode == 2 && big_tiles >= 512) {
-        hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 32, 128, true, true, false, DistEpilogue>), gbig, dim3(256), 0, st, p, e, (float*)nullptr);
-    } else if (tile_mode == 0 && big_tiles >= 1024) {
-        static const int group_env = env_int("SNAG_DIST_GROUP");       // tuning: row tiles per group (default 4; -1 = row-major order)
+    // 2 x 2-wave 128 x 128 tile at 10,500 x 10,500 x 1,200 (row-private 128 x 128: 1.72).  VEC = false: the loaders pick 16-byte or
+    // 4-byte loads at run time from p.a_vec / p.b_vec (the counted-wait form measured 1.65 vs 1.63 ms here).  Tiles are visited in groups
+    // of 4 row tiles per XCD (1.507 -> 1.473 ms against row-major order).
+    if (big_tiles >= 1024) {
         GemmOperands pg = p;
-        pg.xcd = 1 | ((group_env < 0 ? 0 : group_env == 0 ? 4 : group_env) << 4);
-        if (vec) hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, true, true, true, DistEpilogue>), dim3(ceil_div(p.N, 128), ceil_div(p.M, 256), 1), dim3(512), 0, st, pg, e,
-                           (float*)nullptr);
-        else hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, true, true, false, DistEpilogue>), dim3(ceil_div(p.N, 128), ceil_div(p.M, 256), 1), dim3(512), 0, st, pg, e,
+        pg.xcd = 1 | (4 << 4);
+        hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, true, true, false, DistEpilogue>), dim3(ceil_div(p.N, 128), ceil_div(p.M, 256), 1), dim3(512), 0, st, pg, e,
                            (float*)nullptr);
     } else if (big_tiles >= 512) {
         hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 64, 64, true, true, false, DistEpilogue>), gbig, dim3(256), 0, st, p, e, (float*)nullptr);

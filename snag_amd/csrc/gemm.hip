@@ -283,15 +283,15 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(GemmOperands p, float al
 // VEC: every fetch is an unpredicated dwordx4 (all shapes of the hot path); otherwise the checked loader
 // Measured on one device (tools/tune_gemm.py, A/B builds): the unpredicated loader wins 15-25 % whenever an operand is
 // row-contiguous, but loses 5-20 % when both are K-contiguous, so those keep the checked loader.
-static bool use_vec(const GemmOperands& p, bool a_kc, bool b_kc) {
-    static const int vec_mode = env_int("SNAG_GEMM_VEC");      // tuning: 1 = never, 2 = whenever legal
-    // split-bf16 builds (every tile runs the pre-split loops, which look at VEC for K-contiguous operands only): 16-byte loads as a
-    // compile-time choice whenever they are legal -- the loop's waits are then counted (vmcnt(9) in the ping-pong loop) instead of one
-    // vmcnt(0) every fourth iteration; same box, in the step: 0.6206 / 0.6251 / 0.6268 vs 0.6280 / 0.6303 / 0.6297 ms.  SNAG_GEMM_VEC=1: the
-    // loaders decide at run time (A/B)
-    if (kBf16x != 0) return vec_mode != 1 && (!a_kc || p.a_vec) && (!b_kc || p.b_vec);
+// presplit: the tile runs the pre-split loops (every tile a split-bf16 build instantiates), which look at VEC for K-contiguous operands
+// only; the f32-MFMA loops (run_loop: -DSNAG_GEMM_BF16X=0 builds, the 128 x 160 tile) issue unpredicated float4 loads under VEC and
+// need the full shape test.
+static bool use_vec(const GemmOperands& p, bool a_kc, bool b_kc, bool presplit = kBf16x != 0) {
+    // 16-byte loads as a compile-time choice whenever they are legal -- the loop's waits are then counted (vmcnt(9) in the ping-pong
+    // loop) instead of one vmcnt(0) every fourth iteration; same box, in the step: 0.6206 / 0.6251 / 0.6268 vs 0.6280 / 0.6303 / 0.6297 ms
+    if (presplit) return (!a_kc || p.a_vec) && (!b_kc || p.b_vec);
     const bool legal = p.a_vec && p.b_vec && (a_kc || p.M % 4 == 0) && (b_kc || p.N % 4 == 0) && p.M >= 4 && p.N >= 4;
-    return legal && vec_mode != 1 && (vec_mode == 2 || !(a_kc && b_kc));
+    return legal && !(a_kc && b_kc);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -313,7 +313,7 @@ static void launch_cfg_pair(const GemmOperands& p0, const Epilogue& e0, float* s
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(const GemmOperands& p, const Epilogue& e, float* slab, int splits, bool a_kc, bool b_kc, hipStream_t st) {
     dim3 grid(ceil_div(p.N, BN), ceil_div(p.M, BM), splits), block(64 * (BM / WM) * (BN / WN));
-    const bool vec = use_vec(p, a_kc, b_kc);
+    const bool vec = use_vec(p, a_kc, b_kc, GemmCore<BM, BN, WM, WN, true, true, true>::kPresplit);
 #define SNAG_GEMM(AK, BK_)                                                                                        \
     do {                                                                                                          \
         if (vec) hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN, AK, BK_, true, Epilogue>), grid, block, 0, st, p, e, slab);  \
@@ -326,8 +326,7 @@ static void launch_cfg(const GemmOperands& p, const Epilogue& e, float* slab, in
 #undef SNAG_GEMM
 }
 
-static int streamk_blocks() { static const int v = env_int("SNAG_GEMM_SK_BLOCKS"); return v > 0 ? v : 512; }    // 2 per CU (measured: 512 < 768 < 1024 in time; 256 / 384 much worse)
-static int streamk_mode() { static const int v = env_int("SNAG_GEMM_SK"); return v; }                          // tuning: 1 = never, 2 = whenever splitting
+static constexpr int kStreamKBlocks = 512;          // 2 per CU (measured: 512 < 768 < 1024 in time; 256 / 384 much worse)
 
 struct StreamKChoice {
     int G;
@@ -341,7 +340,7 @@ static StreamKChoice plan_streamk(int M, int N, int K, int BM, int BN) {
     c.plan.tiles_n = ceil_div(N, BN);
     c.plan.nkt = std::max(1, ceil_div(K, kBK));          // K == 0 never takes this route; keep the arithmetic below defined
     c.plan.total = (int64_t)tiles_m * c.plan.tiles_n * c.plan.nkt;
-    int64_t G = streamk_blocks();
+    int64_t G = kStreamKBlocks;
     while (G > 256 && c.plan.total / G < 16) G -= 256;
     c.G = (int)std::min<int64_t>(G, std::max<int64_t>(1, c.plan.total));
     const int64_t len = ceil_div(c.plan.total, (int64_t)c.G);
@@ -352,7 +351,7 @@ static StreamKChoice plan_streamk(int M, int N, int K, int BM, int BN) {
 
 template <int BM, int BN, int WM, int WN>
 static int launch_streamk(const GemmOperands& p, const Epilogue& e, float* slab, const StreamKChoice& c, bool a_kc, bool b_kc, hipStream_t st) {
-    const bool vec = use_vec(p, a_kc, b_kc);
+    const bool vec = use_vec(p, a_kc, b_kc, GemmCore<BM, BN, WM, WN, true, true, true>::kPresplit);
     dim3 grid(c.G), block(256);
 #define SNAG_SK(AK, BK_)                                                                                                           \
     do {                                                                                                                           \
@@ -376,9 +375,7 @@ static int launch_streamk(const GemmOperands& p, const Epilogue& e, float* slab,
 // blocks per CU hide it.  Each split keeps at least kMinKTiles k-tiles of work.
 static constexpr int kTargetBlocks = 1024, kMinKTiles = 16;
 
-static int target_blocks() { static const int v = env_int("SNAG_GEMM_TARGET"); return v > 0 ? v : kTargetBlocks; }   // tuning
 static int pick_splits(int64_t tiles, int K, bool both_kc = false) {
-    const int kTargetBlocks = target_blocks();
     if (tiles >= kTargetBlocks / 2) return 1;
     if (both_kc && tiles >= 192) return 1;      // measured: X W^T shapes with ~1 tile per CU gain nothing from splitting
     const int64_t want = (kTargetBlocks + tiles - 1) / tiles;
@@ -386,16 +383,13 @@ static int pick_splits(int64_t tiles, int K, bool both_kc = false) {
     return (int)std::min(want, cap);
 }
 
-static int xcd_mode() { static const int v = env_int("SNAG_GEMM_XCD"); return v == 2 ? 0 : 1; }   // tuning: SNAG_GEMM_XCD=2 switches the remap off
-static int log_shapes() { static const int v = env_int("SNAG_GEMM_LOG"); return v; }          // tuning: one line per launch on stderr
-static int force_tile() { static const int v = env_int("SNAG_GEMM_TILE"); return v; }        // tuning hooks: 1 = 64x128, 2 = 128x128, 3 = 128x160
-static int force_splits() { static const int v = env_int("SNAG_GEMM_SPLITS"); return v; }
+static int log_shapes() { static const int v = env_int("SNAG_GEMM_LOG"); return v; }          // diagnostics: one line per launch on stderr
 
 int64_t gemm_workspace_floats(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     // the largest fan-out any tile configuration may pick for this shape (the dispatcher clamps to what it is given)
     const int64_t t64 = (int64_t)ceil_div(M, 64) * ceil_div(N, 128), t160 = (int64_t)ceil_div(M, 128) * ceil_div(N, 160);
-    const int splits = force_splits() > 0 ? force_splits() : std::max(pick_splits(t64, K), pick_splits(t160, K));
+    const int splits = std::max(pick_splits(t64, K), pick_splits(t160, K));
     const int64_t sk = plan_streamk(M, N, K, 64, 128).slab_floats;
     return splits > 1 ? std::max((int64_t)splits * M * N, sk) : 0;
 }
@@ -416,15 +410,16 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb; p.M = d->M; p.N = d->N; p.K = d->K;
     p.a_vec = (d->lda % 4 == 0) && (((uintptr_t)d->A & 15) == 0);
     p.b_vec = (d->ldb % 4 == 0) && (((uintptr_t)d->B & 15) == 0);
+#if SNAG_GEMM_ABLATE            // -DSNAG_GEMM_ABLATE=1 timing builds only (tools/build_variant.sh): parts of the loops switched off at run time
     static const int dbg = env_int("SNAG_GEMM_DBG");
     p.dbg = dbg;
-    p.xcd = xcd_mode();
+#else
+    p.dbg = 0;
+#endif
+    p.xcd = 1;                  // XCD-aware workgroup -> tile mapping (xcd_swizzle)
     e.C = d->C; e.ldc = d->ldc; e.bias = d->bias; e.alpha = d->alpha; e.act = d->act; e.pre = d->pre_act;
     e.mask = d->keep_mask; e.ldm = d->ldmask > 0 ? d->ldmask : d->N; e.mscale = d->keep_scale; e.add1 = d->add1; e.ld1 = d->ld1; e.add2 = d->add2; e.ld2 = d->ld2;
     e.accumulate = d->accumulate; e.M = d->M; e.N = d->N; e.aux = d->aux; e.ldaux = d->ldaux; e.ct = d->c_transposed;
-    p.a_nkt = d->a_tiled ? ceil_div(d->K, 16) : 0;
-    p.a_layout = d->a_tiled;
-    p.b_image = d->b_image;
     e.mirror = d->mirror; e.ldmirror = d->ldmirror; e.mirror_mask = d->mirror_rowmask; e.mirror_scale = d->mirror_scale;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     e.fast = (d->ldc % 4 == 0) && al16(d->C) && (!d->bias || al16(d->bias)) && (!d->pre_act || al16(d->pre_act)) &&
@@ -449,7 +444,7 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     bool wide = wide_tiles * max_splits >= 512 && c_wide < (big ? c_big : c_small);
     // Split-bf16 builds: the pre-split staging loop (gemm.hip.h) runs the 64 x 128 tile fastest on every shape of the path
     // (forced 64 x 128 vs the choice above, one device: DB15K step 0.715 -> 0.704 ms, MKG-W 0.799 -> 0.788, MMEA step 22.5 -> 21.4 ms,
-    // 10,500^2 x 1,200 similarity eval 7.8 -> 7.2 ms); the larger tiles stay reachable through SNAG_GEMM_TILE for A/B runs.
+    // 10,500^2 x 1,200 similarity eval 7.8 -> 7.2 ms); the larger tiles are what -DSNAG_GEMM_BF16X=0 builds run.
     // (128 x 128 for the long-K shapes only, K >= 512 or 2048: step 0.708 / 0.711 vs 0.697 ms -- no.)
     if (kBf16x != 0) big = wide = false;
     // Long K (the projections and their weight gradients): 128 x 128 "row-private" tiles -- four waves stacked along M, each wave's
@@ -457,32 +452,25 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     // re-reads of B per launch).  For K = 128 / 256 the 64 x 128 tile stays (twice the workgroups for the same output).
     // (per shape, in the step: [15000,128,4096] 110 -> 92 us, [4096,128,15000] 94 -> 87, [15000,128,768] 29.7 -> 28.6; but
     // [128,128,15000] x 2 16.4 -> 20.6, [256,128,45000] 30.5 -> 31.6: long K AND many rows only.)
-    static const int tallk = env_int("SNAG_GEMM_TALLK");        // tuning: K threshold (default 512); -1 = never
-    static const int tallm = env_int("SNAG_GEMM_TALLM");        // tuning: M threshold (default 1024)
-    if (kBf16x != 0 && tallk >= 0 && p.K >= (tallk > 0 ? tallk : 512) && p.M >= (tallm > 0 ? tallm : 1024)) big = true;
-    if (force_tile() != 0) { big = force_tile() == 2; wide = force_tile() == 3; }
+    if (kBf16x != 0 && p.K >= 512 && p.M >= 1024) big = true;
     if (kBK != 16) wide = false;        // the 128x160 tiles of a 32-deep k-tile do not fit the 64 KB static LDS limit
     if (wide) big = false;
     // the eight-wave ping-pong form of the row-private tile (256 rows, one workgroup per CU) where the output is one tile wide, i.e.
     // A is read exactly once (the projections): DB15K step 0.651 vs 0.657 ms, MKG-W 0.727 vs 0.737; with several column tiles
     // (MMEA: N = 300 / 1,200) the four-wave form is faster (MMEA step 20.6 vs 21.8 ms; only for shapes with >= 256 / >= 1,024 tiles
-    // of 256 rows, in grouped order: 21.3 / 20.6-20.7 vs 20.2-20.6 -- SNAG_GEMM_PP_WIDE); the 10,500^2 similarity GEMM, 83 column
+    // of 256 rows, in grouped order: 21.3 / 20.6-20.7 vs 20.2-20.6); the 10,500^2 similarity GEMM, 83 column
     // tiles wide, does gain (eval.hip picks the tile itself)
-    static const int pp_off = env_int("SNAG_GEMM_PP_OFF");
-    static const int pp_wide = env_int("SNAG_GEMM_PP_WIDE");     // tuning: 256-row tiles needed for the eight-wave form when N > 128 (0 = never)
-    const int64_t tiles256 = (int64_t)ceil_div(p.M, 256) * (pn128 / 128);
-    if (d->a_tiled) { big = true; wide = false; }            // the tiled A layout exists for the eight-wave row-private tile only (gemm_check)
-    const bool pp = (big && kBf16x != 0 && !pp_off && (p.N <= 128 || (pp_wide > 0 && tiles256 >= pp_wide))) || d->a_tiled;
+    const bool pp = big && kBf16x != 0 && p.N <= 128;
     const int64_t tall_tiles = (int64_t)ceil_div(p.M, pp ? 256 : 128) * (pn128 / 128);
     const int64_t tiles = wide ? wide_tiles : big ? (kBf16x != 0 ? tall_tiles : big_tiles) : (pm64 / 64) * (pn128 / 128);
     // split K when the output alone cannot fill 256 CUs (the dW = dY^T X shapes: tiny output, long K)
     int splits = 1;
     if (d->workspace != nullptr) {
-        splits = force_splits() > 0 ? force_splits() : pick_splits(tiles, p.K, d->a_kcontig && d->b_kcontig);
+        splits = pick_splits(tiles, p.K, d->a_kcontig && d->b_kcontig);
         // row-private tiles: at most ONE resident wave of workgroups -- 512 four-wave ones (two per CU), 256 eight-wave ones (measured
         // with four waves: 590 workgroups 0.7135 ms per step, 472-512 0.702, against 0.720 with 64 x 128 tiles)
         if (d->splits > 0) splits = (int)std::min<int64_t>(d->splits, std::max<int64_t>(1, p.K / (kMinKTiles * 16)));
-        else if (kBf16x != 0 && big && force_splits() <= 0 && env_int("SNAG_GEMM_TARGET") <= 0)
+        else if (kBf16x != 0 && big)
             splits = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(1, p.K / (kMinKTiles * 16)),
                                                                 (pp ? 256 : 512) / std::max<int64_t>(1, tiles)));
         const int64_t cap = d->workspace_floats / ((int64_t)p.M * p.N);
@@ -493,14 +481,13 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     // arithmetic below would otherwise divide by zero
     if (p.K == 0) splits = 1;
     pl.big = big; pl.wide = wide; pl.streamk = false; pl.pp = pp;
-    if (pp && p.N > 128 && p.xcd) p.xcd |= 4 << 4;           // several column tiles: grouped tile order (4 row tiles deep per XCD, gemm_tile_body)
-    if (splits > 1 && !big && !wide && streamk_mode() != 1 && d->splits <= 0) {      // (an explicit split request is a split-K request)
+    if (splits > 1 && !big && !wide && d->splits <= 0) {      // (an explicit split request is a split-K request)
         // blocks per CU of the split grid vs what the slowest CU gets
         const double per_cu = (double)tiles * splits / 256.0;
         const double balance = per_cu / std::ceil(per_cu);
         const StreamKChoice c = plan_streamk(p.M, p.N, p.K, 64, 128);
         // few tiles shared by many blocks (the dW shapes) keep split-K: their slabs reduce in parallel over the whole output
-        if ((balance < 0.95 || streamk_mode() == 2) && c.G >= 256 && tiles * 8 >= c.G && c.slab_floats <= d->workspace_floats) {
+        if (balance < 0.95 && c.G >= 256 && tiles * 8 >= c.G && c.slab_floats <= d->workspace_floats) {
             p.k_per_split = 0;
             pl.streamk = true;
             pl.sk = c;
@@ -530,22 +517,11 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     if (log_shapes())
         fprintf(stderr, "snag_gemm M=%d N=%d K=%d a_kc=%d b_kc=%d tile=%s splits=%d fast=%d acc=%d\n", p.M, p.N, p.K, (int)d->a_kcontig,
                 (int)d->b_kcontig, pl.wide ? "128x160" : pl.pp ? "256x128" : pl.big ? "128x128" : "64x128", splits, (int)e.fast, (int)d->accumulate);
-    const bool img = d->b_image != nullptr && !pl.wide && pl.big && pl.pp && kBf16x != 0;      // (other tiles split B themselves: the image is ignored)
-#if SNAG_GEMM_BK == 16
+#if SNAG_GEMM_BK == 16 && SNAG_GEMM_BF16X == 0          // (the 128 x 160 tile: f32-MFMA builds only)
     if (pl.wide) launch_cfg<128, 160, 32, 160>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else
 #endif
-    if (img) {
-        // B from its pre-split image (LDS-DMA): A tiled, K-contiguous (16-byte loads) or row-contiguous
-        dim3 grid(ceil_div(p.N, 128), ceil_div(p.M, 256), splits), block(512);
-        if (d->a_tiled) hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, false, false, true, Epilogue, true, true>), grid, block, 0, st, p, e, slab);
-        else if (d->a_kcontig) hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, true, false, true, Epilogue, false, true>), grid, block, 0, st, p, e, slab);
-        else hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, false, false, true, Epilogue, false, true>), grid, block, 0, st, p, e, slab);
-    } else if (d->a_tiled) {
-        dim3 grid(ceil_div(p.N, 128), ceil_div(p.M, 256), splits), block(512);
-        if (d->b_kcontig) hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, false, true, true, Epilogue, true>), grid, block, 0, st, p, e, slab);
-        else hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, false, false, true, Epilogue, true>), grid, block, 0, st, p, e, slab);
-    } else if (pl.big && pl.pp) launch_cfg<256, 128, 32, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
+    if (pl.big && pl.pp) launch_cfg<256, 128, 32, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else if (pl.big) launch_cfg<128, 128, 32, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else launch_cfg<64, 128, 32, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     int rc = check_launch("snag_gemm_f32");
@@ -566,14 +542,13 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
 // Two problems in one launch when the dispatcher decides the same for both (same shape, layouts, tile, split count, loader);
 // anything else runs them one after the other.
 int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStream_t st) {
-    static const int off = env_int("SNAG_GEMM_PAIR_OFF");      // tuning / A-B
     const GemmPlan a = plan_gemm(d0), b = plan_gemm(d1);
-    const bool same = !off && !a.streamk && !b.streamk && !a.wide && !b.wide && a.big == b.big && !a.pp && !b.pp && a.splits == b.splits && d0->M == d1->M && d0->N == d1->N &&
+    const bool same = !a.streamk && !b.streamk && !a.wide && !b.wide && a.big == b.big && !a.pp && !b.pp && a.splits == b.splits && d0->M == d1->M && d0->N == d1->N &&
                       d0->K == d1->K && d0->a_kcontig == d1->a_kcontig && d0->b_kcontig == d1->b_kcontig && a.p.k_per_split == b.p.k_per_split &&
                       use_vec(a.p, d0->a_kcontig, d0->b_kcontig) == use_vec(b.p, d1->a_kcontig, d1->b_kcontig) &&
                       (a.splits == 1 || (d0->workspace != d1->workspace));
     // different shapes, same layouts, 64 x 128 tiles, no K split on either side: one grouped launch
-    const bool group = !off && !same && !a.streamk && !b.streamk && !a.wide && !b.wide && !a.big && !b.big && a.splits == 1 && b.splits == 1 &&
+    const bool group = !same && !a.streamk && !b.streamk && !a.wide && !b.wide && !a.big && !b.big && a.splits == 1 && b.splits == 1 &&
                        d0->K > 0 && d1->K > 0 && d0->a_kcontig == d1->a_kcontig && d0->b_kcontig == d1->b_kcontig &&
                        use_vec(a.p, d0->a_kcontig, d0->b_kcontig) == use_vec(b.p, d1->a_kcontig, d1->b_kcontig);
     if (group) {
@@ -632,9 +607,8 @@ static int launch_reduce(const GemmPlan& pl, float* slab, hipStream_t st);
 // (no stream-K) on the same operand layouts; anything else: one after the other.  Each problem keeps the K split, slab and epilogue its
 // own dispatch would use, so the results are the same bits as one-by-one launches.
 int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) {
-    static const int off = env_int("SNAG_GEMM_GROUP_OFF");      // tuning / A-B
     GemmPlan pl[kGroupMax];
-    bool ok = !off && n >= 2 && n <= kGroupMax;
+    bool ok = n >= 2 && n <= kGroupMax;
     bool pp = false;                  // every problem on the eight-wave 256 x 128 tile instead (512 threads per workgroup)
     for (int i = 0; ok && i < n; ++i) {
         const snag_gemm_desc* d = ds[i];
@@ -643,7 +617,7 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
         // (in a group of eight-wave tiles a problem with an explicit split request rides along even if, alone, its row count would pick
         // the 64 x 128 tile: its K split and epilogue do not depend on the tile)
         const bool pp_ok = (pl[i].big && pl[i].pp) || (d->splits > 0 && kBf16x != 0 && d->K >= 512 && d->N <= 128 && !pl[i].big);
-        ok = d->M > 0 && d->N > 0 && d->K > 0 && !pl[i].streamk && !pl[i].wide && (pp ? pp_ok : (!pl[i].big && !pl[i].pp)) && !d->a_tiled && !d->b_image &&
+        ok = d->M > 0 && d->N > 0 && d->K > 0 && !pl[i].streamk && !pl[i].wide && (pp ? pp_ok : (!pl[i].big && !pl[i].pp)) &&
              d->a_kcontig == ds[0]->a_kcontig && d->b_kcontig == ds[0]->b_kcontig &&
              use_vec(pl[i].p, d->a_kcontig, d->b_kcontig) == use_vec(pl[0].p, ds[0]->a_kcontig, ds[0]->b_kcontig);
         for (int j = 0; ok && j < i; ++j) ok = !(pl[i].splits > 1 && pl[j].splits > 1 && ds[i]->workspace == ds[j]->workspace);
@@ -737,49 +711,6 @@ int gemm_reduce_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStre
     return gemm_reduce_multi(ds, 2, st);
 }
 
-// one thread = one 16-byte slot of the image of one plane triple: (column tile, k-tile, k-half q, row n) <- the exact split of
-// B(n, 16 kt + 4 q + 0..3) and B(n, 16 kt + 8 + 4 q + 0..3) -- the same split_pair the kernels apply to a staged value
-__global__ __launch_bounds__(256) void presplit_b_kernel(const float* __restrict__ src, int64_t ld, int64_t N, int64_t K, int kcontig, unsigned char* __restrict__ img,
-                                                         int64_t nkt, int64_t slots) {
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < slots; t += (int64_t)gridDim.x * 256) {
-        const int nl = (int)(t & 127), q = (int)((t >> 7) & 1);
-        const int64_t blk = t >> 8, kt = blk % nkt, nt = blk / nkt;
-        const int64_t n = nt * 128 + nl, k0 = kt * 16 + 4 * q;
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int64_t k = k0 + (j & 3) + 8 * (j >> 2);
-            v[j] = (n < N && k < K) ? (kcontig ? src[n * ld + k] : src[k * ld + n]) : 0.f;
-        }
-        uint32_t h[4], m[4], l[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
-        unsigned char* base = img + blk * ImageStager::kBlock + ((int64_t)q * 128 + nl) * 16;
-        *reinterpret_cast<uint4*>(base) = make_uint4(h[0], h[1], h[2], h[3]);
-        *reinterpret_cast<uint4*>(base + 2 * 128 * 16) = make_uint4(m[0], m[1], m[2], m[3]);
-        *reinterpret_cast<uint4*>(base + 4 * 128 * 16) = make_uint4(l[0], l[1], l[2], l[3]);
-    }
-}
-
-// one thread = one 16-byte piece of the tiled copy: (block mb, k-tile kt, c, lh, li) <- A(32 mb + li, 16 kt + 8 c + 4 lh + 0..3)
-__global__ __launch_bounds__(256) void tile_a_kernel(const float* __restrict__ src, int64_t ld, int64_t M, int64_t K, int kcontig, float* __restrict__ dst,
-                                                     int64_t nkt, int64_t pieces, int layout) {
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < pieces; t += (int64_t)gridDim.x * 256) {
-        const int li = (int)(t & 31), lh = (int)((t >> 5) & 1), c = (int)((t >> 6) & 1);
-        const int64_t blk = t >> 7, kt = blk % nkt, mb = blk / nkt;
-        const int64_t m = mb * 32 + li, k0 = kt * 16 + 8 * c + 4 * lh;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (m < M) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k0 + j < K) v[j] = kcontig ? src[m * ld + k0 + j] : src[(k0 + j) * ld + m];
-        }
-        // layout 1: the piece index IS the lane order; layout 2: row li's 64 bytes hold its pieces (c, lh) in k order
-        const int64_t at = layout == 2 ? (blk * 128 + (int64_t)li * 4 + c * 2 + lh) : t;
-        reinterpret_cast<float4*>(dst)[at] = make_float4(v[0], v[1], v[2], v[3]);
-    }
-}
-
 int gemm_check(const snag_gemm_desc* d) {
     SNAG_REQUIRE(d != nullptr, SNAG_ERR_ARG, "gemm: null descriptor");
     SNAG_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, SNAG_ERR_ARG, "gemm: negative size M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -788,13 +719,10 @@ int gemm_check(const snag_gemm_desc* d) {
     SNAG_REQUIRE(d->K == 0 || (d->A && d->B), SNAG_ERR_ARG, "gemm: null A or B");
     SNAG_REQUIRE(d->ldc >= (d->c_transposed ? d->M : d->N), SNAG_ERR_ARG, "gemm: ldc=%ld < %s=%d", (long)d->ldc, d->c_transposed ? "M" : "N", d->c_transposed ? d->M : d->N);
     SNAG_REQUIRE(!d->c_transposed || (!d->pre_act && !d->mirror), SNAG_ERR_UNSUPPORTED, "gemm: a transposed C takes no pre_act / mirror copy");
-    SNAG_REQUIRE(d->a_tiled >= 0 && d->a_tiled <= 2, SNAG_ERR_ARG, "gemm: a_tiled=%d (0 plain, 1 lane order, 2 row order)", d->a_tiled);
-    SNAG_REQUIRE(!d->a_tiled || (kBf16x != 0 && kBK == 16 && d->N <= 128 && ((uintptr_t)d->A & 15) == 0), SNAG_ERR_UNSUPPORTED,
-                 "gemm: the tiled A layout feeds the 256 x 128 row-private tile only (N <= 128, 16-byte aligned A)");
-    SNAG_REQUIRE(d->a_tiled || d->lda >= (d->a_kcontig ? d->K : d->M), SNAG_ERR_ARG, "gemm: lda=%ld too small", (long)d->lda);
+    SNAG_REQUIRE(d->lda >= (d->a_kcontig ? d->K : d->M), SNAG_ERR_ARG, "gemm: lda=%ld too small", (long)d->lda);
     SNAG_REQUIRE(d->ldb >= (d->b_kcontig ? d->K : d->N), SNAG_ERR_ARG, "gemm: ldb=%ld too small", (long)d->ldb);
     // the staged loaders address one operand tile with 32-bit byte offsets from a 64-bit base: 128 rows (or 16 k rows) x pitch < 4 GB
-    SNAG_REQUIRE((d->a_tiled || d->lda < (1 << 22)) && d->ldb < (1 << 22), SNAG_ERR_UNSUPPORTED, "gemm: operand pitch lda=%ld / ldb=%ld above 4M elements", (long)d->lda,
+    SNAG_REQUIRE(d->lda < (1 << 22) && d->ldb < (1 << 22), SNAG_ERR_UNSUPPORTED, "gemm: operand pitch lda=%ld / ldb=%ld above 4M elements", (long)d->lda,
                  (long)d->ldb);
     SNAG_REQUIRE(d->act >= 0 && d->act <= 4, SNAG_ERR_ARG, "gemm: act=%d unknown", d->act);
     SNAG_REQUIRE(d->act < 3 || (d->aux && d->ldaux >= d->N), SNAG_ERR_ARG, "gemm: act=%d needs aux [M,N]", d->act);
@@ -814,38 +742,6 @@ extern "C" SNAG_API int snag_gemm_f32(const snag_gemm_desc* d, void* stream) {
     if (rc) return rc;
     if (d->M == 0 || d->N == 0) return SNAG_OK;
     return gemm_dispatch(d, (hipStream_t)stream);
-}
-
-extern "C" SNAG_API int64_t snag_presplit_b_bytes(int64_t N, int64_t K) {
-    if (N < 0 || K < 0) return 0;
-    return ((N + 127) / 128) * ((K + 15) / 16) * (int64_t)ImageStager::kBlock;
-}
-
-extern "C" SNAG_API int snag_presplit_b(const float* B, int64_t ldb, int b_kcontig, int64_t N, int64_t K, void* image, void* stream) {
-    SNAG_REQUIRE(N >= 0 && K >= 0 && ldb >= (b_kcontig ? K : N), SNAG_ERR_ARG, "presplit_b: bad sizes (N=%ld K=%ld ldb=%ld)", (long)N, (long)K, (long)ldb);
-    if (N == 0 || K == 0) return SNAG_OK;
-    SNAG_REQUIRE(B && image && ((uintptr_t)image & 15) == 0, SNAG_ERR_ARG, "presplit_b: null pointer or unaligned image");
-    SNAG_REQUIRE(kBf16x != 0, SNAG_ERR_UNSUPPORTED, "presplit_b: this build multiplies on the f32 matrix pipe (no split operands)");
-    const int64_t nkt = (K + 15) / 16, slots = ((N + 127) / 128) * nkt * 256;
-    hipLaunchKernelGGL(presplit_b_kernel, dim3((unsigned)std::min<int64_t>(65536, (slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, ldb, N, K, b_kcontig,
-                       (unsigned char*)image, nkt, slots);
-    return check_launch("snag_presplit_b");
-}
-
-extern "C" SNAG_API int64_t snag_tile_a_floats(int64_t M, int64_t K) {
-    if (M < 0 || K < 0) return 0;
-    return ((M + 31) / 32) * ((K + 15) / 16) * 512;
-}
-
-extern "C" SNAG_API int snag_tile_a_f32(const float* src, int64_t ld, int64_t M, int64_t K, int kcontig, int layout, float* dst, void* stream) {
-    SNAG_REQUIRE(M >= 0 && K >= 0 && ld >= (kcontig ? K : M) && (layout == 1 || layout == 2), SNAG_ERR_ARG, "tile_a: bad sizes / layout (M=%ld K=%ld ld=%ld layout=%d)",
-                 (long)M, (long)K, (long)ld, layout);
-    if (M == 0 || K == 0) return SNAG_OK;
-    SNAG_REQUIRE(src && dst && ((uintptr_t)dst & 15) == 0, SNAG_ERR_ARG, "tile_a: null pointer or unaligned destination");
-    const int64_t nkt = (K + 15) / 16, pieces = ((M + 31) / 32) * nkt * 128;
-    hipLaunchKernelGGL(tile_a_kernel, dim3((unsigned)std::min<int64_t>(65536, (pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld, M, K, kcontig, dst,
-                       nkt, pieces, layout);
-    return check_launch("snag_tile_a_f32");
 }
 
 extern "C" SNAG_API int snag_gemm_f32_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, void* stream) {
@@ -903,7 +799,7 @@ extern "C" SNAG_API int snag_gram_f32(const float* Z, int64_t ldz, int n, int k,
     p.k_per_split = ceil_div(std::max(k, 1), kBK) * kBK;
     p.dbg = 0;
     const int t = ceil_div(n, 128);
-    p.xcd = xcd_mode();
+    p.xcd = 1;
     hipLaunchKernelGGL(gram_tile_kernel, dim3(t * (t + 1) / 2), dim3(256), 0, (hipStream_t)stream, p, alpha, S, lds, t);
     return check_launch("snag_gram_f32");
 }

@@ -187,11 +187,9 @@ static int launch_fused(const ElemT* ent, int64_t eld, const ElemT* rel, int dim
                         const void* neg_t, int64_t batch, int n_neg, float margin, float gscale, float* pos, float* neg,
                         float* loss_part, float* loss, unsigned* ticket, float* d_ent, int64_t dld, float* d_rel, hipStream_t st) {
     // waves per triple: enough short waves to keep ~16 per CU (256 CUs) while a triple still has >= 8 negatives per wave
-    static const int forced = env_int("SNAG_SCORE_WPT");          // tuning
     int wpt = 1;
     if (batch * 4 <= 4096 && n_neg >= 32) wpt = 4;
     else if (batch * 2 <= 4096 && n_neg >= 16) wpt = 2;
-    if (forced == 1 || forced == 2 || forced == 4) wpt = forced;
     const dim3 grid((unsigned)ceil_div(batch, 4 / wpt)), block(256);
     const int ns = (dim + 63) / 64;
 #define SNAG_FUSED_W(NS, W)                                                                                                      \

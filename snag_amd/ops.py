@@ -254,43 +254,17 @@ def gram(z, alpha=1.0, out=None):
     return out
 
 
-def tile_a(a, kcontig=True, layout=1, out=None):
-    """The tiled copy of an operand A (a: [M, K] when kcontig else [K, M]) for ``gemm(..., a_tiled=(M, K), a_layout=layout)``.
-    C ABI: snag_tile_a_f32."""
-    if not (torch.is_tensor(a) and a.is_cuda and a.dtype == f32 and a.dim() == 2 and a.stride(1) == 1):
-        raise ValueError("tile_a: a must be a 2-D fp32 CUDA tensor with unit inner stride")
-    M, K = a.shape if kcontig else (a.shape[1], a.shape[0])
-    if out is None:
-        out = torch.empty(_lib.load().snag_tile_a_floats(M, K), device=a.device, dtype=f32)
-    call("snag_tile_a_f32", ptr(a), a.stride(0), M, K, int(kcontig), int(layout), ptr(out), stream())
-    return out
-
-
-def presplit_b(b, kcontig=True, out=None):
-    """The pre-split bf16 image of an operand B (b: [N, K] when kcontig else [K, N]) for ``gemm(..., b_image=...)``.  C ABI: snag_presplit_b."""
-    if not (torch.is_tensor(b) and b.is_cuda and b.dtype == f32 and b.dim() == 2 and b.stride(1) == 1):
-        raise ValueError("presplit_b: b must be a 2-D fp32 CUDA tensor with unit inner stride")
-    N, K = b.shape if kcontig else (b.shape[1], b.shape[0])
-    nbytes = _lib.load().snag_presplit_b_bytes(N, K)
-    if out is None:
-        out = torch.empty(nbytes, device=b.device, dtype=torch.uint8)
-    call("snag_presplit_b", ptr(b), b.stride(0), int(kcontig), N, K, ptr(out), stream())
-    return out
-
-
 def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, alpha=1.0, act=None, want_pre_act=False,
-         keep_mask=None, keep_p=0.0, add1=None, add2=None, out=None, accumulate=False, splitk=True, aux=None, a_tiled=None, c_transposed=False, b_image=None, a_layout=1):
+         keep_mask=None, keep_p=0.0, add1=None, add2=None, out=None, accumulate=False, splitk=True, aux=None, c_transposed=False):
     """C = add1 + add2 + keep * act(alpha * A.B + bias)   (C ABI: snag_gemm_f32; fp32 via split-bf16 MFMA).
 
     a: [M,K] if a_kcontig else [K,M];  b: [N,K] if b_kcontig else [K,N]  (2-D, last dim contiguous,
     row stride free).  Returns C [M,N] (and the pre-activation when want_pre_act).
     """
     for t, nm in ((a, "a"), (b, "b")):
-        if nm == "a" and a_tiled is not None:
-            continue
         if not (torch.is_tensor(t) and t.is_cuda and t.dtype == f32 and t.dim() == 2 and t.stride(1) == 1):
             raise ValueError(f"gemm: {nm} must be a 2-D fp32 CUDA tensor with unit inner stride")
-    M, K = a_tiled if a_tiled is not None else (a.shape if a_kcontig else (a.shape[1], a.shape[0]))
+    M, K = a.shape if a_kcontig else (a.shape[1], a.shape[0])
     N, Kb = (b.shape if b_kcontig else (b.shape[1], b.shape[0]))
     if K != Kb:
         raise ValueError(f"gemm: inner sizes differ ({K} vs {Kb})")
@@ -302,9 +276,8 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, alpha=1.0, act=None
     d = _lib.GemmDesc()
     d.M, d.N, d.K = M, N, K
     d.a_kcontig, d.b_kcontig = int(a_kcontig), int(b_kcontig)
-    d.a_tiled, d.c_transposed = (int(a_layout) if a_tiled is not None else 0), int(c_transposed)
-    d.b_image = ptr(b_image)
-    d.A, d.lda = ptr(a), (0 if a_tiled is not None else a.stride(0))
+    d.c_transposed = int(c_transposed)
+    d.A, d.lda = ptr(a), a.stride(0)
     d.B, d.ldb = ptr(b), b.stride(0)
     d.C, d.ldc = ptr(out), out.stride(0)
     d.bias = ptr(_chk(bias, "bias", ndim=1)) if bias is not None else None

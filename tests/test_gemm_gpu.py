@@ -395,29 +395,6 @@ def test_gemm_mirror_output(M, N, K, split):
     assert torch.equal(mirror[:, :N], out * scale) and float((mirror[:, N:] - 7.0).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 128, 4096), (15000, 128, 768), (4096, 128, 15000), (257, 100, 333), (31, 5, 17), (700, 128, 16), (512, 64, 2048)])
-@pytest.mark.parametrize("src_kc,b_kc", [(True, True), (False, False), (False, True), (True, False)])
-@pytest.mark.parametrize("layout", [1, 2])
-def test_gemm_tiled_a_equals_the_plain_layout_bit_for_bit(M, N, K, src_kc, b_kc, layout):
-    """snag_tile_a_f32 + snag_gemm_desc.a_tiled: the same eight-wave row-private kernel fed from the tiled copy of A (two 16-byte loads
-    per lane and k-tile instead of eight 4-byte ones) gives the BITS of the plain-layout call when both run that tile (N <= 128, long K,
-    many rows), and fp64-close results everywhere; ragged M and K are zero-padded inside the tiled copy."""
-    from snag_amd import ops
-    g = torch.Generator().manual_seed(M + 3 * N + 5 * K)
-    a = torch.randn((M, K) if src_kc else (K, M), generator=g).to(DEV)
-    b = torch.randn((N, K) if b_kc else (K, N), generator=g).to(DEV)
-    at = ops.tile_a(a, kcontig=src_kc, layout=layout)
-    assert at.numel() == ((M + 31) // 32) * ((K + 15) // 16) * 512
-    c = ops.gemm(at, b, a_tiled=(M, K), a_layout=layout, b_kcontig=b_kc)
-    ref = _ref(a.cpu(), b.cpu(), src_kc, b_kc)
-    assert_close(c, ref, atol=2e-6 * K + 1e-5, rtol=2e-5, what=f"tiled gemm {M}x{N}x{K}")
-    if K >= 512 and M >= 1024:                       # the plain call picks the same tile and K split: same summation order
-        plain = ops.gemm(a, b, a_kcontig=src_kc, b_kcontig=b_kc)
-        assert torch.equal(c, plain)
-    c2 = ops.gemm(at, b, a_tiled=(M, K), a_layout=layout, b_kcontig=b_kc)
-    assert torch.equal(c, c2)
-
-
 @pytest.mark.parametrize("M,N,K,split", [(4096, 128, 15000, True), (300, 70, 41, False), (128, 128, 5000, True), (1000, 128, 128, False)])
 def test_gemm_transposed_output(M, N, K, split):
     """c_transposed: value (m, n) lands at C[n, m] -- the bits of the plain call, transposed; bias / activation / accumulate still follow (m, n)."""
@@ -432,32 +409,6 @@ def test_gemm_transposed_output(M, N, K, split):
     acc = torch.ones(N, M, device=DEV)
     ops.gemm(a, b, a_kcontig=False, b_kcontig=False, splitk=split, c_transposed=True, out=acc, accumulate=True)
     assert_close(acc.t(), 1.0 + ops.gemm(a, b, a_kcontig=False, b_kcontig=False, splitk=split), atol=1e-5, rtol=1e-6)
-
-
-@pytest.mark.parametrize("M,N,K", [(15000, 128, 4096), (15000, 128, 768), (4096, 128, 15000), (1100, 100, 777), (1024, 128, 512)])
-@pytest.mark.parametrize("a_mode,b_kc", [("rowc", False), ("rowc", True), ("kc", False), ("tiled", True)])
-def test_gemm_presplit_b_image_equals_the_plain_call_bit_for_bit(M, N, K, a_mode, b_kc):
-    """snag_presplit_b + snag_gemm_desc.b_image: the weight's three bf16 planes made ONCE (not per workgroup and k-tile) and copied into
-    the LDS by DMA give the bits of the call that splits B itself (same split, same order of products and k-tiles); ragged N / K are
-    zero-padded inside the image; epilogue (bias, ReLU) as usual."""
-    from snag_amd import ops
-    g = torch.Generator().manual_seed(M + 7 * N + 11 * K)
-    a = torch.randn((M, K) if a_mode != "rowc" else (K, M), generator=g).to(DEV)
-    b = torch.randn((N, K) if b_kc else (K, N), generator=g).to(DEV)
-    bias = torch.randn(N, generator=g).to(DEV)
-    img = ops.presplit_b(b, kcontig=b_kc)
-    assert img.numel() == ((N + 127) // 128) * ((K + 15) // 16) * 16384
-    kw = dict(b_kcontig=b_kc, bias=bias, act="relu")
-    if a_mode == "tiled":
-        at = ops.tile_a(a, kcontig=True)
-        plain = ops.gemm(at, b, a_tiled=(M, K), **kw)
-        got = ops.gemm(at, b, a_tiled=(M, K), b_image=img, **kw)
-    else:
-        plain = ops.gemm(a, b, a_kcontig=(a_mode == "kc"), **kw)
-        got = ops.gemm(a, b, a_kcontig=(a_mode == "kc"), b_image=img, **kw)
-    assert torch.equal(got, plain)
-    ref = torch.relu(_ref(a.cpu(), b.cpu(), a_mode != "rowc", b_kc) + bias.cpu().double())
-    assert_close(got, ref, atol=2e-6 * K + 1e-5, rtol=2e-5)
 
 
 def test_gemm_non_finite_and_extreme_operands_are_documented_behaviour():
