@@ -67,6 +67,31 @@ __device__ __forceinline__ float max64(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// One LayerNorm row held by a wave, column c = lane + 64 u in x[u] (0 where c >= D): biased variance, eps inside the sqrt
+// (nn.LayerNorm(eps=1e-12); model/SNAG_tools.py:215,221).  ONE statement of the arithmetic for every kernel that normalises a row
+// (ln_fwd_kernel, the GEMM launch that normalises its own output rows), so that they agree bit for bit.
+template <int NU>
+__device__ __forceinline__ void ln_row_forward(const float (&x)[NU], int D, int lane, const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                               float (&o)[NU], float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) s += x[u];
+    mean = sum64(s) / (float)D;
+    float vs = 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const float dlt = (lane + 64 * u < D) ? x[u] - mean : 0.f;
+        vs = fmaf(dlt, dlt, vs);
+    }
+    rstd = 1.0f / sqrtf(sum64(vs) / (float)D + eps);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int c = lane + 64 * u;
+        const float gg = c < D ? g[c] : 0.f, bb = c < D ? b[c] : 0.f;
+        o[u] = (x[u] - mean) * rstd * gg + bb;
+    }
+}
+
 __device__ __forceinline__ int wave_id_uniform() {
     return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
@@ -89,5 +114,9 @@ int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipSt
 int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st);   // 2..6 problems, one launch when their plans allow
 int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st);   // finishes problems launched with defer_reduce
 int64_t gemm_workspace_floats(int M, int N, int K);
+// C = epilogue(A B) AND y = LayerNorm(C) (rows of y D = N wide, dense) in ONE launch, when the product runs as unsplit 64 x 128 tiles that hold
+// whole rows (N <= 128; K < 512 or M < 1024; no workspace, accumulate, pre_act, mirror or transposed store).  Returns 1 -- nothing launched --
+// when the problem does not qualify: the caller then runs gemm_dispatch + ln_fwd_kernel, which give the same bits.  stats[m] = (mean, rstd).
+int gemm_dispatch_ln(const snag_gemm_desc* d, const float* gamma, const float* beta, float eps, float* y, float* stats, hipStream_t st);
 
 }  // namespace snag

@@ -148,10 +148,14 @@ static int fusion_fwd_readout(const snag_fusion_desc* f, const snag_fusion_layer
     gd = gemm_desc(N, D, D, S.ctx, D, true, P.wo, D, true, S.t1, D);
     gd.bias = P.bo; gd.keep_scale = kscale; gd.add1 = xin + (int64_t)g * D; gd.ld1 = MD;
     if (P.keep_attn_out) { gd.keep_mask = P.keep_attn_out + (int64_t)g * D; gd.ldmask = MD; }
-    if ((rc = gemm_dispatch(&gd, st))) return rc;
     float* y1 = ffn ? S.y1 : f->hidden;
-    SNAG_NU(ln_fwd_kernel, D, egrid, st, (const float*)S.t1, (int64_t)N, D, P.ln1_g, P.ln1_b, 1e-12f, y1, S.st1);
-    if ((rc = check_launch("fusion LayerNorm (read-out)"))) return rc;
+    // dense + dropout + residual AND the LayerNorm of the row in one launch where a tile holds whole rows (D <= 128)
+    if ((rc = gemm_dispatch_ln(&gd, P.ln1_g, P.ln1_b, 1e-12f, y1, S.st1, st)) == 1) {
+        if ((rc = gemm_dispatch(&gd, st))) return rc;
+        SNAG_NU(ln_fwd_kernel, D, egrid, st, (const float*)S.t1, (int64_t)N, D, P.ln1_g, P.ln1_b, 1e-12f, y1, S.st1);
+        rc = check_launch("fusion LayerNorm (read-out)");
+    }
+    if (rc) return rc;
     if (ffn) {
         gd = gemm_desc(N, I, D, y1, D, true, P.w1, D, true, S.g, I);
         gd.bias = P.b1; gd.act = 2; gd.pre_act = S.u;
@@ -159,9 +163,12 @@ static int fusion_fwd_readout(const snag_fusion_desc* f, const snag_fusion_layer
         gd = gemm_desc(N, D, I, S.g, I, true, P.w2, I, true, S.t2, D);
         gd.bias = P.b2; gd.keep_scale = kscale; gd.add1 = y1; gd.ld1 = D;
         if (P.keep_ffn_out) { gd.keep_mask = P.keep_ffn_out + (int64_t)g * D; gd.ldmask = MD; }
-        if ((rc = gemm_dispatch(&gd, st))) return rc;
-        SNAG_NU(ln_fwd_kernel, D, egrid, st, (const float*)S.t2, (int64_t)N, D, P.ln2_g, P.ln2_b, 1e-12f, f->hidden, S.st2);
-        if ((rc = check_launch("fusion LayerNorm 2 (read-out)"))) return rc;
+        if ((rc = gemm_dispatch_ln(&gd, P.ln2_g, P.ln2_b, 1e-12f, f->hidden, S.st2, st)) == 1) {
+            if ((rc = gemm_dispatch(&gd, st))) return rc;
+            SNAG_NU(ln_fwd_kernel, D, egrid, st, (const float*)S.t2, (int64_t)N, D, P.ln2_g, P.ln2_b, 1e-12f, f->hidden, S.st2);
+            rc = check_launch("fusion LayerNorm 2 (read-out)");
+        }
+        if (rc) return rc;
     }
     return SNAG_OK;
 }
@@ -192,10 +199,13 @@ int fusion_fwd(const snag_fusion_desc* f, hipStream_t st) {
         // dense + dropout + residual                            (:219-221)
         g = gemm_desc((int)NM, D, D, S.ctx, D, true, P.wo, D, true, S.t1, D);
         g.bias = P.bo; g.keep_mask = P.keep_attn_out; g.keep_scale = kscale; g.add1 = xin; g.ld1 = D;
-        if ((rc = gemm_dispatch(&g, st))) return rc;
         float* y1 = (!ffn && last) ? f->hidden : S.y1;
-        SNAG_NU(ln_fwd_kernel, D, rgrid, st, (const float*)S.t1, NM, D, P.ln1_g, P.ln1_b, 1e-12f, y1, S.st1);
-        if ((rc = check_launch("fusion LayerNorm"))) return rc;
+        if ((rc = gemm_dispatch_ln(&g, P.ln1_g, P.ln1_b, 1e-12f, y1, S.st1, st)) == 1) {
+            if ((rc = gemm_dispatch(&g, st))) return rc;
+            SNAG_NU(ln_fwd_kernel, D, rgrid, st, (const float*)S.t1, NM, D, P.ln1_g, P.ln1_b, 1e-12f, y1, S.st1);
+            rc = check_launch("fusion LayerNorm");
+        }
+        if (rc) return rc;
         float* yout = y1;
         if (ffn) {                                              // :295-298
             g = gemm_desc((int)NM, I, D, y1, D, true, P.w1, D, true, S.g, I);
@@ -203,10 +213,13 @@ int fusion_fwd(const snag_fusion_desc* f, hipStream_t st) {
             if ((rc = gemm_dispatch(&g, st))) return rc;
             g = gemm_desc((int)NM, D, I, S.g, I, true, P.w2, I, true, S.t2, D);
             g.bias = P.b2; g.keep_mask = P.keep_ffn_out; g.keep_scale = kscale; g.add1 = y1; g.ld1 = D;
-            if ((rc = gemm_dispatch(&g, st))) return rc;
             yout = last ? f->hidden : S.y2;
-            SNAG_NU(ln_fwd_kernel, D, rgrid, st, (const float*)S.t2, NM, D, P.ln2_g, P.ln2_b, 1e-12f, yout, S.st2);
-            if ((rc = check_launch("fusion LayerNorm 2"))) return rc;
+            if ((rc = gemm_dispatch_ln(&g, P.ln2_g, P.ln2_b, 1e-12f, yout, S.st2, st)) == 1) {
+                if ((rc = gemm_dispatch(&g, st))) return rc;
+                SNAG_NU(ln_fwd_kernel, D, rgrid, st, (const float*)S.t2, NM, D, P.ln2_g, P.ln2_b, 1e-12f, yout, S.st2);
+                rc = check_launch("fusion LayerNorm 2");
+            }
+            if (rc) return rc;
         }
         xin = yout;
     }

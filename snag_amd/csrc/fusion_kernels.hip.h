@@ -462,21 +462,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ t
     if (row >= R) return;
     const int lane = threadIdx.x & 63;
     const Cols<NU> x = ld_cols<NU>(t + row * D, D, lane);
-    float s = 0.f;
-#pragma unroll
-    for (int u = 0; u < NU; ++u) s += x.v[u];
-    const float mean = sum64(s) / (float)D;
-    float vs = 0.f;
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const float dlt = (lane + 64 * u < D) ? x.v[u] - mean : 0.f;
-        vs = fmaf(dlt, dlt, vs);
-    }
-    const float rstd = 1.0f / sqrtf(sum64(vs) / (float)D + eps);
-    const Cols<NU> gg = ld_cols<NU>(g, D, lane), bb = ld_cols<NU>(b, D, lane);
     Cols<NU> o;
-#pragma unroll
-    for (int u = 0; u < NU; ++u) o.v[u] = (x.v[u] - mean) * rstd * gg.v[u] + bb.v[u];
+    float mean, rstd;
+    ln_row_forward<NU>(x.v, D, lane, g, b, eps, o.v, mean, rstd);
     st_cols<NU>(y + row * D, o, D, lane);
     if (lane == 0) {
         stats[2 * row] = mean;

@@ -283,6 +283,98 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(GemmOperands p, float al
 // VEC: every fetch is an unpredicated dwordx4 (all shapes of the hot path); otherwise the checked loader
 // Measured on one device (tools/tune_gemm.py, A/B builds): the unpredicated loader wins 15-25 % whenever an operand is
 // row-contiguous, but loses 5-20 % when both are K-contiguous, so those keep the checked loader.
+// The product AND the LayerNorm of its output rows in one launch (gemm_dispatch_ln): a 64 x 128 tile holds whole rows when N <= 128 (the
+// output projection of a D <= 128 Mformer layer: dense + dropout + residual, then LayerNorm -- model/SNAG_tools.py:218-222).  The
+// accumulators go through the LDS as one [64][132] tile; wave w then owns rows 16 w .. 16 w + 15: the epilogue value of column
+// lane + 64 u (Epilogue::one: bias, keep mask, residual), the row written to C (the backward reads the pre-LayerNorm sum), the row's
+// LayerNorm by ln_row_forward -- the arithmetic of ln_fwd_kernel, bit for bit -- written to y, (mean, rstd) to stats.
+struct LnTail {
+    const float *g, *b;
+    float eps;
+    float* y;
+    float* stats;
+};
+template <bool A_KC, bool B_KC, bool VEC>
+__global__ __launch_bounds__(256) void gemm_tile_ln_kernel(GemmOperands p, Epilogue e, LnTail t) {
+    using Core = GemmCore<64, 128, 32, 64, A_KC, B_KC, VEC>;
+    constexpr int P = 132;
+    constexpr int kSmem = Core::SMEM_FLOATS > 64 * P ? Core::SMEM_FLOATS : 64 * P;
+    __shared__ __attribute__((aligned(16))) float smem[kSmem];
+    const int m0 = blockIdx.x * 64;
+    Core core;
+    core.run(p, smem, m0, 0, 0, p.K);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = wave_id_uniform();
+    const int li = lane & 31, lh = lane >> 5, wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
+    lds_float* T = (lds_float*)smem;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) T[(wm0 + (q & 3) + 8 * (q >> 2) + 4 * lh) * P + wn0 + 32 * j + li] = core.acc[0][j][q];
+    __syncthreads();
+    const int N = p.N;
+    // Epilogue::one for act = 0 without pre / add2 (gemm_dispatch_ln admits nothing else), in its operation order: alpha, bias, keep mask, add1.
+    // Eight rows at a time, the side inputs of all eight requested before any is used: one round trip per group, not one per row.
+    const bool hb = e.bias != nullptr, hm = e.mask != nullptr, ha = e.add1 != nullptr;
+    float bv[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (hb && lane + 64 * u < N) bv[u] = e.bias[lane + 64 * u];
+    for (int r0 = 0; r0 < 16; r0 += 8) {
+        float x[8][2], av[8][2];
+        uint8_t kv[8][2];
+        if (hm) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int m = min(m0 + wave * 16 + r0 + q, p.M - 1), c = min(lane + 64 * u, N - 1);         // (clamped: rows / columns past the edge are never stored)
+                    kv[q][u] = e.mask[(int64_t)m * e.ldm + c];
+                }
+        }
+        if (ha) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int m = min(m0 + wave * 16 + r0 + q, p.M - 1), c = min(lane + 64 * u, N - 1);
+                    av[q][u] = e.add1[(int64_t)m * e.ld1 + c];
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = lane + 64 * u;
+                float v = T[(wave * 16 + r0 + q) * P + min(c, 127)] * e.alpha;
+                if (hb) v += bv[u];
+                if (hm) v = kv[q][u] ? v * e.mscale : 0.f;
+                if (ha) v += av[q][u];
+                x[q][u] = c < N ? v : 0.f;
+            }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = m0 + wave * 16 + r0 + q;
+            if (m < p.M) {                        // (wave-uniform)
+                float o[2], mean, rstd;
+                ln_row_forward<2>(x[q], N, lane, t.g, t.b, t.eps, o, mean, rstd);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = lane + 64 * u;
+                    if (c < N) {
+                        e.C[(int64_t)m * e.ldc + c] = x[q][u];
+                        t.y[(int64_t)m * N + c] = o[u];
+                    }
+                }
+                if (lane == 0) {
+                    t.stats[2 * (int64_t)m] = mean;
+                    t.stats[2 * (int64_t)m + 1] = rstd;
+                }
+            }
+        }
+    }
+}
+
 // presplit: the tile runs the pre-split loops (every tile a split-bf16 build instantiates), which look at VEC for K-contiguous operands
 // only; the f32-MFMA loops (run_loop: -DSNAG_GEMM_BF16X=0 builds, the 128 x 160 tile) issue unpredicated float4 loads under VEC and
 // need the full shape test.
@@ -539,6 +631,28 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     return rc;
 }
 
+int gemm_dispatch_ln(const snag_gemm_desc* d, const float* gamma, const float* beta, float eps, float* y, float* stats, hipStream_t st) {
+    if (d->M <= 0 || d->N <= 0 || d->N > 128 || d->workspace || d->accumulate || d->pre_act || d->mirror || d->c_transposed || d->act != 0 || d->add2) return 1;
+    const GemmPlan pl = plan_gemm(d);
+    if (pl.streamk || pl.big || pl.wide || pl.splits != 1) return 1;
+    const bool vec = use_vec(pl.p, d->a_kcontig, d->b_kcontig, GemmCore<64, 128, 32, 64, true, true, true>::kPresplit);
+    const LnTail t{gamma, beta, eps, y, stats};
+    if (log_shapes())
+        fprintf(stderr, "snag_gemm+LN M=%d N=%d K=%d a_kc=%d b_kc=%d tile=64x128\n", pl.p.M, pl.p.N, pl.p.K, (int)d->a_kcontig, (int)d->b_kcontig);
+    const dim3 grid(ceil_div(pl.p.M, 64)), block(256);
+#define SNAG_GEMM_LN(AK, BK_)                                                                                          \
+    do {                                                                                                               \
+        if (vec) hipLaunchKernelGGL((gemm_tile_ln_kernel<AK, BK_, true>), grid, block, 0, st, pl.p, pl.e, t);          \
+        else hipLaunchKernelGGL((gemm_tile_ln_kernel<AK, BK_, false>), grid, block, 0, st, pl.p, pl.e, t);             \
+    } while (0)
+    if (d->a_kcontig && d->b_kcontig) SNAG_GEMM_LN(true, true);
+    else if (d->a_kcontig && !d->b_kcontig) SNAG_GEMM_LN(true, false);
+    else if (!d->a_kcontig && d->b_kcontig) SNAG_GEMM_LN(false, true);
+    else SNAG_GEMM_LN(false, false);
+#undef SNAG_GEMM_LN
+    return check_launch("snag_gemm_f32 + LayerNorm");
+}
+
 // Two problems in one launch when the dispatcher decides the same for both (same shape, layouts, tile, split count, loader);
 // anything else runs them one after the other.
 int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStream_t st) {
@@ -646,6 +760,7 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
                     (int)ds[i]->b_kcontig, pp ? "256x128" : "64x128", pl[i].splits);
     }
     g.first[n] = blocks;
+    g.xcd = !pp && !ds[0]->a_kcontig && !ds[0]->b_kcontig;          // the weight-gradient shapes (dW = dY^T X): see gemm_tile_group_kernel
     const bool vec = use_vec(pl[0].p, ds[0]->a_kcontig, ds[0]->b_kcontig);
 #define SNAG_GROUPN(AK, BK_)                                                                                                              \
     do {                                                                                                                                  \

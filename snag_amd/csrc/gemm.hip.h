@@ -90,8 +90,9 @@ __device__ unsigned long long g_gemm_stamps[2 * 4 * 9];
 #define SNAG_GEMM_STREAM_ONLY 0          // timing experiment only (wrong products): the ping-pong loop issues the very same loads (both operands, same descriptors,
 #endif                                   // same order, same counted waits, same barriers) and the same slab stores, but no split, no LDS image, no fragment reads, no MFMA
 #ifndef SNAG_GEMM_QUAD_A
-#define SNAG_GEMM_QUAD_A 1               // ping-pong loop, K-contiguous A: rows fetched four lanes per row + a wave-private LDS transpose (QuadLoader); 0: FragLoader
-#endif
+#define SNAG_GEMM_QUAD_A 0               // A/B: 1 = ping-pong loop, K-contiguous A: rows fetched four lanes per row + a wave-private LDS transpose (QuadLoader).
+#endif                                   // Round 4: the stream alone gets faster (stream-only launch 81.5 -> 74.4 us in the step), the whole kernel does not
+                                         // (109-110 -> 112-115 us; similarity GEMM 1.74 -> 1.76-1.79 ms): the loop, not the stream, paces it (DESIGN.md par. 4)
 #ifndef SNAG_GEMM_PP_SETS
 #define SNAG_GEMM_PP_SETS 4              // ping-pong loop: register sets = k-tiles in flight per wave (tile t lives in set t % SETS)
 #endif
@@ -1395,14 +1396,22 @@ struct GemmGroup {
     int first[kGroupMax + 1];        // block ranges
     int tiles[kGroupMax], tiles_n[kGroupMax];
     int n;
+    int xcd;                         // 1: XCD-aware block -> (problem, split, tile) mapping
 };
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_group_kernel(GemmGroup<Epi> g) {
     using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
     __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
+    // Linear ids run problem by problem, split by split, tile by tile: neighbours share the k-range of their split -- the same slice of
+    // the narrow operand B.  Workgroups are dealt round-robin over the eight XCDs, so without the remap the tiles of one split land on
+    // eight different L2s and each fetches its own copy of that slice; with it every XCD owns a contiguous run of ids.
+    // (Set by the host for the weight-gradient groups only -- both operands row-contiguous, K = the entity rows, equal k-ranges per
+    // block: 40.8 -> 37.0 us.  Launches whose problems differ in work per block lose by it: an XCD that owns the short problem's run idles
+    // at the end -- first projections 110.5 -> 117.8 us, input-gradient group 38.0 -> 44.7.)
+    const int id = g.xcd ? xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     int q = 0;
-    while (q + 1 < g.n && (int)blockIdx.x >= g.first[q + 1]) ++q;
-    const int b = (int)blockIdx.x - g.first[q];
+    while (q + 1 < g.n && id >= g.first[q + 1]) ++q;
+    const int b = id - g.first[q];
     const int z = b / g.tiles[q], t = b % g.tiles[q];
     gemm_tile_at<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi>(g.p[q], g.e[q], g.slab[q], z, (t / g.tiles_n[q]) * BM, (t % g.tiles_n[q]) * BN, smem);
 }
