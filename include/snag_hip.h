@@ -366,6 +366,11 @@ typedef struct snag_small_mm {
     const float* A2; const float* B2;     /* optional second term with the same sizes and strides: C (=|+=) A B + A2 B2 (NULL: none) */
 } snag_small_mm;
 SNAG_API int snag_small_matmul(const snag_small_mm* problems, int n_problems, void* stream);
+/* snag_gemm_reduce_group (n <= 4 deferred K-split problems) AND up to four small products in ONE launch: the two jobs are independent
+ * (the small products must not read what the reduces write, nor write what they read) and each alone is a short, latency-bound launch --
+ * the reduce of the first projections' weight gradients and the chain rule of projection folding onto Wkv / l2_m run side by side
+ * instead of one after the other.  Results are those of the two separate calls, bit for bit.  n_small = 0: snag_gemm_reduce_group. */
+SNAG_API int snag_gemm_reduce_group_mm(const snag_gemm_desc* const* descs, int n, const snag_small_mm* small_products, int n_small, void* stream);
 
 /* Backward.  `f` is the forward's descriptor (same save buffer, still holding the forward's
  * activations; f.hidden etc. are not read).  Upstream gradients d_* may each be NULL (= zero).

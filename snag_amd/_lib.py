@@ -95,6 +95,7 @@ SIGNATURES = {
     "snag_gemm_f32": [_c.POINTER(GemmDesc), _P],
     "snag_gemm_reduce_pair": [_P, _P, _P],
     "snag_gemm_reduce_group": [_P, _c.c_int, _P],
+    "snag_gemm_reduce_group_mm": [_P, _c.c_int, _P, _c.c_int, _P],
     "snag_gemm_f32_group": [_P, _c.c_int, _P],
     "snag_gemm_f32_pair": [_c.POINTER(GemmDesc), _c.POINTER(GemmDesc), _P],
     "snag_fusion_fwd": [_c.POINTER(FusionDesc), _P],

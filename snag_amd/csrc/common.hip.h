@@ -112,7 +112,8 @@ int gemm_check(const snag_gemm_desc* d);
 int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st);
 int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStream_t st);
 int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st);   // 2..6 problems, one launch when their plans allow
-int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st);   // finishes problems launched with defer_reduce
+// finishes problems launched with defer_reduce (+ optionally up to four small products in the same launch)
+int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, const snag_small_mm* small = nullptr, int n_small = 0);
 int64_t gemm_workspace_floats(int M, int N, int K);
 // C = epilogue(A B) AND y = LayerNorm(C) (rows of y D = N wide, dense) in ONE launch, when the product runs as unsplit 64 x 128 tiles that hold
 // whole rows (N <= 128; K < 512 or M < 1024; no workspace, accumulate, pre_act, mirror or transposed store).  Returns 1 -- nothing launched --

@@ -6,6 +6,7 @@
 #include <algorithm>
 
 #include "gemm.hip.h"
+#include "small_mm.hip.h"
 
 namespace snag {
 
@@ -213,8 +214,13 @@ struct ReduceSet {
     int splits[4], mode[4], nblk[4];
     Epilogue e[4];
 };
-__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceSet rs) {
+// (blockIdx.y == n_reduce: the small products of snag_gemm_reduce_group_mm, one 16 x 16 output tile per workgroup)
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceSet rs, int n_reduce, SmallMMSet mm, int mm_blocks) {
     const int q = blockIdx.y;
+    if (q >= n_reduce) {
+        if ((int)blockIdx.x < mm_blocks) small_matmul_body(mm, (int)blockIdx.x);
+        return;
+    }
     if ((int)blockIdx.x >= rs.nblk[q]) return;
     if (rs.mode[q] == 2) splitk_reduce_small_body(rs.slab[q], rs.splits[q], rs.e[q], blockIdx.x);
     else if (rs.mode[q] == 1) splitk_reduce_body<true>(rs.slab[q], rs.splits[q], rs.e[q], (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)rs.nblk[q] * 256);
@@ -794,7 +800,13 @@ static int launch_reduce(const GemmPlan& pl, float* slab, hipStream_t st) {
 }
 
 // finishes up to four problems launched with defer_reduce (distinct workspaces): ONE launch for all that left slabs behind
-int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st) {
+int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, const snag_small_mm* small, int n_small) {
+    SmallMMSet mm{};
+    int mm_blocks = 0;
+    if (n_small > 0) {
+        mm_blocks = fill_small_mm(small, n_small, mm, "gemm_reduce_group_mm");
+        if (mm_blocks < 0) return mm_blocks;
+    }
     ReduceSet rs{};
     int cnt = 0, maxblk = 0;
     GemmPlan last{};
@@ -815,10 +827,10 @@ int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st) {
         last = pl; last_slab = d->workspace;
         ++cnt;
     }
-    if (cnt == 0) return SNAG_OK;
-    if (cnt == 1) return launch_reduce(last, last_slab, st);
-    hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(maxblk, cnt), dim3(256), 0, st, rs);
-    return check_launch("snag_gemm_reduce_pair");
+    if (cnt == 0 && mm_blocks == 0) return SNAG_OK;
+    if (cnt == 1 && mm_blocks == 0) return launch_reduce(last, last_slab, st);
+    hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(std::max(maxblk, mm_blocks), cnt + (mm_blocks > 0 ? 1 : 0)), dim3(256), 0, st, rs, cnt, mm, mm_blocks);
+    return check_launch("snag_gemm_reduce_group");
 }
 
 int gemm_reduce_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStream_t st) {
@@ -902,6 +914,17 @@ extern "C" SNAG_API int snag_gemm_reduce_group(const snag_gemm_desc* const* desc
         if (rc) return rc;
     }
     return gemm_reduce_multi(descs, n, (hipStream_t)stream);
+}
+
+extern "C" SNAG_API int snag_gemm_reduce_group_mm(const snag_gemm_desc* const* descs, int n, const snag_small_mm* small_products, int n_small, void* stream) {
+    SNAG_REQUIRE(n >= 0 && n <= 4 && (n == 0 || descs), SNAG_ERR_ARG, "gemm_reduce_group_mm: n=%d (0..4 problems per launch)", n);
+    SNAG_REQUIRE(n_small >= 0 && n_small <= 4 && (n_small == 0 || small_products), SNAG_ERR_ARG, "gemm_reduce_group_mm: n_small=%d (0..4 small products)", n_small);
+    for (int i = 0; i < n; ++i) {
+        SNAG_REQUIRE(descs[i], SNAG_ERR_ARG, "gemm_reduce_group_mm: null descriptor %d", i);
+        int rc = gemm_check(descs[i]);
+        if (rc) return rc;
+    }
+    return gemm_reduce_multi(descs, n, (hipStream_t)stream, small_products, n_small);
 }
 
 extern "C" SNAG_API int snag_gram_f32(const float* Z, int64_t ldz, int n, int k, float alpha, float* S, int64_t lds, void* stream) {

@@ -402,9 +402,10 @@ class MKGCHotPath:
                 return s
             s[i] += 1
 
-    def _grouped_long_k(self, descs, shapes, tags=None):
+    def _grouped_long_k(self, descs, shapes, tags=None, small=None):
         """Two long-K split-K GEMMs (the modalities' first projections, or their weight gradients) as ONE launch of eight-wave tiles with
-        balanced K splits + ONE reduce; False when the shapes do not qualify (the caller then launches them one by one)."""
+        balanced K splits + ONE reduce; False when the shapes do not qualify (the caller then launches them one by one).
+        ``small``: an array of independent snag_small_mm products that ride in the reduce launch (snag_gemm_reduce_group_mm)."""
         if len(descs) != 2 or self.cfg.dim > 128 or any(k < 512 for _, k in shapes) or max(m for m, _ in shapes) < 1024:
             return False
         order = sorted(range(2), key=lambda j: -shapes[j][0])          # the problem that picks the eight-wave tile on its own goes first
@@ -415,7 +416,10 @@ class MKGCHotPath:
             group[pos] = ctypes.pointer(descs[j])
         tag = tags[0] if tags else ""
         self._probed(tag, call, "snag_gemm_f32_group", group, 2, self._st)
-        self._probed((tag + "_reduce") if tag else "", call, "snag_gemm_reduce_pair", ctypes.byref(descs[0]), ctypes.byref(descs[1]), self._st)
+        if small is not None:
+            self._probed((tag + "_reduce") if tag else "", call, "snag_gemm_reduce_group_mm", group, 2, small, len(small), self._st)
+        else:
+            self._probed((tag + "_reduce") if tag else "", call, "snag_gemm_reduce_pair", ctypes.byref(descs[0]), ctypes.byref(descs[1]), self._st)
         return True
 
     def _fold_bwd_descs(self, defer):
@@ -432,6 +436,30 @@ class MKGCHotPath:
         dmid = [self._gemm_desc(Nl, D, 2 * D, dkv + 4 * i * 2 * D, 2 * MD, 1, ptr(self.wf[i]), D, 0, ptr(self.d_mid[i]), D, act=4, aux=ptr(self.mid[i]),
                                 ldaux=D, keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout), splitk=False) for i in range(nmod)]
         return dl2, dmid
+
+    def _fold_chain_products(self, i0=0):
+        """snag_small_mm array for modalities i0, i0 + 1: d l2_m = Wkv^T d Wf_m (disjoint outputs) and ONE two-term problem d Wkv += sum_m d Wf_m l2_m^T."""
+        cfg = self.cfg
+        D, nmod = cfg.dim, len(cfg.feat_dims)
+        wkv = self.p["layer0.wqkv"].data_ptr() + 4 * D * D
+        gkv = self.g["layer0.wqkv"].data_ptr() + 4 * D * D
+        n_here = min(2, nmod - i0)
+        probs = (_lib.SmallMM * (n_here + 1))()
+        for j in range(n_here):
+            i = i0 + j
+            a = probs[j]
+            a.M, a.N, a.K, a.accumulate = D, D, 2 * D, 0
+            a.A, a.sam, a.sak = wkv, 1, D
+            a.B, a.sbk, a.sbn = ptr(self.d_wf[i]), D, 1
+            a.C, a.ldc = ptr(self.g[f"proj{i}.l2"]), D
+        b2 = probs[n_here]
+        b2.M, b2.N, b2.K, b2.accumulate = 2 * D, D, D, 1
+        b2.A, b2.sam, b2.sak = ptr(self.d_wf[i0]), D, 1
+        b2.B, b2.sbk, b2.sbn = ptr(self.p[f"proj{i0}.l2"]), 1, D
+        if n_here == 2:
+            b2.A2, b2.B2 = ptr(self.d_wf[i0 + 1]), ptr(self.p[f"proj{i0 + 1}.l2"])
+        b2.C, b2.ldc = gkv, D
+        return probs
 
     def _gemm_pair(self, d0, d1):
         """Two same-shaped GEMMs (the two modalities' second projections / their backward) as ONE launch: each is a grid of fewer
@@ -837,6 +865,9 @@ class MKGCHotPath:
                     self._gemm_pair(group[i], group[i + 1])
                 if nmod % 2:
                     call("snag_gemm_f32", ctypes.byref(group[-1]), st)
+        # folded second projections, the chain rule onto the two factors of Wf_m = Wkv l2_m (d Wf_m is final by now):
+        #   d l2_m = Wkv^T d Wf_m ;  d Wkv += d Wf_m l2_m^T   (the read-out token's own contribution to d Wkv is already there)
+        chain, chain_done = (self._fold_chain_products() if (self.fold and nmod <= 2) else None), False
         dl1 = []
         for i, fd in enumerate(cfg.feat_dims):
             feat = self.noisy[i] if noisy else self.feats[i]
@@ -857,35 +888,19 @@ class MKGCHotPath:
             call("snag_gemm_f32", ctypes.byref(dl1[0]), st)
             call("snag_gemm_f32", ctypes.byref(dl1[1]), st)
             call("snag_gemm_reduce_group", group, 4, st)
-        elif reducer is None and self._grouped_long_k(dl1, [(fd, Nl) for fd in cfg.feat_dims]):
+        elif reducer is None and self._grouped_long_k(dl1, [(fd, Nl) for fd in cfg.feat_dims], small=chain):
             # (both weight gradients in ONE launch of eight-wave tiles: alone, the visual one fills the chip exactly -- 16 row tiles x 16
             # K splits -- and the text one then runs as a second, under-filled launch; together, 13 splits each, every CU walks the same
-            # k-range once: 78.5 + 30.4 -> 97.8 us)
-            pass
+            # k-range once: 78.5 + 30.4 -> 97.8 us.  The chain rule of projection folding -- parameter-sized products that depend on
+            # nothing this launch writes -- rides in its reduce launch: two latency-bound launches side by side instead of in a row.)
+            chain_done = chain is not None
         elif reducer is None:       # weight gradients of the first projections: two kernels, ONE reduce launch per pair of modalities
             self._gemm_deferred_pairs(dl1)
         if self.fold:
-            # d l2_m = Wkv^T d Wf_m ; d Wkv += d Wf_m l2_m^T   (the read-out token's own contribution to d Wkv is already there)
-            wkv = self.p["layer0.wqkv"].data_ptr() + 4 * D * D
-            gkv = self.g["layer0.wqkv"].data_ptr() + 4 * D * D
-            for i0 in range(0, nmod, 2):           # two modalities per launch: their d l2 (disjoint outputs) and ONE two-term problem for d Wkv
-                n_here = min(2, nmod - i0)
-                probs = (_lib.SmallMM * (n_here + 1))()
-                for j in range(n_here):
-                    i = i0 + j
-                    a = probs[j]
-                    a.M, a.N, a.K, a.accumulate = D, D, 2 * D, 0
-                    a.A, a.sam, a.sak = wkv, 1, D
-                    a.B, a.sbk, a.sbn = ptr(self.d_wf[i]), D, 1
-                    a.C, a.ldc = ptr(self.g[f"proj{i}.l2"]), D
-                b2 = probs[n_here]
-                b2.M, b2.N, b2.K, b2.accumulate = 2 * D, D, D, 1
-                b2.A, b2.sam, b2.sak = ptr(self.d_wf[i0]), D, 1
-                b2.B, b2.sbk, b2.sbn = ptr(self.p[f"proj{i0}.l2"]), 1, D
-                if n_here == 2:
-                    b2.A2, b2.B2 = ptr(self.d_wf[i0 + 1]), ptr(self.p[f"proj{i0 + 1}.l2"])
-                b2.C, b2.ldc = gkv, D
-                call("snag_small_matmul", probs, len(probs), st)
+            if not chain_done:
+                for i0 in range(0, nmod, 2):           # two modalities per launch: their d l2 (disjoint outputs) and ONE two-term problem for d Wkv
+                    probs = self._fold_chain_products(i0)
+                    call("snag_small_matmul", probs, len(probs), st)
             if reducer is not None:
                 reducer.start(buckets[1])
         bias_pair = cfg.num_proj == 1 and reducer is None and nmod == 2
