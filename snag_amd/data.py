@@ -221,25 +221,27 @@ def load_word_char_features(node_size, word2vec_path, args, logger):
             return pickle.load(f1), pickle.load(f2)
     word_vecs = load_word2vec(word2vec_path)
     ent_names, char2id = load_char_bigram(name_path)
+    n_gram = len(char2id)
     ent_vec = np.zeros((node_size, 300))
-    char_vec = np.zeros((node_size, len(char2id)))
-    for i, name in ent_names:
-        known = 0
-        for word in name:
-            word = word.lower()
-            if word in word_vecs:
-                ent_vec[i] += word_vecs[word]
-                known += 1
-            for j in range(len(word) - 1):
-                char_vec[i, char2id[word[j:j + 2]]] += 1
+    char_vec = np.zeros((node_size, n_gram))
+
+    def unit(v):
+        return v / np.linalg.norm(v)
+
+    for ent, name in ent_names:
+        words = [w.lower() for w in name]
+        # name row: what the row holds so far (zeros unless the id repeats) + the known words' vectors, added top to bottom, then the mean
+        known = [word_vecs[w] for w in words if w in word_vecs]
         if known:
-            ent_vec[i] /= known
+            row = np.add.reduce(np.vstack([ent_vec[ent]] + known), axis=0) / len(known)
         else:
-            ent_vec[i] = np.random.random(300) - 0.5
-        if np.sum(char_vec[i]) == 0:
-            char_vec[i] = np.random.random(len(char2id)) - 0.5
-        ent_vec[i] = ent_vec[i] / np.linalg.norm(ent_vec[i])
-        char_vec[i] = char_vec[i] / np.linalg.norm(char_vec[i])
+            row = np.random.random(300) - 0.5                     # global RNG, name draw first (src/data.py:353)
+        # bigram row: occurrence counts (integers: any order gives the same floats)
+        grams = np.fromiter((char2id[w[j:j + 2]] for w in words for j in range(len(w) - 1)), dtype=np.int64)
+        counts = char_vec[ent] + np.bincount(grams, minlength=n_gram)
+        if not counts.sum():
+            counts = np.random.random(n_gram) - 0.5               # ... then the char draw (:356)
+        ent_vec[ent], char_vec[ent] = unit(row), unit(counts)
     os.makedirs(osp.dirname(save_name), exist_ok=True)
     with open(save_name, "wb") as f:
         pickle.dump(ent_vec, f)

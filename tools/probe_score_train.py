@@ -1,5 +1,5 @@
 """Time the scorer's training forms on one device: fused one-launch (snag_score_margin_fwd_bwd) vs forward + backward + reduce.
-SNAG_SCORE_WPT=1|2|4 forces the waves-per-triple of the fused kernel (read once per process)."""
+(the waves-per-triple of the fused kernel are chosen by the library from the batch size)."""
 import os
 import sys
 
@@ -47,7 +47,7 @@ def main():
         by = B * ((K + 3) * D * 4 * 3 + (K + 3) * 4 + (K + 1) * 4)
         print(f"    segmented (no float atomics, overwrite): {t_seg:.2f} us = {by / t_seg / 8e6:.3f} of 8 TB/s on the same algorithmic bytes", flush=True)
         tf = timed(fused)
-        print(f"N={N} D={D} K={K} B={B} WPT={os.environ.get('SNAG_SCORE_WPT', 'auto')}: fused {tf:.2f} us ({by / tf / 1e3:.0f} GB/s algorithmic = "
+        print(f"N={N} D={D} K={K} B={B}: fused {tf:.2f} us ({by / tf / 1e3:.0f} GB/s algorithmic = "
               f"{by / tf / 8e6:.3f} of 8 TB/s; atomic floor {B * (K + 3) * D * 4 / 1.3e6:.1f} us), fused without loss sum {timed(fused_noloss):.2f}, "
               f"fwd {timed(fwd):.2f} + bwd {timed(bwd):.2f} + reduce {timed(red):.2f}", flush=True)
 
