@@ -89,6 +89,11 @@ __device__ unsigned long long g_gemm_stamps[2 * 4 * 9];
 #ifndef SNAG_GEMM_STREAM_ONLY
 #define SNAG_GEMM_STREAM_ONLY 0          // timing experiment only (wrong products): the ping-pong loop issues the very same loads (both operands, same descriptors,
 #endif                                   // same order, same counted waits, same barriers) and the same slab stores, but no split, no LDS image, no fragment reads, no MFMA
+#ifndef SNAG_GEMM_W64
+#define SNAG_GEMM_W64 0                  // A/B: the 256 x 128 tile as FOUR waves of 64 rows (GemmCore::kW64, one wave per SIMD) instead of the eight-wave ping-pong form
+#endif
+constexpr int kTallWM = SNAG_GEMM_W64 ? 64 : 32;            // wave rows of the 256-row tile, and its workgroup size
+constexpr int kTallThreads = SNAG_GEMM_W64 ? 256 : 512;
 #ifndef SNAG_GEMM_QUAD_A
 #define SNAG_GEMM_QUAD_A 0               // A/B: 1 = ping-pong loop, K-contiguous A: rows fetched four lanes per row + a wave-private LDS transpose (QuadLoader).
 #endif                                   // Round 4: the stream alone gets faster (stream-only launch 81.5 -> 74.4 us in the step), the whole kernel does not
@@ -686,17 +691,21 @@ struct GemmCore {
     static constexpr int NW = (BM / WM) * (BN / WN), NT = 64 * NW;       // waves / threads per workgroup
     static constexpr int STAGE_FLOATS = NW * 32 * CW;
     // pre-split staging loop: split-bf16 builds, 64 / 128-row operand tiles (the 128 x 160 tile keeps the in-fragment split)
-    static constexpr bool kPresplit = kBf16x != 0 && (BM == 64 || BM == 128 || (BM == 256 && WM == 32 && WN == BN)) && (BN == 64 || BN == 128) && kBK == 16 &&
+    static constexpr bool kPresplit = kBf16x != 0 && (BM == 64 || BM == 128 || (BM == 256 && (WM == 32 || WM == 64) && WN == BN)) && (BN == 64 || BN == 128) && kBK == 16 &&
                                       (SNAG_GEMM_PRESPLIT_KC != 0 || (!A_KC && !B_KC));
     // waves stacked along M (each wave's 32 rows are its own): the A operand never goes through the LDS (FragLoader)
     static constexpr bool kRowPrivate = kPresplit && WN == BN && WM == 32;
-    static constexpr int PS_STAGE_FLOATS = 6 * ((kRowPrivate ? 0 : BM) + BN) * 16 / 4;          // one stage: both images (B's only when row-private)
+    // FOUR waves, ONE per SIMD, each owning 64 rows x all BN columns (two row fragments x four column fragments = 128 accumulator
+    // registers): per k-tile 48 MFMAs against the same twelve B fragment reads and one barrier the 32-row forms spend on 24.  With a single
+    // wave per SIMD nothing hides a wait but the wave's own instruction stream: the loop is software-pipelined (run_w64).
+    static constexpr bool kW64 = kPresplit && WN == BN && WM == 64 && BM == 256;
+    static constexpr int PS_STAGE_FLOATS = 6 * (((kRowPrivate || kW64) ? 0 : BM) + BN) * 16 / 4;          // one stage: both images (B's only when row-private)
     // (the eight-wave ping-pong loop keeps THREE B images: a group reads the fragments of tile kt inside its matrix half, while the other
     // group is already writing tile kt+2 -- SNAG_GEMM_PP_LATE_READS)
     // eight-wave ping-pong loop with a K-contiguous A: the rows are fetched four lanes per row (QuadLoader) and change hands through a
     // wave-private 2 KiB LDS slot behind the B images
     static constexpr bool kQuadA = kPresplit && kRowPrivate && (BM / WM) * (BN / WN) == 8 && A_KC && SNAG_GEMM_QUAD_A;
-    static constexpr int PS_IMAGES = (kRowPrivate && (BM / WM) * (BN / WN) == 8 && SNAG_GEMM_PP_LATE_READS) ? 3 : 2;
+    static constexpr int PS_IMAGES = ((kRowPrivate && (BM / WM) * (BN / WN) == 8 && SNAG_GEMM_PP_LATE_READS) || kW64) ? 3 : 2;
     static constexpr int PS_FLOATS = kPresplit ? PS_IMAGES * PS_STAGE_FLOATS + (kQuadA ? 8 * 512 : 0) : 0;
     static constexpr int SMEM_FLOATS_ = TILE_FLOATS > STAGE_FLOATS ? TILE_FLOATS : STAGE_FLOATS;
     static constexpr int SMEM_FLOATS = kPresplit ? (PS_FLOATS > STAGE_FLOATS ? PS_FLOATS : STAGE_FLOATS) : SMEM_FLOATS_;
@@ -775,6 +784,91 @@ struct GemmCore {
         SNAG_MFMA_TERM(acc, h, m)
         SNAG_MFMA_TERM(acc, h, h)
 #undef SNAG_MFMA_TERM
+#endif
+    }
+
+    // kW64: A rows straight to registers (two FragLoaders per wave), B through three LDS images.  Iteration kt:
+    //   MFMAs of tile kt (a_cur x b_cur, both in registers)  ||  fragment reads of tile kt+1 (image (kt+1) % 3, published by the barrier at
+    //   the end of iteration kt-1) into b_nxt, the split of A tile kt+1 into a_nxt, the split + image write of B tile kt+2, the loads of
+    //   tile kt+1+SETS; then ONE barrier.  Everything beside the MFMAs is independent of them, so the scheduler may run it in their shadow.
+    __device__ __forceinline__ void run_w64(const GemmOperands& p, float* __restrict__ smem, int m0, int n0, int kbeg, int kend) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int tid = threadIdx.x, lane = tid & 63, wave = wave_id_uniform();
+        const int wm0 = wave * 64;
+        const int li = lane & 31, lh = lane >> 5;
+        unsigned char* const sm = reinterpret_cast<unsigned char*>(smem);
+        constexpr int IMG = 6 * BN * 16;                    // one B image, bytes
+        constexpr int S = 4;                                // register sets: tiles kt+2 .. kt+1+S in flight
+        const int kleft = kend - kbeg;
+        const int nk = kleft / 16;
+        FragLoader<A_KC, VEC> fa[2];
+        SplitStager<BN, B_KC, 256, VEC> sb;
+        fa[0].init(p.A, p.lda, p.a_vec, m0 + wm0, p.M, kbeg, lane);
+        fa[1].init(p.A, p.lda, p.a_vec, m0 + wm0 + 32, p.M, kbeg, lane);
+        sb.init(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, tid);
+        fa[0].ablate = fa[1].ablate = sb.ablate = 0;
+        Split3 a_cur[2], a_nxt[2], b_cur[TN], b_nxt[TN];
+        auto frags = [&](int img, Split3 (&b)[TN]) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + img * IMG, 32 * j + li, lh, b[j]);
+        };
+        if (nk > 0) {
+            // prologue: tiles 0 .. S-1 requested; B image 0 and 1 written; A tile 0 split; fragments of tile 0 read
+#pragma unroll
+            for (int q = 0; q < S; ++q) {
+                fa[0].load(q, q, kleft);
+                fa[1].load(q, q, kleft);
+                sb.load(q, q, kleft);
+            }
+            fa[0].split(0, a_cur[0]);
+            fa[1].split(0, a_cur[1]);
+            sb.split_store(0, sm);
+            sb.split_store(1, sm + IMG);
+            fa[0].load(0, S, kleft);
+            fa[1].load(0, S, kleft);
+            sb.load(0, S, kleft);
+            sb.load(1, S + 1, kleft);
+            __syncthreads();
+            frags(0, b_cur);
+            int rd = 1, wr = 2;                             // image of tile kt+1 (read now), of tile kt+2 (written now)
+            auto iteration = [&](int kt, auto SA, auto SB) {
+                constexpr int sa = decltype(SA)::value, sbs = decltype(SB)::value;       // A set of tile kt+1, B set of tile kt+2
+                frags(rd, b_nxt);
+                fa[0].split(sa, a_nxt[0]);
+                fa[1].split(sa, a_nxt[1]);
+                fa[0].load(sa, kt + 1 + S, kleft);
+                fa[1].load(sa, kt + 1 + S, kleft);
+                sb.split_store(sbs, sm + wr * IMG);
+                sb.load(sbs, kt + 2 + S, kleft);
+                mfma_split(a_cur, b_cur);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b_cur[j] = b_nxt[j];
+                __syncthreads();
+                rd = rd == 2 ? 0 : rd + 1;
+                wr = wr == 2 ? 0 : wr + 1;
+            };
+            for (int kt = 0; kt < nk; kt += 4) {            // whole quadruples: a tile past the end reads zeros through an empty descriptor
+                iteration(kt, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+                iteration(kt + 1, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
+                iteration(kt + 2, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+                iteration(kt + 3, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            }
+        }
+        if (kleft % 16 != 0) {
+            fa[0].load_tail(0, nk, kleft);
+            fa[1].load_tail(0, nk, kleft);
+            sb.load_tail(0, nk, kleft);
+            fa[0].split(0, a_cur[0]);
+            fa[1].split(0, a_cur[1]);
+            __syncthreads();                                // (every wave is done with the images of the loop)
+            sb.split_store(0, sm);
+            __syncthreads();
+            frags(0, b_cur);
+            mfma_split(a_cur, b_cur);
+            __syncthreads();
+        }
 #endif
     }
 
@@ -1086,7 +1180,10 @@ struct GemmCore {
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-            if (kend > kbeg) run_presplit(p, smem, m0, n0, kbeg, kend);
+            if (kend > kbeg) {
+                if constexpr (kW64) run_w64(p, smem, m0, n0, kbeg, kend);
+                else run_presplit(p, smem, m0, n0, kbeg, kend);
+            }
             return;
         }
         run_loop(p, smem, m0, n0, kbeg, kend);
