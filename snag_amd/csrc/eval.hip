@@ -534,7 +534,7 @@ static void launch_dist_gemm(const GemmOperands& p, const DistEpilogue& e, hipSt
     if (big_tiles >= 1024) {
         GemmOperands pg = p;
         pg.xcd = 1 | (4 << 4);
-        hipLaunchKernelGGL((gemm_tile_kernel<256, 128, kTallWM, 128, true, true, false, DistEpilogue>), dim3(ceil_div(p.N, 128), ceil_div(p.M, 256), 1), dim3(kTallThreads), 0, st, pg, e,
+        hipLaunchKernelGGL((gemm_tile_kernel<256, 128, 32, 128, true, true, false, DistEpilogue>), dim3(ceil_div(p.N, 128), ceil_div(p.M, 256), 1), dim3(512), 0, st, pg, e,
                            (float*)nullptr);
     } else if (big_tiles >= 512) {
         hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 64, 64, true, true, false, DistEpilogue>), gbig, dim3(256), 0, st, p, e, (float*)nullptr);

@@ -619,7 +619,7 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     if (pl.wide) launch_cfg<128, 160, 32, 160>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else
 #endif
-    if (pl.big && pl.pp) launch_cfg<256, 128, kTallWM, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
+    if (pl.big && pl.pp) launch_cfg<256, 128, 32, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else if (pl.big) launch_cfg<128, 128, 32, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else launch_cfg<64, 128, 32, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     int rc = check_launch("snag_gemm_f32");
@@ -770,8 +770,8 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
     const bool vec = use_vec(pl[0].p, ds[0]->a_kcontig, ds[0]->b_kcontig);
 #define SNAG_GROUPN(AK, BK_)                                                                                                              \
     do {                                                                                                                                  \
-        if (pp && vec) hipLaunchKernelGGL((gemm_tile_group_kernel<256, 128, kTallWM, 128, AK, BK_, true, Epilogue>), dim3(blocks), dim3(kTallThreads), 0, st, g);     \
-        else if (pp) hipLaunchKernelGGL((gemm_tile_group_kernel<256, 128, kTallWM, 128, AK, BK_, false, Epilogue>), dim3(blocks), dim3(kTallThreads), 0, st, g);      \
+        if (pp && vec) hipLaunchKernelGGL((gemm_tile_group_kernel<256, 128, 32, 128, AK, BK_, true, Epilogue>), dim3(blocks), dim3(512), 0, st, g);     \
+        else if (pp) hipLaunchKernelGGL((gemm_tile_group_kernel<256, 128, 32, 128, AK, BK_, false, Epilogue>), dim3(blocks), dim3(512), 0, st, g);      \
         else if (vec) hipLaunchKernelGGL((gemm_tile_group_kernel<64, 128, 32, 64, AK, BK_, true, Epilogue>), dim3(blocks), dim3(256), 0, st, g);     \
         else hipLaunchKernelGGL((gemm_tile_group_kernel<64, 128, 32, 64, AK, BK_, false, Epilogue>), dim3(blocks), dim3(256), 0, st, g);       \
     } while (0)

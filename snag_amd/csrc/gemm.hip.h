@@ -89,15 +89,11 @@ __device__ unsigned long long g_gemm_stamps[2 * 4 * 9];
 #ifndef SNAG_GEMM_STREAM_ONLY
 #define SNAG_GEMM_STREAM_ONLY 0          // timing experiment only (wrong products): the ping-pong loop issues the very same loads (both operands, same descriptors,
 #endif                                   // same order, same counted waits, same barriers) and the same slab stores, but no split, no LDS image, no fragment reads, no MFMA
-#ifndef SNAG_GEMM_W64
-#define SNAG_GEMM_W64 0                  // A/B: the 256 x 128 tile as FOUR waves of 64 rows (GemmCore::kW64, one wave per SIMD) instead of the eight-wave ping-pong form
-#endif
-constexpr int kTallWM = SNAG_GEMM_W64 ? 64 : 32;            // wave rows of the 256-row tile, and its workgroup size
-constexpr int kTallThreads = SNAG_GEMM_W64 ? 256 : 512;
-#ifndef SNAG_GEMM_QUAD_A
-#define SNAG_GEMM_QUAD_A 0               // A/B: 1 = ping-pong loop, K-contiguous A: rows fetched four lanes per row + a wave-private LDS transpose (QuadLoader).
-#endif                                   // Round 4: the stream alone gets faster (stream-only launch 81.5 -> 74.4 us in the step), the whole kernel does not
-                                         // (109-110 -> 112-115 us; similarity GEMM 1.74 -> 1.76-1.79 ms): the loop, not the stream, paces it (DESIGN.md par. 4)
+#ifndef SNAG_GEMM_PP_EARLY_H
+#define SNAG_GEMM_PP_EARLY_H 1           // ping-pong loop: the h planes of the B fragments (what the first four MFMAs multiply) are read at the END of the
+#endif                                   // memory half, in front of the barrier -- the image of tile kt has been complete for a whole interval by then.
+                                         // Same box, in the step: first projections 109.7 -> 106.3 us, similarity GEMM 1.628 -> 1.598 ms; the l plane
+                                         // there too: 101.0 vs 97.9 us for the weight gradients, 1.68 vs 1.63 ms; all three: 106 / 104 us, 1.71 ms
 #ifndef SNAG_GEMM_PP_SETS
 #define SNAG_GEMM_PP_SETS 4              // ping-pong loop: register sets = k-tiles in flight per wave (tile t lives in set t % SETS)
 #endif
@@ -569,102 +565,6 @@ struct FragLoader {
     }
 };
 
-// The same wave-private operand, K-contiguous, fetched in the shape the memory pipeline likes.  FragLoader's K-contiguous loads put 32 rows
-// into every wave-instruction (lane li <-> row li: the MFMA operand layout), 16 bytes each -- every group of 16 lanes touches 16 cache
-// lines.  Measured on the [15000, 4096] table, cold, same workgroups / register sets / barriers (tools/ubench/stream_rows.hip): that
-// shape streams at 3.6 TB/s, while FOUR ADJACENT LANES PER ROW (16 rows x 64 contiguous bytes per wave-instruction) reach 5.1 TB/s, the
-// plain linear read 5.3-5.5.  So: lane (r = lane / 4, c = lane % 4) loads chunk c (16 bytes) of rows r and r + 16 -- two dwordx4 per k-tile
-// as before -- and the 32 x 64-byte tile takes a trip through a wave-private 2 KiB LDS slot to change hands: written as it was
-// loaded (one contiguous KiB per instruction), read back as lane (li, lh) = chunks {lh, lh + 2} of row li.  Chunk c of row r sits at 16-byte
-// position c ^ ((r >> 2) & 3) of the row's 64 bytes, so that the 16 rows a ds_read_b128 group covers hit 16 different bank groups.  No
-// barrier: the slot is the wave's own, and one wave's DS operations execute in order (stage(t + 1) right behind fetch(t) is safe).
-template <bool VK = true>
-struct QuadLoader {
-    float r[SNAG_GEMM_PP_SETS < 4 ? 4 : SNAG_GEMM_PP_SETS][8];          // set s: [0..3] chunk c of row r, [4..7] chunk c of row r + 16
-    const char* ubase;
-    int64_t ldb;
-    uint32_t voff, voff2;
-    int c, vec, ablate;
-    int wr_off, wr_off2, rd_off, rd_off2;                                // byte offsets inside the wave's slot
-
-    __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, int vec_ok, int row0 /* of the wave */, int nrows, int kbeg, int lane) {
-        ldb = ld * 4;
-        vec = vec_ok;
-        const int r = lane >> 2;
-        c = lane & 3;
-        const int base = min(row0, nrows - 1);              // a wave wholly past the edge of the last tile reads the last row
-        ubase = reinterpret_cast<const char*>(P) + (int64_t)base * ldb + (int64_t)kbeg * 4;
-        voff = (uint32_t)(min(row0 + r, nrows - 1) - base) * (uint32_t)ldb + (uint32_t)c * 16u;
-        voff2 = (uint32_t)(min(row0 + r + 16, nrows - 1) - base) * (uint32_t)ldb + (uint32_t)c * 16u;
-        wr_off = r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
-        wr_off2 = (r + 16) * 64 + ((c ^ (((r + 16) >> 2) & 3)) << 4);
-        const int li = lane & 31, lh = lane >> 5, sw = (li >> 2) & 3;
-        rd_off = li * 64 + ((lh ^ sw) << 4);
-        rd_off2 = li * 64 + (((lh + 2) ^ sw) << 4);
-    }
-    __device__ __forceinline__ void load(int s, int kt, int kleft) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const int range = __builtin_amdgcn_readfirstlane(kt * 16 + 16 <= kleft && !(ablate && kt >= 2) ? (int)0xffffffffu : 0);
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, range, 0x00020000);
-        const uint32_t so = (uint32_t)kt * 64u;
-        if (VK || vec) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, i ? voff2 : voff, so, 0);
-                r[s][4 * i + 0] = __uint_as_float(v[0]);
-                r[s][4 * i + 1] = __uint_as_float(v[1]);
-                r[s][4 * i + 2] = __uint_as_float(v[2]);
-                r[s][4 * i + 3] = __uint_as_float(v[3]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) r[s][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (j < 4 ? voff : voff2) + 4 * (j & 3), so, 0));
-        }
-#endif
-    }
-    // the ragged last k-tile: element by element, k >= kend reads as zero
-    __device__ __forceinline__ void load_tail(int s, int kt, int kleft) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = kt * 16 + 4 * c + (j & 3);
-            const char* g = ubase + (j < 4 ? voff : voff2) + (int64_t)kt * 64 + 4 * (j & 3);
-            r[s][j] = k < kleft ? *reinterpret_cast<const float*>(g) : 0.f;
-        }
-    }
-    // register set s -> the wave's slot, as loaded
-    __device__ __forceinline__ void stage(int s, unsigned char* slot) const {
-#if defined(__HIP_DEVICE_COMPILE__)
-        auto* sl = (__attribute__((address_space(3))) unsigned char*)slot;
-        *(lds_float4*)(sl + wr_off) = make_float4(r[s][0], r[s][1], r[s][2], r[s][3]);
-        *(lds_float4*)(sl + wr_off2) = make_float4(r[s][4], r[s][5], r[s][6], r[s][7]);
-#endif
-    }
-    // the slot -> this lane's eight values in MFMA operand order (chunks lh and lh + 2 of row li)
-    __device__ __forceinline__ void fetch(const unsigned char* slot, float (&f)[8]) const {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const auto* sl = (const __attribute__((address_space(3))) unsigned char*)slot;
-        const float4 a = *(const lds_float4*)(sl + rd_off), b = *(const lds_float4*)(sl + rd_off2);
-        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
-        f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-#endif
-    }
-    __device__ __forceinline__ void sink(int s, uint32_t& acc) const {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc ^= __float_as_uint(r[s][j]);
-    }
-    static __device__ __forceinline__ void split(const float (&f)[8], Split3& o) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        uint32_t h[4], m[4], l[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) split_pair(f[2 * j], f[2 * j + 1], h[j], m[j], l[j]);
-        using u4 = __attribute__((ext_vector_type(4))) uint32_t;
-        o.h = __builtin_bit_cast(bf16x8, (u4){h[0], h[1], h[2], h[3]});
-        o.m = __builtin_bit_cast(bf16x8, (u4){m[0], m[1], m[2], m[3]});
-        o.l = __builtin_bit_cast(bf16x8, (u4){l[0], l[1], l[2], l[3]});
-#endif
-    }
-};
-
 // a lane's three operand pieces of one 32-row fragment: rows row0 .. row0+31 of an image with BR rows
 template <int BR>
 __device__ __forceinline__ void load_split_fragment(const unsigned char* image, int row, int lh, Split3& f) {
@@ -674,6 +574,17 @@ __device__ __forceinline__ void load_split_fragment(const unsigned char* image, 
     f.h = *(const lds_b8*)(im);
     f.m = *(const lds_b8*)(im + 2 * BR * 16);
     f.l = *(const lds_b8*)(im + 4 * BR * 16);
+#endif
+}
+
+// one plane (0 = h, 1 = m, 2 = l) of the same fragment
+template <int BR>
+__device__ __forceinline__ bf16x8 load_split_plane(const unsigned char* image, int row, int lh, int plane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using lds_b8 = __attribute__((address_space(3))) bf16x8;
+    return *(const lds_b8*)((const __attribute__((address_space(3))) unsigned char*)image + (lh * BR + row) * 16 + plane * 2 * BR * 16);
+#else
+    return bf16x8{};
 #endif
 }
 
@@ -691,22 +602,15 @@ struct GemmCore {
     static constexpr int NW = (BM / WM) * (BN / WN), NT = 64 * NW;       // waves / threads per workgroup
     static constexpr int STAGE_FLOATS = NW * 32 * CW;
     // pre-split staging loop: split-bf16 builds, 64 / 128-row operand tiles (the 128 x 160 tile keeps the in-fragment split)
-    static constexpr bool kPresplit = kBf16x != 0 && (BM == 64 || BM == 128 || (BM == 256 && (WM == 32 || WM == 64) && WN == BN)) && (BN == 64 || BN == 128) && kBK == 16 &&
+    static constexpr bool kPresplit = kBf16x != 0 && (BM == 64 || BM == 128 || (BM == 256 && WM == 32 && WN == BN)) && (BN == 64 || BN == 128) && kBK == 16 &&
                                       (SNAG_GEMM_PRESPLIT_KC != 0 || (!A_KC && !B_KC));
     // waves stacked along M (each wave's 32 rows are its own): the A operand never goes through the LDS (FragLoader)
     static constexpr bool kRowPrivate = kPresplit && WN == BN && WM == 32;
-    // FOUR waves, ONE per SIMD, each owning 64 rows x all BN columns (two row fragments x four column fragments = 128 accumulator
-    // registers): per k-tile 48 MFMAs against the same twelve B fragment reads and one barrier the 32-row forms spend on 24.  With a single
-    // wave per SIMD nothing hides a wait but the wave's own instruction stream: the loop is software-pipelined (run_w64).
-    static constexpr bool kW64 = kPresplit && WN == BN && WM == 64 && BM == 256;
-    static constexpr int PS_STAGE_FLOATS = 6 * (((kRowPrivate || kW64) ? 0 : BM) + BN) * 16 / 4;          // one stage: both images (B's only when row-private)
+    static constexpr int PS_STAGE_FLOATS = 6 * ((kRowPrivate ? 0 : BM) + BN) * 16 / 4;          // one stage: both images (B's only when row-private)
     // (the eight-wave ping-pong loop keeps THREE B images: a group reads the fragments of tile kt inside its matrix half, while the other
     // group is already writing tile kt+2 -- SNAG_GEMM_PP_LATE_READS)
-    // eight-wave ping-pong loop with a K-contiguous A: the rows are fetched four lanes per row (QuadLoader) and change hands through a
-    // wave-private 2 KiB LDS slot behind the B images
-    static constexpr bool kQuadA = kPresplit && kRowPrivate && (BM / WM) * (BN / WN) == 8 && A_KC && SNAG_GEMM_QUAD_A;
-    static constexpr int PS_IMAGES = ((kRowPrivate && (BM / WM) * (BN / WN) == 8 && SNAG_GEMM_PP_LATE_READS) || kW64) ? 3 : 2;
-    static constexpr int PS_FLOATS = kPresplit ? PS_IMAGES * PS_STAGE_FLOATS + (kQuadA ? 8 * 512 : 0) : 0;
+    static constexpr int PS_IMAGES = (kRowPrivate && (BM / WM) * (BN / WN) == 8 && SNAG_GEMM_PP_LATE_READS) ? 3 : 2;
+    static constexpr int PS_FLOATS = kPresplit ? PS_IMAGES * PS_STAGE_FLOATS : 0;
     static constexpr int SMEM_FLOATS_ = TILE_FLOATS > STAGE_FLOATS ? TILE_FLOATS : STAGE_FLOATS;
     static constexpr int SMEM_FLOATS = kPresplit ? (PS_FLOATS > STAGE_FLOATS ? PS_FLOATS : STAGE_FLOATS) : SMEM_FLOATS_;
     static_assert(NW == 4 || NW == 8, "four or eight waves per block");
@@ -787,91 +691,6 @@ struct GemmCore {
 #endif
     }
 
-    // kW64: A rows straight to registers (two FragLoaders per wave), B through three LDS images.  Iteration kt:
-    //   MFMAs of tile kt (a_cur x b_cur, both in registers)  ||  fragment reads of tile kt+1 (image (kt+1) % 3, published by the barrier at
-    //   the end of iteration kt-1) into b_nxt, the split of A tile kt+1 into a_nxt, the split + image write of B tile kt+2, the loads of
-    //   tile kt+1+SETS; then ONE barrier.  Everything beside the MFMAs is independent of them, so the scheduler may run it in their shadow.
-    __device__ __forceinline__ void run_w64(const GemmOperands& p, float* __restrict__ smem, int m0, int n0, int kbeg, int kend) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const int tid = threadIdx.x, lane = tid & 63, wave = wave_id_uniform();
-        const int wm0 = wave * 64;
-        const int li = lane & 31, lh = lane >> 5;
-        unsigned char* const sm = reinterpret_cast<unsigned char*>(smem);
-        constexpr int IMG = 6 * BN * 16;                    // one B image, bytes
-        constexpr int S = 4;                                // register sets: tiles kt+2 .. kt+1+S in flight
-        const int kleft = kend - kbeg;
-        const int nk = kleft / 16;
-        FragLoader<A_KC, VEC> fa[2];
-        SplitStager<BN, B_KC, 256, VEC> sb;
-        fa[0].init(p.A, p.lda, p.a_vec, m0 + wm0, p.M, kbeg, lane);
-        fa[1].init(p.A, p.lda, p.a_vec, m0 + wm0 + 32, p.M, kbeg, lane);
-        sb.init(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, tid);
-        fa[0].ablate = fa[1].ablate = sb.ablate = 0;
-        Split3 a_cur[2], a_nxt[2], b_cur[TN], b_nxt[TN];
-        auto frags = [&](int img, Split3 (&b)[TN]) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + img * IMG, 32 * j + li, lh, b[j]);
-        };
-        if (nk > 0) {
-            // prologue: tiles 0 .. S-1 requested; B image 0 and 1 written; A tile 0 split; fragments of tile 0 read
-#pragma unroll
-            for (int q = 0; q < S; ++q) {
-                fa[0].load(q, q, kleft);
-                fa[1].load(q, q, kleft);
-                sb.load(q, q, kleft);
-            }
-            fa[0].split(0, a_cur[0]);
-            fa[1].split(0, a_cur[1]);
-            sb.split_store(0, sm);
-            sb.split_store(1, sm + IMG);
-            fa[0].load(0, S, kleft);
-            fa[1].load(0, S, kleft);
-            sb.load(0, S, kleft);
-            sb.load(1, S + 1, kleft);
-            __syncthreads();
-            frags(0, b_cur);
-            int rd = 1, wr = 2;                             // image of tile kt+1 (read now), of tile kt+2 (written now)
-            auto iteration = [&](int kt, auto SA, auto SB) {
-                constexpr int sa = decltype(SA)::value, sbs = decltype(SB)::value;       // A set of tile kt+1, B set of tile kt+2
-                frags(rd, b_nxt);
-                fa[0].split(sa, a_nxt[0]);
-                fa[1].split(sa, a_nxt[1]);
-                fa[0].load(sa, kt + 1 + S, kleft);
-                fa[1].load(sa, kt + 1 + S, kleft);
-                sb.split_store(sbs, sm + wr * IMG);
-                sb.load(sbs, kt + 2 + S, kleft);
-                mfma_split(a_cur, b_cur);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a_cur[i] = a_nxt[i];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b_cur[j] = b_nxt[j];
-                __syncthreads();
-                rd = rd == 2 ? 0 : rd + 1;
-                wr = wr == 2 ? 0 : wr + 1;
-            };
-            for (int kt = 0; kt < nk; kt += 4) {            // whole quadruples: a tile past the end reads zeros through an empty descriptor
-                iteration(kt, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
-                iteration(kt + 1, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
-                iteration(kt + 2, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
-                iteration(kt + 3, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-            }
-        }
-        if (kleft % 16 != 0) {
-            fa[0].load_tail(0, nk, kleft);
-            fa[1].load_tail(0, nk, kleft);
-            sb.load_tail(0, nk, kleft);
-            fa[0].split(0, a_cur[0]);
-            fa[1].split(0, a_cur[1]);
-            __syncthreads();                                // (every wave is done with the images of the loop)
-            sb.split_store(0, sm);
-            __syncthreads();
-            frags(0, b_cur);
-            mfma_split(a_cur, b_cur);
-            __syncthreads();
-        }
-#endif
-    }
-
     __device__ __forceinline__ void run_presplit(const GemmOperands& p, float* __restrict__ smem, int m0, int n0, int kbeg, int kend) {
         const int tid = threadIdx.x, lane = tid & 63, wave = wave_id_uniform();
         const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
@@ -885,11 +704,9 @@ struct GemmCore {
             // A: registers only.  Iteration kt multiplies tile kt (A pieces split during iteration kt-1, B fragments out of buffer
             // kt & 1), splits A of tile kt+1 and stages B of tile kt+1 (register sets (kt+1) & 1), fetches tile kt+3 into those sets.
             static_assert(TM == 1, "row-private: one 32-row fragment per wave");
-            std::conditional_t<kQuadA, QuadLoader<VEC>, FragLoader<A_KC, VEC>> fa;
+            FragLoader<A_KC, VEC> fa;
             SplitStager<BN, B_KC, NT, VEC> sb;
             fa.init(p.A, p.lda, p.a_vec, m0 + wm0, p.M, kbeg, lane);
-            [[maybe_unused]] unsigned char* const aslot = sm + kPPImages * STAGE + wave * 2048;     // (QuadLoader) this wave's transpose slot
-            [[maybe_unused]] float afrag[8];                                                          // (QuadLoader) the fragment of the NEXT tile, fetched one iteration ahead
             sb.init(p.B, p.ldb, p.b_vec, n0, p.N, kbeg, tid);
             fa.ablate = p.dbg & 1;
             sb.ablate = p.dbg & 2;
@@ -903,25 +720,23 @@ struct GemmCore {
 #if defined(__HIP_DEVICE_COMPILE__) && SNAG_GEMM_PIN_READS
                 __builtin_amdgcn_sched_barrier(0);      // all fragment reads issue before anything else of the iteration (left alone, the
 #endif                                                  // compiler re-reads fragment by fragment right in front of each MFMA: exposed LDS latency)
-                if constexpr (!kQuadA) {            // (the four-wave form: FragLoader only)
 #if SNAG_GEMM_ABLATE
-                    if (!(p.dbg & 16)) fa.split(set, a_nxt[0]);
-                    if (!(p.dbg & 32)) fa.load(set, kt + 3, kleft);
-                    if (!(p.dbg & 16)) sb.split_store(set, sm + (cur ^ 1) * STAGE);
-                    if (!(p.dbg & 32)) sb.load(set, kt + 3, kleft);
-                    if (!(p.dbg & 8)) mfma_split(a_cur, b);
-                    a_cur[0] = a_nxt[0];
-                    if (!(p.dbg & 4)) __syncthreads();
+                if (!(p.dbg & 16)) fa.split(set, a_nxt[0]);
+                if (!(p.dbg & 32)) fa.load(set, kt + 3, kleft);
+                if (!(p.dbg & 16)) sb.split_store(set, sm + (cur ^ 1) * STAGE);
+                if (!(p.dbg & 32)) sb.load(set, kt + 3, kleft);
+                if (!(p.dbg & 8)) mfma_split(a_cur, b);
+                a_cur[0] = a_nxt[0];
+                if (!(p.dbg & 4)) __syncthreads();
 #else
-                    fa.split(set, a_nxt[0]);
-                    fa.load(set, kt + 3, kleft);
-                    sb.split_store(set, sm + (cur ^ 1) * STAGE);
-                    sb.load(set, kt + 3, kleft);
-                    mfma_split(a_cur, b);
-                    a_cur[0] = a_nxt[0];
-                    __syncthreads();
+                fa.split(set, a_nxt[0]);
+                fa.load(set, kt + 3, kleft);
+                sb.split_store(set, sm + (cur ^ 1) * STAGE);
+                sb.load(set, kt + 3, kleft);
+                mfma_split(a_cur, b);
+                a_cur[0] = a_nxt[0];
+                __syncthreads();
 #endif
-                }
             };
             // Eight waves: PING-PONG.  The two groups of four waves (one wave of each group per SIMD) run the same loop half an
             // iteration apart, and an iteration is cut by a barrier into its memory half (fragment reads, the A split, the group's
@@ -960,27 +775,15 @@ struct GemmCore {
 #else
                 constexpr bool do_asplit = true, do_bsplit = true, do_load = true;
 #endif
-                // A, K-contiguous (QuadLoader): tile kt+1's fragment was fetched an iteration ago; tile kt+2 (register set aset) changes hands
-                // through the wave's LDS slot now and its set is refilled with tile kt+2+SETS.  Otherwise: tile kt+1 is split where it landed.
-                constexpr int aset = kQuadA ? (set + 1) % kPPSets : set;
-                const int atile = kt + (kQuadA ? 2 : 1) + kPPSets;
 #if SNAG_GEMM_STREAM_ONLY
-                fa.sink(aset, stream_sink);
-                fa.load(aset, atile, kleft);
+                fa.sink(set, stream_sink);
+                fa.load(set, kt + 1 + kPPSets, kleft);
                 sb.sink(set, stream_sink);
                 sb.load(set, kt + 1 + kPPSets, kleft);
 #else
-                if constexpr (kQuadA) {
-                    if (do_asplit) {
-                        fa.split(afrag, a_nxt[0]);
-                        fa.stage(aset, aslot);
-                        fa.fetch(aslot, afrag);
-                    }
-                } else {
-                    if (do_asplit) fa.split(set, a_nxt[0]);
-                }
+                if (do_asplit) fa.split(set, a_nxt[0]);
                 SNAG_STAMP(set, 5);
-                if (do_load) fa.load(aset, atile, kleft);
+                if (do_load) fa.load(set, kt + 1 + kPPSets, kleft);
                 SNAG_STAMP(set, 6);
                 if (do_bsplit) sb.split_store(set, sm + wr_off);
                 SNAG_STAMP(set, 7);
@@ -989,12 +792,24 @@ struct GemmCore {
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
                 __builtin_amdgcn_sched_barrier(0);
+#if SNAG_GEMM_PP_LATE_READS && SNAG_GEMM_PP_EARLY_H && !SNAG_GEMM_STREAM_ONLY
+                // (tile kt's image was completed by the barrier that ended the PREVIOUS interval: both groups wrote their halves one and two
+                // intervals ago; nobody overwrites it before tile kt+3 is staged)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j].h = load_split_plane<BN>(sm + rd_off, wn0 + 32 * j + li, lh, 0);
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 SNAG_STAMP(set, 1);
                 __builtin_amdgcn_s_barrier();
                 SNAG_STAMP(set, 2);
                 __builtin_amdgcn_sched_barrier(0);
-#if SNAG_GEMM_PP_LATE_READS && !SNAG_GEMM_STREAM_ONLY
+#if SNAG_GEMM_PP_LATE_READS && SNAG_GEMM_PP_EARLY_H && !SNAG_GEMM_STREAM_ONLY
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    b[j].l = load_split_plane<BN>(sm + rd_off, wn0 + 32 * j + li, lh, 2);
+                    b[j].m = load_split_plane<BN>(sm + rd_off, wn0 + 32 * j + li, lh, 1);
+                }
+#elif SNAG_GEMM_PP_LATE_READS && !SNAG_GEMM_STREAM_ONLY
 #pragma unroll
                 for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + rd_off, wn0 + 32 * j + li, lh, b[j]);
 #endif
@@ -1025,18 +840,8 @@ struct GemmCore {
                         sb.load(q, q, kleft);
                     }
                 }
-                if constexpr (kQuadA) {
-                    fa.stage(0, aslot);                 // tile 0 -> operand order -> a_cur
-                    fa.fetch(aslot, afrag);
-                    fa.split(afrag, a_cur[0]);
-                    fa.load(0, kPPSets, kleft);
-                    fa.stage(1, aslot);                 // tile 1's fragment: split by iteration 0
-                    fa.fetch(aslot, afrag);
-                    fa.load(1, kPPSets + 1, kleft);
-                } else {
-                    fa.split(0, a_cur[0]);
-                    fa.load(0, kPingPong ? kPPSets : 2, kleft);
-                }
+                fa.split(0, a_cur[0]);
+                fa.load(0, kPingPong ? kPPSets : 2, kleft);
                 sb.split_store(0, sm);
                 sb.load(0, kPingPong ? kPPSets : 2, kleft);
                 __syncthreads();
@@ -1082,13 +887,7 @@ struct GemmCore {
             if (kleft % 16 != 0) {
                 fa.load_tail(0, nk, kleft);
                 sb.load_tail(0, nk, kleft);
-                if constexpr (kQuadA) {
-                    fa.stage(0, aslot);
-                    fa.fetch(aslot, afrag);
-                    fa.split(afrag, a_cur[0]);
-                } else {
-                    fa.split(0, a_cur[0]);
-                }
+                fa.split(0, a_cur[0]);
                 sb.split_store(0, sm);
                 __syncthreads();
                 Split3 b[TN];
@@ -1180,10 +979,7 @@ struct GemmCore {
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-            if (kend > kbeg) {
-                if constexpr (kW64) run_w64(p, smem, m0, n0, kbeg, kend);
-                else run_presplit(p, smem, m0, n0, kbeg, kend);
-            }
+            if (kend > kbeg) run_presplit(p, smem, m0, n0, kbeg, kend);
             return;
         }
         run_loop(p, smem, m0, n0, kbeg, kend);
