@@ -118,6 +118,29 @@ SNAG_API int snag_score_margin_fwd_bwd_seg(const float* ent, int64_t ent_ld, int
                           float* d_ent, int64_t d_ent_ld, float* d_rel, int write_untouched,
                           void* work, int64_t work_bytes, void* stream);
 
+/* snag_score_margin_fwd_bwd_seg when the entity table `ent` [n_ent, dim] (dense) IS the output of a LayerNorm -- the Mformer's read-out
+ * rows, model/SNAG_tools.py:218-222 -- and the gradient is wanted on the LayerNorm's INPUT: the 16-lane group of pass B that has just formed
+ * an entity's gradient row g applies the LayerNorm backward to it in registers, so the row never travels through memory:
+ *   dt[n]  = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)),  dxhat = g gamma,  xhat = (t[n] - mean) rstd     (every row written)
+ *   dtm[n] = dt[n] * keep[n] * keep_scale                         (NULL keep / dtm: not formed)
+ *   part[ceil(n_ent / 16)][3][dim]: per 16 rows, the column sums of g xhat (dgamma), g (dbeta) and dtm-or-dt (the bias gradient of the dense
+ *   layer in front of the LayerNorm); the caller reduces the slab over its rows (snag_fusion_bwd does, snag_fusion_bwd_desc.ln_bwd_done).
+ * The relation gradient d_rel and all scores / losses are those of snag_score_margin_fwd_bwd_seg; d_ent is not formed. */
+typedef struct snag_ln_bwd_tail {
+    const float* t;          /* [n_ent, dim] pre-LayerNorm rows */
+    const float* stats;      /* [n_ent, 2] (mean, rstd) of the forward */
+    const float* gamma;      /* [dim] */
+    const uint8_t* keep; int64_t keep_ld; float keep_scale;
+    float* dt;               /* [n_ent, dim] */
+    float* dtm;              /* [n_ent, dim] or NULL */
+    float* part;             /* [ceil(n_ent / 16), 3, dim] */
+} snag_ln_bwd_tail;
+SNAG_API int snag_score_margin_fwd_bwd_seg_ln(const float* ent, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+                          const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                          int64_t batch, int n_neg, float margin, float grad_scale,
+                          float* pos, float* neg, float* loss_part, float* loss, float* d_rel,
+                          void* work, int64_t work_bytes, const snag_ln_bwd_tail* tail, void* stream);
+
 /* The segmented form for tables far LARGER than a batch's footprint (BASELINE configs[4]: 1M entities, 134k entries per batch): pass A
  * additionally appends every destination to a compact list when it receives its FIRST entry (the slot atomic returns 0), and pass B
  * walks that list -- at most batch * (n_neg + 3) destinations -- instead of all n_ent + n_rel counters.  Only touched rows of d_ent /
@@ -365,6 +388,11 @@ typedef struct snag_small_mm {
     float* C; int64_t ldc;
     const float* A2; const float* B2;     /* optional second term with the same sizes and strides: C (=|+=) A B + A2 B2 (NULL: none) */
 } snag_small_mm;
+/* Where snag_fusion_bwd keeps what the LayerNorm backward of the read-out rows reads and writes (float offsets into f->save / the work
+ * buffer; read-out mode without FFN, N <= 16384): the pre-LayerNorm rows t [N, D] and (mean, rstd) [N, 2] in save; dt [N, D], dtm [N, D] and
+ * the partial slab [1024, 3, D] in work.  A caller that sets snag_fusion_bwd_desc.ln_bwd_done fills dt / dtm / the slab itself. */
+SNAG_API int snag_fusion_readout_ln_offsets(const snag_fusion_desc* f, int64_t* t_save_offset, int64_t* stats_save_offset, int64_t* dt_work_offset,
+                                            int64_t* dtm_work_offset, int64_t* part_work_offset);
 SNAG_API int snag_small_matmul(const snag_small_mm* problems, int n_problems, void* stream);
 /* snag_gemm_reduce_group (n <= 4 deferred K-split problems) AND up to four small products in ONE launch: the two jobs are independent
  * (the small products must not read what the reduces write, nor write what they read) and each alone is a short, latency-bound launch --
@@ -397,6 +425,10 @@ typedef struct snag_fusion_bwd_desc {
      *          with d Wo and the read-out token's d Wqkv; ONE reduce launch finishes all four. */
     const snag_gemm_desc* co_dx[2]; int32_t n_co_dx;
     const snag_gemm_desc* co_dw[2]; int32_t n_co_dw;
+    /* read-out mode without FFN: 1 = the LayerNorm backward of the read-out rows has been done by the caller's scorer
+     * (snag_score_margin_fwd_bwd_seg_ln wrote dt, dtm and its partial slab of ceil(N / 16) rows at the offsets of
+     * snag_fusion_readout_ln_offsets): d_hidden is not read, the backward starts at the output projection. */
+    int32_t ln_bwd_done;
 } snag_fusion_bwd_desc;
 
 SNAG_API int snag_fusion_bwd(const snag_fusion_bwd_desc* desc, void* stream);

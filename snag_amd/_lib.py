@@ -72,7 +72,13 @@ class FusionBwdDesc(_c.Structure):
     _fields_ = [("f", FusionDesc), ("d_joint", _P), ("d_joint_fz", _P), ("d_hidden", _P), ("d_weight_norm", _P),
                 ("d_x0", _P), ("grads", _c.POINTER(FusionLayerGrad)), ("d_weight_raw", _P), ("accumulate", _c.c_int32),
                 ("zero_d_hidden", _c.c_int32), ("d_slot_out", _P), ("d_slot_ld", _L), ("d_slot_rowmask", _P), ("d_slot_scale", _F),
-                ("co_dx", _c.POINTER(GemmDesc) * 2), ("n_co_dx", _c.c_int32), ("co_dw", _c.POINTER(GemmDesc) * 2), ("n_co_dw", _c.c_int32)]
+                ("co_dx", _c.POINTER(GemmDesc) * 2), ("n_co_dx", _c.c_int32), ("co_dw", _c.POINTER(GemmDesc) * 2), ("n_co_dw", _c.c_int32),
+                ("ln_bwd_done", _c.c_int32)]
+
+
+class LnBwdTail(_c.Structure):
+    """struct snag_ln_bwd_tail."""
+    _fields_ = [("t", _P), ("stats", _P), ("gamma", _P), ("keep", _P), ("keep_ld", _L), ("keep_scale", _F), ("dt", _P), ("dtm", _P), ("part", _P)]
 
 
 # name -> argtypes; every entry returns int (0 = enqueued) except the two listed in _SPECIAL
@@ -101,6 +107,8 @@ SIGNATURES = {
     "snag_fusion_fwd": [_c.POINTER(FusionDesc), _P],
     "snag_fusion_bwd": [_c.POINTER(FusionBwdDesc), _P],
     "snag_fusion_readout_offsets": [_c.POINTER(FusionDesc), _P, _P],
+    "snag_fusion_readout_ln_offsets": [_c.POINTER(FusionDesc), _P, _P, _P, _P, _P],
+    "snag_score_margin_fwd_bwd_seg_ln": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _L, _c.POINTER(LnBwdTail), _P],
     "snag_small_matmul": [_P, _I, _P],
     "snag_pack_tokens": [_c.POINTER(_P), _I, _L, _I, _I, _P, _P, _F, _P, _P],
     "snag_token_mean": [_P, _L, _I, _I, _P, _P],

@@ -367,9 +367,12 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             }
             float* dtm = P.keep_attn_out ? W.dB : nullptr;
             // (its slab [blocks][3][D] stays in W.part; the attention backward's goes behind it and ONE launch reduces both)
-            if ((rc = ln_bwd(dout, S.t1, S.st1, P.ln1_g, N, D, P.keep_attn_out ? P.keep_attn_out + (int64_t)ro * D : nullptr, kscale, W.dA, dtm, W.part,
-                             G.ln1_g, G.ln1_b, G.bo, acc, st, MD, zero_up, true))) return rc;
-            const int lnblocks = (int)std::min<int64_t>(kRedBlocks, (N + 3) / 4);
+            // ln_bwd_done: the caller's scorer has carried the gradient through this LayerNorm already (snag_score_margin_fwd_bwd_seg_ln wrote
+            // dA, dB and a slab of ceil(N / 16) rows at the offsets of snag_fusion_readout_ln_offsets)
+            const bool ln_done = b->ln_bwd_done != 0 && !ffn;
+            if (!ln_done && (rc = ln_bwd(dout, S.t1, S.st1, P.ln1_g, N, D, P.keep_attn_out ? P.keep_attn_out + (int64_t)ro * D : nullptr, kscale, W.dA, dtm, W.part,
+                                         G.ln1_g, G.ln1_b, G.bo, acc, st, MD, zero_up, true))) return rc;
+            const int lnblocks = ln_done ? ceil_div(N, 16) : (int)std::min<int64_t>(kRedBlocks, (N + 3) / 4);
             float* partq = W.part + (int64_t)kRedBlocks * 3 * D;
             const float* dz = dtm ? dtm : W.dA;
             // (dWo = dz^T ctx_g is launched further down, paired with dWq)
@@ -531,6 +534,25 @@ extern "C" SNAG_API int snag_fusion_readout_offsets(const snag_fusion_desc* f, i
     const SaveLayout lay(f->N, f->M, f->D, f->H, f->I, ffn);
     *qkv_save_offset = lay.per_layer * (f->L - 1);                       // LayerSave::qkv is the first region of a layer
     *dkv_work_offset = 3 * (int64_t)f->N * f->M * f->D;                  // Work: dA, dB, dC, then dqkv (dkv first)
+    return SNAG_OK;
+}
+
+extern "C" SNAG_API int snag_fusion_readout_ln_offsets(const snag_fusion_desc* f, int64_t* t_save_offset, int64_t* stats_save_offset, int64_t* dt_work_offset,
+                                                       int64_t* dtm_work_offset, int64_t* part_work_offset) {
+    SNAG_REQUIRE(f != nullptr && t_save_offset && stats_save_offset && dt_work_offset && dtm_work_offset && part_work_offset, SNAG_ERR_ARG,
+                 "fusion_readout_ln_offsets: null argument");
+    SNAG_REQUIRE(f->readout_slot_p1 > 0 && f->L >= 1 && !f->use_intermediate, SNAG_ERR_UNSUPPORTED, "fusion_readout_ln_offsets: read-out mode without FFN only");
+    SNAG_REQUIRE(ceil_div(f->N, 16) <= kRedBlocks, SNAG_ERR_UNSUPPORTED, "fusion_readout_ln_offsets: N = %d > %d rows (the slab holds %d partial rows of 16)", f->N,
+                 16 * kRedBlocks, kRedBlocks);
+    const SaveLayout lay(f->N, f->M, f->D, f->H, f->I, false);
+    float* const zero = nullptr;
+    const LayerSave S = lay.at(zero, f->L - 1);
+    const Work W = carve(zero, f->N, f->M, f->D, f->H, f->I, false);
+    *t_save_offset = S.t1 - zero;
+    *stats_save_offset = S.st1 - zero;
+    *dt_work_offset = W.dA - zero;
+    *dtm_work_offset = W.dB - zero;
+    *part_work_offset = W.part - zero;
     return SNAG_OK;
 }
 

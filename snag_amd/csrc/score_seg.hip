@@ -229,11 +229,16 @@ __global__ __launch_bounds__(256) void score_seg_a_kernel(
 // canonical order (by (row, weight) key, found with 16 in-group shuffles) and summed in fp32 in that order -- the slot order the
 // atomics of pass A produced varies from run to run, the sorted order does not.  Larger destinations (hubs, big batches) sum in
 // 64-bit fixed point instead, which is order-free.
-template <int NV>
+// LN: the entity table IS the output of a LayerNorm (the Mformer's read-out rows, model/SNAG_tools.py:218-222) and the caller wants the
+// gradient carried through it here: the group that has just formed its entity's gradient row g applies the LayerNorm backward to it in
+// registers -- dT = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)), dxhat = g gamma, the arithmetic of ln_bwd_kernel -- writes dT (and
+// dT * keep * scale), and the workgroup's 16 rows leave their sums of g xhat / g / dT(m) in part[block][3][dim] for the slab reduction the
+// fusion backward runs anyway.  d_ent is then not written at all.
+template <int NV, bool LN>
 __global__ __launch_bounds__(256) void score_seg_b_kernel(const float* __restrict__ ent, int64_t eld, const float* __restrict__ rel, int dim,
                                                           int n_ent, int n_dest, float* __restrict__ d_ent, int64_t dld, float* __restrict__ d_rel,
                                                           SegWork w, int write_untouched, const float* __restrict__ loss_part, int64_t batch,
-                                                          float* __restrict__ loss) {
+                                                          float* __restrict__ loss, snag_ln_bwd_tail tail) {
     if (blockIdx.x == gridDim.x - 1) {
         // the extra workgroup: loss = sum of the per-triple losses pass A left, in one fixed order (thread-strided partial sums, a wave
         // reduction each, the four wave sums added in wave order)
@@ -261,6 +266,25 @@ __global__ __launch_bounds__(256) void score_seg_b_kernel(const float* __restric
     const SegEntry mine = w.list[(int64_t)dest * w.cap + sub];
     const float* xrow = is_rel ? rel + (int64_t)(dest - n_ent) * dim : ent + (int64_t)dest * eld;      // (one load sequence, not two branches)
     Row4<NV> x = ld_row4<NV>(xrow, 0, 0, dim, sub);
+    // (LN: everything the LayerNorm backward of this row needs is requested in the same round trip)
+    [[maybe_unused]] const bool row_ok = have && !is_rel;
+    [[maybe_unused]] Row4<NV> tr, gam;
+    [[maybe_unused]] float ln_mean = 0.f, ln_rstd = 0.f;
+    [[maybe_unused]] uchar4 kk[NV];
+    if constexpr (LN) {
+        const int64_t lr = row_ok ? dest : 0;
+        tr = ld_row4<NV>(tail.t, lr, dim, dim, sub);
+        gam = ld_row4<NV>(tail.gamma, 0, 0, dim, sub);
+        ln_mean = tail.stats[2 * lr];
+        ln_rstd = tail.stats[2 * lr + 1];
+        if (tail.dtm != nullptr) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = (sub + 16 * j) * 4;
+                kk[j] = *reinterpret_cast<const uchar4*>(tail.keep + lr * tail.keep_ld + (c < dim ? c : 0));
+            }
+        }
+    }
     float* out = is_rel ? d_rel + (int64_t)(dest - n_ent) * dim : d_ent + (int64_t)dest * dld;
     Row4<NV> g;
 #pragma unroll
@@ -323,7 +347,81 @@ __global__ __launch_bounds__(256) void score_seg_b_kernel(const float* __restric
         }
     }
     normalize_bwd4<NV>(x, g);
-    if (have && (n > 0u || write_untouched)) st_row4<NV>(out, 0, 0, dim, sub, g);      // n == 0: g is exactly zero
+    if constexpr (!LN) {
+        if (have && (n > 0u || write_untouched)) st_row4<NV>(out, 0, 0, dim, sub, g);      // n == 0: g is exactly zero
+    } else {
+        if (have && is_rel && (n > 0u || write_untouched)) st_row4<NV>(out, 0, 0, dim, sub, g);
+        // ---- LayerNorm backward of the entity rows (every row: an untouched entity has g = 0 and contributes zeros) ----
+        __shared__ float red[4][3][64 * NV];
+        const float mean = ln_mean, rstd = ln_rstd;
+        Row4<NV> xh, dxh, o;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const bool in = (sub + 16 * j) * 4 < dim;
+            const float tv[4] = {tr.v[j].x, tr.v[j].y, tr.v[j].z, tr.v[j].w}, gv[4] = {g.v[j].x, g.v[j].y, g.v[j].z, g.v[j].w};
+            const float ga[4] = {gam.v[j].x, gam.v[j].y, gam.v[j].z, gam.v[j].w};
+            float xv[4], dv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[e] = in ? (tv[e] - mean) * rstd : 0.f;
+                dv[e] = gv[e] * ga[e];
+                s1 += dv[e];
+                s2 = fmaf(dv[e], xv[e], s2);
+            }
+            xh.v[j] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+            dxh.v[j] = make_float4(dv[0], dv[1], dv[2], dv[3]);
+        }
+        s1 = sum16(s1) / (float)dim;
+        s2 = sum16(s2) / (float)dim;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            o.v[j].x = rstd * (dxh.v[j].x - s1 - xh.v[j].x * s2); o.v[j].y = rstd * (dxh.v[j].y - s1 - xh.v[j].y * s2);
+            o.v[j].z = rstd * (dxh.v[j].z - s1 - xh.v[j].z * s2); o.v[j].w = rstd * (dxh.v[j].w - s1 - xh.v[j].w * s2);
+        }
+        if (row_ok) st_row4<NV>(tail.dt, dest, dim, dim, sub, o);
+        Row4<NV> z = o;
+        if (tail.dtm != nullptr) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const uchar4 k = kk[j];
+                z.v[j].x = k.x ? o.v[j].x * tail.keep_scale : 0.f; z.v[j].y = k.y ? o.v[j].y * tail.keep_scale : 0.f;
+                z.v[j].z = k.z ? o.v[j].z * tail.keep_scale : 0.f; z.v[j].w = k.w ? o.v[j].w * tail.keep_scale : 0.f;
+            }
+            if (row_ok) st_row4<NV>(tail.dtm, dest, dim, dim, sub, z);
+        }
+        // the workgroup's 16 rows: column sums of g xhat (dgamma), g (dbeta) and z (the bias gradient of the dense in front).  A wave's four
+        // rows meet in registers (two butterfly steps across its 16-lane groups), the four waves in LDS: a fixed order
+        const int wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = (sub + 16 * j) * 4;
+            float v[3][4] = {{g.v[j].x * xh.v[j].x, g.v[j].y * xh.v[j].y, g.v[j].z * xh.v[j].z, g.v[j].w * xh.v[j].w},
+                             {g.v[j].x, g.v[j].y, g.v[j].z, g.v[j].w},
+                             {z.v[j].x, z.v[j].y, z.v[j].z, z.v[j].w}};
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = row_ok ? v[q][e] : 0.f;
+                    t += __shfl_xor(t, 16);
+                    t += __shfl_xor(t, 32);
+                    v[q][e] = t;
+                }
+            if (lane < 16 && c < dim) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) *reinterpret_cast<float4*>(&red[wv][q][c]) = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+            }
+        }
+        __syncthreads();
+        const int first_row = (int)blockIdx.x * 16;
+        if (first_row < n_ent) {
+            for (int i = threadIdx.x; i < 3 * dim; i += 256) {
+                const int which = i / dim, c = i % dim;
+                tail.part[((int64_t)blockIdx.x * 3 + which) * dim + c] = ((red[0][which][c] + red[1][which][c]) + red[2][which][c]) + red[3][which][c];
+            }
+        }
+    }
 }
 
 }  // namespace snag
@@ -335,14 +433,22 @@ extern "C" SNAG_API int64_t snag_score_seg_work_bytes(int64_t n_ent, int64_t n_r
     return (int64_t)seg_work_bytes(n_ent, n_rel, batch, n_neg, dim);
 }
 
-extern "C" SNAG_API int snag_score_margin_fwd_bwd_seg(const float* ent, int64_t ent_ld, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
-                                                      const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
-                                                      int64_t batch, int n_neg, float margin, float grad_scale, float* pos, float* neg,
-                                                      float* loss_part, float* loss, uint32_t* ticket, float* d_ent, int64_t d_ent_ld,
-                                                      float* d_rel, int write_untouched, void* work, int64_t work_bytes, void* stream) {
-    (void)ticket;          // (the loss is summed by pass B since round 3: no last-block election, the ticket words are not touched)
-    SNAG_REQUIRE(ent && rel && d_ent && d_rel && work && (batch == 0 || loss_part), SNAG_ERR_ARG,
+static int score_seg_launch(const float* ent, int64_t ent_ld, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+                            const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                            int64_t batch, int n_neg, float margin, float grad_scale, float* pos, float* neg,
+                            float* loss_part, float* loss, float* d_ent, int64_t d_ent_ld,
+                            float* d_rel, int write_untouched, void* work, int64_t work_bytes, const snag_ln_bwd_tail* tail, void* stream) {
+    SNAG_REQUIRE(ent && rel && (d_ent || tail) && d_rel && work && (batch == 0 || loss_part), SNAG_ERR_ARG,
                  "score_fwd_bwd_seg: null table / gradient / workspace / loss_part");
+    if (tail != nullptr) {
+        SNAG_REQUIRE(tail->t && tail->stats && tail->gamma && tail->dt && tail->part, SNAG_ERR_ARG, "score_fwd_bwd_seg_ln: null t / stats / gamma / dt / part");
+        SNAG_REQUIRE((tail->dtm == nullptr) == (tail->keep == nullptr) && (tail->keep == nullptr || (tail->keep_ld >= dim && tail->keep_ld % 4 == 0 && ((uintptr_t)tail->keep & 3) == 0)),
+                     SNAG_ERR_ARG, "score_fwd_bwd_seg_ln: dtm and keep come together; the mask rows must be 4-byte addressable");
+        SNAG_REQUIRE(ent_ld == dim && write_untouched, SNAG_ERR_UNSUPPORTED, "score_fwd_bwd_seg_ln: the table must be the dense [n_ent, dim] LayerNorm output, every row written");
+        SNAG_REQUIRE((((uintptr_t)tail->t | (uintptr_t)tail->gamma | (uintptr_t)tail->dt | (uintptr_t)tail->dtm) & 15) == 0, SNAG_ERR_UNSUPPORTED,
+                     "score_fwd_bwd_seg_ln: t / gamma / dt / dtm must be 16-byte aligned");
+        if (d_ent == nullptr) { d_ent = tail->dt; d_ent_ld = dim; }           // (never written in this form; keeps the checks below uniform)
+    }
     SNAG_REQUIRE(n_ent > 0 && n_rel > 0 && dim > 0 && batch >= 0 && n_neg >= 0, SNAG_ERR_ARG, "score_fwd_bwd_seg: bad sizes");
     SNAG_REQUIRE(idx_bytes == 4 || idx_bytes == 8, SNAG_ERR_ARG, "score_fwd_bwd_seg: idx_bytes=%d (want 4 or 8)", idx_bytes);
     SNAG_REQUIRE(dim <= 512 && dim % 4 == 0 && ent_ld % 4 == 0 && d_ent_ld % 4 == 0 && ent_ld >= dim && d_ent_ld >= dim, SNAG_ERR_UNSUPPORTED,
@@ -378,8 +484,11 @@ extern "C" SNAG_API int snag_score_margin_fwd_bwd_seg(const float* ent, int64_t 
     }
     // (+ 1: the workgroup that sums the per-triple losses; with an empty batch it writes loss = 0)
     const dim3 gridb((unsigned)ceil_div((int64_t)n_dest * 16, 256) + 1), block(256);
-#define SNAG_SEG_B(NV) hipLaunchKernelGGL((score_seg_b_kernel<NV>), gridb, block, 0, st, ent, ent_ld, rel, dim, (int)n_ent, n_dest, d_ent, d_ent_ld, d_rel, w, write_untouched, \
-                                          (const float*)loss_part, batch, loss)
+    const snag_ln_bwd_tail tl = tail ? *tail : snag_ln_bwd_tail{};
+#define SNAG_SEG_B(NV) do { if (tail) hipLaunchKernelGGL((score_seg_b_kernel<NV, true>), gridb, block, 0, st, ent, ent_ld, rel, dim, (int)n_ent, n_dest, d_ent, d_ent_ld, d_rel, w, \
+                                                          write_untouched, (const float*)loss_part, batch, loss, tl); \
+                            else hipLaunchKernelGGL((score_seg_b_kernel<NV, false>), gridb, block, 0, st, ent, ent_ld, rel, dim, (int)n_ent, n_dest, d_ent, d_ent_ld, d_rel, w, \
+                                                    write_untouched, (const float*)loss_part, batch, loss, tl); } while (0)
     switch (nv) {
         case 1: SNAG_SEG_B(1); break;
         case 2: SNAG_SEG_B(2); break;
@@ -391,3 +500,24 @@ extern "C" SNAG_API int snag_score_margin_fwd_bwd_seg(const float* ent, int64_t 
 #undef SNAG_SEG_B
     return check_launch("snag_score_margin_fwd_bwd_seg (pass B)");
 }
+
+extern "C" SNAG_API int snag_score_margin_fwd_bwd_seg(const float* ent, int64_t ent_ld, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+                                                      const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                                                      int64_t batch, int n_neg, float margin, float grad_scale, float* pos, float* neg,
+                                                      float* loss_part, float* loss, uint32_t* ticket, float* d_ent, int64_t d_ent_ld,
+                                                      float* d_rel, int write_untouched, void* work, int64_t work_bytes, void* stream) {
+    (void)ticket;          // (the loss is summed by pass B since round 3: no last-block election, the ticket words are not touched)
+    return score_seg_launch(ent, ent_ld, n_ent, rel, n_rel, dim, h, r, t, neg_t, idx_bytes, batch, n_neg, margin, grad_scale, pos, neg, loss_part, loss, d_ent, d_ent_ld,
+                            d_rel, write_untouched, work, work_bytes, nullptr, stream);
+}
+
+extern "C" SNAG_API int snag_score_margin_fwd_bwd_seg_ln(const float* ent, int64_t n_ent, const float* rel, int64_t n_rel, int dim,
+                                                         const void* h, const void* r, const void* t, const void* neg_t, int idx_bytes,
+                                                         int64_t batch, int n_neg, float margin, float grad_scale, float* pos, float* neg,
+                                                         float* loss_part, float* loss, float* d_rel, void* work, int64_t work_bytes,
+                                                         const snag_ln_bwd_tail* tail, void* stream) {
+    SNAG_REQUIRE(tail != nullptr, SNAG_ERR_ARG, "score_fwd_bwd_seg_ln: null tail");
+    return score_seg_launch(ent, dim, n_ent, rel, n_rel, dim, h, r, t, neg_t, idx_bytes, batch, n_neg, margin, grad_scale, pos, neg, loss_part, loss, nullptr, dim,
+                            d_rel, 1, work, work_bytes, tail, stream);
+}
+

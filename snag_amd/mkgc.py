@@ -365,6 +365,20 @@ class MKGCHotPath:
         b.d_weight_raw = ptr(self.g["weight_raw"]) if cfg.joint_way == "learnable_weight" else None
         b.accumulate = 0
         self._bdesc = b
+        # The scorer's per-destination pass carries the gradient through the read-out rows' LayerNorm itself (snag_score_margin_fwd_bwd_seg_ln:
+        # the row never travels through memory, the LayerNorm backward launch disappears) when the scorer's table IS that LayerNorm's output:
+        # read-out-only hd_graph without FFN, one rank, at most 16,384 rows (the partial slab holds 1,024 rows of 16)
+        self._ln_fuse = (self.ro and not ffn and not self.shard.sharded and cfg.scorer == "segmented" and cfg.loss == "hinge" and self.sdim % 4 == 0
+                         and -(-self.shard.n_loc // 16) <= 1024)
+        if self._ln_fuse:
+            offs = [ctypes.c_int64() for _ in range(5)]
+            call("snag_fusion_readout_ln_offsets", ctypes.byref(d), *[ctypes.byref(o) for o in offs])
+            t_off, st_off, dt_off, dtm_off, part_off = (o.value for o in offs)
+            tl = _lib.LnBwdTail()
+            tl.t, tl.stats = self.save.data_ptr() + 4 * t_off, self.save.data_ptr() + 4 * st_off
+            tl.gamma = ptr(self.p[f"layer{L - 1}.ln1_g"])
+            tl.dt, tl.part = self.work.data_ptr() + 4 * dt_off, self.work.data_ptr() + 4 * part_off
+            self._ln_tail, self._ln_dtm = tl, self.work.data_ptr() + 4 * dtm_off
         self._set_dropout(self.training)
 
     def _set_dropout(self, on):
@@ -374,6 +388,14 @@ class MKGCHotPath:
             self._layers[l].keep_ffn_out = ptr(self.keep_ffn[l]) if (on and self.keep_ffn) else None
         self._bdesc.f = self._fdesc
         self._bdesc.f.n_co_fwd = 0           # (the forward's co-launched products are the forward call's alone)
+        if getattr(self, "_ln_fuse", False):
+            # the read-out token's rows of the output projection's dropout mask (row stride M * D), as the LayerNorm backward takes them
+            cfg, tl, l = self.cfg, self._ln_tail, self.cfg.num_layers - 1
+            if on:
+                tl.keep, tl.keep_ld, tl.keep_scale = self.keep_attn[l].data_ptr() + self.g_slot * cfg.dim, cfg.n_tokens * cfg.dim, 1.0 / (1.0 - cfg.dropout)
+                tl.dtm = self._ln_dtm
+            else:
+                tl.keep, tl.keep_ld, tl.keep_scale, tl.dtm = None, 0, 1.0, None
 
     def train(self, mode=True):
         self.training = bool(mode)
@@ -604,6 +626,7 @@ class MKGCHotPath:
         N, D, M = cfg.n_ent, cfg.dim, cfg.n_tokens
         Nl, lo = self.shard.n_loc, self.shard.lo               # this rank's entity rows (all of them with one rank)
         st = self._st = stream()
+        self._bdesc.ln_bwd_done = 0
         noisy = self.training and cfg.add_noise and self.noise_active
         if self.keep_proj is not None and self.training:
             call("snag_bernoulli_regions", self._proj_regions, len(self._proj_regions), ptr(self.tick), st)
@@ -716,9 +739,15 @@ class MKGCHotPath:
             else:
                 tgt, tld = self.d_repr.data_ptr(), self.sdim
             work = self._seg_workspace(B, K)
-            self._probed("score_fwd_bwd", call, "snag_score_margin_fwd_bwd_seg", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D,
-                         ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K, float(cfg.margin), float(grad_scale), ptr(self._pos), ptr(self._neg),
-                         ptr(self._loss_part), ptr(self.loss), ptr(self._ticket), tgt, tld, ptr(self.g["rel"]), 1, ptr(work), work.numel(), st)
+            if self._ln_fuse:
+                self._probed("score_fwd_bwd", call, "snag_score_margin_fwd_bwd_seg_ln", self._repr, N, ptr(self.p["rel"]), cfg.n_rel, D,
+                             ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K, float(cfg.margin), float(grad_scale), ptr(self._pos), ptr(self._neg),
+                             ptr(self._loss_part), ptr(self.loss), ptr(self.g["rel"]), ptr(work), work.numel(), ctypes.byref(self._ln_tail), st)
+            else:
+                self._probed("score_fwd_bwd", call, "snag_score_margin_fwd_bwd_seg", self._repr, self._repr_ld, N, ptr(self.p["rel"]), cfg.n_rel, D,
+                             ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K, float(cfg.margin), float(grad_scale), ptr(self._pos), ptr(self._neg),
+                             ptr(self._loss_part), ptr(self.loss), ptr(self._ticket), tgt, tld, ptr(self.g["rel"]), 1, ptr(work), work.numel(), st)
+            self._bdesc.ln_bwd_done = int(self._ln_fuse)
             self._score_bwd_scale = float(grad_scale)
             self._d_repr_clean = False
             self._mark("score")

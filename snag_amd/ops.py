@@ -189,6 +189,42 @@ def score_margin_fwd_bwd_seg(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, d
     return loss, pos, neg, loss_part, d_ent, d_rel
 
 
+def score_margin_fwd_bwd_seg_ln(t_pre, gamma, beta, rel, h, r, t, neg_t, margin, grad_scale=1.0, keep=None, keep_p=0.0, eps=1e-12):
+    """The segmented hinge scorer on the table ent = LayerNorm(t_pre) (formed here with torch, as the Mformer's read-out rows are by the
+    fusion forward), its entity gradient carried through the LayerNorm inside the per-destination pass:
+    -> (loss, pos, neg, dt [N, D], dtm or None, dgamma, dbeta, dcol [D] (column sums of dtm-or-dt), d_rel).
+    C ABI: snag_score_margin_fwd_bwd_seg_ln (the partial slab is reduced here with torch, in slab order)."""
+    _rows(t_pre, "t_pre"), _chk(rel, "rel", ndim=2)
+    N, D = t_pre.shape
+    R = rel.shape[0]
+    mean = t_pre.mean(dim=1, keepdim=True)
+    var = ((t_pre - mean) ** 2).mean(dim=1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    ent = ((t_pre - mean) * rstd * gamma + beta).contiguous()
+    stats = torch.cat([mean, rstd], dim=1).contiguous()
+    B, K, ib = _idx_group(h, r, t, neg_t)
+    nbytes = _lib.load().snag_score_seg_work_bytes(N, R, B, K, D)
+    work = torch.zeros((nbytes + 255) // 256 * 256, device=ent.device, dtype=torch.uint8)
+    pos, neg = torch.empty(B, device=ent.device, dtype=f32), torch.empty(B, K, device=ent.device, dtype=f32)
+    loss_part, loss = torch.empty(B, device=ent.device, dtype=f32), torch.empty((), device=ent.device, dtype=f32)
+    d_rel = torch.empty_like(rel)
+    nblk = (N + 15) // 16
+    dt = torch.empty(N, D, device=ent.device, dtype=f32)
+    dtm = torch.empty(N, D, device=ent.device, dtype=f32) if keep is not None else None
+    part = torch.zeros(nblk, 3, D, device=ent.device, dtype=f32)
+    tl = _lib.LnBwdTail()
+    tl.t, tl.stats, tl.gamma = ptr(t_pre), ptr(stats), ptr(gamma)
+    if keep is not None:
+        _chk(keep, "keep", dtype=torch.uint8, ndim=2)
+        tl.keep, tl.keep_ld, tl.keep_scale, tl.dtm = ptr(keep), keep.stride(0), 1.0 / (1.0 - keep_p), ptr(dtm)
+    tl.dt, tl.part = ptr(dt), ptr(part)
+    import ctypes
+    call("snag_score_margin_fwd_bwd_seg_ln", ptr(ent), N, ptr(rel), R, D, ptr(h), ptr(r), ptr(t), ptr(neg_t), ib, B, K, float(margin), float(grad_scale),
+         ptr(pos), ptr(neg), ptr(loss_part), ptr(loss), ptr(d_rel), ptr(work), work.numel(), ctypes.byref(tl), stream())
+    sums = part.sum(dim=0)
+    return loss, pos, neg, dt, dtm, sums[0], sums[1], sums[2], d_rel, ent
+
+
 _TOUCHED_WORK = {}
 
 

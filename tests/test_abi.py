@@ -127,7 +127,8 @@ def _structs():
 def test_ctypes_structures_match_the_header_structs():
     from snag_amd import _lib
     pairs = {"snag_gemm_desc": _lib.GemmDesc, "snag_fusion_layer": _lib.FusionLayer, "snag_fusion_layer_grad": _lib.FusionLayerGrad,
-             "snag_fusion_desc": _lib.FusionDesc, "snag_fusion_bwd_desc": _lib.FusionBwdDesc, "snag_mask_region": _lib.MaskRegion, "snag_small_mm": _lib.SmallMM}
+             "snag_fusion_desc": _lib.FusionDesc, "snag_fusion_bwd_desc": _lib.FusionBwdDesc, "snag_mask_region": _lib.MaskRegion, "snag_small_mm": _lib.SmallMM,
+             "snag_ln_bwd_tail": _lib.LnBwdTail}
     structs = _structs()
     assert set(structs) == set(pairs)
 

@@ -399,3 +399,37 @@ def test_score_bwd_fixed_point_is_reproducible_and_equal_to_the_float_path():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert_close(a[0], de_ref, atol=1e-5 * float(de_ref.abs().max()), rtol=1e-5)
     assert_close(a[1], dr_ref, atol=1e-5 * float(dr_ref.abs().max()), rtol=1e-5)
+
+
+@pytest.mark.parametrize("N,R,D,B,K,masked", [(700, 9, 128, 100, 32, True), (700, 9, 128, 100, 32, False), (333, 3, 64, 40, 5, True), (1000, 5, 256, 64, 16, True),
+                                              (17, 1, 8, 5, 2, True), (15000, 558, 128, 1024, 32, True)])
+def test_score_segmented_entry_with_layernorm_backward(N, R, D, B, K, masked):
+    """snag_score_margin_fwd_bwd_seg_ln: the scorer's table is LayerNorm(t) and the per-destination pass carries the gradient through the
+    LayerNorm itself.  Scores / loss / d_rel equal the plain segmented entry's bits; dt, dtm and the three column sums equal torch autograd
+    through layer_norm (fp64) on the same table (model/SNAG_tools.py:218-222 backward; model/MSNEA.py:110-122)."""
+    from snag_amd import ops
+    g = torch.Generator().manual_seed(N + D + K)
+    t_pre = torch.randn(N, D, generator=g)
+    gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    rel = torch.randn(R, D, generator=g) * 0.5
+    h, r, t = (torch.randint(0, hi, (B,), generator=g, dtype=torch.int32) for hi in (N, R, N))
+    neg = torch.randint(0, N, (B, K), generator=g, dtype=torch.int32)
+    keep = (torch.rand(N, D, generator=g) > 0.1).to(torch.uint8) if masked else None
+    dev = [x.to(DEV) for x in (t_pre, gamma, beta, rel, h, r, t, neg)]
+    loss, pos, ng, dt, dtm, dgam, dbet, dcol, d_rel, ent = ops.score_margin_fwd_bwd_seg_ln(*dev, 6.0, keep=keep.to(DEV) if masked else None, keep_p=0.1)
+    # the plain entry on the same table: same scores / loss / relation gradient, bit for bit
+    l2, p2, n2, _, d_ent, d_rel2 = ops.score_margin_fwd_bwd_seg(ent, dev[3], *dev[4:], 6.0)
+    assert torch.equal(pos, p2) and torch.equal(ng, n2) and torch.equal(loss, l2) and torch.equal(d_rel, d_rel2)
+    # LayerNorm backward of the plain entry's entity gradient, fp64 autograd
+    tp = t_pre.double().requires_grad_(True)
+    gm, bt = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(tp, (D,), gm, bt, 1e-12)
+    y.backward(d_ent.cpu().double())
+    scale = max(1.0, float(tp.grad.abs().max()))
+    assert_close(dt, tp.grad, atol=2e-5 * scale, rtol=1e-5, what="dt")
+    assert_close(dgam, gm.grad, atol=2e-4 * max(1.0, float(gm.grad.abs().max())), rtol=1e-4, what="dgamma")
+    assert_close(dbet, bt.grad, atol=2e-4 * max(1.0, float(bt.grad.abs().max())), rtol=1e-4, what="dbeta")
+    ref_m = tp.grad * keep.double() / 0.9 if masked else tp.grad
+    if masked:
+        assert_close(dtm, ref_m, atol=2e-5 * scale / 0.9, rtol=1e-5, what="dtm")
+    assert_close(dcol, ref_m.sum(0), atol=2e-4 * max(1.0, float(ref_m.sum(0).abs().max())), rtol=1e-4, what="column sums")
