@@ -23,6 +23,15 @@
 
 namespace snag {
 
+#ifndef SNAG_TA_WAVES
+#define SNAG_TA_WAVES 2                  // (waves per SIMD pass A is compiled for: 2 = up to 256 registers, no spills: 46 -> 38 us against 3)
+#endif
+#ifndef SNAG_TB_WAVES
+#define SNAG_TB_WAVES 4
+#endif
+#ifndef SNAG_HUB_GRID
+#define SNAG_HUB_GRID 512
+#endif
 constexpr int kTCap = 16;                   // inline slots per destination (slot 0 is the owner's own record)
 constexpr int kTChunk = 64;                 // entries per hash chunk
 
@@ -30,7 +39,8 @@ struct TouchedHeader {                      // first 64 bytes of the workspace (
     unsigned phase;                         // which hash-key table / hub counter the NEXT pass A uses (flipped by pass B)
     unsigned cur;                           // which one the CURRENT launch uses (written by pass A, read by the later passes)
     unsigned n_hubs[2];
-    unsigned pad[12];
+    unsigned n_chunks[2];                   // claimed hash chunks of the even / odd launch (their slots: TouchedWork::chunks)
+    unsigned pad[10];
 };
 struct TouchedRec {                         // one entry in triple order: weight * rows[src] goes to destination dest; slot = arrival number there
     int dest, src;
@@ -50,6 +60,7 @@ struct TouchedWork {
     unsigned long long* hkeys[2];           // [hmask + 1] each: (dest, chunk) + 1, 0 = free; even / odd launch
     SegEntry* hbuckets;                     // [hmask + 1, kTChunk]
     long long* hpart;                       // [hmask + 1, dim]: fixed-point sum of a chunk
+    unsigned* chunks;                       // [hmask + 1]: hash slots of the claimed chunks, in claiming order (pass B' walks this list, not the table)
     TouchedHub* hubs;                       // [max_hubs]
     float* rows;                            // [(1 + parts) * batch, dim]: q_b, then dq_{b,p} at batch + b * parts + p
     float* lpart;                           // [batch * parts] hinge sums per (triple, part)
@@ -64,6 +75,7 @@ static size_t t_align(size_t x) { return (x + 255) / 256 * 256; }
 static int touched_parts(int64_t batch, int n_neg) {
     int p = n_neg >= 96 ? 4 : (n_neg >= 48 ? 2 : 1);
     while (p > 1 && batch * p > 16384) p /= 2;
+    while ((n_neg + p - 1) / p > 250) p *= 2;           // pass A keeps a part's negatives in four 64-lane id blocks and a 1,024-slot LDS table per workgroup
     return p;
 }
 static unsigned touched_hash_slots(int64_t n_rec) {
@@ -89,7 +101,7 @@ static TouchedSizes touched_sizes(int64_t n_ent, int64_t n_rel, int64_t batch, i
 static size_t touched_work_bytes(int64_t n_ent, int64_t n_rel, int64_t batch, int n_neg, int dim) {
     const TouchedSizes z = touched_sizes(n_ent, n_rel, batch, n_neg);
     return t_align(sizeof(TouchedHeader)) + t_align(z.n_dest * 4) + t_align(z.n_dest * kTCap * sizeof(SegEntry)) + t_align(z.n_rec * sizeof(TouchedRec)) +
-           2 * t_align(z.hs * 8) + t_align(z.hs * kTChunk * sizeof(SegEntry)) + t_align(z.hs * (size_t)dim * 8) + t_align(z.max_hubs * sizeof(TouchedHub)) +
+           2 * t_align(z.hs * 8) + t_align(z.hs * kTChunk * sizeof(SegEntry)) + t_align(z.hs * (size_t)dim * 8) + t_align(z.hs * 4) + t_align(z.max_hubs * sizeof(TouchedHub)) +
            t_align((size_t)(1 + z.parts) * batch * dim * 4) + t_align((size_t)batch * z.parts * 4);
 }
 static TouchedWork touched_carve(void* base, int64_t n_ent, int64_t n_rel, int64_t batch, int n_neg, int dim) {
@@ -104,6 +116,7 @@ static TouchedWork touched_carve(void* base, int64_t n_ent, int64_t n_rel, int64
     w.hkeys[1] = (unsigned long long*)p; p += t_align(z.hs * 8);
     w.hbuckets = (SegEntry*)p; p += t_align(z.hs * kTChunk * sizeof(SegEntry));
     w.hpart = (long long*)p; p += t_align(z.hs * (size_t)dim * 8);
+    w.chunks = (unsigned*)p; p += t_align(z.hs * 4);
     w.hubs = (TouchedHub*)p; p += t_align(z.max_hubs * sizeof(TouchedHub));
     w.rows = (float*)p; p += t_align((size_t)(1 + z.parts) * batch * dim * 4);
     w.lpart = (float*)p;
@@ -139,6 +152,7 @@ __device__ __forceinline__ void touched_emit(const TouchedWork& w, unsigned whic
     unsigned hslot = touched_hash(key) & w.hmask;
     for (unsigned probe = 0; probe <= w.hmask; ++probe) {            // claim the chunk's slot or find it claimed (no waiting: one CAS per probe)
         const unsigned long long old = atomicCAS(keys + hslot, 0ull, key);
+        if (old == 0ull) w.chunks[atomicAdd(&w.hdr->n_chunks[which], 1u)] = hslot;      // the claimer lists the chunk for pass B'
         if (old == 0ull || old == key) break;
         hslot = (hslot + 1u) & w.hmask;
     }
@@ -146,30 +160,65 @@ __device__ __forceinline__ void touched_emit(const TouchedWork& w, unsigned whic
 }
 
 // ---- pass A --------------------------------------------------------------------------------------------------------------------
-template <typename IdxT, int NV, typename TabT>
-__global__ __launch_bounds__(256, 3) void touched_a_kernel(
+template <typename IdxT, int NV, typename TabT, int kAgg>
+__global__ __launch_bounds__(256, SNAG_TA_WAVES) void touched_a_kernel(
     const TabT* __restrict__ ent, int64_t eld, const TabT* __restrict__ rel, int dim, int n_ent,
     const IdxT* __restrict__ h, const IdxT* __restrict__ r, const IdxT* __restrict__ t, const IdxT* __restrict__ neg_t,
     int64_t batch, int n_neg_all, float margin, float gscale, float* __restrict__ pos, float* __restrict__ neg, TouchedWork w) {
     const int wave = wave_id_uniform();
     const int lane = threadIdx.x & 63;
     const int sub = lane & 15, grp = lane >> 4;
-    const int64_t vb = (int64_t)blockIdx.x * 4 + wave;             // (triple, part)
+    const int64_t vb_raw = (int64_t)blockIdx.x * 4 + wave;         // (triple, part)
     const unsigned which = w.hdr->phase & 1u;                      // stable during pass A (only pass B flips it)
     if (blockIdx.x == 0 && threadIdx.x == 0) w.hdr->cur = which;
-    if (vb >= batch * w.parts) return;
+    // SLOT RESERVATION, one returning atomic per workgroup and distinct destination.  Every entry needs its arrival number at its
+    // destination; taken one by one (a returning atomicAdd per entry) the ~9,000 entries a Zipf(1.0) batch sends to its hottest row queue
+    // up on one address at ~12 ns each -- pass A took 127 us against 42 on uniform indices.  The workgroup's entries (four (triple, part)
+    // waves: <= 4 (per + 3)) first meet in an LDS hash keyed by destination (local arrival number = an LDS atomic), then ONE lane per
+    // distinct destination reserves the whole run at the global counter; an entry's slot is the run's base + its local number.  The global
+    // round trip is in flight while the rows are gathered and scored; it is waited for just before the records are written.
+    // kAgg LDS hash slots: 256 when the workgroup's <= 4 (per + 3) entries fill at most 5/8 of them, 1,024 otherwise (per <= 250: touched_parts)
+    __shared__ unsigned agg_key[kAgg], agg_cnt[kAgg], agg_base[kAgg];
+    for (int i = threadIdx.x; i < kAgg; i += 256) { agg_key[i] = 0u; agg_cnt[i] = 0u; }
+    __syncthreads();
+    const bool live = vb_raw < batch * w.parts;
+    const int64_t vb = live ? vb_raw : 0;
     const int64_t b = vb / w.parts;
     const int part = (int)(vb % w.parts);
     const int k_lo = min(n_neg_all, part * w.per);
-    const int n_neg = min(n_neg_all - k_lo, w.per);
+    const int n_neg = live ? min(n_neg_all - k_lo, w.per) : 0;
     const int64_t rec0 = vb * (w.per + 3);                          // this part's records: t, h, r, then its negatives (slots past n_neg: void)
     float hinge = 0.f;
     const int64_t hi = (int64_t)h[b], ri = (int64_t)r[b], ti = (int64_t)t[b];
     const IdxT* nrow = neg_t + b * (int64_t)n_neg_all + k_lo;
-    // slots for the positive tail, the head and the relation (lanes 0, 1, 2); the negatives' follow per id block below
+    // local arrival number of an entry at `dest` inside this workgroup, and the LDS slot that stands for the destination
+    auto agg_insert = [&](int dest, unsigned& local, int& aslot) {
+        unsigned a = (((unsigned)dest * 2654435761u) >> 22) & (kAgg - 1);
+        for (;;) {
+            const unsigned old = atomicCAS(&agg_key[a], 0u, (unsigned)dest + 1u);
+            if (old == 0u || old == (unsigned)dest + 1u) break;
+            a = (a + 1u) & (kAgg - 1);
+        }
+        local = atomicAdd(&agg_cnt[a], 1u);
+        aslot = (int)a;
+    };
+    // the positive tail, the head and the relation (lanes 0, 1, 2); the negatives' destinations follow
     const int dest3 = lane == 0 ? (int)ti : (lane == 1 ? (int)hi : n_ent + (int)ri);
-    unsigned slot3 = 0u;
-    if (lane < 3) slot3 = atomicAdd(w.cnt + dest3, 1u);
+    unsigned local3 = 0u;
+    int aslot3 = 0;
+    if (live && lane < 3) agg_insert(dest3, local3, aslot3);
+    constexpr int kMaxBlocks = 4;                                   // id blocks of 64 negatives per part held in registers (per <= 256)
+    unsigned nlocal[kMaxBlocks];
+    int naslot[kMaxBlocks];
+#pragma unroll
+    for (int q = 0; q < kMaxBlocks; ++q) {
+        nlocal[q] = 0u; naslot[q] = 0;
+        const int k0 = 64 * q;
+        if (k0 < w.per && lane < max(0, min(64, n_neg - k0))) agg_insert((int)nrow[k0 + lane], nlocal[q], naslot[q]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kAgg; i += 256)
+        if (agg_cnt[i] != 0u) agg_base[i] = atomicAdd(w.cnt + (agg_key[i] - 1u), agg_cnt[i]);       // in flight while the rows are gathered
     // RB rounds x 4 rows gathered before the first is used (wide rows: 4 rounds -- 64 fewer registers, three waves per SIMD instead of two;
     // a group meets its negatives in the same order either way, so the sums are the same bits).  (Issuing the first batch next to the
     // head / relation / tail rows, before any arithmetic, was tried: 241 registers, or 168 with spills -- 78 us instead of 43.)
@@ -198,13 +247,11 @@ __global__ __launch_bounds__(256, 3) void touched_a_kernel(
         d = q.v[j].z - tt.v[j].z; s_pos = fmaf(d, d, s_pos); d = q.v[j].w - tt.v[j].w; s_pos = fmaf(d, d, s_pos);
     }
     s_pos = sum16(s_pos);
-    if (lane == 0 && part == 0) pos[b] = s_pos;
+    if (live && lane == 0 && part == 0) pos[b] = s_pos;
     float c_pos = 0.f;
     for (int k0 = 0; k0 < w.per; k0 += 64) {
         const int cnt = max(0, min(64, n_neg - k0));
         const int my = (lane < cnt) ? (int)nrow[k0 + lane] : 0;
-        unsigned my_slot = 0u;
-        if (lane < cnt) my_slot = atomicAdd(w.cnt + my, 1u);    // in flight while the rows are gathered
         float my_s = 0.f;                               // lane k: score of negative k0 + k
         for (int it0 = 0; it0 < cnt; it0 += 4 * RB) {
             Row4<NV> x[RB];
@@ -241,15 +288,21 @@ __global__ __launch_bounds__(256, 3) void touched_a_kernel(
                 if (((lane - it0) >> 2) == u && lane >= it0 && lane < it0 + 4 * RB) my_s = sk;
             }
         }
-        // lane k: score out, its negative's record (weight 2 a_k; zero for an inactive hinge); slots of this id block past the part's
-        // negatives are void records
+        // the reserved runs have arrived by now (first id block: the workgroup meets here; same trip count in every wave)
+        if (k0 == 0) __syncthreads();
+        // lane k: score out, its negative's record (slot = its destination's base + its local number; weight 2 a_k, zero for an inactive
+        // hinge); slots of this id block past the part's negatives are void records
+        const int q = k0 >> 6;
+        const unsigned nl = q == 0 ? nlocal[0] : (q == 1 ? nlocal[1] : (q == 2 ? nlocal[2] : nlocal[3]));
+        const int na = q == 0 ? naslot[0] : (q == 1 ? naslot[1] : (q == 2 ? naslot[2] : naslot[3]));
         if (lane < cnt) {
             neg[b * (int64_t)n_neg_all + k_lo + k0 + lane] = my_s;
-            touched_emit(w, which, rec0 + 3 + k0 + lane, my, my_slot, (int)b, (margin + s_pos - my_s > 0.f) ? 2.f * gscale : 0.f);
-        } else if (k0 + lane < w.per) {
+            touched_emit(w, which, rec0 + 3 + k0 + lane, my, agg_base[na] + nl, (int)b, (margin + s_pos - my_s > 0.f) ? 2.f * gscale : 0.f);
+        } else if (live && k0 + lane < w.per) {
             w.rec[rec0 + 3 + k0 + lane] = TouchedRec{-1, 0, 0.f, 1u};
         }
     }
+    if (w.per <= 0) __syncthreads();
     // the four groups' partial sums, combined in fixed order: every group then holds the whole part's values
     {
         const float h1 = __shfl_xor(hinge, 16), c1 = __shfl_xor(c_pos, 16);
@@ -264,8 +317,8 @@ __global__ __launch_bounds__(256, 3) void touched_a_kernel(
         }
     }
     // rows[b] = q_b (part 0) ; rows[batch + vb] = dq_{b,p} = 2 c_p (q - t^) - 2 sum_{k in p} a_k (q - x^_k)
-    if (grp == 0 && part == 0) st_row4<NV>(w.rows, b, dim, dim, sub, q);
-    if (grp == 1) {
+    if (live && grp == 0 && part == 0) st_row4<NV>(w.rows, b, dim, dim, sub, q);
+    if (live && grp == 1) {
         Row4<NV> dq;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -274,38 +327,46 @@ __global__ __launch_bounds__(256, 3) void touched_a_kernel(
         }
         st_row4<NV>(w.rows, batch + vb, dim, dim, sub, dq);
     }
-    if (lane < 3) touched_emit(w, which, rec0 + lane, dest3, slot3, lane == 0 ? (int)b : (int)(batch + vb), lane == 0 ? -2.f * c_pos : 1.f);
+    if (!live) return;
+    if (lane < 3) touched_emit(w, which, rec0 + lane, dest3, agg_base[aslot3] + local3, lane == 0 ? (int)b : (int)(batch + vb), lane == 0 ? -2.f * c_pos : 1.f);
     if (lane == 0) w.lpart[vb] = hinge;
 }
 
 // ---- pass B': chunk sums (a role of pass B's launch: its first `chunk_blocks` workgroups; only pass C reads the result) ------------------
 template <int NV>
-__device__ __forceinline__ void touched_chunk_body(const TouchedWork& w, int dim, int vblock) {
-    const int lane = threadIdx.x & 63, sub = lane & 15, gbase = lane & 48;
-    const unsigned hslot = (unsigned)(((int64_t)vblock * 256 + threadIdx.x) >> 4);
+__device__ __forceinline__ void touched_chunk_body(const TouchedWork& w, int dim, int vblock, int nblocks) {
+    // ONE WAVE per listed chunk (a fixed grid walks the list): its four 16-lane groups take 16 entries each -- four dependent round trips
+    // instead of sixteen for a full chunk -- and meet in registers; integer sums, so the result does not depend on who added what
+    const int lane = threadIdx.x & 63, sub = lane & 15, gbase = lane & 48, grp = lane >> 4;
     const unsigned which = w.hdr->cur & 1u;
-    const unsigned long long key = hslot <= w.hmask ? w.hkeys[which][hslot] : 0ull;
-    if (__ballot(key != 0ull) == 0ull) return;
-    long long acc[4 * NV];
-#pragma unroll
-    for (int i = 0; i < 4 * NV; ++i) acc[i] = 0;
-    unsigned count = 0u;
-    if (key != 0ull) {
+    const unsigned n_list = min(w.hdr->n_chunks[which], w.hmask + 1u);
+    for (unsigned ci = (unsigned)vblock * 4u + (threadIdx.x >> 6); ci < n_list; ci += (unsigned)nblocks * 4u) {
+        const unsigned hslot = w.chunks[ci];
+        const unsigned long long key = w.hkeys[which][hslot];
         const int dest = (int)((key - 1ull) >> 24);
         const unsigned j = (unsigned)((key - 1ull) & 0xffffffull);
         const unsigned n = w.cnt[dest];                         // (hot rows' counters are reset by pass C, not by pass B)
         const unsigned over = n > (unsigned)kTCap ? n - (unsigned)kTCap : 0u;
-        count = over > j * kTChunk ? min((unsigned)kTChunk, over - j * kTChunk) : 0u;
-    }
-    fix_add_run<NV>(acc, w.hbuckets + (int64_t)min(hslot, w.hmask) * kTChunk, count, w.rows, dim, sub, gbase);
-    if (key != 0ull) {
-        long long* out = w.hpart + (int64_t)hslot * dim;
+        const unsigned count = over > j * kTChunk ? min((unsigned)kTChunk, over - j * kTChunk) : 0u;
+        const unsigned mine = count > 16u * grp ? min(16u, count - 16u * grp) : 0u;
+        long long acc[4 * NV];
 #pragma unroll
-        for (int jv = 0; jv < NV; ++jv) {
-            const int c = (sub + 16 * jv) * 4;
-            if (c < dim) {
-                reinterpret_cast<longlong2*>(out + c)[0] = make_longlong2(acc[4 * jv + 0], acc[4 * jv + 1]);
-                reinterpret_cast<longlong2*>(out + c)[1] = make_longlong2(acc[4 * jv + 2], acc[4 * jv + 3]);
+        for (int i = 0; i < 4 * NV; ++i) acc[i] = 0;
+        fix_add_run<NV>(acc, w.hbuckets + (int64_t)hslot * kTChunk + 16 * grp, mine, w.rows, dim, sub, gbase);
+#pragma unroll
+        for (int i = 0; i < 4 * NV; ++i) {
+            acc[i] += __shfl_xor(acc[i], 16);
+            acc[i] += __shfl_xor(acc[i], 32);
+        }
+        if (grp == 0) {
+            long long* out = w.hpart + (int64_t)hslot * dim;
+#pragma unroll
+            for (int jv = 0; jv < NV; ++jv) {
+                const int c = (sub + 16 * jv) * 4;
+                if (c < dim) {
+                    reinterpret_cast<longlong2*>(out + c)[0] = make_longlong2(acc[4 * jv + 0], acc[4 * jv + 1]);
+                    reinterpret_cast<longlong2*>(out + c)[1] = make_longlong2(acc[4 * jv + 2], acc[4 * jv + 3]);
+                }
             }
         }
     }
@@ -313,14 +374,14 @@ __device__ __forceinline__ void touched_chunk_body(const TouchedWork& w, int dim
 
 // ---- pass B: one group per record -----------------------------------------------------------------------------------------------------
 template <int NV, typename TabT>
-__global__ __launch_bounds__(256, 4) void touched_b_kernel(const TabT* __restrict__ ent, int64_t eld, const TabT* __restrict__ rel, int dim, int n_ent,
+__global__ __launch_bounds__(256, SNAG_TB_WAVES) void touched_b_kernel(const TabT* __restrict__ ent, int64_t eld, const TabT* __restrict__ rel, int dim, int n_ent,
                                                         float* __restrict__ d_ent, int64_t dld, float* __restrict__ d_rel, TouchedWork w,
                                                         float* __restrict__ loss_part, int64_t batch, float* __restrict__ loss, int group_blocks,
                                                         int chunk_blocks) {
     // workgroup roles: [0, chunk_blocks) chunk sums of the overflow hash (pass B'), then one group per record, then the loss sum, then
     // the wipe of the previous launch's hash keys
     if ((int)blockIdx.x < chunk_blocks) {
-        touched_chunk_body<NV>(w, dim, (int)blockIdx.x);
+        touched_chunk_body<NV>(w, dim, (int)blockIdx.x, chunk_blocks);
         return;
     }
     const int bid = (int)blockIdx.x - chunk_blocks;
@@ -350,6 +411,7 @@ __global__ __launch_bounds__(256, 4) void touched_b_kernel(const TabT* __restric
     }
     if (bid == 0 && threadIdx.x == 0) {               // hand the other table / hub counter to the next launch
         w.hdr->n_hubs[which ^ 1u] = 0u;
+        w.hdr->n_chunks[which ^ 1u] = 0u;
         w.hdr->phase = which ^ 1u;
     }
     const int lane = threadIdx.x & 63, sub = lane & 15, gbase = lane & 48;
@@ -444,6 +506,7 @@ template <int NV, typename TabT>
 __global__ __launch_bounds__(256) void touched_hub_kernel(const TabT* __restrict__ ent, int64_t eld, const TabT* __restrict__ rel, int dim, int n_ent,
                                                           float* __restrict__ d_ent, int64_t dld, float* __restrict__ d_rel, TouchedWork w) {
     __shared__ long long red[16][16][4 * NV];
+    __shared__ long long tot[16][4 * NV];
     const int lane = threadIdx.x & 63, sub = lane & 15, gbase = lane & 48;
     const int gi = threadIdx.x >> 4;                       // group inside the workgroup
     const unsigned which = w.hdr->cur & 1u;
@@ -461,7 +524,7 @@ __global__ __launch_bounds__(256) void touched_hub_kernel(const TabT* __restrict
         if (gi == 0) {                                     // the owner's own entry and the bucket's slots 1..15
             const TouchedRec rc = w.rec[hb.rec];
             fix_add_row<NV>(acc, ld_row4<NV>(w.rows, rc.src, dim, dim, sub), rc.w);
-            fix_add_run<NV>(acc, w.list + (int64_t)dest * kTCap + 1, (unsigned)kTCap - 1u, w.rows, dim, sub, gbase);
+            fix_add_run<NV, 2>(acc, w.list + (int64_t)dest * kTCap + 1, (unsigned)kTCap - 1u, w.rows, dim, sub, gbase);
         }
         for (unsigned j = (unsigned)gi; j * kTChunk < over; j += 16u) {          // the chunk partials pass B' left
             const unsigned hslot = touched_find(keys, w.hmask, dest, j);
@@ -478,14 +541,19 @@ __global__ __launch_bounds__(256) void touched_hub_kernel(const TabT* __restrict
 #pragma unroll
         for (int i = 0; i < 4 * NV; ++i) red[gi][sub][i] = acc[i];
         __syncthreads();
+        // the sixteen groups' partial rows summed by ALL threads: thread (gi, sub) takes components gi, gi + 16, ... of lane sub's share
+        // (integer sums: any order gives the same bits); group 0 collects the totals
+        for (int i = gi; i < 4 * NV; i += 16) {
+            long long t = 0;
+#pragma unroll 4
+            for (int g2 = 0; g2 < 16; ++g2) t += red[g2][sub][i];
+            tot[sub][i] = t;
+        }
+        __syncthreads();
         if (gi == 0) {
             if (sub == 0) w.cnt[dest] = 0u;                // ready for the next launch
 #pragma unroll
-            for (int i = 0; i < 4 * NV; ++i) {
-                long long t = acc[i];
-                for (int g2 = 1; g2 < 16; ++g2) t += red[g2][sub][i];
-                acc[i] = t;
-            }
+            for (int i = 0; i < 4 * NV; ++i) acc[i] = tot[sub][i];
             const TabT* xrow = is_rel ? rel + (int64_t)(dest - n_ent) * dim : ent + (int64_t)dest * eld;
             Row4<NV> x = ld_row4<NV>(xrow, 0, 0, dim, sub);
             Row4<NV> gsum;
@@ -532,18 +600,20 @@ static int launch_touched(const char* who, const TabT* ent, int64_t ent_ld, int6
     }
     if (batch > 0) {
         const dim3 grid((unsigned)ceil_div(batch * w.parts, 4));
-#define SNAG_TA(NV) do { if (idx_bytes == 4) hipLaunchKernelGGL((touched_a_kernel<int32_t, NV, TabT>), grid, block, 0, st, ent, ent_ld, rel, dim, (int)n_ent, \
-                             (const int32_t*)h, (const int32_t*)r, (const int32_t*)t, (const int32_t*)neg_t, batch, n_neg, margin, grad_scale, pos, neg, w); \
-                         else hipLaunchKernelGGL((touched_a_kernel<int64_t, NV, TabT>), grid, block, 0, st, ent, ent_ld, rel, dim, (int)n_ent, \
-                             (const int64_t*)h, (const int64_t*)r, (const int64_t*)t, (const int64_t*)neg_t, batch, n_neg, margin, grad_scale, pos, neg, w); } while (0)
+        const bool small_agg = 4 * (w.per + 3) <= 160;
+#define SNAG_TA_(IDX, NV, AGG) hipLaunchKernelGGL((touched_a_kernel<IDX, NV, TabT, AGG>), grid, block, 0, st, ent, ent_ld, rel, dim, (int)n_ent, \
+                             (const IDX*)h, (const IDX*)r, (const IDX*)t, (const IDX*)neg_t, batch, n_neg, margin, grad_scale, pos, neg, w)
+#define SNAG_TA(NV) do { if (idx_bytes == 4) { if (small_agg) SNAG_TA_(int32_t, NV, 256); else SNAG_TA_(int32_t, NV, 1024); } \
+                         else { if (small_agg) SNAG_TA_(int64_t, NV, 256); else SNAG_TA_(int64_t, NV, 1024); } } while (0)
         SNAG_NV_SWITCH(SNAG_TA)
 #undef SNAG_TA
+#undef SNAG_TA_
         int rc = check_launch(who);
         if (rc) return rc;
     }
     // pass B: one group per record, + 1 workgroup that sums the losses (an empty batch: loss = 0), + 8 that wipe the previous launch's hash keys
     const int group_blocks = ceil_div(w.n_rec * 16, 256);
-    const int chunk_blocks = batch > 0 ? ceil_div(((int64_t)w.hmask + 1) * 16, 256) : 0;
+    const int chunk_blocks = batch > 0 ? 512 : 0;                   // pass B': a fixed grid of 2,048 waves walks the list of claimed chunks
     const dim3 gridb((unsigned)(chunk_blocks + group_blocks) + 9u);
 #define SNAG_TB(NV) hipLaunchKernelGGL((touched_b_kernel<NV, TabT>), gridb, block, 0, st, ent, ent_ld, rel, dim, (int)n_ent, d_ent, d_ent_ld, d_rel, w, loss_part, batch, loss, \
                                        group_blocks, chunk_blocks)
@@ -551,7 +621,7 @@ static int launch_touched(const char* who, const TabT* ent, int64_t ent_ld, int6
 #undef SNAG_TB
     int rc = check_launch(who);
     if (rc || batch == 0) return rc;
-    const dim3 gridh((unsigned)std::min<int64_t>(512, (int64_t)w.max_hubs));
+    const dim3 gridh((unsigned)std::min<int64_t>(SNAG_HUB_GRID, (int64_t)w.max_hubs));
 #define SNAG_TH(NV) hipLaunchKernelGGL((touched_hub_kernel<NV, TabT>), gridh, block, 0, st, ent, ent_ld, rel, dim, (int)n_ent, d_ent, d_ent_ld, d_rel, w)
     SNAG_NV_SWITCH(SNAG_TH)
 #undef SNAG_TH

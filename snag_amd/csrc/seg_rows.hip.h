@@ -92,23 +92,24 @@ __device__ __forceinline__ void fix_add_row(long long (&acc)[4 * NV], const Row4
 
 // A contiguous run of entries summed in fixed point, 16 at a time: lane i of the group fetches entry i (one coalesced 128-byte read), then
 // the rows they name are gathered four at a time -- two dependent round trips per 16 entries instead of two per entry.
-template <int NV>
+// (U rows in flight per step: 4, or 2 where the caller's registers are short)
+template <int NV, int U = 4>
 __device__ __forceinline__ void fix_add_run(long long (&acc)[4 * NV], const SegEntry* __restrict__ run, unsigned count, const float* __restrict__ rows, int dim,
                                             int sub, int gbase) {
     for (unsigned i0 = 0; i0 < count; i0 += 16) {
         const SegEntry e = (i0 + sub < count) ? run[i0 + sub] : SegEntry{0, 0.f};
         const unsigned m = min(16u, count - i0);
-        for (unsigned u0 = 0; u0 < m; u0 += 4) {
-            Row4<NV> y[4];
-            float wt[4];
+        for (unsigned u0 = 0; u0 < m; u0 += U) {
+            Row4<NV> y[U];
+            float wt[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int src = __shfl(e.src, gbase + (int)((u0 + u) & 15u));
                 wt[u] = (u0 + u < m) ? __shfl(e.w, gbase + (int)((u0 + u) & 15u)) : 0.f;
                 y[u] = ld_row4<NV>(rows, (u0 + u < m) ? src : 0, dim, dim, sub);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) fix_add_row<NV>(acc, y[u], wt[u]);
+            for (int u = 0; u < U; ++u) fix_add_row<NV>(acc, y[u], wt[u]);
         }
     }
 }
