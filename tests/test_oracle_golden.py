@@ -204,3 +204,36 @@ def test_gcn():
     assert_close(x.grad, z["g.x"], atol=1e-6, rtol=1e-5)
     for k, v in p.items():
         assert_close(v.grad, z["g.p." + k], atol=1e-5, rtol=1e-5, what=k)
+
+
+def test_mkgc_forward_passes_the_keep_masks_through():
+    """oracle.mkgc_forward(drop_masks=, proj_keep=) -- what the GPU dropout-parity tests feed the engine's masks into -- is the composition of the
+    pinned pieces: projection_head with its keep mask (G6), fusion_forward with the Bert masks (G1-train), the read-out, score_margin (G3)."""
+    import torch
+    from oracle import ref_cpu as O
+    g = torch.Generator().manual_seed(3)
+    N, D, H, M, B, K = 40, 16, 2, 3, 8, 4
+    feats = [torch.rand(N, 10, generator=g), torch.randn(N, 6, generator=g)]
+    proj = [{"l1": torch.randn(D, 10, generator=g), "l2": torch.randn(D, D, generator=g)}, {"l1": torch.randn(D, 6, generator=g), "l2": torch.randn(D, D, generator=g)}]
+    fp = {"weight_raw": torch.randn(6, generator=g)}
+    pre = "fusion_layer.0."
+    for nm in ("query", "key", "value"):
+        fp[pre + f"attention.self.{nm}.weight"], fp[pre + f"attention.self.{nm}.bias"] = torch.randn(D, D, generator=g) * 0.3, torch.randn(D, generator=g) * 0.1
+    fp[pre + "attention.output.dense.weight"], fp[pre + "attention.output.dense.bias"] = torch.randn(D, D, generator=g) * 0.3, torch.randn(D, generator=g) * 0.1
+    fp[pre + "attention.output.LayerNorm.weight"], fp[pre + "attention.output.LayerNorm.bias"] = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    ent, rel = torch.randn(N, D, generator=g), torch.randn(3, D, generator=g)
+    masks = [{"probs": (torch.rand(N, H, M, M, generator=g) > 0.1).float(), "attn_out": (torch.rand(N, M, D, generator=g) > 0.1).float()}]
+    keep = [(torch.rand(N, D, generator=g) > 0.2).float() for _ in range(2)]
+    h, r, t = torch.randint(0, N, (B,), generator=g), torch.randint(0, 3, (B,), generator=g), torch.randint(0, N, (B,), generator=g)
+    neg = torch.randint(0, N, (B, K), generator=g)
+    for jw in O.JOINT_WAYS:
+        rl = rel if jw.startswith("Mformer_hd") else torch.randn(3, M * D, generator=g)
+        loss, pos, ng, rep = O.mkgc_forward(feats, proj, ent, fp, rl, h, r, t, neg, num_heads=H, margin=4.0, joint_way=jw, drop_masks=masks, drop_p=0.1,
+                                            proj_keep=keep, proj_p=0.2)
+        toks = [O.projection_head(f, p["l1"], p["l2"], keep_mask=k, p=0.2) for f, p, k in zip(feats, proj, keep)] + [ent]
+        joint, joint_fz, hidden, _ = O.fusion_forward(toks, fp, H, 1, False, drop_masks=masks, drop_p=0.1)
+        want = O.readout(jw, joint, joint_fz, hidden, graph_index=M - 1)
+        l2, p2, n2 = O.score_margin(want, rl, h, r, t, neg, 4.0)
+        assert torch.equal(rep, want) and torch.equal(loss, l2) and torch.equal(pos, p2) and torch.equal(ng, n2)
+        # and the masks matter: without them the read-out differs
+        assert not torch.equal(O.mkgc_forward(feats, proj, ent, fp, rl, h, r, t, neg, num_heads=H, margin=4.0, joint_way=jw)[3], want)
