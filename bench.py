@@ -137,7 +137,7 @@ def score_train_bytes(cfg, n_triples):
     return score_bytes(cfg, n_triples) + n_triples * (cfg.neg_num + 3) * cfg.dim * 4 * 2
 
 
-def roofline_score(cfg, batch, timer):
+def roofline_score(cfg, batch, timer, ln_fused=False):
     """north_star's kernel in its training form (snag_score_margin_fwd_bwd_seg): per 1024-triple batch a per-triple pass (every table
     row gathered ONCE; scores, losses, q / dq rows, one 8-byte entry per touched destination) and a per-destination pass (gathers the
     L2-resident q / dq rows, applies the normalisation backward once, WRITES each gradient row: no float atomics, no zero-fill,
@@ -147,11 +147,18 @@ def roofline_score(cfg, batch, timer):
     cache holds; ``batch_8192`` the same two launches with eight times the work."""
     us, n = timer.mean_us()
     by = score_train_bytes(cfg, batch)
+    # the entry the headline engine calls since round 4 also carries the gradient through the read-out rows' LayerNorm inside pass B
+    # (snag_score_margin_fwd_bwd_seg_ln): the separate LayerNorm-backward launch's bytes -- the pre-LN rows read, dT and dT * keep written,
+    # the keep mask read -- belong to the timed launches, while the scorer's own gradient rows are no longer written
+    ln_bytes = cfg.n_ent * cfg.dim * (4 + 4 + 4 + 1) - cfg.n_ent * cfg.dim * 4 if ln_fused else 0
+    by += ln_bytes
     ach = by / (us * 1e-6) / 1e9 if us else 0.0
     atomic_bytes = batch * (cfg.neg_num + 3) * cfg.dim * 4
-    return {"kernel": "score_seg_a_kernel + score_seg_b_kernel (snag_score_margin_fwd_bwd_seg: fwd + hinge bwd + summed loss, no float atomics)",
+    return {"kernel": ("score_seg_a_kernel + score_seg_b_kernel<LN> (snag_score_margin_fwd_bwd_seg_ln: fwd + hinge bwd + summed loss + the LayerNorm backward of "
+                       "the read-out rows, no float atomics)" if ln_fused else
+                       "score_seg_a_kernel + score_seg_b_kernel (snag_score_margin_fwd_bwd_seg: fwd + hinge bwd + summed loss, no float atomics)"),
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_us": us, "launches_timed": n,
-            "algorithmic_bytes_per_launch": by, "forward_only_bytes_per_launch": score_bytes(cfg, batch),
+            "algorithmic_bytes_per_launch": by, "layernorm_backward_bytes_included": ln_bytes, "forward_only_bytes_per_launch": score_bytes(cfg, batch),
             "fp32_atomic_form": {"entry": "snag_score_margin_fwd_bwd (MKGCConfig.scorer='atomic')", "atomic_bytes_per_launch": atomic_bytes,
                                  "atomic_floor_us": atomic_bytes / 1.3e12 * 1e6},
             "timed": "HIP events around the entry (both passes), inside the timed region; rocprofv3 per-kernel times: profiles/"}
@@ -830,7 +837,7 @@ def main():
         out.update(extras)
         if timers:
             out["roofline"] = roofline_dominant(cfg, timers["proj_l1_fwd"], rows=eng.shard.n_loc, reduce_timer=timers["proj_l1_fwd_reduce"], grouped=eng.l1_grouped)
-            out["roofline_score"] = roofline_score(cfg, args.batch, timers["score_fwd_bwd"])
+            out["roofline_score"] = roofline_score(cfg, args.batch, timers["score_fwd_bwd"], ln_fused=bool(getattr(eng, "_ln_fuse", False)))
             if not args.no_extras:
                 out["roofline_score"]["batch_8192"] = score_train_larger_batch(eng, cfg, device)
                 out["roofline_score"]["hbm_resident"] = score_hbm_resident(device)

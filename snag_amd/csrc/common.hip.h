@@ -52,6 +52,17 @@ __device__ __forceinline__ float sum64(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// the same for 32-bit integers (lane 63's total, handed to every lane)
+__device__ __forceinline__ int isum64(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ float max16(float v) {
     v = fmaxf(v, dpp_f32<0x128>(v));
     v = fmaxf(v, dpp_f32<0x124>(v));

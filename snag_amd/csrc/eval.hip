@@ -336,6 +336,69 @@ __global__ __launch_bounds__(64) void rank_cols4_kernel(const float* __restrict_
     for (int j = 0; j < nc; ++j) atomicAdd(rank + col + j, cnt[j]);
 }
 
+// BOTH directions in ONE sweep of the square matrix (the separate row and column passes read its 441 MB twice at 10,500^2): the column
+// kernel's walk -- a lane owns four adjacent columns, a wave 256, the workgroup a chunk of rows -- with the row counts taken on the way: for
+// row r the wave's 256 values are compared with the row's own reference, four ballots count the hits and one integer atomic adds them to
+// rank_l2r[r].  The same eval_dist values feed both comparisons; integer counts do not care who adds what.  n == m, dwordx4-addressable rows.
+__global__ __launch_bounds__(64) void rank_both4_kernel(const float* __restrict__ dist, int64_t ld, int n, const float* __restrict__ r1,
+                                                        const float* __restrict__ r2, int csls, int rows_per_chunk, int* __restrict__ rank_rows,
+                                                        int* __restrict__ rank_cols) {
+    // (n % 4 == 0: a lane owns four whole columns or none; a lane past the edge walks the last four columns again and counts nothing)
+    const int col_raw = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const bool live = col_raw < n;
+    const int col = live ? col_raw : n - 4;
+    const int r0 = blockIdx.y * rows_per_chunk, r1e = min(n, r0 + rows_per_chunk);
+    float b[4], ref[4];
+    int cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = col + j;
+        b[j] = csls ? r2[c] : 0.f;
+        ref[j] = eval_dist(dist[(int64_t)c * ld + c], csls ? r1[c] : 0.f, b[j], csls);
+    }
+    // this lane's hits of one row (0..4): column counts as a side effect
+    auto lane_hits = [&](float4 d, float a, float rref) {
+        const float v0 = eval_dist(d.x, a, b[0], csls), v1 = eval_dist(d.y, a, b[1], csls), v2 = eval_dist(d.z, a, b[2], csls), v3 = eval_dist(d.w, a, b[3], csls);
+        cnt[0] += v0 < ref[0] ? 1 : 0;
+        cnt[1] += v1 < ref[1] ? 1 : 0;
+        cnt[2] += v2 < ref[2] ? 1 : 0;
+        cnt[3] += v3 < ref[3] ? 1 : 0;
+        const int hits = (v0 < rref ? 1 : 0) + (v1 < rref ? 1 : 0) + (v2 < rref ? 1 : 0) + (v3 < rref ? 1 : 0);
+        return live ? hits : 0;
+    };
+    auto one_row = [&](int r, float4 d, float a, float rref) {
+        const int hits = isum64(lane_hits(d, a, rref));
+        if (threadIdx.x == 0 && hits != 0) atomicAdd(rank_rows + r, hits);
+    };
+    auto load_row = [&](int r) { return *reinterpret_cast<const float4*>(dist + (int64_t)r * ld + col); };
+    // 64 rows at a time: lane i fetches row s0 + i's neighbourhood term and its own diagonal element ONCE (three loads per lane and 64
+    // rows, not three wave-wide loads per row); a row's two scalars then come out of that lane's registers
+    for (int s0 = r0; s0 < r1e; s0 += 64) {
+        const int mine = min(s0 + (int)threadIdx.x, r1e - 1);
+        const float a_l = csls ? r1[mine] : 0.f;
+        const float rr_l = eval_dist(dist[(int64_t)mine * ld + mine], a_l, csls ? r2[mine] : 0.f, csls);
+        const int cnt_rows = min(64, r1e - s0);
+        int i = 0;
+        for (; i + 4 <= cnt_rows; i += 4) {
+            float4 d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d[u] = load_row(s0 + i + u);
+            // four rows' hit counts travel through TWO wave reductions, 16 bits per row (a wave's count is at most 256)
+            int h[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) h[u] = lane_hits(d[u], __shfl(a_l, i + u), __shfl(rr_l, i + u));
+            const int t01 = isum64(h[0] | (h[1] << 16)), t23 = isum64(h[2] | (h[3] << 16));
+            if (threadIdx.x < 4) {
+                const int mine_hits = threadIdx.x == 0 ? (t01 & 0xffff) : threadIdx.x == 1 ? (t01 >> 16) : threadIdx.x == 2 ? (t23 & 0xffff) : (t23 >> 16);
+                if (mine_hits != 0) atomicAdd(rank_rows + s0 + i + (int)threadIdx.x, mine_hits);
+            }
+        }
+        for (; i < cnt_rows; ++i) one_row(s0 + i, load_row(s0 + i), __shfl(a_l, i), __shfl(rr_l, i));
+    }
+    if (live)
+        for (int j = 0; j < 4; ++j) atomicAdd(rank_cols + col + j, cnt[j]);
+}
+
 // the k largest values per column (descending) instead of their mean: what a rank contributes to the global column neighbourhoods
 template <int KK>
 __global__ __launch_bounds__(256) void col_topk_values_kernel(const float* __restrict__ part, int chunks, int m, int k, float* __restrict__ out) {
@@ -673,6 +736,15 @@ extern "C" SNAG_API int snag_rank_diagonal(const float* dist, int64_t ld, int n,
     hipStream_t st = (hipStream_t)stream;
     const int csls = r1 != nullptr;
     const int vec = matrix_vec_ok(dist, ld);
+    if (rank_l2r && rank_r2l && vec && n % 4 == 0 && n >= 4) {
+        // both directions from ONE sweep of the matrix
+        if (hipMemsetAsync(rank_l2r, 0, sizeof(int32_t) * n, st) != hipSuccess || hipMemsetAsync(rank_r2l, 0, sizeof(int32_t) * m, st) != hipSuccess)
+            return fail(SNAG_ERR_LAUNCH, "rank_diagonal: memset failed");
+        const int chunks = std::min(kColChunks, n);
+        const int rpc = ceil_div(n, chunks);
+        hipLaunchKernelGGL(rank_both4_kernel, dim3(ceil_div(n, 256), ceil_div(n, rpc)), dim3(64), 0, st, dist, ld, n, r1, r2, csls, rpc, rank_l2r, rank_r2l);
+        return check_launch("snag_rank_diagonal");
+    }
     if (rank_l2r) hipLaunchKernelGGL(rank_rows_kernel, dim3(n), dim3(256), 0, st, dist, ld, n, m, r1, r2, csls, rank_l2r, vec && (((uintptr_t)r2 & 15) == 0));
     if (rank_r2l) {
         if (hipMemsetAsync(rank_r2l, 0, sizeof(int32_t) * m, st) != hipSuccess) return fail(SNAG_ERR_LAUNCH, "rank_diagonal: memset failed");
