@@ -480,28 +480,37 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             if ((rc = gemm_dispatch(&g, st))) return rc;
             dout = W.dC;
         }
-        // LN1 backward -> dA = dT1 (residual route to the layer input), dB = dT1 * keep
+        // LN1 backward -> dA = dT1 (residual route to the layer input), dB = dT1 * keep.  Its slab [blocks][3][D] stays in W.part; the
+        // attention backward's goes behind it and ONE launch reduces both (as in the read-out layer)
         float* dtm = P.keep_attn_out ? W.dB : nullptr;
-        if ((rc = ln_bwd(dout, S.t1, S.st1, P.ln1_g, NM, D, P.keep_attn_out, kscale, W.dA, dtm, W.part, G.ln1_g, G.ln1_b, G.bo, acc, st, 0, zero_up_full))) return rc;
+        if ((rc = ln_bwd(dout, S.t1, S.st1, P.ln1_g, NM, D, P.keep_attn_out, kscale, W.dA, dtm, W.part, G.ln1_g, G.ln1_b, G.bo, acc, st, 0, zero_up_full, true))) return rc;
         zero_up_full = false;
+        const int lnblocks = (int)std::min<int64_t>(kRedBlocks, (NM + 3) / 4);
+        float* partq = W.part + (int64_t)kRedBlocks * 3 * D;
         const float* dz = dtm ? dtm : W.dA;
-        // dWo = dz^T ctx ; dbo
-        g = gemm_desc(D, D, (int)NM, dz, D, false, S.ctx, D, false, G.wo, D);
-        g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
-        if ((rc = gemm_dispatch(&g, st))) return rc;
         // dctx = dz Wo   -> dC  (dout is dead from here on)
         g = gemm_desc((int)NM, D, D, dz, D, true, P.wo, D, false, W.dC, D);
         if ((rc = gemm_dispatch(&g, st))) return rc;
         // attention backward -> dqkv
         const int ablocks = (int)std::min<int64_t>(kRedBlocks, (N + 3) / 4);
         SNAG_MNU(attn_bwd_kernel, M, D, dim3(ablocks), st, (const float*)S.qkv, (const float*)W.dC, N, D, H, 1.0f / sqrtf((float)(D / H)), P.keep_probs,
-                 kscale, (l == L - 1) ? dpx : (const float*)nullptr, W.dqkv, W.part);
-        hipLaunchKernelGGL(slab_colsum_kernel, dim3(ceil_div(3 * D, 64)), dim3(1024), 0, st, (const float*)W.part, ablocks, (int64_t)3 * D, 3 * D, G.bqkv, acc);
+                 kscale, (l == L - 1) ? dpx : (const float*)nullptr, W.dqkv, partq);
+        hipLaunchKernelGGL(slab_colsum_ro_kernel, dim3(ceil_div(3 * D, 64), 2), dim3(1024), 0, st, (const float*)W.part, lnblocks, D, G.ln1_g, G.ln1_b, G.bo,
+                           (const float*)partq, ablocks, G.bqkv, acc);
         if ((rc = check_launch("fusion attention backward"))) return rc;
-        // dWqkv = dqkv^T xin ; dbqkv
-        g = gemm_desc(3 * D, D, (int)NM, W.dqkv, 3 * D, false, xin, D, false, G.wqkv, D);
-        g.accumulate = acc; g.workspace = W.gemm_ws; g.workspace_floats = W.gemm_ws_floats;
-        if ((rc = gemm_dispatch(&g, st))) return rc;
+        // the layer's two weight gradients, dWqkv = dqkv^T xin [3D, D] and dWo = dz^T ctx [D, D] (both K = N M rows, independent): ONE
+        // grouped launch + ONE reduce (they used to be two launches and two reduces around the attention backward)
+        {
+            snag_gemm_desc g0 = gemm_desc(D, D, (int)NM, dz, D, false, S.ctx, D, false, G.wo, D);
+            snag_gemm_desc g1 = gemm_desc(3 * D, D, (int)NM, W.dqkv, 3 * D, false, xin, D, false, G.wqkv, D);
+            const int64_t pw = (gemm_workspace_floats(D, D, (int)NM) + 64) / 64 * 64;
+            g0.accumulate = acc; g0.workspace = W.gemm_ws; g0.workspace_floats = pw;
+            g1.accumulate = acc; g1.workspace = W.gemm_ws + pw; g1.workspace_floats = W.gemm_ws_floats - pw;
+            g0.defer_reduce = g1.defer_reduce = 1;
+            const snag_gemm_desc* grp[2] = {&g1, &g0};
+            if ((rc = gemm_dispatch_group(grp, 2, st))) return rc;
+            if ((rc = gemm_reduce_multi(grp, 2, st))) return rc;
+        }
         // d(layer input) = dqkv Wqkv + dT1 (+ epilogue route at layer 0)
         float* dxin = (l == 0) ? b->d_x0 : W.dC;
         g = gemm_desc((int)NM, D, 3 * D, W.dqkv, 3 * D, true, P.wqkv, D, false, dxin, D);

@@ -34,6 +34,8 @@ def test_engine_step_through_rccl_equals_the_plain_step_bit_for_bit():
         assert o["params_bit_equal"] and o["grads_bit_equal"] and o["moments_bit_equal"] and o["losses_equal"], o
         assert o["loss3"] < o["loss0"]
         assert o["rows_params_bit_equal"] and o["rows_grads_bit_equal"] and o["rows_losses_equal"], o      # row-sharded data path over RCCL
+        fa, fb = o["ln_tail_losses"]              # LayerNorm backward inside the scorer's pass vs its own launch: same step up to summation order
+        assert all(abs(x - y) <= 1e-4 * abs(x) for x, y in zip(fa, fb)), o
     la, lb = out["fused_losses"]                  # default step (fused scorer, fp32 atomics): equal up to the atomics' arrival order
     assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(la, lb)) and la[2] < la[0], (la, lb)
     assert out["steps_agreed"] == 4 and out["epoch_loss_finite"]
