@@ -3,6 +3,7 @@
 #include <algorithm>
 
 #include "fusion_kernels.hip.h"
+#include "readout_fused.hip.h"
 
 namespace snag {
 
@@ -116,6 +117,63 @@ static int check_fusion(const snag_fusion_desc* f) {
     return SNAG_OK;
 }
 
+// The read-out layer's forward as ONE launch (readout_fused.hip) when the shape is the one that kernel is written for: hidden_size 128,
+// three tokens of which two are projected tokens whose keys / values the caller computes from folded weights (co_fwd), no FFN.
+// Returns 1 -- nothing launched -- otherwise; the three-launch path below gives the same bits.
+static int fusion_fwd_readout_one_launch(const snag_fusion_desc* f, const snag_fusion_layer& P, const LayerSave& S, const float* xin, hipStream_t st) {
+    const int N = f->N, M = f->M, D = f->D, H = f->H, g = f->readout_slot_p1 - 1;
+    if (!(f->fold_others && f->n_co_fwd == 2 && M == 3 && D == 128 && !f->use_intermediate && H <= kRoMaxHeads)) return 1;
+    const int64_t MD = (int64_t)M * D;
+    auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!aligned(xin) || !aligned(P.wqkv) || !aligned(P.wo)) return 1;
+    RoFusedArgs a{};
+    a.N = N; a.H = H; a.g = g; a.ldw = D;
+    a.inv_sqrt_d = 1.0f / sqrtf((float)(D / H));
+    a.panel[0] = xin + (int64_t)g * D; a.ldp[0] = MD;
+    float* const qkv_g = S.qkv + (int64_t)g * 3 * D;
+    // the schedule: q, the read-out token's key, the other keys (the one whose panel the first value needs last), the values in token order
+    // (attn_ro_fwd_kernel sums p v over the tokens in that order), the output projection
+    RoTile qkv_t[3][3];          // [token][q / k / v]
+    int panel_of[3];
+    for (int i = 0; i < 3; ++i) qkv_t[g][i] = RoTile{P.wqkv + (int64_t)i * D * D, P.bqkv + i * D, qkv_g + i * D, 3 * MD, g, i, 0};
+    panel_of[g] = 0;
+    int seen = 1 << g;
+    for (int i = 0; i < 2; ++i) {
+        const snag_gemm_desc* c = f->co_fwd[i];
+        const int64_t off = c->C - (S.qkv + D);
+        const bool plain = c->M == N && c->N == 2 * D && c->K == D && c->a_kcontig && c->b_kcontig && c->ldb == D && c->alpha == 1.0f && c->act == 0 &&
+                           !c->pre_act && !c->keep_mask && !c->add1 && !c->add2 && !c->accumulate && !c->mirror && !c->c_transposed && c->ldc == 3 * MD &&
+                           c->lda % 4 == 0 && aligned(c->A) && aligned(c->B);
+        if (!plain || off < 0 || off % (3 * D) != 0 || off / (3 * D) >= M || (seen >> (off / (3 * D))) & 1) return 1;
+        const int tok = (int)(off / (3 * D));
+        seen |= 1 << tok;
+        a.panel[1 + i] = c->A; a.ldp[1 + i] = c->lda;
+        panel_of[tok] = 1 + i;
+        qkv_t[tok][1] = RoTile{c->B, c->bias, c->C, c->ldc, tok, 1, 1 + i};
+        qkv_t[tok][2] = RoTile{c->B + (int64_t)D * D, c->bias ? c->bias + D : nullptr, c->C + D, c->ldc, tok, 2, 1 + i};
+    }
+    int others[2], no = 0;
+    for (int j = 0; j < 3; ++j)
+        if (j != g) others[no++] = j;
+    const int first_v = 0;                                               // values run over tokens 0, 1, 2
+    if (others[0] == first_v) std::swap(others[0], others[1]);           // its key product last: the panel stays
+    a.t[0] = qkv_t[g][0];
+    a.t[1] = qkv_t[g][1];
+    a.t[2] = qkv_t[others[0]][1];
+    a.t[3] = qkv_t[others[1]][1];
+    for (int j = 0; j < 3; ++j) a.t[4 + j] = qkv_t[j][2];
+    a.t[7] = RoTile{P.wo, P.bo, S.t1, D, g, 3, 3};
+    (void)panel_of;
+    a.keep_probs = P.keep_probs; a.kscale = 1.0f / (1.0f - f->drop_p);
+    a.probs = S.probs; a.ctx = S.ctx;
+    a.keep_out = P.keep_attn_out ? P.keep_attn_out + (int64_t)g * D : nullptr; a.ldkeep = MD;
+    a.resid = xin + (int64_t)g * D; a.ldres = MD;
+    a.ln_g = P.ln1_g; a.ln_b = P.ln1_b; a.eps = 1e-12f;
+    a.hidden = f->hidden; a.stats = S.st1;
+    a.wimg = reinterpret_cast<unsigned char*>(f->save + SaveLayout(N, M, D, H, f->I, false).per_layer * f->L);
+    return readout_fwd_fused(a, st);
+}
+
 // Last layer when only token g = readout_slot_p1 - 1 is consumed (joint_way Mformer_hd_graph): keys / values for all M tokens, but
 // the query, the attention row, the output projection, the LayerNorm (and the FFN) for token g only.  hidden is then [N, D].
 // Compact [N, D] activations reuse the first N*D floats of the [N*M, D] save regions.
@@ -126,6 +184,7 @@ static int fusion_fwd_readout(const snag_fusion_desc* f, const snag_fusion_layer
     const float kscale = 1.0f / (1.0f - f->drop_p);
     const dim3 egrid((unsigned)ceil_div(N, 4));
     int rc;
+    if ((rc = fusion_fwd_readout_one_launch(f, P, S, xin, st)) != 1) return rc;
     // K,V of every token: columns D..3D of the stacked projection (fold_others: of the read-out token only -- the caller has written
     // the other tokens' keys / values, computed from what their tokens are projected from)
     snag_gemm_desc gd = f->fold_others ? gemm_desc(N, 2 * D, D, xin + (int64_t)g * D, MD, true, P.wqkv + (int64_t)D * D, D, true, S.qkv + (int64_t)g * 3 * D + D, 3 * MD)
@@ -528,7 +587,8 @@ using namespace snag;
 
 extern "C" SNAG_API int64_t snag_fusion_save_floats(int N, int M, int D, int H, int I, int L, int use_intermediate) {
     if (N < 0 || M < 1 || D < 1 || H < 1 || L < 1) return 0;
-    return SaveLayout(N, M, D, H, I, use_intermediate != 0).per_layer * L;
+    // (+ the split weight images of the one-launch read-out forward behind the last layer's activations: 768 KB whatever the shape)
+    return SaveLayout(N, M, D, H, I, use_intermediate != 0).per_layer * L + readout_fused_image_bytes() / 4;
 }
 
 extern "C" SNAG_API int64_t snag_fusion_work_floats(int N, int M, int D, int H, int I, int L, int use_intermediate) {

@@ -1214,7 +1214,16 @@ __device__ __forceinline__ void gemm_tile_at(const GemmOperands& p, const Epi& e
     const int kbeg = z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     Core core;
+#if SNAG_GEMM_ABLATE       // timing experiments: 256 = no main loop at all (zero accumulators), 128 = no epilogue (nothing is stored)
+    if (p.dbg & 256) core.run(p, smem, m0, n0, kbeg, kbeg);
+    else core.run(p, smem, m0, n0, kbeg, kend);
+    if (p.dbg & 128) {
+        if (core.acc[0][0][0] == 1.2345f) epi(m0, n0, make_float4(0.f, 0.f, 0.f, 0.f));
+        return;
+    }
+#else
     core.run(p, smem, m0, n0, kbeg, kend);
+#endif
     if (slab == nullptr) {
         core.for_each(smem, m0, n0, epi);
     } else {

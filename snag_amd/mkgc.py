@@ -139,6 +139,7 @@ class MKGCHotPath:
         # 105.0 us for the visual projection + its reduce); it cost 290 MB, a full rewrite at every noise refresh (the refresh now touches
         # only the rows in the new or the previous mask) and a second layout for the weights.
         self.g_slot = M - 1                                   # structural token last
+        self.co_launch = True        # folded key / value products ride in snag_fusion_fwd's launches (False: launches of their own; the same bits -- tests)
         I, L, ffn = cfg.intermediate_size, cfg.num_layers, bool(cfg.use_intermediate)
 
         # ---- flat parameter layout ---------------------------------------------------------------
@@ -689,12 +690,14 @@ class MKGCHotPath:
                 call("snag_small_matmul", probs, len(probs), st)
             kv = [self._gemm_desc(Nl, 2 * D, D, ptr(self.mid[i]), D, 1, ptr(self.wf[i]), D, 1, self._qkv_ptr + 4 * (i * 3 * D + D), 3 * MD,
                                   bias=self.p["layer0.bqkv"].data_ptr() + 4 * D, splitk=False) for i in range(nmod)]
-            if nmod <= 2:             # launched by snag_fusion_fwd together with the read-out token's q/k/v projection (one grouped launch)
+            if nmod <= 2 and self.co_launch:      # launched by snag_fusion_fwd: ONE launch for the whole read-out forward at hidden_size 128 (csrc/readout_fused.hip),
+                                                  # otherwise one grouped launch with the read-out token's q/k/v projection
                 self._co_fwd = kv
                 for j, d in enumerate(kv):
                     self._fdesc.co_fwd[j] = ctypes.pointer(d)
                 self._fdesc.n_co_fwd = nmod
             else:
+                self._fdesc.n_co_fwd = 0
                 for i in range(0, nmod - 1, 2):
                     self._gemm_pair(kv[i], kv[i + 1])
                 if nmod % 2:

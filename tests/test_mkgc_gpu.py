@@ -269,6 +269,48 @@ def test_folded_second_projection_equals_the_unfolded_step(dropout, proj_dropout
         assert float((a[4][k] - b[4][k]).abs().max()) <= 1e-4 * scale, (k, float((a[4][k] - b[4][k]).abs().max()), scale)
 
 
+@pytest.mark.parametrize("N,heads,dropout,train", [(1500, 2, 0.1, True), (15000, 2, 0.1, True), (1000, 4, 0.0, True), (999, 1, 0.2, True), (70, 2, 0.1, False), (33, 2, 0.1, True)])
+def test_one_launch_readout_forward_equals_the_separate_launches_bit_for_bit(N, heads, dropout, train):
+    """csrc/readout_fused.hip: at hidden_size 128 with two folded projected tokens the read-out layer's forward -- seven key / value /
+    query products, the attention row, the output projection, the LayerNorm -- is ONE launch.  It repeats the arithmetic of the launches
+    it replaces statement by statement (split-bf16 products in mfma_split's order, sum64 as a reduce-scatter over the same lane bits,
+    ln_row_forward), so the read-out, every saved activation the backward reads, the loss and EVERY gradient are the same bits as with
+    the engine's separate launches (co_launch = False: the caller's key / value products as launches of their own, then the grouped
+    q|k|v product, attn_ro_fwd_kernel, gemm_tile_ln_kernel).  Ragged last workgroups (N % 64 = 39, 33, 6) included."""
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    R, B, K, D = 9, 128, 8, 128
+    g = torch.Generator().manual_seed(91)
+    feats = [torch.rand(N, 72, generator=g), torch.randn(N, 40, generator=g)]
+    idx = [torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(DEV) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (N, (B, K)))]
+    ent0 = torch.randn(N, D, generator=g).to(DEV)
+    out = {}
+    for co in (True, False):
+        cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[72, 40], num_proj=2, num_heads=heads, joint_way="Mformer_hd_graph", margin=6.0, neg_num=K,
+                         dropout=dropout, proj_dropout=0.1, add_noise=1, seed=7)
+        eng = MKGCHotPath(cfg, feats, device=DEV)
+        assert eng.fold and eng.ro
+        eng.co_launch = co
+        eng.p["ent"].copy_(ent0)
+        eng.update_noise()
+        if not train:
+            eng.eval()
+        loss = eng.forward(*idx, with_backward=train)
+        if train:
+            eng.backward()
+        torch.cuda.synchronize()
+        out[co] = (eng.entity_representation().clone(), loss.clone(), eng.save.clone()[:eng.save.numel() - 8 * 8 * 12288 // 4],
+                   {k: v.clone() for k, v in eng.named_gradients().items()} if train else {})
+    a, b = out[True], out[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # the saved activations (q|k|v, probs of the read-out row, ctx, the pre-LayerNorm sum, the LayerNorm statistics): everything either path wrote
+    # (regions neither path writes -- the other tokens' query columns, their probs -- hold whatever the allocation held: compared through the gradients)
+    D3, M = 3 * D, 3
+    qkv_a, qkv_b = a[2][:N * M * D3].view(N, M, D3), b[2][:N * M * D3].view(N, M, D3)
+    assert torch.equal(qkv_a[:, :, D:], qkv_b[:, :, D:]) and torch.equal(qkv_a[:, M - 1, :D], qkv_b[:, M - 1, :D])
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+
+
 def test_projection_head_dropout_in_the_engine():
     """num_proj=2 is the in-tree ProjectionHead, which drops between ReLU and l2 (model/layers.py:142-147): with proj_dropout > 0 the
     engine's step must equal the oracle's projection_head fed with the very masks the engine drew; eval mode ignores them."""
