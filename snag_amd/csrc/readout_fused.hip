@@ -29,6 +29,10 @@
 #ifndef SNAG_RO_NH
 #define SNAG_RO_NH 2             // 32-row halves per workgroup
 #endif
+#ifndef SNAG_RO_PRESPLIT
+#define SNAG_RO_PRESPLIT 1       // 1: the weights are split into k-tile images by a launch of their own (readout_presplit_kernel) and copied into the LDS;
+#endif                           // 0: the loop splits them itself -- one 16-byte load and two split_pair per thread and k-tile with 512 threads
+                                 // (same box: 4.7 + 58.8 us against 63.9 us in one launch; step 487.5 against 489.8 us)
 #ifndef SNAG_RO_STAMP
 #define SNAG_RO_STAMP 0          // diagnostic build: cycle stamps of one wave printed per launch
 #endif
@@ -154,6 +158,8 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
     const int valid = max(0, min(BM, N - m_first));            // rows of this half that exist
 
     f32x16 acc[TN];
+    int cur_tile = 0;                                          // the product that is running
+#if SNAG_RO_PRESPLIT
     constexpr int NB = NH == 1 ? 3 : 2;                        // 16-byte pieces of an image per thread (NH = 2: 768 pieces over 512 threads)
     u4 br[4][NB];                                              // four register sets of the weight stream
     // image i of the 64-step weight stream -> register set S; past the end: zeros through an empty descriptor, no traffic
@@ -173,6 +179,40 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
             if (NH == 1 || gtid + 512 * q < 768) *(lds_u4*)(im + 4096 * NH * q) = br[set][q];
 #endif
     };
+#else
+    // The weight stream in f32: thread = (weight row t / 4 [+ 64 with 256 threads], chunk t % 4) of a k-tile -- SplitStager<128, K-contiguous>'s
+    // mapping and split_pair, i.e. the bits the GEMM kernels put into their LDS images.  wcur / wnext: the weight rows of this product and
+    // the next one (set once per product: no scalar load, hence no lgkmcnt wait, inside the loop).
+    constexpr int NB = 2 / NH;
+    u4 br[4][NB];
+    const char *wcur = reinterpret_cast<const char*>(a.t[0].W), *wnext = wcur;
+    const uint32_t bvoff = (uint32_t)(gtid >> 2) * (uint32_t)(a.ldw * 4) + (uint32_t)(gtid & 3) * 16u;
+    const int bwr = (((gtid & 3) & 1) * 128 + (gtid >> 2)) * 16 + ((gtid & 3) >> 1) * 8;
+    // k-tile kt (0 .. 12) of the product that is running: past its eighth k-tile the next product's; past the last product: zeros, no traffic
+    auto fetch_b = [&](auto S, int i) {
+        constexpr int set = decltype(S)::value;
+        const int kt = i & 7;
+        const bool next = (i >> 3) != cur_tile;
+        const auto rsrc = uniform_rsrc(next ? wnext : wcur, i < 8 * kRoTiles ? 0xffffffffu : 0u);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) br[set][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, bvoff + (uint32_t)(64 * q) * (uint32_t)(a.ldw * 4), (uint32_t)kt * 64u, 0);
+    };
+    auto stage_b = [&](auto S, unsigned char* image) {
+        constexpr int set = decltype(S)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+        auto* im = (__attribute__((address_space(3))) unsigned char*)image + bwr;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            uint32_t h0, m0_, l0, h1, m1, l1;
+            split_pair(__uint_as_float(br[set][q][0]), __uint_as_float(br[set][q][1]), h0, m0_, l0);
+            split_pair(__uint_as_float(br[set][q][2]), __uint_as_float(br[set][q][3]), h1, m1, l1);
+            *(lds_u2*)(im + q * 64 * 16) = make_uint2(h0, h1);
+            *(lds_u2*)(im + q * 64 * 16 + 2 * 128 * 16) = make_uint2(m0_, m1);
+            *(lds_u2*)(im + q * 64 * 16 + 4 * 128 * 16) = make_uint2(l0, l1);
+        }
+#endif
+    };
+#endif
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>;
@@ -256,6 +296,11 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
         const RoTile& t = a.t[tile];
         SNAG_RO_ST(0);
         // the next product's A panel, if it is another one, and this product's bias travel while the product runs
+#if !SNAG_RO_PRESPLIT
+        cur_tile = tile;
+        wcur = reinterpret_cast<const char*>(t.W);
+        wnext = reinterpret_cast<const char*>(a.t[min(tile + 1, kRoTiles - 1)].W);
+#endif
         const int next_panel = tile + 1 < kRoTiles ? a.t[tile + 1].panel : t.panel;
         const bool switch_panel = next_panel != t.panel;
         if (switch_panel && next_panel < 3) pr.load(a.panel[next_panel], a.ldp[next_panel], m0, N, tid);
@@ -538,7 +583,9 @@ int64_t readout_fused_image_bytes() { return (int64_t)8 * kRoTiles * kBImg; }
 
 int readout_fwd_fused(const RoFusedArgs& a, hipStream_t st) {
     if (a.N <= 0) return SNAG_OK;
+#if SNAG_RO_PRESPLIT
     hipLaunchKernelGGL(readout_presplit_kernel, dim3(8 * kRoTiles), dim3(256), 0, st, a);
+#endif
     hipLaunchKernelGGL((readout_fwd_fused_kernel<SNAG_RO_BM, SNAG_RO_NH>), dim3((unsigned)ceil_div(a.N, SNAG_RO_BM * SNAG_RO_NH)), dim3(256 * SNAG_RO_NH), 0, st, a);
     return check_launch("fusion read-out forward (one launch)");
 }
