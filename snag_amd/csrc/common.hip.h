@@ -118,13 +118,59 @@ static inline int env_int(const char* name) {
     return v ? atoi(v) : 0;
 }
 
+// The two slab reductions of a layer's backward (results nobody reads before the optimiser): y = 0 -> the LayerNorm slab [nb3][3][D]
+// into dgamma / dbeta / dbias, y = 1 -> the attention slab [nbq][3D] into the stacked q/k/v bias gradient.  Column block x covers 64 columns.
+// Sixteen partial sums per column (slab rows split into sixteen runs), then their sum in order (the arithmetic of the launch this used to be).
+struct SlabColsum {
+    const float* part3; int nb3; int D;
+    float *a, *b, *c;
+    const float* partq; int nbq;
+    float* outq;
+    int accumulate;
+};
+// 256 threads = 16 runs x 16 columns (column block bx covers 16 columns): every run of a column has its own thread, as in a launch of
+// sixteen waves, so the role is as short as that launch was (6.8 us) and hides behind the reduce it rides with.
+__device__ __forceinline__ void slab_colsum_body(const SlabColsum& s, int bx, int by, float (*red)[16]) {
+    const int run = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    const int c = bx * 16 + cl;
+    const int ncol = 3 * s.D;
+    const bool ln = by == 0;
+    const float* part = ln ? s.part3 : s.partq;
+    const int nblocks = ln ? s.nb3 : s.nbq;
+    const int64_t stride = ncol;
+    const int per = (nblocks + 15) / 16;
+    const int b0 = run * per, b1 = min(nblocks, b0 + per);
+    float sum = 0.f;
+    if (c < ncol) {
+        int blk = b0;
+        for (; blk + 8 <= b1; blk += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = part[(int64_t)(blk + u) * stride + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += t[u];
+        }
+        for (; blk < b1; ++blk) sum += part[(int64_t)blk * stride + c];
+    }
+    red[run][cl] = sum;
+    __syncthreads();
+    if (run == 0 && c < ncol) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w][cl];
+        float* dst = ln ? (c < s.D ? s.a + c : (c < 2 * s.D ? s.b + (c - s.D) : s.c + (c - 2 * s.D))) : s.outq + c;
+        *dst = s.accumulate ? *dst + t : t;
+    }
+}
+
 // gemm.hip
 int gemm_check(const snag_gemm_desc* d);
 int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st);
 int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStream_t st);
 int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st);   // 2..6 problems, one launch when their plans allow
 // finishes problems launched with defer_reduce (+ optionally up to four small products in the same launch)
-int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, const snag_small_mm* small = nullptr, int n_small = 0);
+// (+ optionally a layer's slab reductions, independent of everything the launch reduces: a 7 us launch of their own otherwise)
+int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, const snag_small_mm* small = nullptr, int n_small = 0, const SlabColsum* colsum = nullptr);
 int64_t gemm_workspace_floats(int M, int N, int K);
 // C = epilogue(A B) AND y = LayerNorm(C) (rows of y D = N wide, dense) in ONE launch, when the product runs as unsplit 64 x 128 tiles that hold
 // whole rows (N <= 128; K < 512 or M < 1024; no workspace, accumulate, pre_act, mirror or transposed store).  Returns 1 -- nothing launched --

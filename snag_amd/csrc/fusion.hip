@@ -446,8 +446,8 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             float* ro3 = (f->fold_others && M >= 3) ? dq_g : nullptr;
             SNAG_MNU(attn_ro_bwd_kernel, M, D, dim3(ablocks), st, (const float*)S.qkv, (const float*)W.dC, N, D, H, ro, 1.0f / sqrtf((float)(D / H)),
                      P.keep_probs, kscale, dq_g, dkv, partq, ro3);
-            hipLaunchKernelGGL(slab_colsum_ro_kernel, dim3(ceil_div(3 * D, 64), 2), dim3(1024), 0, st, (const float*)W.part, lnblocks, D, G.ln1_g, G.ln1_b, G.bo,
-                               (const float*)partq, ablocks, G.bqkv, acc);
+            // (the two bias / LayerNorm slab sums ride in the weight gradients' reduce launch below: nobody reads them before the optimiser)
+            const SlabColsum slabs{W.part, lnblocks, D, G.ln1_g, G.ln1_b, G.bo, partq, ablocks, G.bqkv, acc};
             if ((rc = check_launch("fusion attention backward (read-out)"))) return rc;
             float* dxin = (l == 0) ? b->d_x0 : W.dC;
             if (ro3) {
@@ -463,7 +463,7 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
                 int ng = 2;
                 for (int i = 0; i < b->n_co_dw; ++i) grp[ng++] = b->co_dw[i];
                 if ((rc = gemm_dispatch_group(grp, ng, st))) return rc;
-                if ((rc = gemm_reduce_multi(grp, ng, st))) return rc;
+                if ((rc = gemm_reduce_multi(grp, ng, st, nullptr, 0, &slabs))) return rc;
                 // d(layer input), rows of token ro: [dq | dk | dv] Wqkv + dT1 (K = 3D), with the caller's co_dx problems in the same launch
                 g = gemm_desc(N, D, 3 * D, ro3, 3 * D, true, P.wqkv, D, false, dxin + (int64_t)ro * D, MD);
                 g.add1 = W.dA; g.ld1 = D;
@@ -493,7 +493,7 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
                 if ((rc = gemm_dispatch_pair(&g0, &g1, st))) return rc;
                 if ((rc = gemm_dispatch(&gk, st))) return rc;
                 const snag_gemm_desc* three[3] = {&g0, &g1, &gk};
-                if ((rc = gemm_reduce_multi(three, 3, st))) return rc;
+                if ((rc = gemm_reduce_multi(three, 3, st, nullptr, 0, &slabs))) return rc;
             }
             // d(layer input) = dkv Wkv for every token, + dq_g Wq + dT1 into the rows of token ro
             g = f->fold_others ? gemm_desc(N, D, 2 * D, dkv + (int64_t)ro * 2 * D, 2 * MD, true, P.wqkv + (int64_t)D * D, D, false, dxin + (int64_t)ro * D, MD)
@@ -554,8 +554,7 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
         const int ablocks = (int)std::min<int64_t>(kRedBlocks, (N + 3) / 4);
         SNAG_MNU(attn_bwd_kernel, M, D, dim3(ablocks), st, (const float*)S.qkv, (const float*)W.dC, N, D, H, 1.0f / sqrtf((float)(D / H)), P.keep_probs,
                  kscale, (l == L - 1) ? dpx : (const float*)nullptr, W.dqkv, partq);
-        hipLaunchKernelGGL(slab_colsum_ro_kernel, dim3(ceil_div(3 * D, 64), 2), dim3(1024), 0, st, (const float*)W.part, lnblocks, D, G.ln1_g, G.ln1_b, G.bo,
-                           (const float*)partq, ablocks, G.bqkv, acc);
+        const SlabColsum slabs{W.part, lnblocks, D, G.ln1_g, G.ln1_b, G.bo, partq, ablocks, G.bqkv, acc};      // (ride in the reduce launch below)
         if ((rc = check_launch("fusion attention backward"))) return rc;
         // the layer's two weight gradients, dWqkv = dqkv^T xin [3D, D] and dWo = dz^T ctx [D, D] (both K = N M rows, independent): ONE
         // grouped launch + ONE reduce (they used to be two launches and two reduces around the attention backward)
@@ -568,7 +567,7 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             g0.defer_reduce = g1.defer_reduce = 1;
             const snag_gemm_desc* grp[2] = {&g1, &g0};
             if ((rc = gemm_dispatch_group(grp, 2, st))) return rc;
-            if ((rc = gemm_reduce_multi(grp, 2, st))) return rc;
+            if ((rc = gemm_reduce_multi(grp, 2, st, nullptr, 0, &slabs))) return rc;
         }
         // d(layer input) = dqkv Wqkv + dT1 (+ epilogue route at layer 0)
         float* dxin = (l == 0) ? b->d_x0 : W.dC;

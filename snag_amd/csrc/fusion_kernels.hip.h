@@ -614,45 +614,6 @@ static __global__ __launch_bounds__(1024) void slab_colsum3_kernel(const float* 
     }
 }
 
-// The two slab reductions of the read-out layer's backward in ONE launch (both are 6-block, latency-bound launches whose results
-// nobody reads before the optimiser): blockIdx.y = 0 -> the LayerNorm slab [nb3][3][D] into dgamma / dbeta / dbias (slab_colsum3's
-// arithmetic), blockIdx.y = 1 -> the attention slab [nbq][3D] into the stacked q/k/v bias gradient (slab_colsum's).
-static __global__ __launch_bounds__(1024) void slab_colsum_ro_kernel(const float* __restrict__ part3, int nb3, int D, float* __restrict__ a,
-                                                                      float* __restrict__ b, float* __restrict__ c_, const float* __restrict__ partq,
-                                                                      int nbq, float* __restrict__ outq, int accumulate) {
-    __shared__ float red[16][64];
-    const int lane = threadIdx.x & 63, wave = wave_id_uniform();
-    const int c = blockIdx.x * 64 + lane;
-    const int ncol = 3 * D;
-    const bool ln = blockIdx.y == 0;
-    const float* part = ln ? part3 : partq;
-    const int nblocks = ln ? nb3 : nbq;
-    const int64_t stride = ncol;
-    const int per = (nblocks + 15) / 16;
-    const int b0 = wave * per, b1 = min(nblocks, b0 + per);
-    float s = 0.f;
-    if (c < ncol) {
-        int blk = b0;
-        for (; blk + 8 <= b1; blk += 8) {
-            float t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = part[(int64_t)(blk + u) * stride + c];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += t[u];
-        }
-        for (; blk < b1; ++blk) s += part[(int64_t)blk * stride + c];
-    }
-    red[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0 && c < ncol) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) t += red[w][lane];
-        float* dst = ln ? (c < D ? a + c : (c < 2 * D ? b + (c - D) : c_ + (c - 2 * D))) : outq + c;
-        *dst = accumulate ? *dst + t : t;
-    }
-}
-
 // column sums of a [R, C] matrix (bias gradients): part[blockIdx.y][c]
 static __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, int64_t R, int C, int64_t ld,
                                                           float* __restrict__ part) {

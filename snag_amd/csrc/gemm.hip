@@ -215,10 +215,17 @@ struct ReduceSet {
     Epilogue e[4];
 };
 // (blockIdx.y == n_reduce: the small products of snag_gemm_reduce_group_mm, one 16 x 16 output tile per workgroup)
-__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceSet rs, int n_reduce, SmallMMSet mm, int mm_blocks) {
+// (blockIdx.y behind those: a layer's slab reductions, 2 x ceil(3 D / 16) workgroups)
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceSet rs, int n_reduce, SmallMMSet mm, int mm_blocks, SlabColsum cs, int cs_blocks) {
     const int q = blockIdx.y;
     if (q >= n_reduce) {
-        if ((int)blockIdx.x < mm_blocks) small_matmul_body(mm, (int)blockIdx.x);
+        if (q == n_reduce && mm_blocks > 0) {
+            if ((int)blockIdx.x < mm_blocks) small_matmul_body(mm, (int)blockIdx.x);
+        } else if ((int)blockIdx.x < cs_blocks) {
+            __shared__ float red[16][16];
+            const int ncb = cs_blocks / 2;
+            slab_colsum_body(cs, (int)blockIdx.x % ncb, (int)blockIdx.x / ncb, red);
+        }
         return;
     }
     if ((int)blockIdx.x >= rs.nblk[q]) return;
@@ -800,7 +807,9 @@ static int launch_reduce(const GemmPlan& pl, float* slab, hipStream_t st) {
 }
 
 // finishes up to four problems launched with defer_reduce (distinct workspaces): ONE launch for all that left slabs behind
-int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, const snag_small_mm* small, int n_small) {
+int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, const snag_small_mm* small, int n_small, const SlabColsum* colsum) {
+    const int cs_blocks = colsum ? 2 * ceil_div(3 * colsum->D, 16) : 0;
+    const SlabColsum cs = colsum ? *colsum : SlabColsum{};
     SmallMMSet mm{};
     int mm_blocks = 0;
     if (n_small > 0) {
@@ -827,9 +836,10 @@ int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, co
         last = pl; last_slab = d->workspace;
         ++cnt;
     }
-    if (cnt == 0 && mm_blocks == 0) return SNAG_OK;
-    if (cnt == 1 && mm_blocks == 0) return launch_reduce(last, last_slab, st);
-    hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(std::max(maxblk, mm_blocks), cnt + (mm_blocks > 0 ? 1 : 0)), dim3(256), 0, st, rs, cnt, mm, mm_blocks);
+    if (cnt == 0 && mm_blocks == 0 && cs_blocks == 0) return SNAG_OK;
+    if (cnt == 1 && mm_blocks == 0 && cs_blocks == 0) return launch_reduce(last, last_slab, st);
+    hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(std::max(std::max(maxblk, mm_blocks), cs_blocks), cnt + (mm_blocks > 0 ? 1 : 0) + (cs_blocks > 0 ? 1 : 0)),
+                       dim3(256), 0, st, rs, cnt, mm, mm_blocks, cs, cs_blocks);
     return check_launch("snag_gemm_reduce_group");
 }
 

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
     const int valid = max(0, min(BM, N - m_first));            // rows of this half that exist
 
     f32x16 acc[TN];
-    int cur_tile = 0;                                          // the product that is running
+    [[maybe_unused]] int cur_tile = 0;                         // the product that is running
 #if SNAG_RO_PRESPLIT
     constexpr int NB = NH == 1 ? 3 : 2;                        // 16-byte pieces of an image per thread (NH = 2: 768 pieces over 512 threads)
     u4 br[4][NB];                                              // four register sets of the weight stream
