@@ -371,8 +371,17 @@ typedef struct snag_fusion_desc {
      * operands are ready when snag_fusion_fwd is called. */
     const snag_gemm_desc* co_fwd[2];
     int32_t n_co_fwd;
+    /* 1: the split weight images of the one-launch read-out forward were prepared for THIS step's weights by snag_fusion_fwd_prepare_reduce
+     * (which reports it); snag_fusion_fwd then skips its own preparation launch.  0 (default): snag_fusion_fwd prepares them itself. */
+    int32_t weight_images_ready;
 } snag_fusion_desc;
 
+/* snag_gemm_reduce_group(descs, n) AND, in the same launch, the preparation of the read-out forward's weight images for `f` (its layers'
+ * parameters and co_fwd products as snag_fusion_fwd will see them; the weights must be final, the activations need not exist yet): the
+ * preparation is parameter-sized, depends on nothing the reduce touches, and a launch of its own costs ~5 us on the step's critical path.
+ * *prepared = 1 when the images were written (set f->weight_images_ready = 1 for the coming snag_fusion_fwd), 0 when `f` does not take the
+ * one-launch path (nothing else changes: the reduce ran). */
+SNAG_API int snag_fusion_fwd_prepare_reduce(const snag_fusion_desc* f, const snag_gemm_desc* const* descs, int n, int32_t* prepared, void* stream);
 SNAG_API int64_t snag_fusion_save_floats(int N, int M, int D, int H, int I, int L, int use_intermediate);
 SNAG_API int64_t snag_fusion_work_floats(int N, int M, int D, int H, int I, int L, int use_intermediate);
 SNAG_API int snag_fusion_fwd(const snag_fusion_desc* desc, void* stream);

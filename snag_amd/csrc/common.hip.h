@@ -163,6 +163,14 @@ __device__ __forceinline__ void slab_colsum_body(const SlabColsum& s, int bx, in
     }
 }
 
+// The weights of the one-launch read-out forward (csrc/readout_fused.hip) as split k-tile images in consumption order: image 8 s + kt =
+// k-tile kt of product s, 12 KB each.  One workgroup (256 threads) per image.
+struct RoWeightImages {
+    const float* W[8];         // 128 weight rows each, K-contiguous, pitch ldw floats
+    int ldw;
+    unsigned char* wimg;
+};
+
 // gemm.hip
 int gemm_check(const snag_gemm_desc* d);
 int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st);
@@ -170,7 +178,8 @@ int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipSt
 int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st);   // 2..6 problems, one launch when their plans allow
 // finishes problems launched with defer_reduce (+ optionally up to four small products in the same launch)
 // (+ optionally a layer's slab reductions, independent of everything the launch reduces: a 7 us launch of their own otherwise)
-int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, const snag_small_mm* small = nullptr, int n_small = 0, const SlabColsum* colsum = nullptr);
+int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, const snag_small_mm* small = nullptr, int n_small = 0, const SlabColsum* colsum = nullptr,
+                      const RoWeightImages* images = nullptr);      // (+ optionally the 64 weight images of the read-out forward)
 int64_t gemm_workspace_floats(int M, int N, int K);
 // C = epilogue(A B) AND y = LayerNorm(C) (rows of y D = N wide, dense) in ONE launch, when the product runs as unsplit 64 x 128 tiles that hold
 // whole rows (N <= 128; K < 512 or M < 1024; no workspace, accumulate, pre_act, mirror or transposed store).  Returns 1 -- nothing launched --

@@ -120,13 +120,13 @@ static int check_fusion(const snag_fusion_desc* f) {
 // The read-out layer's forward as ONE launch (readout_fused.hip) when the shape is the one that kernel is written for: hidden_size 128,
 // three tokens of which two are projected tokens whose keys / values the caller computes from folded weights (co_fwd), no FFN.
 // Returns 1 -- nothing launched -- otherwise; the three-launch path below gives the same bits.
-static int fusion_fwd_readout_one_launch(const snag_fusion_desc* f, const snag_fusion_layer& P, const LayerSave& S, const float* xin, hipStream_t st) {
+static int readout_one_launch_args(const snag_fusion_desc* f, const snag_fusion_layer& P, const LayerSave& S, const float* xin, RoFusedArgs& a) {
     const int N = f->N, M = f->M, D = f->D, H = f->H, g = f->readout_slot_p1 - 1;
     if (!(f->fold_others && f->n_co_fwd == 2 && M == 3 && D == 128 && !f->use_intermediate && H <= kRoMaxHeads)) return 1;
     const int64_t MD = (int64_t)M * D;
     auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!aligned(xin) || !aligned(P.wqkv) || !aligned(P.wo)) return 1;
-    RoFusedArgs a{};
+    a = RoFusedArgs{};
     a.N = N; a.H = H; a.g = g; a.ldw = D;
     a.inv_sqrt_d = 1.0f / sqrtf((float)(D / H));
     a.panel[0] = xin + (int64_t)g * D; a.ldp[0] = MD;
@@ -171,7 +171,13 @@ static int fusion_fwd_readout_one_launch(const snag_fusion_desc* f, const snag_f
     a.ln_g = P.ln1_g; a.ln_b = P.ln1_b; a.eps = 1e-12f;
     a.hidden = f->hidden; a.stats = S.st1;
     a.wimg = reinterpret_cast<unsigned char*>(f->save + SaveLayout(N, M, D, H, f->I, false).per_layer * f->L);
-    return readout_fwd_fused(a, st);
+    return SNAG_OK;
+}
+
+static int fusion_fwd_readout_one_launch(const snag_fusion_desc* f, const snag_fusion_layer& P, const LayerSave& S, const float* xin, hipStream_t st) {
+    RoFusedArgs a;
+    const int rc = readout_one_launch_args(f, P, S, xin, a);
+    return rc ? rc : readout_fwd_fused(a, st, f->weight_images_ready != 0);
 }
 
 // Last layer when only token g = readout_slot_p1 - 1 is consumed (joint_way Mformer_hd_graph): keys / values for all M tokens, but
@@ -583,6 +589,29 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
 }  // namespace snag
 
 using namespace snag;
+
+extern "C" SNAG_API int snag_fusion_fwd_prepare_reduce(const snag_fusion_desc* f, const snag_gemm_desc* const* descs, int n, int32_t* prepared, void* stream) {
+    SNAG_REQUIRE(prepared != nullptr && n >= 0 && n <= 4 && (n == 0 || descs != nullptr), SNAG_ERR_ARG, "fusion_fwd_prepare_reduce: bad arguments");
+    *prepared = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = gemm_check(descs[i]);
+        if (rc) return rc;
+    }
+    RoFusedArgs a;
+    RoWeightImages w{};
+    bool fused = false;
+    if (f != nullptr && f->N > 0 && f->L == 1 && f->readout_slot_p1 > 0 && check_fusion(f) == SNAG_OK) {
+        // (one layer: the read-out layer's input is x0, known before the forward runs)
+        const LayerSave S = SaveLayout(f->N, f->M, f->D, f->H, f->I, f->use_intermediate != 0).at(f->save, 0);
+        if (readout_one_launch_args(f, f->layers[0], S, f->x0, a) == SNAG_OK) {
+            w = readout_weight_images(a);
+            fused = true;
+        }
+    }
+    const int rc = gemm_reduce_multi(descs, n, (hipStream_t)stream, nullptr, 0, nullptr, fused ? &w : nullptr);
+    if (rc == SNAG_OK && fused) *prepared = 1;
+    return rc;
+}
 
 extern "C" SNAG_API int64_t snag_fusion_save_floats(int N, int M, int D, int H, int I, int L, int use_intermediate) {
     if (N < 0 || M < 1 || D < 1 || H < 1 || L < 1) return 0;

@@ -214,29 +214,55 @@ struct ReduceSet {
     int splits[4], mode[4], nblk[4];
     Epilogue e[4];
 };
-// (blockIdx.y == n_reduce: the small products of snag_gemm_reduce_group_mm, one 16 x 16 output tile per workgroup)
-// (blockIdx.y behind those: a layer's slab reductions, 2 x ceil(3 D / 16) workgroups)
-__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceSet rs, int n_reduce, SmallMMSet mm, int mm_blocks, SlabColsum cs, int cs_blocks) {
-    const int q = blockIdx.y;
-    if (q >= n_reduce) {
-        if (q == n_reduce && mm_blocks > 0) {
-            if ((int)blockIdx.x < mm_blocks) small_matmul_body(mm, (int)blockIdx.x);
-        } else if ((int)blockIdx.x < cs_blocks) {
-            __shared__ float red[16][16];
-            const int ncb = cs_blocks / 2;
-            slab_colsum_body(cs, (int)blockIdx.x % ncb, (int)blockIdx.x / ncb, red);
-        }
+// A 1-D grid: the riders that are present, then the reduce problems' workgroups one problem after the other.  Riders: the small products of
+// snag_gemm_reduce_group_mm (one 16 x 16 output tile per workgroup), a layer's slab reductions (2 x ceil(3 D / 16) workgroups), the 64
+// weight images of the one-launch read-out forward.  (A problem-per-row grid padded every row to the longest one: 3,686 empty workgroups
+// beside the 64 of the weight images.)
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceSet rs, int n_reduce, SmallMMSet mm, int mm_blocks, SlabColsum cs, int cs_blocks,
+                                                                  RoWeightImages wi, int wi_blocks) {
+    int b = (int)blockIdx.x;          // (riders first: latency-bound work starts with the launch and hides behind the reduce's stream)
+    if (b < mm_blocks) {
+        small_matmul_body(mm, b);
         return;
     }
-    if ((int)blockIdx.x >= rs.nblk[q]) return;
-    if (rs.mode[q] == 2) splitk_reduce_small_body(rs.slab[q], rs.splits[q], rs.e[q], blockIdx.x);
-    else if (rs.mode[q] == 1) splitk_reduce_body<true>(rs.slab[q], rs.splits[q], rs.e[q], (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)rs.nblk[q] * 256);
-    else splitk_reduce_body<false>(rs.slab[q], rs.splits[q], rs.e[q], (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)rs.nblk[q] * 256);
+    b -= mm_blocks;
+    if (b < cs_blocks) {
+        __shared__ float red[16][16];
+        const int ncb = cs_blocks / 2;
+        slab_colsum_body(cs, b % ncb, b / ncb, red);
+        return;
+    }
+    b -= cs_blocks;
+    if (b < wi_blocks) {
+        ro_weight_image_body(wi, b);
+        return;
+    }
+    b -= wi_blocks;
+    for (int q = 0; q < n_reduce; ++q) {
+        if (b < rs.nblk[q]) {
+            if (rs.mode[q] == 2) splitk_reduce_small_body(rs.slab[q], rs.splits[q], rs.e[q], b);
+            else if (rs.mode[q] == 1) splitk_reduce_body<true>(rs.slab[q], rs.splits[q], rs.e[q], (int64_t)b * 256 + threadIdx.x, (int64_t)rs.nblk[q] * 256);
+            else splitk_reduce_body<false>(rs.slab[q], rs.splits[q], rs.e[q], (int64_t)b * 256 + threadIdx.x, (int64_t)rs.nblk[q] * 256);
+            return;
+        }
+        b -= rs.nblk[q];
+    }
 }
 
 template <bool QUAD>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, Epilogue epi) {
     splitk_reduce_body<QUAD>(slab, splits, epi, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+}
+
+// one problem + the 64 weight images of the one-launch read-out forward in front (the generic multi-problem kernel is ~2 us slower on the
+// same reduce: four epilogues in the kernel arguments, indexed at run time)
+template <bool QUAD>
+__global__ __launch_bounds__(256) void splitk_reduce_images_kernel(const float* __restrict__ slab, int splits, Epilogue epi, RoWeightImages wi) {
+    if (blockIdx.x < 64) {
+        ro_weight_image_body(wi, (int)blockIdx.x);
+        return;
+    }
+    splitk_reduce_body<QUAD>(slab, splits, epi, (int64_t)(blockIdx.x - 64) * 256 + threadIdx.x, (int64_t)(gridDim.x - 64) * 256);
 }
 
 // the same for the two problems of gemm_tile_pair_kernel (blockIdx.y = problem)
@@ -807,9 +833,12 @@ static int launch_reduce(const GemmPlan& pl, float* slab, hipStream_t st) {
 }
 
 // finishes up to four problems launched with defer_reduce (distinct workspaces): ONE launch for all that left slabs behind
-int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, const snag_small_mm* small, int n_small, const SlabColsum* colsum) {
+int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, const snag_small_mm* small, int n_small, const SlabColsum* colsum,
+                      const RoWeightImages* images) {
     const int cs_blocks = colsum ? 2 * ceil_div(3 * colsum->D, 16) : 0;
     const SlabColsum cs = colsum ? *colsum : SlabColsum{};
+    const int wi_blocks = images ? 64 : 0;
+    const RoWeightImages wi = images ? *images : RoWeightImages{};
     SmallMMSet mm{};
     int mm_blocks = 0;
     if (n_small > 0) {
@@ -817,7 +846,7 @@ int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, co
         if (mm_blocks < 0) return mm_blocks;
     }
     ReduceSet rs{};
-    int cnt = 0, maxblk = 0;
+    int cnt = 0;
     GemmPlan last{};
     float* last_slab = nullptr;
     for (int i = 0; i < n && i < 4; ++i) {
@@ -832,14 +861,19 @@ int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, co
         rs.mode[cnt] = quad ? (reduce_small(total, pl.splits) ? 2 : 1) : 0;
         rs.nblk[cnt] = rs.mode[cnt] == 2 ? (int)((total / 4 + 63) / 64) : (int)std::min<int64_t>(2048, (total / (quad ? 4 : 1) + 255) / 256);
         rs.e[cnt] = pl.e;
-        maxblk = std::max(maxblk, rs.nblk[cnt]);
         last = pl; last_slab = d->workspace;
         ++cnt;
     }
-    if (cnt == 0 && mm_blocks == 0 && cs_blocks == 0) return SNAG_OK;
-    if (cnt == 1 && mm_blocks == 0 && cs_blocks == 0) return launch_reduce(last, last_slab, st);
-    hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(std::max(std::max(maxblk, mm_blocks), cs_blocks), cnt + (mm_blocks > 0 ? 1 : 0) + (cs_blocks > 0 ? 1 : 0)),
-                       dim3(256), 0, st, rs, cnt, mm, mm_blocks, cs, cs_blocks);
+    if (cnt == 0 && mm_blocks == 0 && cs_blocks == 0 && wi_blocks == 0) return SNAG_OK;
+    if (cnt == 1 && mm_blocks == 0 && cs_blocks == 0 && wi_blocks == 0) return launch_reduce(last, last_slab, st);
+    if (cnt == 1 && mm_blocks == 0 && cs_blocks == 0 && rs.mode[0] != 2) {          // one problem + the weight images
+        if (rs.mode[0] == 1) hipLaunchKernelGGL(splitk_reduce_images_kernel<true>, dim3(rs.nblk[0] + 64), dim3(256), 0, st, rs.slab[0], rs.splits[0], rs.e[0], wi);
+        else hipLaunchKernelGGL(splitk_reduce_images_kernel<false>, dim3(rs.nblk[0] + 64), dim3(256), 0, st, rs.slab[0], rs.splits[0], rs.e[0], wi);
+        return check_launch("snag_gemm_reduce_group");
+    }
+    int total_blocks = mm_blocks + cs_blocks + wi_blocks;
+    for (int i = 0; i < cnt; ++i) total_blocks += rs.nblk[i];
+    hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, rs, cnt, mm, mm_blocks, cs, cs_blocks, wi, wi_blocks);
     return check_launch("snag_gemm_reduce_group");
 }
 

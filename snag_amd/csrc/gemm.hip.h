@@ -366,6 +366,25 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint
     l = cvt_pk_bf16(s0, s1);
 }
 
+// One weight image of RoWeightImages: SplitStager<128, K-contiguous>'s thread mapping and split_pair -- the bits the GEMM kernels put into
+// their LDS images -- written to memory instead.
+__device__ __forceinline__ void ro_weight_image_body(const RoWeightImages& w, int image) {
+    const int s = image >> 3, kt = image & 7, tid = threadIdx.x;
+    const int row = tid >> 2, c = tid & 3;
+    const float* W = w.W[s];
+    unsigned char* im = w.wimg + (size_t)image * (6 * 128 * 16) + ((c & 1) * 128 + row) * 16 + (c >> 1) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float4 f = *reinterpret_cast<const float4*>(W + (int64_t)(row + 64 * i) * w.ldw + kt * 16 + c * 4);
+        uint32_t h0, m0, l0, h1, m1, l1;
+        split_pair(f.x, f.y, h0, m0, l0);
+        split_pair(f.z, f.w, h1, m1, l1);
+        *reinterpret_cast<uint2*>(im + i * 64 * 16) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(im + i * 64 * 16 + 2 * 128 * 16) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(im + i * 64 * 16 + 4 * 128 * 16) = make_uint2(l0, l1);
+    }
+}
+
 // VK: a K-contiguous operand is fetched by 16-byte loads as a COMPILE-TIME choice; otherwise the choice is the run-time `vec`.  With the
 // run-time branch around the loads the compiler cannot count them and the waits of the ping-pong loop degrade to one vmcnt(0) every
 // fourth iteration (all register sets landed) instead of vmcnt(9) in each: use_vec() in gemm.hip picks VK whenever it is legal.

@@ -115,24 +115,9 @@ struct Panel {
 
 }  // namespace
 
-// The weights of the eight products as k-tile images in consumption order: image 8 s + kt = k-tile kt of step s.  One workgroup per
-// image, SplitStager<128, K-contiguous>'s thread mapping and split_pair: the bits the GEMM kernels put into their LDS images.
-__global__ __launch_bounds__(256) void readout_presplit_kernel(RoFusedArgs a) {
-    const int s = blockIdx.x >> 3, kt = blockIdx.x & 7, tid = threadIdx.x;
-    const int row = tid >> 2, c = tid & 3;
-    const float* W = a.t[s].W;
-    unsigned char* im = a.wimg + (size_t)blockIdx.x * kBImg + ((c & 1) * 128 + row) * 16 + (c >> 1) * 8;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float4 f = *reinterpret_cast<const float4*>(W + (int64_t)(row + 64 * i) * a.ldw + kt * 16 + c * 4);
-        uint32_t h0, m0, l0, h1, m1, l1;
-        split_pair(f.x, f.y, h0, m0, l0);
-        split_pair(f.z, f.w, h1, m1, l1);
-        *reinterpret_cast<uint2*>(im + i * 64 * 16) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(im + i * 64 * 16 + 2 * 128 * 16) = make_uint2(m0, m1);
-        *reinterpret_cast<uint2*>(im + i * 64 * 16 + 4 * 128 * 16) = make_uint2(l0, l1);
-    }
-}
+// The weights of the eight products as k-tile images in consumption order (ro_weight_image_body, gemm.hip.h): a launch of its own when
+// nobody prepared them (snag_fusion_fwd_prepare_reduce lets them ride in a split-K reduce launch of the step instead).
+__global__ __launch_bounds__(256) void readout_presplit_kernel(RoWeightImages w) { ro_weight_image_body(w, (int)blockIdx.x); }
 
 // NH: 32-row halves per workgroup (BM = 32 only).  NH = 2: eight waves, each half with its own A images and row tile, ONE weight stream
 // for both -- the images cross from the L2 once per 64 entities instead of once per 32 (469 workgroups x 768 KB = 360 MB ran at the
@@ -581,10 +566,18 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
 
 int64_t readout_fused_image_bytes() { return (int64_t)8 * kRoTiles * kBImg; }
 
-int readout_fwd_fused(const RoFusedArgs& a, hipStream_t st) {
+RoWeightImages readout_weight_images(const RoFusedArgs& a) {
+    RoWeightImages w{};
+    for (int i = 0; i < kRoTiles; ++i) w.W[i] = a.t[i].W;
+    w.ldw = a.ldw;
+    w.wimg = a.wimg;
+    return w;
+}
+
+int readout_fwd_fused(const RoFusedArgs& a, hipStream_t st, bool images_ready) {
     if (a.N <= 0) return SNAG_OK;
 #if SNAG_RO_PRESPLIT
-    hipLaunchKernelGGL(readout_presplit_kernel, dim3(8 * kRoTiles), dim3(256), 0, st, a);
+    if (!images_ready) hipLaunchKernelGGL(readout_presplit_kernel, dim3(8 * kRoTiles), dim3(256), 0, st, readout_weight_images(a));
 #endif
     hipLaunchKernelGGL((readout_fwd_fused_kernel<SNAG_RO_BM, SNAG_RO_NH>), dim3((unsigned)ceil_div(a.N, SNAG_RO_BM * SNAG_RO_NH)), dim3(256 * SNAG_RO_NH), 0, st, a);
     return check_launch("fusion read-out forward (one launch)");

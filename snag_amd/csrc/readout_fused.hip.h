@@ -40,6 +40,8 @@ struct RoFusedArgs {
 };
 
 int64_t readout_fused_image_bytes();
-int readout_fwd_fused(const RoFusedArgs& a, hipStream_t st);
+RoWeightImages readout_weight_images(const RoFusedArgs& a);
+// images_ready: the weight images in a.wimg are this step's already (prepared inside another launch): no preparation launch
+int readout_fwd_fused(const RoFusedArgs& a, hipStream_t st, bool images_ready);
 
 }  // namespace snag

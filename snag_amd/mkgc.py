@@ -425,7 +425,7 @@ class MKGCHotPath:
                 return s
             s[i] += 1
 
-    def _grouped_long_k(self, descs, shapes, tags=None, small=None):
+    def _grouped_long_k(self, descs, shapes, tags=None, small=None, prepare_fusion=False):
         """Two long-K split-K GEMMs (the modalities' first projections, or their weight gradients) as ONE launch of eight-wave tiles with
         balanced K splits + ONE reduce; False when the shapes do not qualify (the caller then launches them one by one).
         ``small``: an array of independent snag_small_mm products that ride in the reduce launch (snag_gemm_reduce_group_mm)."""
@@ -441,9 +441,21 @@ class MKGCHotPath:
         self._probed(tag, call, "snag_gemm_f32_group", group, 2, self._st)
         if small is not None:
             self._probed((tag + "_reduce") if tag else "", call, "snag_gemm_reduce_group_mm", group, 2, small, len(small), self._st)
+        elif prepare_fusion:
+            # the reduce launch also prepares the weight images of the one-launch read-out forward (parameter-sized, independent of the reduce)
+            ready = ctypes.c_int32(0)
+            self._probed((tag + "_reduce") if tag else "", call, "snag_fusion_fwd_prepare_reduce", ctypes.byref(self._fdesc), group, 2, ctypes.byref(ready), self._st)
+            self._fdesc.weight_images_ready = ready.value
         else:
             self._probed((tag + "_reduce") if tag else "", call, "snag_gemm_reduce_pair", ctypes.byref(descs[0]), ctypes.byref(descs[1]), self._st)
         return True
+
+    def _fold_kv_descs(self):
+        """Folded second projections, forward: K|V_m = mid_m Wf_m^T + b_kv straight into the layer's q/k/v activation."""
+        cfg = self.cfg
+        D, MD, Nl = cfg.dim, cfg.n_tokens * cfg.dim, self.shard.n_loc
+        return [self._gemm_desc(Nl, 2 * D, D, ptr(self.mid[i]), D, 1, ptr(self.wf[i]), D, 1, self._qkv_ptr + 4 * (i * 3 * D + D), 3 * MD,
+                                bias=self.p["layer0.bqkv"].data_ptr() + 4 * D, splitk=False) for i in range(len(cfg.feat_dims))]
 
     def _fold_bwd_descs(self, defer):
         """Folded second projections, backward: (d Wf_m = dKV_m^T mid_m, K split over the rows, slabs in work_l2), (d mid_m = (dKV_m Wf_m) *
@@ -672,7 +684,15 @@ class MKGCHotPath:
         # the modalities' first projections: K-split GEMMs of different K.  Two modalities: ONE launch of eight-wave tiles with the K
         # splits balanced across both (visual 3 + text 1 at the DB15K shape: 236 workgroups walking 86 / 48 k-tiles instead of a 236-
         # and a 177-workgroup launch) + one reduce; otherwise two kernels and ONE reduce launch per pair
-        self.l1_grouped = self._grouped_long_k(l1, [(Nl, fd) for fd in cfg.feat_dims], ["proj_l1_fwd"])
+        self._fdesc.weight_images_ready = 0
+        co = self.fold and nmod <= 2 and self.co_launch
+        if co:      # the folded key / value products ride in snag_fusion_fwd: described now, so that the first projections' reduce launch can prepare its weights
+            kv = self._fold_kv_descs()
+            self._co_fwd = kv
+            for j, d in enumerate(kv):
+                self._fdesc.co_fwd[j] = ctypes.pointer(d)
+            self._fdesc.n_co_fwd = nmod
+        self.l1_grouped = self._grouped_long_k(l1, [(Nl, fd) for fd in cfg.feat_dims], ["proj_l1_fwd"], prepare_fusion=co and n_wf > 0)
         if not self.l1_grouped:
             self._gemm_deferred_pairs(l1, ["proj_l1_fwd"] + [""] * (len(l1) - 1))
         if self.fold:
@@ -688,15 +708,10 @@ class MKGCHotPath:
                     pm.B, pm.sbk, pm.sbn = ptr(self.p[f"proj{i}.l2"]), D, 1
                     pm.C, pm.ldc = ptr(self.wf[i]), D
                 call("snag_small_matmul", probs, len(probs), st)
-            kv = [self._gemm_desc(Nl, 2 * D, D, ptr(self.mid[i]), D, 1, ptr(self.wf[i]), D, 1, self._qkv_ptr + 4 * (i * 3 * D + D), 3 * MD,
-                                  bias=self.p["layer0.bqkv"].data_ptr() + 4 * D, splitk=False) for i in range(nmod)]
-            if nmod <= 2 and self.co_launch:      # launched by snag_fusion_fwd: ONE launch for the whole read-out forward at hidden_size 128 (csrc/readout_fused.hip),
-                                                  # otherwise one grouped launch with the read-out token's q/k/v projection
-                self._co_fwd = kv
-                for j, d in enumerate(kv):
-                    self._fdesc.co_fwd[j] = ctypes.pointer(d)
-                self._fdesc.n_co_fwd = nmod
-            else:
+            # (co: launched by snag_fusion_fwd -- ONE launch for the whole read-out forward at hidden_size 128 (csrc/readout_fused.hip), otherwise
+            # one grouped launch with the read-out token's q/k/v projection)
+            if not co:
+                kv = self._fold_kv_descs()
                 self._fdesc.n_co_fwd = 0
                 for i in range(0, nmod - 1, 2):
                     self._gemm_pair(kv[i], kv[i + 1])
