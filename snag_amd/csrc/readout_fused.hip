@@ -267,16 +267,13 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
             for (int j = 0; j < M; ++j) kp[h][j] = (a.keep_probs != nullptr && mine && h < H) ? (int)a.keep_probs[n * HMM + h * M * M + g * M + j] : 1;
     }
 #if SNAG_RO_STAMP
-    unsigned long long stamp[kRoTiles][5];
+    __shared__ unsigned long long stamp[kRoTiles][5];        // (in LDS: a register array indexed by the running product would unroll the loop)
     const unsigned long long t_begin = __builtin_readcyclecounter();
-#define SNAG_RO_ST(I) do { __builtin_amdgcn_sched_barrier(0); stamp[tile][I] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SNAG_RO_ST(I) do { __builtin_amdgcn_sched_barrier(0); if (gtid == 0) stamp[tile][I] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SNAG_RO_ST(I) do { } while (0)
 #endif
 
-#if SNAG_RO_STAMP
-#pragma unroll
-#endif
     for (int tile = 0; tile < kRoTiles; ++tile) {
         const RoTile& t = a.t[tile];
         SNAG_RO_ST(0);
