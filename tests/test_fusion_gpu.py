@@ -129,3 +129,36 @@ def test_fusion_at_config5_scale_has_no_index_overflow():
             assert float((got.detach() - ref.detach()).abs().max()) < 1e-6
     del embs, joint, joint_fz, hidden, w
     torch.cuda.empty_cache()
+
+
+def test_prepare_reduce_reports_whether_the_weight_images_were_written():
+    """snag_fusion_fwd_prepare_reduce = snag_gemm_reduce_group + the read-out forward's weight images in one launch.  It must say 0 -- and
+    do nothing but the reduce -- for a descriptor that does not take the one-launch path (here: no co_fwd products), and the engine's
+    step must not depend on who prepared the images: same read-out with the flag forced off (snag_fusion_fwd then prepares them itself)."""
+    import ctypes
+    from snag_amd import _lib
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    N, R, B, K, D = 1100, 5, 64, 8, 128
+    g = torch.Generator().manual_seed(5)
+    # row count and feature widths at which both first projections share one grouped launch (its reduce is what the images ride in)
+    feats = [torch.rand(N, 640, generator=g), torch.randn(N, 512, generator=g)]
+    idx = [torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(DEV) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (N, (B, K)))]
+    outs = []
+    for force_off in (False, True):
+        cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[640, 512], num_proj=2, joint_way="Mformer_hd_graph", margin=6.0, neg_num=K, dropout=0.1, seed=3)
+        eng = MKGCHotPath(cfg, feats, device=DEV)
+        if force_off:
+            orig = eng._grouped_long_k
+            eng._grouped_long_k = lambda *a, **kw: orig(*a, **{**kw, "prepare_fusion": False})
+        loss = eng.forward(*idx, with_backward=True)
+        torch.cuda.synchronize()
+        outs.append((eng.entity_representation().clone(), loss.clone(), int(eng._fdesc.weight_images_ready), bool(eng.l1_grouped)))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][3] and outs[0][2] == 1 and outs[1][2] == 0          # prepared by the grouped launch's reduce / by snag_fusion_fwd itself
+    # a descriptor without co_fwd products: nothing prepared, rc 0
+    lib = _lib.load()
+    fd = _lib.FusionDesc()
+    ctypes.memmove(ctypes.byref(fd), ctypes.byref(eng._fdesc), ctypes.sizeof(fd))
+    fd.n_co_fwd = 0
+    ready = ctypes.c_int32(7)
+    assert lib.snag_fusion_fwd_prepare_reduce(ctypes.byref(fd), None, 0, ctypes.byref(ready), None) == 0 and ready.value == 0

@@ -269,7 +269,8 @@ def test_folded_second_projection_equals_the_unfolded_step(dropout, proj_dropout
         assert float((a[4][k] - b[4][k]).abs().max()) <= 1e-4 * scale, (k, float((a[4][k] - b[4][k]).abs().max()), scale)
 
 
-@pytest.mark.parametrize("N,heads,dropout,train", [(1500, 2, 0.1, True), (15000, 2, 0.1, True), (1000, 4, 0.0, True), (999, 1, 0.2, True), (70, 2, 0.1, False), (33, 2, 0.1, True)])
+@pytest.mark.parametrize("N,heads,dropout,train", [(1500, 2, 0.1, True), (15000, 2, 0.1, True), (1000, 4, 0.0, True), (999, 1, 0.2, True), (70, 2, 0.1, False), (33, 2, 0.1, True),
+                                                   (1, 2, 0.1, True), (32, 2, 0.1, True), (64, 4, 0.1, True), (65, 1, 0.0, False), (127, 2, 0.3, True)])
 def test_one_launch_readout_forward_equals_the_separate_launches_bit_for_bit(N, heads, dropout, train):
     """csrc/readout_fused.hip: at hidden_size 128 with two folded projected tokens the read-out layer's forward -- seven key / value /
     query products, the attention row, the output projection, the LayerNorm -- is ONE launch.  It repeats the arithmetic of the launches
