@@ -129,7 +129,8 @@ static TouchedWork touched_carve(void* base, int64_t n_ent, int64_t n_rel, int64
 }
 
 __device__ __forceinline__ unsigned long long touched_key(int dest, unsigned chunk) { return (((unsigned long long)(unsigned)dest << 24) | chunk) + 1ull; }
-__device__ __forceinline__ unsigned touched_hash(unsigned long long key) { return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 40); }
+// (the top 32 bits of the product: masked down to the table size by the callers -- tables above 2^24 slots keep spreading)
+__device__ __forceinline__ unsigned touched_hash(unsigned long long key) { return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 32); }
 // slot of the chunk (dest, j) in the table `keys` (present: pass A inserted it)
 __device__ __forceinline__ unsigned touched_find(const unsigned long long* __restrict__ keys, unsigned hmask, int dest, unsigned j) {
     const unsigned long long key = touched_key(dest, j);

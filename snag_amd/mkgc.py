@@ -1196,9 +1196,16 @@ class MKGCHotPath:
                 self.noisy[i].copy_(x)
             self.ent_noise.copy_(sd["ent_noise"])
             self.ent_noise_mask.copy_(sd["ent_noise_mask"])
-            for pair, saved in zip(self.row_mask, sd["row_mask"]):        # the next refresh takes back the rows of the CURRENT mask
-                for m, x in zip(pair, saved):
-                    m.copy_(x)
+            if sd.get("row_mask") is not None:
+                for pair, saved in zip(self.row_mask, sd["row_mask"]):    # the next refresh takes back the rows of the CURRENT mask
+                    for m, x in zip(pair, saved):
+                        m.copy_(x)
+            else:
+                # a checkpoint from before the incremental refresh: which rows carry noise is unknown, so every row counts as noisy -- the
+                # next update_noise takes the noise back from all rows its new mask does not cover (stale noisy rows otherwise)
+                for pair in self.row_mask:
+                    for m in pair:
+                        m.fill_(1)
 
     def save_checkpoint(self, path):
         """``torch.save`` of ``state_dict()`` (the reference's checkpoints are ``torch.save(model.state_dict())`` too, main.py:482-500)."""
