@@ -1,16 +1,18 @@
 // The read-out layer's forward as ONE launch (hidden_size 128, three tokens, the two projected tokens' second projections folded into
-// their key / value weights): a workgroup owns 64 entities and walks the eight 64 x 128 x 128 products of the chain
+// their key / value weights): a workgroup owns 64 entities -- two halves of 32 rows, four waves each -- and a half walks the eight
+// 32 x 128 x 128 products of the chain on its rows
 //     q | k_g | v_g = x_g Wqkv^T ;  k_a | v_a = mid_a Wf_a^T ;  k_b | v_b = mid_b Wf_b^T ;  t1 = dropout(ctx Wo^T + bo) + x_g
 // (reference: BertSelfAttention / BertSelfOutput, model/SNAG_tools.py:178-222; ProjectionHead's second Linear folded, layers.py:135-148)
 // with the attention row of the read-out token and the LayerNorm in between, instead of three launches (grouped GEMM, attention,
 // output projection + LayerNorm) whose prologues, loops and epilogues add up.
 //   * The A operand of a product -- BM rows x 128 k of x_g, mid_a, mid_b, ctx -- is split ONCE into eight resident k-tile images
 //     and serves one to three products; the next panel is already in registers when the current one retires.
-//   * B (the weights) is split once per step by readout_presplit_kernel into k-tile images in the order the launch consumes them
-//     (64 images of 12 KB, L2-resident); they stream through two LDS images as ONE 64-step pipeline across all eight products -- no
-//     per-product prologue, no split arithmetic in the loop: three 16-byte loads and three ds_write_b128 per thread and k-tile.
-//   * BM = 32 rows per workgroup: 65 KB of LDS, TWO workgroups per CU -- while one runs an epilogue (LDS, VALU, stores) the other one
-//     multiplies.  (BM = 64, one workgroup = one wave per SIMD: every wait idles the matrix pipe; 84 us against 82 for the three launches.)
+//   * B (the weights) is split once per step into k-tile images in the order the launch consumes them (64 images of 12 KB, L2-resident;
+//     written by the first workgroups of a split-K reduce launch of the step -- snag_fusion_fwd_prepare_reduce -- or by
+//     readout_presplit_kernel); they stream through two LDS images as ONE 64-step pipeline across all eight products and both halves -- no
+//     per-product prologue, no split arithmetic in the loop.
+//   * Two waves per SIMD (eight waves per workgroup, 107 KB of LDS).  64 rows per four-wave workgroup = one wave per SIMD measured 84 us
+//     against 82 for the three launches: every wait idles the matrix pipe.
 //   * Accumulators go through a [BM][132] LDS tile; wave w then owns rows BM/4 w .. with column lane + 64 u in the lane --
 //     the layout of attn_ro_fwd_kernel / ln_fwd_kernel, whose arithmetic (sum64 partial dot products, softmax, ln_row_forward) is
 //     repeated statement by statement: q, k, v, probs, ctx, t1, hidden and stats are the three-launch path's, bit for bit.
