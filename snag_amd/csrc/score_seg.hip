@@ -116,9 +116,20 @@ __global__ __launch_bounds__(256) void score_seg_a_kernel(
         const int dest3 = lane == 0 ? (int)ti : (lane == 1 ? (int)hi : n_ent + (int)ri);
         unsigned pos3 = 0u;
         if (lane < 3) pos3 = seg_reserve(w, dest3);
+        // (the first id block of negatives travels with h / r / t, and its first 32 rows with the positive's three rows: two round trips in
+        // front of the arithmetic instead of four)
+        const int cnt0 = min(64, n_neg);
+        const int my0 = (lane < cnt0) ? (int)nrow[lane] : 0;
         Row4<NV> q = ld_row4<NV>(ent, hi, eld, dim, sub);
         const Row4<NV> rr = ld_row4<NV>(rel, ri, dim, dim, sub);
         Row4<NV> tt = ld_row4<NV>(ent, ti, eld, dim, sub);
+        Row4<NV> x0[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = 4 * u + grp;
+            const int idx = __shfl(my0, k & 63);
+            x0[u] = ld_row4<NV>(ent, (k < cnt0) ? idx : 0, eld, dim, sub);
+        }
         {
             const float ih = 1.0f / l2_denominator(sum16(sumsq4<NV>(q)));
             const float ir = 1.0f / l2_denominator(sum16(sumsq4<NV>(rr)));
@@ -145,17 +156,22 @@ __global__ __launch_bounds__(256) void score_seg_a_kernel(
         float c_pos = 0.f;
         for (int k0 = 0; k0 < n_neg; k0 += 64) {
             const int cnt = min(64, n_neg - k0);
-            const int my = (lane < cnt) ? (int)nrow[k0 + lane] : 0;
+            const int my = k0 == 0 ? my0 : ((lane < cnt) ? (int)nrow[k0 + lane] : 0);
             unsigned my_pos = 0u;
             if (lane < cnt) my_pos = seg_reserve(w, my);    // in flight while the rows are gathered
             float my_s = 0.f;                               // lane k: score of negative k0 + k
             for (int it0 = 0; it0 < cnt; it0 += 32) {       // 8 rounds x 4 rows gathered before the first is used
                 Row4<NV> x[8];
+                if (k0 == 0 && it0 == 0) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int k = it0 + 4 * u + grp;
-                    const int idx = __shfl(my, k & 63);
-                    x[u] = ld_row4<NV>(ent, (k < cnt) ? idx : 0, eld, dim, sub);
+                    for (int u = 0; u < 8; ++u) x[u] = x0[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int k = it0 + 4 * u + grp;
+                        const int idx = __shfl(my, k & 63);
+                        x[u] = ld_row4<NV>(ent, (k < cnt) ? idx : 0, eld, dim, sub);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
