@@ -499,15 +499,21 @@ struct PrologueArgs {
     RegionArgs masks;
     // parameter-sized products (the last blocks): the folded-projection weights Wf_m = Wkv l2_m of the step
     SmallMMSet mm;
-    int nb_s, nb_e, nb_d;
+    int nb_s, nb_e, nb_d, nb_m;
 };
 
 __global__ __launch_bounds__(256) void step_prologue_kernel(PrologueArgs a) {
-    const int b = blockIdx.x;
+    // (the two roles that are dependent chains -- the parameter-sized products and the sampler -- take the FIRST workgroups: dispatched
+    // behind 8,000 streaming workgroups they would start late and their latency would be the launch's tail)
+    int b = blockIdx.x;
+    if (b < a.nb_m) {
+        small_matmul_body(a.mm, b);
+        return;
+    }
+    b -= a.nb_m;
     if (b < a.nb_s) sample_negatives_body(b, a.s_seed, a.tick, a.h, a.r, a.t, a.B, a.K, a.n_ent, a.n_rel, a.mode, a.known, a.n_known, a.neg_h, a.neg_t);
     else if (b < a.nb_s + a.nb_e) entity_token_fwd_body(b - a.nb_s, a.nb_e, a.table, a.N, a.D, a.noise, a.nmask, a.a, a.tok, a.tok_ld);
-    else if (b < a.nb_s + a.nb_e + a.nb_d) bernoulli_regions_body(b - a.nb_s - a.nb_e, a.masks, a.tick);
-    else small_matmul_body(a.mm, b - a.nb_s - a.nb_e - a.nb_d);
+    else bernoulli_regions_body(b - a.nb_s - a.nb_e, a.masks, a.tick);
 }
 
 static int grid_for(int64_t n) { return (int)std::min<int64_t>(4096, (n + 255) / 256); }
@@ -881,6 +887,7 @@ extern "C" SNAG_API int snag_step_prologue(uint64_t sample_seed, const uint64_t*
     a.nb_d = nb_d;
     const int nb_m = fill_small_mm(small_products, n_small_products, a.mm, "step_prologue");
     if (nb_m < 0) return nb_m;
+    a.nb_m = nb_m;
     const int total = a.nb_s + a.nb_e + nb_d + nb_m;
     if (total == 0) return SNAG_OK;
     hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
