@@ -490,6 +490,10 @@ typedef struct snag_mask_region {
     float p;
     int32_t invert;
     uint8_t* out;
+    /* period > 0: only the elements j of the region with skip <= j % period < skip + take are drawn (the others are left alone); offset,
+     * period, skip and take multiples of 4, n a multiple of period.  The read-out-only last Mformer layer consumes the output-dropout mask
+     * of ONE token: rows of `take` = D bytes every `period` = M D.  The bytes drawn are those of the dense region.  period = 0: dense. */
+    int64_t period, skip, take;
 } snag_mask_region;
 SNAG_API int snag_bernoulli_regions(const snag_mask_region* regions, int n_regions, const uint64_t* tick, void* stream);
 /* snag_noise_apply for a table that is refreshed once per epoch (model/SNAG.py:86-92), incremental and keyed on GLOBAL rows:

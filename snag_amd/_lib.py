@@ -37,7 +37,7 @@ class GemmDesc(_c.Structure):
 
 class MaskRegion(_c.Structure):
     """struct snag_mask_region."""
-    _fields_ = [("seed", _U64), ("offset", _L), ("n", _L), ("p", _F), ("invert", _c.c_int32), ("out", _P)]
+    _fields_ = [("seed", _U64), ("offset", _L), ("n", _L), ("p", _F), ("invert", _c.c_int32), ("out", _P), ("period", _L), ("skip", _L), ("take", _L)]
 
 
 class FusionLayer(_c.Structure):

@@ -25,9 +25,16 @@ __device__ __forceinline__ float4 normal4(uint64_t seed, uint64_t ctr) {
 // those rows).  out[i] = (u(offset + i) >= p) != invert: invert = 0 is the inverted-dropout keep mask of nn.Dropout(p), invert = 1 the
 // "rand < p" row mask of the noise injection (model/SNAG.py:68).
 __device__ __forceinline__ void bernoulli_region_body(int64_t vblock, uint64_t seed, const uint64_t* __restrict__ tick, int64_t offset, int64_t n, float p,
-                                                      int invert, uint8_t* __restrict__ out) {
-    const int64_t q = (offset >> 2) + vblock * 256 + threadIdx.x;       // one Philox draw = 4 elements of the global stream
-    if (q * 4 >= offset + n) return;
+                                                      int invert, uint8_t* __restrict__ out, int64_t period = 0, int64_t skip = 0, int64_t take = 0) {
+    int64_t q;                                            // one Philox draw = 4 elements of the global stream
+    if (period > 0) {                                     // strided: draw `take` elements at `skip` of every `period` (all multiples of 4)
+        const int64_t tq = take >> 2, sel = vblock * 256 + threadIdx.x;
+        if (sel >= (n / period) * tq) return;
+        q = (offset + (sel / tq) * period + skip) / 4 + sel % tq;
+    } else {
+        q = (offset >> 2) + vblock * 256 + threadIdx.x;
+        if (q * 4 >= offset + n) return;
+    }
     if (tick != nullptr) seed += tick[0] * 0x9E3779B97F4A7C15ull;    // a fresh stream per training step inside a replayed graph
     const Philox4 r = philox4x32_10(seed, (uint64_t)q);
     const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
@@ -65,13 +72,14 @@ __device__ __forceinline__ void bernoulli_regions_body(int vblock, const RegionA
     int i = 0;
     while (i + 1 < a.n && vblock >= a.cum[i]) ++i;
     const int first = i ? a.cum[i - 1] : 0;
-    bernoulli_region_body(vblock - first, a.r[i].seed, tick, a.r[i].offset, a.r[i].n, a.r[i].p, a.r[i].invert, a.r[i].out);
+    bernoulli_region_body(vblock - first, a.r[i].seed, tick, a.r[i].offset, a.r[i].n, a.r[i].p, a.r[i].invert, a.r[i].out, a.r[i].period, a.r[i].skip, a.r[i].take);
 }
 __global__ __launch_bounds__(256) void bernoulli_regions_kernel(RegionArgs a, const uint64_t* __restrict__ tick) {
     bernoulli_regions_body(blockIdx.x, a, tick);
 }
 static int region_blocks(const snag_mask_region& r) {
     if (r.n <= 0) return 0;
+    if (r.period > 0) return (int)(((r.n / r.period) * (r.take / 4) + 255) / 256);
     const int64_t q0 = r.offset >> 2, q1 = (r.offset + r.n + 3) >> 2;
     return (int)((q1 - q0 + 255) / 256);
 }
@@ -85,6 +93,10 @@ static int fill_regions(const snag_mask_region* regions, int n_regions, RegionAr
         const snag_mask_region& r = regions[i];
         if (r.n < 0 || r.offset < 0 || (r.n > 0 && r.out == nullptr) || !(r.p >= 0.f && r.p < 1.f))
             return fail(SNAG_ERR_ARG, "%s: bad mask region %d (n=%ld offset=%ld p=%g)", who, i, (long)r.n, (long)r.offset, r.p);
+        if (r.period != 0 && !(r.period > 0 && r.skip >= 0 && r.take > 0 && r.skip + r.take <= r.period && r.n % r.period == 0 &&
+                               ((r.offset | r.period | r.skip | r.take) & 3) == 0))
+            return fail(SNAG_ERR_ARG, "%s: bad strided mask region %d (period=%ld skip=%ld take=%ld n=%ld offset=%ld: multiples of 4, n a multiple of period)", who, i,
+                        (long)r.period, (long)r.skip, (long)r.take, (long)r.n, (long)r.offset);
         const int nb = region_blocks(r);
         if (nb == 0) continue;
         total += nb;

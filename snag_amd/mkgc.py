@@ -255,9 +255,12 @@ class MKGCHotPath:
         regs = []
         for l in range(L):
             regs.append((cfg.seed * 131 + 17 * l + 1, lo * H * M * M, Nl * H * M * M, cfg.dropout, self.keep_probs[l]))
-            regs.append((cfg.seed * 131 + 17 * l + 2, lo * M * D, Nl * M * D, cfg.dropout, self.keep_attn[l]))
+            # (the read-out-only last layer consumes the output-dropout masks of the read-out token alone: D bytes of every M D -- the
+            # same bytes the dense region draws for them, a third of the Philox work)
+            only_g = ((M * D, self.g_slot * D, D),) if (self.ro and l == L - 1 and D % 4 == 0) else ()
+            regs.append((cfg.seed * 131 + 17 * l + 2, lo * M * D, Nl * M * D, cfg.dropout, self.keep_attn[l]) + only_g)
             if ffn:
-                regs.append((cfg.seed * 131 + 17 * l + 3, lo * M * D, Nl * M * D, cfg.dropout, self.keep_ffn[l]))
+                regs.append((cfg.seed * 131 + 17 * l + 3, lo * M * D, Nl * M * D, cfg.dropout, self.keep_ffn[l]) + only_g)
         if len(regs) > _lib.MAX_MASK_REGIONS:
             raise NotImplementedError(f"{len(regs)} dropout masks per step: the step prologue draws at most {_lib.MAX_MASK_REGIONS} (num_layers <= "
                                       f"{_lib.MAX_MASK_REGIONS // (3 if ffn else 2)})")
@@ -559,8 +562,11 @@ class MKGCHotPath:
     def _regions(rows):
         """(seed, offset, n, p, tensor) rows -> a host array of snag_mask_region."""
         arr = (_lib.MaskRegion * len(rows))()
-        for a, (seed, off, n, p, out) in zip(arr, rows):
+        for a, row in zip(arr, rows):
+            seed, off, n, p, out = row[:5]
             a.seed, a.offset, a.n, a.p, a.invert, a.out = int(seed) & (2 ** 64 - 1), int(off), int(n), float(p), 0, out.data_ptr()
+            if len(row) > 5:         # (period, skip, take): only those bytes of every period are drawn
+                a.period, a.skip, a.take = (int(v) for v in row[5])
         return arr
 
     def update_noise(self, seed: Optional[int] = None):

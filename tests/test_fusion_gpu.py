@@ -162,3 +162,35 @@ def test_prepare_reduce_reports_whether_the_weight_images_were_written():
     fd.n_co_fwd = 0
     ready = ctypes.c_int32(7)
     assert lib.snag_fusion_fwd_prepare_reduce(ctypes.byref(fd), None, 0, ctypes.byref(ready), None) == 0 and ready.value == 0
+
+
+def test_strided_mask_region_draws_the_dense_regions_bytes():
+    """snag_mask_region.period / skip / take: the read-out-only layer draws the output-dropout mask of ONE token (D bytes of every M D).
+    Those bytes must be the dense region's (same Philox counters), everything else must be left alone, and a region that starts at a
+    later global row must draw what the whole stream holds there (N ranks = 1 rank)."""
+    import ctypes
+    from snag_amd import _lib
+    lib = _lib.load()
+    rows, M, D, g = 37, 3, 128, 2
+    n = rows * M * D
+
+    def draw(offset, n_el, strided, fill):
+        out = torch.full((n_el,), fill, dtype=torch.uint8, device=DEV)
+        r = (_lib.MaskRegion * 1)()
+        r[0].seed, r[0].offset, r[0].n, r[0].p, r[0].invert, r[0].out = 1234, offset, n_el, 0.3, 0, out.data_ptr()
+        if strided:
+            r[0].period, r[0].skip, r[0].take = M * D, g * D, D
+        assert lib.snag_bernoulli_regions(r, 1, None, None) == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        return out.view(-1, M, D)
+    dense = draw(0, n, False, 7)
+    strided = draw(0, n, True, 7)
+    assert torch.equal(strided[:, g], dense[:, g]) and bool((strided[:, :g] == 7).all())
+    assert 0.6 < float(dense.float().mean()) < 0.8
+    lo = 11                                                   # a rank that owns rows 11 .. 36
+    part = draw(lo * M * D, (rows - lo) * M * D, True, 9)
+    assert torch.equal(part[:, g], dense[lo:, g]) and bool((part[:, :g] == 9).all())
+    bad = (_lib.MaskRegion * 1)()
+    bad[0].seed, bad[0].offset, bad[0].n, bad[0].p, bad[0].out = 1, 0, n, 0.3, dense.data_ptr()
+    bad[0].period, bad[0].skip, bad[0].take = M * D, g * D + 2, D          # not multiples of 4 / past the period
+    assert lib.snag_bernoulli_regions(bad, 1, None, None) != 0
