@@ -440,6 +440,13 @@ typedef struct snag_fusion_bwd_desc {
      * (snag_score_margin_fwd_bwd_seg_ln wrote dt, dtm and its partial slab of ceil(N / 16) rows at the offsets of
      * snag_fusion_readout_ln_offsets): d_hidden is not read, the backward starts at the output projection. */
     int32_t ln_bwd_done;
+    /* 1: snag_fusion_fwd_prepare_reduce reported `prepared` for this step's weights (it also writes the output projection's weight as the backward's
+     * d ctx = dz Wo operand); 0 (default): the backward prepares that operand with a launch of its own when it needs it. */
+    int32_t wo_images_ready;
+    /* 1: the read-out layer's d ctx product and attention backward stay two launches where the library would run them as one (hidden_size 128,
+     * three tokens, fold_others): an A/B and test handle -- every gradient is the same bits either way except dbqkv, whose column sums over the
+     * entities are associated differently (one partial per 32 entities instead of one per strided workgroup). */
+    int32_t separate_attention_backward;
 } snag_fusion_bwd_desc;
 
 SNAG_API int snag_fusion_bwd(const snag_fusion_bwd_desc* desc, void* stream);

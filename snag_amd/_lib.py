@@ -73,7 +73,7 @@ class FusionBwdDesc(_c.Structure):
                 ("d_x0", _P), ("grads", _c.POINTER(FusionLayerGrad)), ("d_weight_raw", _P), ("accumulate", _c.c_int32),
                 ("zero_d_hidden", _c.c_int32), ("d_slot_out", _P), ("d_slot_ld", _L), ("d_slot_rowmask", _P), ("d_slot_scale", _F),
                 ("co_dx", _c.POINTER(GemmDesc) * 2), ("n_co_dx", _c.c_int32), ("co_dw", _c.POINTER(GemmDesc) * 2), ("n_co_dw", _c.c_int32),
-                ("ln_bwd_done", _c.c_int32)]
+                ("ln_bwd_done", _c.c_int32), ("wo_images_ready", _c.c_int32), ("separate_attention_backward", _c.c_int32)]
 
 
 class LnBwdTail(_c.Structure):

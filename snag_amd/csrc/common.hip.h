@@ -165,9 +165,13 @@ __device__ __forceinline__ void slab_colsum_body(const SlabColsum& s, int bx, in
 
 // The weights of the one-launch read-out forward (csrc/readout_fused.hip) as split k-tile images in consumption order: image 8 s + kt =
 // k-tile kt of product s, 12 KB each.  One workgroup (256 threads) per image.
+// Images 64 .. 71 (optional, Wt != nullptr): a ninth weight as the B operand of its TRANSPOSED use, B(n, k) = Wt[k * ldw + n] -- the output
+// projection's weight in the backward's d ctx = dz Wo.
 struct RoWeightImages {
     const float* W[8];         // 128 weight rows each, K-contiguous, pitch ldw floats
+    const float* Wt;
     int ldw;
+    int n_images;              // 64 or 72
     unsigned char* wimg;
 };
 

@@ -5,6 +5,10 @@
 #include "fusion_kernels.hip.h"
 #include "readout_fused.hip.h"
 
+#ifndef SNAG_RO_BWD_FUSED
+#define SNAG_RO_BWD_FUSED 1      // A/B: 0 keeps the d ctx GEMM and the attention backward as two launches in the read-out layer's backward
+#endif
+
 namespace snag {
 
 // ---- activation layout inside `save` (identical in forward and backward) ----------------------
@@ -441,17 +445,31 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             float* partq = W.part + (int64_t)kRedBlocks * 3 * D;
             const float* dz = dtm ? dtm : W.dA;
             // (dWo = dz^T ctx_g is launched further down, paired with dWq)
-            // dctx_g = dz Wo -> dC
-            g = gemm_desc(N, D, D, dz, D, true, P.wo, D, false, W.dC, D);
-            if ((rc = gemm_dispatch(&g, st))) return rc;
             // attention backward: dq_g [N, D] (behind dkv in the dqkv region), dkv [N*M, 2D]
             float* dkv = W.dqkv;
             float* dq_g = W.dqkv + NM * 2 * D;
-            const int ablocks = (int)std::min<int64_t>(kRedBlocks, (N + 3) / 4);
+            int ablocks = (int)std::min<int64_t>(kRedBlocks, (N + 3) / 4);
             // fold_others with M >= 3: the read-out token's dq | dk | dv side by side in the [N, 3D] block where dq_g alone would go
             float* ro3 = (f->fold_others && M >= 3) ? dq_g : nullptr;
-            SNAG_MNU(attn_ro_bwd_kernel, M, D, dim3(ablocks), st, (const float*)S.qkv, (const float*)W.dC, N, D, H, ro, 1.0f / sqrtf((float)(D / H)),
-                     P.keep_probs, kscale, dq_g, dkv, partq, ro3);
+            const bool one_launch = SNAG_RO_BWD_FUSED && !b->separate_attention_backward && ro3 && M == 3 && D == 128 && !ffn && ceil_div(N, 32) <= kRedBlocks && ((uintptr_t)dz & 15) == 0;
+            if (one_launch) {
+                // d ctx = dz Wo and the attention backward in ONE launch (readout_fused.hip): d ctx never travels; the bias slab has one row per
+                // 32 entities (its column sums are associated differently from the separate launches': dbqkv agrees to rounding, all else bit for bit)
+                RoBwdArgs a{};
+                a.dz = dz; a.lddz = D; a.wo = P.wo; a.ldw = D;
+                a.wimg = reinterpret_cast<unsigned char*>(f->save + SaveLayout(N, M, D, H, f->I, false).per_layer * f->L) + (size_t)64 * 6 * 128 * 16;
+                a.images_ready = b->wo_images_ready != 0 && L == 1;
+                a.qkv = S.qkv; a.keep_probs = P.keep_probs; a.kscale = kscale; a.inv_sqrt_d = 1.0f / sqrtf((float)(D / H));
+                a.N = N; a.H = H; a.g = ro; a.dq_g = dq_g; a.dkv = dkv; a.ro3 = ro3; a.bias_part = partq;
+                if ((rc = readout_bwd_attn_fused(a, st))) return rc;
+                ablocks = ceil_div(N, 32);
+            } else {
+                // dctx_g = dz Wo -> dC
+                g = gemm_desc(N, D, D, dz, D, true, P.wo, D, false, W.dC, D);
+                if ((rc = gemm_dispatch(&g, st))) return rc;
+                SNAG_MNU(attn_ro_bwd_kernel, M, D, dim3(ablocks), st, (const float*)S.qkv, (const float*)W.dC, N, D, H, ro, 1.0f / sqrtf((float)(D / H)),
+                         P.keep_probs, kscale, dq_g, dkv, partq, ro3);
+            }
             // (the two bias / LayerNorm slab sums ride in the weight gradients' reduce launch below: nobody reads them before the optimiser)
             const SlabColsum slabs{W.part, lnblocks, D, G.ln1_g, G.ln1_b, G.bo, partq, ablocks, G.bqkv, acc};
             if ((rc = check_launch("fusion attention backward (read-out)"))) return rc;
@@ -605,6 +623,8 @@ extern "C" SNAG_API int snag_fusion_fwd_prepare_reduce(const snag_fusion_desc* f
         const LayerSave S = SaveLayout(f->N, f->M, f->D, f->H, f->I, f->use_intermediate != 0).at(f->save, 0);
         if (readout_one_launch_args(f, f->layers[0], S, f->x0, a) == SNAG_OK) {
             w = readout_weight_images(a);
+            w.Wt = f->layers[0].wo;          // + the backward's d ctx = dz Wo operand (images 64 .. 71)
+            w.n_images += 8;
             fused = true;
         }
     }

@@ -354,36 +354,55 @@ __global__ __launch_bounds__(256) void attn_ro_fwd_kernel(const float* __restric
 
 //   dctx_g [N, D] -> dq_g [N, D] (compact) and dkv [N*M, 2D] (k then v); bias_part [block][3][D] = column sums of dq_g, dk, dv.
 //   (ro3: see below)
+// The attention backward of the read-out row: rows = what attn_ro_load fetched for an entity, go = d ctx_g [D] in the lanes (column lane + 64 u);
+// writes dq / dk / dv and adds them to the wave's running bias sums.  ONE statement of the arithmetic for attn_ro_bwd_kernel and for the launch that
+// forms d ctx itself (readout_fused.hip).
+// an entity's rows as the attention backward reads them: the read-out token's query, every token's key and value, the keep flags
 template <int M, int NU>
-__global__ __launch_bounds__(256) void attn_ro_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx_g, int N, int D,
-                                                          int H, int g, float inv_sqrt_d, const uint8_t* __restrict__ keep, float kscale,
-                                                          float* __restrict__ dq_g, float* __restrict__ dkv, float* __restrict__ bias_part,
-                                                          float* __restrict__ ro3) {
-    __shared__ float red[4][3][64 * NU];
-    const int lane = threadIdx.x & 63;
-    const int wave = wave_id_uniform();
+struct AttnRoRows {
+    Cols<NU> q, k[M], v[M];
+    Entries3 kb;
+};
+template <int M, int NU>
+__device__ __forceinline__ AttnRoRows<M, NU> attn_ro_load(const float* __restrict__ qkv, int64_t n, int D, int H, int g, const uint8_t* __restrict__ keep, int lane) {
+    AttnRoRows<M, NU> r;
+    const int HMM = H * M * M;
+    r.kb = load_keep3(keep, n * HMM, HMM, lane);
+    r.q = ld_cols<NU>(qkv + (n * M + g) * (int64_t)(3 * D), D, lane);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const float* row = qkv + (n * M + i) * (int64_t)(3 * D);
+        r.k[i] = ld_cols<NU>(row + D, D, lane);
+        r.v[i] = ld_cols<NU>(row + 2 * D, D, lane);
+    }
+    return r;
+}
+// NE entities side by side (NE = 2 in the launch that forms d ctx itself: the two entities' dependent chains -- sum64 after sum64 -- interleave;
+// every entity's own arithmetic and the order in which the entities enter the bias sums are those of NE = 1).  live[e] = 0: entity e is a
+// stand-in (its rows were fetched at a clamped index): nothing of it is stored or summed.
+template <int M, int NU, int NE>
+__device__ __forceinline__ void attn_ro_bwd_entities(const AttnRoRows<M, NU> (&rows)[NE], const Cols<NU> (&go)[NE], const int64_t (&n)[NE], const bool (&live)[NE],
+                                                     int D, int H, int g, float inv_sqrt_d, const uint8_t* __restrict__ keep, float kscale,
+                                                     float* __restrict__ dq_g, float* __restrict__ dkv, float* __restrict__ ro3, int lane, Cols<NU>& sq,
+                                                     Cols<NU>& sk, Cols<NU>& sv) {
     const int d = D / H;
-    Cols<NU> sq, sk, sv;
+    Cols<NU> dk[NE][M], dv[NE][M], dq[NE];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) sq.v[u] = sk.v[u] = sv.v[u] = 0.f;
-    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
-        const int HMM = H * M * M;
-        const Entries3 kb = load_keep3(keep, n * HMM, HMM, lane);
-        Cols<NU> k[M], v[M], dk[M], dv[M], dq;
-        const Cols<NU> q = ld_cols<NU>(qkv + (n * M + g) * (int64_t)(3 * D), D, lane);
-        const Cols<NU> go = ld_cols<NU>(dctx_g + n * (int64_t)D, D, lane);
+    for (int e = 0; e < NE; ++e) {
 #pragma unroll
-        for (int i = 0; i < M; ++i) {
-            const float* row = qkv + (n * M + i) * (int64_t)(3 * D);
-            k[i] = ld_cols<NU>(row + D, D, lane);
-            v[i] = ld_cols<NU>(row + 2 * D, D, lane);
+        for (int i = 0; i < M; ++i)
 #pragma unroll
-            for (int u = 0; u < NU; ++u) dk[i].v[u] = dv[i].v[u] = 0.f;
-        }
+            for (int u = 0; u < NU; ++u) dk[e][i].v[u] = dv[e][i].v[u] = 0.f;
 #pragma unroll
-        for (int u = 0; u < NU; ++u) dq.v[u] = 0.f;
-        for (int h = 0; h < H; ++h) {
-            const int lo = h * d, hi = lo + d;
+        for (int u = 0; u < NU; ++u) dq[e].v[u] = 0.f;
+    }
+    for (int h = 0; h < H; ++h) {
+        const int lo = h * d, hi = lo + d;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const Cols<NU>& q = rows[e].q;
+            const Cols<NU> (&k)[M] = rows[e].k;
+            const Cols<NU> (&v)[M] = rows[e].v;
             float p[M], dp[M], ds[M];
             head_scores_row<M, NU>(q, k, lo, hi, lane, inv_sqrt_d, p);
             float rowdot = 0.f;
@@ -393,17 +412,16 @@ __global__ __launch_bounds__(256) void attn_ro_bwd_kernel(const float* __restric
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     const int c = lane + 64 * u;
-                    part += (c >= lo && c < hi) ? go.v[u] * v[j].v[u] : 0.f;
+                    part += (c >= lo && c < hi) ? go[e].v[u] * v[j].v[u] : 0.f;
                 }
                 const float gg = sum64(part);
-                const int e = h * M * M + g * M + j;
-                const int kf = entry_at(kb, e);
+                const int kf = entry_at(rows[e].kb, h * M * M + g * M + j);
                 const float km = (keep == nullptr) ? 1.f : (kf ? kscale : 0.f);
                 const float pt = p[j] * km;
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     const int c = lane + 64 * u;
-                    dv[j].v[u] += (c >= lo && c < hi) ? pt * go.v[u] : 0.f;
+                    dv[e][j].v[u] += (c >= lo && c < hi) ? pt * go[e].v[u] : 0.f;
                 }
                 dp[j] = gg * km;
                 rowdot += dp[j] * p[j];
@@ -418,27 +436,52 @@ __global__ __launch_bounds__(256) void attn_ro_bwd_kernel(const float* __restric
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
                     aq += ds[j] * k[j].v[u];
-                    dk[j].v[u] += in ? ds[j] * q.v[u] : 0.f;
+                    dk[e][j].v[u] += in ? ds[j] * q.v[u] : 0.f;
                 }
-                dq.v[u] += in ? aq : 0.f;
+                dq[e].v[u] += in ? aq : 0.f;
             }
         }
-        // ro3 != nullptr: the read-out token's dq | dk | dv side by side in ro3 [N, 3D] (one K = 3D operand for d x and d Wqkv) instead of
-        // dq_g and the token's own rows of dkv
-        st_cols<NU>(ro3 ? ro3 + n * (int64_t)(3 * D) : dq_g + n * (int64_t)D, dq, D, lane);
+    }
+    // ro3 != nullptr: the read-out token's dq | dk | dv side by side in ro3 [N, 3D] (one K = 3D operand for d x and d Wqkv) instead of
+    // dq_g and the token's own rows of dkv
 #pragma unroll
-        for (int u = 0; u < NU; ++u) sq.v[u] += dq.v[u];
+    for (int e = 0; e < NE; ++e) {
+        if (!live[e]) continue;
+        st_cols<NU>(ro3 ? ro3 + n[e] * (int64_t)(3 * D) : dq_g + n[e] * (int64_t)D, dq[e], D, lane);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) sq.v[u] += dq[e].v[u];
 #pragma unroll
         for (int i = 0; i < M; ++i) {
-            float* row = (ro3 && i == g) ? ro3 + n * (int64_t)(3 * D) + D : dkv + (n * M + i) * (int64_t)(2 * D);
-            st_cols<NU>(row, dk[i], D, lane);
-            st_cols<NU>(row + D, dv[i], D, lane);
+            float* row = (ro3 && i == g) ? ro3 + n[e] * (int64_t)(3 * D) + D : dkv + (n[e] * M + i) * (int64_t)(2 * D);
+            st_cols<NU>(row, dk[e][i], D, lane);
+            st_cols<NU>(row + D, dv[e][i], D, lane);
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
-                sk.v[u] += dk[i].v[u];
-                sv.v[u] += dv[i].v[u];
+                sk.v[u] += dk[e][i].v[u];
+                sv.v[u] += dv[e][i].v[u];
             }
         }
+    }
+}
+
+template <int M, int NU>
+__global__ __launch_bounds__(256) void attn_ro_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx_g, int N, int D,
+                                                          int H, int g, float inv_sqrt_d, const uint8_t* __restrict__ keep, float kscale,
+                                                          float* __restrict__ dq_g, float* __restrict__ dkv, float* __restrict__ bias_part,
+                                                          float* __restrict__ ro3) {
+    __shared__ float red[4][3][64 * NU];
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id_uniform();
+    Cols<NU> sq, sk, sv;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) sq.v[u] = sk.v[u] = sv.v[u] = 0.f;
+    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
+        const Cols<NU> go = ld_cols<NU>(dctx_g + n * (int64_t)D, D, lane);
+        const AttnRoRows<M, NU> rows[1] = {attn_ro_load<M, NU>(qkv, n, D, H, g, keep, lane)};
+        const Cols<NU> gos[1] = {go};
+        const int64_t ns[1] = {n};
+        const bool live[1] = {true};
+        attn_ro_bwd_entities<M, NU, 1>(rows, gos, ns, live, D, H, g, inv_sqrt_d, keep, kscale, dq_g, dkv, ro3, lane, sq, sk, sv);
     }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {

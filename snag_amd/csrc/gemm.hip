@@ -254,15 +254,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     splitk_reduce_body<QUAD>(slab, splits, epi, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
 }
 
-// one problem + the 64 weight images of the one-launch read-out forward in front (the generic multi-problem kernel is ~2 us slower on the
+// one problem + the 64 (72) weight images of the one-launch read-out forward (and backward) in front (the generic multi-problem kernel is ~2 us slower on the
 // same reduce: four epilogues in the kernel arguments, indexed at run time)
 template <bool QUAD>
 __global__ __launch_bounds__(256) void splitk_reduce_images_kernel(const float* __restrict__ slab, int splits, Epilogue epi, RoWeightImages wi) {
-    if (blockIdx.x < 64) {
+    const int ni = wi.n_images;
+    if ((int)blockIdx.x < ni) {
         ro_weight_image_body(wi, (int)blockIdx.x);
         return;
     }
-    splitk_reduce_body<QUAD>(slab, splits, epi, (int64_t)(blockIdx.x - 64) * 256 + threadIdx.x, (int64_t)(gridDim.x - 64) * 256);
+    splitk_reduce_body<QUAD>(slab, splits, epi, (int64_t)(blockIdx.x - ni) * 256 + threadIdx.x, (int64_t)(gridDim.x - ni) * 256);
 }
 
 // the same for the two problems of gemm_tile_pair_kernel (blockIdx.y = problem)
@@ -837,7 +838,7 @@ int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, co
                       const RoWeightImages* images) {
     const int cs_blocks = colsum ? 2 * ceil_div(3 * colsum->D, 16) : 0;
     const SlabColsum cs = colsum ? *colsum : SlabColsum{};
-    const int wi_blocks = images ? 64 : 0;
+    const int wi_blocks = images ? images->n_images : 0;
     const RoWeightImages wi = images ? *images : RoWeightImages{};
     SmallMMSet mm{};
     int mm_blocks = 0;
@@ -867,8 +868,8 @@ int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, co
     if (cnt == 0 && mm_blocks == 0 && cs_blocks == 0 && wi_blocks == 0) return SNAG_OK;
     if (cnt == 1 && mm_blocks == 0 && cs_blocks == 0 && wi_blocks == 0) return launch_reduce(last, last_slab, st);
     if (cnt == 1 && mm_blocks == 0 && cs_blocks == 0 && rs.mode[0] != 2) {          // one problem + the weight images
-        if (rs.mode[0] == 1) hipLaunchKernelGGL(splitk_reduce_images_kernel<true>, dim3(rs.nblk[0] + 64), dim3(256), 0, st, rs.slab[0], rs.splits[0], rs.e[0], wi);
-        else hipLaunchKernelGGL(splitk_reduce_images_kernel<false>, dim3(rs.nblk[0] + 64), dim3(256), 0, st, rs.slab[0], rs.splits[0], rs.e[0], wi);
+        if (rs.mode[0] == 1) hipLaunchKernelGGL(splitk_reduce_images_kernel<true>, dim3(rs.nblk[0] + wi_blocks), dim3(256), 0, st, rs.slab[0], rs.splits[0], rs.e[0], wi);
+        else hipLaunchKernelGGL(splitk_reduce_images_kernel<false>, dim3(rs.nblk[0] + wi_blocks), dim3(256), 0, st, rs.slab[0], rs.splits[0], rs.e[0], wi);
         return check_launch("snag_gemm_reduce_group");
     }
     int total_blocks = mm_blocks + cs_blocks + wi_blocks;

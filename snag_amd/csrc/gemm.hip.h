@@ -371,14 +371,20 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint
 __device__ __forceinline__ void ro_weight_image_body(const RoWeightImages& w, int image) {
     const int s = image >> 3, kt = image & 7, tid = threadIdx.x;
     const int row = tid >> 2, c = tid & 3;
-    const float* W = w.W[s];
     unsigned char* im = w.wimg + (size_t)image * (6 * 128 * 16) + ((c & 1) * 128 + row) * 16 + (c >> 1) * 8;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const float4 f = *reinterpret_cast<const float4*>(W + (int64_t)(row + 64 * i) * w.ldw + kt * 16 + c * 4);
+        float f[4];
+        if (s < 8) {
+            const float4 v = *reinterpret_cast<const float4*>(w.W[s] + (int64_t)(row + 64 * i) * w.ldw + kt * 16 + c * 4);
+            f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+        } else {        // the transposed use: the k of the image runs over the weight's rows (SplitStager<128, row-contiguous> keeps the same chunks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = w.Wt[(int64_t)(kt * 16 + 4 * c + j) * w.ldw + row + 64 * i];
+        }
         uint32_t h0, m0, l0, h1, m1, l1;
-        split_pair(f.x, f.y, h0, m0, l0);
-        split_pair(f.z, f.w, h1, m1, l1);
+        split_pair(f[0], f[1], h0, m0, l0);
+        split_pair(f[2], f[3], h1, m1, l1);
         *reinterpret_cast<uint2*>(im + i * 64 * 16) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(im + i * 64 * 16 + 2 * 128 * 16) = make_uint2(m0, m1);
         *reinterpret_cast<uint2*>(im + i * 64 * 16 + 4 * 128 * 16) = make_uint2(l0, l1);

@@ -563,12 +563,161 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
 #endif
 }
 
-int64_t readout_fused_image_bytes() { return (int64_t)8 * kRoTiles * kBImg; }
+// ---- backward: d ctx + attention backward -----------------------------------------------------------------------------------------
+// Wo^T as k-tile images: image kt holds B(n = input column i, k = output row o) = Wo[o * ldw + i] for o = 16 kt .. 16 kt + 15 --
+// SplitStager<128, row-contiguous>'s k permutation inside the k-tile is the K-contiguous one's (chunk c = four consecutive k), so the
+// images are the ones gemm_tile_kernel<.., B row-contiguous> builds in its LDS.
+__global__ __launch_bounds__(256) void readout_presplit_t_kernel(RoBwdArgs a) {
+    const int kt = blockIdx.x, tid = threadIdx.x;
+    const int row = tid >> 2, c = tid & 3;
+    unsigned char* im = a.wimg + (size_t)kt * kBImg + ((c & 1) * 128 + row) * 16 + (c >> 1) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float f[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = a.wo[(int64_t)(kt * 16 + 4 * c + j) * a.ldw + row + 64 * i];
+        uint32_t h0, m0, l0, h1, m1, l1;
+        split_pair(f[0], f[1], h0, m0, l0);
+        split_pair(f[2], f[3], h1, m1, l1);
+        *reinterpret_cast<uint2*>(im + i * 64 * 16) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(im + i * 64 * 16 + 2 * 128 * 16) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(im + i * 64 * 16 + 4 * 128 * 16) = make_uint2(l0, l1);
+    }
+}
+
+template <int NH>
+__global__ __launch_bounds__(256 * NH) void readout_bwd_attn_kernel(RoBwdArgs a) {
+    constexpr int M = 3, D = 128, BM = 32, RPW = 8;
+    constexpr int kAImg = Panel<BM>::kImg;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kBImg + NH * (8 * kAImg + BM * kP * 4)];
+    __shared__ float red[NH][4][3][D];
+    const int gtid = threadIdx.x, tid = gtid & 255, lane = tid & 63, wave = wave_id_uniform() & 3, half = wave_id_uniform() >> 2;
+    unsigned char* const bbuf = lds;
+    unsigned char* const aimg = lds + 2 * kBImg + half * 8 * kAImg;
+    lds_float* const T = (lds_float*)(lds + 2 * kBImg + NH * 8 * kAImg + half * BM * kP * 4);
+    const int li = lane & 31, lh = lane >> 5, wn0 = wave * 32;
+    const int N = a.N;
+    const int m_first = (blockIdx.x * NH + half) * BM, m0 = min(m_first, N - 1);
+    const int rw = RPW * wave, valid = max(0, min(BM, N - m_first));
+    constexpr int NB = NH == 1 ? 3 : 2;
+    u4 br[4][NB];
+    auto fetch_b = [&](auto S, int i) {
+        constexpr int set = decltype(S)::value;
+        const auto rsrc = uniform_rsrc(a.wimg + (size_t)(i < 8 ? i : 0) * kBImg, i < 8 ? kBImg : 0);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) br[set][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)(gtid + 256 * NH * q) * 16u, 0, 0);
+    };
+    auto stage_b = [&](auto S, unsigned char* image) {
+        constexpr int set = decltype(S)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+        auto* im = (__attribute__((address_space(3))) unsigned char*)image + gtid * 16;
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            if (NH == 1 || gtid + 512 * q < 768) *(lds_u4*)(im + 4096 * NH * q) = br[set][q];
+#endif
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    using S3 = std::integral_constant<int, 3>;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    auto sub_iteration = [&](int kt, auto S) {
+        Split3 af, bf;
+        const int cur = kt & 1;
+        load_split_fragment<BM>(aimg + kt * kAImg, li, lh, af);
+        load_split_fragment<128>(bbuf + cur * kBImg, wn0 + li, lh, bf);
+        stage_b(S, bbuf + (cur ^ 1) * kBImg);
+        fetch_b(S, kt + 5);
+#if defined(__HIP_DEVICE_COMPILE__)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.l, bf.h, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.h, bf.l, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.m, bf.m, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.m, bf.h, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.h, bf.m, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.h, bf.h, acc, 0, 0, 0);
+#endif
+        __syncthreads();
+    };
+    // (the first two entities' rows travel during the product: they do not depend on d ctx)
+    const int n_mine = max(0, min(RPW, valid - rw));
+    const int64_t n0 = (int64_t)m_first + rw, n_last = (int64_t)N - 1;
+    AttnRoRows<M, 2> nxt[2] = {attn_ro_load<M, 2>(a.qkv, min(n0, n_last), D, a.H, a.g, a.keep_probs, lane),
+                               attn_ro_load<M, 2>(a.qkv, min(n0 + 1, n_last), D, a.H, a.g, a.keep_probs, lane)};
+    Panel<BM> pr;
+    pr.load(a.dz, a.lddz, m0, N, tid);
+    fetch_b(S0{}, 0);
+    fetch_b(S1{}, 1);
+    fetch_b(S2{}, 2);
+    fetch_b(S3{}, 3);
+    pr.store(aimg, tid);
+    stage_b(S0{}, bbuf);
+    fetch_b(S0{}, 4);
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < 8; kt += 4) {
+        sub_iteration(kt, S1{});
+        sub_iteration(kt + 1, S2{});
+        sub_iteration(kt + 2, S3{});
+        sub_iteration(kt + 3, S0{});
+    }
+    // d ctx rows -> the row tile
+#pragma unroll
+    for (int e = 0; e < 16; ++e) T[((e & 3) + 8 * (e >> 2) + 4 * lh) * kP + wn0 + li] = acc[e];
+    __syncthreads();
+    // the wave's eight entities, one after the other (attn_ro_bwd_kernel's arithmetic; d ctx from the row tile)
+    Cols<2> sq, sk, sv;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) sq.v[u] = sk.v[u] = sv.v[u] = 0.f;
+    // Two entities at a time (their sum64 chains interleave), the next pair's rows requested before the current pair's arithmetic: eight waves
+    // per CU do not hide a round trip or a dependent chain by themselves.
+#pragma unroll 1
+    for (int r = 0; r < n_mine; r += 2) {
+        const AttnRoRows<M, 2> cur[2] = {nxt[0], nxt[1]};
+        nxt[0] = attn_ro_load<M, 2>(a.qkv, min(n0 + r + 2, n_last), D, a.H, a.g, a.keep_probs, lane);
+        nxt[1] = attn_ro_load<M, 2>(a.qkv, min(n0 + r + 3, n_last), D, a.H, a.g, a.keep_probs, lane);
+        Cols<2> go[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int rr = min(rw + r + e, BM - 1);
+            go[e].v[0] = T[rr * kP + lane];
+            go[e].v[1] = T[rr * kP + lane + 64];
+        }
+        const int64_t ns[2] = {n0 + r, n0 + r + 1};
+        const bool live[2] = {true, r + 1 < n_mine};
+        attn_ro_bwd_entities<M, 2, 2>(cur, go, ns, live, D, a.H, a.g, a.inv_sqrt_d, a.keep_probs, a.kscale, a.dq_g, a.dkv, a.ro3, lane, sq, sk, sv);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        red[half][wave][0][lane + 64 * u] = sq.v[u];
+        red[half][wave][1][lane + 64 * u] = sk.v[u];
+        red[half][wave][2][lane + 64 * u] = sv.v[u];
+    }
+    __syncthreads();
+    if (m_first < N)
+        for (int i = tid; i < 3 * D; i += 256) {
+            const int which = i / D, c = i % D;
+            a.bias_part[(int64_t)(blockIdx.x * NH + half) * 3 * D + which * D + c] =
+                ((red[half][0][which][c] + red[half][1][which][c]) + red[half][2][which][c]) + red[half][3][which][c];
+        }
+}
+
+int readout_bwd_attn_fused(const RoBwdArgs& a, hipStream_t st) {
+    if (a.N <= 0) return SNAG_OK;
+    if (!a.images_ready) hipLaunchKernelGGL(readout_presplit_t_kernel, dim3(8), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((readout_bwd_attn_kernel<SNAG_RO_NH>), dim3((unsigned)ceil_div(a.N, 32 * SNAG_RO_NH)), dim3(256 * SNAG_RO_NH), 0, st, a);
+    return check_launch("fusion attention backward (read-out, with its d ctx product)");
+}
+
+int64_t readout_fused_image_bytes() { return (int64_t)(8 * kRoTiles + 8) * kBImg; }      // + Wo^T for the backward
 
 RoWeightImages readout_weight_images(const RoFusedArgs& a) {
     RoWeightImages w{};
     for (int i = 0; i < kRoTiles; ++i) w.W[i] = a.t[i].W;
+    w.Wt = nullptr;
     w.ldw = a.ldw;
+    w.n_images = 8 * kRoTiles;
     w.wimg = a.wimg;
     return w;
 }

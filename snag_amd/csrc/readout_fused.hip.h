@@ -40,6 +40,22 @@ struct RoFusedArgs {
 };
 
 int64_t readout_fused_image_bytes();
+
+// The read-out layer's attention backward with its d ctx product in ONE launch (readout_fused.hip): d ctx = dz Wo for 32 entities per half-workgroup
+// (split-bf16 products of gemm_tile_kernel's bits), then attn_ro_bwd_entity per entity with d ctx taken from the LDS row tile.
+struct RoBwdArgs {
+    const float* dz; int64_t lddz;       // [N, 128] K-contiguous: the gradient of the output projection's result
+    const float* wo; int ldw;            // output.dense weight [128 out, 128 in]
+    unsigned char* wimg;                 // 8 x 12 KB: Wo^T as split k-tile images
+    int images_ready;                    // 1: they hold this step's weights already (written beside the forward's images); 0: a launch of this call writes them
+    const float* qkv;
+    const uint8_t* keep_probs;
+    float kscale, inv_sqrt_d;
+    int N, H, g;
+    float *dq_g, *dkv, *ro3;
+    float* bias_part;                    // [ceil(N / 32)][3][128]: per-half column sums of dq, dk, dv
+};
+int readout_bwd_attn_fused(const RoBwdArgs& a, hipStream_t st);
 RoWeightImages readout_weight_images(const RoFusedArgs& a);
 // images_ready: the weight images in a.wimg are this step's already (prepared inside another launch): no preparation launch
 int readout_fwd_fused(const RoFusedArgs& a, hipStream_t st, bool images_ready);

@@ -449,6 +449,7 @@ class MKGCHotPath:
             ready = ctypes.c_int32(0)
             self._probed((tag + "_reduce") if tag else "", call, "snag_fusion_fwd_prepare_reduce", ctypes.byref(self._fdesc), group, 2, ctypes.byref(ready), self._st)
             self._fdesc.weight_images_ready = ready.value
+            self._bdesc.wo_images_ready = ready.value
         else:
             self._probed((tag + "_reduce") if tag else "", call, "snag_gemm_reduce_pair", ctypes.byref(descs[0]), ctypes.byref(descs[1]), self._st)
         return True
@@ -691,6 +692,7 @@ class MKGCHotPath:
         # splits balanced across both (visual 3 + text 1 at the DB15K shape: 236 workgroups walking 86 / 48 k-tiles instead of a 236-
         # and a 177-workgroup launch) + one reduce; otherwise two kernels and ONE reduce launch per pair
         self._fdesc.weight_images_ready = 0
+        self._bdesc.wo_images_ready = 0
         co = self.fold and nmod <= 2 and self.co_launch
         if co:      # the folded key / value products ride in snag_fusion_fwd: described now, so that the first projections' reduce launch can prepare its weights
             kv = self._fold_kv_descs()

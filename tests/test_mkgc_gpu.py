@@ -315,6 +315,41 @@ def test_one_launch_readout_forward_equals_the_separate_launches_bit_for_bit(N, 
         assert torch.equal(a[3][k], b[3][k]), k
 
 
+@pytest.mark.parametrize("N,heads,dropout", [(1500, 2, 0.1), (15000, 2, 0.1), (999, 4, 0.0), (33, 1, 0.2), (1, 2, 0.1), (64, 2, 0.1)])
+def test_attention_backward_with_its_own_d_ctx_product_equals_the_two_launches(N, heads, dropout):
+    """csrc/readout_fused.hip, readout_bwd_attn_kernel: d ctx = dz Wo (the split-bf16 products of gemm_tile_kernel, bit for bit) and the
+    attention backward of the read-out row (attn_ro_bwd_entities, the arithmetic of attn_ro_bwd_kernel) as ONE launch, d ctx never
+    travelling.  Against the two launches (snag_fusion_bwd_desc.separate_attention_backward = 1): every gradient the same bits, except
+    the stacked q/k/v bias gradient -- a column sum over the entities whose partial sums are formed per 32 contiguous entities instead of
+    per strided workgroup: equal to rounding."""
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    R, B, K, D = 9, 128, 8, 128
+    g = torch.Generator().manual_seed(17)
+    feats = [torch.rand(N, 72, generator=g), torch.randn(N, 40, generator=g)]
+    idx = [torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(DEV) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (N, (B, K)))]
+    ent0 = torch.randn(N, D, generator=g).to(DEV)
+    out = {}
+    for separate in (0, 1):
+        cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[72, 40], num_proj=2, num_heads=heads, joint_way="Mformer_hd_graph", margin=6.0, neg_num=K,
+                         dropout=dropout, proj_dropout=0.1, add_noise=1, seed=7)
+        eng = MKGCHotPath(cfg, feats, device=DEV)
+        eng._bdesc.separate_attention_backward = separate
+        eng.p["ent"].copy_(ent0)
+        eng.update_noise()
+        loss = eng.forward(*idx, with_backward=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        out[separate] = (loss.clone(), {k: v.clone() for k, v in eng.named_gradients().items()})
+    a, b = out[0], out[1]
+    assert torch.equal(a[0], b[0])
+    for k in a[1]:
+        if k == "layer0.bqkv":
+            scale = max(1e-6, float(b[1][k].abs().max()))
+            assert float((a[1][k] - b[1][k]).abs().max()) <= 2e-5 * scale, (k, float((a[1][k] - b[1][k]).abs().max()), scale)
+        else:
+            assert torch.equal(a[1][k], b[1][k]), k
+
+
 def test_projection_head_dropout_in_the_engine():
     """num_proj=2 is the in-tree ProjectionHead, which drops between ReLU and l2 (model/layers.py:142-147): with proj_dropout > 0 the
     engine's step must equal the oracle's projection_head fed with the very masks the engine drew; eval mode ignores them."""
