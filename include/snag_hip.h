@@ -374,6 +374,10 @@ typedef struct snag_fusion_desc {
     /* 1: the split weight images of the one-launch read-out forward were prepared for THIS step's weights by snag_fusion_fwd_prepare_reduce
      * (which reports it); snag_fusion_fwd then skips its own preparation launch.  0 (default): snag_fusion_fwd prepares them itself. */
     int32_t weight_images_ready;
+    /* The one-launch read-out forward (and the backward's fused launch) pay off from ~5,000 (10,000) entities on: a workgroup walks the whole
+     * chain, so its time does not shrink with N -- one rank's 1,875 rows of an 8-way row-sharded step run faster as separate launches (224 vs 238 us
+     * for the rank's step).  Below the thresholds the library keeps the separate launches; 1 here takes the one-launch paths whatever N (tests, A/B). */
+    int32_t force_one_launch;
 } snag_fusion_desc;
 
 /* snag_gemm_reduce_group(descs, n) AND, in the same launch, the preparation of the read-out forward's weight images for `f` (its layers'

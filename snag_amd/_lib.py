@@ -58,7 +58,7 @@ class FusionDesc(_c.Structure):
                 ("layers", _c.POINTER(FusionLayer)), ("weight_raw", _P), ("x0", _P),
                 ("joint", _P), ("joint_fz", _P), ("hidden", _P), ("weight_norm", _P),
                 ("save", _P), ("save_floats", _L), ("work", _P), ("work_floats", _L), ("readout_slot_p1", _c.c_int32),
-                ("fold_others", _c.c_int32), ("co_fwd", _c.POINTER(GemmDesc) * 2), ("n_co_fwd", _c.c_int32), ("weight_images_ready", _c.c_int32)]
+                ("fold_others", _c.c_int32), ("co_fwd", _c.POINTER(GemmDesc) * 2), ("n_co_fwd", _c.c_int32), ("weight_images_ready", _c.c_int32), ("force_one_launch", _c.c_int32)]
 
 
 class SmallMM(_c.Structure):

@@ -5,6 +5,15 @@
 #include "fusion_kernels.hip.h"
 #include "readout_fused.hip.h"
 
+// The one-launch read-out forward / the backward's fused launch are taken from this many entities on (a workgroup walks the whole chain: its
+// time does not shrink with N).  One rank's share of an R-way row-sharded DB15K step, separate launches vs one launch (tools/ab_shard.sh):
+// forward 53.4 / 48.9 us at 7,500 rows, 42.1 / 45.8 at 3,750, 38.2 / 44.9 at 1,875; backward 27.1 / 28.3, 20.7 / 25.0, 17.2 / 24.6 (36.3 / 32.5 at 15,000).
+#ifndef SNAG_RO_FWD_MIN_ROWS
+#define SNAG_RO_FWD_MIN_ROWS 5120
+#endif
+#ifndef SNAG_RO_BWD_MIN_ROWS
+#define SNAG_RO_BWD_MIN_ROWS 10240
+#endif
 #ifndef SNAG_RO_BWD_FUSED
 #define SNAG_RO_BWD_FUSED 1      // A/B: 0 keeps the d ctx GEMM and the attention backward as two launches in the read-out layer's backward
 #endif
@@ -126,7 +135,7 @@ static int check_fusion(const snag_fusion_desc* f) {
 // Returns 1 -- nothing launched -- otherwise; the three-launch path below gives the same bits.
 static int readout_one_launch_args(const snag_fusion_desc* f, const snag_fusion_layer& P, const LayerSave& S, const float* xin, RoFusedArgs& a) {
     const int N = f->N, M = f->M, D = f->D, H = f->H, g = f->readout_slot_p1 - 1;
-    if (!(f->fold_others && f->n_co_fwd == 2 && M == 3 && D == 128 && !f->use_intermediate && H <= kRoMaxHeads)) return 1;
+    if (!(f->fold_others && f->n_co_fwd == 2 && M == 3 && D == 128 && !f->use_intermediate && H <= kRoMaxHeads && (N >= SNAG_RO_FWD_MIN_ROWS || f->force_one_launch))) return 1;
     const int64_t MD = (int64_t)M * D;
     auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!aligned(xin) || !aligned(P.wqkv) || !aligned(P.wo)) return 1;
@@ -451,7 +460,7 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             int ablocks = (int)std::min<int64_t>(kRedBlocks, (N + 3) / 4);
             // fold_others with M >= 3: the read-out token's dq | dk | dv side by side in the [N, 3D] block where dq_g alone would go
             float* ro3 = (f->fold_others && M >= 3) ? dq_g : nullptr;
-            const bool one_launch = SNAG_RO_BWD_FUSED && !b->separate_attention_backward && ro3 && M == 3 && D == 128 && !ffn && ceil_div(N, 32) <= kRedBlocks && ((uintptr_t)dz & 15) == 0;
+            const bool one_launch = SNAG_RO_BWD_FUSED && (N >= SNAG_RO_BWD_MIN_ROWS || f->force_one_launch) && !b->separate_attention_backward && ro3 && M == 3 && D == 128 && !ffn && ceil_div(N, 32) <= kRedBlocks && ((uintptr_t)dz & 15) == 0;
             if (one_launch) {
                 // d ctx = dz Wo and the attention backward in ONE launch (readout_fused.hip): d ctx never travels; the bias slab has one row per
                 // 32 entities (its column sums are associated differently from the separate launches': dbqkv agrees to rounding, all else bit for bit)

@@ -140,6 +140,7 @@ class MKGCHotPath:
         # only the rows in the new or the previous mask) and a second layout for the weights.
         self.g_slot = M - 1                                   # structural token last
         self.co_launch = True        # folded key / value products ride in snag_fusion_fwd's launches (False: launches of their own; the same bits -- tests)
+        self.force_one_launch = False    # True: the one-launch read-out forward / fused backward below the library's row thresholds too (tests)
         I, L, ffn = cfg.intermediate_size, cfg.num_layers, bool(cfg.use_intermediate)
 
         # ---- flat parameter layout ---------------------------------------------------------------
@@ -693,6 +694,7 @@ class MKGCHotPath:
         # and a 177-workgroup launch) + one reduce; otherwise two kernels and ONE reduce launch per pair
         self._fdesc.weight_images_ready = 0
         self._bdesc.wo_images_ready = 0
+        self._fdesc.force_one_launch = self._bdesc.f.force_one_launch = int(self.force_one_launch)
         co = self.fold and nmod <= 2 and self.co_launch
         if co:      # the folded key / value products ride in snag_fusion_fwd: described now, so that the first projections' reduce launch can prepare its weights
             kv = self._fold_kv_descs()

@@ -147,6 +147,7 @@ def test_prepare_reduce_reports_whether_the_weight_images_were_written():
     for force_off in (False, True):
         cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=[640, 512], num_proj=2, joint_way="Mformer_hd_graph", margin=6.0, neg_num=K, dropout=0.1, seed=3)
         eng = MKGCHotPath(cfg, feats, device=DEV)
+        eng.force_one_launch = True            # (1,100 entities: below the row threshold of the one-launch paths)
         if force_off:
             orig = eng._grouped_long_k
             eng._grouped_long_k = lambda *a, **kw: orig(*a, **{**kw, "prepare_fusion": False})

@@ -294,6 +294,7 @@ def test_one_launch_readout_forward_equals_the_separate_launches_bit_for_bit(N, 
         eng = MKGCHotPath(cfg, feats, device=DEV)
         assert eng.fold and eng.ro
         eng.co_launch = co
+        eng.force_one_launch = True
         eng.p["ent"].copy_(ent0)
         eng.update_noise()
         if not train:
@@ -334,6 +335,7 @@ def test_attention_backward_with_its_own_d_ctx_product_equals_the_two_launches(N
                          dropout=dropout, proj_dropout=0.1, add_noise=1, seed=7)
         eng = MKGCHotPath(cfg, feats, device=DEV)
         eng._bdesc.separate_attention_backward = separate
+        eng.force_one_launch = True
         eng.p["ent"].copy_(ent0)
         eng.update_noise()
         loss = eng.forward(*idx, with_backward=True)

@@ -34,6 +34,7 @@ for seed in range(first, first + count):
                          dropout=dropout, proj_dropout=0.1, add_noise=rnd.choice([0, 1]) if co is True else cfg.add_noise, seed=seed % 97)
         eng = MKGCHotPath(cfg, feats, device=DEV)
         eng.co_launch = bool(co)
+        eng.force_one_launch = True
         eng._bdesc.separate_attention_backward = int(co == "separate_bwd")      # d ctx GEMM + attention backward as two launches
         eng.p["ent"].copy_(ent0)
         if cfg.add_noise:
