@@ -14,6 +14,19 @@
 #ifndef SNAG_RO_BWD_MIN_ROWS
 #define SNAG_RO_BWD_MIN_ROWS 10240
 #endif
+// ... and only when their workgroups (64 entities each, one per CU) fill the last round of the chip to 70 %: 20,000 entities = 313 workgroups
+// = two rounds of which the second is a quarter full, i.e. twice the time of 16,384 entities.
+static bool ro_rounds_filled(int N) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else cus = 256;
+    }
+    const int wgs = snag::ceil_div(N, 64), rounds = snag::ceil_div(wgs, cus);
+    return wgs * 10 >= rounds * cus * 7;
+}
+
 #ifndef SNAG_RO_BWD_FUSED
 #define SNAG_RO_BWD_FUSED 1      // A/B: 0 keeps the d ctx GEMM and the attention backward as two launches in the read-out layer's backward
 #endif
@@ -135,7 +148,7 @@ static int check_fusion(const snag_fusion_desc* f) {
 // Returns 1 -- nothing launched -- otherwise; the three-launch path below gives the same bits.
 static int readout_one_launch_args(const snag_fusion_desc* f, const snag_fusion_layer& P, const LayerSave& S, const float* xin, RoFusedArgs& a) {
     const int N = f->N, M = f->M, D = f->D, H = f->H, g = f->readout_slot_p1 - 1;
-    if (!(f->fold_others && f->n_co_fwd == 2 && M == 3 && D == 128 && !f->use_intermediate && H <= kRoMaxHeads && (N >= SNAG_RO_FWD_MIN_ROWS || f->force_one_launch))) return 1;
+    if (!(f->fold_others && f->n_co_fwd == 2 && M == 3 && D == 128 && !f->use_intermediate && H <= kRoMaxHeads && ((N >= SNAG_RO_FWD_MIN_ROWS && ro_rounds_filled(N)) || f->force_one_launch))) return 1;
     const int64_t MD = (int64_t)M * D;
     auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!aligned(xin) || !aligned(P.wqkv) || !aligned(P.wo)) return 1;
@@ -460,7 +473,7 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             int ablocks = (int)std::min<int64_t>(kRedBlocks, (N + 3) / 4);
             // fold_others with M >= 3: the read-out token's dq | dk | dv side by side in the [N, 3D] block where dq_g alone would go
             float* ro3 = (f->fold_others && M >= 3) ? dq_g : nullptr;
-            const bool one_launch = SNAG_RO_BWD_FUSED && (N >= SNAG_RO_BWD_MIN_ROWS || f->force_one_launch) && !b->separate_attention_backward && ro3 && M == 3 && D == 128 && !ffn && ceil_div(N, 32) <= kRedBlocks && ((uintptr_t)dz & 15) == 0;
+            const bool one_launch = SNAG_RO_BWD_FUSED && ((N >= SNAG_RO_BWD_MIN_ROWS && ro_rounds_filled(N)) || f->force_one_launch) && !b->separate_attention_backward && ro3 && M == 3 && D == 128 && !ffn && ceil_div(N, 32) <= kRedBlocks && ((uintptr_t)dz & 15) == 0;
             if (one_launch) {
                 // d ctx = dz Wo and the attention backward in ONE launch (readout_fused.hip): d ctx never travels; the bias slab has one row per
                 // 32 entities (its column sums are associated differently from the separate launches': dbqkv agrees to rounding, all else bit for bit)
