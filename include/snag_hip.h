@@ -327,7 +327,7 @@ SNAG_API int snag_gram_f32(const float* Z, int64_t ldz, int n, int k, float alph
  * Sizes: snag_fusion_save_floats / snag_fusion_work_floats.  M <= 6, D <= 512, D % H == 0, H*M*M <= 192 (the reference's default
  * 5 heads with all 6 modalities is 180).
  * Read-out mode with D == 128, M == 3, two co_fwd products, no FFN, H <= 4: the whole layer forward is ONE launch (csrc/readout_fused.hip;
- * the last 768 KB of `save` hold its split weight images); results and saved activations are the bits of the separate launches.
+ * the last 864 KB of `save` hold its split weight images and the backward's Wo^T ones); results and saved activations are the bits of the separate launches.
  */
 typedef struct snag_fusion_layer {
     const float *wqkv, *bqkv;

@@ -657,7 +657,7 @@ extern "C" SNAG_API int snag_fusion_fwd_prepare_reduce(const snag_fusion_desc* f
 
 extern "C" SNAG_API int64_t snag_fusion_save_floats(int N, int M, int D, int H, int I, int L, int use_intermediate) {
     if (N < 0 || M < 1 || D < 1 || H < 1 || L < 1) return 0;
-    // (+ the split weight images of the one-launch read-out forward behind the last layer's activations: 768 KB whatever the shape)
+    // (+ the split weight images of the one-launch read-out forward behind the last layer's activations -- and the backward's Wo^T: 864 KB whatever the shape)
     return SaveLayout(N, M, D, H, I, use_intermediate != 0).per_layer * L + readout_fused_image_bytes() / 4;
 }
 

@@ -303,7 +303,7 @@ def test_one_launch_readout_forward_equals_the_separate_launches_bit_for_bit(N, 
         if train:
             eng.backward()
         torch.cuda.synchronize()
-        out[co] = (eng.entity_representation().clone(), loss.clone(), eng.save.clone()[:eng.save.numel() - 8 * 8 * 12288 // 4],
+        out[co] = (eng.entity_representation().clone(), loss.clone(), eng.save.clone()[:eng.save.numel() - 9 * 8 * 12288 // 4],
                    {k: v.clone() for k, v in eng.named_gradients().items()} if train else {})
     a, b = out[True], out[False]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
