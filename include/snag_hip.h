@@ -28,7 +28,9 @@ extern "C" {
 #define SNAG_ERR_UNSUPPORTED (-2) /* shape outside what the kernels are built for */
 #define SNAG_ERR_LAUNCH (-3)      /* HIP refused the launch (hipGetLastError text in snag_last_error) */
 
-#define SNAG_ABI_VERSION 1
+/* Bumped whenever a struct layout or an entry's argument list changes: snag_amd/_lib.py refuses a library whose snag_version()
+ * differs from the constant it was written against (a stale or variant .so would otherwise be read with the wrong field offsets). */
+#define SNAG_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define SNAG_API __attribute__((visibility("default")))
@@ -464,6 +466,25 @@ SNAG_API int snag_pack_tokens(const float* const* src_host, int M, int64_t N, in
 
 /* README joint_way "Mformer_hd_mean": out[n,:] = mean_m hidden[n,m,:]  (a9; parity unpinned). */
 SNAG_API int snag_token_mean(const float* hidden, int64_t N, int M, int D, float* out, void* stream);
+
+/* README joint_way "atten_weight" (a9; README.md:51): non-transformer attention over an entity's M modality tokens x [rows, M, D] (dense).
+ * The only arithmetic of that name in the reference tree is EVA_tools.SelfAttention.forward (model/EVA_tools.py:190-232, dead code):
+ *   pre_m = x_m . a ;  w = softmax_m(relu(pre)) ;  out[n, :] = sum_m w_m x[n, m, :]            (a [D] learnable; PARITY UNPINNED).
+ * aw [rows, 2 M] receives (w, pre) for the backward.  1 <= M <= 6, 4 | D <= 512.
+ * snag_atten_weight_bwd: d_x [rows, M, D] = w_m d_out + d pre_m a (written), d_a [D] (=|+=) sum_n sum_m d pre_m x_m through
+ *   snag_atten_weight_work_floats(D) floats of fixed-order partial slabs (no float atomics). */
+SNAG_API int64_t snag_atten_weight_work_floats(int D);
+SNAG_API int snag_atten_weight_fwd(const float* x, int64_t rows, int M, int D, const float* a, float* out, int64_t ld_out, float* aw,
+                                   void* stream);
+SNAG_API int snag_atten_weight_bwd(const float* x, int64_t rows, int M, int D, const float* a, const float* aw, const float* d_out,
+                                   int64_t ld_dout, float* d_x, float* d_a, int accumulate_da, float* work, void* stream);
+
+/* README POOL=1 / use_pool (README.md:68,79: "pooling operations are applied to all pre-extracted visual/text features for
+ * dimensionality reduction and uniformity in dimensions"; no code in the tree: PARITY UNPINNED).  Every row of x [N, H * W] (row stride ld),
+ * viewed as an H x W image, is adaptively average-pooled to oh x ow (torch.nn.functional.adaptive_avg_pool2d's windows; H = oh = 1 is
+ * the 1-D pool) into out [N, oh * ow] (row stride ld_out).  Once per feature table at load time. */
+SNAG_API int snag_adaptive_avg_pool_rows(const float* x, int64_t N, int64_t ld, int H, int W, int oh, int ow, float* out, int64_t ld_out,
+                                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a6  Gaussian noise-mask injection (GMNM) and its statistics.

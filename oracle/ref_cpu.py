@@ -155,7 +155,28 @@ def fusion_forward(embs: Sequence[Optional[Tensor]],
     return joint, joint_fz, hidden, w
 
 
-JOINT_WAYS = ("Mformer_hd_mean", "Mformer_hd_graph", "Mformer_weight", "learnable_weight")
+JOINT_WAYS = ("Mformer_hd_mean", "Mformer_hd_graph", "Mformer_weight", "atten_weight", "learnable_weight")
+
+
+def atten_weight_readout(tokens: Tensor, a: Tensor) -> Tensor:
+    """README joint_way "atten_weight" (README.md:51): non-transformer attention over the modality tokens [N, M, D].
+
+    reference: the only arithmetic of that name in the tree, SelfAttention.forward model/EVA_tools.py:203-232 (dead code there):
+    weights = inputs @ att_weights^T (:215-222), attentions = softmax(relu(weights)) over the tokens (:224), representations =
+    sum_m attentions_m * inputs_m (:227-231).  PARITY UNPINNED beyond that formula: the MKGC source that wires it is absent.
+    """
+    pre = tokens @ a                                               # [N, M]
+    w = torch.softmax(torch.relu(pre), dim=1)
+    return (tokens * w.unsqueeze(-1)).sum(dim=1)
+
+
+def adaptive_avg_pool_rows(x: Tensor, out_hw, view_hw=None) -> Tensor:
+    """README POOL=1 / ``use_pool`` (README.md:68,79; no code in the tree, PARITY UNPINNED): each row of x [N, F] viewed as (H, W) and
+    adaptively average-pooled to (oh, ow); (1, F) -> (1, P) is the 1-D pool.  torch's own definition of the windows is the specification."""
+    N, Fw = x.shape
+    H, W = (1, Fw) if view_hw is None else view_hw
+    oh, ow = (1, out_hw) if isinstance(out_hw, int) else out_hw
+    return F.adaptive_avg_pool2d(x.reshape(N, 1, H, W), (oh, ow)).reshape(N, oh * ow)
 
 
 def readout(joint_way: str, joint: Tensor, joint_fz: Tensor, hidden: Tensor, graph_index: int) -> Tensor:
@@ -173,6 +194,8 @@ def readout(joint_way: str, joint: Tensor, joint_fz: Tensor, hidden: Tensor, gra
         return joint
     if joint_way == "learnable_weight":
         return joint_fz
+    if joint_way == "atten_weight":
+        raise ValueError("atten_weight reads the tokens, not the Mformer's outputs: atten_weight_readout(tokens, a)")
     raise ValueError(f"unknown joint_way {joint_way!r}")
 
 
@@ -269,6 +292,15 @@ def selfadv_loss(e: Tensor, r: Tensor, h: Tensor, rel: Tensor, t: Tensor, neg_t:
     return loss, pos, neg
 
 
+def full_table_scores(e: Tensor, r: Tensor, h: Tensor, rel: Tensor) -> Tensor:
+    """s(h, r, n) for every candidate tail n: [B, N] TransE-L2^2 scores on normalised rows (model/MSNEA.py:110-121,151-152), formed in
+    chunks of 32 queries so that the [b, N, D] difference tensor stays small."""
+    q = nrm(e[h.long()]) + nrm(r[rel.long()])
+    en = nrm(e)
+    out = [(q[b0:b0 + 32].unsqueeze(1) - en.unsqueeze(0)).pow(2).sum(-1) for b0 in range(0, q.shape[0], 32)]
+    return torch.cat(out) if out else torch.zeros(0, e.shape[0], dtype=e.dtype)
+
+
 def rank_full_table(e: Tensor, r: Tensor, h: Tensor, rel: Tensor, t: Tensor,
                     filter_mask: Optional[Tensor] = None) -> Tensor:
     """Link-prediction rank of the true tail against all N entities (count-less-than).
@@ -276,13 +308,11 @@ def rank_full_table(e: Tensor, r: Tensor, h: Tensor, rel: Tensor, t: Tensor,
     PARITY UNPINNED (MKGC eval absent from the tree).  rank[b] = #{n : s(h,r,n) < s(h,r,t_b),
     n not filtered}.  ``filter_mask`` [B,N] bool marks known true tails to skip.
     """
-    q = nrm(e[h.long()]) + nrm(r[rel.long()])
-    en = nrm(e)
-    s = (q.unsqueeze(1) - en.unsqueeze(0)).pow(2).sum(-1)          # [B,N]
+    s = full_table_scores(e, r, h, rel)
     st = s.gather(1, t.long().view(-1, 1))
     less = s < st
     if filter_mask is not None:
-        less = less & ~filter_mask
+        less = less & ~filter_mask.bool()
     return less.sum(dim=1)
 
 
@@ -438,7 +468,8 @@ def mkgc_forward(feats: Sequence[Tensor], proj: Sequence[Dict[str, Tensor]], ent
                  ent_noise: Optional[Tensor] = None, ent_noise_mask: Optional[Tensor] = None,
                  mask_ratio: float = 0.0, loss_kind: str = "hinge", adv_temp: float = 1.0,
                  drop_masks: Optional[List[Dict[str, Tensor]]] = None, drop_p: float = 0.1,
-                 proj_keep: Optional[Sequence[Optional[Tensor]]] = None, proj_p: float = 0.0):
+                 proj_keep: Optional[Sequence[Optional[Tensor]]] = None, proj_p: float = 0.0,
+                 atten_a: Optional[Tensor] = None):
     """One MKGC hot-path step: projections -> tokens -> Mformer -> read-out -> margin score.
 
     Token order is [modality_0, ..., modality_{P-1}, structural]; the structural token is the
@@ -461,9 +492,12 @@ def mkgc_forward(feats: Sequence[Tensor], proj: Sequence[Dict[str, Tensor]], ent
     if ent_noise is not None:
         e = entity_noise_blend(e, ent_noise, ent_noise_mask, mask_ratio)
     toks.append(e)
-    joint, joint_fz, hidden, w = fusion_forward(toks, fusion_params, num_heads, num_layers, use_intermediate,
-                                                drop_masks=drop_masks, drop_p=drop_p)
-    ent = readout(joint_way, joint, joint_fz, hidden, graph_index=len(toks) - 1)
+    if joint_way == "atten_weight":          # no transformer: the read-out is a function of the tokens and ``atten_a`` [D] alone
+        ent = atten_weight_readout(torch.stack(toks, dim=1), atten_a)
+    else:
+        joint, joint_fz, hidden, w = fusion_forward(toks, fusion_params, num_heads, num_layers, use_intermediate,
+                                                    drop_masks=drop_masks, drop_p=drop_p)
+        ent = readout(joint_way, joint, joint_fz, hidden, graph_index=len(toks) - 1)
     if loss_kind == "self_adversarial":
         loss, pos, neg = selfadv_loss(ent, rel_table, h, rel, t, neg_t, margin, adv_temp)
     else:

@@ -18,6 +18,7 @@ _F = _c.c_float
 _U64 = _c.c_uint64
 SCORE_TICKET_WORDS = 1056      # SNAG_SCORE_TICKET_WORDS (include/snag_hip.h)
 MAX_MASK_REGIONS = 8           # SNAG_MAX_MASK_REGIONS
+ABI_VERSION = 2                # SNAG_ABI_VERSION: the struct layouts and argument lists below are those of this version
 
 
 
@@ -113,6 +114,9 @@ SIGNATURES = {
     "snag_small_matmul": [_P, _I, _P],
     "snag_pack_tokens": [_c.POINTER(_P), _I, _L, _I, _I, _P, _P, _F, _P, _P],
     "snag_token_mean": [_P, _L, _I, _I, _P, _P],
+    "snag_atten_weight_fwd": [_P, _L, _I, _I, _P, _P, _L, _P, _P],
+    "snag_atten_weight_bwd": [_P, _L, _I, _I, _P, _P, _P, _L, _P, _P, _I, _P, _P],
+    "snag_adaptive_avg_pool_rows": [_P, _L, _L, _I, _I, _I, _I, _P, _L, _P],
     "snag_colstats": [_P, _L, _I, _P, _L, _P, _P, _P, _P],
     "snag_noise_apply": [_P, _L, _I, _P, _P, _P, _P, _P, _U64, _F, _P, _P],
     "snag_dropout_keep_mask": [_U64, _P, _L, _F, _P, _P],
@@ -162,7 +166,7 @@ SIGNATURES = {
 _SPECIAL = {"snag_version": ([], _I), "snag_last_error": ([], _c.c_char_p),
             "snag_gemm_workspace_floats": ([_I, _I, _I], _L),
             "snag_fusion_save_floats": ([_I] * 7, _L), "snag_fusion_work_floats": ([_I] * 7, _L),
-            "snag_colstats_work_floats": ([_I], _L), "snag_eval_work_floats": ([_I, _I], _L),
+            "snag_colstats_work_floats": ([_I], _L), "snag_atten_weight_work_floats": ([_I], _L), "snag_eval_work_floats": ([_I, _I], _L),
             "snag_gat_work_floats": ([_L, _I, _I], _L), "snag_score_seg_work_bytes": ([_L, _L, _L, _I, _I], _L),
             "snag_score_touched_work_bytes": ([_L, _L, _L, _I, _I], _L)}
 
@@ -191,6 +195,10 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argt
         fn.restype = rest
+    got = lib.snag_version()
+    if got != ABI_VERSION:
+        raise SnagHipError(f"{LIB_PATH} reports ABI version {got}, this binding is written against {ABI_VERSION}: a stale or variant library "
+                           "would be read with the wrong struct offsets -- rebuild it (`python -m snag_amd.build --force`)")
     _lib = lib
     return lib
 

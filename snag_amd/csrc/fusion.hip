@@ -735,6 +735,12 @@ extern "C" SNAG_API int snag_fusion_bwd(const snag_fusion_bwd_desc* b, void* str
     }
     const int64_t need = snag_fusion_work_floats(b->f.N, b->f.M, b->f.D, b->f.H, b->f.I, b->f.L, b->f.use_intermediate);
     SNAG_REQUIRE(b->f.work_floats >= need, SNAG_ERR_ARG, "fusion_bwd: work buffer holds %ld floats, need %ld", (long)b->f.work_floats, (long)need);
+    // ln_bwd_done: the caller's scorer wrote dA / dB and a slab of ceil(N / 16) partial rows where the read-out LayerNorm's backward would have;
+    // the slab region holds kRedBlocks rows and the epilogue backward (d_joint / d_joint_fz / d_weight_norm) writes the same region first
+    SNAG_REQUIRE(!b->ln_bwd_done || b->f.use_intermediate ||
+                     (ceil_div(b->f.N, 16) <= kRedBlocks && b->f.readout_slot_p1 > 0 && !b->d_joint && !b->d_joint_fz && !b->d_weight_norm),
+                 SNAG_ERR_ARG, "fusion_bwd: ln_bwd_done needs a read-out-only last layer of at most %d rows and no joint / weight_norm gradients (N = %d)",
+                 16 * kRedBlocks, b->f.N);
     for (int l = 0; l < b->f.L; ++l) {
         const snag_fusion_layer_grad& G = b->grads[l];
         SNAG_REQUIRE(G.wqkv && G.bqkv && G.wo && G.bo && G.ln1_g && G.ln1_b, SNAG_ERR_ARG, "fusion_bwd: layer %d has a null attention gradient", l);

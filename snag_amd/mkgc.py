@@ -60,6 +60,12 @@ class MKGCConfig:
                                         # scatter-adds with fp32 atomics (snag_score_margin_fwd_bwd)
     deterministic: bool = False         # with scorer="atomic": fixed-point integer atomics instead (bit-reproducible, two launches)
     clip: float = 1.0                   # torch.nn.utils.clip_grad_norm_ of the reference's train loop (main.py:266-268, --clip default 1.0); 0 = off
+    use_pool: int = 0                   # README POOL=1 / ``use_pool`` (README.md:68,79): every raw feature table is average-pooled ONCE at load "for
+                                        # dimensionality reduction and uniformity in dimensions" -- F_m -> pool_dim columns (snag_adaptive_avg_pool_rows);
+                                        # tables already at most pool_dim wide are kept.  No code in the tree: PARITY UNPINNED (oracle.adaptive_avg_pool_rows)
+    pool_dim: int = 256
+    pool_views: Optional[List[Optional[tuple]]] = None     # per modality (H, W, oh, ow): pool the row as an H x W image to oh x ow instead of the
+                                        # 1-D pool (e.g. (64, 64, 16, 16) for a 4096-wide and (12, 64, 4, 64) for a 768-wide table); None = 1-D
     seed: int = 1234
 
     @property
@@ -97,10 +103,18 @@ class MKGCHotPath:
         gradient reduce-scattered back (SURVEY.md par. 8e).  Default: one rank owning every row.  ``feats``: the full [N, F_m]
         tables (sliced here) or this rank's rows only."""
         _lib.require_gpu()
+        from dataclasses import replace
         from .parallel import RowShard
-        self.cfg = cfg
         self.dev = torch.device(device)
         self.lib = _lib.load()
+        self.pooled_from = None
+        if cfg.use_pool:
+            # README POOL=1: the step never sees the raw tables again -- only the pooled ones stay in HBM, and the engine's configuration
+            # from here on is the pooled widths (a checkpoint records them with use_pool = 0 and ``pooled_from`` = the raw widths)
+            feats, dims = self._pool_features(cfg, feats)
+            self.pooled_from = list(cfg.feat_dims)
+            cfg = replace(cfg, feat_dims=dims, use_pool=0, pool_views=None)
+        self.cfg = cfg
         N, R, D, M = cfg.n_ent, cfg.n_rel, cfg.dim, cfg.n_tokens
         self.shard = shard if shard is not None else RowShard(N)
         if self.shard.n_rows != N:
@@ -108,9 +122,15 @@ class MKGCHotPath:
         Nl, Ns, lo = self.shard.n_loc, self.shard.n_shard, self.shard.lo
         # README.md:51 joint_way: the two hidden-state read-outs ([N, dim]) and the two weighted concatenations of the normalised INPUT
         # tokens ([N, M*dim]: Mformer_weight = attention-derived weights, learnable_weight = softmax(weight_raw); a1's joint / joint_fz).
-        # "atten_weight" (non-transformer attention; only dead code in the tree, EVA_tools.py:190-232) is not built.
-        if cfg.joint_way not in ("Mformer_hd_graph", "Mformer_hd_mean", "Mformer_weight", "learnable_weight"):
-            raise ValueError("joint_way must be Mformer_hd_graph, Mformer_hd_mean, Mformer_weight or learnable_weight (atten_weight is not built)")
+        # "atten_weight": non-transformer attention over the tokens -- one learnable vector a [D], w = softmax_m(relu(x_m . a)), read-out
+        # sum_m w_m x_m [N, dim] (the arithmetic of EVA_tools.SelfAttention, model/EVA_tools.py:190-232, the only code of that name in the
+        # tree); the Mformer is not run and owns no parameters in that mode.
+        if cfg.joint_way not in ("Mformer_hd_graph", "Mformer_hd_mean", "Mformer_weight", "atten_weight", "learnable_weight"):
+            raise ValueError("joint_way must be Mformer_hd_graph, Mformer_hd_mean, Mformer_weight, atten_weight or learnable_weight")
+        self.atten = cfg.joint_way == "atten_weight"
+        if self.atten and (cfg.dim % 4 or cfg.dim > 512 or cfg.n_tokens > 6):
+            raise ValueError(f"atten_weight: hidden size must be a multiple of 4 up to 512 with at most 6 tokens, got dim={cfg.dim}, tokens={cfg.n_tokens}")
+        self.n_layers = 0 if self.atten else cfg.num_layers
         if cfg.scorer not in ("segmented", "atomic"):
             raise ValueError(f"scorer must be 'segmented' or 'atomic', got {cfg.scorer!r}")
         self.concat = cfg.joint_way in ("Mformer_weight", "learnable_weight")
@@ -141,7 +161,7 @@ class MKGCHotPath:
         self.g_slot = M - 1                                   # structural token last
         self.co_launch = True        # folded key / value products ride in snag_fusion_fwd's launches (False: launches of their own; the same bits -- tests)
         self.force_one_launch = False    # True: the one-launch read-out forward / fused backward below the library's row thresholds too (tests)
-        I, L, ffn = cfg.intermediate_size, cfg.num_layers, bool(cfg.use_intermediate)
+        I, L, ffn = cfg.intermediate_size, self.n_layers, bool(cfg.use_intermediate)
 
         # ---- flat parameter layout ---------------------------------------------------------------
         self.slices = {}
@@ -165,6 +185,8 @@ class MKGCHotPath:
                 add(f"proj{i}.l1", D, fd)
                 add(f"proj{i}.l2", D, D)
         add("weight_raw", 6)
+        if self.atten:
+            add("atten.a", D)
         for l in range(L):
             add(f"layer{l}.wqkv", 3 * D, D); add(f"layer{l}.bqkv", 3 * D)
             add(f"layer{l}.wo", D, D); add(f"layer{l}.bo", D)
@@ -205,11 +227,14 @@ class MKGCHotPath:
         self.x0 = torch.empty(Nl, M, D, device=dev)
         # read-out-only last layer: hidden IS the [rows, D] read-out, and its gradient the compact scatter target of the scorer
         self.ro = bool(cfg.readout_only) and cfg.joint_way == "Mformer_hd_graph"
-        if self.shard.sharded and not (self.ro or self.concat or cfg.joint_way == "Mformer_hd_mean"):
+        if self.shard.sharded and not (self.ro or self.concat or self.atten or cfg.joint_way == "Mformer_hd_mean"):
             raise ValueError("row-sharded fusion exchanges a compact [rows, dim] read-out: use readout_only=True with Mformer_hd_graph")
         # compact read-outs hold Ns = shard.n_shard rows (the collectives move equal chunks; rows past Nl stay zero)
-        self.hidden = torch.zeros((Ns, D) if self.ro else (Nl, M, D), device=dev)
-        self.d_hidden = None if (self.ro or self.concat) else torch.empty(Nl, M, D, device=dev)
+        # (atten_weight: ``hidden`` is the [rows, D] attention read-out, ``aw`` its weights / pre-activations for the backward)
+        self.hidden = torch.zeros((Ns, D) if (self.ro or self.atten) else (Nl, M, D), device=dev)
+        self.d_hidden = None if (self.ro or self.concat or self.atten) else torch.empty(Nl, M, D, device=dev)
+        self.aw = torch.empty(max(Nl, 1), 2 * M, device=dev) if self.atten else None
+        self._aw_work = torch.empty(max(1, self.lib.snag_atten_weight_work_floats(D)), device=dev) if self.atten else None
         # concatenation read-outs: joint (or joint_fz) [rows, M*D] straight from the fusion epilogue, its gradient the scatter target
         self.joint = torch.zeros(Ns, M * D, device=dev) if self.concat else None
         self.d_x0 = torch.empty(Nl, M, D, device=dev)
@@ -219,7 +244,7 @@ class MKGCHotPath:
         # compact [rows, D] gradient of the read-out (hd_mean, read-out-only hd_graph): zeroed once here; afterwards whoever READS it
         # in the backward clears it behind itself (snag_fusion_bwd zero_d_hidden / snag_token_mean_bwd zero_src), so the fused
         # scorer of the next step finds it clean without a fill launch
-        self.d_repr = torch.zeros(Ns, self.sdim, device=dev) if (self.ro or self.concat or cfg.joint_way == "Mformer_hd_mean") else None
+        self.d_repr = torch.zeros(Ns, self.sdim, device=dev) if (self.ro or self.concat or self.atten or cfg.joint_way == "Mformer_hd_mean") else None
         self._d_repr_clean = True
         # row-sharded: the table the scorer reads is the all-gather of every rank's read-outs, its gradient is reduce-scattered back
         self.repr_full = torch.zeros(self.shard.n_pad, self.sdim, device=dev) if self.shard.sharded else None
@@ -288,6 +313,26 @@ class MKGCHotPath:
         self._build_descs()
 
     # ------------------------------------------------------------------------------------------
+    def _pool_features(self, cfg, feats):
+        """README POOL=1 (README.md:68,79): each raw table wider than ``pool_dim`` -> [rows, pool_dim] by one adaptive average pool on the
+        device (1-D, or the (H, W) -> (oh, ow) image view ``pool_views`` names for that modality)."""
+        from . import ops
+        out, dims = [], []
+        views = cfg.pool_views or [None] * len(feats)
+        if len(views) != len(feats):
+            raise ValueError("pool_views: one entry (or None) per feature table")
+        for f, fd, view in zip(feats, cfg.feat_dims, views):
+            if f.dtype != f32 or f.dim() != 2 or f.shape[1] != fd:
+                raise ValueError(f"feature table must be fp32 [rows, {fd}], got {tuple(f.shape)} {f.dtype}")
+            if view is not None:
+                H, W, oh, ow = (int(v) for v in view)
+                f = ops.adaptive_avg_pool_rows(f.to(self.dev).contiguous(), (oh, ow), view_hw=(H, W))
+            elif fd > cfg.pool_dim:
+                f = ops.adaptive_avg_pool_rows(f.to(self.dev).contiguous(), int(cfg.pool_dim))
+            out.append(f)
+            dims.append(int(f.shape[1]))
+        return out, dims
+
     def _init_params(self):
         """Reference initialisers: entity table N(0, 1/sqrt(N)) (SNAG_tools.py:85), nn.Linear defaults, LN 1/0, weight_raw 1."""
         cfg = self.cfg
@@ -311,8 +356,10 @@ class MKGCHotPath:
                 self.p[f"proj{i}.l1"].copy_(lin((D, fd)))
                 self.p[f"proj{i}.l2"].copy_(lin((D, D)))
         self.p["weight_raw"].fill_(1.0)
+        if self.atten:          # nn.init.xavier_uniform on the [1, D] parameter (model/EVA_tools.py:197-200): U(+-sqrt(6 / (1 + D)))
+            self.p["atten.a"].copy_((torch.rand(D, generator=g) * 2 - 1) * math.sqrt(6.0 / (1 + D)))
         I = cfg.intermediate_size
-        for l in range(cfg.num_layers):
+        for l in range(self.n_layers):
             self.p[f"layer{l}.wqkv"].copy_(torch.cat([lin((D, D)) for _ in range(3)], 0))
             self.p[f"layer{l}.bqkv"].copy_(torch.cat([bias(D, D) for _ in range(3)], 0))
             self.p[f"layer{l}.wo"].copy_(lin((D, D)))
@@ -326,7 +373,7 @@ class MKGCHotPath:
 
     def _build_descs(self):
         cfg = self.cfg
-        L, ffn = cfg.num_layers, bool(cfg.use_intermediate)
+        L, ffn = self.n_layers, bool(cfg.use_intermediate)
         self._layers = (_lib.FusionLayer * L)()
         self._grads = (_lib.FusionLayerGrad * L)()
         names = ["wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b"] + (["w1", "b1", "w2", "b2", "ln2_g", "ln2_b"] if ffn else [])
@@ -387,7 +434,7 @@ class MKGCHotPath:
         self._set_dropout(self.training)
 
     def _set_dropout(self, on):
-        for l in range(self.cfg.num_layers):
+        for l in range(self.n_layers):
             self._layers[l].keep_probs = ptr(self.keep_probs[l]) if on else None
             self._layers[l].keep_attn_out = ptr(self.keep_attn[l]) if on else None
             self._layers[l].keep_ffn_out = ptr(self.keep_ffn[l]) if (on and self.keep_ffn) else None
@@ -733,11 +780,14 @@ class MKGCHotPath:
                 self._gemm_pair(l2[i], l2[i + 1])
             if len(l2) % 2:
                 call("snag_gemm_f32", ctypes.byref(l2[-1]), st)
-        call("snag_fusion_fwd", ctypes.byref(self._fdesc), st)
+        if self.atten:
+            call("snag_atten_weight_fwd", x0p, Nl, M, D, ptr(self.p["atten.a"]), ptr(self.hidden), D, ptr(self.aw), st)
+        else:
+            call("snag_fusion_fwd", ctypes.byref(self._fdesc), st)
         if cfg.joint_way == "Mformer_hd_mean":
             call("snag_token_mean", ptr(self.hidden), Nl, M, D, ptr(self.repr_mean), st)
             self._repr, self._repr_ld = self.repr_mean.data_ptr(), D
-        elif self.ro:
+        elif self.ro or self.atten:
             self._repr, self._repr_ld = self.hidden.data_ptr(), D
         elif self.concat:
             self._repr, self._repr_ld = self.joint.data_ptr(), MD
@@ -877,7 +927,11 @@ class MKGCHotPath:
             for j in range(nmod):
                 bd.co_dw[j], bd.co_dx[j] = ctypes.pointer(dl2[j]), ctypes.pointer(dmid[j])
             bd.n_co_dw = bd.n_co_dx = nmod
-        call("snag_fusion_bwd", ctypes.byref(bd), st)
+        if self.atten:
+            call("snag_atten_weight_bwd", self.x0.data_ptr(), Nl, M, D, ptr(self.p["atten.a"]), ptr(self.aw), ptr(self.d_repr), D, ptr(self.d_x0),
+                 ptr(self.g["atten.a"]), 0, ptr(self._aw_work), st)
+        else:
+            call("snag_fusion_bwd", ctypes.byref(bd), st)
         self._d_repr_clean = cfg.scorer != "segmented"     # (atomic scorer: its reader cleared it behind itself)
         dx0 = self.d_x0.data_ptr()
         wk = ptr(self.work)
@@ -1116,7 +1170,7 @@ class MKGCHotPath:
             return self.repr_mean
         if self.concat:
             return self.joint
-        return self.hidden if self.ro else self.hidden[:, self.g_slot, :]
+        return self.hidden if (self.ro or self.atten) else self.hidden[:, self.g_slot, :]
 
     def link_prediction(self, h, r, t, filter_mask=None, top_k=(1, 10), method="exact", known_sorted=None):
         """Eval-mode fusion of the whole table, then the rank of each true tail against all entities (Hits@1/10, MR, MRR);
@@ -1142,7 +1196,7 @@ class MKGCHotPath:
         """The Mformer part under the REFERENCE's state_dict keys (``weight_raw``, ``fusion_layer.{l}.attention.self.query.weight`` ...,
         model/SNAG_tools.py:159-298): loads into the reference's ``MformerFusion`` / ``snag_amd.fusion.MformerFusion`` unchanged."""
         D, out = self.cfg.dim, {"weight_raw": self.p["weight_raw"].clone()}
-        for l in range(self.cfg.num_layers):
+        for l in range(self.n_layers):
             pre = f"fusion_layer.{l}."
             for j, nm in enumerate(("query", "key", "value")):
                 out[pre + f"attention.self.{nm}.weight"] = self.p[f"layer{l}.wqkv"][j * D:(j + 1) * D].clone()
@@ -1166,7 +1220,7 @@ class MKGCHotPath:
         D = self.cfg.dim
         with torch.no_grad():
             self.p["weight_raw"].copy_(sd["weight_raw"])
-            for l in range(self.cfg.num_layers):
+            for l in range(self.n_layers):
                 pre = f"fusion_layer.{l}."
                 for j, nm in enumerate(("query", "key", "value")):
                     self.p[f"layer{l}.wqkv"][j * D:(j + 1) * D].copy_(sd[pre + f"attention.self.{nm}.weight"])
@@ -1187,7 +1241,7 @@ class MKGCHotPath:
         for name, buf in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
             views = {k: buf[o:o + math.prod(shp)].view(shp) for k, (o, shp) in self.slices.items()}
             moments[name] = {k: v.clone() for k, v in self._logical(views).items()}
-        return {"cfg": asdict(self.cfg), "params": {k: v.clone() for k, v in self.named_parameters().items()}, **moments,
+        return {"cfg": asdict(self.cfg), "pooled_from": self.pooled_from, "params": {k: v.clone() for k, v in self.named_parameters().items()}, **moments,
                 "tick": self.tick.clone(), "noise_epoch": self.noise_epoch, "noise_active": self.noise_active,
                 "noisy": [x.clone() for x in self.noisy], "ent_noise": self.ent_noise.clone(), "ent_noise_mask": self.ent_noise_mask.clone(),
                 "row_mask": [[m.clone() for m in pair] for pair in self.row_mask]}

@@ -192,7 +192,8 @@ def score_margin_fwd_bwd_seg(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, d
 def score_margin_fwd_bwd_seg_ln(t_pre, gamma, beta, rel, h, r, t, neg_t, margin, grad_scale=1.0, keep=None, keep_p=0.0, eps=1e-12):
     """The segmented hinge scorer on the table ent = LayerNorm(t_pre) (formed here with torch, as the Mformer's read-out rows are by the
     fusion forward), its entity gradient carried through the LayerNorm inside the per-destination pass:
-    -> (loss, pos, neg, dt [N, D], dtm or None, dgamma, dbeta, dcol [D] (column sums of dtm-or-dt), d_rel).
+    -> the 10-tuple (loss, pos, neg, dt [N, D], dtm or None, dgamma, dbeta, dcol [D] (column sums of dtm-or-dt), d_rel, ent [N, D] (the
+    LayerNorm output the scorer gathered)).
     C ABI: snag_score_margin_fwd_bwd_seg_ln (the partial slab is reduced here with torch, in slab order)."""
     _rows(t_pre, "t_pre"), _chk(rel, "rel", ndim=2)
     N, D = t_pre.shape
@@ -426,6 +427,50 @@ def pack_tokens(embs, g_slot=-1, noise=None, noise_mask=None, mask_ratio=0.0, ou
         _chk(noise, "noise", ndim=2), _chk(noise_mask, "noise_mask", dtype=torch.uint8, ndim=1)
     call("snag_pack_tokens", arr, M, N, D, g_slot % M if M else 0, ptr(noise), ptr(noise_mask), float(mask_ratio) * 0.5,
          ptr(out), stream())
+    return out
+
+
+def atten_weight_fwd(x, a, out=None):
+    """README joint_way "atten_weight": x [rows, M, D] tokens, a [D] -> (out [rows, D] = sum_m softmax_m(relu(x_m . a)) x_m, aw [rows, 2 M] = the
+    weights and pre-activations the backward reads).  C ABI: snag_atten_weight_fwd (arithmetic: model/EVA_tools.py:190-232)."""
+    _chk(x, "x", ndim=3), _chk(a, "a", ndim=1)
+    rows, M, D = x.shape
+    if a.shape[0] != D:
+        raise ValueError(f"a has {a.shape[0]} entries, the tokens are {D} wide")
+    if out is None:
+        out = torch.empty(rows, D, device=x.device, dtype=f32)
+    _rows(out, "out")
+    aw = torch.empty(rows, 2 * M, device=x.device, dtype=f32)
+    call("snag_atten_weight_fwd", ptr(x), rows, M, D, ptr(a), ptr(out), out.stride(0), ptr(aw), stream())
+    return out, aw
+
+
+def atten_weight_bwd(x, a, aw, d_out, d_x=None, d_a=None, accumulate_da=False):
+    """-> (d_x [rows, M, D], d_a [D]).  C ABI: snag_atten_weight_bwd."""
+    _chk(x, "x", ndim=3), _chk(a, "a", ndim=1), _chk(aw, "aw", ndim=2), _rows(d_out, "d_out")
+    rows, M, D = x.shape
+    if tuple(aw.shape) != (rows, 2 * M) or tuple(d_out.shape) != (rows, D):
+        raise ValueError(f"aw must be [{rows}, {2 * M}] and d_out [{rows}, {D}], got {tuple(aw.shape)}, {tuple(d_out.shape)}")
+    d_x = torch.empty_like(x) if d_x is None else _chk(d_x, "d_x", ndim=3)
+    d_a = torch.zeros(D, device=x.device, dtype=f32) if d_a is None else _chk(d_a, "d_a", ndim=1)
+    work = torch.empty(max(1, _lib.load().snag_atten_weight_work_floats(D)), device=x.device, dtype=f32)
+    call("snag_atten_weight_bwd", ptr(x), rows, M, D, ptr(a), ptr(aw), ptr(d_out), d_out.stride(0), ptr(d_x), ptr(d_a), int(accumulate_da), ptr(work), stream())
+    return d_x, d_a
+
+
+def adaptive_avg_pool_rows(x, out_hw, view_hw=None, out=None):
+    """README POOL=1 (README.md:68,79): every row of x [N, F], viewed as ``view_hw`` = (H, W) with H W = F (default (1, F): the 1-D pool), is
+    adaptively average-pooled to ``out_hw`` = (oh, ow) -> [N, oh * ow].  C ABI: snag_adaptive_avg_pool_rows."""
+    _rows(x, "x")
+    N, F = x.shape
+    H, W = (1, F) if view_hw is None else (int(view_hw[0]), int(view_hw[1]))
+    oh, ow = (1, int(out_hw)) if isinstance(out_hw, int) else (int(out_hw[0]), int(out_hw[1]))
+    if H * W != F:
+        raise ValueError(f"view {H} x {W} does not cover rows of {F} features")
+    if out is None:
+        out = torch.empty(N, oh * ow, device=x.device, dtype=f32)
+    _rows(out, "out")
+    call("snag_adaptive_avg_pool_rows", ptr(x), N, x.stride(0), H, W, oh, ow, ptr(out), out.stride(0), stream())
     return out
 
 

@@ -24,6 +24,7 @@ Vectors (SURVEY.md par. 8c):
   g14_set_optim.npz  set_optim parameter groups / cosine schedule on the SNAG model (src/utils.py:25-86)
   g12_gcn.npz        GCN structural encoder option (model/Tool_model.py:98-110, model/layers.py:102-130), output and grads
   g8_icl_loss.npz    icl_loss (bidirectional InfoNCE, model/SNAG_loss.py:31-128) + CustomMultiLossLayer, loss and grads
+  g15_atten_weight.npz  EVA_tools.SelfAttention.forward (model/EVA_tools.py:190-232; the in-tree arithmetic of joint_way "atten_weight"), output, weights, grads
 """
 import csv
 import io
@@ -737,10 +738,30 @@ def gen_g13():
     save("g13_data_surface_unsup.npz", d)
 
 
+def gen_g15():
+    """The non-transformer attention read-out: SelfAttention(hidden, batch_first=True) on [N, M, D] tokens, M in {3, 4, 6}, D in {128, 300}."""
+    import warnings
+    from model.EVA_tools import SelfAttention
+    g = torch.Generator().manual_seed(1515)
+    d = {}
+    for tag, (N, M, D) in {"m3_d128": (67, 3, 128), "m4_d300": (33, 4, 300), "m6_d64": (21, 6, 64)}.items():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")          # nn.init.xavier_uniform / implicit softmax dim are deprecated spellings
+            att = SelfAttention(D, batch_first=True)
+            att.att_weights.data = torch.randn(1, D, generator=g) * 0.3
+            x = (torch.randn(N, M, D, generator=g)).requires_grad_(True)
+            cw = torch.randn(N, D, generator=g)
+            rep, w = att(x)
+        (rep * cw).sum().backward()
+        d.update({f"{tag}.x": x, f"{tag}.a": att.att_weights.data[0], f"{tag}.cw": cw, f"{tag}.rep": rep, f"{tag}.w": w,
+                  f"{tag}.g.x": x.grad, f"{tag}.g.a": att.att_weights.grad[0]})
+    save("g15_atten_weight.npz", d)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # regenerate selected vectors only: gen_golden.py g11 g8 ...
         for name in sys.argv[1:]:
             globals()["gen_" + name]()
         sys.exit(0)
-    for fn in (gen_g1, gen_g2, gen_g3, gen_g4_g5, gen_g6, gen_g7, gen_g8, gen_g9, gen_g10, gen_g11, gen_g12, gen_g13, gen_g14):
+    for fn in (gen_g1, gen_g2, gen_g3, gen_g4_g5, gen_g6, gen_g7, gen_g8, gen_g9, gen_g10, gen_g11, gen_g12, gen_g13, gen_g14, gen_g15):
         fn()                        # "regenerate all" means ALL: G11-G14 included

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _declared():
         assert hasattr(lib, name), f"{name} declared in include/snag_hip.h but not exported"
-    assert lib.snag_version() == 1
+    assert lib.snag_version() == _lib.ABI_VERSION == 2
     # every declared entry point has a ctypes signature on the Python side
     bound = set(_lib.SIGNATURES) | set(_lib._SPECIAL)
     assert set(_declared()) == bound, sorted(set(_declared()) ^ bound)
@@ -159,7 +159,7 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
     src.write_text(
         '#include "snag_hip.h"\n#include <stdio.h>\n#include <string.h>\n'
         "int main(void) {\n"
-        "    if (snag_version() != 1) return 2;\n"
+        "    if (snag_version() != SNAG_ABI_VERSION) return 2;\n"
         "    int rc = snag_score_margin_fwd(0, 128, 10, 0, 2, 128, 0, 0, 0, 0, 4, 8, 4, 1.0f, 0, 0, 0, 0);\n"
         "    if (rc != SNAG_ERR_ARG || strlen(snag_last_error()) == 0) return 3;\n"
         "    snag_gemm_desc d; memset(&d, 0, sizeof d); d.M = -1;\n"
@@ -198,3 +198,13 @@ def test_ticket_words_constant_matches_header():
     from snag_amd import _lib
     text = open(os.path.join(ROOT, "include", "snag_hip.h")).read()
     assert int(re.search(r"#define\s+SNAG_SCORE_TICKET_WORDS\s+(\d+)", text).group(1)) == _lib.SCORE_TICKET_WORDS
+
+
+def test_a_library_of_another_abi_version_is_refused(monkeypatch):
+    """a stale or variant .so (SNAG_HIP_LIB) must not be read with this binding's struct offsets."""
+    from snag_amd import _lib
+    _lib.load()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", 99)
+    with pytest.raises(_lib.SnagHipError, match="ABI version"):
+        _lib.load()

@@ -22,7 +22,7 @@ def oracle_params(eng, dtype=torch.float32):
         else:
             proj.append({"l1": p[f"proj{i}.l1"], "l2": p[f"proj{i}.l2"]})
     fp = {"weight_raw": p["weight_raw"]}
-    for l in range(cfg.num_layers):
+    for l in range(eng.n_layers):             # (atten_weight: the Mformer is not run and owns no parameters)
         pre = f"fusion_layer.{l}."
         wqkv, bqkv = p[f"layer{l}.wqkv"], p[f"layer{l}.bqkv"]
         for j, nm in enumerate(("query", "key", "value")):
@@ -67,6 +67,11 @@ def oracle_params(eng, dtype=torch.float32):
     # two Mformer layers (num_hidden_layers = 2), with and without the FFN: shape tuple carries an 8th entry = layer count
     (2, "Mformer_hd_graph", 1, True, torch.int32, (400, 7, 64, 48, 8, 40, 24, 2)),
     (1, "Mformer_hd_mean", 0, False, torch.int32, (400, 7, 64, 48, 8, 40, 24, 2)),
+    # README joint_way "atten_weight": non-transformer attention over the tokens (oracle pinned to EVA_tools.SelfAttention by golden G15)
+    (2, "atten_weight", 0, True, torch.int32, (700, 23, 128, 96, 32, 200, 72)),
+    (1, "atten_weight", 0, False, torch.int64, (333, 3, 36, 17, 3, 13, 9)),
+    (2, "atten_weight", 0, True, torch.int32, (5, 1, 128, 1, 1, 9, 4)),
+    (2, "atten_weight", 0, True, torch.int32, (15000, 558, 128, 1024, 32, 4096, 768)),
 ])
 def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape, loss_kind):
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
@@ -86,6 +91,8 @@ def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape, loss_k
     # make the entity table and relations O(1) so scores are not degenerate
     eng.p["ent"].copy_(torch.randn(N, D, generator=g).to(DEV))
     eng.p["weight_raw"].copy_(torch.randn(6, generator=g).to(DEV))
+    if joint_way == "atten_weight":               # pre-activations of both signs and O(1) size: the relu gate and the softmax both matter
+        eng.p["atten.a"].copy_((torch.randn(D, generator=g) * (2.0 / D ** 0.5)).to(DEV))
     if noise:
         eng.update_noise()
     h = torch.randint(0, N, (B,), generator=g).to(idt)
@@ -103,7 +110,7 @@ def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape, loss_k
         ofeats, proj, p["ent"], fp, p["rel"], h, r, t, neg, num_heads=cfg.num_heads, margin=cfg.margin, joint_way=joint_way,
         use_intermediate=bool(ffn), num_layers=cfg.num_layers,
         ent_noise=eng.ent_noise.cpu() if noise else None, ent_noise_mask=eng.ent_noise_mask.cpu().bool() if noise else None,
-        mask_ratio=cfg.mask_ratio, loss_kind=loss_kind, adv_temp=cfg.adv_temp)
+        mask_ratio=cfg.mask_ratio, loss_kind=loss_kind, adv_temp=cfg.adv_temp, atten_a=p.get("atten.a"))
     oloss.backward()
     assert_close(pos, opos, atol=1e-4, what="pos")                      # north_star: scores within 1e-4
     assert_close(ng, oneg, atol=1e-4, what="neg")
@@ -437,6 +444,34 @@ def test_mkgc_hits_at_k_equal_oracle():
         ref_hits = round(float((oref < k).float().mean()), 4)
         assert abs(hk - ref_hits) <= float((near > 0).float().mean()) + 1e-9, (k, hk, ref_hits)
     assert res["hits"][1] > 0.2          # training on these triples must have made them rank well
+
+
+def test_mkgc_hits_at_k_equal_oracle_full_size():
+    """The metric's second half at the headline size (BASELINE configs[1]: |E| = 15,000, 4096 + 768-wide features, dim 128): after real
+    training steps, ``eng.link_prediction`` (filtered, all 15,000 candidates) against the oracle's mkgc_forward -> count-less-than in float64
+    on the same parameters -- the very routine bench.py puts into the driver-run line as ``hits_parity``.  Every rank that differs must be a
+    proven near-tie (a candidate within 5e-6 of the true tail's float64 score); Hits@1/10 may differ only through those queries."""
+    import bench
+    from snag_amd import ops
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    cfg = MKGCConfig()                              # DB15K-shaped defaults: exactly what bench.py times
+    feats, batches, known = bench.synth(cfg, 1024, 4, cfg.seed, DEV)
+    eng = MKGCHotPath(cfg, feats, device=DEV)
+    neg = torch.empty(1024, cfg.neg_num, device=DEV, dtype=torch.int32)
+    eng.update_noise()
+    for i in range(12):
+        h, r, t = batches[i % 4]
+        eng.forward(h, r, t, neg, with_backward=True, sample=(7, known))
+        eng.backward()
+        eng.optimizer_step()
+    rep = bench.hits_parity(eng, [f.cpu() for f in eng.feats], known, DEV)
+    print("hits_parity:", rep)
+    assert rep["n"] == 512 and rep["n_unexplained"] == 0, rep
+    assert rep["max_abs_score_err_vs_f64"] < 1e-4, rep                                   # north_star: scores within 1e-4
+    for k in ("hits1", "hits10"):
+        assert abs(rep[k + "_gpu"] - rep[k + "_oracle"]) <= rep["n_hits_affecting_diffs"] / rep["n"] + 0.5e-4, rep
+    assert 0.0 < rep["hits1_oracle"] < 0.5 and 0.1 < rep["hits10_oracle"] < 1.0, rep     # the planted half makes both informative
+    assert rep["n_rank_diffs"] <= 32, rep                                                # near-ties are rare: a handful of 512 queries at most
 
 
 @pytest.mark.parametrize("num_proj", [1, 2])

@@ -226,14 +226,42 @@ def test_mkgc_forward_passes_the_keep_masks_through():
     keep = [(torch.rand(N, D, generator=g) > 0.2).float() for _ in range(2)]
     h, r, t = torch.randint(0, N, (B,), generator=g), torch.randint(0, 3, (B,), generator=g), torch.randint(0, N, (B,), generator=g)
     neg = torch.randint(0, N, (B, K), generator=g)
+    a = torch.randn(D, generator=g) * 0.3
     for jw in O.JOINT_WAYS:
-        rl = rel if jw.startswith("Mformer_hd") else torch.randn(3, M * D, generator=g)
+        rl = rel if (jw.startswith("Mformer_hd") or jw == "atten_weight") else torch.randn(3, M * D, generator=g)
         loss, pos, ng, rep = O.mkgc_forward(feats, proj, ent, fp, rl, h, r, t, neg, num_heads=H, margin=4.0, joint_way=jw, drop_masks=masks, drop_p=0.1,
-                                            proj_keep=keep, proj_p=0.2)
+                                            proj_keep=keep, proj_p=0.2, atten_a=a)
         toks = [O.projection_head(f, p["l1"], p["l2"], keep_mask=k, p=0.2) for f, p, k in zip(feats, proj, keep)] + [ent]
         joint, joint_fz, hidden, _ = O.fusion_forward(toks, fp, H, 1, False, drop_masks=masks, drop_p=0.1)
-        want = O.readout(jw, joint, joint_fz, hidden, graph_index=M - 1)
+        want = O.atten_weight_readout(torch.stack(toks, 1), a) if jw == "atten_weight" else O.readout(jw, joint, joint_fz, hidden, graph_index=M - 1)
         l2, p2, n2 = O.score_margin(want, rl, h, r, t, neg, 4.0)
         assert torch.equal(rep, want) and torch.equal(loss, l2) and torch.equal(pos, p2) and torch.equal(ng, n2)
         # and the masks matter: without them the read-out differs
-        assert not torch.equal(O.mkgc_forward(feats, proj, ent, fp, rl, h, r, t, neg, num_heads=H, margin=4.0, joint_way=jw)[3], want)
+        assert not torch.equal(O.mkgc_forward(feats, proj, ent, fp, rl, h, r, t, neg, num_heads=H, margin=4.0, joint_way=jw, atten_a=a)[3], want)
+
+
+@pytest.mark.parametrize("tag", ["m3_d128", "m4_d300", "m6_d64"])
+def test_atten_weight_readout(tag):
+    """G15: joint_way "atten_weight" -- the oracle's restatement against EVA_tools.SelfAttention.forward run from the reference tree
+    (model/EVA_tools.py:190-232): representation and, through autograd, both gradients."""
+    z = load("g15_atten_weight.npz")
+    x, a = T(z[f"{tag}.x"]).requires_grad_(True), T(z[f"{tag}.a"]).requires_grad_(True)
+    rep = O.atten_weight_readout(x, a)
+    assert_close(rep, z[f"{tag}.rep"], atol=1e-5, rtol=1e-5, what="rep")          # (pre-activations of size ~10 go through exp: fp32 noise of the dot product x e^s)
+    (rep * T(z[f"{tag}.cw"])).sum().backward()
+    assert_close(x.grad, z[f"{tag}.g.x"], atol=2e-5, rtol=1e-4, what="g.x")
+    assert_close(a.grad, z[f"{tag}.g.a"], atol=2e-4, rtol=1e-4, what="g.a")
+
+
+def test_adaptive_avg_pool_rows_windows():
+    """README POOL=1: the oracle's pool is torch's adaptive windows; restated here by hand for the 1-D case and a 2-D view."""
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(5, 770, generator=g)
+    P = 256
+    got = O.adaptive_avg_pool_rows(x, P)
+    for i in (0, 1, 100, 255):
+        lo, hi = (i * 770) // P, -(-((i + 1) * 770) // P)
+        assert_close(got[:, i], x[:, lo:hi].mean(dim=1), atol=1e-6, what=f"window {i}")
+    y = torch.randn(3, 12 * 64, generator=g)
+    got2 = O.adaptive_avg_pool_rows(y, (4, 64), view_hw=(12, 64))
+    assert_close(got2, y.view(3, 4, 3, 64).mean(dim=2).reshape(3, 256), atol=1e-6, what="12x64 -> 4x64")

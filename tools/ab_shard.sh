@@ -1,7 +1,7 @@
 #!/bin/bash
 # one rank's share of an R-way row-sharded step under several libraries: tools/ab_shard.sh "R..." NAME...   ("base" = in-tree)
 cd /tmp && export TMPDIR=/tmp
-cd "$GRAFT_REPO_ROOT"
+cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT to the repository root (gpurun exports it)}"
 RS=$1; shift
 for R in $RS; do
   for v in "$@"; do

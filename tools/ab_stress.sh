@@ -1,7 +1,7 @@
 #!/bin/bash
 # configs[4] scorer kernels under several libraries: tools/ab_stress.sh NAME...   ("base" = in-tree); prints the touched_* kernel averages, uniform and Zipf
 cd /tmp && export TMPDIR=/tmp
-cd "$GRAFT_REPO_ROOT"
+cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT to the repository root (gpurun exports it)}"
 for v in "$@"; do
   if [ "$v" = base ]; then unset SNAG_HIP_LIB; else export SNAG_HIP_LIB=$PWD/snag_amd/variants/libsnag_hip_$v.so; fi
   for dist in uniform zipf; do

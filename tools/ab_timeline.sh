@@ -2,7 +2,7 @@
 # rocprofv3 step timelines of several variant libraries, one after the other on one box: tools/ab_timeline.sh NAME... ("base" = the in-tree library)
 # prints the step total and the lines of the kernels matching $AB_GREP (default: the 256-row grouped GEMM launches)
 cd /tmp && export TMPDIR=/tmp
-cd "$GRAFT_REPO_ROOT"
+cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT to the repository root (gpurun exports it)}"
 PAT=${AB_GREP:-"gemm_tile_group_kernel<256"}
 for v in "$@"; do
   if [ "$v" = base ]; then unset SNAG_HIP_LIB; else export SNAG_HIP_LIB=$PWD/snag_amd/variants/libsnag_hip_$v.so; fi

@@ -3,7 +3,7 @@
 #   tools/build_variant.sh ablate -DSNAG_GEMM_ABLATE=1 ; tools/gpu.sh 'bash tools/ablate_timeline.sh 0 8 16 24 3 56'
 # bits: 1 no A traffic, 2 no B traffic (k-tiles >= 2 read zeros), 4 no barrier, 8 no MFMAs, 16 no split / image write, 32 no fetch, 64 no B split (ping-pong loop)
 cd /tmp && export TMPDIR=/tmp
-cd "$GRAFT_REPO_ROOT"
+cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT to the repository root (gpurun exports it)}"
 export SNAG_HIP_LIB=$PWD/snag_amd/variants/libsnag_hip_ablate.so
 PAT=${AB_GREP:-"gemm_tile"}
 for m in "$@"; do

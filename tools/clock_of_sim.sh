@@ -1,7 +1,7 @@
 #!/bin/bash
 # shader clock held during the similarity GEMM (configs[3]): GRBM_GUI_ACTIVE (cycles, per XCD) / kernel duration, same rocprofv3 run
 cd /tmp && export TMPDIR=/tmp
-cd "$GRAFT_REPO_ROOT"
+cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT to the repository root (gpurun exports it)}"
 O=gpurun_out/clk_sim; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/t -- python3 tools/probe_eval.py > $O/log 2>&1
 python3 - <<'PY'

@@ -5,7 +5,7 @@
 #   tools/collect_gemm_pmc.sh tools/probe_eval.py the similarity GEMM of configs[3] (10,500 x 10,500 x 1,200)
 set -u
 cd /tmp && export TMPDIR=/tmp
-cd "$GRAFT_REPO_ROOT"
+cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT to the repository root (gpurun exports it)}"
 O=gpurun_out/gemm_pmc
 rm -rf $O && mkdir -p $O
 if [ $# -ge 1 ]; then CMD="$*"; else CMD="tools/one_shape.py 4096 15000 128"; fi

@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh <tag> [pmc]     (without "pmc": kernel trace only)
 set -u
 cd /tmp && export TMPDIR=/tmp
-cd "$GRAFT_REPO_ROOT"
+cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT to the repository root (gpurun exports it)}"
 TAG=${1:-r02}
 O=gpurun_out/$TAG
 rm -rf $O && mkdir -p $O

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel stats of bench.py --config stress (uniform and Zipf): tools/prof_stress.sh <tag>
 cd /tmp && export TMPDIR=/tmp
-cd "$GRAFT_REPO_ROOT"
+cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT to the repository root (gpurun exports it)}"
 TAG=${1:-r03_stress}
 for dist in uniform zipf; do
   O=gpurun_out/${TAG}_$dist
