@@ -298,25 +298,33 @@ def score_hbm_resident(device):
             by = B * ((K + 3) * D * esz + (K + 3) * 4 + (K + 1) * 4)
             out[f"{dt}_B{B}"] = {"avg_us": us, "achieved": by / us / 1e3, "unit": "GB/s", "frac": by / us / 1e3 / HBM_PEAK_GBS, "triples_per_s": B / us * 1e6}
     # the TRAINING form on the same table (bf16 rows, fp32 gradient rows): forward bytes + read-modify-write of the (K + 3) gradient rows per
-    # triple (SURVEY par. 8d) over the time of the entry's launches (segmented form over the batch's entries: no float atomics)
-    from snag_amd import ops
+    # triple (SURVEY par. 8d) over the time of the entry's launches (segmented form over the batch's entries: no float atomics).  The entry is
+    # called straight through the C ABI over preallocated buffers, as the stress engine calls it: the Python wrapper's per-call allocations are
+    # host time, and at B = 1,024 they, not the device, paced a back-to-back loop
+    from snag_amd import _lib
     e16, r16 = tables["bf16"][0], tables["bf16"][1]
     d_ent, d_rel = torch.zeros(N, D, device=device), torch.zeros(R, D, device=device)
     for B in (1024, 8192):
         idx = [torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(device) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (N, (B, K)))]
-        run = lambda: ops.score_margin_fwd_bwd_touched(e16, r16, *idx, 12.0, d_ent=d_ent, d_rel=d_rel)
+        pos, ng, lp, loss = torch.empty(B, device=device), torch.empty(B, K, device=device), torch.empty(B, device=device), torch.empty((), device=device)
+        nb = _lib.load().snag_score_touched_work_bytes(N, R, B, K, D)
+        work = torch.zeros((nb + 255) // 256 * 256, device=device, dtype=torch.uint8)
+        run = lambda: call("snag_score_margin_fwd_bwd_touched_bf16", ptr(e16), D, N, ptr(r16), R, D, ptr(idx[0]), ptr(idx[1]), ptr(idx[2]), ptr(idx[3]), 4, B, K, 12.0, 1.0,
+                           ptr(pos), ptr(ng), ptr(lp), ptr(loss), ptr(d_ent), D, ptr(d_rel), ptr(work), work.numel(), stream())
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10):
+        for _ in range(20):
             run()
         e1.record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / 10
+        us = e0.elapsed_time(e1) * 1e3 / 20
         by = B * ((K + 3) * D * 2 + (K + 3) * 4 + (K + 1) * 4) + B * (K + 3) * D * 4 * 2
-        out[f"train_bf16_B{B}"] = {"entry": "snag_score_margin_fwd_bwd_touched_bf16", "avg_us": us, "achieved": by / us / 1e3, "unit": "GB/s",
+        out[f"train_bf16_B{B}"] = {"entry": "snag_score_margin_fwd_bwd_touched_bf16 (pass A writes the single-entry gradient rows itself; pass B one lane per record + the "
+                                            "relation role; hot-row launch)", "avg_us": us, "achieved": by / us / 1e3, "unit": "GB/s",
                                    "frac": by / us / 1e3 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": by, "triples_per_s": B / us * 1e6}
+        del work
     return out
 
 

@@ -144,9 +144,11 @@ SNAG_API int snag_score_margin_fwd_bwd_seg_ln(const float* ent, int64_t n_ent, c
                           void* work, int64_t work_bytes, const snag_ln_bwd_tail* tail, void* stream);
 
 /* The segmented form for tables far LARGER than a batch's footprint (BASELINE configs[4]: 1M entities, 134k entries per batch): pass A
- * additionally appends every destination to a compact list when it receives its FIRST entry (the slot atomic returns 0), and pass B
- * walks that list -- at most batch * (n_neg + 3) destinations -- instead of all n_ent + n_rel counters.  Only touched rows of d_ent /
- * d_rel are written (overwritten, not accumulated into): the caller keeps the rest of the buffers zero.  Hot rows of skewed index
+ * writes one record per entry and -- for a negative tail, whose row and query it holds in registers -- the destination's gradient row as if
+ * that entry were its only one (round 5); pass B walks the records, at most batch * (n_neg + 3) of them, one LANE each, instead of all
+ * n_ent + n_rel counters, and redoes only the destinations that received more.  Only touched rows of d_ent are written (overwritten, not
+ * accumulated into): the caller keeps the rest of that buffer zero.  EVERY row of d_rel is written (zeros where no triple of the batch names
+ * the relation): the caller does not clear it.  Hot rows of skewed index
  * distributions: entries beyond a destination's 16 inline slots go to an open-addressed hash of 64-entry chunks keyed (dest, chunk)
  * (wait-free insertion, one home per entry) and are summed in 64-bit fixed point -- bit-reproducible whatever the arrival order.
  * Same scores / losses / gradients as snag_score_margin_fwd_bwd_seg.  _bf16: tables of raw bfloat16 bit patterns (8-byte aligned rows),

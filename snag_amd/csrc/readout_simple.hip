@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void atten_weight_fwd_kernel(const float* __re
                 dot[m] = fmaf(v.w, av.w, dot[m]);
             }
         }
-        float w[M], mx = 0.f;          // relu: every score >= 0, so 0 is a valid running maximum start only if some score is; take the true max
+        float w[M], mx = 0.f;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             dot[m] = sum16(dot[m]);
@@ -212,10 +212,10 @@ extern "C" SNAG_API int64_t snag_atten_weight_work_floats(int D) { return (int64
 
 extern "C" SNAG_API int snag_atten_weight_fwd(const float* x, int64_t rows, int M, int D, const float* a, float* out, int64_t ld_out, float* aw,
                                               void* stream) {
-    SNAG_REQUIRE(x && a && out && aw, SNAG_ERR_ARG, "atten_weight_fwd: null pointer");
     SNAG_REQUIRE(rows >= 0 && ld_out >= D, SNAG_ERR_ARG, "atten_weight_fwd: bad sizes");
     SNAG_REQUIRE(M >= 1 && M <= 6 && D >= 4 && D <= 512 && D % 4 == 0, SNAG_ERR_UNSUPPORTED, "atten_weight_fwd: 1 <= M <= 6 tokens of 4 | D <= 512 (got M=%d D=%d)", M, D);
-    if (rows == 0) return SNAG_OK;
+    if (rows == 0) return SNAG_OK;          // (an empty tensor's data pointer is null)
+    SNAG_REQUIRE(x && a && out && aw, SNAG_ERR_ARG, "atten_weight_fwd: null pointer");
     const dim3 grid(grid_rows16(rows, 1 << 16)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define SNAG_AW_FWD(MM) case MM: hipLaunchKernelGGL(atten_weight_fwd_kernel<MM>, grid, block, 0, st, x, rows, D, a, out, ld_out, aw); break;
@@ -226,14 +226,15 @@ extern "C" SNAG_API int snag_atten_weight_fwd(const float* x, int64_t rows, int 
 
 extern "C" SNAG_API int snag_atten_weight_bwd(const float* x, int64_t rows, int M, int D, const float* a, const float* aw, const float* d_out,
                                               int64_t ld_dout, float* d_x, float* d_a, int accumulate_da, float* work, void* stream) {
-    SNAG_REQUIRE(x && a && aw && d_out && d_x && d_a && work, SNAG_ERR_ARG, "atten_weight_bwd: null pointer");
     SNAG_REQUIRE(rows >= 0 && ld_dout >= D, SNAG_ERR_ARG, "atten_weight_bwd: bad sizes");
     SNAG_REQUIRE(M >= 1 && M <= 6 && D >= 4 && D <= 512 && D % 4 == 0, SNAG_ERR_UNSUPPORTED, "atten_weight_bwd: 1 <= M <= 6 tokens of 4 | D <= 512 (got M=%d D=%d)", M, D);
+    SNAG_REQUIRE(d_a != nullptr, SNAG_ERR_ARG, "atten_weight_bwd: null d_a");
     hipStream_t st = (hipStream_t)stream;
-    if (rows == 0) {
+    if (rows == 0) {          // (an empty tensor's data pointer is null) no entity: d a = 0
         if (!accumulate_da) (void)hipMemsetAsync(d_a, 0, sizeof(float) * D, st);
         return check_launch("snag_atten_weight_bwd");
     }
+    SNAG_REQUIRE(x && a && aw && d_out && d_x && work, SNAG_ERR_ARG, "atten_weight_bwd: null pointer");
     const int nb = grid_rows16(rows, kAttenBlocks);
     const dim3 grid(nb), block(256);
 #define SNAG_AW_BWD(MM)                                                                                                                      \

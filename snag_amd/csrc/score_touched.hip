@@ -11,12 +11,23 @@
 //            of skewed index distributions) to an open-addressed hash of 64-entry chunks keyed (dest, chunk): wait-free insertion (one
 //            compare-and-swap per probe), every entry has exactly one home.
 //   pass B'  one 16-lane group per hash slot: the chunk's <= 64 rows summed in 64-bit fixed point into the slot's partial row.
-//   pass B   one 16-lane group per RECORD.  The record whose slot is 0 owns its destination: with one entry (nearly every destination of
-//            a uniformly drawn batch) it has all it needs in hand -- two dependent round trips: the record, then {counter, own table
-//            row, the entry's row} --, with up to 16 it adds the bucket in a canonical order (sorted fp32); hot rows are handed to
-//            pass C.  Records with other slots leave at once.  The per-part losses are summed here too (fixed order).
+//            A negative tail's 16-lane group has the tail's row AND q_b in registers when it scores it, i.e. everything the gradient row of a
+//            destination with ONE entry is made of: it writes that row -- normalize_bwd(x, w q_b), statement for statement pass B's
+//            single-entry arithmetic -- straight into d_ent (round 5).  Nearly every destination of a uniformly drawn batch has one entry,
+//            so pass B no longer re-reads the 69 MB of table rows pass A just gathered, nor the q rows, nor writes 137 MB; where more
+//            entries arrive the rows written here are provisional (several writers race, harmlessly) and pass B overwrites them.
+//   pass B   one 16-lane group per RECORD.  The record whose slot is 0 owns its destination: with one entry that pass A has written
+//            (flag in the record) it only resets the counter -- two dependent round trips: the record, then the counter --; otherwise a third
+//            one fetches {own table row, the entry's row, the bucket} and with up to 16 entries it adds them in a canonical order (sorted
+//            fp32); hot rows are handed to pass C.  Records with other slots leave at once.  The per-part losses are summed here too.
+//   relations (round 5): a 1,024-triple batch sends 4 x 1,024 entries to ~1,000 relation rows -- every one of them a multi-entry destination and
+//            a few of them "hot" (> 16 entries): on uniform entity indices the hot-row launch existed for four relations (16 us of dependent
+//            round trips).  While n_rel x batch is small the relation rows take no part in the records at all: one 16-lane group per relation
+//            (a role of pass B's launch) scans the batch's relation ids, finds its triples in batch order and sums their dq rows -- the order
+//            and the arithmetic (sorted fp32 up to 16 entries, fixed point beyond) of the generic path, so the same bits -- and writes EVERY
+//            relation's row (zeros where no triple names it: the caller no longer clears d_rel).
 //   pass C   one 16-lane group per hot row: bucket + chunk partials in fixed point (order-free), normalisation backward, store.
-// Only touched rows of d_ent / d_rel are written; the caller keeps the rest zero.
+// Only touched rows of d_ent are written (the caller keeps the rest zero); every row of d_rel is.
 #include <algorithm>
 
 #include "seg_rows.hip.h"
@@ -27,10 +38,17 @@ namespace snag {
 #define SNAG_TA_WAVES 2                  // (waves per SIMD pass A is compiled for: 2 = up to 256 registers, no spills: 46 -> 38 us against 3)
 #endif
 #ifndef SNAG_TB_WAVES
-#define SNAG_TB_WAVES 4
+#define SNAG_TB_WAVES 3                  // (162 registers with four rows per gather step: the launch is a handful of dependent round trips per wave, not occupancy-bound)
 #endif
 #ifndef SNAG_HUB_GRID
 #define SNAG_HUB_GRID 512
+#endif
+#ifndef SNAG_T_WT
+#define SNAG_T_WT 1                      // gradient rows as write-through (sc1) stores: see st_row4_wt
+#endif
+#ifndef SNAG_T_ABLATE
+#define SNAG_T_ABLATE 0                  // timing experiments (wrong results): 1 no hot-row launch, 2 no pass B launch, 4 pass A stores no gradient rows, 8 pass B resets no counters,
+                                         // 16 pass B does no arithmetic, 32 no relation role, 64 no chunk-sum role
 #endif
 constexpr int kTCap = 16;                   // inline slots per destination (slot 0 is the owner's own record)
 constexpr int kTChunk = 64;                 // entries per hash chunk
@@ -45,8 +63,9 @@ struct TouchedHeader {                      // first 64 bytes of the workspace (
 struct TouchedRec {                         // one entry in triple order: weight * rows[src] goes to destination dest; slot = arrival number there
     int dest, src;
     float w;
-    unsigned slot;
+    unsigned slot;                          // | kRecWritten: pass A has written the destination's gradient row as if this were its only entry
 };
+constexpr unsigned kRecWritten = 0x80000000u;
 struct TouchedHub {
     int dest;
     unsigned rec;                           // index of the owner's record (the entry in slot 0)
@@ -67,6 +86,7 @@ struct TouchedWork {
     unsigned hmask, max_hubs;
     int parts, per;                         // waves per triple, negatives per part
     int64_t n_rec;                          // batch * parts * (per + 3)
+    int rel_role;                           // the relation rows are summed by pass B's relation role: pass A emits no relation entries
 };
 
 static size_t t_align(size_t x) { return (x + 255) / 256 * 256; }
@@ -140,8 +160,9 @@ __device__ __forceinline__ unsigned touched_find(const unsigned long long* __res
 }
 
 // the entry's record, and its home: bucket slot 1..15 or a hash chunk (slot 0 lives in the record alone)
-__device__ __forceinline__ void touched_emit(const TouchedWork& w, unsigned which, int64_t rec_idx, int dest, unsigned slot, int src, float weight) {
-    w.rec[rec_idx] = TouchedRec{dest, src, weight, slot};
+__device__ __forceinline__ void touched_emit(const TouchedWork& w, unsigned which, int64_t rec_idx, int dest, unsigned slot, int src, float weight,
+                                             unsigned flags = 0u) {
+    w.rec[rec_idx] = TouchedRec{dest, src, weight, slot | flags};
     if (slot == 0u) return;
     if (slot < (unsigned)kTCap) {
         w.list[(int64_t)dest * kTCap + slot] = SegEntry{src, weight};
@@ -165,7 +186,8 @@ template <typename IdxT, int NV, typename TabT, int kAgg>
 __global__ __launch_bounds__(256, SNAG_TA_WAVES) void touched_a_kernel(
     const TabT* __restrict__ ent, int64_t eld, const TabT* __restrict__ rel, int dim, int n_ent,
     const IdxT* __restrict__ h, const IdxT* __restrict__ r, const IdxT* __restrict__ t, const IdxT* __restrict__ neg_t,
-    int64_t batch, int n_neg_all, float margin, float gscale, float* __restrict__ pos, float* __restrict__ neg, TouchedWork w) {
+    int64_t batch, int n_neg_all, float margin, float gscale, float* __restrict__ pos, float* __restrict__ neg, TouchedWork w,
+    float* __restrict__ d_ent, int64_t dld) {
     const int wave = wave_id_uniform();
     const int lane = threadIdx.x & 63;
     const int sub = lane & 15, grp = lane >> 4;
@@ -207,7 +229,8 @@ __global__ __launch_bounds__(256, SNAG_TA_WAVES) void touched_a_kernel(
     const int dest3 = lane == 0 ? (int)ti : (lane == 1 ? (int)hi : n_ent + (int)ri);
     unsigned local3 = 0u;
     int aslot3 = 0;
-    if (live && lane < 3) agg_insert(dest3, local3, aslot3);
+    const int n3 = w.rel_role ? 2 : 3;                             // (relation role: the relation's entry is a void record)
+    if (live && lane < n3) agg_insert(dest3, local3, aslot3);
     constexpr int kMaxBlocks = 4;                                   // id blocks of 64 negatives per part held in registers (per <= 256)
     unsigned nlocal[kMaxBlocks];
     int naslot[kMaxBlocks];
@@ -223,7 +246,8 @@ __global__ __launch_bounds__(256, SNAG_TA_WAVES) void touched_a_kernel(
     // RB rounds x 4 rows gathered before the first is used (wide rows: 4 rounds -- 64 fewer registers, three waves per SIMD instead of two;
     // a group meets its negatives in the same order either way, so the sums are the same bits).  (Issuing the first batch next to the
     // head / relation / tail rows, before any arithmetic, was tried: 241 registers, or 168 with spills -- 78 us instead of 43.)
-    constexpr int RB = NV >= 3 ? 4 : 8;
+    constexpr int RB = NV >= 3 ? 4 : 8;       // (round 5, with the row stores in the loop: 2 or 8 rounds, or the next batch requested before the current one
+                                              //  is scored -- register double-buffered --, all measured slower: 54.9 / 60.9 / 52.4-85.2 us against 46.2)
     Row4<NV> q = ld_row4<NV>(ent, hi, eld, dim, sub);
     const Row4<NV> rr = ld_row4<NV>(rel, ri, dim, dim, sub);
     Row4<NV> tt = ld_row4<NV>(ent, ti, eld, dim, sub);
@@ -250,30 +274,40 @@ __global__ __launch_bounds__(256, SNAG_TA_WAVES) void touched_a_kernel(
     s_pos = sum16(s_pos);
     if (live && lane == 0 && part == 0) pos[b] = s_pos;
     float c_pos = 0.f;
+    // the reserved runs have arrived by now -- their round trip went out in front of the head / relation / tail gather the arithmetic above
+    // waited for: the workgroup meets here, and every negative then knows its slot BEFORE its row is scored (slot 0 writes the row)
+    __syncthreads();
     for (int k0 = 0; k0 < w.per; k0 += 64) {
         const int cnt = max(0, min(64, n_neg - k0));
         const int my = (lane < cnt) ? (int)nrow[k0 + lane] : 0;
         float my_s = 0.f;                               // lane k: score of negative k0 + k
-        for (int it0 = 0; it0 < cnt; it0 += 4 * RB) {
-            Row4<NV> x[RB];
+        const int qb = k0 >> 6;
+        const unsigned nl = qb == 0 ? nlocal[0] : (qb == 1 ? nlocal[1] : (qb == 2 ? nlocal[2] : nlocal[3]));
+        const int na = qb == 0 ? naslot[0] : (qb == 1 ? naslot[1] : (qb == 2 ? naslot[2] : naslot[3]));
+        const unsigned my_slot = (lane < cnt) ? agg_base[na] + nl : 1u;      // lane k: arrival number of negative k0 + k at its destination
+        auto issue = [&](int it0, Row4<NV> (&x)[RB]) {
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
-                const int k = it0 + 4 * u + grp;
-                const int idx = __shfl(my, k & 63);
-                x[u] = ld_row4<NV>(ent, (k < cnt) ? idx : 0, eld, dim, sub);
-            }
+                    const int k = it0 + 4 * u + grp;
+                    const int idx = __shfl(my, k & 63);
+                    x[u] = ld_row4<NV>(ent, (k < cnt) ? idx : 0, eld, dim, sub);
+                }
+        };
+        auto score = [&](int it0, Row4<NV> (&x)[RB]) {
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
                 const int k = it0 + 4 * u + grp;
                 const bool valid = k < cnt;
-                const float inv = 1.0f / l2_denominator(sum16(sumsq4<NV>(x[u])));
+                const float den = l2_denominator(sum16(sumsq4<NV>(x[u])));
+                const float inv = 1.0f / den;
                 float s = 0.f;
 #pragma unroll
-                for (int j = 0; j < NV; ++j) {          // x[u] <- q - x^
-                    x[u].v[j].x = q.v[j].x - x[u].v[j].x * inv; s = fmaf(x[u].v[j].x, x[u].v[j].x, s);
-                    x[u].v[j].y = q.v[j].y - x[u].v[j].y * inv; s = fmaf(x[u].v[j].y, x[u].v[j].y, s);
-                    x[u].v[j].z = q.v[j].z - x[u].v[j].z * inv; s = fmaf(x[u].v[j].z, x[u].v[j].z, s);
-                    x[u].v[j].w = q.v[j].w - x[u].v[j].w * inv; s = fmaf(x[u].v[j].w, x[u].v[j].w, s);
+                for (int j = 0; j < NV; ++j) {          // x[u] <- x^ ; s = |q - x^|^2
+                    float d;
+                    x[u].v[j].x *= inv; d = q.v[j].x - x[u].v[j].x; s = fmaf(d, d, s);
+                    x[u].v[j].y *= inv; d = q.v[j].y - x[u].v[j].y; s = fmaf(d, d, s);
+                    x[u].v[j].z *= inv; d = q.v[j].z - x[u].v[j].z; s = fmaf(d, d, s);
+                    x[u].v[j].w *= inv; d = q.v[j].w - x[u].v[j].w; s = fmaf(d, d, s);
                 }
                 s = sum16(s);
                 const float viol = margin + s_pos - s;
@@ -282,28 +316,55 @@ __global__ __launch_bounds__(256, SNAG_TA_WAVES) void touched_a_kernel(
                 c_pos += a;
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
-                    acc.v[j].x = fmaf(a, x[u].v[j].x, acc.v[j].x); acc.v[j].y = fmaf(a, x[u].v[j].y, acc.v[j].y);
-                    acc.v[j].z = fmaf(a, x[u].v[j].z, acc.v[j].z); acc.v[j].w = fmaf(a, x[u].v[j].w, acc.v[j].w);
+                    acc.v[j].x = fmaf(a, q.v[j].x - x[u].v[j].x, acc.v[j].x); acc.v[j].y = fmaf(a, q.v[j].y - x[u].v[j].y, acc.v[j].y);
+                    acc.v[j].z = fmaf(a, q.v[j].z - x[u].v[j].z, acc.v[j].z); acc.v[j].w = fmaf(a, q.v[j].w - x[u].v[j].w, acc.v[j].w);
+                }
+                // the tail's gradient row as if this entry were its destination's only one: normalize_bwd4(x, w q_b) with the entry's weight
+                // (2 gscale, or 0 for an inactive hinge) -- pass B's single-entry arithmetic on the same values, so the same bits
+                {
+                    const float w0 = (viol > 0.f) ? 2.f * gscale : 0.f;
+                    Row4<NV> gr;
+                    float dot = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) {
+                        gr.v[j] = make_float4(w0 * q.v[j].x, w0 * q.v[j].y, w0 * q.v[j].z, w0 * q.v[j].w);
+                        dot = fmaf(x[u].v[j].x, gr.v[j].x, dot); dot = fmaf(x[u].v[j].y, gr.v[j].y, dot);
+                        dot = fmaf(x[u].v[j].z, gr.v[j].z, dot); dot = fmaf(x[u].v[j].w, gr.v[j].w, dot);
+                    }
+                    dot = sum16(dot);
+                    if (!(den > 1e-12f)) dot = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) {
+                        gr.v[j].x = (gr.v[j].x - x[u].v[j].x * dot) * inv; gr.v[j].y = (gr.v[j].y - x[u].v[j].y * dot) * inv;
+                        gr.v[j].z = (gr.v[j].z - x[u].v[j].z * dot) * inv; gr.v[j].w = (gr.v[j].w - x[u].v[j].w * dot) * inv;
+                    }
+                    const int idx = __shfl(my, k & 63);
+                    const unsigned slot_k = __shfl(my_slot, k & 63);
+                    // the FIRST entry to arrive at a destination writes: one writer per row (a Zipf batch's hot rows would otherwise take
+                    // thousands of write-through stores each: pass A 153 us instead of 53)
+                    if (valid && slot_k == 0u && !(SNAG_T_ABLATE & 4)) {
+                        if (SNAG_T_WT) st_row4_wt<NV>(d_ent, idx, dld, dim, sub, gr);
+                        else st_row4<NV>(d_ent, idx, dld, dim, sub, gr);
+                    }
                 }
                 const float sk = __shfl(s, (lane & 3) * 16);
                 if (((lane - it0) >> 2) == u && lane >= it0 && lane < it0 + 4 * RB) my_s = sk;
             }
+                };
+        for (int it0 = 0; it0 < cnt; it0 += 4 * RB) {
+            Row4<NV> x[RB];
+            issue(it0, x);
+            score(it0, x);
         }
-        // the reserved runs have arrived by now (first id block: the workgroup meets here; same trip count in every wave)
-        if (k0 == 0) __syncthreads();
         // lane k: score out, its negative's record (slot = its destination's base + its local number; weight 2 a_k, zero for an inactive
         // hinge); slots of this id block past the part's negatives are void records
-        const int q = k0 >> 6;
-        const unsigned nl = q == 0 ? nlocal[0] : (q == 1 ? nlocal[1] : (q == 2 ? nlocal[2] : nlocal[3]));
-        const int na = q == 0 ? naslot[0] : (q == 1 ? naslot[1] : (q == 2 ? naslot[2] : naslot[3]));
         if (lane < cnt) {
             neg[b * (int64_t)n_neg_all + k_lo + k0 + lane] = my_s;
-            touched_emit(w, which, rec0 + 3 + k0 + lane, my, agg_base[na] + nl, (int)b, (margin + s_pos - my_s > 0.f) ? 2.f * gscale : 0.f);
+            touched_emit(w, which, rec0 + 3 + k0 + lane, my, my_slot, (int)b, (margin + s_pos - my_s > 0.f) ? 2.f * gscale : 0.f, my_slot == 0u ? kRecWritten : 0u);
         } else if (live && k0 + lane < w.per) {
             w.rec[rec0 + 3 + k0 + lane] = TouchedRec{-1, 0, 0.f, 1u};
         }
     }
-    if (w.per <= 0) __syncthreads();
     // the four groups' partial sums, combined in fixed order: every group then holds the whole part's values
     {
         const float h1 = __shfl_xor(hinge, 16), c1 = __shfl_xor(c_pos, 16);
@@ -329,7 +390,8 @@ __global__ __launch_bounds__(256, SNAG_TA_WAVES) void touched_a_kernel(
         st_row4<NV>(w.rows, batch + vb, dim, dim, sub, dq);
     }
     if (!live) return;
-    if (lane < 3) touched_emit(w, which, rec0 + lane, dest3, agg_base[aslot3] + local3, lane == 0 ? (int)b : (int)(batch + vb), lane == 0 ? -2.f * c_pos : 1.f);
+    if (lane < n3) touched_emit(w, which, rec0 + lane, dest3, agg_base[aslot3] + local3, lane == 0 ? (int)b : (int)(batch + vb), lane == 0 ? -2.f * c_pos : 1.f);
+    else if (lane == 2) w.rec[rec0 + 2] = TouchedRec{-1, 0, 0.f, 1u};
     if (lane == 0) w.lpart[vb] = hinge;
 }
 
@@ -373,19 +435,156 @@ __device__ __forceinline__ void touched_chunk_body(const TouchedWork& w, int dim
     }
 }
 
+// ---- relation role of pass B's launch: one 16-lane group per relation ------------------------------------------------------------------
+template <int NV, typename TabT>
+__device__ __forceinline__ void touched_rel_body(const TabT* __restrict__ rel, int dim, int n_rel, const void* __restrict__ r_idx, int idx_bytes, int64_t batch,
+                                                 float* __restrict__ d_rel, const TouchedWork& w, int vblock) {
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4, gbase = lane & 48;
+    const int rho = (vblock * 4 + (int)(threadIdx.x >> 6)) * 4 + grp;
+    const bool live = rho < n_rel;
+    const int parts = w.parts;
+    // scan 1: the triples that name this relation, in batch order; lane `sub` keeps the sub-th one (16 are all the sorted fp32 path can take).
+    // Eight 64-id blocks are requested together: one round trip per 512 triples, not eight.
+    int cnt = 0, mine_b = 0;
+    auto rid = [&](int64_t i) { return i < batch ? (idx_bytes == 4 ? reinterpret_cast<const int32_t*>(r_idx)[i] : (int)reinterpret_cast<const int64_t*>(r_idx)[i]) : -1; };
+    for (int64_t b0 = 0; b0 < batch; b0 += 512) {
+        int rv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rv[q] = rid(b0 + 64 * q + lane);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int rho_g = __shfl(rho, 16 * g4);
+                unsigned long long m = __ballot(rv[q] == rho_g);
+                if (grp == g4) {
+                    while (m != 0ull) {
+                        if (cnt == sub) mine_b = (int)b0 + 64 * q + __builtin_ctzll(m);
+                        ++cnt;
+                        m &= m - 1ull;
+                    }
+                }
+            }
+        }
+    }
+    const int n = live ? cnt * parts : 0;                          // entries: one dq row per (triple, part), weight 1
+    Row4<NV> x = ld_row4<NV>(rel, live ? rho : 0, dim, dim, sub);
+    Row4<NV> gsum;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) gsum.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool small = n <= kTCap;
+    if (__ballot(small && n > 0) != 0ull) {
+        // up to 16 entries: fp32 sums in ascending (triple, part) order = the generic path's sorted-key order (key = entry row, weight 1)
+        int wave_max = small ? n : 0;
+        wave_max = max(wave_max, __shfl_xor(wave_max, 16));
+        wave_max = max(wave_max, __shfl_xor(wave_max, 32));
+        for (int e0 = 0; e0 < wave_max; e0 += 4) {
+            Row4<NV> y[4];
+            float wt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u;
+                const bool on = small && e < n;
+                const int bb = __shfl(mine_b, gbase + ((e / parts) & 15));
+                wt[u] = on ? 1.f : 0.f;
+                y[u] = ld_row4<NV>(w.rows, on ? batch + (int64_t)bb * parts + e % parts : 0, dim, dim, sub);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    gsum.v[j].x = fmaf(wt[u], y[u].v[j].x, gsum.v[j].x); gsum.v[j].y = fmaf(wt[u], y[u].v[j].y, gsum.v[j].y);
+                    gsum.v[j].z = fmaf(wt[u], y[u].v[j].z, gsum.v[j].z); gsum.v[j].w = fmaf(wt[u], y[u].v[j].w, gsum.v[j].w);
+                }
+        }
+    }
+    if (__ballot(!small) != 0ull) {
+        // more than 16 entries: 64-bit fixed point (order-free), as the hot-row pass sums them
+        long long acc[4 * NV];
+#pragma unroll
+        for (int i = 0; i < 4 * NV; ++i) acc[i] = 0;
+        const bool mid = !small && cnt <= 16;                     // its triples are all in the group's lanes: four rows per step
+        if (__ballot(mid) != 0ull) {
+            int wave_max = mid ? n : 0;
+            wave_max = max(wave_max, __shfl_xor(wave_max, 16));
+            wave_max = max(wave_max, __shfl_xor(wave_max, 32));
+            for (int e0 = 0; e0 < wave_max; e0 += 4) {
+                Row4<NV> y[4];
+                float wt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u;
+                    const bool on = mid && e < n;
+                    const int bb = __shfl(mine_b, gbase + ((e / parts) & 15));
+                    wt[u] = on ? 1.f : 0.f;
+                    y[u] = ld_row4<NV>(w.rows, on ? batch + (int64_t)bb * parts + e % parts : 0, dim, dim, sub);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fix_add_row<NV>(acc, y[u], wt[u]);
+            }
+        }
+        const bool big = live && cnt > 16;                        // (a relation named by more than 16 triples of the batch: scan 2 walks the batch again)
+        if (__ballot(big) != 0ull) {
+            for (int64_t b0 = 0; b0 < batch; b0 += 64) {
+                const int rv = rid(b0 + lane);
+                const int want = big ? rho : -2;
+                unsigned long long mg[4];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) mg[g4] = __ballot(rv == __shfl(want, 16 * g4));
+                unsigned long long m = grp == 0 ? mg[0] : (grp == 1 ? mg[1] : (grp == 2 ? mg[2] : mg[3]));
+                unsigned long long any = mg[0] | mg[1] | mg[2] | mg[3];
+                while (any != 0ull) {                                     // (uniform trip count: the longest group's)
+                    const bool on = m != 0ull;
+                    const int64_t bb = b0 + (on ? __builtin_ctzll(m) : 0);
+                    for (int p0 = 0; p0 < parts; p0 += 4) {
+                        Row4<NV> y[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) y[u] = ld_row4<NV>(w.rows, (on && p0 + u < parts) ? batch + bb * parts + p0 + u : 0, dim, dim, sub);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) fix_add_row<NV>(acc, y[u], (on && p0 + u < parts) ? 1.f : 0.f);
+                    }
+                    m &= m - 1ull;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) mg[g4] &= mg[g4] - (mg[g4] != 0ull ? 1ull : 0ull);
+                    any = mg[0] | mg[1] | mg[2] | mg[3];
+                }
+            }
+        }
+        if (!small) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                gsum.v[j].x = (float)((double)acc[4 * j + 0] * (1.0 / kFix)); gsum.v[j].y = (float)((double)acc[4 * j + 1] * (1.0 / kFix));
+                gsum.v[j].z = (float)((double)acc[4 * j + 2] * (1.0 / kFix)); gsum.v[j].w = (float)((double)acc[4 * j + 3] * (1.0 / kFix));
+            }
+        }
+    }
+    normalize_bwd4<NV>(x, gsum);
+    if (live) {
+        if (n == 0) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) gsum.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        st_row4<NV>(d_rel, rho, dim, dim, sub, gsum);
+    }
+}
+
 // ---- pass B: one group per record -----------------------------------------------------------------------------------------------------
 template <int NV, typename TabT>
 __global__ __launch_bounds__(256, SNAG_TB_WAVES) void touched_b_kernel(const TabT* __restrict__ ent, int64_t eld, const TabT* __restrict__ rel, int dim, int n_ent,
                                                         float* __restrict__ d_ent, int64_t dld, float* __restrict__ d_rel, TouchedWork w,
                                                         float* __restrict__ loss_part, int64_t batch, float* __restrict__ loss, int group_blocks,
-                                                        int chunk_blocks) {
+                                                        int chunk_blocks, int rel_blocks, int n_rel, const void* __restrict__ r_idx, int idx_bytes) {
     // workgroup roles: [0, chunk_blocks) chunk sums of the overflow hash (pass B'), then one group per record, then the loss sum, then
     // the wipe of the previous launch's hash keys
-    if ((int)blockIdx.x < chunk_blocks) {
-        touched_chunk_body<NV>(w, dim, (int)blockIdx.x, chunk_blocks);
+    if ((int)blockIdx.x < rel_blocks) {
+        if (!(SNAG_T_ABLATE & 32)) touched_rel_body<NV, TabT>(rel, dim, n_rel, r_idx, idx_bytes, batch, d_rel, w, (int)blockIdx.x);
         return;
     }
-    const int bid = (int)blockIdx.x - chunk_blocks;
+    if ((int)blockIdx.x - rel_blocks < chunk_blocks) {
+        if (!(SNAG_T_ABLATE & 64)) touched_chunk_body<NV>(w, dim, (int)blockIdx.x - rel_blocks, chunk_blocks);
+        return;
+    }
+    const int bid = (int)blockIdx.x - rel_blocks - chunk_blocks;
     if (bid == group_blocks) {
         // per-triple losses = the parts' sums in part order; the total in one fixed order (thread-strided, wave reductions, wave order)
         __shared__ float part[4];
@@ -406,7 +605,7 @@ __global__ __launch_bounds__(256, SNAG_TB_WAVES) void touched_b_kernel(const Tab
     if (bid > group_blocks) {
         // the remaining workgroups wipe the keys of the PREVIOUS launch's overflow hash (nobody reads that table in this launch)
         unsigned long long* keys = w.hkeys[which ^ 1u];
-        const unsigned nb = gridDim.x - chunk_blocks - group_blocks - 1u;
+        const unsigned nb = gridDim.x - rel_blocks - chunk_blocks - group_blocks - 1u;
         for (unsigned i = ((unsigned)bid - group_blocks - 1u) * 256u + threadIdx.x; i <= w.hmask; i += nb * 256u) keys[i] = 0ull;
         return;
     }
@@ -415,87 +614,113 @@ __global__ __launch_bounds__(256, SNAG_TB_WAVES) void touched_b_kernel(const Tab
         w.hdr->n_chunks[which ^ 1u] = 0u;
         w.hdr->phase = which ^ 1u;
     }
-    const int lane = threadIdx.x & 63, sub = lane & 15, gbase = lane & 48;
-    const int64_t g = ((int64_t)bid * 256 + threadIdx.x) >> 4;
-    // round trip 1: the record (the 16 lanes of a group read the same 16 bytes)
+    const int lane = threadIdx.x & 63, sub = lane & 15, gbase = lane & 48, grp = lane >> 4;
+    // CLASSIFICATION, one LANE per record (round 5; a 16-lane group per record made this launch 8,400 workgroups -- eight rounds of
+    // two dependent round trips -- for the one record in twelve that has arithmetic to do).  Round trip 1: the record; round trip 2, for
+    // the record that owns its destination (slot 0): how many entries arrived.  One entry whose row pass A has written: reset the counter, done.
+    const int64_t g = (int64_t)bid * 256 + threadIdx.x;
     const TouchedRec rc = g < w.n_rec ? w.rec[g] : TouchedRec{-1, 0, 0.f, 1u};
-    const bool owner = rc.dest >= 0 && rc.slot == 0u;
+    const bool owner = rc.dest >= 0 && (rc.slot & ~kRecWritten) == 0u;
     if (__ballot(owner) == 0ull) return;
-    const int dest = owner ? rc.dest : 0;
-    const bool is_rel = dest >= n_ent;
-    // round trip 2: how many entries arrived, the destination's own row, the owner entry's row, the rest of the bucket
-    const unsigned n = owner ? w.cnt[dest] : 0u;
-    // (one load sequence through a selected pointer: as two branches the compiler waits for the row inside its branch, before the
-    // other round-trip-2 loads are even issued)
-    const TabT* xrow = is_rel ? rel + (int64_t)(dest - n_ent) * dim : ent + (int64_t)dest * eld;
-    Row4<NV> x = ld_row4<NV>(xrow, 0, 0, dim, sub);
-    const Row4<NV> y0 = ld_row4<NV>(w.rows, owner ? rc.src : 0, dim, dim, sub);
-    const bool hub = n > (unsigned)kTCap;
-    if (owner && !hub && sub == 0) w.cnt[dest] = 0u;          // ready for the next launch (hot rows: pass C)
+    const unsigned n1 = owner ? w.cnt[rc.dest] : 0u;
+    const bool hub1 = n1 > (unsigned)kTCap;
+    if (owner && !hub1 && !(SNAG_T_ABLATE & 8)) w.cnt[rc.dest] = 0u;                  // ready for the next launch (hot rows: pass C)
     // hot rows go to pass C: one list slot per wave-instruction
     {
-        const unsigned long long hm = __ballot(owner && hub && sub == 0);
+        const unsigned long long hm = __ballot(owner && hub1);
         if (hm != 0ull) {
             const int leader = __builtin_ctzll(hm);
             unsigned base = 0u;
             if (lane == leader) base = atomicAdd(&w.hdr->n_hubs[which], (unsigned)__builtin_popcountll(hm));
             base = __shfl(base, leader);
-            if (owner && hub && sub == 0) {
+            if (owner && hub1) {
                 const unsigned at = base + (unsigned)__builtin_popcountll(hm & ((1ull << lane) - 1ull));
-                if (at < w.max_hubs) w.hubs[at] = TouchedHub{dest, (unsigned)g};
+                if (at < w.max_hubs) w.hubs[at] = TouchedHub{rc.dest, (unsigned)g};
             }
         }
     }
-    Row4<NV> gsum;
+    // ARITHMETIC, one 16-lane group per record that has some: its destination received 2..16 entries, or one that pass A did not write
+    unsigned long long todo_mask = (SNAG_T_ABLATE & 16) ? 0ull : __ballot(owner && !hub1 && !(n1 == 1u && (rc.slot & kRecWritten) != 0u));
+    while (todo_mask != 0ull) {
+        // the next four such records, one per group (a group past the last one idles along: its loads go to row 0, it stores nothing)
+        unsigned long long mm = todo_mask;
+        int src_lane = 0;
+        bool todo = false;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const float w0 = (owner && n == 1u) ? rc.w : 0.f;
-        gsum.v[j] = make_float4(w0 * y0.v[j].x, w0 * y0.v[j].y, w0 * y0.v[j].z, w0 * y0.v[j].w);
-    }
-    const bool multi = owner && !hub && n > 1u;
-    if (__ballot(multi) != 0ull) {
-        // (a third round trip, for the ~6 % of a uniform batch's destinations that received more than one entry: the bucket's slots 1..15)
-        SegEntry mine = multi ? w.list[(int64_t)dest * kTCap + sub] : SegEntry{0, 0.f};
-        if (sub == 0) mine = SegEntry{rc.src, rc.w};              // slot 0 is the record itself
-        // 2..16 entries: canonical order by (row, weight bits, slot) key -- the slot order the atomics produced varies from run to run, the
-        // sorted order does not --, fp32 sums in that order, four rows gathered per step
-        const int nf = multi ? (int)n : 0;
-        const long long key = ((long long)mine.src << 32) | (unsigned)__float_as_int(mine.w);
-        int rank = 0;
-#pragma unroll
-        for (int j = 0; j < kTCap; ++j) {
-            const long long kj = __shfl(key, gbase + j);
-            rank += (j < nf && (kj < key || (kj == key && j < sub))) ? 1 : 0;
+        for (int i = 0; i < 4; ++i) {
+            const bool have = mm != 0ull;
+            const int l = have ? __builtin_ctzll(mm) : 0;
+            if (i == grp) { src_lane = l; todo = have; }
+            mm &= mm - 1ull;
         }
-        int wave_max = nf;
-        wave_max = max(wave_max, __shfl_xor(wave_max, 16));
-        wave_max = max(wave_max, __shfl_xor(wave_max, 32));
-        for (int r0 = 0; r0 < wave_max; r0 += 2) {                 // (two rows per step: this path is rare, the kernel's register count is every group's)
-            Row4<NV> y[2];
-            float wt[2];
+        todo_mask = mm;
+        // (every lane takes part in the exchanges -- the record's lane may sit in another group -- and selects afterwards)
+        const int dest_x = __shfl(rc.dest, src_lane);
+        const int rsrc = __shfl(rc.src, src_lane);
+        const float rw = __shfl(rc.w, src_lane);
+        const unsigned n_x = __shfl(n1, src_lane);
+        const int dest = todo ? dest_x : 0;
+        const unsigned n = todo ? n_x : 0u;
+        const bool is_rel = dest >= n_ent;
+        // round trip 3: the destination's own row, the owner entry's row, the rest of the bucket
+        // (one load sequence through a selected pointer: as two branches the compiler waits for the row inside its branch, before the
+        // other loads are even issued)
+        const TabT* xrow = !todo ? ent : (is_rel ? rel + (int64_t)(dest - n_ent) * dim : ent + (int64_t)dest * eld);
+        Row4<NV> x = ld_row4<NV>(xrow, 0, 0, dim, sub);
+        const Row4<NV> y0 = ld_row4<NV>(w.rows, todo ? rsrc : 0, dim, dim, sub);
+        Row4<NV> gsum;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const unsigned long long m = __ballot(sub < nf && rank == r0 + u) >> gbase;
-                const int src_lane = gbase + (int)__builtin_ctzll(m | 0x10000ull);
-                const int src = __shfl(mine.src, src_lane);
-                const bool on = r0 + u < nf;
-                wt[u] = on ? __shfl(mine.w, src_lane) : 0.f;
-                y[u] = ld_row4<NV>(w.rows, on ? src : 0, dim, dim, sub);
-                if (!on) wt[u] = 0.f;
+        for (int j = 0; j < NV; ++j) {
+            const float w0 = (todo && n == 1u) ? rw : 0.f;
+            gsum.v[j] = make_float4(w0 * y0.v[j].x, w0 * y0.v[j].y, w0 * y0.v[j].z, w0 * y0.v[j].w);
+        }
+        const bool multi = todo && n > 1u;
+        if (__ballot(multi) != 0ull) {
+            // (the bucket's slots 1..15: destinations that received more than one entry -- ~6 % of a uniform batch's, and every head / relation /
+            // positive tail of a triple dealt to several parts)
+            SegEntry mine = multi ? w.list[(int64_t)dest * kTCap + sub] : SegEntry{0, 0.f};
+            if (sub == 0) mine = SegEntry{rsrc, rw};                  // slot 0 is the record itself
+            // 2..16 entries: canonical order by (row, weight bits, slot) key -- the slot order the atomics produced varies from run to run, the
+            // sorted order does not --, fp32 sums in that order, two rows gathered per step
+            const int nf = multi ? (int)n : 0;
+            const long long key = ((long long)mine.src << 32) | (unsigned)__float_as_int(mine.w);
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < kTCap; ++j) {
+                const long long kj = __shfl(key, gbase + j);
+                rank += (j < nf && (kj < key || (kj == key && j < sub))) ? 1 : 0;
             }
+            int wave_max = nf;
+            wave_max = max(wave_max, __shfl_xor(wave_max, 16));
+            wave_max = max(wave_max, __shfl_xor(wave_max, 32));
+            for (int r0 = 0; r0 < wave_max; r0 += 4) {                 // four rows per step: a head or tail dealt to four parts is ONE round trip
+                Row4<NV> y[4];
+                float wt[4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int j = 0; j < NV; ++j) {
-                    gsum.v[j].x = fmaf(wt[u], y[u].v[j].x, gsum.v[j].x); gsum.v[j].y = fmaf(wt[u], y[u].v[j].y, gsum.v[j].y);
-                    gsum.v[j].z = fmaf(wt[u], y[u].v[j].z, gsum.v[j].z); gsum.v[j].w = fmaf(wt[u], y[u].v[j].w, gsum.v[j].w);
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long m = __ballot(sub < nf && rank == r0 + u) >> gbase;
+                    const int pick = gbase + (int)__builtin_ctzll(m | 0x10000ull);
+                    const int src = __shfl(mine.src, pick);
+                    const bool on = r0 + u < nf;
+                    wt[u] = on ? __shfl(mine.w, pick) : 0.f;
+                    y[u] = ld_row4<NV>(w.rows, on ? src : 0, dim, dim, sub);
+                    if (!on) wt[u] = 0.f;
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) {
+                        gsum.v[j].x = fmaf(wt[u], y[u].v[j].x, gsum.v[j].x); gsum.v[j].y = fmaf(wt[u], y[u].v[j].y, gsum.v[j].y);
+                        gsum.v[j].z = fmaf(wt[u], y[u].v[j].z, gsum.v[j].z); gsum.v[j].w = fmaf(wt[u], y[u].v[j].w, gsum.v[j].w);
+                    }
+            }
         }
-    }
-    normalize_bwd4<NV>(x, gsum);
-    if (owner && !hub) {
-        float* out = is_rel ? d_rel + (int64_t)(dest - n_ent) * dim : d_ent + (int64_t)dest * dld;
-        st_row4<NV>(out, 0, 0, dim, sub, gsum);
+        normalize_bwd4<NV>(x, gsum);
+        if (todo) {
+            float* out = is_rel ? d_rel + (int64_t)(dest - n_ent) * dim : d_ent + (int64_t)dest * dld;
+            if (SNAG_T_WT) st_row4_wt<NV>(out, 0, 0, dim, sub, gsum);
+            else st_row4<NV>(out, 0, 0, dim, sub, gsum);
+        }
     }
 }
 
@@ -587,7 +812,10 @@ static int launch_touched(const char* who, const TabT* ent, int64_t ent_ld, int6
     SNAG_REQUIRE(((uintptr_t)work & 255) == 0 && ((uintptr_t)ent & tab_align) == 0 && ((uintptr_t)rel & tab_align) == 0 && ((uintptr_t)d_ent & 15) == 0 &&
                  ((uintptr_t)d_rel & 15) == 0, SNAG_ERR_UNSUPPORTED, "%s: tables and gradients must be 16-byte aligned (bf16 tables: 8), the workspace 256-byte aligned", who);
     SNAG_REQUIRE(batch == 0 || (h && r && t && pos && (n_neg == 0 || (neg && neg_t))), SNAG_ERR_ARG, "%s: null index or score pointer", who);
-    const TouchedWork w = touched_carve(work, n_ent, n_rel, batch, n_neg, dim);
+    TouchedWork w = touched_carve(work, n_ent, n_rel, batch, n_neg, dim);
+    // the relation role scans the whole batch once per relation: while that product is small (configs[4]: 1,000 x 1,024)
+    w.rel_role = (n_rel * std::max<int64_t>(batch, 1) <= (1LL << 24)) ? 1 : 0;
+    if (!w.rel_role && hipMemsetAsync(d_rel, 0, sizeof(float) * (size_t)n_rel * dim, st) != hipSuccess) return fail(SNAG_ERR_LAUNCH, "%s: memset failed", who);
     const int nv = (dim + 63) / 64;
     const dim3 block(256);
 #define SNAG_NV_SWITCH(CALL)          \
@@ -603,7 +831,7 @@ static int launch_touched(const char* who, const TabT* ent, int64_t ent_ld, int6
         const dim3 grid((unsigned)ceil_div(batch * w.parts, 4));
         const bool small_agg = 4 * (w.per + 3) <= 160;
 #define SNAG_TA_(IDX, NV, AGG) hipLaunchKernelGGL((touched_a_kernel<IDX, NV, TabT, AGG>), grid, block, 0, st, ent, ent_ld, rel, dim, (int)n_ent, \
-                             (const IDX*)h, (const IDX*)r, (const IDX*)t, (const IDX*)neg_t, batch, n_neg, margin, grad_scale, pos, neg, w)
+                             (const IDX*)h, (const IDX*)r, (const IDX*)t, (const IDX*)neg_t, batch, n_neg, margin, grad_scale, pos, neg, w, d_ent, d_ent_ld)
 #define SNAG_TA(NV) do { if (idx_bytes == 4) { if (small_agg) SNAG_TA_(int32_t, NV, 256); else SNAG_TA_(int32_t, NV, 1024); } \
                          else { if (small_agg) SNAG_TA_(int64_t, NV, 256); else SNAG_TA_(int64_t, NV, 1024); } } while (0)
         SNAG_NV_SWITCH(SNAG_TA)
@@ -612,19 +840,20 @@ static int launch_touched(const char* who, const TabT* ent, int64_t ent_ld, int6
         int rc = check_launch(who);
         if (rc) return rc;
     }
-    // pass B: one group per record, + 1 workgroup that sums the losses (an empty batch: loss = 0), + 8 that wipe the previous launch's hash keys
-    const int group_blocks = ceil_div(w.n_rec * 16, 256);
+    // pass B: one lane per record, + 1 workgroup that sums the losses (an empty batch: loss = 0), + 8 that wipe the previous launch's hash keys
+    const int group_blocks = ceil_div(w.n_rec, 256);          // one lane per record
     const int chunk_blocks = batch > 0 ? 512 : 0;                   // pass B': a fixed grid of 2,048 waves walks the list of claimed chunks
-    const dim3 gridb((unsigned)(chunk_blocks + group_blocks) + 9u);
+    const int rel_blocks = w.rel_role ? ceil_div(n_rel, 16) : 0;   // one 16-lane group per relation
+    const dim3 gridb((unsigned)(rel_blocks + chunk_blocks + group_blocks) + 9u);
 #define SNAG_TB(NV) hipLaunchKernelGGL((touched_b_kernel<NV, TabT>), gridb, block, 0, st, ent, ent_ld, rel, dim, (int)n_ent, d_ent, d_ent_ld, d_rel, w, loss_part, batch, loss, \
-                                       group_blocks, chunk_blocks)
-    SNAG_NV_SWITCH(SNAG_TB)
+                                       group_blocks, chunk_blocks, rel_blocks, (int)n_rel, r, idx_bytes)
+    if (!(SNAG_T_ABLATE & 2)) { SNAG_NV_SWITCH(SNAG_TB) }
 #undef SNAG_TB
     int rc = check_launch(who);
     if (rc || batch == 0) return rc;
     const dim3 gridh((unsigned)std::min<int64_t>(SNAG_HUB_GRID, (int64_t)w.max_hubs));
 #define SNAG_TH(NV) hipLaunchKernelGGL((touched_hub_kernel<NV, TabT>), gridh, block, 0, st, ent, ent_ld, rel, dim, (int)n_ent, d_ent, d_ent_ld, d_rel, w)
-    SNAG_NV_SWITCH(SNAG_TH)
+    if (!(SNAG_T_ABLATE & 1)) { SNAG_NV_SWITCH(SNAG_TH) }
 #undef SNAG_TH
 #undef SNAG_NV_SWITCH
     return check_launch(who);

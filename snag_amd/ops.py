@@ -231,7 +231,7 @@ _TOUCHED_WORK = {}
 
 def score_margin_fwd_bwd_touched(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, d_ent=None, d_rel=None):
     """The segmented hinge scorer for tables far larger than a batch's footprint: pass B walks the compact list of destinations that
-    received an entry instead of every counter; only touched rows of d_ent / d_rel are written (allocated zeroed when None).  fp32 or
+    received an entry instead of every counter; only touched rows of d_ent are written (allocated zeroed when None), every row of d_rel is.  fp32 or
     bfloat16 tables.  -> (loss, pos, neg, loss_part, d_ent, d_rel).  C ABI: snag_score_margin_fwd_bwd_touched(_bf16)."""
     bf16 = ent.dtype == torch.bfloat16
     for x, nm in ((ent, "ent"), (rel, "rel")):

@@ -120,7 +120,8 @@ class StressHotPath:
             return e
 
         phase("t0")
-        self.d_rel.zero_()
+        if cfg.deterministic or cfg.scorer != "touched":
+            self.d_rel.zero_()                   # (the touched scorer writes every relation row itself)
         if cfg.deterministic:
             self._acc_ent.zero_()
             self._acc_rel.zero_()
@@ -130,7 +131,7 @@ class StressHotPath:
             call("snag_fixed_to_float", ptr(self._acc_ent), N, D, ptr(self.d_ent_full), D, 0, st)
             call("snag_fixed_to_float", ptr(self._acc_rel), R, D, ptr(self.d_rel), D, 0, st)
         elif cfg.scorer == "touched":
-            # scores, loss and every touched gradient row WRITTEN (the rest of d_ent_full / d_rel is zero: cleared row by row below)
+            # scores, loss, every touched entity gradient row and EVERY relation row WRITTEN (the rest of d_ent_full is zero: cleared row by row below)
             if self._touched_work is None or self._touched_work[0] != (B, K):
                 nb = _lib.load().snag_score_touched_work_bytes(sh.n_pad, R, B, K, D)
                 self._touched_work = ((B, K), torch.zeros((nb + 255) // 256 * 256, device=self.dev, dtype=torch.uint8))
