@@ -966,6 +966,8 @@ def main():
     # all-gathered before scoring and their gradient reduce-scattered back (SURVEY.md par. 8e); --replicate-fusion keeps full replicas
     row_sharded = world > 1 and not args.replicate_fusion
     shard = RowShard(cfg.n_ent, rank, world) if row_sharded else None
+    if os.environ.get("BENCH_L1_ROUND"):                 # A/B only (tools/): K splits of the grouped first projections sized for two workgroups per CU
+        MKGCHotPath.l1_round = int(os.environ["BENCH_L1_ROUND"])
     eng = MKGCHotPath(cfg, feats, device=device, shard=shard)
     raw_dims, cfg = list(cfg.feat_dims), eng.cfg               # (--pool: the engine's configuration carries the pooled widths)
     reducer = GradAllReduce(world) if world > 1 else None

@@ -179,7 +179,7 @@ struct RoWeightImages {
 int gemm_check(const snag_gemm_desc* d);
 int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st);
 int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStream_t st);
-int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st);   // 2..6 problems, one launch when their plans allow
+int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st);   // 2..8 problems, one launch when their plans allow (A layouts may differ per problem on the 64 x 128 tile)
 // finishes problems launched with defer_reduce (+ optionally up to four small products in the same launch)
 // (+ optionally a layer's slab reductions, independent of everything the launch reduces: a 7 us launch of their own otherwise)
 int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, const snag_small_mm* small = nullptr, int n_small = 0, const SlabColsum* colsum = nullptr,

@@ -105,6 +105,10 @@ static snag_gemm_desc gemm_desc(int M, int N, int K, const float* A, int64_t lda
     return d;
 }
 
+#ifndef SNAG_RO_BWD_ONE_GROUP
+#define SNAG_RO_BWD_ONE_GROUP 1      // the read-out layer's backward: weight gradients and input gradients as ONE grouped launch (0: two; A/B)
+#endif
+static constexpr int kGroupMaxProblems = 8;       // = kGroupMax (gemm.hip.h): problems one grouped launch takes
 static constexpr int kRedBlocks = 1024;  // fixed partial-sum fan-in for LayerNorm / bias / weight_raw gradients
 
 static int check_fusion(const snag_fusion_desc* f) {
@@ -508,9 +512,7 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
                 const snag_gemm_desc* grp[4] = {&g1, &g0, nullptr, nullptr};
                 int ng = 2;
                 for (int i = 0; i < b->n_co_dw; ++i) grp[ng++] = b->co_dw[i];
-                if ((rc = gemm_dispatch_group(grp, ng, st))) return rc;
-                if ((rc = gemm_reduce_multi(grp, ng, st, nullptr, 0, &slabs))) return rc;
-                // d(layer input), rows of token ro: [dq | dk | dv] Wqkv + dT1 (K = 3D), with the caller's co_dx problems in the same launch
+                // d(layer input), rows of token ro: [dq | dk | dv] Wqkv + dT1 (K = 3D), with the caller's co_dx problems
                 g = gemm_desc(N, D, 3 * D, ro3, 3 * D, true, P.wqkv, D, false, dxin + (int64_t)ro * D, MD);
                 g.add1 = W.dA; g.ld1 = D;
                 if (b->d_slot_out != nullptr && l == 0) {
@@ -519,7 +521,20 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
                 const snag_gemm_desc* gx[3] = {&g, nullptr, nullptr};
                 int nx = 1;
                 for (int i = 0; i < b->n_co_dx; ++i) gx[nx++] = b->co_dx[i];
+#if SNAG_RO_BWD_ONE_GROUP
+                // Weight gradients and input gradients depend on the attention backward alone: ONE grouped launch (the A operand's layout per
+                // problem: gemm_tile_group_mixed_kernel), the weight gradients -- the XCD-ordered front of the launch -- then their one reduce
+                const snag_gemm_desc* all[kGroupMaxProblems];
+                int na = 0;
+                for (int i = 0; i < ng; ++i) all[na++] = grp[i];
+                for (int i = 0; i < nx; ++i) all[na++] = gx[i];
+                if ((rc = gemm_dispatch_group(all, na, st))) return rc;
+                if ((rc = gemm_reduce_multi(grp, ng, st, nullptr, 0, &slabs))) return rc;
+#else
+                if ((rc = gemm_dispatch_group(grp, ng, st))) return rc;
+                if ((rc = gemm_reduce_multi(grp, ng, st, nullptr, 0, &slabs))) return rc;
                 if ((rc = nx > 1 ? gemm_dispatch_group(gx, nx, st) : gemm_dispatch(&g, st))) return rc;
+#endif
                 dout = W.dC;
                 continue;
             }

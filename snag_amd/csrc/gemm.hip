@@ -764,6 +764,7 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
     GemmPlan pl[kGroupMax];
     bool ok = n >= 2 && n <= kGroupMax;
     bool pp = false;                  // every problem on the eight-wave 256 x 128 tile instead (512 threads per workgroup)
+    bool mixed = false;               // the A operands' layouts differ (64 x 128 tiles only): gemm_tile_group_mixed_kernel
     for (int i = 0; ok && i < n; ++i) {
         const snag_gemm_desc* d = ds[i];
         pl[i] = plan_gemm(d);
@@ -771,8 +772,9 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
         // (in a group of eight-wave tiles a problem with an explicit split request rides along even if, alone, its row count would pick
         // the 64 x 128 tile: its K split and epilogue do not depend on the tile)
         const bool pp_ok = (pl[i].big && pl[i].pp) || (d->splits > 0 && kBf16x != 0 && d->K >= 512 && d->N <= 128 && !pl[i].big);
+        mixed = mixed || d->a_kcontig != ds[0]->a_kcontig;
         ok = d->M > 0 && d->N > 0 && d->K > 0 && !pl[i].streamk && !pl[i].wide && (pp ? pp_ok : (!pl[i].big && !pl[i].pp)) &&
-             d->a_kcontig == ds[0]->a_kcontig && d->b_kcontig == ds[0]->b_kcontig &&
+             (d->a_kcontig == ds[0]->a_kcontig || !pp) && d->b_kcontig == ds[0]->b_kcontig &&
              use_vec(pl[i].p, d->a_kcontig, d->b_kcontig) == use_vec(pl[0].p, ds[0]->a_kcontig, ds[0]->b_kcontig);
         for (int j = 0; ok && j < i; ++j) ok = !(pl[i].splits > 1 && pl[j].splits > 1 && ds[i]->workspace == ds[j]->workspace);
     }
@@ -795,13 +797,25 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
         g.tiles[i] = g.tiles_n[i] * ceil_div(pl[i].p.M, pp ? 256 : 64);
         g.first[i] = blocks;
         blocks += g.tiles[i] * pl[i].splits;
+        if (ds[i]->a_kcontig) g.a_kc_mask |= 1u << i;
+        // the weight-gradient shapes (dW = dY^T X: both operands row-contiguous, K = the entity rows) at the FRONT of the launch get the XCD-aware
+        // block order (see gemm_tile_group_kernel); it stops at the first problem of another shape
+        if (!pp && !ds[i]->a_kcontig && !ds[i]->b_kcontig && g.xcd == g.first[i]) g.xcd = blocks;
         if (log_shapes())
             fprintf(stderr, "snag_gemm GROUP[%d/%d] M=%d N=%d K=%d a_kc=%d b_kc=%d tile=%s splits=%d\n", i, n, pl[i].p.M, pl[i].p.N, pl[i].p.K, (int)ds[i]->a_kcontig,
                     (int)ds[i]->b_kcontig, pp ? "256x128" : "64x128", pl[i].splits);
     }
     g.first[n] = blocks;
-    g.xcd = !pp && !ds[0]->a_kcontig && !ds[0]->b_kcontig;          // the weight-gradient shapes (dW = dY^T X): see gemm_tile_group_kernel
     const bool vec = use_vec(pl[0].p, ds[0]->a_kcontig, ds[0]->b_kcontig);
+    if (mixed) {
+        if (ds[0]->b_kcontig) {
+            if (vec) hipLaunchKernelGGL((gemm_tile_group_mixed_kernel<64, 128, 32, 64, true, true, Epilogue>), dim3(blocks), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((gemm_tile_group_mixed_kernel<64, 128, 32, 64, true, false, Epilogue>), dim3(blocks), dim3(256), 0, st, g);
+        } else {
+            if (vec) hipLaunchKernelGGL((gemm_tile_group_mixed_kernel<64, 128, 32, 64, false, true, Epilogue>), dim3(blocks), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((gemm_tile_group_mixed_kernel<64, 128, 32, 64, false, false, Epilogue>), dim3(blocks), dim3(256), 0, st, g);
+        }
+    } else {
 #define SNAG_GROUPN(AK, BK_)                                                                                                              \
     do {                                                                                                                                  \
         if (pp && vec) hipLaunchKernelGGL((gemm_tile_group_kernel<256, 128, 32, 128, AK, BK_, true, Epilogue>), dim3(blocks), dim3(512), 0, st, g);     \
@@ -809,11 +823,12 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
         else if (vec) hipLaunchKernelGGL((gemm_tile_group_kernel<64, 128, 32, 64, AK, BK_, true, Epilogue>), dim3(blocks), dim3(256), 0, st, g);     \
         else hipLaunchKernelGGL((gemm_tile_group_kernel<64, 128, 32, 64, AK, BK_, false, Epilogue>), dim3(blocks), dim3(256), 0, st, g);       \
     } while (0)
-    if (ds[0]->a_kcontig && ds[0]->b_kcontig) SNAG_GROUPN(true, true);
-    else if (ds[0]->a_kcontig && !ds[0]->b_kcontig) SNAG_GROUPN(true, false);
-    else if (!ds[0]->a_kcontig && ds[0]->b_kcontig) SNAG_GROUPN(false, true);
-    else SNAG_GROUPN(false, false);
+        if (ds[0]->a_kcontig && ds[0]->b_kcontig) SNAG_GROUPN(true, true);
+        else if (ds[0]->a_kcontig && !ds[0]->b_kcontig) SNAG_GROUPN(true, false);
+        else if (!ds[0]->a_kcontig && ds[0]->b_kcontig) SNAG_GROUPN(false, true);
+        else SNAG_GROUPN(false, false);
 #undef SNAG_GROUPN
+    }
     int rc = check_launch("snag_gemm_f32_group");
     for (int i = 0; !rc && i < n; ++i)
         if (pl[i].splits > 1 && !ds[i]->defer_reduce) rc = launch_reduce(pl[i], ds[i]->workspace, st);

@@ -1314,7 +1314,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_pair_ker
 // problem by problem, inside a problem split by split.  The backward of the read-out layer has six independent [15000 x 128 x 128..384]-
 // class products behind the attention backward; one by one each is a 235-workgroup grid that pays its own launch, first-load latency
 // and drain (16-27 us each for 1-3 us of matrix work).
-constexpr int kGroupMax = 6;
+constexpr int kGroupMax = 8;
 template <class Epi>
 struct GemmGroup {
     GemmOperands p[kGroupMax];
@@ -1323,7 +1323,8 @@ struct GemmGroup {
     int first[kGroupMax + 1];        // block ranges
     int tiles[kGroupMax], tiles_n[kGroupMax];
     int n;
-    int xcd;                         // 1: XCD-aware block -> (problem, split, tile) mapping
+    int xcd;                         // > 0: XCD-aware block -> (problem, split, tile) mapping for the first `xcd` blocks of the launch
+    unsigned a_kc_mask;              // gemm_tile_group_mixed_kernel: bit q = problem q's A operand is K-contiguous
 };
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_group_kernel(GemmGroup<Epi> g) {
@@ -1335,12 +1336,30 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_group_ke
     // (Set by the host for the weight-gradient groups only -- both operands row-contiguous, K = the entity rows, equal k-ranges per
     // block: 40.8 -> 37.0 us.  Launches whose problems differ in work per block lose by it: an XCD that owns the short problem's run idles
     // at the end -- first projections 110.5 -> 117.8 us, input-gradient group 38.0 -> 44.7.)
-    const int id = g.xcd ? xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int id = (int)blockIdx.x < g.xcd ? xcd_swizzle((int)blockIdx.x, g.xcd) : (int)blockIdx.x;
     int q = 0;
     while (q + 1 < g.n && id >= g.first[q + 1]) ++q;
     const int b = id - g.first[q];
     const int z = b / g.tiles[q], t = b % g.tiles[q];
     gemm_tile_at<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi>(g.p[q], g.e[q], g.slab[q], z, (t / g.tiles_n[q]) * BM, (t % g.tiles_n[q]) * BN, smem);
+}
+
+// The same with the A operand's layout chosen PER PROBLEM (round 5): the read-out layer's backward issues four weight gradients (A = an
+// activation gradient read row-contiguously, K = the entity rows) and three input gradients (A K-contiguous, K = 128 .. 384) that all depend on
+// the attention backward alone -- two launches of 896 and 705 workgroups, each with its own ramp and tail (37 + 38 us), become one.  Every
+// problem runs the very code of its own instantiation: the same bits.
+template <int BM, int BN, int WM, int WN, bool B_KC, bool VEC, class Epi>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_group_mixed_kernel(GemmGroup<Epi> g) {
+    using CoreK = GemmCore<BM, BN, WM, WN, true, B_KC, VEC>;
+    using CoreR = GemmCore<BM, BN, WM, WN, false, B_KC, VEC>;
+    __shared__ __attribute__((aligned(16))) float smem[CoreK::SMEM_FLOATS > CoreR::SMEM_FLOATS ? CoreK::SMEM_FLOATS : CoreR::SMEM_FLOATS];
+    const int id = (int)blockIdx.x < g.xcd ? xcd_swizzle((int)blockIdx.x, g.xcd) : (int)blockIdx.x;
+    int q = 0;
+    while (q + 1 < g.n && id >= g.first[q + 1]) ++q;
+    const int b = id - g.first[q];
+    const int z = b / g.tiles[q], t = b % g.tiles[q];
+    if ((g.a_kc_mask >> q) & 1u) gemm_tile_at<BM, BN, WM, WN, true, B_KC, VEC, Epi>(g.p[q], g.e[q], g.slab[q], z, (t / g.tiles_n[q]) * BM, (t % g.tiles_n[q]) * BN, smem);
+    else gemm_tile_at<BM, BN, WM, WN, false, B_KC, VEC, Epi>(g.p[q], g.e[q], g.slab[q], z, (t / g.tiles_n[q]) * BM, (t % g.tiles_n[q]) * BN, smem);
 }
 
 // Stream-K: G persistent blocks (512 = two per CU by default) share the (tile, k-tile) iteration space evenly, so every CU gets the same MFMA work whatever

@@ -35,6 +35,9 @@
 #define SNAG_RO_PRESPLIT 1       // 1: the weights are split into k-tile images by a launch of their own (readout_presplit_kernel) and copied into the LDS;
 #endif                           // 0: the loop splits them itself -- one 16-byte load and two split_pair per thread and k-tile with 512 threads
                                  // (same box: 4.7 + 58.8 us against 63.9 us in one launch; step 487.5 against 489.8 us)
+#ifndef SNAG_RO_PP
+#define SNAG_RO_PP 1             // 1: the two halves of a workgroup run every k-loop half an iteration apart (ping-pong): a barrier cuts an iteration into its
+#endif                           // memory half (fragment reads, the half's share of the next weight image, the stream's loads) and its matrix half (six MFMAs)
 #ifndef SNAG_RO_STAMP
 #define SNAG_RO_STAMP 0          // diagnostic build: cycle stamps of one wave printed per launch
 #endif
@@ -225,6 +228,20 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
         stage_b(S, bbuf + (cur ^ 1) * kBImg);
         fetch_b(S, i0 + kt + 5);
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && SNAG_RO_PP
+        // PING-PONG (NH = 2): everything above is the MEMORY half of the iteration -- it ends with the fragments in registers and this half's
+        // share of image i + 1 in the LDS -- everything below the MATRIX half.  The second half-workgroup entered the k-loop one barrier late
+        // (see the loop), so while one half multiplies the other one reads and stages: a SIMD's matrix pipe always has exactly one of its two
+        // waves on it, and the LDS traffic of an iteration (48 KB of fragment reads, 12 KB of image writes) runs in the MFMAs' shadow instead
+        // of in front of them.  Image i + 1 is complete one barrier after the late half's memory half, one barrier before the early half reads it;
+        // the image it replaces was last read two barriers earlier.
+        if constexpr (NH == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !(SNAG_RO_ABLATE & 2)
 #define SNAG_RO_TERM(X, Y) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.X, bf[j].Y, acc[j], 0, 0, 0);
         SNAG_RO_TERM(l, h)
@@ -235,7 +252,17 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
         SNAG_RO_TERM(h, h)
 #undef SNAG_RO_TERM
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && SNAG_RO_PP
+        if constexpr (NH == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            __syncthreads();
+        }
+#else
         __syncthreads();
+#endif
     };
 
     Panel<BM> pr;
@@ -318,6 +345,9 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
         const int i0 = tile * 8;
+#if defined(__HIP_DEVICE_COMPILE__) && SNAG_RO_PP
+        if (NH == 2 && half == 1) __builtin_amdgcn_s_barrier();          // the late half: its memory halves face the early half's matrix halves
+#endif
 #pragma unroll 1
         for (int kt = 0; kt < 8; kt += 4) {
             sub_iteration(kt, S1{}, i0);
@@ -325,6 +355,9 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
             sub_iteration(kt + 2, S3{}, i0);
             sub_iteration(kt + 3, S0{}, i0);
         }
+#if defined(__HIP_DEVICE_COMPILE__) && SNAG_RO_PP
+        if (NH == 2 && half == 0) __builtin_amdgcn_s_barrier();          // the halves meet again: the epilogues below run side by side
+#endif
         SNAG_RO_ST(1);
         // accumulators -> the row tile
 #pragma unroll

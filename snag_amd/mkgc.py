@@ -461,18 +461,21 @@ class MKGCHotPath:
     def _gemm(self, *a, **k):
         call("snag_gemm_f32", ctypes.byref(self._gemm_desc(*a, **k)), self._st)
 
-    @staticmethod
-    def _balanced_splits(shapes):
+    l1_round = 256          # workgroups one launch of eight-wave tiles should fill (one per CU; 512 = two per CU: tools/ab experiments only --
+                            # the kernel's 176 registers admit one eight-wave workgroup per CU)
+
+    @classmethod
+    def _balanced_splits(cls, shapes):
         """K splits for long-K problems [(M, K)] that share ONE launch of eight-wave 256-row tiles (snag_gemm_f32_group): every
         workgroup should walk about the same number of k-tiles and all row tiles x splits should fit one round of 256 workgroups."""
         tiles = [(m + 255) // 256 for m, _ in shapes]
         nk = [(k + 15) // 16 for _, k in shapes]
-        per_wg = max(1.0, sum(t * k for t, k in zip(tiles, nk)) / 256.0)
+        per_wg = max(1.0, sum(t * k for t, k in zip(tiles, nk)) / float(cls.l1_round))
         cap = [max(1, k // 64) for _, k in shapes]
         s = [max(1, min(c, int(k / per_wg))) for k, c in zip(nk, cap)]
         while True:      # left-over workgroups go to the problem with the longest k-range per workgroup
             i = max(range(len(s)), key=lambda j: nk[j] / s[j])
-            if s[i] >= cap[i] or sum(t * x for t, x in zip(tiles, s)) + tiles[i] > 256:
+            if s[i] >= cap[i] or sum(t * x for t, x in zip(tiles, s)) + tiles[i] > cls.l1_round:
                 return s
             s[i] += 1
 
