@@ -542,12 +542,7 @@ static GemmPlan plan_gemm(const snag_gemm_desc* d) {
     p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb; p.M = d->M; p.N = d->N; p.K = d->K;
     p.a_vec = (d->lda % 4 == 0) && (((uintptr_t)d->A & 15) == 0);
     p.b_vec = (d->ldb % 4 == 0) && (((uintptr_t)d->B & 15) == 0);
-#if SNAG_GEMM_ABLATE            // -DSNAG_GEMM_ABLATE=1 timing builds only (tools/build_variant.sh): parts of the loops switched off at run time
-    static const int dbg = env_int("SNAG_GEMM_DBG");
-    p.dbg = dbg;
-#else
     p.dbg = 0;
-#endif
     p.xcd = 1;                  // XCD-aware workgroup -> tile mapping (xcd_swizzle)
     e.C = d->C; e.ldc = d->ldc; e.bias = d->bias; e.alpha = d->alpha; e.act = d->act; e.pre = d->pre_act;
     e.mask = d->keep_mask; e.ldm = d->ldmask > 0 ? d->ldmask : d->N; e.mscale = d->keep_scale; e.add1 = d->add1; e.ld1 = d->ld1; e.add2 = d->add2; e.ld2 = d->ld2;
@@ -649,10 +644,6 @@ int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st) {
     if (log_shapes())
         fprintf(stderr, "snag_gemm M=%d N=%d K=%d a_kc=%d b_kc=%d tile=%s splits=%d fast=%d acc=%d\n", p.M, p.N, p.K, (int)d->a_kcontig,
                 (int)d->b_kcontig, pl.wide ? "128x160" : pl.pp ? "256x128" : pl.big ? "128x128" : "64x128", splits, (int)e.fast, (int)d->accumulate);
-#if SNAG_GEMM_BK == 16 && SNAG_GEMM_BF16X == 0          // (the 128 x 160 tile: f32-MFMA builds only)
-    if (pl.wide) launch_cfg<128, 160, 32, 160>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
-    else
-#endif
     if (pl.big && pl.pp) launch_cfg<256, 128, 32, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else if (pl.big) launch_cfg<128, 128, 32, 128>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
     else launch_cfg<64, 128, 32, 64>(p, e, slab, splits, d->a_kcontig, d->b_kcontig, st);
@@ -1004,9 +995,3 @@ extern "C" SNAG_API int snag_gram_f32(const float* Z, int64_t ldz, int n, int k,
 
 extern "C" SNAG_API int64_t snag_gemm_workspace_floats(int M, int N, int K) { return gemm_workspace_floats(M, N, K); }
 
-#if SNAG_GEMM_STAMP
-// diagnostic builds only (not part of the ABI): the s_memtime stamps of the last ping-pong GEMM launch
-extern "C" __attribute__((visibility("default"))) int snag_debug_read_gemm_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(snag::g_gemm_stamps), sizeof(unsigned long long) * 72, 0, hipMemcpyDeviceToHost);
-}
-#endif

@@ -5,15 +5,13 @@
 // Each operand is either "K-contiguous" (element (r,k) at ptr[r*ld + k]: activations [rows,K], nn.Linear weights W[out,in]) or
 // "row-contiguous" (element (r,k) at ptr[k*ld + r]: the transposed uses in the projections and the backward GEMMs).
 //
-// Three main loops live in GemmCore, chosen at compile time (DESIGN.md par. 4):
-//   * run_presplit, row-private (kRowPrivate: waves stacked along M; long K): the default build multiplies f32 values as six bf16
-//     MFMA products of exactly split operands (SNAG_GEMM_BF16X = 6).  A wave's 32 rows of A go from global memory to its registers
+// Two main loops live in GemmCore::run_presplit, chosen at compile time (DESIGN.md par. 4):
+//   * row-private (kRowPrivate: waves stacked along M; long K): f32 values are multiplied as six bf16 MFMA products of exactly split
+//     operands.  A wave's 32 rows of A go from global memory to its registers
 //     and are split there; B is split once per workgroup into an LDS image in MFMA operand order.  Two forms: 128 x 128, four
 //     waves; 256 x 128, eight waves in two groups running half an iteration apart (kPingPong: outputs one column tile wide).
-//   * run_presplit, 64 x 128 tile (2 x 2 waves; short K, small outputs): both operands are split once per workgroup into LDS images.
-//   * run_loop: the f32-MFMA form (v_mfma_f32_32x32x2_f32; -DSNAG_GEMM_BF16X=0) and the in-fragment split (the 128 x 160 tile,
-//     reachable through SNAG_GEMM_TILE=3 only): f32 tiles in LDS -- K-contiguous tiles row-major with XOR-swizzled 16-byte chunks,
-//     row-contiguous tiles [k][row] -- filled by LDS-DMA or through registers, double-buffered.
+//   * 64 x 128 tile (2 x 2 waves; short K, small outputs; the 128 x 128 Gram tile likewise): both operands are split once per workgroup
+//     into LDS images.
 // Within a k-tile the sum runs over a fixed permutation of k, the same for both operands.  256 threads = 4 waves (512 = 8 in the ping-pong form).
 #pragma once
 #include <type_traits>
@@ -33,95 +31,19 @@ using lds_float = float;
 using lds_float4 = float4;
 #endif
 
-#ifndef SNAG_GEMM_BK
-#define SNAG_GEMM_BK 16
-#endif
-constexpr int kBK = SNAG_GEMM_BK;          // k-tile depth: 16, or 32 (A/B switch: half the barriers per MFMA, twice the LDS)
-static_assert(kBK == 16 || kBK == 32, "k-tile depth");
+constexpr int kBK = 16;          // k-tile depth
 constexpr int kCPR = kBK / 4;               // 16-byte chunks per K-contiguous tile row
-// XOR swizzle of the chunk index: 16 consecutive rows x one chunk column must hit 16 distinct 16-byte bank slots
-__host__ __device__ constexpr int swz(int row) { return kBK == 16 ? ((row >> 2) & 3) : ((row >> 1) & 7); }
 
-// Build-time structure switches (A/B'ed on one device):
-//   SNAG_GEMM_SWZ  1: K-contiguous tiles stay row-major in LDS with XOR-swizzled 16-byte chunks (b128 in, b128 out)
-//                  0: K-contiguous tiles are transposed to k-major on the way in (4x ds_write_b32, b32 fragment reads)
-//   SNAG_GEMM_PIPE 1: software pipeline (fragments of tile t+1 and global loads of tile t+2 issued before the MFMAs of t)
-//                  0: load fragments, MFMA chain, stage tile t+1
-#ifndef SNAG_GEMM_SWZ
-#define SNAG_GEMM_SWZ 1
-#endif
-#ifndef SNAG_GEMM_PIPE
-#define SNAG_GEMM_PIPE 0
-#endif
-//   SNAG_GEMM_DMA  1: the unpredicated (VEC) kernels fetch full k-tiles with global_load_lds_dwordx4 (LDS-DMA: no VGPR
-//                  staging, no ds_write); needs SNAG_GEMM_SWZ=1 (dense tiles: the DMA writes 64 lanes x 16 B linearly)
-#ifndef SNAG_GEMM_DMA
-#define SNAG_GEMM_DMA 1
-#endif
-//   SNAG_GEMM_BF16X 0: v_mfma_f32_32x32x2_f32 on the f32 operands (157 TF peak)
-//                   6: every operand value is split EXACTLY into three bf16 pieces a = h + m + l (round-to-nearest each time, the
-//                      two remainders are exact in f32) in registers, and a product a*b becomes the six bf16 MFMA products with weight
-//                      >= 2^-16: h*h, h*m, m*h, m*m, h*l, l*h (v_mfma_f32_32x32x16_bf16, f32 accumulation; the three dropped
-//                      products m*l, l*m, l*l are below 2^-23 of a*b -- the size of f32's own product rounding).  The bf16 matrix
-//                      rate is 16x the f32 one, so six products still cost 3/8 of the f32 MFMA time.
-//                   9: all nine products
-#ifndef SNAG_GEMM_BF16X
-#define SNAG_GEMM_BF16X 6
-#endif
-#ifndef SNAG_GEMM_ABLATE
-#define SNAG_GEMM_ABLATE 0
-#endif
-#ifndef SNAG_GEMM_PIN_READS
-#define SNAG_GEMM_PIN_READS 0
-#endif
-#ifndef SNAG_GEMM_STAMP
-#define SNAG_GEMM_STAMP 0                // diagnostic builds only: s_memtime stamps around the halves of four ping-pong iterations (tools/stamp_gemm.py)
-#endif
-#if SNAG_GEMM_STAMP
-__device__ unsigned long long g_gemm_stamps[2 * 4 * 9];
-#define SNAG_STAMP(I, P) do { __builtin_amdgcn_sched_barrier(0); if ((kt >> 2) == 6) stamp[I][P] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define SNAG_STAMP(I, P) do { } while (0)
-#endif
-#ifndef SNAG_GEMM_SKIP_ASPLIT
-#define SNAG_GEMM_SKIP_ASPLIT 0
-#endif
-#ifndef SNAG_GEMM_STREAM_ONLY
-#define SNAG_GEMM_STREAM_ONLY 0          // timing experiment only (wrong products): the ping-pong loop issues the very same loads (both operands, same descriptors,
-#endif                                   // same order, same counted waits, same barriers) and the same slab stores, but no split, no LDS image, no fragment reads, no MFMA
-#ifndef SNAG_GEMM_PP_EARLY_H
-#define SNAG_GEMM_PP_EARLY_H 1           // ping-pong loop: the h planes of the B fragments (what the first four MFMAs multiply) are read at the END of the
-#endif                                   // memory half, in front of the barrier -- the image of tile kt has been complete for a whole interval by then.
-                                         // Same box, in the step: first projections 109.7 -> 106.3 us, similarity GEMM 1.628 -> 1.598 ms; the l plane
-                                         // there too: 101.0 vs 97.9 us for the weight gradients, 1.68 vs 1.63 ms; all three: 106 / 104 us, 1.71 ms
-#ifndef SNAG_GEMM_PP_SETS
-#define SNAG_GEMM_PP_SETS 4              // ping-pong loop: register sets = k-tiles in flight per wave (tile t lives in set t % SETS)
-#endif
-#ifndef SNAG_GEMM_PP_LATE_READS
-#define SNAG_GEMM_PP_LATE_READS 1        // ping-pong loop: B fragments are read in the MATRIX half (in the MFMAs' shadow), three B images
-#endif
-#ifndef SNAG_GEMM_PP_PRIO
-#define SNAG_GEMM_PP_PRIO 0
-#endif
 #ifndef SNAG_GEMM_SK_WAVES
 #define SNAG_GEMM_SK_WAVES 2             // A/B: waves per SIMD the stream-K kernel is compiled for (4: at most 128 registers)
 #endif
-#ifndef SNAG_GEMM_PRESPLIT_KC
-#define SNAG_GEMM_PRESPLIT_KC 1          // A/B: 0 keeps the in-fragment split for kernels with a K-contiguous operand
-#endif
-constexpr int kBf16x = SNAG_GEMM_BF16X;
-static_assert(kBf16x == 0 || kBf16x == 6 || kBf16x == 9, "SNAG_GEMM_BF16X");
-constexpr bool kDma = (SNAG_GEMM_DMA != 0) && (SNAG_GEMM_SWZ != 0);
-constexpr bool kSwz = SNAG_GEMM_SWZ != 0;
-constexpr bool kPipe = SNAG_GEMM_PIPE != 0;
-
-// LDS leading dimension of a tile: swizzled row-major tiles are dense; k-major tiles are padded (+2 makes the four
-// transposing ds_write_b32 of a float4 conflict-free, +4 keeps ds_write_b128 rows 16-byte aligned)
-template <int BR, bool KC>
-struct TileLd {
-    static constexpr int value = KC ? (kSwz ? kBK : BR + 2) : (kSwz ? BR : BR + 4);
-    static constexpr int floats = KC ? (kSwz ? BR * kBK : kBK * (BR + 2)) : (kSwz ? kBK * BR : kBK * (BR + 4));
-};
+// fp32 products on the bf16 matrix pipe: every operand value is split EXACTLY into three bf16 pieces a = h + m + l (round-to-nearest each
+// time, the two remainders are exact in f32), and a product a*b becomes the six bf16 MFMA products of weight >= 2^-16: h*h, h*m, m*h, m*m,
+// h*l, l*h (v_mfma_f32_32x32x16_bf16, f32 accumulation; the three dropped products m*l, l*m, l*l are below 2^-23 of a*b -- the size of f32's
+// own product rounding).  The bf16 matrix rate is 16x the f32 one, so six products cost 3/8 of the f32 MFMA time.  (The f32-MFMA loop, the
+// nine-product form, 32-deep k-tiles and the un-swizzled / software-pipelined / LDS-DMA f32 tile loops of rounds 1-3 are gone: no shape of the
+// build reached them; HISTORY.md has their measurements.)
+constexpr int kBf16x = 6;
 
 struct GemmOperands {
     const float* A;
@@ -143,178 +65,6 @@ __device__ __forceinline__ int xcd_swizzle(int orig, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (orig >> 3);
 }
 
-// --- global -> register staging ---------------------------------------------------------------
-// One "slot" is a float4: along k for K-contiguous operands, along the row index otherwise.
-template <int BR, bool KC>
-struct Stager {
-    static constexpr int TOTAL = BR * kBK / 4;                 // float4 slots per tile
-    static constexpr int SLOTS = (TOTAL + 255) / 256;          // per thread; the last one may be half used (BR = 160: waves 0-1 only)
-    static_assert(TOTAL % 128 == 0, "a partly used slot must still split on a wave boundary");
-    static constexpr bool used(int s, int slot) { return (s + 1) * 256 <= TOTAL || slot < TOTAL; }
-    float4 r[SLOTS];
-    const float* base[SLOTS];      // per-slot address of k = 0, rows clamped (hot-path loader only)
-
-    __device__ __forceinline__ void init(const float* __restrict__ P, int64_t ld, int row0, int nrows, int tid) {
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int slot = min(tid + 256 * s, TOTAL - 1);
-            if (KC) {
-                const int row = min(row0 + slot / (kBK / 4), nrows - 1);
-                base[s] = P + (int64_t)row * ld + (slot % (kBK / 4)) * 4;
-            } else {
-                const int row = max(0, min(row0 + (slot % (BR / 4)) * 4, nrows - 4));
-                base[s] = P + (int64_t)(slot / (BR / 4)) * ld + row;
-            }
-        }
-    }
-
-    // LDS-DMA fetch of one full k-tile: lane L of wave w writes the 16-byte chunk at tile position 256*s + 64*w + L, so
-    // it must READ the chunk that belongs there.  Row-contiguous tiles are linear in slot order already; K-contiguous
-    // tiles store chunk c of a row at position c ^ ((row >> 2) & 3), an involution, so position p holds chunk p ^ swz.
-    __device__ __forceinline__ void init_dma(const float* __restrict__ P, int64_t ld, int row0, int nrows, int tid) {
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int slot = min(tid + 256 * s, TOTAL - 1);
-            if (KC) {
-                const int lrow = slot / (kBK / 4);
-                const int c = (slot % (kBK / 4)) ^ swz(lrow);
-                base[s] = P + (int64_t)min(row0 + lrow, nrows - 1) * ld + 4 * c;
-            } else {
-                const int row = max(0, min(row0 + (slot % (BR / 4)) * 4, nrows - 4));
-                base[s] = P + (int64_t)(slot / (BR / 4)) * ld + row;
-            }
-        }
-    }
-
-    __device__ __forceinline__ void dma(lds_float* tile, int64_t ld, int k0, int wave) const {
-        [[maybe_unused]] const int64_t off = KC ? (int64_t)k0 : (int64_t)k0 * ld;      // (the host pass compiles the body away)
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            if (!used(s, 256 * s + 64 * wave)) continue;        // wave-uniform
-#if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base[s] + off),
-                                             (__attribute__((address_space(3))) void*)(tile + (256 * s + 64 * wave) * 4), 16, 0, 0);
-#endif
-        }
-    }
-
-    // FULL: the whole k-tile lies inside [kbeg, kend) -> no k predicates; rows past the edge are clamped to the
-    // last valid row (their products land in accumulator rows/cols the epilogue discards).
-    template <bool FULL, bool VEC>
-    __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int vec_ok, int row0, int nrows, int k0,
-                                         int kend, int tid) {
-        if (FULL && VEC) {
-            // hot path: whole tile in range along k, 16-byte loads legal (decided on the host): no predicates, and the
-            // only per-tile address arithmetic is one wave-uniform offset.  Rows past the edge were clamped in init();
-            // their products land in accumulator rows/cols the epilogue never stores.
-            const int64_t off = KC ? (int64_t)k0 : (int64_t)k0 * ld;
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s)
-                if (used(s, tid + 256 * s)) r[s] = *reinterpret_cast<const float4*>(base[s] + off);
-            return;
-        }
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int slot = tid + 256 * s;
-            if (!used(s, slot)) continue;
-            int row, k;
-            if (KC) {
-                row = row0 + slot / (kBK / 4);
-                k = k0 + (slot % (kBK / 4)) * 4;
-            } else {
-                row = row0 + (slot % (BR / 4)) * 4;
-                k = k0 + slot / (BR / 4);
-            }
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (KC) {
-                if (FULL) {
-                    const float* g = P + (int64_t)min(row, nrows - 1) * ld + k;
-                    if (vec_ok) v = *reinterpret_cast<const float4*>(g);
-                    else v = make_float4(g[0], g[1], g[2], g[3]);
-                } else if (row < nrows) {
-                    const float* g = P + (int64_t)row * ld + k;
-                    if (vec_ok && k + 3 < kend) {
-                        v = *reinterpret_cast<const float4*>(g);
-                    } else {
-                        if (k + 0 < kend) v.x = g[0];
-                        if (k + 1 < kend) v.y = g[1];
-                        if (k + 2 < kend) v.z = g[2];
-                        if (k + 3 < kend) v.w = g[3];
-                    }
-                }
-            } else {
-                if (FULL || k < kend) {
-                    const float* g = P + (int64_t)k * ld + row;
-                    if (vec_ok && row + 3 < nrows) {
-                        v = *reinterpret_cast<const float4*>(g);
-                    } else {
-                        if (row + 0 < nrows) v.x = g[0];
-                        if (row + 1 < nrows) v.y = g[1];
-                        if (row + 2 < nrows) v.z = g[2];
-                        if (row + 3 < nrows) v.w = g[3];
-                    }
-                }
-            }
-            r[s] = v;
-        }
-    }
-
-    // SWZ & KC: tile[row][16] with swizzled 16-byte chunks; otherwise tile[k][LD]
-    __device__ __forceinline__ void store(lds_float* tile, int tid) const {
-        constexpr int LD = TileLd<BR, KC>::value;
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int slot = tid + 256 * s;
-            if (!used(s, slot)) continue;
-            if (KC) {
-                const int row = slot / (kBK / 4);
-                const int c = slot % (kBK / 4);
-                if (kSwz) {
-                    *reinterpret_cast<lds_float4*>(tile + row * kBK + 4 * (c ^ swz(row))) = r[s];
-                } else {
-                    tile[(4 * c + 0) * LD + row] = r[s].x;
-                    tile[(4 * c + 1) * LD + row] = r[s].y;
-                    tile[(4 * c + 2) * LD + row] = r[s].z;
-                    tile[(4 * c + 3) * LD + row] = r[s].w;
-                }
-            } else {
-                const int row = (slot % (BR / 4)) * 4;
-                const int k = slot / (BR / 4);
-                *reinterpret_cast<lds_float4*>(tile + k * LD + row) = r[s];
-            }
-        }
-    }
-};
-
-// operand fragments of one k-tile for NF 32-row fragments: f[t][n] feeds MFMA k-step t.
-// SWZ: t = 4*cp + j <-> k = 8cp + 4h + j (a permutation of k shared by both operands); else k = 2t + h.
-template <int BR, bool KC, int NF>
-__device__ __forceinline__ void load_fragments(const lds_float* tile, int row0, int li, int lh, float (&f)[kBK / 2][NF]) {
-    constexpr int LD = TileLd<BR, KC>::value;
-#pragma unroll
-    for (int n = 0; n < NF; ++n) {
-        const int row = row0 + 32 * n + li;
-        if (kSwz) {
-#pragma unroll
-            for (int cp = 0; cp < kBK / 8; ++cp) {
-                if (KC) {
-                    const int c = 2 * cp + lh;
-                    const float4 v = *reinterpret_cast<const lds_float4*>(tile + row * kBK + 4 * (c ^ swz(li)));
-                    f[4 * cp + 0][n] = v.x;
-                    f[4 * cp + 1][n] = v.y;
-                    f[4 * cp + 2][n] = v.z;
-                    f[4 * cp + 3][n] = v.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) f[4 * cp + j][n] = tile[(8 * cp + 4 * lh + j) * LD + row];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < kBK / 2; ++t) f[t][n] = tile[(2 * t + lh) * LD + row];
-        }
-    }
-}
 
 #if defined(__HIP_DEVICE_COMPILE__)
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -408,7 +158,7 @@ struct SplitStager {
     //   K-contiguous,   BR = 128: thread = (rows t / 4 and t / 4 + 64, chunk t % 4)      2 dwordx4 loads
     // (row-contiguous: a wave-instruction covers 64 consecutive rows of one k, 256 contiguous bytes; K-contiguous: 4 adjacent
     // lanes cover the 64 contiguous bytes a row has in this k-tile.)
-    float r[SNAG_GEMM_PP_SETS < 4 ? 4 : SNAG_GEMM_PP_SETS][KPT];                 // register sets: two in flight (tiles t+1, t+2) in the four-wave loops, four in the ping-pong loop
+    float r[4 < 4 ? 4 : 4][KPT];                 // register sets: two in flight (tiles t+1, t+2) in the four-wave loops, four in the ping-pong loop
     const char* ubase;               // wave-uniform.  row-contiguous: element (k = kbeg, row 0); K-contiguous: element (row0, k = kbeg)
     int64_t ldb;                     // pitch in bytes
     uint32_t voff, voff2;            // the lane's part of the address, bytes (rows past the edge clamped: their products are never stored)
@@ -512,7 +262,7 @@ struct SplitStager {
 //   K-contiguous:   2 dwordx4 loads (bytes 16 h and 32 + 16 h of the row's 64 bytes in this k-tile)
 template <bool KC, bool VK = true>
 struct FragLoader {
-    float r[SNAG_GEMM_PP_SETS < 4 ? 4 : SNAG_GEMM_PP_SETS][8];
+    float r[4 < 4 ? 4 : 4][8];
     const char* ubase;
     int64_t ldb;
     uint32_t voff;
@@ -575,13 +325,8 @@ struct FragLoader {
     __device__ __forceinline__ void split(int s, Split3& f) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         uint32_t h[4], m[4], l[4];
-#if SNAG_GEMM_SKIP_ASPLIT     // timing experiment only (wrong products): the loaded words taken as if they were split planes
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { h[j] = __float_as_uint(r[s][j]); m[j] = __float_as_uint(r[s][4 + j]); l[j] = h[j] ^ m[j]; }
-#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) split_pair(r[s][2 * j], r[s][2 * j + 1], h[j], m[j], l[j]);
-#endif
         using u4 = __attribute__((ext_vector_type(4))) uint32_t;
         f.h = __builtin_bit_cast(bf16x8, (u4){h[0], h[1], h[2], h[3]});
         f.m = __builtin_bit_cast(bf16x8, (u4){m[0], m[1], m[2], m[3]});
@@ -621,23 +366,20 @@ __device__ __forceinline__ bf16x8 load_split_plane(const unsigned char* image, i
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC>
 struct GemmCore {
     static constexpr int TM = WM / 32, TN = WN / 32;
-    static constexpr int A_BUF = TileLd<BM, A_KC>::floats, B_BUF = TileLd<BN, B_KC>::floats, B_BASE = 2 * A_BUF;
-    static constexpr int TILE_FLOATS = 2 * (A_BUF + B_BUF);
     static constexpr int CW = (WN % 64 == 0) ? 64 : 32;   // epilogue staging chunk: 32 rows x CW columns per wave at a time
     static constexpr int NW = (BM / WM) * (BN / WN), NT = 64 * NW;       // waves / threads per workgroup
     static constexpr int STAGE_FLOATS = NW * 32 * CW;
     // pre-split staging loop: split-bf16 builds, 64 / 128-row operand tiles (the 128 x 160 tile keeps the in-fragment split)
     static constexpr bool kPresplit = kBf16x != 0 && (BM == 64 || BM == 128 || (BM == 256 && WM == 32 && WN == BN)) && (BN == 64 || BN == 128) && kBK == 16 &&
-                                      (SNAG_GEMM_PRESPLIT_KC != 0 || (!A_KC && !B_KC));
+                                      (1 != 0 || (!A_KC && !B_KC));
     // waves stacked along M (each wave's 32 rows are its own): the A operand never goes through the LDS (FragLoader)
     static constexpr bool kRowPrivate = kPresplit && WN == BN && WM == 32;
     static constexpr int PS_STAGE_FLOATS = 6 * ((kRowPrivate ? 0 : BM) + BN) * 16 / 4;          // one stage: both images (B's only when row-private)
     // (the eight-wave ping-pong loop keeps THREE B images: a group reads the fragments of tile kt inside its matrix half, while the other
     // group is already writing tile kt+2 -- SNAG_GEMM_PP_LATE_READS)
-    static constexpr int PS_IMAGES = (kRowPrivate && (BM / WM) * (BN / WN) == 8 && SNAG_GEMM_PP_LATE_READS) ? 3 : 2;
+    static constexpr int PS_IMAGES = (kRowPrivate && (BM / WM) * (BN / WN) == 8 && 1) ? 3 : 2;
     static constexpr int PS_FLOATS = kPresplit ? PS_IMAGES * PS_STAGE_FLOATS : 0;
-    static constexpr int SMEM_FLOATS_ = TILE_FLOATS > STAGE_FLOATS ? TILE_FLOATS : STAGE_FLOATS;
-    static constexpr int SMEM_FLOATS = kPresplit ? (PS_FLOATS > STAGE_FLOATS ? PS_FLOATS : STAGE_FLOATS) : SMEM_FLOATS_;
+    static constexpr int SMEM_FLOATS = PS_FLOATS > STAGE_FLOATS ? PS_FLOATS : STAGE_FLOATS;
     static_assert(NW == 4 || NW == 8, "four or eight waves per block");
     // eight waves stacked along M: two groups of four run the k-loop half an iteration apart (ping-pong, run_presplit)
     static constexpr bool kPingPong = kRowPrivate && NW == 8;
@@ -645,67 +387,12 @@ struct GemmCore {
 
     f32x16 acc[TM][TN];
 
-    // one k-tile's worth of matrix work: av[s][i] / bv[s][j] are this lane's operand values of k-step s
-    __device__ __forceinline__ void mfma_chain(const float (&av)[kBK / 2][TM], const float (&bv)[kBK / 2][TN]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (kBf16x == 0) {
-#pragma unroll
-            for (int s = 0; s < kBK / 2; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[i][j], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int g = 0; g < kBK / 16; ++g) {
-                Split3 a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    float f[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = av[8 * g + e][i];
-                    a[i].from(f);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float f[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = bv[8 * g + e][j];
-                    b[j].from(f);
-                }
-                // smallest products first; one pass over the accumulators per product keeps dependent MFMAs apart
-#define SNAG_MFMA_TERM(ACC, X, Y)                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                     \
-        ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].X, b[j].Y, ACC[i][j], 0, 0, 0);
-                if constexpr (kBf16x == 9) {
-                    SNAG_MFMA_TERM(acc, l, l)
-                    SNAG_MFMA_TERM(acc, l, m)
-                    SNAG_MFMA_TERM(acc, m, l)
-                }
-                SNAG_MFMA_TERM(acc, l, h)
-                SNAG_MFMA_TERM(acc, h, l)
-                SNAG_MFMA_TERM(acc, m, m)
-                SNAG_MFMA_TERM(acc, m, h)
-                SNAG_MFMA_TERM(acc, h, m)
-                SNAG_MFMA_TERM(acc, h, h)
-#undef SNAG_MFMA_TERM
-            }
-        }
-#endif
-    }
-
-    // the six (nine) products of one k-tile on pre-split fragments
+    // the six products of one k-tile on pre-split fragments (smallest first; one pass over the accumulators per product keeps dependent MFMAs apart)
     __device__ __forceinline__ void mfma_split(const Split3 (&a)[TM], const Split3 (&b)[TN]) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SNAG_MFMA_TERM(ACC, X, Y)                                                                                     \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                     \
         ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].X, b[j].Y, ACC[i][j], 0, 0, 0);
-        if constexpr (kBf16x == 9) {
-            SNAG_MFMA_TERM(acc, l, l)
-            SNAG_MFMA_TERM(acc, l, m)
-            SNAG_MFMA_TERM(acc, m, l)
-        }
         SNAG_MFMA_TERM(acc, l, h)
         SNAG_MFMA_TERM(acc, h, l)
         SNAG_MFMA_TERM(acc, m, m)
@@ -742,18 +429,6 @@ struct GemmCore {
                 Split3 b[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + cur * STAGE, wn0 + 32 * j + li, lh, b[j]);
-#if defined(__HIP_DEVICE_COMPILE__) && SNAG_GEMM_PIN_READS
-                __builtin_amdgcn_sched_barrier(0);      // all fragment reads issue before anything else of the iteration (left alone, the
-#endif                                                  // compiler re-reads fragment by fragment right in front of each MFMA: exposed LDS latency)
-#if SNAG_GEMM_ABLATE
-                if (!(p.dbg & 16)) fa.split(set, a_nxt[0]);
-                if (!(p.dbg & 32)) fa.load(set, kt + 3, kleft);
-                if (!(p.dbg & 16)) sb.split_store(set, sm + (cur ^ 1) * STAGE);
-                if (!(p.dbg & 32)) sb.load(set, kt + 3, kleft);
-                if (!(p.dbg & 8)) mfma_split(a_cur, b);
-                a_cur[0] = a_nxt[0];
-                if (!(p.dbg & 4)) __syncthreads();
-#else
                 fa.split(set, a_nxt[0]);
                 fa.load(set, kt + 3, kleft);
                 sb.split_store(set, sm + (cur ^ 1) * STAGE);
@@ -761,7 +436,6 @@ struct GemmCore {
                 mfma_split(a_cur, b);
                 a_cur[0] = a_nxt[0];
                 __syncthreads();
-#endif
             };
             // Eight waves: PING-PONG.  The two groups of four waves (one wave of each group per SIMD) run the same loop half an
             // iteration apart, and an iteration is cut by a barrier into its memory half (fragment reads, the A split, the group's
@@ -771,83 +445,42 @@ struct GemmCore {
             // the bytes in flight per CU of the four-wave loops).  B image of tile kt+1: group 0's half is written
             // in interval 2 kt, group 1's in interval 2 kt + 1, both before anyone reads it (group 0 in interval 2 kt + 2); the
             // buffer it replaces was last read in intervals 2 kt - 2 / 2 kt - 1.
-#if SNAG_GEMM_STAMP
-            unsigned long long stamp[4][9] = {};
-#endif
             // In-kernel stamps (tools/stamp_gemm.py) of the first form of this loop -- fragment reads at the END of the memory half,
             // behind the split's VALU block -- showed the memory half (780-1,100 cycles with every load landed) longer than the matrix
             // half (~860): the intervals ran at the pace of the feeding group.  The fragment reads therefore moved INTO the matrix half
             // (SNAG_GEMM_PP_LATE_READS): twelve ds_read_b128 in the shadow of 24 MFMAs cost next to nothing there (2 per MFMA gap are
             // free, MI355X_MICROARCH.md "LDS"), the memory half is the split and the loads alone.  A group then reads tile kt one
             // interval later than before -- while the other group writes tile kt+2 -- hence three B images instead of two.
-            constexpr int kPPSets = SNAG_GEMM_PP_SETS;
+            constexpr int kPPSets = 4;
             static_assert(kPPSets == 4 || kPPSets == 6 || kPPSets == 8, "ping-pong register sets");
             [[maybe_unused]] int rd_off = 0, wr_off = STAGE;               // byte offsets of the image being read (tile kt) / written (tile kt+1)
             [[maybe_unused]] uint32_t stream_sink = 0;
             [[maybe_unused]] auto pp_iteration = [&](int kt, auto S) {
                 constexpr int set = decltype(S)::value;
                 [[maybe_unused]] Split3 b[TN];
-                SNAG_STAMP(set, 0);
-#if !SNAG_GEMM_PP_LATE_READS
-#pragma unroll
-                for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + rd_off, wn0 + 32 * j + li, lh, b[j]);
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && SNAG_GEMM_PIN_READS
-                __builtin_amdgcn_sched_barrier(0);      // the fragment reads issue first: their latency runs under the A split
-#endif
-#if SNAG_GEMM_ABLATE       // -DSNAG_GEMM_ABLATE=1 builds only (results are wrong): SNAG_GEMM_DBG & 16 / 64 / 32 / 8 drop the A split / the B split + image write / the loads / the MFMAs
-                const bool do_asplit = !(p.dbg & 16), do_bsplit = !(p.dbg & 64), do_load = !(p.dbg & 32);
-#else
                 constexpr bool do_asplit = true, do_bsplit = true, do_load = true;
-#endif
-#if SNAG_GEMM_STREAM_ONLY
-                fa.sink(set, stream_sink);
-                fa.load(set, kt + 1 + kPPSets, kleft);
-                sb.sink(set, stream_sink);
-                sb.load(set, kt + 1 + kPPSets, kleft);
-#else
                 if (do_asplit) fa.split(set, a_nxt[0]);
-                SNAG_STAMP(set, 5);
                 if (do_load) fa.load(set, kt + 1 + kPPSets, kleft);
-                SNAG_STAMP(set, 6);
                 if (do_bsplit) sb.split_store(set, sm + wr_off);
-                SNAG_STAMP(set, 7);
                 if (do_load) sb.load(set, kt + 1 + kPPSets, kleft);
-                SNAG_STAMP(set, 8);
-#endif
 #if defined(__HIP_DEVICE_COMPILE__)
                 __builtin_amdgcn_sched_barrier(0);
-#if SNAG_GEMM_PP_LATE_READS && SNAG_GEMM_PP_EARLY_H && !SNAG_GEMM_STREAM_ONLY
                 // (tile kt's image was completed by the barrier that ended the PREVIOUS interval: both groups wrote their halves one and two
                 // intervals ago; nobody overwrites it before tile kt+3 is staged)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[j].h = load_split_plane<BN>(sm + rd_off, wn0 + 32 * j + li, lh, 0);
-#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                SNAG_STAMP(set, 1);
                 __builtin_amdgcn_s_barrier();
-                SNAG_STAMP(set, 2);
                 __builtin_amdgcn_sched_barrier(0);
-#if SNAG_GEMM_PP_LATE_READS && SNAG_GEMM_PP_EARLY_H && !SNAG_GEMM_STREAM_ONLY
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     b[j].l = load_split_plane<BN>(sm + rd_off, wn0 + 32 * j + li, lh, 2);
                     b[j].m = load_split_plane<BN>(sm + rd_off, wn0 + 32 * j + li, lh, 1);
                 }
-#elif SNAG_GEMM_PP_LATE_READS && !SNAG_GEMM_STREAM_ONLY
-#pragma unroll
-                for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + rd_off, wn0 + 32 * j + li, lh, b[j]);
-#endif
-#if SNAG_GEMM_ABLATE
-                if (!(p.dbg & 8)) mfma_split(a_cur, b);
-#elif !SNAG_GEMM_STREAM_ONLY
                 mfma_split(a_cur, b);
-#endif
                 a_cur[0] = a_nxt[0];
                 __builtin_amdgcn_sched_barrier(0);
-                SNAG_STAMP(set, 3);
                 __builtin_amdgcn_s_barrier();
-                SNAG_STAMP(set, 4);
                 __builtin_amdgcn_sched_barrier(0);
 #endif
                 rd_off = wr_off;
@@ -873,9 +506,6 @@ struct GemmCore {
                 if constexpr (kPingPong) {
 #if defined(__HIP_DEVICE_COMPILE__)
                     const bool late = wave >= 4;
-#if SNAG_GEMM_PP_PRIO
-                    if (late) __builtin_amdgcn_s_setprio(1);      // the second-dispatched half loses every issue arbitration otherwise (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-#endif
                     if (late) __builtin_amdgcn_s_barrier();
                     for (int kt = 0; kt < nk; kt += kPPSets) {       // iteration kt consumes tile kt + 1: set (kt + 1) % SETS
                         pp_iteration(kt, std::integral_constant<int, 1>{});
@@ -893,14 +523,6 @@ struct GemmCore {
                     }
                     if (!late) __builtin_amdgcn_s_barrier();
                     __syncthreads();
-#if SNAG_GEMM_STREAM_ONLY
-                    acc[0][0][0] += __uint_as_float(stream_sink & 0x007fffffu);       // (a denormal: the loads stay live, the slab stays finite)
-#endif
-#if SNAG_GEMM_STAMP
-                    if (blockIdx.x == 0 && blockIdx.y == 17 && blockIdx.z == 1 && lane == 0 && (wave == 0 || wave == 4))
-                        for (int i = 0; i < 4; ++i)
-                            for (int q = 0; q < 9; ++q) g_gemm_stamps[((wave >> 2) * 4 + i) * 9 + q] = stamp[i][q];
-#endif
 #endif
                 } else {
                     for (int kt = 0; kt < nk; kt += 2) {
@@ -957,20 +579,10 @@ struct GemmCore {
             for (int i = 0; i < TM; ++i) load_split_fragment<BM>(sm + cur * STAGE, wm0 + 32 * i + li, lh, a[i]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) load_split_fragment<BN>(sm + cur * STAGE + A_IMG, wn0 + 32 * j + li, lh, b[j]);
-#if defined(__HIP_DEVICE_COMPILE__) && SNAG_GEMM_PIN_READS
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#if SNAG_GEMM_ABLATE       // -DSNAG_GEMM_ABLATE=1 builds only: SNAG_GEMM_DBG & 4 / 8 / 16 / 32 drop the barrier / MFMAs / staging / fetch
-            if (!(p.dbg & 16)) stage(set, cur ^ 1);
-            if (!(p.dbg & 32)) fetch(set, kt + 3);
-            if (!(p.dbg & 8)) mfma_split(a, b);
-            if (!(p.dbg & 4)) __syncthreads();
-#else                       // (a conditional fetch in the production loop would degrade its counted vmcnt waits to vmcnt(0))
             stage(set, cur ^ 1);
             fetch(set, kt + 3);
             mfma_split(a, b);
             __syncthreads();
-#endif
         };
         if (nk > 0) {
             fetch(0, 0);
@@ -997,143 +609,14 @@ struct GemmCore {
     }
 
     __device__ __forceinline__ void run(const GemmOperands& p, float* __restrict__ smem, int m0, int n0, int kbeg, int kend) {
-        if constexpr (kPresplit) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-            if (kend > kbeg) run_presplit(p, smem, m0, n0, kbeg, kend);
-            return;
-        }
-        run_loop(p, smem, m0, n0, kbeg, kend);
-    }
-
-    __device__ __forceinline__ void run_loop(const GemmOperands& p, float* __restrict__ smem, int m0, int n0, int kbeg, int kend) {
-        const int tid = threadIdx.x;
-        const int lane = tid & 63;
-        const int wave = wave_id_uniform();
-        const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
-        lds_float* const sm = (lds_float*)smem;
+        static_assert(kPresplit, "every tile of the build multiplies pre-split bf16 images");
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-        Stager<BM, A_KC> sa;
-        Stager<BN, B_KC> sb;
-        const int nk = (kend - kbeg + kBK - 1) / kBK;
-        if (nk <= 0) return;
-        const int li = lane & 31, lh = lane >> 5;
-        if (VEC) {
-            sa.init(p.A, p.lda, m0, p.M, tid);
-            sb.init(p.B, p.ldb, n0, p.N, tid);
-        }
-        // wave-uniform choice between the predicate-free loader and the ragged-K one (last tile only)
-        auto fetch = [&](int kt) {
-            const int k0 = kbeg + kt * kBK;
-            if (k0 + kBK <= kend) {
-                sa.template load<true, VEC>(p.A, p.lda, p.a_vec, m0, p.M, k0, kend, tid);
-                sb.template load<true, VEC>(p.B, p.ldb, p.b_vec, n0, p.N, k0, kend, tid);
-            } else {
-                sa.template load<false, false>(p.A, p.lda, p.a_vec, m0, p.M, k0, kend, tid);
-                sb.template load<false, false>(p.B, p.ldb, p.b_vec, n0, p.N, k0, kend, tid);
-            }
-        };
-        auto stage = [&](int buf) {
-            sa.store(sm + buf * A_BUF, tid);
-            sb.store(sm + B_BASE + buf * B_BUF, tid);
-        };
-
-        float av[kBK / 2][TM], bv[kBK / 2][TN];
-        if (kDma && VEC) {
-            // LDS-DMA main loop: the copy of tile kt+1 runs while tile kt feeds the matrix pipe; the only wait is the
-            // vmcnt(0) in front of the barrier that publishes it.  A ragged last tile takes the register path.
-            sa.init_dma(p.A, p.lda, m0, p.M, tid);
-            sb.init_dma(p.B, p.ldb, n0, p.N, tid);
-            auto full = [&](int kt) { return kbeg + (kt + 1) * kBK <= kend; };
-            auto bring = [&](int kt, int buf) {        // returns true when the tile went through registers
-                if (full(kt)) {
-                    sa.dma(sm + buf * A_BUF, p.lda, kbeg + kt * kBK, wave);
-                    sb.dma(sm + B_BASE + buf * B_BUF, p.ldb, kbeg + kt * kBK, wave);
-                    return false;
-                }
-                sa.template load<false, false>(p.A, p.lda, p.a_vec, m0, p.M, kbeg + kt * kBK, kend, tid);
-                sb.template load<false, false>(p.B, p.ldb, p.b_vec, n0, p.N, kbeg + kt * kBK, kend, tid);
-                return true;
-            };
-            if (bring(0, 0)) stage(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            for (int kt = 0; kt < nk; ++kt) {
-                const int cur = kt & 1;
-                const bool more = (kt + 1 < nk) && p.dbg == 0;
-                bool via_regs = false;
-                if (more) via_regs = bring(kt + 1, cur ^ 1);
-                load_fragments<BM, A_KC, TM>(sm + cur * A_BUF, wm0, li, lh, av);
-                load_fragments<BN, B_KC, TN>(sm + B_BASE + cur * B_BUF, wn0, li, lh, bv);
-                mfma_chain(av, bv);
-                if (via_regs) stage(cur ^ 1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (p.dbg != 2) __syncthreads();       // dbg 2: ablation without the per-k-tile barrier (results are wrong)
-            }
-            return;
-        }
-        if (!kPipe) {
-            fetch(0);
-            stage(0);
-            __syncthreads();
-            for (int kt = 0; kt < nk; ++kt) {
-                const int cur = kt & 1;
-                const bool more = (kt + 1 < nk) && p.dbg == 0;
-                if (more) fetch(kt + 1);
-                load_fragments<BM, A_KC, TM>(sm + cur * A_BUF, wm0, li, lh, av);
-                load_fragments<BN, B_KC, TN>(sm + B_BASE + cur * B_BUF, wn0, li, lh, bv);
-                mfma_chain(av, bv);
-                if (more) stage(cur ^ 1);
-                __syncthreads();
-            }
-            return;
-        }
-        // Software pipeline, one barrier per k-tile.  At the top of iteration kt: av/bv hold the operand fragments of
-        // tile kt, LDS buffer (kt+1)&1 holds tile kt+1.  The iteration issues the global loads of tile kt+2 and the LDS
-        // fragment reads of tile kt+1 BEFORE its MFMA chain, so a wave covers both latencies with its own matrix work
-        // instead of relying on other waves; tile kt+2 is written to LDS after the chain.
-        fetch(0);
-        stage(0);
-        __syncthreads();
-        load_fragments<BM, A_KC, TM>(sm, wm0, li, lh, av);
-        load_fragments<BN, B_KC, TN>(sm + B_BASE, wn0, li, lh, bv);
-        if (nk > 1) {
-            fetch(1);
-            stage(1);
-        }
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int nxt = (kt + 1) & 1;
-            const bool more2 = (kt + 2 < nk) && p.dbg == 0;
-            if (more2) fetch(kt + 2);
-            float an[kBK / 2][TM], bn[kBK / 2][TN];
-            if (kt + 1 < nk) {
-                load_fragments<BM, A_KC, TM>(sm + nxt * A_BUF, wm0, li, lh, an);
-                load_fragments<BN, B_KC, TN>(sm + B_BASE + nxt * B_BUF, wn0, li, lh, bn);
-            }
-            mfma_chain(av, bv);
-            if (more2) stage(kt & 1);
-            __syncthreads();
-            if (kt + 1 < nk) {
-#pragma unroll
-                for (int s = 0; s < kBK / 2; ++s) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) av[s][i] = an[s][i];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bv[s][j] = bn[s][j];
-                }
-            }
-        }
+        if (kend > kbeg) run_presplit(p, smem, m0, n0, kbeg, kend);
     }
 
     // Visit the block tile four columns at a time: f(row, col, float4).  The accumulators take a trip through
@@ -1239,16 +722,7 @@ __device__ __forceinline__ void gemm_tile_at(const GemmOperands& p, const Epi& e
     const int kbeg = z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     Core core;
-#if SNAG_GEMM_ABLATE       // timing experiments: 256 = no main loop at all (zero accumulators), 128 = no epilogue (nothing is stored)
-    if (p.dbg & 256) core.run(p, smem, m0, n0, kbeg, kbeg);
-    else core.run(p, smem, m0, n0, kbeg, kend);
-    if (p.dbg & 128) {
-        if (core.acc[0][0][0] == 1.2345f) epi(m0, n0, make_float4(0.f, 0.f, 0.f, 0.f));
-        return;
-    }
-#else
     core.run(p, smem, m0, n0, kbeg, kend);
-#endif
     if (slab == nullptr) {
         core.for_each(smem, m0, n0, epi);
     } else {

@@ -394,17 +394,30 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         pi = pd - (lr_i / bc1) * (mi / denom);
     };
     const int64_t n4 = vec ? n / 4 : 0;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
-        const float4 g4 = reinterpret_cast<const float4*>(g)[q];
-        float4 p4 = reinterpret_cast<const float4*>(p)[q], m4 = reinterpret_cast<const float4*>(m)[q], v4 = reinterpret_cast<const float4*>(v)[q];
-        float lr0, wd0, lr3, wd3;
-        group_of(4 * q, lr0, wd0);
-        group_of(4 * q + 3, lr3, wd3);
+    // A thread keeps the parameter group of its last quad: [seg_lo, seg_hi) -- a quad inside it needs no search (the groups are a handful of long
+    // runs; two binary searches per quad, eight dependent loads in front of the update, paced the launch: 22 us for 77 MB).  Two quads per
+    // iteration, all eight operand loads requested before the first update.
+    int64_t seg_lo = 0, seg_hi = n_seg > 0 ? -1 : n;
+    float c_lr = lr, c_wd = wd;
+    auto locate = [&](int64_t i) {
+        int lo = 0, hi = n_seg - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (i < seg_end[mid]) hi = mid;
+            else lo = mid + 1;
+        }
+        seg_lo = lo > 0 ? seg_end[lo - 1] : 0;
+        seg_hi = seg_end[lo];
+        c_lr = lr * seg_lr[lo];
+        c_wd = seg_wd[lo];
+    };
+    auto quad = [&](int64_t q, const float4& g4, float4& p4, float4& m4, float4& v4) {
+        if (!(4 * q >= seg_lo && 4 * q < seg_hi)) locate(4 * q);
         float* pp = &p4.x; float* mm = &m4.x; float* vv = &v4.x; const float* gg = &g4.x;
-        if (lr0 == lr3 && wd0 == wd3) {
+        if (4 * q + 3 < seg_hi) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) update(pp[e], gg[e], mm[e], vv[e], lr0, wd0);
-        } else {
+            for (int e = 0; e < 4; ++e) update(pp[e], gg[e], mm[e], vv[e], c_lr, c_wd);
+        } else {                              // a group boundary inside the quad: per element
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float lr_e, wd_e;
@@ -412,9 +425,25 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                 update(pp[e], gg[e], mm[e], vv[e], lr_e, wd_e);
             }
         }
-        reinterpret_cast<float4*>(p)[q] = p4;
-        reinterpret_cast<float4*>(m)[q] = m4;
-        reinterpret_cast<float4*>(v)[q] = v4;
+    };
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += 2 * stride) {
+        const int64_t q1 = q + stride;
+        const bool two = q1 < n4;
+        const int64_t qb = two ? q1 : q;
+        const float4 ga = reinterpret_cast<const float4*>(g)[q], gb = reinterpret_cast<const float4*>(g)[qb];
+        float4 pa = reinterpret_cast<const float4*>(p)[q], ma = reinterpret_cast<const float4*>(m)[q], va = reinterpret_cast<const float4*>(v)[q];
+        float4 pb = reinterpret_cast<const float4*>(p)[qb], mb = reinterpret_cast<const float4*>(m)[qb], vb = reinterpret_cast<const float4*>(v)[qb];
+        quad(q, ga, pa, ma, va);
+        reinterpret_cast<float4*>(p)[q] = pa;
+        reinterpret_cast<float4*>(m)[q] = ma;
+        reinterpret_cast<float4*>(v)[q] = va;
+        if (two) {
+            quad(q1, gb, pb, mb, vb);
+            reinterpret_cast<float4*>(p)[q1] = pb;
+            reinterpret_cast<float4*>(m)[q1] = mb;
+            reinterpret_cast<float4*>(v)[q1] = vb;
+        }
     }
     for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float lr_i, wd_i, pi = p[i], mi = m[i], vi = v[i];
@@ -529,6 +558,8 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(PrologueArgs a) {
 }
 
 static int grid_for(int64_t n) { return (int)std::min<int64_t>(4096, (n + 255) / 256); }
+// AdamW over a flat buffer: four workgroups per CU walk it with a stride (a workgroup's preamble -- the clip coefficient from the partials -- is paid 1,024 times, not 2,650)
+static int adamw_grid(int64_t n4) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n4 + 255) / 256)); }
 
 }  // namespace snag
 
@@ -785,7 +816,7 @@ extern "C" SNAG_API int snag_adamw_step(float* param, const float* grad, float* 
     if (n == 0) return SNAG_OK;
     SNAG_REQUIRE(param && grad && exp_avg && exp_avg_sq, SNAG_ERR_ARG, "adamw_step: null pointer");
     const float bc1 = 1.0f - powf(beta1, (float)std::max<int64_t>(step, 1)), bc2 = 1.0f - powf(beta2, (float)std::max<int64_t>(step, 1));
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+    hipLaunchKernelGGL(adamw_kernel, dim3(adamw_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
                        eps, weight_decay, bc1, bc2, grad_scale, tick, (const int64_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0,
                        adamw_vec_ok(param, grad, exp_avg, exp_avg_sq));
     return check_launch("snag_adamw_step");
@@ -800,7 +831,7 @@ extern "C" SNAG_API int snag_adamw_step_groups(float* param, const float* grad, 
     if (n == 0) return SNAG_OK;
     SNAG_REQUIRE(param && grad && exp_avg && exp_avg_sq, SNAG_ERR_ARG, "adamw_step_groups: null pointer");
     const float bc1 = 1.0f - powf(beta1, (float)std::max<int64_t>(step, 1)), bc2 = 1.0f - powf(beta2, (float)std::max<int64_t>(step, 1));
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+    hipLaunchKernelGGL(adamw_kernel, dim3(adamw_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
                        eps, 0.0f, bc1, bc2, grad_scale, tick, seg_end, seg_weight_decay, seg_lr_scale, n_seg, grad_scale_dev, tick_advanced,
                        adamw_vec_ok(param, grad, exp_avg, exp_avg_sq));
     return check_launch("snag_adamw_step_groups");
@@ -817,7 +848,7 @@ extern "C" SNAG_API int snag_clip_adamw_step_groups(float* param, const float* g
     hipStream_t st = (hipStream_t)stream;
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kNormBlocks, (n + 255) / 256));
     hipLaunchKernelGGL(sumsq_part_kernel, dim3(nb), dim3(256), 0, st, grad, n, grad_scale, work, tick);          // also advances the step counter
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, 0.0f, 1.0f, 1.0f,
+    hipLaunchKernelGGL(adamw_kernel, dim3(adamw_grid((n + 3) / 4)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, 0.0f, 1.0f, 1.0f,
                        grad_scale, (const uint64_t*)tick, seg_end, seg_weight_decay, seg_lr_scale, n_seg, (const float*)nullptr, 1,
                        adamw_vec_ok(param, grad, exp_avg, exp_avg_sq), (const float*)work, nb, max_norm, out2);
     return check_launch("snag_clip_adamw_step_groups");
