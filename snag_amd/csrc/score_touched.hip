@@ -43,8 +43,8 @@ namespace snag {
 #ifndef SNAG_HUB_GRID
 #define SNAG_HUB_GRID 512
 #endif
-#ifndef SNAG_T_WT
-#define SNAG_T_WT 1                      // gradient rows as write-through (sc1) stores: see st_row4_wt
+#ifndef SNAG_T_COMBINE
+#define SNAG_T_COMBINE 1                 // a triple's parts meet in LDS: one head / tail / relation entry per triple (0: one per part; A/B)
 #endif
 #ifndef SNAG_T_ABLATE
 #define SNAG_T_ABLATE 0                  // timing experiments (wrong results): 1 no hot-row launch, 2 no pass B launch, 4 pass A stores no gradient rows, 8 pass B resets no counters,
@@ -87,6 +87,8 @@ struct TouchedWork {
     int parts, per;                         // waves per triple, negatives per part
     int64_t n_rec;                          // batch * parts * (per + 3)
     int rel_role;                           // the relation rows are summed by pass B's relation role: pass A emits no relation entries
+    int combine;                            // the parts of a triple sit in ONE workgroup (2 or 4 parts): they meet in LDS and the triple sends ONE head, ONE
+                                            // tail (and one relation) entry instead of one per part
 };
 
 static size_t t_align(size_t x) { return (x + 255) / 256 * 256; }
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256, SNAG_TA_WAVES) void touched_a_kernel(
     const int dest3 = lane == 0 ? (int)ti : (lane == 1 ? (int)hi : n_ent + (int)ri);
     unsigned local3 = 0u;
     int aslot3 = 0;
-    const int n3 = w.rel_role ? 2 : 3;                             // (relation role: the relation's entry is a void record)
+    const int n3 = (w.combine && part != 0) ? 0 : (w.rel_role ? 2 : 3);      // (relation role: the relation's entry is a void record; combined parts: part 0 speaks for the triple)
     if (live && lane < n3) agg_insert(dest3, local3, aslot3);
     constexpr int kMaxBlocks = 4;                                   // id blocks of 64 negatives per part held in registers (per <= 256)
     unsigned nlocal[kMaxBlocks];
@@ -342,10 +344,9 @@ __global__ __launch_bounds__(256, SNAG_TA_WAVES) void touched_a_kernel(
                     const unsigned slot_k = __shfl(my_slot, k & 63);
                     // the FIRST entry to arrive at a destination writes: one writer per row (a Zipf batch's hot rows would otherwise take
                     // thousands of write-through stores each: pass A 153 us instead of 53)
-                    if (valid && slot_k == 0u && !(SNAG_T_ABLATE & 4)) {
-                        if (SNAG_T_WT) st_row4_wt<NV>(d_ent, idx, dld, dim, sub, gr);
-                        else st_row4<NV>(d_ent, idx, dld, dim, sub, gr);
-                    }
+                    // (write-through -- sc1 -- stores for these rows, so that the launch does not end on an L2 full of dirty lines: measured
+                    // 2-3 % slower on the same box, 72.3-73.3 against 70.5-70.8 us for the entry)
+                    if (valid && slot_k == 0u && !(SNAG_T_ABLATE & 4)) st_row4<NV>(d_ent, idx, dld, dim, sub, gr);
                 }
                 const float sk = __shfl(s, (lane & 3) * 16);
                 if (((lane - it0) >> 2) == u && lane >= it0 && lane < it0 + 4 * RB) my_s = sk;
@@ -379,19 +380,47 @@ __global__ __launch_bounds__(256, SNAG_TA_WAVES) void touched_a_kernel(
         }
     }
     // rows[b] = q_b (part 0) ; rows[batch + vb] = dq_{b,p} = 2 c_p (q - t^) - 2 sum_{k in p} a_k (q - x^_k)
+    // COMBINED (2 or 4 parts = the waves of this workgroup): the parts' sums meet in LDS in part order and part 0 writes ONE row
+    // rows[batch + b] = dq_b for the triple -- head, tail and relation then receive one entry per triple, not one per part (a head dealt to four
+    // parts was a four-entry destination for pass B: list fetch, sort, four rows)
+    __shared__ float comb[4][64 * NV];
+    __shared__ float ccomb[4];
+    if (w.combine) {
+        if (grp == 1) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) *reinterpret_cast<float4*>(&comb[wave][(sub + 16 * j) * 4]) = acc.v[j];
+            if (sub == 0) ccomb[wave] = c_pos;
+        }
+        __syncthreads();
+        if (part == 0) {
+            c_pos = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) acc.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int pp = 0; pp < w.parts; ++pp) {
+                c_pos += ccomb[wave + pp];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const float4 v = *reinterpret_cast<const float4*>(&comb[wave + pp][(sub + 16 * j) * 4]);
+                    acc.v[j].x += v.x; acc.v[j].y += v.y; acc.v[j].z += v.z; acc.v[j].w += v.w;
+                }
+            }
+        }
+    }
+    const bool speaks = !w.combine || part == 0;                   // this wave emits the triple's (or its part's) head / tail / relation entries
+    const int64_t dq_row = w.combine ? batch + b : batch + vb;
     if (live && grp == 0 && part == 0) st_row4<NV>(w.rows, b, dim, dim, sub, q);
-    if (live && grp == 1) {
+    if (live && grp == 1 && speaks) {
         Row4<NV> dq;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             dq.v[j].x = 2.f * (c_pos * (q.v[j].x - tt.v[j].x) - acc.v[j].x); dq.v[j].y = 2.f * (c_pos * (q.v[j].y - tt.v[j].y) - acc.v[j].y);
             dq.v[j].z = 2.f * (c_pos * (q.v[j].z - tt.v[j].z) - acc.v[j].z); dq.v[j].w = 2.f * (c_pos * (q.v[j].w - tt.v[j].w) - acc.v[j].w);
         }
-        st_row4<NV>(w.rows, batch + vb, dim, dim, sub, dq);
+        st_row4<NV>(w.rows, dq_row, dim, dim, sub, dq);
     }
     if (!live) return;
-    if (lane < n3) touched_emit(w, which, rec0 + lane, dest3, agg_base[aslot3] + local3, lane == 0 ? (int)b : (int)(batch + vb), lane == 0 ? -2.f * c_pos : 1.f);
-    else if (lane == 2) w.rec[rec0 + 2] = TouchedRec{-1, 0, 0.f, 1u};
+    if (lane < n3) touched_emit(w, which, rec0 + lane, dest3, agg_base[aslot3] + local3, lane == 0 ? (int)b : (int)dq_row, lane == 0 ? -2.f * c_pos : 1.f);
+    else if (lane < 3) w.rec[rec0 + lane] = TouchedRec{-1, 0, 0.f, 1u};
     if (lane == 0) w.lpart[vb] = hinge;
 }
 
@@ -442,7 +471,7 @@ __device__ __forceinline__ void touched_rel_body(const TabT* __restrict__ rel, i
     const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4, gbase = lane & 48;
     const int rho = (vblock * 4 + (int)(threadIdx.x >> 6)) * 4 + grp;
     const bool live = rho < n_rel;
-    const int parts = w.parts;
+    const int parts = w.combine ? 1 : w.parts;                     // dq rows per triple
     // scan 1: the triples that name this relation, in batch order; lane `sub` keeps the sub-th one (16 are all the sorted fp32 path can take).
     // Eight 64-id blocks are requested together: one round trip per 512 triples, not eight.
     int cnt = 0, mine_b = 0;
@@ -718,8 +747,7 @@ __global__ __launch_bounds__(256, SNAG_TB_WAVES) void touched_b_kernel(const Tab
         normalize_bwd4<NV>(x, gsum);
         if (todo) {
             float* out = is_rel ? d_rel + (int64_t)(dest - n_ent) * dim : d_ent + (int64_t)dest * dld;
-            if (SNAG_T_WT) st_row4_wt<NV>(out, 0, 0, dim, sub, gsum);
-            else st_row4<NV>(out, 0, 0, dim, sub, gsum);
+            st_row4<NV>(out, 0, 0, dim, sub, gsum);
         }
     }
 }
@@ -815,6 +843,7 @@ static int launch_touched(const char* who, const TabT* ent, int64_t ent_ld, int6
     TouchedWork w = touched_carve(work, n_ent, n_rel, batch, n_neg, dim);
     // the relation role scans the whole batch once per relation: while that product is small (configs[4]: 1,000 x 1,024)
     w.rel_role = (n_rel * std::max<int64_t>(batch, 1) <= (1LL << 24)) ? 1 : 0;
+    w.combine = (SNAG_T_COMBINE && (w.parts == 2 || w.parts == 4)) ? 1 : 0;
     if (!w.rel_role && hipMemsetAsync(d_rel, 0, sizeof(float) * (size_t)n_rel * dim, st) != hipSuccess) return fail(SNAG_ERR_LAUNCH, "%s: memset failed", who);
     const int nv = (dim + 63) / 64;
     const dim3 block(256);

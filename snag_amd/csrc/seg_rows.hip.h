@@ -44,25 +44,6 @@ __device__ __forceinline__ void st_row4(float* __restrict__ base, int64_t row, i
     }
 }
 
-// The same row as WRITE-THROUGH stores (sc1: the line leaves the XCD's L2 with the store instead of staying there dirty).  For rows that
-// nobody re-reads in this launch -- the scorers' gradient rows: 137 MB per 1,024 x 131 of them -- so that the launch does not end on an L2
-// full of dirty lines, which the NEXT launch's start then waits for (MI355X_MICROARCH.md, price list "boundary" / "publish-large").
-template <int NV>
-__device__ __forceinline__ void st_row4_wt(float* __restrict__ base, int64_t row, int64_t ld, int dim, int sub, const Row4<NV>& r) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    using f4 = __attribute__((ext_vector_type(4))) float;
-    float* p = base + row * ld;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int c = sub + 16 * j;
-        if (c * 4 < dim) {
-            const f4 v = {r.v[j].x, r.v[j].y, r.v[j].z, r.v[j].w};
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p + 4 * c), "v"(v) : "memory");
-        }
-    }
-#endif
-}
-
 template <int NV>
 __device__ __forceinline__ float sumsq4(const Row4<NV>& r) {
     float s = 0.f;
