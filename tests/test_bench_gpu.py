@@ -40,6 +40,38 @@ def test_bench_single_gpu_line():
         assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1.5 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
 
 
+def test_bench_default_line_carries_hits_parity_fusion_roofline_and_the_pool_variant():
+    """The driver-run form (extras and the cpu_baseline leg on): the metric's second half -- Hits@1/10 of the timed engine against the float64
+    oracle, with the counts behind "bit-exact ranking indices" --, the fusion roofline object (SURVEY par. 8d), the configs[3] check at full
+    size and the README POOL=1 variant are all in the ONE JSON line."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--cpu-seconds", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    o = _json_line(p.stdout)
+    hp = o["hits_parity"]
+    assert hp["n"] == 512 and hp["n_unexplained"] == 0 and hp["n_rank_diffs"] == hp["n_near_tie_explained"] and hp["max_abs_score_err_vs_f64"] < 1e-4
+    assert abs(hp["hits1_gpu"] - hp["hits1_oracle"]) <= hp["n_hits_affecting_diffs"] / 512 + 0.5e-4
+    assert abs(hp["hits10_gpu"] - hp["hits10_oracle"]) <= hp["n_hits_affecting_diffs"] / 512 + 0.5e-4
+    rf = o["roofline_fusion"]
+    assert rf["loop_equals_module_forward"] and rf["per_entity"]["bytes"] == 4620 and 0 < rf["fwd"]["frac_hbm"] < 1 and 0 < rf["bwd"]["frac_f32_mfma_peak"] < 2
+    assert rf["cpu_probe"]["max_abs_err_gpu_vs_oracle"] < 1e-4
+    full = o["roofline_sim"]["oracle_check"]["full_size"]
+    assert full["n"] == 10500 and full["window_covers_2_delta"] and full["l2r"]["n_unexplained"] == 0 and full["r2l"]["n_unexplained"] == 0
+    pv = o["pool_variant"]
+    assert pv["feat_dims"] == [256, 256] and pv["pooled_from"] == [4096, 768] and 0 < pv["ms_per_step"] < o["ms_per_step"]
+    assert o["cpu_baseline"]["kind"] == "port" and o["cpu_baseline"]["value"] > 0
+
+
+def test_bench_pool_and_atten_weight_flags():
+    """`--pool` (README POOL=1) and `--joint-way atten_weight` run the same loop; the workload string says what was timed."""
+    for extra, want in ((["--pool"], "POOL=1"), (["--joint-way", "atten_weight"], "atten_weight")):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--cpu-seconds", "0", "--no-extras"] + extra,
+                           capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        o = _json_line(p.stdout)
+        assert want in o["config"]["workload"] and o["value"] > 1e5 and o["config"]["final_loss"] > 0
+
+
 def test_bench_noise_level_step_refreshes_the_noise_in_every_timed_step():
     """README "noise-level: step": --noise-level step puts a refresh into every timed step; the line also carries the measured cost of one refresh."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3", "--cpu-seconds", "0", "--no-kernel-timers",
