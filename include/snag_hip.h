@@ -286,12 +286,13 @@ typedef struct snag_gemm_desc {
 } snag_gemm_desc;
 
 /* Up to SNAG_GEMM_GROUP_MAX independent problems of ANY shapes in one call -- one launch when each of them would run the 64 x 128 tile
- * (plain or split K, no stream-K plan), or each of them the eight-wave 256 x 128 tile of the long-K shapes (M >= 1024, K >= 512,
- * N <= 128), on the same operand layouts (a_kcontig / b_kcontig equal across the group), one launch per problem otherwise.  Results are the same bits as separate snag_gemm_f32 calls: every problem keeps its own K split, workspace (distinct per
- * split problem) and epilogue; defer_reduce is honoured per problem.  The outputs must not overlap.  (The six independent products behind
- * the read-out layer's attention backward, reference ops: the nn.Linear backward of BertSelfAttention / ProjectionHead,
- * model/SNAG_tools.py:32-51, 134-142.) */
-#define SNAG_GEMM_GROUP_MAX 6
+ * (plain or split K, no stream-K plan; b_kcontig equal across the group, a_kcontig free per problem since ABI version 2), or each of them
+ * the eight-wave 256 x 128 tile of the long-K shapes (M >= 1024, K >= 512, N <= 128; a_kcontig / b_kcontig equal across the group), one
+ * launch per problem otherwise.  Results are the same bits as separate snag_gemm_f32 calls: every problem keeps its own K split, workspace
+ * (distinct per split problem) and epilogue; defer_reduce is honoured per problem.  The outputs must not overlap.  (The seven independent
+ * products behind the read-out layer's attention backward -- four weight gradients and three input gradients --, reference ops: the
+ * nn.Linear backward of BertSelfAttention / ProjectionHead, model/SNAG_tools.py:32-51, 134-142.) */
+#define SNAG_GEMM_GROUP_MAX 8
 SNAG_API int snag_gemm_f32_group(const snag_gemm_desc* const* descs, int n, void* stream);
 
 SNAG_API int snag_gemm_f32(const snag_gemm_desc* desc, void* stream);

@@ -108,7 +108,7 @@ static snag_gemm_desc gemm_desc(int M, int N, int K, const float* A, int64_t lda
 #ifndef SNAG_RO_BWD_ONE_GROUP
 #define SNAG_RO_BWD_ONE_GROUP 1      // the read-out layer's backward: weight gradients and input gradients as ONE grouped launch (0: two; A/B)
 #endif
-static constexpr int kGroupMaxProblems = 8;       // = kGroupMax (gemm.hip.h): problems one grouped launch takes
+static constexpr int kGroupMaxProblems = SNAG_GEMM_GROUP_MAX;       // problems one grouped launch takes
 static constexpr int kRedBlocks = 1024;  // fixed partial-sum fan-in for LayerNorm / bias / weight_raw gradients
 
 static int check_fusion(const snag_fusion_desc* f) {

@@ -789,6 +789,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_pair_ker
 // class products behind the attention backward; one by one each is a 235-workgroup grid that pays its own launch, first-load latency
 // and drain (16-27 us each for 1-3 us of matrix work).
 constexpr int kGroupMax = 8;
+static_assert(kGroupMax == SNAG_GEMM_GROUP_MAX, "include/snag_hip.h");
 template <class Epi>
 struct GemmGroup {
     GemmOperands p[kGroupMax];
