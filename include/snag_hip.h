@@ -729,15 +729,23 @@ SNAG_API int snag_build_filter_mask(const int32_t* h, const int32_t* r, const in
  * The backward also takes the same edge set grouped by DESTINATION (t_rowptr [N+1], t_col [E] = sources): it runs as two gather
  * passes (out-edges per source, in-edges per destination) with no atomics, and parameter gradients use fixed-order partial
  * sums, so it is deterministic.
+ * Training options (ABI version 2): edge_keep [H, n_edges] (bytes, in the STORED order of the COO list; NULL = no dropout) is the keep mask
+ * of F.dropout(edge_e, attn_dropout) (model/layers.py:83: applied after the row sums -- the aggregation uses e * keep * edge_keep_scale, the
+ * normaliser the undropped e); eid [E] / t_eid [E] give the stored edge id of every position of the two CSR orders.  The input dropout of
+ * the non-final layers (model/Tool_model.py:78-79) is snag_keep_scale: out = keep ? x * scale : 0, forward and backward alike.
+ * instance_normalization: the reference's nn.InstanceNorm1d(n_units[0]) raises on [N, f] node features (ValueError, torch >= 1.x): not built.
  */
 SNAG_API int64_t snag_gat_work_floats(int64_t N, int f, int H);
+SNAG_API int snag_keep_scale(const float* x, int64_t n, const uint8_t* keep, float scale, float* out, void* stream);
 SNAG_API int snag_gat_layer_fwd(const float* x, int64_t N, int f, int H, const float* w, const float* a_src_dst,
                                 const int32_t* rowptr, const int32_t* col, int apply_elu,
-                                float* s_src, float* s_dst, float* agg, float* rsum, float* pre, float* out, void* stream);
+                                float* s_src, float* s_dst, float* agg, float* rsum, float* pre, float* out,
+                                const uint8_t* edge_keep, const int32_t* eid, int64_t n_edges, float edge_keep_scale, void* stream);
 SNAG_API int snag_gat_layer_bwd(const float* x, int64_t N, int f, int H, const float* w, const float* a_src_dst,
                                 const int32_t* rowptr, const int32_t* col, const int32_t* t_rowptr, const int32_t* t_col,
                                 const float* s_src, const float* s_dst, const float* agg, const float* rsum, const float* pre, int had_elu, const float* d_out,
-                                float* d_x, float* d_w, float* d_a, int accumulate, float* work, void* stream);
+                                float* d_x, float* d_w, float* d_a, int accumulate, float* work,
+                                const uint8_t* edge_keep, const int32_t* eid, const int32_t* t_eid, int64_t n_edges, float edge_keep_scale, void* stream);
 
 /* GCN structural encoder option (structure_encoder == "gcn": GraphConvolution model/layers.py:102-130, GCN model/Tool_model.py:98-110):
  * out [N, f] = A x (+ bias) with A given as CSR (rowptr [N+1], col/val [E]; duplicate coordinates add up) -- the torch.spmm of

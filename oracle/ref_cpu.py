@@ -417,8 +417,12 @@ def multi_loss(losses: Sequence[Tensor], log_vars: Tensor) -> Tensor:
 # --------------------------------------------------------------------------
 
 
-def gat_forward(x: Tensor, edges: Tensor, layers: Sequence[Dict[str, Tensor]]) -> Tensor:
-    """GAT(diag=True) in eval mode / zero dropout (the SNAG configuration: run_snag.sh sets neither --dropout nor --attn_dropout).
+def gat_forward(x: Tensor, edges: Tensor, layers: Sequence[Dict[str, Tensor]],
+                in_keep: Optional[Sequence[Optional[Tensor]]] = None, edge_keep: Optional[Sequence[Optional[Tensor]]] = None,
+                p_in: float = 0.0, p_edge: float = 0.0) -> Tensor:
+    """GAT(diag=True): eval mode by default (the SNAG configuration: run_snag.sh sets neither --dropout nor --attn_dropout); training mode with
+    explicit keep masks: ``in_keep[l]`` [N, f] = F.dropout on the input of layer l (every layer but the last, model/Tool_model.py:78-79),
+    ``edge_keep[l]`` [H, E] = F.dropout on head i's edge weights AFTER the row sums (model/layers.py:81-83), inverted dropout at rates p_in / p_edge.
 
     reference: MultiHeadGraphAttention.forward model/layers.py:68-94 and GAT.forward model/Tool_model.py:75-94.
     Per layer and head i: h = x * w_i ; e = exp(-leaky_relu_0.2([h_u | h_v] . a_i)) per edge (u, v) ; h'_u = sum_e e h_v / sum_e e ;
@@ -430,12 +434,16 @@ def gat_forward(x: Tensor, edges: Tensor, layers: Sequence[Dict[str, Tensor]]) -
     for li, p in enumerate(layers):
         w, a = p["w"], p["a_src_dst"]
         H, f = w.shape[0], w.shape[2]
+        if in_keep is not None and in_keep[li] is not None:
+            x = x * in_keep[li].to(x.dtype) / (1.0 - p_in)                   # Tool_model.py:78-79
         outs = []
         for i in range(H):
             h = x * w[i]                                                     # :74
             z = torch.cat([h[src], h[dst]], dim=1) @ a[i]                    # :78-79
             e = torch.exp(-F.leaky_relu(z.squeeze(1), 0.2))                  # :79
             rowsum = torch.zeros(N, dtype=x.dtype).index_add(0, src, e)      # :81 (spmm with ones)
+            if edge_keep is not None and edge_keep[li] is not None:
+                e = e * edge_keep[li][i].to(x.dtype) / (1.0 - p_edge)        # :83
             hp = torch.zeros(N, f, dtype=x.dtype).index_add(0, src, e.unsqueeze(1) * h[dst])      # :85
             outs.append(hp / rowsum.unsqueeze(1))                            # :86
         x = torch.stack(outs, 0).mean(dim=0)                                 # Tool_model.py:84-85

@@ -130,8 +130,9 @@ SIGNATURES = {
     "snag_clip_adamw_step_groups": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P, _P, _I, _P, _F, _F, _P, _P, _P],
     "snag_clip_grad_norm": [_P, _L, _F, _F, _P, _P, _P, _P],
     "snag_tick": [_P, _P],
-    "snag_gat_layer_fwd": [_P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
-    "snag_gat_layer_bwd": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P],
+    "snag_gat_layer_fwd": [_P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _F, _P],
+    "snag_gat_layer_bwd": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _F, _P],
+    "snag_keep_scale": [_P, _L, _P, _F, _P, _P],
     "snag_build_filter_mask": [_P, _P, _P, _L, _I, _I, _P, _L, _P, _P],
     "snag_sample_negatives": [_U64, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P, _P, _P],
     "snag_step_prologue": [_U64, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P, _P, _F, _P, _L, _P, _I, _P, _I, _P],

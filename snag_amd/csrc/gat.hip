@@ -7,6 +7,10 @@
 //   A_i[u,:] = sum_{(u,v)} e_i(u,v) x[v,:] ,  r_i[u] = sum_{(u,v)} e_i(u,v)
 //   pre[u,:] = (1/H) sum_i w_i * A_i[u,:] / r_i[u] ;  out = elu(pre) between layers, pre after the last.
 //
+// Training options of the reference (round 5): edge dropout -- F.dropout(edge_e, attn_dropout) AFTER the row sums (layers.py:81-83): the aggregation
+// uses e * keep / (1 - p), the normaliser r the undropped e -- as an optional byte mask keep[i, stored edge] read through the CSR position ->
+// stored-edge-id arrays; the input dropout of the non-final layers (Tool_model.py:78-79) is an elementwise launch of its own (snag_keep_scale).
+//
 // Edges arrive as CSR over the source node (duplicates and self loops preserved, values unused).  One wave per source
 // node; a feature row is spread over the wave as col = lane + 64*u (256-byte segments).  The backward is two gather passes (out-edges per
 // source, in-edges per destination) with no atomics; parameter gradients go through fixed-order per-block partial sums.
@@ -53,7 +57,8 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(const float* __r
                                                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                                 const float* __restrict__ s_src, const float* __restrict__ s_dst, int apply_elu,
                                                                 float* __restrict__ agg, float* __restrict__ rsum, float* __restrict__ pre,
-                                                                float* __restrict__ out) {
+                                                                float* __restrict__ out, const uint8_t* __restrict__ edge_keep,
+                                                                const int32_t* __restrict__ eid, int64_t n_edges, float escale) {
     const int64_t u = (int64_t)blockIdx.x * 4 + wave_id_uniform();
     if (u >= N) return;
     const int lane = threadIdx.x & 63;
@@ -74,9 +79,10 @@ __global__ __launch_bounds__(256) void gat_aggregate_fwd_kernel(const float* __r
         for (int i = 0; i < kGatMaxH; ++i) {
             if (i < H) {
                 const float al = gat_edge_weight(ss[i] + s_dst[v * H + i]);
-                rs[i] += al;
+                rs[i] += al;                                                           // the row sum takes the undropped weight (:81)
+                const float ald = edge_keep == nullptr ? al : (edge_keep[(int64_t)i * n_edges + eid[e]] ? al * escale : 0.f);      // F.dropout(edge_e) (:83)
 #pragma unroll
-                for (int q = 0; q < NU; ++q) acc[i].v[q] = fmaf(al, xv.v[q], acc[i].v[q]);
+                for (int q = 0; q < NU; ++q) acc[i].v[q] = fmaf(ald, xv.v[q], acc[i].v[q]);
             }
         }
     }
@@ -117,7 +123,8 @@ __global__ __launch_bounds__(256) void gat_bwd_out_edges_kernel(const float* __r
                                                                 const float* __restrict__ agg, const float* __restrict__ rsum,
                                                                 const float* __restrict__ pre, int had_elu, const float* __restrict__ d_out,
                                                                 float* __restrict__ gq, float* __restrict__ drs_out, float* __restrict__ ds_src,
-                                                                float* __restrict__ part) {
+                                                                float* __restrict__ part, const uint8_t* __restrict__ edge_keep,
+                                                                const int32_t* __restrict__ eid, int64_t n_edges, float escale) {
     __shared__ float red[4][64 * NU];
     const int lane = threadIdx.x & 63, wave = wave_id_uniform();
     Cols<NU> pw[kGatMaxH], wi[kGatMaxH];
@@ -168,7 +175,8 @@ __global__ __launch_bounds__(256) void gat_bwd_out_edges_kernel(const float* __r
                     float dal = 0.f;
 #pragma unroll
                     for (int q = 0; q < NU; ++q) dal = fmaf(dA[i].v[q], xv.v[q], dal);
-                    dal = sum64(dal) + drs[i];                                // through A_i and through r_i
+                    const float ks = edge_keep == nullptr ? 1.f : (edge_keep[(int64_t)i * n_edges + eid[e]] ? escale : 0.f);
+                    dal = ks * sum64(dal) + drs[i];                           // through A_i (the dropped weight) and through r_i (the undropped one)
                     dsu[i] += -gat_edge_weight(z) * (z > 0.f ? 1.0f : 0.2f) * dal;
                 }
             }
@@ -198,7 +206,9 @@ __global__ __launch_bounds__(256) void gat_bwd_in_edges_kernel(const float* __re
                                                                const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_col,
                                                                const float* __restrict__ s_src, const float* __restrict__ s_dst,
                                                                const float* __restrict__ rsum, const float* __restrict__ gq,
-                                                               const float* __restrict__ drs, float* __restrict__ d_x, float* __restrict__ ds_dst) {
+                                                               const float* __restrict__ drs, float* __restrict__ d_x, float* __restrict__ ds_dst,
+                                                               const uint8_t* __restrict__ edge_keep, const int32_t* __restrict__ t_eid, int64_t n_edges,
+                                                               float escale) {
     const int64_t v = (int64_t)blockIdx.x * 4 + wave_id_uniform();
     if (v >= N) return;
     const int lane = threadIdx.x & 63;
@@ -227,13 +237,14 @@ __global__ __launch_bounds__(256) void gat_bwd_in_edges_kernel(const float* __re
             if (i < H) {
                 const float z = s_src[u * H + i] + sd[i];
                 const float al = gat_edge_weight(z), c = invH / rsum[u * H + i];
+                const float ks = edge_keep == nullptr ? 1.f : (edge_keep[(int64_t)i * n_edges + t_eid[e]] ? escale : 0.f);
                 float dot = 0.f;
 #pragma unroll
                 for (int q = 0; q < NU; ++q) {
-                    acc[i].v[q] = fmaf(al * c, g.v[q], acc[i].v[q]);
+                    acc[i].v[q] = fmaf(al * ks * c, g.v[q], acc[i].v[q]);
                     dot = fmaf(g.v[q], xw[i].v[q], dot);
                 }
-                const float dal = c * sum64(dot) + drs[u * H + i];
+                const float dal = ks * c * sum64(dot) + drs[u * H + i];
                 dsd[i] += -al * (z > 0.f ? 1.0f : 0.2f) * dal;
             }
         }
@@ -359,6 +370,12 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict
     st_cols<NU>(out + u * f, acc, f, lane);
 }
 
+// F.dropout with an explicit keep mask: out = keep ? x * scale : 0  (forward: x -> the dropped layer input; backward: d of it -> d x)
+__global__ __launch_bounds__(256) void keep_scale_kernel(const float* __restrict__ x, int64_t n, const uint8_t* __restrict__ keep, float scale,
+                                                         float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = keep[i] ? x[i] * scale : 0.f;
+}
+
 static constexpr int kGatBlocks = 1024;
 
 }  // namespace snag
@@ -386,25 +403,31 @@ extern "C" SNAG_API int64_t snag_gat_work_floats(int64_t N, int f, int H) { retu
 
 extern "C" SNAG_API int snag_gat_layer_fwd(const float* x, int64_t N, int f, int H, const float* w, const float* a_src_dst, const int32_t* rowptr,
                                            const int32_t* col, int apply_elu, float* s_src, float* s_dst, float* agg, float* rsum, float* pre,
-                                           float* out, void* stream) {
+                                           float* out, const uint8_t* edge_keep, const int32_t* eid, int64_t n_edges, float edge_keep_scale, void* stream) {
     int rc = gat_check(N, f, H, x, w, a_src_dst, rowptr, col);
     if (rc || N == 0) return rc;
     SNAG_REQUIRE(s_src && s_dst && agg && rsum && out, SNAG_ERR_ARG, "gat_layer_fwd: null output");
+    SNAG_REQUIRE(edge_keep == nullptr || (eid != nullptr && n_edges >= 0), SNAG_ERR_ARG, "gat_layer_fwd: the edge keep mask needs the CSR position -> stored edge id array");
     SNAG_REQUIRE(!apply_elu || pre, SNAG_ERR_ARG, "gat_layer_fwd: the ELU layer needs the pre-activation buffer");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)ceil_div(N, 4));
     SNAG_GAT_NU(gat_node_scores_kernel, f, grid, st, x, N, f, H, w, a_src_dst, s_src, s_dst);
-    SNAG_GAT_NU(gat_aggregate_fwd_kernel, f, grid, st, x, N, f, H, w, rowptr, col, (const float*)s_src, (const float*)s_dst, apply_elu, agg, rsum, pre, out);
+    SNAG_GAT_NU(gat_aggregate_fwd_kernel, f, grid, st, x, N, f, H, w, rowptr, col, (const float*)s_src, (const float*)s_dst, apply_elu, agg, rsum, pre, out,
+                edge_keep, eid, n_edges, edge_keep_scale);
     return check_launch("snag_gat_layer_fwd");
 }
 
 extern "C" SNAG_API int snag_gat_layer_bwd(const float* x, int64_t N, int f, int H, const float* w, const float* a_src_dst, const int32_t* rowptr,
                                            const int32_t* col, const int32_t* t_rowptr, const int32_t* t_col, const float* s_src,
                                            const float* s_dst, const float* agg, const float* rsum, const float* pre, int had_elu,
-                                           const float* d_out, float* d_x, float* d_w, float* d_a, int accumulate, float* work, void* stream) {
+                                           const float* d_out, float* d_x, float* d_w, float* d_a, int accumulate, float* work,
+                                           const uint8_t* edge_keep, const int32_t* eid, const int32_t* t_eid, int64_t n_edges, float edge_keep_scale,
+                                           void* stream) {
     int rc = gat_check(N, f, H, x, w, a_src_dst, rowptr, col);
     if (rc || N == 0) return rc;
     SNAG_REQUIRE(s_src && s_dst && agg && rsum && d_out && d_x && d_w && d_a && work, SNAG_ERR_ARG, "gat_layer_bwd: null pointer");
+    SNAG_REQUIRE(edge_keep == nullptr || (eid != nullptr && t_eid != nullptr && n_edges >= 0), SNAG_ERR_ARG,
+                 "gat_layer_bwd: the edge keep mask needs both CSR position -> stored edge id arrays");
     SNAG_REQUIRE(t_rowptr && t_col, SNAG_ERR_ARG, "gat_layer_bwd: the destination-grouped edge list (t_rowptr, t_col) is required");
     SNAG_REQUIRE(!had_elu || pre, SNAG_ERR_ARG, "gat_layer_bwd: the ELU layer needs the saved pre-activation");
     hipStream_t st = (hipStream_t)stream;
@@ -415,12 +438,21 @@ extern "C" SNAG_API int snag_gat_layer_bwd(const float* x, int64_t N, int f, int
     float* part = gq + N * f;
     float* part2 = part + (int64_t)kGatBlocks * H * f;
     const int nb = (int)std::min<int64_t>(kGatBlocks, (N + 3) / 4);
-    SNAG_GAT_NU(gat_bwd_out_edges_kernel, f, dim3(nb), st, x, N, f, H, w, rowptr, col, s_src, s_dst, agg, rsum, pre, had_elu, d_out, gq, drs, ds_src, part);
+    SNAG_GAT_NU(gat_bwd_out_edges_kernel, f, dim3(nb), st, x, N, f, H, w, rowptr, col, s_src, s_dst, agg, rsum, pre, had_elu, d_out, gq, drs, ds_src, part, edge_keep, eid,
+                n_edges, edge_keep_scale);
     SNAG_GAT_NU(gat_bwd_in_edges_kernel, f, dim3((unsigned)ceil_div(N, 4)), st, x, N, f, H, w, t_rowptr, t_col, s_src, s_dst, rsum, (const float*)gq,
-                (const float*)drs, d_x, ds_dst);
+                (const float*)drs, d_x, ds_dst, edge_keep, t_eid, n_edges, edge_keep_scale);
     SNAG_GAT_NU(gat_node_scores_bwd_kernel, f, dim3(nb), st, x, N, f, H, w, a_src_dst, (const float*)ds_src, (const float*)ds_dst, d_x, part2);
     hipLaunchKernelGGL(gat_param_reduce_kernel, dim3(ceil_div(H * f, 16)), dim3(256), 0, st, (const float*)part, (const float*)part2, nb, nb, H, f, d_w, d_a, accumulate);
     return check_launch("snag_gat_layer_bwd");
+}
+
+extern "C" SNAG_API int snag_keep_scale(const float* x, int64_t n, const uint8_t* keep, float scale, float* out, void* stream) {
+    SNAG_REQUIRE(n >= 0, SNAG_ERR_ARG, "keep_scale: n=%ld", (long)n);
+    if (n == 0) return SNAG_OK;
+    SNAG_REQUIRE(x && keep && out, SNAG_ERR_ARG, "keep_scale: null pointer");
+    hipLaunchKernelGGL(keep_scale_kernel, dim3((unsigned)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, keep, scale, out);
+    return check_launch("snag_keep_scale");
 }
 
 extern "C" SNAG_API int snag_spmm_csr(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t N, int f,

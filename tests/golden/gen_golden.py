@@ -24,6 +24,7 @@ Vectors (SURVEY.md par. 8c):
   g14_set_optim.npz  set_optim parameter groups / cosine schedule on the SNAG model (src/utils.py:25-86)
   g12_gcn.npz        GCN structural encoder option (model/Tool_model.py:98-110, model/layers.py:102-130), output and grads
   g8_icl_loss.npz    icl_loss (bidirectional InfoNCE, model/SNAG_loss.py:31-128) + CustomMultiLossLayer, loss and grads
+  g16_gat_dropout.npz   the same GAT in TRAIN mode with dropout 0.2 / attn_dropout 0.3 (F.dropout replaced by recorded masks): output, masks, grads
   g15_atten_weight.npz  EVA_tools.SelfAttention.forward (model/EVA_tools.py:190-232; the in-tree arithmetic of joint_way "atten_weight"), output, weights, grads
 """
 import csv
@@ -738,6 +739,36 @@ def gen_g13():
     save("g13_data_surface_unsup.npz", d)
 
 
+def gen_g16():
+    """GAT training options: input dropout of the non-final layers (Tool_model.py:78-79) and edge dropout after the row sums (layers.py:83).
+    Masks in call order: layer 0 input, layer 0 head 0 edges, head 1 edges, layer 1 head 0 edges, head 1 edges."""
+    from model.Tool_model import GAT
+    from src.utils import get_adjr
+    g = torch.Generator().manual_seed(1616)
+    N, f = 150, 64
+    triples = [(int(a), 0, int(b)) for a, b in zip(torch.randint(0, N, (600,), generator=g), torch.randint(0, N, (600,), generator=g))]
+    adj = get_adjr(N, triples, norm=True)
+    gat = GAT(n_units=[f, f, f], n_heads=[2, 2], dropout=0.2, attn_dropout=0.3, instance_normalization=False, diag=True)
+    with torch.no_grad():
+        for l in gat.layer_stack:
+            l.w.copy_(1.0 + 0.3 * torch.randn(l.w.shape, generator=g))
+            l.a_src_dst.copy_(torch.randn(l.a_src_dst.shape, generator=g) * 0.4)
+    gat.train()
+    x = (torch.randn(N, f, generator=g) * 0.8).requires_grad_(True)
+    cw = torch.randn(N, f, generator=g)
+    with DropoutRecorder(torch.Generator().manual_seed(16)) as rec:
+        y = gat(x, adj)
+    (y * cw).sum().backward()
+    assert len(rec.masks) == 5 and tuple(rec.masks[0].shape) == (N, f)
+    d = {"x": x, "edges": adj._indices(), "cw": cw, "y": y, "g.x": x.grad, "n_heads": np.array([2, 2]), "p_in": 0.2, "p_edge": 0.3,
+         "in_keep0": rec.masks[0], "edge_keep0": torch.stack(rec.masks[1:3]), "edge_keep1": torch.stack(rec.masks[3:5])}
+    for k, v in gat.state_dict().items():
+        d["p." + k] = v
+    for k, p in gat.named_parameters():
+        d["g.p." + k] = p.grad
+    save("g16_gat_dropout.npz", d)
+
+
 def gen_g15():
     """The non-transformer attention read-out: SelfAttention(hidden, batch_first=True) on [N, M, D] tokens, M in {3, 4, 6}, D in {128, 300}."""
     import warnings
@@ -763,5 +794,5 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()["gen_" + name]()
         sys.exit(0)
-    for fn in (gen_g1, gen_g2, gen_g3, gen_g4_g5, gen_g6, gen_g7, gen_g8, gen_g9, gen_g10, gen_g11, gen_g12, gen_g13, gen_g14, gen_g15):
+    for fn in (gen_g1, gen_g2, gen_g3, gen_g4_g5, gen_g6, gen_g7, gen_g8, gen_g9, gen_g10, gen_g11, gen_g12, gen_g13, gen_g14, gen_g15, gen_g16):
         fn()                        # "regenerate all" means ALL: G11-G14 included

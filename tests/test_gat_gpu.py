@@ -34,8 +34,77 @@ def test_gat_state_dict_keys():
     gat = GAT([64, 64, 64], [2, 2], 0.0, 0.0, False, True)
     assert set(gat.state_dict()) == {k[2:] for k in z if k.startswith("p.")}
     assert torch.equal(gat.layer_stack[0].w, torch.ones(2, 1, 64))            # init=nn.init.ones_ (Tool_model.py:72)
-    with pytest.raises(NotImplementedError):
-        GAT([64, 64], [2], 0.1, 0.0, False, True)
+    with pytest.raises(NotImplementedError):                                  # the reference's own InstanceNorm1d path raises on [N, f] inputs
+        GAT([64, 64], [2], 0.0, 0.0, True, True)
+    with pytest.raises(ValueError):
+        GAT([64, 64], [2], 1.0, 0.0, False, True)
+
+
+def test_gat_dropout_golden():
+    """G16: the reference GAT in TRAIN mode -- dropout 0.2 on the first layer's input (Tool_model.py:78-79), attn_dropout 0.3 on every head's
+    edge weights after the row sums (layers.py:83) -- with the reference's recorded masks: output and every gradient."""
+    from snag_amd.gat import GAT
+    z = load("g16_gat_dropout.npz")
+    gat = GAT(n_units=[64, 64, 64], n_heads=[2, 2], dropout=float(z["p_in"]), attn_dropout=float(z["p_edge"]), instance_normalization=False, diag=True)
+    gat.load_state_dict({k[2:]: T(v) for k, v in z.items() if k.startswith("p.")}, strict=True)
+    gat = gat.to(DEV).train()
+    masks = {"in": [T(z["in_keep0"], DEV), None], "edge": [T(z["edge_keep0"], DEV), T(z["edge_keep1"], DEV)]}
+    x = T(z["x"], DEV).requires_grad_(True)
+    y = gat(x, T(z["edges"], DEV), drop_masks=masks)
+    assert_close(y, z["y"], atol=1e-5, rtol=1e-5)
+    (y * T(z["cw"], DEV)).sum().backward()
+    assert_close(x.grad, z["g.x"], atol=1e-5, rtol=1e-4)
+    for k, p in gat.named_parameters():
+        assert_close(p.grad, z["g.p." + k], atol=5e-5, rtol=1e-4, what=k)
+    # eval mode ignores the rates (F.dropout(training=False)); drawn masks: reproducible under torch.manual_seed, different across draws
+    gat.eval()
+    y_eval = gat(x.detach(), T(z["edges"], DEV))
+    g0 = GAT([64, 64, 64], [2, 2], 0.0, 0.0, False, True)
+    g0.load_state_dict(gat.state_dict())
+    assert torch.equal(y_eval, g0.to(DEV)(x.detach(), T(z["edges"], DEV)))
+    gat.train()
+    torch.manual_seed(5)
+    a = gat(x.detach(), T(z["edges"], DEV))
+    torch.manual_seed(5)
+    b = gat(x.detach(), T(z["edges"], DEV))
+    c = gat(x.detach(), T(z["edges"], DEV))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+@pytest.mark.parametrize("N,f,heads,p_in,p_edge", [(700, 300, [2, 2], 0.3, 0.2), (333, 36, [1, 3, 2], 0.0, 0.5), (2000, 128, [2, 2], 0.4, 0.0)])
+def test_gat_dropout_vs_oracle(N, f, heads, p_in, p_edge):
+    """Ragged widths, three layers, either option alone, duplicate edges and self loops: engine with explicit masks vs the float64 oracle."""
+    from snag_amd.gat import GAT
+    g = torch.Generator().manual_seed(N + f)
+    E0 = 5 * N
+    a, b = torch.randint(0, N, (E0,), generator=g), torch.randint(0, N, (E0,), generator=g)
+    edges = torch.cat([torch.stack([a, b]), torch.stack([b, a]), torch.arange(N).repeat(2, 1)], dim=1)
+    E = edges.shape[1]
+    L = len(heads)
+    gat = GAT([f] * (L + 1), heads, p_in, p_edge, False, True)
+    with torch.no_grad():
+        for l in gat.layer_stack:
+            l.w.copy_(1.0 + 0.2 * torch.randn(l.w.shape, generator=g))
+            l.a_src_dst.copy_(torch.randn(l.a_src_dst.shape, generator=g) * 0.2)
+    x = torch.randn(N, f, generator=g) * 0.5
+    in_keep = [((torch.rand(N, f, generator=g) >= p_in).to(torch.uint8) if (p_in > 0 and i + 1 < L) else None) for i in range(L)]
+    edge_keep = [((torch.rand(heads[i], E, generator=g) >= p_edge).to(torch.uint8) if p_edge > 0 else None) for i in range(L)]
+    layers = [{"w": l.w.detach().double().requires_grad_(True), "a_src_dst": l.a_src_dst.detach().double().requires_grad_(True)} for l in gat.layer_stack]
+    xo = x.double().requires_grad_(True)
+    yo = O.gat_forward(xo, edges, layers, in_keep=in_keep, edge_keep=edge_keep, p_in=p_in, p_edge=p_edge)
+    cw = torch.randn(N, f, generator=g)
+    (yo * cw.double()).sum().backward()
+    gat = gat.to(DEV).train()
+    xd = x.to(DEV).requires_grad_(True)
+    dev = lambda ms: [m.to(DEV) if m is not None else None for m in ms]
+    y = gat(xd, edges.to(DEV), drop_masks={"in": dev(in_keep), "edge": dev(edge_keep)})
+    assert_close(y, yo, atol=2e-5, rtol=1e-5)
+    (y * cw.to(DEV)).sum().backward()
+    assert_close(xd.grad, xo.grad, atol=2e-5, rtol=1e-3)
+    for l in range(L):
+        gw, ga = layers[l]["w"].grad, layers[l]["a_src_dst"].grad
+        assert_close(gat.layer_stack[l].w.grad, gw, atol=2e-4 * float(gw.abs().max()), rtol=1e-3)
+        assert_close(gat.layer_stack[l].a_src_dst.grad, ga, atol=2e-4 * float(ga.abs().max()), rtol=1e-3)
 
 
 def test_gat_dbp15k_sized_graph_vs_oracle():

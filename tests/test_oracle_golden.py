@@ -265,3 +265,22 @@ def test_adaptive_avg_pool_rows_windows():
     y = torch.randn(3, 12 * 64, generator=g)
     got2 = O.adaptive_avg_pool_rows(y, (4, 64), view_hw=(12, 64))
     assert_close(got2, y.view(3, 4, 3, 64).mean(dim=2).reshape(3, 256), atol=1e-6, what="12x64 -> 4x64")
+
+
+def test_gat_with_dropout():
+    """G16: the reference GAT in TRAIN mode (dropout 0.2 on the first layer's input, attn_dropout 0.3 on every head's edge weights after the row
+    sums; F.dropout replaced by recorded masks): oracle.gat_forward with the same masks, output and all gradients."""
+    z = load("g16_gat_dropout.npz")
+    x = T(z["x"]).requires_grad_(True)
+    layers = [{"w": T(z[f"p.layer_stack.{l}.w"]).requires_grad_(True), "a_src_dst": T(z[f"p.layer_stack.{l}.a_src_dst"]).requires_grad_(True)}
+              for l in range(2)]
+    y = O.gat_forward(x, T(z["edges"]), layers, in_keep=[T(z["in_keep0"]), None], edge_keep=[T(z["edge_keep0"]), T(z["edge_keep1"])],
+                      p_in=float(z["p_in"]), p_edge=float(z["p_edge"]))
+    assert_close(y, z["y"], atol=2e-6, rtol=1e-5)
+    (y * T(z["cw"])).sum().backward()
+    assert_close(x.grad, z["g.x"], atol=2e-6, rtol=1e-4)
+    for l in range(2):
+        assert_close(layers[l]["w"].grad, z[f"g.p.layer_stack.{l}.w"], atol=2e-5, rtol=1e-4)
+        assert_close(layers[l]["a_src_dst"].grad, z[f"g.p.layer_stack.{l}.a_src_dst"], atol=2e-5, rtol=1e-4)
+    # the masks matter
+    assert not torch.allclose(O.gat_forward(x.detach(), T(z["edges"]), [{k: v.detach() for k, v in l.items()} for l in layers]), T(z["y"]), atol=1e-3)
