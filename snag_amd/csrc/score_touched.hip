@@ -780,17 +780,44 @@ __global__ __launch_bounds__(256) void touched_hub_kernel(const TabT* __restrict
             fix_add_row<NV>(acc, ld_row4<NV>(w.rows, rc.src, dim, dim, sub), rc.w);
             fix_add_run<NV, 2>(acc, w.list + (int64_t)dest * kTCap + 1, (unsigned)kTCap - 1u, w.rows, dim, sub, gbase);
         }
-        for (unsigned j = (unsigned)gi; j * kTChunk < over; j += 16u) {          // the chunk partials pass B' left
-            const unsigned hslot = touched_find(keys, w.hmask, dest, j);
-            const long long* pr = w.hpart + (int64_t)hslot * dim;
+        // the chunk partials pass B' left, FOUR chunks of the group per step: their hash slots are probed side by side (first probes together; a
+        // collision falls back to the sequential search) and their partial rows requested together -- two dependent round trips per four chunks
+        // instead of eight (a Zipf(1.0) batch's hottest row has ~144 chunks, nine per group: the launch was that row's 18 round trips)
+        for (unsigned j0 = (unsigned)gi; j0 * kTChunk < over; j0 += 64u) {
+            unsigned hs[4];
+            bool on[4];
+            unsigned long long k0[4];
 #pragma unroll
-            for (int jv = 0; jv < NV; ++jv) {
-                const int c = (sub + 16 * jv) * 4;
-                if (c < dim) {
-                    const longlong2 a = reinterpret_cast<const longlong2*>(pr + c)[0], b2 = reinterpret_cast<const longlong2*>(pr + c)[1];
-                    acc[4 * jv + 0] += a.x; acc[4 * jv + 1] += a.y; acc[4 * jv + 2] += b2.x; acc[4 * jv + 3] += b2.y;
+            for (int u = 0; u < 4; ++u) {
+                const unsigned j = j0 + 16u * u;
+                on[u] = j * kTChunk < over;
+                hs[u] = touched_hash(touched_key(dest, on[u] ? j : 0u)) & w.hmask;
+                k0[u] = keys[hs[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (on[u] && k0[u] != touched_key(dest, j0 + 16u * u)) hs[u] = touched_find(keys, w.hmask, dest, j0 + 16u * u);
+            longlong2 pa[4][NV], pb[4][NV];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long* pr = w.hpart + (int64_t)hs[u] * dim;
+#pragma unroll
+                for (int jv = 0; jv < NV; ++jv) {
+                    const int c = (sub + 16 * jv) * 4;
+                    const int cc = c < dim ? c : 0;
+                    pa[u][jv] = reinterpret_cast<const longlong2*>(pr + cc)[0];
+                    pb[u][jv] = reinterpret_cast<const longlong2*>(pr + cc)[1];
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int jv = 0; jv < NV; ++jv) {
+                    const int c = (sub + 16 * jv) * 4;
+                    if (on[u] && c < dim) {
+                        acc[4 * jv + 0] += pa[u][jv].x; acc[4 * jv + 1] += pa[u][jv].y; acc[4 * jv + 2] += pb[u][jv].x; acc[4 * jv + 3] += pb[u][jv].y;
+                    }
+                }
         }
 #pragma unroll
         for (int i = 0; i < 4 * NV; ++i) red[gi][sub][i] = acc[i];
