@@ -751,6 +751,9 @@ static int launch_reduce(const GemmPlan& pl, float* slab, hipStream_t st);
 // Up to kGroupMax problems in ONE launch (gemm_tile_group_kernel) when every one of them would run the 64 x 128 tile with plain or split K
 // (no stream-K) on the same operand layouts; anything else: one after the other.  Each problem keeps the K split, slab and epilogue its
 // own dispatch would use, so the results are the same bits as one-by-one launches.
+#ifndef SNAG_GEMM_GROUP_BM
+#define SNAG_GEMM_GROUP_BM 256      // rows per tile of the long-K grouped launches: 256 = eight waves in two ping-pong groups; 128 = four waves (A/B)
+#endif
 int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) {
     GemmPlan pl[kGroupMax];
     bool ok = n >= 2 && n <= kGroupMax;
@@ -785,7 +788,7 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
         g.e[i] = pl[i].e;
         g.slab[i] = pl[i].splits > 1 ? ds[i]->workspace : nullptr;
         g.tiles_n[i] = ceil_div(pl[i].p.N, 128);
-        g.tiles[i] = g.tiles_n[i] * ceil_div(pl[i].p.M, pp ? 256 : 64);
+        g.tiles[i] = g.tiles_n[i] * ceil_div(pl[i].p.M, pp ? SNAG_GEMM_GROUP_BM : 64);
         g.first[i] = blocks;
         blocks += g.tiles[i] * pl[i].splits;
         if (ds[i]->a_kcontig) g.a_kc_mask |= 1u << i;
@@ -809,8 +812,8 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
     } else {
 #define SNAG_GROUPN(AK, BK_)                                                                                                              \
     do {                                                                                                                                  \
-        if (pp && vec) hipLaunchKernelGGL((gemm_tile_group_kernel<256, 128, 32, 128, AK, BK_, true, Epilogue>), dim3(blocks), dim3(512), 0, st, g);     \
-        else if (pp) hipLaunchKernelGGL((gemm_tile_group_kernel<256, 128, 32, 128, AK, BK_, false, Epilogue>), dim3(blocks), dim3(512), 0, st, g);      \
+        if (pp && vec) hipLaunchKernelGGL((gemm_tile_group_kernel<SNAG_GEMM_GROUP_BM, 128, 32, 128, AK, BK_, true, Epilogue>), dim3(blocks), dim3(2 * SNAG_GEMM_GROUP_BM), 0, st, g);     \
+        else if (pp) hipLaunchKernelGGL((gemm_tile_group_kernel<SNAG_GEMM_GROUP_BM, 128, 32, 128, AK, BK_, false, Epilogue>), dim3(blocks), dim3(2 * SNAG_GEMM_GROUP_BM), 0, st, g);      \
         else if (vec) hipLaunchKernelGGL((gemm_tile_group_kernel<64, 128, 32, 64, AK, BK_, true, Epilogue>), dim3(blocks), dim3(256), 0, st, g);     \
         else hipLaunchKernelGGL((gemm_tile_group_kernel<64, 128, 32, 64, AK, BK_, false, Epilogue>), dim3(blocks), dim3(256), 0, st, g);       \
     } while (0)
