@@ -137,7 +137,7 @@ def score_train_bytes(cfg, n_triples):
     return score_bytes(cfg, n_triples) + n_triples * (cfg.neg_num + 3) * cfg.dim * 4 * 2
 
 
-def roofline_score(cfg, batch, timer, ln_fused=False):
+def roofline_score(cfg, batch, timer, ln_fused=False, ln_dropout=True):
     """north_star's kernel in its training form (snag_score_margin_fwd_bwd_seg): per 1024-triple batch a per-triple pass (every table
     row gathered ONCE; scores, losses, q / dq rows, one 8-byte entry per touched destination) and a per-destination pass (gathers the
     L2-resident q / dq rows, applies the normalisation backward once, WRITES each gradient row: no float atomics, no zero-fill,
@@ -150,7 +150,8 @@ def roofline_score(cfg, batch, timer, ln_fused=False):
     # the entry the headline engine calls since round 4 also carries the gradient through the read-out rows' LayerNorm inside pass B
     # (snag_score_margin_fwd_bwd_seg_ln): the separate LayerNorm-backward launch's bytes -- the pre-LN rows read, dT and dT * keep written,
     # the keep mask read -- belong to the timed launches, while the scorer's own gradient rows are no longer written
-    ln_bytes = cfg.n_ent * cfg.dim * (4 + 4 + 4 + 1) - cfg.n_ent * cfg.dim * 4 if ln_fused else 0
+    # (the dT * keep rows and the keep-mask bytes only when the engine runs with the output dropout on: snag_ln_bwd_tail.dtm set)
+    ln_bytes = cfg.n_ent * cfg.dim * (4 + 4 + ((4 + 1) if ln_dropout else 0)) - cfg.n_ent * cfg.dim * 4 if ln_fused else 0
     by += ln_bytes
     ach = by / (us * 1e-6) / 1e9 if us else 0.0
     atomic_bytes = batch * (cfg.neg_num + 3) * cfg.dim * 4
@@ -1100,7 +1101,8 @@ def main():
         out.update(extras)
         if timers:
             out["roofline"] = roofline_dominant(cfg, timers["proj_l1_fwd"], rows=eng.shard.n_loc, reduce_timer=timers["proj_l1_fwd_reduce"], grouped=eng.l1_grouped)
-            out["roofline_score"] = roofline_score(cfg, args.batch, timers["score_fwd_bwd"], ln_fused=bool(getattr(eng, "_ln_fuse", False)))
+            out["roofline_score"] = roofline_score(cfg, args.batch, timers["score_fwd_bwd"], ln_fused=bool(getattr(eng, "_ln_fuse", False)),
+                                                   ln_dropout=bool(eng.training and cfg.dropout > 0))
             if not args.no_extras:
                 out["roofline_score"]["batch_8192"] = score_train_larger_batch(eng, cfg, device)
                 out["roofline_score"]["hbm_resident"] = score_hbm_resident(device)
