@@ -77,7 +77,8 @@ def _worker(rank, world, port, joint_way, out, row_sharded=False, n_ent=900, ste
 
 @pytest.mark.parametrize("joint_way,row_sharded,n_ent", [("Mformer_hd_graph", False, 900), ("Mformer_hd_mean", False, 900),
                                                          ("Mformer_hd_graph", True, 900), ("Mformer_hd_mean", True, 900),
-                                                         ("Mformer_hd_graph", True, 901)])
+                                                         ("Mformer_hd_graph", True, 901),
+                                                         ("atten_weight", False, 900), ("atten_weight", True, 901)])
 def test_two_rank_engine_step_equals_global_batch_step(tmp_path, joint_way, row_sharded, n_ent):
     """row_sharded: each rank projects and fuses ITS half of the entity rows only (the read-out table is all-gathered before scoring,
     its gradient reduce-scattered back, the entity-table gradient gathered); 901 rows: padded shards, the in-place gather of the
