@@ -753,15 +753,15 @@ __global__ __launch_bounds__(256, SNAG_TB_WAVES) void touched_b_kernel(const Tab
 }
 
 // ---- pass C: hot rows -----------------------------------------------------------------------------------------------------------------
-// One WORKGROUP per hot row (a persistent grid walks the list): its sixteen 16-lane groups share the row's chunk partials -- group i takes
-// chunks i, i + 16, ... -- and meet in LDS; 64-bit integer sums are order-free, so the result does not depend on who added what.  (One group
+// One WORKGROUP per hot row (a persistent grid walks the list): its sixteen 16-lane groups share the row's inline entries (one each) and
+// chunk partials -- group i takes chunks i, i + 16, ... -- and meet in LDS; 64-bit integer sums are order-free, so the result does not depend on who added what.  (One group
 // per hot row walked a Zipf(1.0) batch's hottest row -- 9,200 entries, 144 chunks -- alone: 215 us.)
 template <int NV, typename TabT>
 __global__ __launch_bounds__(256) void touched_hub_kernel(const TabT* __restrict__ ent, int64_t eld, const TabT* __restrict__ rel, int dim, int n_ent,
                                                           float* __restrict__ d_ent, int64_t dld, float* __restrict__ d_rel, TouchedWork w) {
     __shared__ long long red[16][16][4 * NV];
     __shared__ long long tot[16][4 * NV];
-    const int lane = threadIdx.x & 63, sub = lane & 15, gbase = lane & 48;
+    const int lane = threadIdx.x & 63, sub = lane & 15;
     const int gi = threadIdx.x >> 4;                       // group inside the workgroup
     const unsigned which = w.hdr->cur & 1u;
     const unsigned nh = min(w.hdr->n_hubs[which], w.max_hubs);
@@ -775,10 +775,17 @@ __global__ __launch_bounds__(256) void touched_hub_kernel(const TabT* __restrict
         long long acc[4 * NV];
 #pragma unroll
         for (int i = 0; i < 4 * NV; ++i) acc[i] = 0;
-        if (gi == 0) {                                     // the owner's own entry and the bucket's slots 1..15
-            const TouchedRec rc = w.rec[hb.rec];
-            fix_add_row<NV>(acc, ld_row4<NV>(w.rows, rc.src, dim, dim, sub), rc.w);
-            fix_add_run<NV, 2>(acc, w.list + (int64_t)dest * kTCap + 1, (unsigned)kTCap - 1u, w.rows, dim, sub, gbase);
+        {   // the sixteen inline entries, ONE per group (group 0: the owner's own record; group i: bucket slot i): two dependent round trips for
+            // all of them (group 0 used to walk them alone: one entry fetch + eight gather steps behind each other)
+            SegEntry e0;
+            if (gi == 0) {
+                const TouchedRec rc = w.rec[hb.rec];
+                e0 = SegEntry{rc.src, rc.w};
+            } else {
+                e0 = w.list[(int64_t)dest * kTCap + gi];
+            }
+            const bool have = (unsigned)gi < min(n, (unsigned)kTCap);
+            fix_add_row<NV>(acc, ld_row4<NV>(w.rows, have ? e0.src : 0, dim, dim, sub), have ? e0.w : 0.f);
         }
         // the chunk partials pass B' left, FOUR chunks of the group per step: their hash slots are probed side by side (first probes together; a
         // collision falls back to the sequential search) and their partial rows requested together -- two dependent round trips per four chunks
