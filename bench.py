@@ -969,6 +969,8 @@ def main():
     shard = RowShard(cfg.n_ent, rank, world) if row_sharded else None
     if os.environ.get("BENCH_L1_ROUND"):                 # A/B only (tools/): K splits of the grouped first projections sized for two workgroups per CU
         MKGCHotPath.l1_round = int(os.environ["BENCH_L1_ROUND"])
+    if os.environ.get("BENCH_W_ROUND"):                  # A/B only: see MKGCHotPath.w_round
+        MKGCHotPath.w_round = int(os.environ["BENCH_W_ROUND"])
     eng = MKGCHotPath(cfg, feats, device=device, shard=shard)
     raw_dims, cfg = list(cfg.feat_dims), eng.cfg               # (--pool: the engine's configuration carries the pooled widths)
     reducer = GradAllReduce(world) if world > 1 else None

@@ -461,6 +461,7 @@ class MKGCHotPath:
     def _gemm(self, *a, **k):
         call("snag_gemm_f32", ctypes.byref(self._gemm_desc(*a, **k)), self._st)
 
+    w_round = 256           # workgroups the weight gradients of the merged backward launch are split into (0: the library's choice; tools/ab experiments)
     l1_round = 256          # workgroups one launch of eight-wave tiles should fill (one per CU; 512 = two per CU: tools/ab experiments only --
                             # the kernel's 176 registers admit one eight-wave workgroup per CU)
 
@@ -512,7 +513,7 @@ class MKGCHotPath:
         return [self._gemm_desc(Nl, 2 * D, D, ptr(self.mid[i]), D, 1, ptr(self.wf[i]), D, 1, self._qkv_ptr + 4 * (i * 3 * D + D), 3 * MD,
                                 bias=self.p["layer0.bqkv"].data_ptr() + 4 * D, splitk=False) for i in range(len(cfg.feat_dims))]
 
-    def _fold_bwd_descs(self, defer):
+    def _fold_bwd_descs(self, defer, merged=False):
         """Folded second projections, backward: (d Wf_m = dKV_m^T mid_m, K split over the rows, slabs in work_l2), (d mid_m = (dKV_m Wf_m) *
         [mid_m > 0] (* keep)) for every modality; dKV_m sits in the Mformer backward's scratch (rows n * M + m of its [rows * M, 2 D] block)."""
         cfg = self.cfg
@@ -521,8 +522,12 @@ class MKGCHotPath:
         nmod = len(cfg.feat_dims)
         dl2 = [self._gemm_desc(2 * D, D, Nl, dkv + 4 * i * 2 * D, 2 * MD, 0, ptr(self.mid[i]), D, 0, ptr(self.d_wf[i]), D, splitk=True, half=i % 2,
                                scratch=self.work_l2) for i in range(nmod)]
+        # inside the merged backward launch (snag_fusion_bwd, fold_others) the weight gradients share ONE round of ~256 workgroups: the layer's own
+        # dWqkv (3D / 64 tiles) and dWo (D / 64) + these (2D / 64 each); the library applies the same rule to its two
+        # (``merged``: three tokens -- what snag_fusion_bwd runs as that one launch)
+        want = max(1, self.w_round // ((4 * D + nmod * 2 * D) // 64)) if (self.w_round and merged and M == 3) else 0
         for d in dl2:
-            d.defer_reduce = int(defer)
+            d.defer_reduce, d.splits = int(defer), want
         dmid = [self._gemm_desc(Nl, D, 2 * D, dkv + 4 * i * 2 * D, 2 * MD, 1, ptr(self.wf[i]), D, 0, ptr(self.d_mid[i]), D, act=4, aux=ptr(self.mid[i]),
                                 ldaux=D, keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout), splitk=False) for i in range(nmod)]
         return dl2, dmid
@@ -925,7 +930,7 @@ class MKGCHotPath:
         if co:
             # folded second projections (see below): with one or two modalities their products on the key / value gradient ride in the
             # Mformer backward's own grouped launches (co_dx with d x of the read-out token, co_dw with d Wo / d Wqkv and ONE reduce)
-            dl2, dmid = self._fold_bwd_descs(True)
+            dl2, dmid = self._fold_bwd_descs(True, merged=True)
             self._co_bwd = (dl2, dmid)
             for j in range(nmod):
                 bd.co_dw[j], bd.co_dx[j] = ctypes.pointer(dl2[j]), ctypes.pointer(dmid[j])
