@@ -68,12 +68,26 @@ struct TopK {
         for (int i = 0; i < KK; ++i) v[i] = -INFINITY;
     }
     __device__ __forceinline__ void push(float x) {
-        if (!(x > v[KK - 1])) return;           // cannot enter the buffer
+        if constexpr (KK <= 5) {
+            // branch-free, no dependent chain: new v[0] = max(v[0], x), new v[i] = median(old v[i-1], x, old v[i]) -- x above old v[i-1]: the
+            // slot takes its neighbour (shift); between the two: x itself; below: unchanged.  KK independent VALU operations per value (the
+            // compare-exchange chain below is 2 KK dependent ones behind a divergent branch that a wave takes whenever ANY lane inserts).
+            float p = v[0];
+            v[0] = fmaxf(p, x);
 #pragma unroll
-        for (int i = 0; i < KK; ++i) {          // insertion by compare-exchange down the array
-            const float hi = fmaxf(v[i], x), lo = fminf(v[i], x);
-            v[i] = hi;
-            x = lo;
+            for (int i = 1; i < KK; ++i) {
+                const float c = v[i];
+                v[i] = __builtin_amdgcn_fmed3f(p, x, c);
+                p = c;
+            }
+        } else {
+            if (!(x > v[KK - 1])) return;       // cannot enter the buffer
+#pragma unroll
+            for (int i = 0; i < KK; ++i) {      // insertion by compare-exchange down the array
+                const float hi = fmaxf(v[i], x), lo = fminf(v[i], x);
+                v[i] = hi;
+                x = lo;
+            }
         }
     }
 };
@@ -198,13 +212,90 @@ __global__ __launch_bounds__(64) void col_topk_part4_kernel(const float* __restr
             if (i < k && j < nc) part[((int64_t)blockIdx.y * k + i) * m + col + j] = t[j].v[i];
 }
 
+// Row AND column candidates from ONE sweep of the matrix (round 5; the row means used to be a sweep of their own: 441 MB at 10,500^2).
+// One wave per (256 columns, chunk of rows), EIGHT rows at a time, the next eight in flight (a row's 1 KB per load instruction); the
+// column side pushes them into its four lists as col_topk_part4_kernel does; for the row side the 8 x 256 block changes hands through
+// LDS -- lane (row = lane / 8, part = lane % 8) reads 32 columns of ITS row, so the pushes are lane-local too --, the eight parts of a
+// row merge with three exchanges and the row's k best of these 256 columns go to row_part[block][i][row].
+// A top-k is a set: the same values as row_topk_mean_kernel / col_topk_part4_kernel collect, whatever the visiting order.
+// (9 KB of LDS and 64 registers of row data per wave: a launch of 42 x 64 waves is resident at once; sixteen rows per step -- 17 KB --
+// left a second, nearly empty round of waves: 130 us against the two separate sweeps' 200.)
+constexpr int kRcRows = 8;
+constexpr int kRcPitch = 288;           // floats per staged row: 256 + a 4-float skew per 32 columns, rows 8 bank groups apart (conflict-free reads)
+__device__ __forceinline__ int rc_at(int row, int c) { return row * kRcPitch + c + 4 * (c >> 5); }
+template <int KK>
+__global__ __launch_bounds__(64) void rowcol_topk_part_kernel(const float* __restrict__ mat, int64_t ld, int n, int m, int k, int from_dist,
+                                                              int rows_per_chunk, float* __restrict__ col_part, float* __restrict__ row_part) {
+    __shared__ __attribute__((aligned(16))) float tile[kRcRows * kRcPitch];
+    const int lane = threadIdx.x;
+    const int col = (blockIdx.x * 64 + lane) * 4;           // (m % 4 == 0: a lane's four columns are all inside or all outside)
+    const bool col_on = col < m;
+    const int r0 = blockIdx.y * rows_per_chunk, r_end = min(n, r0 + rows_per_chunk);
+    const int rr = lane >> 3, part = lane & 7;
+    TopK<KK> tc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tc[j].init();
+    auto fetch = [&](int rb, float4 (&v)[kRcRows]) {
+#pragma unroll
+        for (int j = 0; j < kRcRows; ++j)                    // (clamped row and column: nothing conditional around a load)
+            v[j] = *reinterpret_cast<const float4*>(mat + (int64_t)min(rb + j, r_end - 1) * ld + (col_on ? col : 0));
+    };
+    float4 v[kRcRows], nx[kRcRows];
+    fetch(r0, nx);
+    for (int rb = r0; rb < r_end; rb += kRcRows) {
+#pragma unroll
+        for (int j = 0; j < kRcRows; ++j) v[j] = nx[j];
+        fetch(min(rb + kRcRows, r_end - 1), nx);             // the next rows travel while these are processed
+#pragma unroll
+        for (int j = 0; j < kRcRows; ++j) {
+            if (from_dist) v[j] = make_float4(1.0f - v[j].x, 1.0f - v[j].y, 1.0f - v[j].z, 1.0f - v[j].w);
+            if (!col_on) v[j] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            *reinterpret_cast<float4*>(&tile[rc_at(j, 4 * lane)]) = v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < kRcRows; ++j)
+            if (rb + j < r_end) {                            // (uniform)
+                tc[0].push(v[j].x); tc[1].push(v[j].y); tc[2].push(v[j].z); tc[3].push(v[j].w);
+            }
+        __syncthreads();
+        TopK<KK> tr;
+        tr.init();
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float4 w = *reinterpret_cast<const float4*>(&tile[rc_at(rr, 32 * part + 4 * t)]);
+            tr.push(w.x); tr.push(w.y); tr.push(w.z); tr.push(w.w);
+        }
+        __syncthreads();                                     // the next rows overwrite the tile
+#pragma unroll
+        for (int off = 1; off <= 4; off <<= 1) {
+            float o[KK];
+#pragma unroll
+            for (int i = 0; i < KK; ++i) o[i] = __shfl_xor(tr.v[i], off);
+#pragma unroll
+            for (int i = 0; i < KK; ++i) tr.push(o[i]);
+        }
+        if (part == 0 && rb + rr < r_end) {
+#pragma unroll
+            for (int i = 0; i < KK; ++i)
+                if (i < k) row_part[((int64_t)blockIdx.x * k + i) * n + rb + rr] = tr.v[i];
+        }
+    }
+    if (col_on) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < KK; ++i)
+                if (i < k) col_part[((int64_t)blockIdx.y * k + i) * m + col + j] = tc[j].v[i];
+    }
+}
+
 // 64 columns per block; the block's four waves merge every fourth chunk each, wave 0 then merges the four k-lists (a top-k is the same
 // set whatever the order; the mean adds its values in descending order)
 template <int KK>
-__global__ __launch_bounds__(256) void col_topk_merge_kernel(const float* __restrict__ part, int chunks, int m, int k, float* __restrict__ out) {
+__device__ __forceinline__ void col_topk_merge_body(const float* __restrict__ part, int chunks, int m, int k, float* __restrict__ out, int block) {
     __shared__ float ex[3][KK][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + lane;
+    const int col = block * 64 + lane;
     TopK<KK> t;
     t.init();
     if (col < m)
@@ -225,6 +316,17 @@ __global__ __launch_bounds__(256) void col_topk_merge_kernel(const float* __rest
     for (int i = 0; i < KK; ++i)
         if (i < k) acc += t.v[i];
     out[col] = acc / (float)k;
+}
+template <int KK>
+__global__ __launch_bounds__(256) void col_topk_merge_kernel(const float* __restrict__ part, int chunks, int m, int k, float* __restrict__ out) {
+    col_topk_merge_body<KK>(part, chunks, m, k, out, blockIdx.x);
+}
+// two candidate sets (the column side and the row side of rowcol_topk_part_kernel) finished by one launch
+template <int KK>
+__global__ __launch_bounds__(256) void col_topk_merge2_kernel(const float* __restrict__ part0, int chunks0, int m0, float* __restrict__ out0, int blocks0,
+                                                              const float* __restrict__ part1, int chunks1, int m1, float* __restrict__ out1, int k) {
+    if ((int)blockIdx.x < blocks0) col_topk_merge_body<KK>(part0, chunks0, m0, k, out0, blockIdx.x);
+    else col_topk_merge_body<KK>(part1, chunks1, m1, k, out1, blockIdx.x - blocks0);
 }
 
 // the value the ranks compare: Dist' (CSLS) or Dist
@@ -702,6 +804,24 @@ extern "C" SNAG_API int snag_csls_neighbourhood(const float* mat, int64_t ld, in
     const int rpc = ceil_div(n, chunks);
     const int nch = ceil_div(n, rpc);
     const int vec = matrix_vec_ok(mat, ld);
+    const int cb = ceil_div(m, 256);
+    if (vec && m % 4 == 0 && cb <= kColChunks) {
+        // ONE sweep for both neighbourhoods: row candidates per 256-column block behind the column candidates in the workspace
+        const int rpc16 = ceil_div(rpc, kRcRows) * kRcRows, nch16 = ceil_div(n, rpc16);
+        float* row_part = work + (int64_t)kColChunks * kMaxK * std::max(n, m);
+#define SNAG_TOPK(KK)                                                                                                                       \
+    do {                                                                                                                                    \
+        hipLaunchKernelGGL((rowcol_topk_part_kernel<KK>), dim3(cb, nch16), dim3(64), 0, st, mat, ld, n, m, k, from_dist, rpc16, work, row_part); \
+        hipLaunchKernelGGL((col_topk_merge2_kernel<KK>), dim3(ceil_div(m, 64) + ceil_div(n, 64)), dim3(256), 0, st, (const float*)work, nch16, m, r2, \
+                           ceil_div(m, 64), (const float*)row_part, cb, n, r1, k);                                                          \
+    } while (0)
+        if (k <= 3) SNAG_TOPK(3);
+        else if (k <= 5) SNAG_TOPK(5);
+        else if (k <= 10) SNAG_TOPK(10);
+        else SNAG_TOPK(16);
+#undef SNAG_TOPK
+        return check_launch("snag_csls_neighbourhood");
+    }
 #define SNAG_TOPK(KK)                                                                                                                       \
     do {                                                                                                                                    \
         hipLaunchKernelGGL((row_topk_mean_kernel<KK>), dim3(n), dim3(256), 0, st, mat, ld, n, m, k, from_dist, r1, vec);                     \
