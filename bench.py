@@ -197,10 +197,10 @@ def score_train_larger_batch(eng, cfg, device, B=8192):
 
 
 def untimed_extras(eng, batches, args, device):
-    """Reported next to the headline: the forward-only rate (SURVEY.md par. 8d asks for both).  Measured on every rank BEFORE the
-    warm-up steps (forward passes change no state): the same kernels as the step, so the device enters the driver's short warm-up
-    (5 steps = 4 ms) at the clocks it holds under this load -- measured 0.784 ms per step over 20 steps straight after 5 warm-up steps
-    from idle against 0.752 after 50."""
+    """Reported next to the headline: the forward-only rate (SURVEY.md par. 8d asks for both).  Measured on every rank straight BEFORE
+    the warm-up steps (forward passes change no state): the same kernels as the step, so the device enters the driver's short warm-up
+    (5 steps = 2 ms) at the clocks it holds under this load.  From idle the device's power management takes ~35 ms of load to settle
+    (tools/probe_ramp.py: step 1 447 us, step 8 520, step 25 450, step 60 430), so the rate is taken over 300 passes (60 ms)."""
     out = {}
     neg = torch.randint(0, eng.cfg.n_ent, (args.batch, eng.cfg.neg_num), device=device, dtype=torch.int32)
     probe, eng.probe = eng.probe, None            # no per-launch events here: creating them would make this loop host-bound
@@ -208,7 +208,7 @@ def untimed_extras(eng, batches, args, device):
         eng.forward(*batches[i % len(batches)], neg)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = max(args.steps, 100)
+    n = max(args.steps, 300)
     for i in range(n):
         eng.forward(*batches[i % len(batches)], neg)
     torch.cuda.synchronize()
@@ -726,14 +726,14 @@ def run_stress(args, world, rank, device, backend, real_stdout):
             ops.sample_negatives(h, r, t, K, N, R, seed, tick=eng.tick, out=neg)
             eng.train_step(h, r, t, neg, timers=tm)
 
+    gc.collect()
+    gc.disable()                         # (see main(): no full collection inside the timed loop, none between the warm-up and the timed region either)
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    gc.collect()
-    gc.disable()                         # (see main(): no full collection inside the timed loop)
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i, timers)
@@ -827,7 +827,7 @@ def cpu_baseline_stress(cfg, batch, budget_s):
                       f"table) at {thr} of {avail} usable threads, median {med * 1e3:.0f} ms/step"}
 
 
-def pool_variant(args, feats, batches, known, rank_seed, device, steps=20, warmup=5):
+def pool_variant(args, feats, batches, known, rank_seed, device, steps=20, warmup=40):
     """The same step with the README's POOL=1 (``use_pool``, README.md:68,79; scripts/run_base.sh default): both raw tables average-pooled to 256
     columns once at load, so the first projections are [15000, 256] x [128, 256]^T.  A second engine, ``warmup`` + ``steps`` steps, wall clock
     around the timed ones (device synchronised on both sides); the pooling launch itself is load time and is reported separately."""
@@ -1027,13 +1027,23 @@ def main():
             eng.replay_step(*batches[i % len(batches)])
 
     copy_gbs = device_copy_ceiling(device)
-    extras = untimed_extras(eng, batches, args, device) if not args.no_extras else {}
+    extras = {}
     sim_inputs = None
     if world == 1 and not args.no_extras and args.config == "db15k":
         extras["roofline_sim"], *sim_inputs = roofline_sim(device)
         extras["roofline_fusion"] = roofline_fusion(device, cpu_probe=args.cpu_seconds > 0)
     if cfg.add_noise:
         extras["noise_refresh_us"] = noise_refresh_us(eng)
+    # the host enqueues a step in ~140 us of Python; a full garbage collection in the middle of the loop (tens of ms with torch's heap)
+    # would drain the launch queue and show up as device time -- collect now, keep the collector off while the K steps are timed.
+    # (BEFORE the forward-only leg and the warm-up steps: a collection between the warm-up and the timed region idles the device for
+    # tens of ms, and the timed steps then run through its power-management transient -- 0.505-0.516 ms per step at --steps 20 --warmup 5
+    # against 0.44 when nothing idles the device in between; tools/probe_ramp.py)
+    gc.collect()
+    gc.disable()
+    # LAST before the warm-up steps (the legs above hold CPU work -- the device would idle and drop its clocks again): the forward-only rate
+    if not args.no_extras:
+        extras.update(untimed_extras(eng, batches, args, device))
     step_no = 0
     for _ in range(args.warmup):
         one_step(step_no)
@@ -1045,10 +1055,6 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # the host enqueues a step in ~140 us of Python; a full garbage collection in the middle of the loop (tens of ms with torch's heap)
-    # would drain the launch queue and show up as device time -- collect now, keep the collector off while the K steps are timed
-    gc.collect()
-    gc.disable()
     t0 = time.perf_counter()
     for k in range(args.steps):
         # the per-launch HIP events sit INSIDE the timed region, on every TIMER_EVERY-th step only: an event pair around a launch
