@@ -105,6 +105,9 @@ static snag_gemm_desc gemm_desc(int M, int N, int K, const float* A, int64_t lda
     return d;
 }
 
+#ifndef SNAG_FULL_BWD_W_ROUND
+#define SNAG_FULL_BWD_W_ROUND 512        // workgroups the full layer's two weight gradients (one grouped launch) are split into
+#endif
 #ifndef SNAG_RO_BWD_W_ROUND
 #define SNAG_RO_BWD_W_ROUND 256          // workgroups the weight gradients of the merged backward launch are split into (0: the K split a launch of their own would pick; A/B)
 #endif
@@ -642,6 +645,10 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             g0.accumulate = acc; g0.workspace = W.gemm_ws; g0.workspace_floats = pw;
             g1.accumulate = acc; g1.workspace = W.gemm_ws + pw; g1.workspace_floats = W.gemm_ws_floats - pw;
             g0.defer_reduce = g1.defer_reduce = 1;
+            // K splits for the GROUP: ~512 workgroups over all eight (3D + D) / 64 tiles together.  Planned one by one the two problems
+            // ask for ~1,000 workgroups each (166 splits at 45,000 rows: 43 MB of slabs): launch 56.5 -> 48.4 us, its reduce 13.5 -> 9.5
+            // (32 splits: 59.4 + 9.0; 96: 47.4 + 10.8)
+            g0.splits = g1.splits = std::max(1, SNAG_FULL_BWD_W_ROUND / std::max(1, ceil_div(3 * D, 64) + ceil_div(D, 64)) / std::max(1, ceil_div(D, 128)));
             const snag_gemm_desc* grp[2] = {&g1, &g0};
             if ((rc = gemm_dispatch_group(grp, 2, st))) return rc;
             if ((rc = gemm_reduce_multi(grp, 2, st, nullptr, 0, &slabs))) return rc;
