@@ -897,8 +897,11 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the whole step (sampling included) as one captured hipGraph (1 GPU; no per-kernel timers)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch positives PER GPU (default); strong: --batch is the GLOBAL batch, split over the GPUs")
-    ap.add_argument("--replicate-fusion", action="store_true",
-                    help="N > 1: every rank projects and fuses ALL entities (round-1 behaviour) instead of owning 1/N of the rows")
+    ap.add_argument("--shard-fusion", action="store_true",
+                    help="N > 1: every rank OWNS 1/N of the entity rows (projects and fuses them only; all-gather of the read-outs, reduce-scatter of their "
+                         "gradient) instead of the default plain data parallelism (full replicas + ONE summed all-reduce of the gradients per step, "
+                         "SURVEY.md par. 8e: the optional optimisation, off by default)")
+    ap.add_argument("--replicate-fusion", action="store_true", help="(the default since round 5; accepted for older command lines)")
     ap.add_argument("--noise-level", default="epoch", choices=["epoch", "step"],
                     help="README 'noise-level': refresh the feature / entity noise once per epoch (every 78th step; run_snag.sh) or in EVERY step")
     ap.add_argument("--pool", action="store_true",
@@ -963,9 +966,12 @@ def main():
     from snag_amd import ops
     neg_buf = torch.empty(args.batch, cfg.neg_num, device=device, dtype=torch.int32)
     rank_seed = cfg.seed * 7919 + int(os.environ.get("RANK", "0"))
-    # N > 1: the entity rows are owned in equal shards -- each rank projects + fuses 1/N of the table, the [N, D] read-outs are
-    # all-gathered before scoring and their gradient reduce-scattered back (SURVEY.md par. 8e); --replicate-fusion keeps full replicas
-    row_sharded = world > 1 and not args.replicate_fusion
+    # N > 1, default: plain data parallelism -- the batch is sharded, every rank holds full replicas and the gradients are summed by ONE bucketed
+    # all-reduce per step (north_star; SURVEY.md par. 8e).  --shard-fusion: the entity rows are owned in equal shards -- each rank projects +
+    # fuses 1/N of the table, the [N, D] read-outs are all-gathered before scoring and their gradient reduce-scattered back (par. 8e's option)
+    if args.shard_fusion and args.replicate_fusion:
+        sys.exit("--shard-fusion and --replicate-fusion exclude each other")
+    row_sharded = world > 1 and args.shard_fusion
     shard = RowShard(cfg.n_ent, rank, world) if row_sharded else None
     if os.environ.get("BENCH_L1_ROUND"):                 # A/B only (tools/): K splits of the grouped first projections sized for two workgroups per CU
         MKGCHotPath.l1_round = int(os.environ["BENCH_L1_ROUND"])

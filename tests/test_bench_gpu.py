@@ -82,7 +82,8 @@ def test_bench_noise_level_step_refreshes_the_noise_in_every_timed_step():
     assert o["phases_us"]["noise_refresh"] > 0 and "noise_refresh" in o["phases_us"]["order"]
 
 
-@pytest.mark.parametrize("extra,scaling,per_gpu", [([], "weak", 256), (["--scaling", "strong"], "strong", 128), (["--replicate-fusion"], "weak", 256)])
+@pytest.mark.parametrize("extra,scaling,per_gpu", [([], "weak", 256), (["--scaling", "strong"], "strong", 128), (["--shard-fusion"], "weak", 256),
+                                                     (["--shard-fusion", "--scaling", "strong"], "strong", 128)])
 def test_bench_two_rank_dry_run(extra, scaling, per_gpu):
     env = dict(os.environ, BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
@@ -92,11 +93,11 @@ def test_bench_two_rank_dry_run(extra, scaling, per_gpu):
     assert p.returncode == 0, p.stderr[-3000:]
     o = _json_line(p.stdout)
     assert o["n_gpus"] == 2 and o["scaling"] == scaling and o["config"]["batch_per_gpu"] == per_gpu and o["config"]["global_batch"] == 2 * per_gpu
-    assert ("row-sharded" in o["config"]["fusion"]) == ("--replicate-fusion" not in extra)
+    assert ("row-sharded" in o["config"]["fusion"]) == ("--shard-fusion" in extra)          # default: plain data parallelism (full replicas + all-reduce)
     assert o["value"] == pytest.approx(2 * per_gpu * 4 / (o["ms_per_step"] * 4e-3), rel=1e-6) and o["config"]["final_loss"] > 0
     # the N > 1 line splits the step into phases (HIP events on the compute stream): what a first real 8-GPU run is diagnosed with
     ph = o["phases_us"]
-    want = ["fusion_fwd", "score", "backward", "allreduce_wait", "clip_adamw"] + (["all_gather", "reduce_scatter"] if "--replicate-fusion" not in extra else [])
+    want = ["fusion_fwd", "score", "backward", "allreduce_wait", "clip_adamw"] + (["all_gather", "reduce_scatter"] if "--shard-fusion" in extra else [])
     for k in want:
         assert ph[k] > 0, (k, ph)
     assert ph["comm_exposed_us"] > 0 and ph["compute_us"] > 0 and ph["steps_sampled"] >= 1
