@@ -987,6 +987,7 @@ class MKGCHotPath:
         # folded second projections, the chain rule onto the two factors of Wf_m = Wkv l2_m (d Wf_m is final by now):
         #   d l2_m = Wkv^T d Wf_m ;  d Wkv += d Wf_m l2_m^T   (the read-out token's own contribution to d Wkv is already there)
         chain, chain_done = (self._fold_chain_products() if (self.fold and nmod <= 2) else None), False
+        grouped = False             # both first-projection weight gradients went out as the one grouped launch (+ the chain products in its reduce)
         dl1 = []
         for i, fd in enumerate(cfg.feat_dims):
             feat = self.noisy[i] if noisy else self.feats[i]
@@ -1007,12 +1008,16 @@ class MKGCHotPath:
             call("snag_gemm_f32", ctypes.byref(dl1[0]), st)
             call("snag_gemm_f32", ctypes.byref(dl1[1]), st)
             call("snag_gemm_reduce_group", group, 4, st)
-        elif reducer is None and self._grouped_long_k(dl1, [(fd, Nl) for fd in cfg.feat_dims], small=chain):
+        elif self._grouped_long_k(dl1, [(fd, Nl) for fd in cfg.feat_dims], small=chain):
             # (both weight gradients in ONE launch of eight-wave tiles: alone, the visual one fills the chip exactly -- 16 row tiles x 16
             # K splits -- and the text one then runs as a second, under-filled launch; together, 13 splits each, every CU walks the same
             # k-range once: 78.5 + 30.4 -> 97.8 us.  The chain rule of projection folding -- parameter-sized products that depend on
             # nothing this launch writes -- rides in its reduce launch: two latency-bound launches side by side instead of in a row.)
+            # With a reducer (N > 1) too, since round 5: the per-modality launches that let the visual bucket leave early cost the step ~20 us of
+            # launches and two more collectives; now everything behind the tables -- projection weights + (folded) fusion parameters, 3 MB,
+            # the contiguous tail of the flat buffer -- is ONE collective behind this launch's reduce.
             chain_done = chain is not None
+            grouped = True
         elif reducer is None:       # weight gradients of the first projections: two kernels, ONE reduce launch per pair of modalities
             self._gemm_deferred_pairs(dl1)
         if self.fold:
@@ -1020,18 +1025,21 @@ class MKGCHotPath:
                 for i0 in range(0, nmod, 2):           # two modalities per launch: their d l2 (disjoint outputs) and ONE two-term problem for d Wkv
                     probs = self._fold_chain_products(i0)
                     call("snag_small_matmul", probs, len(probs), st)
-            if reducer is not None:
+            if reducer is not None and not grouped:
                 reducer.start(buckets[1])
         bias_pair = cfg.num_proj == 1 and reducer is None and nmod == 2
         if bias_pair:       # db = colsum(dTok) of both modalities in one pair of launches
             call("snag_colsum_pair", dx0, dx0 + 4 * D, Nl, D, MD, ptr(self.g["proj0.bias"]), ptr(self.g["proj1.bias"]), 0, wk, st)
         for i, fd in enumerate(cfg.feat_dims):
-            if reducer is not None:         # data parallel: each modality's bucket goes out as soon as its gradient is final
+            if reducer is not None and not grouped:         # data parallel: each modality's bucket goes out as soon as its gradient is final
                 call("snag_gemm_f32", ctypes.byref(dl1[i]), st)
             if cfg.num_proj == 1 and not bias_pair:
                 call("snag_colsum", dx0 + 4 * i * D, Nl, D, MD, ptr(self.g[f"proj{i}.bias"]), 0, wk, st)
-            if reducer is not None:
+            if reducer is not None and not grouped:
                 reducer.start(buckets[2 + i])
+        if reducer is not None and grouped:
+            first_proj = self.slices["proj0.weight" if cfg.num_proj == 1 else "proj0.l1"][0]
+            reducer.start(self.gflat[first_proj:] if self.fold else self.gflat[first_proj:self.slices["weight_raw"][0]])
         self._mark("backward")
 
     def optimizer_step(self, grad_scale=1.0):

@@ -20,12 +20,12 @@ def _free_port():
     return p
 
 
-def _engine(joint_way, shard=None, n_ent=900, dropout=0.0, add_noise=0):
+def _engine(joint_way, shard=None, n_ent=900, dropout=0.0, add_noise=0, feat_dims=(160, 96)):
     from snag_amd.mkgc import MKGCConfig, MKGCHotPath
-    cfg = MKGCConfig(n_ent=n_ent, n_rel=13, dim=128, feat_dims=[160, 96], num_proj=2, joint_way=joint_way, margin=6.0, neg_num=8, dropout=dropout,
+    cfg = MKGCConfig(n_ent=n_ent, n_rel=13, dim=128, feat_dims=list(feat_dims), num_proj=2, joint_way=joint_way, margin=6.0, neg_num=8, dropout=dropout,
                      add_noise=add_noise, seed=5, lr=1e-3, proj_dropout=0.2 if dropout > 0 else 0.0)
     g = torch.Generator().manual_seed(17)
-    feats = [torch.rand(n_ent, 160, generator=g), torch.randn(n_ent, 96, generator=g)]
+    feats = [torch.rand(n_ent, feat_dims[0], generator=g), torch.randn(n_ent, feat_dims[1], generator=g)]
     eng = MKGCHotPath(cfg, feats, device="cuda", shard=shard)
     eng.p["ent"].copy_(torch.randn(n_ent, 128, generator=g).cuda())
     B = 64
@@ -43,14 +43,14 @@ def _flat(d):
     return torch.cat([d[k].reshape(-1) for k in sorted(d)])
 
 
-def _worker(rank, world, port, joint_way, out, row_sharded=False, n_ent=900, steps=1, callable_reducer=False, dropout=0.0, add_noise=0):
+def _worker(rank, world, port, joint_way, out, row_sharded=False, n_ent=900, steps=1, callable_reducer=False, dropout=0.0, add_noise=0, feat_dims=(160, 96)):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from snag_amd.parallel import GradAllReduce, RowShard, shard_batch
-        eng, batch = _engine(joint_way, RowShard(n_ent, rank, world) if row_sharded else None, n_ent, dropout, add_noise)
+        eng, batch = _engine(joint_way, RowShard(n_ent, rank, world) if row_sharded else None, n_ent, dropout, add_noise, feat_dims)
         local = shard_batch(batch, rank, world)
         red = GradAllReduce(world)
         if callable_reducer:                     # the plain-callable form: allreduce(gflat) after the whole backward
@@ -98,6 +98,26 @@ def test_two_rank_engine_step_equals_global_batch_step(tmp_path, joint_way, row_
     solid = ref_g.abs() > 1e-3 * scale
     assert int(solid.sum()) > 1000
     assert float((got["param"] - ref_p)[solid].abs().max()) <= 5e-6
+
+
+@pytest.mark.parametrize("row_sharded,n_ent", [(False, 1100), (True, 2200)])
+def test_two_rank_step_with_the_grouped_weight_gradient_launch(tmp_path, row_sharded, n_ent):
+    """Feature tables wide enough (>= 1,024 columns, >= 512 rows per rank) for the engine's ONE grouped launch of both first-projection weight gradients:
+    with a reducer (round 5) that launch is kept and everything behind the tables -- projection weights + folded fusion parameters -- travels as ONE
+    collective behind its reduce (before: one launch and one collective per modality).  Two ranks = the one-rank step on the global batch."""
+    out = str(tmp_path / "r0.pt")
+    fd = (1280, 1024)
+    mp.spawn(_worker, args=(2, _free_port(), "Mformer_hd_graph", out, row_sharded, n_ent, 2, False, 0.0, 0, fd), nprocs=2, join=True)
+    got = torch.load(out)
+    eng, batch = _engine("Mformer_hd_graph", None, n_ent, feat_dims=fd)
+    losses = [float(eng.train_step(*batch)) for _ in range(2)]
+    torch.cuda.synchronize()
+    ref_p, ref_g = (_flat(d) for d in _named(eng))
+    for a, b in zip(got["losses"], losses):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b))
+    scale = float(ref_g.abs().max())
+    assert float((got["grad"] - ref_g).abs().max()) <= 5e-5 * scale
+    assert float((got["param"] - ref_p).abs().max()) <= 2.5e-3            # two AdamW steps of lr 1e-3 (sign flips where the gradient is noise)
 
 
 @pytest.mark.parametrize("n_ent,callable_reducer", [(901, False), (901, True), (900, True)])
