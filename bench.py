@@ -196,7 +196,7 @@ def score_train_larger_batch(eng, cfg, device, B=8192):
             "timed": "20 back-to-back calls of the entry (both passes), HIP events, after the timed region"}
 
 
-def untimed_extras(eng, batches, args, device):
+def untimed_extras(eng, batches, args, device, sample=None):
     """Reported next to the headline: the forward-only rate (SURVEY.md par. 8d asks for both).  Measured on every rank straight BEFORE
     the warm-up steps (forward passes change no state): the same kernels as the step, so the device enters the driver's short warm-up
     (5 steps = 2 ms) at the clocks it holds under this load.  From idle the device's power management takes ~35 ms of load to settle
@@ -212,8 +212,18 @@ def untimed_extras(eng, batches, args, device):
     for i in range(n):
         eng.forward(*batches[i % len(batches)], neg)
     torch.cuda.synchronize()
-    eng.probe = probe
     out["forward_only"] = {"value": args.batch * n / (time.perf_counter() - t0), "unit": "triples/s", "passes": n}
+    # ... and forward + backward without the optimiser (par. 8d names both): gradients are overwritten by every pass, parameters, moments
+    # and the step counter stay as they are.  The last thing the device does before the warm-up steps: the step's own kernels but clip + AdamW.
+    if sample is not None:
+        t0 = time.perf_counter()
+        n2 = max(args.steps, 150)
+        for i in range(n2):
+            eng.forward(*batches[i % len(batches)], neg, with_backward=True, grad_scale=1.0, sample=sample)
+            eng.backward(1.0)
+        torch.cuda.synchronize()
+        out["forward_backward"] = {"value": args.batch * n2 / (time.perf_counter() - t0), "unit": "triples/s", "passes": n2}
+    eng.probe = probe
     return out
 
 
@@ -1049,7 +1059,7 @@ def main():
     gc.disable()
     # LAST before the warm-up steps (the legs above hold CPU work -- the device would idle and drop its clocks again): the forward-only rate
     if not args.no_extras:
-        extras.update(untimed_extras(eng, batches, args, device))
+        extras.update(untimed_extras(eng, batches, args, device, sample=None if row_sharded else (rank_seed, known)))          # (a row-sharded backward holds collectives: forward-only there)
     step_no = 0
     for _ in range(args.warmup):
         one_step(step_no)
