@@ -199,6 +199,8 @@ __global__ __launch_bounds__(256) void adaptive_avg_pool_rows_kernel(const float
     }
 }
 
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 static inline int grid_rows16(int64_t rows, int cap) {
     const int64_t b = (rows + 15) / 16;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -216,6 +218,8 @@ extern "C" SNAG_API int snag_atten_weight_fwd(const float* x, int64_t rows, int 
     SNAG_REQUIRE(M >= 1 && M <= 6 && D >= 4 && D <= 512 && D % 4 == 0, SNAG_ERR_UNSUPPORTED, "atten_weight_fwd: 1 <= M <= 6 tokens of 4 | D <= 512 (got M=%d D=%d)", M, D);
     if (rows == 0) return SNAG_OK;          // (an empty tensor's data pointer is null)
     SNAG_REQUIRE(x && a && out && aw, SNAG_ERR_ARG, "atten_weight_fwd: null pointer");
+    SNAG_REQUIRE(ld_out % 4 == 0 && aligned16(x) && aligned16(a) && aligned16(out), SNAG_ERR_UNSUPPORTED,
+                 "atten_weight_fwd: x, a, out must be 16-byte aligned and ld_out a multiple of 4 floats (rows are read and written as float4)");
     const dim3 grid(grid_rows16(rows, 1 << 16)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define SNAG_AW_FWD(MM) case MM: hipLaunchKernelGGL(atten_weight_fwd_kernel<MM>, grid, block, 0, st, x, rows, D, a, out, ld_out, aw); break;
@@ -235,6 +239,8 @@ extern "C" SNAG_API int snag_atten_weight_bwd(const float* x, int64_t rows, int 
         return check_launch("snag_atten_weight_bwd");
     }
     SNAG_REQUIRE(x && a && aw && d_out && d_x && work, SNAG_ERR_ARG, "atten_weight_bwd: null pointer");
+    SNAG_REQUIRE(ld_dout % 4 == 0 && aligned16(x) && aligned16(a) && aligned16(d_out) && aligned16(d_x), SNAG_ERR_UNSUPPORTED,
+                 "atten_weight_bwd: x, a, d_out, d_x must be 16-byte aligned and ld_dout a multiple of 4 floats (rows are read and written as float4)");
     const int nb = grid_rows16(rows, kAttenBlocks);
     const dim3 grid(nb), block(256);
 #define SNAG_AW_BWD(MM)                                                                                                                      \

@@ -15,7 +15,8 @@
 //            destination with ONE entry is made of: it writes that row -- normalize_bwd(x, w q_b), statement for statement pass B's
 //            single-entry arithmetic -- straight into d_ent (round 5).  Nearly every destination of a uniformly drawn batch has one entry,
 //            so pass B no longer re-reads the 69 MB of table rows pass A just gathered, nor the q rows, nor writes 137 MB; where more
-//            entries arrive the rows written here are provisional (several writers race, harmlessly) and pass B overwrites them.
+//            entries arrive the row written here is provisional -- ONE writer per row, the entry that reserved slot 0 (nothing races) --
+//            and pass B overwrites it.
 //   pass B   one 16-lane group per RECORD.  The record whose slot is 0 owns its destination: with one entry that pass A has written
 //            (flag in the record) it only resets the counter -- two dependent round trips: the record, then the counter --; otherwise a third
 //            one fetches {own table row, the entry's row, the bucket} and with up to 16 entries it adds them in a canonical order (sorted
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256, SNAG_TA_WAVES) void touched_a_kernel(
             if (sub == 0) ccomb[wave] = c_pos;
         }
         __syncthreads();
-        if (part == 0) {
+        if (live && part == 0) {          // (a wave past the batch's end has part == 0 too; wave + pp would leave the four rows)
             c_pos = 0.f;
 #pragma unroll
             for (int j = 0; j < NV; ++j) acc.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -525,7 +525,7 @@ class MKGCHotPath:
         # inside the merged backward launch (snag_fusion_bwd, fold_others) the weight gradients share ONE round of ~256 workgroups: the layer's own
         # dWqkv (3D / 64 tiles) and dWo (D / 64) + these (2D / 64 each); the library applies the same rule to its two
         # (``merged``: three tokens -- what snag_fusion_bwd runs as that one launch)
-        want = max(1, self.w_round // ((4 * D + nmod * 2 * D) // 64)) if (self.w_round and merged and M == 3) else 0
+        want = max(1, self.w_round // max(1, (4 * D + nmod * 2 * D) // 64)) if (self.w_round and merged and M == 3) else 0
         for d in dl2:
             d.defer_reduce, d.splits = int(defer), want
         dmid = [self._gemm_desc(Nl, D, 2 * D, dkv + 4 * i * 2 * D, 2 * MD, 1, ptr(self.wf[i]), D, 0, ptr(self.d_mid[i]), D, act=4, aux=ptr(self.mid[i]),
@@ -940,7 +940,8 @@ class MKGCHotPath:
                  ptr(self.g["atten.a"]), 0, ptr(self._aw_work), st)
         else:
             call("snag_fusion_bwd", ctypes.byref(bd), st)
-        self._d_repr_clean = cfg.scorer != "segmented"     # (atomic scorer: its reader cleared it behind itself)
+        # (atomic scorer: snag_fusion_bwd / snag_token_mean_bwd cleared d_repr behind themselves; snag_atten_weight_bwd only reads it)
+        self._d_repr_clean = cfg.scorer != "segmented" and not self.atten
         dx0 = self.d_x0.data_ptr()
         wk = ptr(self.work)
         if not mirror:

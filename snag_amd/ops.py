@@ -57,6 +57,15 @@ def _rows(t, name):
     return t
 
 
+def _quads(entry, **tensors):
+    """The entry moves rows as float4: every base pointer 16-byte aligned, every row stride a multiple of four floats (what the C ABI
+    itself refuses with SNAG_ERR_UNSUPPORTED; checked here for the readable message)."""
+    for name, t in tensors.items():
+        if t.numel() and (t.data_ptr() % 16 or (t.dim() >= 2 and t.stride(0) % 4)):
+            raise ValueError(f"{entry}: {name} must be 16-byte aligned with a row stride that is a multiple of 4 floats "
+                             f"(data_ptr % 16 = {t.data_ptr() % 16}, strides {tuple(t.stride())})")
+
+
 def score_margin_fwd(ent, rel, h, r, t, neg_t, margin, want_loss=True):
     """-> pos [B], neg [B,K], loss_part [B] (or None).  C ABI: snag_score_margin_fwd."""
     _rows(ent, "ent"), _chk(rel, "rel", ndim=2)
@@ -231,7 +240,9 @@ _TOUCHED_WORK = {}
 
 def score_margin_fwd_bwd_touched(ent, rel, h, r, t, neg_t, margin, grad_scale=1.0, d_ent=None, d_rel=None):
     """The segmented hinge scorer for tables far larger than a batch's footprint: pass B walks the compact list of destinations that
-    received an entry instead of every counter; only touched rows of d_ent are written (allocated zeroed when None), every row of d_rel is.  fp32 or
+    received an entry instead of every counter.  Only touched rows of d_ent are written -- OVERWRITTEN, not accumulated into (allocated zeroed
+    when None; the caller keeps the untouched rows zero) -- and EVERY row of d_rel is overwritten (zeros for relations the batch does not
+    name): a d_rel holding gradients of an earlier call loses them (since SNAG_ABI_VERSION 2; the earlier form accumulated).  fp32 or
     bfloat16 tables.  -> (loss, pos, neg, loss_part, d_ent, d_rel).  C ABI: snag_score_margin_fwd_bwd_touched(_bf16)."""
     bf16 = ent.dtype == torch.bfloat16
     for x, nm in ((ent, "ent"), (rel, "rel")):
@@ -440,6 +451,7 @@ def atten_weight_fwd(x, a, out=None):
     if out is None:
         out = torch.empty(rows, D, device=x.device, dtype=f32)
     _rows(out, "out")
+    _quads("atten_weight_fwd", x=x, a=a, out=out)
     aw = torch.empty(rows, 2 * M, device=x.device, dtype=f32)
     call("snag_atten_weight_fwd", ptr(x), rows, M, D, ptr(a), ptr(out), out.stride(0), ptr(aw), stream())
     return out, aw
@@ -453,6 +465,7 @@ def atten_weight_bwd(x, a, aw, d_out, d_x=None, d_a=None, accumulate_da=False):
         raise ValueError(f"aw must be [{rows}, {2 * M}] and d_out [{rows}, {D}], got {tuple(aw.shape)}, {tuple(d_out.shape)}")
     d_x = torch.empty_like(x) if d_x is None else _chk(d_x, "d_x", ndim=3)
     d_a = torch.zeros(D, device=x.device, dtype=f32) if d_a is None else _chk(d_a, "d_a", ndim=1)
+    _quads("atten_weight_bwd", x=x, a=a, d_out=d_out, d_x=d_x)
     work = torch.empty(max(1, _lib.load().snag_atten_weight_work_floats(D)), device=x.device, dtype=f32)
     call("snag_atten_weight_bwd", ptr(x), rows, M, D, ptr(a), ptr(aw), ptr(d_out), d_out.stride(0), ptr(d_x), ptr(d_a), int(accumulate_da), ptr(work), stream())
     return d_x, d_a

@@ -122,6 +122,44 @@ def test_mkgc_step_vs_oracle(num_proj, joint_way, ffn, noise, idt, shape, loss_k
         assert_close(grads[k], gref, atol=2e-4 * scale, rtol=1e-4, what=f"grad {k}")
 
 
+@pytest.mark.parametrize("joint_way,num_proj", [("atten_weight", 2), ("Mformer_hd_graph", 2), ("Mformer_hd_mean", 1), ("Mformer_weight", 2)])
+@pytest.mark.parametrize("loss_kind,scorer", [("hinge", "atomic"), ("hinge", "segmented"), ("self_adversarial", "atomic")])
+def test_second_step_gradients_do_not_carry_the_first_steps(joint_way, num_proj, loss_kind, scorer):
+    """The scorer's scatter target (the read-out gradient) is cleared either by its reader (snag_fusion_bwd, snag_token_mean_bwd) or by
+    the engine before the next scorer launch (snag_atten_weight_bwd only reads it): two forward + backward passes on DIFFERENT batches,
+    the second pass's gradients against the oracle on the second batch alone."""
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    N, R, D, B, K, F0, F1 = 700, 23, 128, 96, 32, 200, 72
+    cfg = MKGCConfig(scorer=scorer, n_ent=N, n_rel=R, dim=D, feat_dims=[F0, F1], num_proj=num_proj, joint_way=joint_way, margin=6.0, neg_num=K,
+                     dropout=0.0, add_noise=0, seed=7, loss=loss_kind, adv_temp=0.7)
+    g = torch.Generator().manual_seed(101)
+    feats = [torch.rand(N, F0, generator=g), torch.randn(N, F1, generator=g)]
+    eng = MKGCHotPath(cfg, feats, device=DEV)
+    eng.p["ent"].copy_(torch.randn(N, D, generator=g).to(DEV))
+    eng.p["weight_raw"].copy_(torch.randn(6, generator=g).to(DEV))
+    if joint_way == "atten_weight":
+        eng.p["atten.a"].copy_((torch.randn(D, generator=g) * (2.0 / D ** 0.5)).to(DEV))
+    fused = loss_kind == "hinge"
+    for step in range(3):
+        h = torch.randint(0, N, (B,), generator=g, dtype=torch.int32)
+        r = torch.randint(0, R, (B,), generator=g, dtype=torch.int32)
+        t = torch.randint(0, N, (B,), generator=g, dtype=torch.int32)
+        neg = torch.randint(0, N, (B, K), generator=g, dtype=torch.int32)
+        loss = eng.forward(h.to(DEV), r.to(DEV), t.to(DEV), neg.to(DEV), with_backward=fused)
+        eng.backward()
+    torch.cuda.synchronize()
+    p, proj, fp = oracle_params(eng)
+    oloss, _, _, _ = O.mkgc_forward([f.cpu() for f in eng.feats], proj, p["ent"], fp, p["rel"], h, r, t, neg, num_heads=cfg.num_heads, margin=cfg.margin,
+                                    joint_way=joint_way, use_intermediate=False, num_layers=cfg.num_layers, loss_kind=loss_kind, adv_temp=cfg.adv_temp,
+                                    atten_a=p.get("atten.a"))
+    oloss.backward()
+    assert_close(loss, oloss, atol=1e-4, rtol=2e-6, what="loss of the third pass")
+    grads = eng.named_gradients()
+    for k, ref in p.items():
+        gref = ref.grad if ref.grad is not None else torch.zeros_like(ref)
+        assert_close(grads[k], gref, atol=2e-4 * max(1.0, float(gref.abs().max())), rtol=1e-4, what=f"grad {k} of the third pass")
+
+
 def engine_masks(eng):
     """The keep masks the engine drew for its last step, in the oracle's form: (fusion_forward's drop_masks, mkgc_forward's proj_keep).
     The buffers cover every token of every layer; the read-out-only last layer draws (and consumes) the read-out token's rows alone --

@@ -64,6 +64,30 @@ def test_atten_weight_empty_and_refusals():
         ops.atten_weight_fwd(torch.zeros(4, 3, 6, device=DEV), torch.ones(6, device=DEV))        # 4 does not divide D
     with pytest.raises(_lib.SnagHipError):
         ops.atten_weight_fwd(torch.zeros(4, 7, 8, device=DEV), torch.ones(8, device=DEV))        # more than 6 tokens
+    # rows travel as float4: a base pointer off the 16-byte grid or a row stride that is not a multiple of four floats is refused --
+    # by the wrapper (ValueError) and by the C ABI itself (SNAG_ERR_UNSUPPORTED = -2), never read misaligned
+    lib, st = _lib.load(), _lib.stream()
+    x, a = torch.zeros(4, 3, 8, device=DEV), torch.ones(16, device=DEV)
+    odd = torch.zeros(4, 9, device=DEV)[:, :8]                   # ld_out = 9
+    off = torch.zeros(4 * 3 * 8 + 1, device=DEV)[1:].view(4, 3, 8)          # base 4 bytes off
+    aw = torch.zeros(4, 6, device=DEV)
+    with pytest.raises(ValueError):
+        ops.atten_weight_fwd(x, a[:8], out=odd)
+    with pytest.raises(ValueError):
+        ops.atten_weight_fwd(off, a[:8])
+    with pytest.raises(ValueError):
+        ops.atten_weight_bwd(x, a[:8], aw, odd)
+    out = torch.zeros(4, 8, device=DEV)
+    assert lib.snag_atten_weight_fwd(x.data_ptr(), 4, 3, 8, a.data_ptr(), odd.data_ptr(), 9, aw.data_ptr(), st) == -2
+    assert lib.snag_atten_weight_fwd(off.data_ptr(), 4, 3, 8, a.data_ptr(), out.data_ptr(), 8, aw.data_ptr(), st) == -2
+    assert lib.snag_atten_weight_fwd(x.data_ptr(), 4, 3, 8, a.data_ptr() + 4, out.data_ptr(), 8, aw.data_ptr(), st) == -2
+    work = torch.zeros(max(1, lib.snag_atten_weight_work_floats(8)), device=DEV)
+    da = torch.zeros(8, device=DEV)
+    assert lib.snag_atten_weight_bwd(x.data_ptr(), 4, 3, 8, a.data_ptr(), aw.data_ptr(), odd.data_ptr(), 9, torch.zeros_like(x).data_ptr(), da.data_ptr(), 0,
+                                     work.data_ptr(), st) == -2
+    assert lib.snag_atten_weight_bwd(x.data_ptr(), 4, 3, 8, a.data_ptr(), aw.data_ptr(), out.data_ptr(), 8, off.data_ptr(), da.data_ptr(), 0,
+                                     work.data_ptr(), st) == -2
+    assert lib.snag_atten_weight_fwd(x.data_ptr(), 4, 3, 8, a.data_ptr(), out.data_ptr(), 8, aw.data_ptr(), st) == 0
 
 
 @pytest.mark.parametrize("N,view,out", [(37, (1, 4096), (1, 256)), (37, (64, 64), (16, 16)), (20, (12, 64), (4, 64)), (9, (1, 770), (1, 256)), (5, (1, 100), (1, 100)),
