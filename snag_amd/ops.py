@@ -61,7 +61,7 @@ def _quads(entry, **tensors):
     """The entry moves rows as float4: every base pointer 16-byte aligned, every row stride a multiple of four floats (what the C ABI
     itself refuses with SNAG_ERR_UNSUPPORTED; checked here for the readable message)."""
     for name, t in tensors.items():
-        if t.numel() and (t.data_ptr() % 16 or (t.dim() >= 2 and t.stride(0) % 4)):
+        if t.numel() and (t.data_ptr() % 16 or (t.dim() == 2 and t.stride(0) % 4)):
             raise ValueError(f"{entry}: {name} must be 16-byte aligned with a row stride that is a multiple of 4 floats "
                              f"(data_ptr % 16 = {t.data_ptr() % 16}, strides {tuple(t.stride())})")
 
