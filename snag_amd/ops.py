@@ -451,7 +451,8 @@ def atten_weight_fwd(x, a, out=None):
     if out is None:
         out = torch.empty(rows, D, device=x.device, dtype=f32)
     _rows(out, "out")
-    _quads("atten_weight_fwd", x=x, a=a, out=out)
+    if D % 4 == 0:            # (otherwise the C ABI refuses the shape itself)
+        _quads("atten_weight_fwd", x=x, a=a, out=out)
     aw = torch.empty(rows, 2 * M, device=x.device, dtype=f32)
     call("snag_atten_weight_fwd", ptr(x), rows, M, D, ptr(a), ptr(out), out.stride(0), ptr(aw), stream())
     return out, aw
@@ -465,7 +466,8 @@ def atten_weight_bwd(x, a, aw, d_out, d_x=None, d_a=None, accumulate_da=False):
         raise ValueError(f"aw must be [{rows}, {2 * M}] and d_out [{rows}, {D}], got {tuple(aw.shape)}, {tuple(d_out.shape)}")
     d_x = torch.empty_like(x) if d_x is None else _chk(d_x, "d_x", ndim=3)
     d_a = torch.zeros(D, device=x.device, dtype=f32) if d_a is None else _chk(d_a, "d_a", ndim=1)
-    _quads("atten_weight_bwd", x=x, a=a, d_out=d_out, d_x=d_x)
+    if D % 4 == 0:
+        _quads("atten_weight_bwd", x=x, a=a, d_out=d_out, d_x=d_x)
     work = torch.empty(max(1, _lib.load().snag_atten_weight_work_floats(D)), device=x.device, dtype=f32)
     call("snag_atten_weight_bwd", ptr(x), rows, M, D, ptr(a), ptr(aw), ptr(d_out), d_out.stride(0), ptr(d_x), ptr(d_a), int(accumulate_da), ptr(work), stream())
     return d_x, d_a
