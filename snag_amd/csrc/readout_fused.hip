@@ -38,10 +38,6 @@
 #ifndef SNAG_RO_PP
 #define SNAG_RO_PP 1             // 1: the two halves of a workgroup run every k-loop half an iteration apart (ping-pong): a barrier cuts an iteration into its
 #endif                           // memory half (fragment reads, the half's share of the next weight image, the stream's loads) and its matrix half (six MFMAs)
-#ifndef SNAG_RO_DIRECT
-#define SNAG_RO_DIRECT 1         // 1: a wave's B fragments (its 32 weight rows of a k-tile image, 3 KB) go from the L2-resident images straight into its registers in
-#endif                           // MFMA operand order -- a wave of a half owns a column block, so nobody else in the half needs them -- all eight k-tiles of the NEXT
-                                 // product requested while the current one runs: no weight image in the LDS, no barrier inside a k-loop (0: the staged stream)
 #ifndef SNAG_RO_STAMP
 #define SNAG_RO_STAMP 0          // diagnostic build: cycle stamps of one wave printed per launch
 #endif
@@ -138,14 +134,11 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
     constexpr int TN = BM / 32;                 // 32-column fragments per wave: BM = 64: 2 x 2 waves of 32 x 64; BM = 32: 1 x 4 waves of 32 x 32
     constexpr int RPW = BM / 4;                 // rows of the row tile a wave owns
     constexpr int kAImg = Panel<BM>::kImg;
-    constexpr bool kDirect = SNAG_RO_DIRECT != 0;
-    static_assert(!kDirect || (BM == 32 && NH == 2 && SNAG_RO_PRESPLIT), "direct weight fragments: two 32-row halves, pre-split images");
-    constexpr int kBBuf = kDirect ? 0 : 2 * kBImg;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kBBuf + NH * (8 * kAImg + BM * kP * 4)];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kBImg + NH * (8 * kAImg + BM * kP * 4)];
     const int gtid = threadIdx.x, tid = gtid & 255, lane = tid & 63, wave = wave_id_uniform() & 3, half = wave_id_uniform() >> 2;
-    [[maybe_unused]] unsigned char* const bbuf = lds;
-    unsigned char* const aimg = lds + kBBuf + half * 8 * kAImg;
-    lds_float* const T = (lds_float*)(lds + kBBuf + NH * 8 * kAImg + half * BM * kP * 4);
+    unsigned char* const bbuf = lds;
+    unsigned char* const aimg = lds + 2 * kBImg + half * 8 * kAImg;
+    lds_float* const T = (lds_float*)(lds + 2 * kBImg + NH * 8 * kAImg + half * BM * kP * 4);
     const int li = lane & 31, lh = lane >> 5;
     const int wm0 = BM == 64 ? (wave >> 1) * 32 : 0, wn0 = BM == 64 ? (wave & 1) * 64 : wave * 32;
     const int N = a.N, H = a.H, g = a.g, d = D / H, HMM = H * M * M;
@@ -156,17 +149,7 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
 
     f32x16 acc[TN];
     [[maybe_unused]] int cur_tile = 0;                         // the product that is running
-#if SNAG_RO_DIRECT
-    // bq[kt][plane]: this lane's operand of k-tile kt of the product that runs (or, once that k-tile's MFMAs are issued, of the next product):
-    // image + ((lh * 128 + weight row) * 16) + plane * 4096 -- what load_split_fragment<128> reads out of an LDS copy of the image.  A wave-instruction
-    // covers two contiguous 512-byte runs.  Both halves ask for the same lines within one k-loop of each other: one trip from the L2 per CU.
-    u4 bq[8][3];
-    const uint32_t bvoff = (uint32_t)(lh * 128 + wn0 + li) * 16u;
-    auto tile_rsrc = [&](int tile) {                // past the last product: an empty descriptor (zeros, no traffic; the instruction count stays static)
-        const bool in = tile < kRoTiles;
-        return uniform_rsrc(a.wimg + (size_t)(in ? tile : 0) * 8 * kBImg, in ? 8u * kBImg : 0u);
-    };
-#elif SNAG_RO_PRESPLIT
+#if SNAG_RO_PRESPLIT
     constexpr int NB = NH == 1 ? 3 : 2;                        // 16-byte pieces of an image per thread (NH = 2: 768 pieces over 512 threads)
     u4 br[4][NB];                                              // four register sets of the weight stream
     // image i of the 64-step weight stream -> register set S; past the end: zeros through an empty descriptor, no traffic
@@ -229,7 +212,6 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
     auto rows_rsrc = [&](float* base, int64_t ld) {
         return uniform_rsrc(base + (int64_t)m0 * ld, (uint32_t)((int64_t)valid * ld * 4));
     };
-#if !SNAG_RO_DIRECT
     // One k-tile of the stream (image i = i0 + kt): fragments of image i out of LDS image i & 1, image i + 1 (register set S = (i + 1) & 3)
     // into the other one, image i + 5 requested into set S (four sets: a request has four k-tiles to land), the six products in
     // mfma_split's order, barrier.  (Requesting the NEXT k-tile's fragments in front of the products -- register double-buffered, the
@@ -282,20 +264,9 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
         __syncthreads();
 #endif
     };
-#endif
 
     Panel<BM> pr;
     pr.load(a.panel[a.t[0].panel], a.ldp[a.t[0].panel], m0, N, tid);
-#if SNAG_RO_DIRECT
-    {
-        const auto rs0 = tile_rsrc(0);
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bq[kt][p] = __builtin_amdgcn_raw_buffer_load_b128(rs0, bvoff, (uint32_t)(kt * kBImg + p * 4096), 0);
-    }
-    pr.store(aimg, tid);
-#else
     fetch_b(S0{}, 0);
     fetch_b(S1{}, 1);
     fetch_b(S2{}, 2);
@@ -303,13 +274,9 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
     pr.store(aimg, tid);
     stage_b(S0{}, bbuf);
     fetch_b(S0{}, 4);
-#endif
     __syncthreads();
 
-    // q rows (products 0-3), then -- the same registers: q is dead once the last key product has left its scores -- the ctx rows (products 4-6) ;
-    // scores, then probabilities: lane r of sc[j][h] = row rw + r
-    float qr[RPW][2], sc[M][kRoMaxHeads];
-    float (&o)[RPW][2] = qr;
+    float qr[RPW][2], o[RPW][2], sc[M][kRoMaxHeads];     // q rows ; ctx rows ; scores, then probabilities: lane r of sc[j][h] = row rw + r
 #pragma unroll
     for (int j = 0; j < M; ++j)
 #pragma unroll
@@ -319,14 +286,14 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
     for (int u = 0; u < 2; ++u) hsel[u] = (lane + 64 * u) / d;
     int n_keys = 0, n_vals = 0;
     // the attention dropout's keep flags of row rw + lane (lanes < RPW), requested now: the softmax finds them in registers
-    uint32_t kp = 0;               // bit h * M + j
+    int kp[kRoMaxHeads][M];
     {
         const int64_t n = m0 + rw + lane;
         const bool mine = lane < RPW && rw + lane < valid;
 #pragma unroll
         for (int h = 0; h < kRoMaxHeads; ++h)
 #pragma unroll
-            for (int j = 0; j < M; ++j) kp |= ((a.keep_probs != nullptr && mine && h < H) ? (a.keep_probs[n * HMM + h * M * M + g * M + j] != 0) : 1u) << (h * M + j);
+            for (int j = 0; j < M; ++j) kp[h][j] = (a.keep_probs != nullptr && mine && h < H) ? (int)a.keep_probs[n * HMM + h * M * M + g * M + j] : 1;
     }
 #if SNAG_RO_STAMP
     __shared__ unsigned long long stamp[kRoTiles][5];        // (in LDS: a register array indexed by the running product would unroll the loop)
@@ -359,58 +326,24 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
         const bool hm = a.keep_out != nullptr, ha = a.resid != nullptr;
         float av0[8][2];
         uint8_t kv0[8][2];
-        auto request_side_inputs = [&]() {
-            if (t.kind == 3) {
-                if (hm) {
+        if (t.kind == 3) {
+            if (hm) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q)
+                for (int q = 0; q < 8; ++q)
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) kv0[q][u] = a.keep_out[(int64_t)min(m0 + rw + q, N - 1) * a.ldkeep + lane + 64 * u];
-                }
-                if (ha) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) av0[q][u] = a.resid[(int64_t)min(m0 + rw + q, N - 1) * a.ldres + lane + 64 * u];
-                }
+                    for (int u = 0; u < 2; ++u) kv0[q][u] = a.keep_out[(int64_t)min(m0 + rw + q, N - 1) * a.ldkeep + lane + 64 * u];
             }
-        };
-#if !SNAG_RO_DIRECT
-        request_side_inputs();
-#endif
+            if (ha) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) av0[q][u] = a.resid[(int64_t)min(m0 + rw + q, N - 1) * a.ldres + lane + 64 * u];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-#if SNAG_RO_DIRECT
-        // The k-loop without a barrier: A fragments out of the half's resident images (one k-tile ahead), B fragments from this wave's registers;
-        // as soon as k-tile kt's six products are issued its registers are requested again for the NEXT product, so that product's whole weight
-        // slice travels during the rest of this loop and the row epilogue below.
-        {
-            const auto rs_next = tile_rsrc(tile + 1);
-            Split3 af[2];
-            load_split_fragment<BM>(aimg, wm0 + li, lh, af[0]);
-#pragma unroll
-            for (int kt = 0; kt < 8; ++kt) {
-                if (kt + 1 < 8) load_split_fragment<BM>(aimg + (kt + 1) * kAImg, wm0 + li, lh, af[(kt + 1) & 1]);
-#if defined(__HIP_DEVICE_COMPILE__)
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[kt][0]), bm = __builtin_bit_cast(bf16x8, bq[kt][1]), bl = __builtin_bit_cast(bf16x8, bq[kt][2]);
-                const Split3& x = af[kt & 1];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.l, bh, acc[0], 0, 0, 0);          // mfma_split's order
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.h, bl, acc[0], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.m, bm, acc[0], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.m, bh, acc[0], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.h, bm, acc[0], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.h, bh, acc[0], 0, 0, 0);
-#endif
-#pragma unroll
-                for (int p = 0; p < 3; ++p) bq[kt][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_next, bvoff, (uint32_t)(kt * kBImg + p * 4096), 0);
-            }
-        }
-        request_side_inputs();      // (behind the k-loop: 32 registers it does not have to carry; the barriers and the row-tile write below cover the round trip)
-        __syncthreads();            // every wave of the workgroup is through the previous row epilogue (the row tile is free) and through this k-loop (so are the A images)
-        SNAG_RO_ST(1);
-#else
         const int i0 = tile * 8;
 #if defined(__HIP_DEVICE_COMPILE__) && SNAG_RO_PP
         if (NH == 2 && half == 1) __builtin_amdgcn_s_barrier();          // the late half: its memory halves face the early half's matrix halves
@@ -426,7 +359,6 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
         if (NH == 2 && half == 0) __builtin_amdgcn_s_barrier();          // the halves meet again: the epilogues below run side by side
 #endif
         SNAG_RO_ST(1);
-#endif
         // accumulators -> the row tile
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -539,7 +471,7 @@ __global__ __launch_bounds__(256 * NH, (BM == 32 && NH == 1) ? 2 : 1) void reado
                         if (a.keep_probs != nullptr) {
 #pragma unroll
                             for (int j = 0; j < M; ++j) {
-                                p[j] = ((kp >> (h * M + j)) & 1u) ? p[j] * a.kscale : 0.f;
+                                p[j] = kp[h][j] ? p[j] * a.kscale : 0.f;
                             }
                         }
 #pragma unroll
