@@ -86,9 +86,20 @@ def _check_train(eng, batch, fused, what):
     assert_close(ng, oneg, atol=1e-4, what=f"{what}: neg")
     assert_close(loss, oloss, atol=2e-4, rtol=4e-6, what=f"{what}: loss")
     grads = eng.named_gradients()
+    cfg = eng.cfg
     for k, ref in p.items():
         gref = ref.grad if ref.grad is not None else torch.zeros_like(ref)
-        assert_close(grads[k], gref, atol=2e-4 * max(1.0, float(gref.abs().max())), rtol=1e-4, what=f"{what}: grad {k}")
+        got = grads[k].cpu()
+        if cfg.num_proj == 2 and k.endswith(".l1"):
+            # ReLU kink: a first-projection pre-activation within rounding of zero (|z| < 1e-6; seen at 1e-8 in 2 of 600 soak sequences) is
+            # positive on one side and zero on the other, and the whole row of that unit's weight gradient gains or loses one entity's term.
+            # Such units are left out of the comparison (nothing else depends on the sign: mid itself is ~0 there).
+            i = int(k[4:k.index(".")])
+            noisy = bool(cfg.add_noise and eng.noise_active)
+            z = (eng.noisy if noisy else eng.feats)[i].cpu().double() @ ref.detach().double().T
+            sure = z.abs().min(dim=0).values > 1e-6 * max(1.0, float(z.abs().max()))
+            got, gref = got[sure], gref[sure]
+        assert_close(got, gref, atol=2e-4 * max(1.0, float(gref.abs().max())) if gref.numel() else 2e-4, rtol=1e-4, what=f"{what}: grad {k}")
 
 
 def _run(seed, n_ops=8, verbose=False):
@@ -149,6 +160,6 @@ def _run(seed, n_ops=8, verbose=False):
     return cfg, trace
 
 
-@pytest.mark.parametrize("seed", list(range(100, 124)))
+@pytest.mark.parametrize("seed", list(range(100, 124)) + [1318, 1473])          # (the last two: ReLU-kink units, see _check_train)
 def test_engine_call_sequences_vs_oracle(seed):
     _run(seed)
