@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a struct layout or an entry's argument list changes: snag_amd/_lib.py refuses a library whose snag_version()
  * differs from the constant it was written against (a stale or variant .so would otherwise be read with the wrong field offsets). */
-#define SNAG_ABI_VERSION 2
+#define SNAG_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define SNAG_API __attribute__((visibility("default")))
@@ -456,6 +456,13 @@ typedef struct snag_fusion_bwd_desc {
      * three tokens, fold_others): an A/B and test handle -- every gradient is the same bits either way except dbqkv, whose column sums over the
      * entities are associated differently (one partial per 32 entities instead of one per strided workgroup). */
     int32_t separate_attention_backward;
+    /* (ABI 3) A grouped launch the caller would issue RIGHT BEHIND this call -- snag_gemm_f32_group(next_group, n_next_group): e.g. the first
+     * projections' weight gradients, which read what this call's input-gradient products write -- and that nobody of this call depends on.
+     * When given (read-out mode with fold_others: the path whose last launch is a reduce of the layer's weight-gradient slabs + its slab column
+     * sums), this call launches that group itself and its own last reduce RIDES in it: a group of eight-wave 256-row tiles leaves CUs idle
+     * (247 workgroups on 256 CUs) and the reduce runs on those instead of as a 9 us launch of its own.  Same bits.  Where the path or the
+     * group's plan does not allow it the reduce and the group go out one after the other, as if the caller had issued the group. */
+    const snag_gemm_desc** next_group; int32_t n_next_group;
 } snag_fusion_bwd_desc;
 
 SNAG_API int snag_fusion_bwd(const snag_fusion_bwd_desc* desc, void* stream);

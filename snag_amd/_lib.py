@@ -18,7 +18,7 @@ _F = _c.c_float
 _U64 = _c.c_uint64
 SCORE_TICKET_WORDS = 1056      # SNAG_SCORE_TICKET_WORDS (include/snag_hip.h)
 MAX_MASK_REGIONS = 8           # SNAG_MAX_MASK_REGIONS
-ABI_VERSION = 2                # SNAG_ABI_VERSION: the struct layouts and argument lists below are those of this version
+ABI_VERSION = 3                # SNAG_ABI_VERSION: the struct layouts and argument lists below are those of this version
 
 
 
@@ -74,7 +74,8 @@ class FusionBwdDesc(_c.Structure):
                 ("d_x0", _P), ("grads", _c.POINTER(FusionLayerGrad)), ("d_weight_raw", _P), ("accumulate", _c.c_int32),
                 ("zero_d_hidden", _c.c_int32), ("d_slot_out", _P), ("d_slot_ld", _L), ("d_slot_rowmask", _P), ("d_slot_scale", _F),
                 ("co_dx", _c.POINTER(GemmDesc) * 2), ("n_co_dx", _c.c_int32), ("co_dw", _c.POINTER(GemmDesc) * 2), ("n_co_dw", _c.c_int32),
-                ("ln_bwd_done", _c.c_int32), ("wo_images_ready", _c.c_int32), ("separate_attention_backward", _c.c_int32)]
+                ("ln_bwd_done", _c.c_int32), ("wo_images_ready", _c.c_int32), ("separate_attention_backward", _c.c_int32),
+                ("next_group", _P), ("n_next_group", _c.c_int32)]
 
 
 class LnBwdTail(_c.Structure):

@@ -130,8 +130,9 @@ struct SlabColsum {
 };
 // 256 threads = 16 runs x 16 columns (column block bx covers 16 columns): every run of a column has its own thread, as in a launch of
 // sixteen waves, so the role is as short as that launch was (6.8 us) and hides behind the reduce it rides with.
-__device__ __forceinline__ void slab_colsum_body(const SlabColsum& s, int bx, int by, float (*red)[16]) {
-    const int run = threadIdx.x >> 4, cl = threadIdx.x & 15;
+// (tid: the thread's index inside its 256-thread block -- a 512-thread workgroup runs two blocks side by side, each with its own `red`)
+__device__ __forceinline__ void slab_colsum_body(const SlabColsum& s, int bx, int by, float (*red)[16], int tid) {
+    const int run = tid >> 4, cl = tid & 15;
     const int c = bx * 16 + cl;
     const int ncol = 3 * s.D;
     const bool ln = by == 0;
@@ -179,7 +180,16 @@ struct RoWeightImages {
 int gemm_check(const snag_gemm_desc* d);
 int gemm_dispatch(const snag_gemm_desc* d, hipStream_t st);
 int gemm_dispatch_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, hipStream_t st);
-int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st);   // 2..8 problems, one launch when their plans allow (A layouts may differ per problem on the 64 x 128 tile)
+// Work that depends on nothing the group computes and that nobody reads before the group is done: deferred K-split reduces (+ a layer's slab
+// column sums).  Handed to a group of eight-wave 256-row tiles it RIDES in that launch, on the CUs the launch leaves idle (one 512-thread workgroup
+// of that kernel fills a CU: a 247-workgroup launch idles 9 of 256) -- otherwise it goes out as the reduce launch it would have been, in front.
+struct GroupTail {
+    const snag_gemm_desc* const* reduce;
+    int n_reduce;
+    const SlabColsum* colsum;
+};
+int gemm_group_checked(const snag_gemm_desc* const* descs, int n, hipStream_t st, const GroupTail* tail);      // snag_gemm_f32_group's body (+ an optional tail)
+int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st, const GroupTail* tail = nullptr);   // 2..8 problems, one launch when their plans allow (A layouts may differ per problem on the 64 x 128 tile)
 // finishes problems launched with defer_reduce (+ optionally up to four small products in the same launch)
 // (+ optionally a layer's slab reductions, independent of everything the launch reduces: a 7 us launch of their own otherwise)
 int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, const snag_small_mm* small = nullptr, int n_small = 0, const SlabColsum* colsum = nullptr,

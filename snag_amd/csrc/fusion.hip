@@ -396,6 +396,7 @@ static int ln_bwd(const float* dy, const float* t, const float* stats, const flo
 
 int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
     const snag_fusion_desc* f = &b->f;
+    bool next_group_done = false;            // b->next_group went out with this call's last reduce riding in it
     const int N = f->N, M = f->M, D = f->D, H = f->H, I = f->I, L = f->L;
     const bool ffn = f->use_intermediate != 0;
     const int64_t NM = (int64_t)N * M;
@@ -548,7 +549,12 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
                 for (int i = 0; i < ng; ++i) all[na++] = grp[i];
                 for (int i = 0; i < nx; ++i) all[na++] = gx[i];
                 if ((rc = gemm_dispatch_group(all, na, st))) return rc;
-                if ((rc = gemm_reduce_multi(grp, ng, st, nullptr, 0, &slabs))) return rc;
+                if (b->n_next_group > 0 && l == 0) {
+                    // the caller's next grouped launch goes out here, this layer's reduce (+ slab column sums) riding on the CUs it leaves idle
+                    const GroupTail tail{grp, ng, &slabs};
+                    if ((rc = gemm_group_checked(b->next_group, b->n_next_group, st, &tail))) return rc;
+                    next_group_done = true;
+                } else if ((rc = gemm_reduce_multi(grp, ng, st, nullptr, 0, &slabs))) return rc;
 #else
                 if ((rc = gemm_dispatch_group(grp, ng, st))) return rc;
                 if ((rc = gemm_reduce_multi(grp, ng, st, nullptr, 0, &slabs))) return rc;
@@ -661,6 +667,8 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
         if ((rc = gemm_dispatch(&g, st))) return rc;
         dout = W.dC;
     }
+    // (every other path: the caller's next grouped launch behind everything of this call, as if the caller had issued it)
+    if (b->n_next_group > 0 && !next_group_done) return gemm_group_checked(b->next_group, b->n_next_group, st, nullptr);
     return SNAG_OK;
 }
 
@@ -757,7 +765,13 @@ extern "C" SNAG_API int snag_fusion_bwd(const snag_fusion_bwd_desc* b, void* str
     SNAG_REQUIRE(b != nullptr, SNAG_ERR_ARG, "fusion_bwd: null descriptor");
     int rc = check_fusion(&b->f);
     if (rc) return rc;
-    if (b->f.N == 0) return SNAG_OK;
+    SNAG_REQUIRE(b->n_next_group >= 0 && b->n_next_group <= SNAG_GEMM_GROUP_MAX && (b->n_next_group == 0 || b->next_group != nullptr), SNAG_ERR_ARG,
+                 "fusion_bwd: n_next_group=%d (0..%d problems)", b->n_next_group, SNAG_GEMM_GROUP_MAX);
+    for (int i = 0; i < b->n_next_group; ++i) {
+        SNAG_REQUIRE(b->next_group[i] != nullptr, SNAG_ERR_ARG, "fusion_bwd: null descriptor %d in next_group", i);
+        if ((rc = gemm_check(b->next_group[i]))) return rc;
+    }
+    if (b->f.N == 0) return b->n_next_group > 0 ? snag_gemm_f32_group(b->next_group, b->n_next_group, stream) : SNAG_OK;
     SNAG_REQUIRE(b->d_x0 && b->grads && b->f.work, SNAG_ERR_ARG, "fusion_bwd: null d_x0 / grads / work");
     SNAG_REQUIRE(b->f.readout_slot_p1 == 0 || !(b->d_joint || b->d_joint_fz || b->d_weight_norm), SNAG_ERR_UNSUPPORTED,
                  "fusion_bwd: read-out-only mode takes d_hidden [N, D] alone");

@@ -168,10 +168,10 @@ __device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ sla
 // Small outputs with many slabs (the D x D and F x D weight gradients: 16-128 K floats, 56-166 slabs): one workgroup = 64 quads,
 // its four waves take every fourth slab each (ascending), the four partial sums meet in LDS in wave order -- a fixed order, four
 // times the loads in flight.
-__device__ __forceinline__ void splitk_reduce_small_body(const float* __restrict__ slab, int splits, const Epilogue& epi, int64_t block) {
-    __shared__ float4 part[3][64];
+// (tid, part: the thread's index inside its 256-thread block and that block's [3][64] staging rows -- a 512-thread workgroup runs two blocks side by side)
+__device__ __forceinline__ void splitk_reduce_small_body(const float* __restrict__ slab, int splits, const Epilogue& epi, int64_t block, int tid, float4 (*part)[64]) {
     const int64_t total = (int64_t)epi.M * epi.N, quads = total / 4;
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int lane = tid & 63, g = tid >> 6;
     const int64_t q = block * 64 + lane;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q < quads) {
@@ -198,11 +198,13 @@ __device__ __forceinline__ void splitk_reduce_small_body(const float* __restrict
     }
 }
 __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const float* __restrict__ slab, int splits, Epilogue epi) {
-    splitk_reduce_small_body(slab, splits, epi, blockIdx.x);
+    __shared__ float4 part[3][64];
+    splitk_reduce_small_body(slab, splits, epi, blockIdx.x, threadIdx.x, part);
 }
 __global__ __launch_bounds__(256) void splitk_reduce_small_pair_kernel(const float* __restrict__ slab0, Epilogue e0, const float* __restrict__ slab1, Epilogue e1,
                                                                        int splits) {
-    splitk_reduce_small_body(blockIdx.y ? slab1 : slab0, splits, blockIdx.y ? e1 : e0, blockIdx.x);
+    __shared__ float4 part[3][64];
+    splitk_reduce_small_body(blockIdx.y ? slab1 : slab0, splits, blockIdx.y ? e1 : e0, blockIdx.x, threadIdx.x, part);
 }
 static bool reduce_small(int64_t total, int splits) { return total <= (1 << 18) && splits >= 8; }
 
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceSet rs, 
     if (b < cs_blocks) {
         __shared__ float red[16][16];
         const int ncb = cs_blocks / 2;
-        slab_colsum_body(cs, b % ncb, b / ncb, red);
+        slab_colsum_body(cs, b % ncb, b / ncb, red, threadIdx.x);
         return;
     }
     b -= cs_blocks;
@@ -240,12 +242,60 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceSet rs, 
     b -= wi_blocks;
     for (int q = 0; q < n_reduce; ++q) {
         if (b < rs.nblk[q]) {
-            if (rs.mode[q] == 2) splitk_reduce_small_body(rs.slab[q], rs.splits[q], rs.e[q], b);
-            else if (rs.mode[q] == 1) splitk_reduce_body<true>(rs.slab[q], rs.splits[q], rs.e[q], (int64_t)b * 256 + threadIdx.x, (int64_t)rs.nblk[q] * 256);
+            if (rs.mode[q] == 2) {
+                __shared__ float4 part[3][64];
+                splitk_reduce_small_body(rs.slab[q], rs.splits[q], rs.e[q], b, threadIdx.x, part);
+            } else if (rs.mode[q] == 1) splitk_reduce_body<true>(rs.slab[q], rs.splits[q], rs.e[q], (int64_t)b * 256 + threadIdx.x, (int64_t)rs.nblk[q] * 256);
             else splitk_reduce_body<false>(rs.slab[q], rs.splits[q], rs.e[q], (int64_t)b * 256 + threadIdx.x, (int64_t)rs.nblk[q] * 256);
             return;
         }
         b -= rs.nblk[q];
+    }
+}
+
+// A group of eight-wave 256-row tiles + a TAIL: blocks [0, n_main) are the group's tiles; the blocks behind them -- as many as the launch leaves
+// CUs idle, one 512-thread workgroup of this kernel fills a CU -- walk deferred split-K reduces and a layer's slab column sums that depend on
+// nothing the group computes (the read-out layer's weight-gradient reduce beside the first projections' weight-gradient GEMM: a 9 us launch of
+// its own otherwise).  A tail workgroup is two 256-thread blocks side by side; every element is summed by the body and in the order of
+// splitk_reduce_multi_kernel: the same bits.
+struct TailSet {
+    ReduceSet rs;
+    int n_reduce;
+    SlabColsum cs;
+    int cs_blocks;
+};
+template <bool A_KC, bool B_KC, bool VEC>
+__global__ __launch_bounds__(512) void gemm_tile_group_tail_kernel(GemmGroup<Epilogue> g, int n_main, TailSet t) {
+    using Core = GemmCore<256, 128, 32, 128, A_KC, B_KC, VEC>;
+    __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
+    static_assert(Core::SMEM_FLOATS >= 2 * 256 + 2 * 3 * 64 * 4, "the tail's staging rows fit in the tile buffers");
+    if ((int)blockIdx.x < n_main) {
+        gemm_group_block<256, 128, 32, 128, A_KC, B_KC, VEC, Epilogue>(g, (int)blockIdx.x, smem);
+        return;
+    }
+    const int r = (int)blockIdx.x - n_main, R = (int)gridDim.x - n_main;
+    const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    float (*red)[16] = reinterpret_cast<float (*)[16]>(smem + half * 256);
+    float4 (*part)[64] = reinterpret_cast<float4 (*)[64]>(smem + 512 + half * 3 * 64 * 4);
+    // slab column sums (cs_blocks is even: both halves always hold a block)
+    const int ncb = t.cs_blocks / 2;
+    for (int vb0 = 2 * r; vb0 < t.cs_blocks; vb0 += 2 * R) {
+        const int vb = vb0 + half;
+        slab_colsum_body(t.cs, vb % ncb, vb / ncb, red, tid);
+        __syncthreads();          // (the staging rows are written again by the next block)
+    }
+    for (int q = 0; q < t.n_reduce; ++q) {
+        const ReduceSet& rs = t.rs;
+        if (rs.mode[q] == 2) {
+            for (int vb0 = 2 * r; vb0 < rs.nblk[q]; vb0 += 2 * R) {          // (a block index past the end: no quad of its own, the barriers stay)
+                splitk_reduce_small_body(rs.slab[q], rs.splits[q], rs.e[q], vb0 + half, tid, part);
+                __syncthreads();
+            }
+        } else if (rs.mode[q] == 1) {
+            splitk_reduce_body<true>(rs.slab[q], rs.splits[q], rs.e[q], (int64_t)r * 512 + threadIdx.x, (int64_t)R * 512);
+        } else {
+            splitk_reduce_body<false>(rs.slab[q], rs.splits[q], rs.e[q], (int64_t)r * 512 + threadIdx.x, (int64_t)R * 512);
+        }
     }
 }
 
@@ -754,7 +804,19 @@ static int launch_reduce(const GemmPlan& pl, float* slab, hipStream_t st);
 #ifndef SNAG_GEMM_GROUP_BM
 #define SNAG_GEMM_GROUP_BM 256      // rows per tile of the long-K grouped launches: 256 = eight waves in two ping-pong groups; 128 = four waves (A/B)
 #endif
-int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) {
+static int device_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else cus = -1;
+    }
+    return cus;
+}
+
+static int fill_reduce_set(const snag_gemm_desc* const* ds, int n, ReduceSet& rs, GemmPlan* last, float** last_slab);
+
+int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st, const GroupTail* tail) {
     GemmPlan pl[kGroupMax];
     bool ok = n >= 2 && n <= kGroupMax;
     bool pp = false;                  // every problem on the eight-wave 256 x 128 tile instead (512 threads per workgroup)
@@ -772,12 +834,12 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
              use_vec(pl[i].p, d->a_kcontig, d->b_kcontig) == use_vec(pl[0].p, ds[0]->a_kcontig, ds[0]->b_kcontig);
         for (int j = 0; ok && j < i; ++j) ok = !(pl[i].splits > 1 && pl[j].splits > 1 && ds[i]->workspace == ds[j]->workspace);
     }
+    // the tail rides only in ONE launch of eight-wave tiles that leaves CUs idle (see below); everywhere else it is the reduce launch it would have been
+    auto tail_alone = [&]() { return tail ? gemm_reduce_multi(tail->reduce, tail->n_reduce, st, nullptr, 0, tail->colsum) : SNAG_OK; };
     if (!ok) {
-        for (int i = 0; i < n; ++i) {
-            const int rc = gemm_dispatch(ds[i], st);
-            if (rc) return rc;
-        }
-        return SNAG_OK;
+        int rc = tail_alone();
+        for (int i = 0; !rc && i < n; ++i) rc = gemm_dispatch(ds[i], st);
+        return rc;
     }
     GemmGroup<Epilogue> g{};
     g.n = n;
@@ -801,6 +863,34 @@ int gemm_dispatch_group(const snag_gemm_desc* const* ds, int n, hipStream_t st) 
     }
     g.first[n] = blocks;
     const bool vec = use_vec(pl[0].p, ds[0]->a_kcontig, ds[0]->b_kcontig);
+    if (tail != nullptr) {
+        // idle CUs of this launch (one 512-thread workgroup of the eight-wave kernel per CU: 176 registers per lane)
+        const int idle = (pp && SNAG_GEMM_GROUP_BM == 256 && !mixed) ? device_cu_count() - blocks : 0;
+        TailSet t{};
+        t.n_reduce = idle >= 4 ? fill_reduce_set(tail->reduce, tail->n_reduce, t.rs, nullptr, nullptr) : 0;
+        if (t.n_reduce < 0) return t.n_reduce;
+        if (idle < 4) {
+            const int rc = tail_alone();
+            if (rc) return rc;
+        } else {
+            if (tail->colsum) { t.cs = *tail->colsum; t.cs_blocks = 2 * ceil_div(3 * tail->colsum->D, 16); }
+            const int riders = std::min(idle, 16);
+#define SNAG_TAILN(AK, BK_)                                                                                                                       \
+    do {                                                                                                                                          \
+        if (vec) hipLaunchKernelGGL((gemm_tile_group_tail_kernel<AK, BK_, true>), dim3(blocks + riders), dim3(512), 0, st, g, blocks, t);          \
+        else hipLaunchKernelGGL((gemm_tile_group_tail_kernel<AK, BK_, false>), dim3(blocks + riders), dim3(512), 0, st, g, blocks, t);            \
+    } while (0)
+            if (ds[0]->a_kcontig && ds[0]->b_kcontig) SNAG_TAILN(true, true);
+            else if (ds[0]->a_kcontig && !ds[0]->b_kcontig) SNAG_TAILN(true, false);
+            else if (!ds[0]->a_kcontig && ds[0]->b_kcontig) SNAG_TAILN(false, true);
+            else SNAG_TAILN(false, false);
+#undef SNAG_TAILN
+            int rc = check_launch("snag_gemm_f32_group (+ tail)");
+            for (int i = 0; !rc && i < n; ++i)
+                if (pl[i].splits > 1 && !ds[i]->defer_reduce) rc = launch_reduce(pl[i], ds[i]->workspace, st);
+            return rc;
+        }
+    }
     if (mixed) {
         if (ds[0]->b_kcontig) {
             if (vec) hipLaunchKernelGGL((gemm_tile_group_mixed_kernel<64, 128, 32, 64, true, true, Epilogue>), dim3(blocks), dim3(256), 0, st, g);
@@ -842,6 +932,28 @@ static int launch_reduce(const GemmPlan& pl, float* slab, hipStream_t st) {
     return check_launch("snag_gemm_f32(split-K reduce)");
 }
 
+// the problems among ds[0..n) that left K-split slabs behind (defer_reduce), as a ReduceSet; returns their number or a negative error
+static int fill_reduce_set(const snag_gemm_desc* const* ds, int n, ReduceSet& rs, GemmPlan* last = nullptr, float** last_slab = nullptr) {
+    int cnt = 0;
+    for (int i = 0; i < n && i < 4; ++i) {
+        const snag_gemm_desc* d = ds[i];
+        const GemmPlan pl = plan_gemm(d);
+        if (!(d->defer_reduce && !pl.streamk && pl.splits > 1 && d->M > 0 && d->N > 0)) continue;      // finished by its own launch
+        for (int j = 0; j < cnt; ++j) SNAG_REQUIRE(rs.slab[j] != d->workspace, SNAG_ERR_ARG, "gemm_reduce: two problems share a workspace");
+        const int64_t total = (int64_t)pl.p.M * pl.p.N;
+        const bool quad = pl.p.N % 4 == 0 && ((uintptr_t)d->workspace & 15) == 0;
+        rs.slab[cnt] = d->workspace;
+        rs.splits[cnt] = pl.splits;
+        rs.mode[cnt] = quad ? (reduce_small(total, pl.splits) ? 2 : 1) : 0;
+        rs.nblk[cnt] = rs.mode[cnt] == 2 ? (int)((total / 4 + 63) / 64) : (int)std::min<int64_t>(2048, (total / (quad ? 4 : 1) + 255) / 256);
+        rs.e[cnt] = pl.e;
+        if (last) *last = pl;
+        if (last_slab) *last_slab = d->workspace;
+        ++cnt;
+    }
+    return cnt;
+}
+
 // finishes up to four problems launched with defer_reduce (distinct workspaces): ONE launch for all that left slabs behind
 int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, const snag_small_mm* small, int n_small, const SlabColsum* colsum,
                       const RoWeightImages* images) {
@@ -856,24 +968,10 @@ int gemm_reduce_multi(const snag_gemm_desc* const* ds, int n, hipStream_t st, co
         if (mm_blocks < 0) return mm_blocks;
     }
     ReduceSet rs{};
-    int cnt = 0;
     GemmPlan last{};
     float* last_slab = nullptr;
-    for (int i = 0; i < n && i < 4; ++i) {
-        const snag_gemm_desc* d = ds[i];
-        const GemmPlan pl = plan_gemm(d);
-        if (!(d->defer_reduce && !pl.streamk && pl.splits > 1 && d->M > 0 && d->N > 0)) continue;      // finished by its own launch
-        for (int j = 0; j < cnt; ++j) SNAG_REQUIRE(rs.slab[j] != d->workspace, SNAG_ERR_ARG, "gemm_reduce: two problems share a workspace");
-        const int64_t total = (int64_t)pl.p.M * pl.p.N;
-        const bool quad = pl.p.N % 4 == 0 && ((uintptr_t)d->workspace & 15) == 0;
-        rs.slab[cnt] = d->workspace;
-        rs.splits[cnt] = pl.splits;
-        rs.mode[cnt] = quad ? (reduce_small(total, pl.splits) ? 2 : 1) : 0;
-        rs.nblk[cnt] = rs.mode[cnt] == 2 ? (int)((total / 4 + 63) / 64) : (int)std::min<int64_t>(2048, (total / (quad ? 4 : 1) + 255) / 256);
-        rs.e[cnt] = pl.e;
-        last = pl; last_slab = d->workspace;
-        ++cnt;
-    }
+    const int cnt = fill_reduce_set(ds, n, rs, &last, &last_slab);
+    if (cnt < 0) return cnt;
     if (cnt == 0 && mm_blocks == 0 && cs_blocks == 0 && wi_blocks == 0) return SNAG_OK;
     if (cnt == 1 && mm_blocks == 0 && cs_blocks == 0 && wi_blocks == 0) return launch_reduce(last, last_slab, st);
     if (cnt == 1 && mm_blocks == 0 && cs_blocks == 0 && rs.mode[0] != 2) {          // one problem + the weight images
@@ -938,7 +1036,9 @@ extern "C" SNAG_API int snag_gemm_f32_pair(const snag_gemm_desc* d0, const snag_
     return gemm_dispatch_pair(d0, d1, (hipStream_t)stream);
 }
 
-extern "C" SNAG_API int snag_gemm_f32_group(const snag_gemm_desc* const* descs, int n, void* stream) {
+namespace snag {
+// snag_gemm_f32_group's body (checked descriptors, empty problems dropped) with an optional tail (common.hip.h: GroupTail)
+int gemm_group_checked(const snag_gemm_desc* const* descs, int n, hipStream_t st, const GroupTail* tail) {
     SNAG_REQUIRE(n >= 0 && n <= kGroupMax && (n == 0 || descs), SNAG_ERR_ARG, "gemm_f32_group: n=%d (0..%d problems per call)", n, kGroupMax);
     const snag_gemm_desc* live[kGroupMax];
     int m = 0;
@@ -948,9 +1048,17 @@ extern "C" SNAG_API int snag_gemm_f32_group(const snag_gemm_desc* const* descs, 
         if (rc) return rc;
         if (descs[i]->M > 0 && descs[i]->N > 0) live[m++] = descs[i];
     }
-    if (m == 0) return SNAG_OK;
-    if (m == 1) return gemm_dispatch(live[0], (hipStream_t)stream);
-    return gemm_dispatch_group(live, m, (hipStream_t)stream);
+    if (m >= 2) return gemm_dispatch_group(live, m, st, tail);
+    if (tail) {          // nothing to ride in: the reduce launch it would have been
+        const int rc = gemm_reduce_multi(tail->reduce, tail->n_reduce, st, nullptr, 0, tail->colsum);
+        if (rc) return rc;
+    }
+    return m == 1 ? gemm_dispatch(live[0], st) : SNAG_OK;
+}
+}  // namespace snag
+
+extern "C" SNAG_API int snag_gemm_f32_group(const snag_gemm_desc* const* descs, int n, void* stream) {
+    return gemm_group_checked(descs, n, (hipStream_t)stream, nullptr);
 }
 
 extern "C" SNAG_API int snag_gemm_reduce_pair(const snag_gemm_desc* d0, const snag_gemm_desc* d1, void* stream) {

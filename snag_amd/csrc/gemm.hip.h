@@ -801,22 +801,27 @@ struct GemmGroup {
     int xcd;                         // > 0: XCD-aware block -> (problem, split, tile) mapping for the first `xcd` blocks of the launch
     unsigned a_kc_mask;              // gemm_tile_group_mixed_kernel: bit q = problem q's A operand is K-contiguous
 };
+// one workgroup of a grouped launch (block index `block`)
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
-__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_group_kernel(GemmGroup<Epi> g) {
-    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
-    __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
+__device__ __forceinline__ void gemm_group_block(const GemmGroup<Epi>& g, int block, float* smem) {
     // Linear ids run problem by problem, split by split, tile by tile: neighbours share the k-range of their split -- the same slice of
     // the narrow operand B.  Workgroups are dealt round-robin over the eight XCDs, so without the remap the tiles of one split land on
     // eight different L2s and each fetches its own copy of that slice; with it every XCD owns a contiguous run of ids.
     // (Set by the host for the weight-gradient groups only -- both operands row-contiguous, K = the entity rows, equal k-ranges per
     // block: 40.8 -> 37.0 us.  Launches whose problems differ in work per block lose by it: an XCD that owns the short problem's run idles
     // at the end -- first projections 110.5 -> 117.8 us, input-gradient group 38.0 -> 44.7.)
-    const int id = (int)blockIdx.x < g.xcd ? xcd_swizzle((int)blockIdx.x, g.xcd) : (int)blockIdx.x;
+    const int id = block < g.xcd ? xcd_swizzle(block, g.xcd) : block;
     int q = 0;
     while (q + 1 < g.n && id >= g.first[q + 1]) ++q;
     const int b = id - g.first[q];
     const int z = b / g.tiles[q], t = b % g.tiles[q];
     gemm_tile_at<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi>(g.p[q], g.e[q], g.slab[q], z, (t / g.tiles_n[q]) * BM, (t % g.tiles_n[q]) * BN, smem);
+}
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, class Epi>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void gemm_tile_group_kernel(GemmGroup<Epi> g) {
+    using Core = GemmCore<BM, BN, WM, WN, A_KC, B_KC, VEC>;
+    __shared__ __attribute__((aligned(16))) float smem[Core::SMEM_FLOATS];
+    gemm_group_block<BM, BN, WM, WN, A_KC, B_KC, VEC, Epi>(g, (int)blockIdx.x, smem);
 }
 
 // The same with the A operand's layout chosen PER PROBLEM (round 5): the read-out layer's backward issues four weight gradients (A = an

@@ -13,6 +13,7 @@ Every learnable tensor is a view into ONE flat fp32 buffer (and its gradient int
 buffer), so the data-parallel exchange is a single RCCL all-reduce and the optimiser a single launch.
 """
 import ctypes
+import os
 import math
 from dataclasses import dataclass, field
 from typing import List, Optional
@@ -159,6 +160,7 @@ class MKGCHotPath:
         # 105.0 us for the visual projection + its reduce); it cost 290 MB, a full rewrite at every noise refresh (the refresh now touches
         # only the rows in the new or the previous mask) and a second layout for the weights.
         self.g_slot = M - 1                                   # structural token last
+        self.tail_riders = os.environ.get("SNAG_TAIL_RIDERS", "1") != "0"      # (the variable: tools/ab_env.sh A/B only) one rank: the Mformer backward's last reduce rides in the first projections' weight-gradient launch (False: a launch of its own; the same bits -- tests)
         self.co_launch = True        # folded key / value products ride in snag_fusion_fwd's launches (False: launches of their own; the same bits -- tests)
         self.force_one_launch = False    # True: the one-launch read-out forward / fused backward below the library's row thresholds too (tests)
         I, L, ffn = cfg.intermediate_size, self.n_layers, bool(cfg.use_intermediate)
@@ -480,20 +482,29 @@ class MKGCHotPath:
                 return s
             s[i] += 1
 
-    def _grouped_long_k(self, descs, shapes, tags=None, small=None, prepare_fusion=False):
-        """Two long-K split-K GEMMs (the modalities' first projections, or their weight gradients) as ONE launch of eight-wave tiles with
-        balanced K splits + ONE reduce; False when the shapes do not qualify (the caller then launches them one by one).
-        ``small``: an array of independent snag_small_mm products that ride in the reduce launch (snag_gemm_reduce_group_mm)."""
+    def _long_k_group(self, descs, shapes):
+        """The pointer array of ``_grouped_long_k``'s one launch (K splits balanced, reduces deferred), or None when the shapes do not qualify."""
         if len(descs) != 2 or self.cfg.dim > 128 or any(k < 512 for _, k in shapes) or max(m for m, _ in shapes) < 1024:
-            return False
+            return None
         order = sorted(range(2), key=lambda j: -shapes[j][0])          # the problem that picks the eight-wave tile on its own goes first
         splits = self._balanced_splits([shapes[j] for j in order])
         group = (ctypes.POINTER(_lib.GemmDesc) * 2)()
         for pos, j in enumerate(order):
             descs[j].defer_reduce, descs[j].splits = 1, splits[pos]
             group[pos] = ctypes.pointer(descs[j])
+        return group
+
+    def _grouped_long_k(self, descs, shapes, tags=None, small=None, prepare_fusion=False, launched=None):
+        """Two long-K split-K GEMMs (the modalities' first projections, or their weight gradients) as ONE launch of eight-wave tiles with
+        balanced K splits + ONE reduce; False when the shapes do not qualify (the caller then launches them one by one).
+        ``small``: an array of independent snag_small_mm products that ride in the reduce launch (snag_gemm_reduce_group_mm).
+        ``launched``: the group (``_long_k_group``) has gone out already -- inside snag_fusion_bwd, as its ``next_group`` -- only the reduce is left."""
+        group = launched if launched is not None else self._long_k_group(descs, shapes)
+        if group is None:
+            return False
         tag = tags[0] if tags else ""
-        self._probed(tag, call, "snag_gemm_f32_group", group, 2, self._st)
+        if launched is None:
+            self._probed(tag, call, "snag_gemm_f32_group", group, 2, self._st)
         if small is not None:
             self._probed((tag + "_reduce") if tag else "", call, "snag_gemm_reduce_group_mm", group, 2, small, len(small), self._st)
         elif prepare_fusion:
@@ -531,6 +542,25 @@ class MKGCHotPath:
         dmid = [self._gemm_desc(Nl, D, 2 * D, dkv + 4 * i * 2 * D, 2 * MD, 1, ptr(self.wf[i]), D, 0, ptr(self.d_mid[i]), D, act=4, aux=ptr(self.mid[i]),
                                 ldaux=D, keep=self._proj_keep(i), keep_scale=1.0 / (1.0 - cfg.proj_dropout), splitk=False) for i in range(nmod)]
         return dl2, dmid
+
+    def _dl1_descs(self, noisy):
+        """The first projections' weight gradients feat_m^T d(projection input) [fd, D], stored transposed straight into the [D, fd] gradients."""
+        cfg = self.cfg
+        D, MD, Nl = cfg.dim, cfg.n_tokens * cfg.dim, self.shard.n_loc
+        dx0 = self.d_x0.data_ptr()
+        dl1 = []
+        for i, fd in enumerate(cfg.feat_dims):
+            feat = self.noisy[i] if noisy else self.feats[i]
+            dslot = dx0 + 4 * i * D
+            if cfg.num_proj == 1:
+                # dW^T [fd, D] = feat^T dTok, stored transposed: straight into the [D, fd] gradient ; db = colsum(dTok)
+                dl1.append(self._gemm_desc(fd, D, Nl, ptr(feat), fd, 0, dslot, MD, 0, ptr(self.g[f"proj{i}.weight"]), fd, splitk=True, half=i % 2))
+            else:
+                dl1.append(self._gemm_desc(fd, D, Nl, ptr(feat), fd, 0, ptr(self.d_mid[i]), D, 0, ptr(self.g[f"proj{i}.l1"]), fd, splitk=True,
+                                           half=i % 2))   # dl1^T [fd, D], stored transposed
+        for d in dl1:
+            d.c_transposed = 1
+        return dl1
 
     def _fold_chain_products(self, i0=0):
         """snag_small_mm array for modalities i0, i0 + 1: d l2_m = Wkv^T d Wf_m (disjoint outputs) and ONE two-term problem d Wkv += sum_m d Wf_m l2_m^T."""
@@ -935,6 +965,16 @@ class MKGCHotPath:
             for j in range(nmod):
                 bd.co_dw[j], bd.co_dx[j] = ctypes.pointer(dl2[j]), ctypes.pointer(dmid[j])
             bd.n_co_dw = bd.n_co_dx = nmod
+        # One rank, folded second projections riding in the Mformer backward (co): the first projections' weight gradients -- the launch this
+        # method would issue next, 247 eight-wave workgroups on 256 CUs -- go out from INSIDE snag_fusion_bwd, whose last reduce (the layer's
+        # weight-gradient slabs + slab column sums, a 9 us launch) rides in them on the CUs they leave idle (snag_fusion_bwd_desc.next_group).
+        # With a reducer the launches stay apart: the tables' bucket leaves right behind the fusion backward and travels under that GEMM.
+        dl1 = self._dl1_descs(noisy)
+        rider_group = None
+        if self.tail_riders and co and reducer is None and not self.atten and cfg.num_proj == 2:
+            rider_group = self._long_k_group(dl1, [(fd, Nl) for fd in cfg.feat_dims])
+        bd.next_group, bd.n_next_group = (ctypes.cast(rider_group, ctypes.c_void_p), 2) if rider_group is not None else (None, 0)
+        self._rider_group = rider_group           # (keeps the pointer array alive for the call)
         if self.atten:
             call("snag_atten_weight_bwd", self.x0.data_ptr(), Nl, M, D, ptr(self.p["atten.a"]), ptr(self.aw), ptr(self.d_repr), D, ptr(self.d_x0),
                  ptr(self.g["atten.a"]), 0, ptr(self._aw_work), st)
@@ -989,18 +1029,6 @@ class MKGCHotPath:
         #   d l2_m = Wkv^T d Wf_m ;  d Wkv += d Wf_m l2_m^T   (the read-out token's own contribution to d Wkv is already there)
         chain, chain_done = (self._fold_chain_products() if (self.fold and nmod <= 2) else None), False
         grouped = False             # both first-projection weight gradients went out as the one grouped launch (+ the chain products in its reduce)
-        dl1 = []
-        for i, fd in enumerate(cfg.feat_dims):
-            feat = self.noisy[i] if noisy else self.feats[i]
-            dslot = dx0 + 4 * i * D
-            if cfg.num_proj == 1:
-                # dW^T [fd, D] = feat^T dTok, stored transposed: straight into the [D, fd] gradient ; db = colsum(dTok)
-                dl1.append(self._gemm_desc(fd, D, Nl, ptr(feat), fd, 0, dslot, MD, 0, ptr(self.g[f"proj{i}.weight"]), fd, splitk=True, half=i % 2))
-            else:
-                dl1.append(self._gemm_desc(fd, D, Nl, ptr(feat), fd, 0, ptr(self.d_mid[i]), D, 0, ptr(self.g[f"proj{i}.l1"]), fd, splitk=True,
-                                           half=i % 2))   # dl1^T [fd, D], stored transposed
-        for d in dl1:
-            d.c_transposed = 1
         if one_reduce:
             group = (ctypes.POINTER(_lib.GemmDesc) * 4)()
             for j, d in enumerate(dl2 + dl1):
@@ -1009,7 +1037,7 @@ class MKGCHotPath:
             call("snag_gemm_f32", ctypes.byref(dl1[0]), st)
             call("snag_gemm_f32", ctypes.byref(dl1[1]), st)
             call("snag_gemm_reduce_group", group, 4, st)
-        elif self._grouped_long_k(dl1, [(fd, Nl) for fd in cfg.feat_dims], small=chain):
+        elif self._grouped_long_k(dl1, [(fd, Nl) for fd in cfg.feat_dims], small=chain, launched=rider_group):
             # (both weight gradients in ONE launch of eight-wave tiles: alone, the visual one fills the chip exactly -- 16 row tiles x 16
             # K splits -- and the text one then runs as a second, under-filled launch; together, 13 splits each, every CU walks the same
             # k-range once: 78.5 + 30.4 -> 97.8 us.  The chain rule of projection folding -- parameter-sized products that depend on

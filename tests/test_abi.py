@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _declared():
         assert hasattr(lib, name), f"{name} declared in include/snag_hip.h but not exported"
-    assert lib.snag_version() == _lib.ABI_VERSION == 2
+    assert lib.snag_version() == _lib.ABI_VERSION == 3
     # every declared entry point has a ctypes signature on the Python side
     bound = set(_lib.SIGNATURES) | set(_lib._SPECIAL)
     assert set(_declared()) == bound, sorted(set(_declared()) ^ bound)

@@ -361,6 +361,47 @@ def test_one_launch_readout_forward_equals_the_separate_launches_bit_for_bit(N, 
         assert torch.equal(a[3][k], b[3][k]), k
 
 
+@pytest.mark.parametrize("N,dims,dropout,steps", [(15000, [4096, 768], 0.1, 2), (700, [1100, 520], 0.1, 3), (1500, [2048, 1000], 0.0, 2), (513, [1024, 512], 0.2, 2),
+                                                  (600, [300, 72], 0.1, 2)])
+def test_backward_reduce_riding_in_the_weight_gradient_launch_equals_its_own_launch(N, dims, dropout, steps):
+    """snag_fusion_bwd_desc.next_group (ABI 3): with one rank the first projections' weight-gradient launch goes out from inside snag_fusion_bwd and the
+    Mformer backward's last reduce -- the layer's weight-gradient slabs and its slab column sums -- rides in it, on the CUs that launch of eight-wave
+    tiles leaves idle (gemm_tile_group_tail_kernel), instead of a launch of its own.  Every element is summed by the same body in the same order: losses,
+    EVERY gradient and the parameters after clip + AdamW are the same bits either way, over several steps (the reduce's slabs and the rider
+    arguments are rewritten every step).  Shapes: the headline's (247 workgroups, 9 riders), small ones (a handful of tiles, 16 riders), and
+    one whose weight gradients do not qualify for the grouped launch at all (300 / 72 columns: the reduce stays a launch, the group goes out one by one)."""
+    from snag_amd.mkgc import MKGCConfig, MKGCHotPath
+    R, B, K, D = 9, 128, 8, 128
+    g = torch.Generator().manual_seed(92)
+    feats = [torch.rand(N, dims[0], generator=g), torch.randn(N, dims[1], generator=g)]
+    batches = [[torch.randint(0, hi, sz, generator=g, dtype=torch.int32).to(DEV) for hi, sz in ((N, (B,)), (R, (B,)), (N, (B,)), (N, (B, K)))] for _ in range(steps)]
+    ent0 = torch.randn(N, D, generator=g).to(DEV)
+    out = {}
+    for riders in (True, False):
+        cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=list(dims), num_proj=2, joint_way="Mformer_hd_graph", margin=6.0, neg_num=K, dropout=dropout,
+                         proj_dropout=0.1 if dropout else 0.0, add_noise=1, seed=7, lr=1e-3)
+        eng = MKGCHotPath(cfg, feats, device=DEV)
+        assert eng.fold and eng.ro and eng.tail_riders
+        eng.tail_riders = riders
+        eng.p["ent"].copy_(ent0)
+        eng.update_noise()
+        rec = []
+        for batch in batches:
+            loss = eng.forward(*batch, with_backward=True)
+            eng.backward()
+            grads = {k: v.clone() for k, v in eng.named_gradients().items()}
+            eng.optimizer_step()
+            rec.append((loss.clone(), grads))
+        torch.cuda.synchronize()
+        out[riders] = (rec, {k: v.clone() for k, v in eng.named_parameters().items()})
+    for (la, ga), (lb, gb) in zip(out[True][0], out[False][0]):
+        assert torch.equal(la, lb)
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+    for k in out[True][1]:
+        assert torch.equal(out[True][1][k], out[False][1][k]), k
+
+
 @pytest.mark.parametrize("N,heads,dropout", [(1500, 2, 0.1), (15000, 2, 0.1), (999, 4, 0.0), (33, 1, 0.2), (1, 2, 0.1), (64, 2, 0.1)])
 def test_attention_backward_with_its_own_d_ctx_product_equals_the_two_launches(N, heads, dropout):
     """csrc/readout_fused.hip, readout_bwd_attn_kernel: d ctx = dz Wo (the split-bf16 products of gemm_tile_kernel, bit for bit) and the
