@@ -458,8 +458,8 @@ typedef struct snag_fusion_bwd_desc {
     int32_t separate_attention_backward;
     /* (ABI 3) A grouped launch the caller would issue RIGHT BEHIND this call -- snag_gemm_f32_group(next_group, n_next_group): e.g. the first
      * projections' weight gradients, which read what this call's input-gradient products write -- and that nobody of this call depends on.
-     * When given (read-out mode with fold_others: the path whose last launch is a reduce of the layer's weight-gradient slabs + its slab column
-     * sums), this call launches that group itself and its own last reduce RIDES in it: a group of eight-wave 256-row tiles leaves CUs idle
+     * When given (read-out mode with fold_others, whose last launch is a reduce of the layer's weight-gradient slabs + its slab column sums; the
+     * full layer, whose layer-0 reduce of the same kind nothing of this call reads), this call launches that group itself and that reduce RIDES in it: a group of eight-wave 256-row tiles leaves CUs idle
      * (247 workgroups on 256 CUs) and the reduce runs on those instead of as a 9 us launch of its own.  Same bits.  Where the path or the
      * group's plan does not allow it the reduce and the group go out one after the other, as if the caller had issued the group. */
     const snag_gemm_desc** next_group; int32_t n_next_group;

@@ -397,6 +397,10 @@ static int ln_bwd(const float* dy, const float* t, const float* stats, const flo
 int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
     const snag_fusion_desc* f = &b->f;
     bool next_group_done = false;            // b->next_group went out with this call's last reduce riding in it
+    // the full layer's weight-gradient reduce of layer 0, held back to ride in b->next_group at the end of the call (nothing of this call reads its results)
+    snag_gemm_desc pend_g0{}, pend_g1{};
+    SlabColsum pend_slabs{};
+    bool pending = false;
     const int N = f->N, M = f->M, D = f->D, H = f->H, I = f->I, L = f->L;
     const bool ffn = f->use_intermediate != 0;
     const int64_t NM = (int64_t)N * M;
@@ -657,7 +661,9 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
             g0.splits = g1.splits = std::max(1, SNAG_FULL_BWD_W_ROUND / std::max(1, ceil_div(3 * D, 64) + ceil_div(D, 64)) / std::max(1, ceil_div(D, 128)));
             const snag_gemm_desc* grp[2] = {&g1, &g0};
             if ((rc = gemm_dispatch_group(grp, 2, st))) return rc;
-            if ((rc = gemm_reduce_multi(grp, 2, st, nullptr, 0, &slabs))) return rc;
+            if (b->n_next_group > 0 && l == 0) {
+                pend_g0 = g0; pend_g1 = g1; pend_slabs = slabs; pending = true;
+            } else if ((rc = gemm_reduce_multi(grp, 2, st, nullptr, 0, &slabs))) return rc;
         }
         // d(layer input) = dqkv Wqkv + dT1 (+ epilogue route at layer 0)
         float* dxin = (l == 0) ? b->d_x0 : W.dC;
@@ -668,6 +674,11 @@ int fusion_bwd(const snag_fusion_bwd_desc* b, hipStream_t st) {
         dout = W.dC;
     }
     // (every other path: the caller's next grouped launch behind everything of this call, as if the caller had issued it)
+    if (pending) {
+        const snag_gemm_desc* grp[2] = {&pend_g1, &pend_g0};
+        const GroupTail tail{grp, 2, &pend_slabs};
+        return gemm_group_checked(b->next_group, b->n_next_group, st, &tail);
+    }
     if (b->n_next_group > 0 && !next_group_done) return gemm_group_checked(b->next_group, b->n_next_group, st, nullptr);
     return SNAG_OK;
 }

@@ -971,7 +971,8 @@ class MKGCHotPath:
         # With a reducer the launches stay apart: the tables' bucket leaves right behind the fusion backward and travels under that GEMM.
         dl1 = self._dl1_descs(noisy)
         rider_group = None
-        if self.tail_riders and co and reducer is None and not self.atten and cfg.num_proj == 2:
+        # (likewise the full layer's layer-0 weight-gradient reduce when the projections are single Linear layers: MKG-W-shaped configurations)
+        if self.tail_riders and reducer is None and not self.atten and ((co and cfg.num_proj == 2) or (cfg.num_proj == 1 and not self.ro)):
             rider_group = self._long_k_group(dl1, [(fd, Nl) for fd in cfg.feat_dims])
         bd.next_group, bd.n_next_group = (ctypes.cast(rider_group, ctypes.c_void_p), 2) if rider_group is not None else (None, 0)
         self._rider_group = rider_group           # (keeps the pointer array alive for the call)

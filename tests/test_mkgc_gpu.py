@@ -361,9 +361,12 @@ def test_one_launch_readout_forward_equals_the_separate_launches_bit_for_bit(N, 
         assert torch.equal(a[3][k], b[3][k]), k
 
 
-@pytest.mark.parametrize("N,dims,dropout,steps", [(15000, [4096, 768], 0.1, 2), (700, [1100, 520], 0.1, 3), (1500, [2048, 1000], 0.0, 2), (513, [1024, 512], 0.2, 2),
-                                                  (600, [300, 72], 0.1, 2)])
-def test_backward_reduce_riding_in_the_weight_gradient_launch_equals_its_own_launch(N, dims, dropout, steps):
+@pytest.mark.parametrize("N,dims,dropout,steps,joint_way,num_proj,ffn", [
+    (15000, [4096, 768], 0.1, 2, "Mformer_hd_graph", 2, 0), (700, [1100, 520], 0.1, 3, "Mformer_hd_graph", 2, 0), (1500, [2048, 1000], 0.0, 2, "Mformer_hd_graph", 2, 0),
+    (513, [1024, 512], 0.2, 2, "Mformer_hd_graph", 2, 0), (600, [300, 72], 0.1, 2, "Mformer_hd_graph", 2, 0),
+    # the full layer (MKG-W-shaped: Mformer_hd_mean over all three tokens, one projection layer): its layer-0 weight-gradient reduce rides the same way
+    (15000, [4096, 768], 0.1, 2, "Mformer_hd_mean", 1, 0), (700, [1100, 520], 0.1, 2, "Mformer_hd_mean", 1, 1), (900, [1030, 600], 0.0, 2, "Mformer_weight", 1, 0)])
+def test_backward_reduce_riding_in_the_weight_gradient_launch_equals_its_own_launch(N, dims, dropout, steps, joint_way, num_proj, ffn):
     """snag_fusion_bwd_desc.next_group (ABI 3): with one rank the first projections' weight-gradient launch goes out from inside snag_fusion_bwd and the
     Mformer backward's last reduce -- the layer's weight-gradient slabs and its slab column sums -- rides in it, on the CUs that launch of eight-wave
     tiles leaves idle (gemm_tile_group_tail_kernel), instead of a launch of its own.  Every element is summed by the same body in the same order: losses,
@@ -378,10 +381,10 @@ def test_backward_reduce_riding_in_the_weight_gradient_launch_equals_its_own_lau
     ent0 = torch.randn(N, D, generator=g).to(DEV)
     out = {}
     for riders in (True, False):
-        cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=list(dims), num_proj=2, joint_way="Mformer_hd_graph", margin=6.0, neg_num=K, dropout=dropout,
-                         proj_dropout=0.1 if dropout else 0.0, add_noise=1, seed=7, lr=1e-3)
+        cfg = MKGCConfig(n_ent=N, n_rel=R, dim=D, feat_dims=list(dims), num_proj=num_proj, joint_way=joint_way, use_intermediate=ffn, intermediate_size=96, margin=6.0,
+                         neg_num=K, dropout=dropout, proj_dropout=0.1 if (dropout and num_proj == 2) else 0.0, add_noise=1, seed=7, lr=1e-3)
         eng = MKGCHotPath(cfg, feats, device=DEV)
-        assert eng.fold and eng.ro and eng.tail_riders
+        assert (eng.fold and eng.ro) == (num_proj == 2) and eng.tail_riders
         eng.tail_riders = riders
         eng.p["ent"].copy_(ent0)
         eng.update_noise()
