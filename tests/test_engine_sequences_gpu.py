@@ -41,7 +41,10 @@ def _config(rnd):
     scorer = rnd.choice(["segmented", "atomic"])
     dropout = rnd.choice([0.0, 0.1])
     num_proj = rnd.choice([1, 2])
-    return MKGCConfig(n_ent=N, n_rel=rnd.randint(1, 9), dim=D, feat_dims=[rnd.choice([24, 40, 72]), rnd.choice([12, 40])], num_proj=num_proj,
+    feat_dims = [rnd.choice([24, 40, 72]), rnd.choice([12, 40])]
+    if rnd.random() < 0.3:          # wide tables over >= 512 entities: the first projections (and their weight gradients) go out as the grouped launch of
+        N, feat_dims = rnd.randint(520, 700), [rnd.choice([1030, 1100]), rnd.choice([520, 600])]          # eight-wave tiles -- with the backward's reduce riding in it
+    return MKGCConfig(n_ent=N, n_rel=rnd.randint(1, 9), dim=D, feat_dims=feat_dims, num_proj=num_proj,
                       joint_way=joint_way, num_heads=rnd.choice([1, 2, 4]), num_layers=layers, use_intermediate=ffn, intermediate_size=96,
                       margin=6.0, loss=loss, adv_temp=0.7, neg_num=rnd.choice([1, 8, 32]), add_noise=rnd.choice([0, 1]), dropout=dropout,
                       proj_dropout=rnd.choice([0.0, 0.2]) if (num_proj == 2 and dropout > 0) else 0.0, lr=2e-3, weight_decay=0.05, clip=1.0,
@@ -160,6 +163,6 @@ def _run(seed, n_ops=8, verbose=False):
     return cfg, trace
 
 
-@pytest.mark.parametrize("seed", list(range(100, 124)) + [1318, 1473])          # (the last two: ReLU-kink units, see _check_train)
+@pytest.mark.parametrize("seed", list(range(100, 124)) + [1318, 1473])
 def test_engine_call_sequences_vs_oracle(seed):
     _run(seed)
