@@ -969,10 +969,10 @@ class MKGCHotPath:
         # method would issue next, 247 eight-wave workgroups on 256 CUs -- go out from INSIDE snag_fusion_bwd, whose last reduce (the layer's
         # weight-gradient slabs + slab column sums, a 9 us launch) rides in them on the CUs they leave idle (snag_fusion_bwd_desc.next_group).
         # With a reducer the launches stay apart: the tables' bucket leaves right behind the fusion backward and travels under that GEMM.
-        dl1 = self._dl1_descs(noisy)
-        rider_group = None
+        dl1, rider_group = None, None
         # (likewise the full layer's layer-0 weight-gradient reduce when the projections are single Linear layers: MKG-W-shaped configurations)
         if self.tail_riders and reducer is None and not self.atten and ((co and cfg.num_proj == 2) or (cfg.num_proj == 1 and not self.ro)):
+            dl1 = self._dl1_descs(noisy)
             rider_group = self._long_k_group(dl1, [(fd, Nl) for fd in cfg.feat_dims])
         bd.next_group, bd.n_next_group = (ctypes.cast(rider_group, ctypes.c_void_p), 2) if rider_group is not None else (None, 0)
         self._rider_group = rider_group           # (keeps the pointer array alive for the call)
@@ -1030,6 +1030,8 @@ class MKGCHotPath:
         #   d l2_m = Wkv^T d Wf_m ;  d Wkv += d Wf_m l2_m^T   (the read-out token's own contribution to d Wkv is already there)
         chain, chain_done = (self._fold_chain_products() if (self.fold and nmod <= 2) else None), False
         grouped = False             # both first-projection weight gradients went out as the one grouped launch (+ the chain products in its reduce)
+        if dl1 is None:             # (described up front only where they ride with the fusion backward: with a reducer the host reaches that call sooner)
+            dl1 = self._dl1_descs(noisy)
         if one_reduce:
             group = (ctypes.POINTER(_lib.GemmDesc) * 4)()
             for j, d in enumerate(dl2 + dl1):

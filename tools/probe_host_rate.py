@@ -24,6 +24,8 @@ cfg = MKGCConfig()
 cfg.n_ent //= a.rows_div
 feats, batches, known = bench.synth(cfg, 1024, 8, cfg.seed, dev)
 eng = MKGCHotPath(cfg, feats, device=dev)
+if a.rows_div > 1:
+    eng.tail_riders = False           # a sharded rank runs with a reducer: the backward's reduce stays a launch of its own (mkgc.backward)
 neg = torch.empty(1024, cfg.neg_num, device=dev, dtype=torch.int32)
 eng.update_noise()
 if a.graph:
