@@ -28,7 +28,11 @@ int main() {
     hipEvent_t e0, e1, ef;
     hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreateWithFlags(&ef, hipEventDisableTiming);
     const long long TA = 10000, TB = 1000;       // clock64 ticks (100 MHz): 100 us and 10 us
-    for (int mode = 0; mode < 3; ++mode) {
+    uint32_t* flag;
+    hipMalloc(&flag, 8);
+    hipMemset(flag, 0, 8);
+    uint32_t seq = 0;
+    for (int mode = 0; mode < 4; ++mode) {
         float best = 1e9f;
         for (int rep = 0; rep < 20; ++rep) {
             hipEventRecord(e0, s0);
@@ -36,6 +40,14 @@ int main() {
                 hipLaunchKernelGGL(spin_big, dim3(236), dim3(512), 0, s0, TA, sink);
                 if (mode == 0) hipLaunchKernelGGL(spin_small, dim3(4096), dim3(256), 0, s0, TB, sink);
                 if (mode == 1) hipExtLaunchKernelGGL(spin_small, dim3(4096), dim3(256), 0, s0, nullptr, nullptr, hipExtAnyOrderLaunch, TB, sink);
+                if (mode == 3) {                     // the same fork / join through stream memory operations instead of events
+                    ++seq;
+                    hipStreamWriteValue32(s0, flag, seq, 0);          // (in the real step: behind the previous step's last launch)
+                    hipStreamWaitValue32(s1, flag, seq, hipStreamWaitValueGte, 0xffffffffu);
+                    hipLaunchKernelGGL(spin_small, dim3(4096), dim3(256), 0, s1, TB, sink);
+                    hipStreamWriteValue32(s1, flag + 1, seq, 0);
+                    hipStreamWaitValue32(s0, flag + 1, seq, hipStreamWaitValueGte, 0xffffffffu);
+                }
                 if (mode == 2) {
                     hipEventRecord(ef, s0);          // fork behind the previous iteration, join in front of the next one
                     hipLaunchKernelGGL(spin_small, dim3(4096), dim3(256), 0, s1, TB, sink);
@@ -49,7 +61,7 @@ int main() {
             hipEventElapsedTime(&ms, e0, e1);
             if (ms < best) best = ms;
         }
-        printf("mode %d (%s): %.1f us per (big + small) pair\n", mode, mode == 0 ? "plain, one stream" : mode == 1 ? "hipExtAnyOrderLaunch on the small one" : "small one on a second stream",
+        printf("mode %d (%s): %.1f us per (big + small) pair\n", mode, mode == 0 ? "plain, one stream" : mode == 1 ? "hipExtAnyOrderLaunch on the small one" : mode == 2 ? "small one on a second stream (join by event)" : "small one on a second stream (fork and join by hipStreamWrite/WaitValue32)",
                best * 100.f);
     }
     return 0;
